@@ -1,0 +1,501 @@
+// K2/K3 — batched blocked LEFT-LOOKING fp64 Cholesky on packed 128x128 tiles, with the forward
+// solve alpha = L^-1 x, log|K| and alpha'alpha fused in (replaces the dpotrf / dtrsv that
+// Gen.mvnormal -> Distributions -> PDMats run behind src/Model.jl:136 of the reference).
+//
+// Per block column k there are two launches over all particles:
+//   k_chol_update (U):  C(i,k) = A(i,k) - sum_{j<k} L(i,j) L(k,j)^T   for every tile i >= k,
+//                       a 128x128xK fp64 GEMM on v_mfma_f64_16x16x4 (each wave owns a 64x64
+//                       quadrant = 4x4 MFMA accumulators), slabs of 16 columns (16 KiB contiguous)
+//                       double-buffered through LDS.  The workgroup that owns the DIAGONAL tile
+//                       additionally carries r = x_k - sum_j L(k,j) alpha_j, then factors
+//                       C(k,k) in LDS with a 16x16-blocked right-looking Cholesky whose
+//                       diagonal 16x16 factor + inverse run in one wave on v_readlane broadcasts
+//                       and whose panel / trailing updates are MFMA; it finishes alpha_k,
+//                       log-det and alpha'alpha partials.
+//   k_chol_trsm (T):    L(i,k) = C(i,k) L(k,k)^-T for i > k, blocked substitution entirely in
+//                       MFMA registers: the f64 16x16x4 accumulator layout (row = 4*reg + lane/16,
+//                       col = lane%16) is exactly the B-operand layout of k-step `reg`, so a
+//                       solved 16x16 block feeds the next MFMA without touching LDS.
+// In "Schur" mode (prediction, src/GP.jl:753-754) the update kernel runs once over the whole
+// trailing block with the sum limited to the factored columns and no factorisation:
+// it leaves K22 - V^T V in place and -(V^T alpha) in the vector.
+//
+// Operand roles in the update GEMM are swapped on purpose: MFMA "A" = the slab of tile (k,j)
+// (columns of C), MFMA "B" = the slab of tile (i,j) (rows of C), so that the accumulator's
+// lane%16 index runs along the ROWS of C, which are contiguous in the column-major tile.
+#pragma once
+#include "agp_common.hpp"
+
+namespace agp {
+
+struct CholArgs {
+  double* A;            // packed tiles
+  long long strideA;    // doubles per particle
+  double* W;            // [P][NSB][256] inverses of the current diagonal tile's 16x16 blocks
+  double* vec;          // [P][ldv]: x on entry, alpha (factored part) / -(V^T alpha) (Schur part) on exit
+  int ldv;
+  double* partial;      // [P][nt][2]: {log det, alpha'alpha} per block column
+  int* info;            // [P]
+  int P;
+  int nt;               // tile rows of the (joint) matrix
+  int k;                // factor mode: block column; Schur mode: unused
+  int nt1;              // Schur mode: number of factored block columns
+};
+
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// LDS byte budget of the update kernel: GEMM double buffers and the potrf block store alias.
+constexpr int U_SLAB = KB * LDS_STRIDE;                // doubles per slab buffer
+constexpr int U_GEMM_DOUBLES = 4 * U_SLAB;             // As[2], Bs[2]      = 9216
+constexpr int U_BLK_DOUBLES = (NSB * (NSB + 1) / 2) * 256;  // 36 blocks   = 9216
+constexpr int U_MAIN_DOUBLES = (U_GEMM_DOUBLES > U_BLK_DOUBLES) ? U_GEMM_DOUBLES : U_BLK_DOUBLES;
+// extras: rvec[128], avec[128] (alpha_k), xv[2][16] (alpha_j slab staging), Wl[256]
+constexpr int U_EXTRA_DOUBLES = 128 + 128 + 32 + 256;
+constexpr int U_LDS_BYTES = (U_MAIN_DOUBLES + U_EXTRA_DOUBLES) * 8;
+
+__device__ __forceinline__ int blk_idx(int rb, int cb) { return rb * (rb + 1) / 2 + cb; }
+
+template <bool FACTOR>
+__global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
+  __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
+  double* rvec = sm + U_MAIN_DOUBLES;
+  double* avec = rvec + 128;
+  double* xv = avec + 128;     // [2][16]
+  double* Wl = xv + 32;        // [256]
+
+  // ---- XCD-aware block -> (particle, tile) map: block b runs on XCD b%8; all tiles of one
+  //      particle go to the same XCD so the shared L(k,j) panel stays in that XCD's L2. ----
+  const int b = blockIdx.x;
+  const int xcd = b & 7, qq = b >> 3;
+  int T, ti, tk, jmax;
+  int pl, tl;
+  if (FACTOR) {
+    T = a.nt - a.k;
+    pl = qq / T; tl = qq - pl * T;
+    tk = a.k; ti = a.k + tl; jmax = a.k;
+  } else {
+    const int nt2 = a.nt - a.nt1;
+    T = nt2 * (nt2 + 1) / 2;
+    pl = qq / T; tl = qq - pl * T;
+    int ii = (int)((sqrt(8.0 * (double)tl + 1.0) - 1.0) * 0.5);
+    while (ii * (ii + 1) / 2 > tl) --ii;
+    while ((ii + 1) * (ii + 2) / 2 <= tl) ++ii;
+    const int kk = tl - ii * (ii + 1) / 2;
+    ti = a.nt1 + ii; tk = a.nt1 + kk; jmax = a.nt1;
+  }
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const bool is_diag = (ti == tk);
+
+  const int tid = threadIdx.x;
+  const int l = tid & 63;
+  const int w = tid >> 6;
+  const int wr = w & 1, wc = w >> 1;
+  const int l15 = l & 15, lq = l >> 4;
+
+  double* __restrict__ Ap = a.A + (long long)p * a.strideA;
+  double* vecp = a.vec + (long long)p * a.ldv;
+
+  d4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+
+  double rv = 0.0;
+  if (is_diag && tid < NB) rv = vecp[tk * NB + tid];
+
+  const int nslab = jmax * (NB / KB);
+  if (nslab > 0) {
+    // thread's staging pattern: 4 x 16 B of each slab; element e = 2*(tid + 256u)
+    const int scol0 = tid >> 6;        // + 4u
+    const int srow = 2 * (tid & 63);
+    d2 ra[4], rb[4];
+    double rx = 0.0;
+    auto gload = [&](int s) {
+      const int j = s >> 3, cs = (s & 7) * KB;
+      const double* __restrict__ srcA = Ap + tile_off(ti, j) + (long long)cs * NB;
+      const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int off = (scol0 + 4 * u) * NB + srow;
+        ra[u] = *reinterpret_cast<const d2*>(srcA + off);
+        rb[u] = *reinterpret_cast<const d2*>(srcB + off);
+      }
+      if (is_diag && tid < KB) rx = vecp[j * NB + cs + tid];
+    };
+    auto lstore = [&](int buf) {
+      double* As = sm + buf * U_SLAB;
+      double* Bs = sm + (2 + buf) * U_SLAB;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int off = (scol0 + 4 * u) * LDS_STRIDE + srow;
+        *reinterpret_cast<d2*>(As + off) = ra[u];
+        *reinterpret_cast<d2*>(Bs + off) = rb[u];
+      }
+      if (is_diag && tid < KB) xv[buf * 16 + tid] = rx;
+    };
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nslab) gload(s + 1);
+      const double* As = sm + buf * U_SLAB;
+      const double* Bs = sm + (2 + buf) * U_SLAB;
+#pragma unroll
+      for (int kk = 0; kk < KB / 4; ++kk) {
+        const int krow = (kk * 4 + lq) * LDS_STRIDE;
+        double fa[4], fb[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa[mi] = Bs[krow + wc * 64 + mi * 16 + l15];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fb[ni] = As[krow + wr * 64 + ni * 16 + l15];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma(fa[mi], fb[ni], acc[mi][ni]);
+      }
+      if (is_diag && tid < NB) {
+        // r -= L(k,j)[:, slab] * alpha_j[slab]
+        const double* xs_ = xv + buf * 16;
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) rv = fma(-Bs[kk * LDS_STRIDE + tid], xs_[kk], rv);
+      }
+      if (s + 1 < nslab) lstore(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  double* __restrict__ Tt = Ap + tile_off(ti, tk);
+
+  if (!(FACTOR && is_diag)) {
+    // ---- plain epilogue: C = A - acc, in place ----
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = wc * 64 + mi * 16 + 4 * r + lq;
+          const int row = wr * 64 + ni * 16 + l15;
+          double* ptr = Tt + (long long)col * NB + row;
+          *ptr = *ptr - acc[mi][ni][r];
+        }
+    if (is_diag && tid < NB) vecp[tk * NB + tid] = rv;   // Schur mode: -(V^T alpha) (+x = 0)
+    return;
+  }
+
+  // =====================  diagonal tile: factor C(k,k) in LDS  =====================
+  // S = A(k,k) - acc into 16x16 blocks (lower block triangle), each block column-major.
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int cb = wc * 4 + mi, rb = wr * 4 + ni;
+      if (rb >= cb) {
+        double* blk = sm + blk_idx(rb, cb) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int col = cb * 16 + 4 * r + lq;
+          const int row = rb * 16 + l15;
+          blk[64 * r + l] = Tt[(long long)col * NB + row] - acc[mi][ni][r];
+        }
+      }
+    }
+  if (tid < NB) rvec[tid] = rv;
+  __syncthreads();
+
+  double logdet = 0.0;   // wave 0, uniform
+  int bad = 0;           // first non-positive pivot (1-based global index), 0 = none
+
+  for (int jb = 0; jb < NSB; ++jb) {
+    // ---- (a) wave 0: 16x16 Cholesky of block (jb,jb) + its inverse, on lane broadcasts ----
+    if (w == 0) {
+      double* blk = sm + blk_idx(jb, jb) * 256;
+      double s[16], rinvs[16], wv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) s[c] = blk[c * 16 + l15];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double pc = readlane_d(s[c], c);
+        if (!(pc > 0.0) && bad == 0) bad = a.k * NB + jb * 16 + c + 1;
+        logdet += log(pc);
+        const double rinv = rsqrt(pc);
+        rinvs[c] = rinv;
+        const double lrc = s[c] * rinv;
+        s[c] = lrc;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; ++c2) s[c2] = fma(-lrc, readlane_d(lrc, c2), s[c2]);
+      }
+      // W = L^-1: lane `col` owns column `col`; W[r][col] for r = 0..15
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double t = (r == l15) ? 1.0 : 0.0;
+#pragma unroll
+        for (int q = 0; q < r; ++q) t = fma(-readlane_d(s[q], r), wv[q], t);
+        wv[r] = t * rinvs[r];
+      }
+      if (l < 16) {
+        double* Wg = a.W + ((long long)p * NSB + jb) * 256;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) blk[c * 16 + l] = (c <= l) ? s[c] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          Wl[l * 16 + r] = wv[r];
+          Wg[l * 16 + r] = wv[r];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- (b) panel: L(ib,jb) = S(ib,jb) W^T for ib > jb (MFMA); alpha_jb = W r_jb ----
+    for (int ib = jb + 1 + w; ib < NSB; ib += 4) {
+      double* blk = sm + blk_idx(ib, jb) * 256;
+      double fw[4], fs[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { fw[s4] = Wl[64 * s4 + l]; fs[s4] = blk[64 * s4 + l]; }
+      d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) x = mfma(fw[s4], fs[s4], x);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[64 * r + l] = x[r];
+    }
+    if (w == 3 && l < 16) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t = fma(Wl[q * 16 + l], rvec[jb * 16 + q], t);
+      avec[jb * 16 + l] = t;
+    }
+    __syncthreads();
+
+    // ---- (c) trailing blocks (ib,cb), jb < cb <= ib: S(ib,cb) -= L(ib,jb) L(cb,jb)^T;
+    //      r_ib -= L(ib,jb) alpha_jb ----
+    {
+      const int nrem = NSB - 1 - jb;              // block rows below jb
+      const int npair = nrem * (nrem + 1) / 2;
+      for (int e = w; e < npair; e += 4) {
+        int ii = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (ii * (ii + 1) / 2 > e) --ii;
+        while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
+        const int cc = e - ii * (ii + 1) / 2;
+        const int ib = jb + 1 + ii, cb = jb + 1 + cc;
+        double* blk = sm + blk_idx(ib, cb) * 256;
+        const double* la = sm + blk_idx(cb, jb) * 256;
+        const double* lb = sm + blk_idx(ib, jb) * 256;
+        d4 x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = blk[64 * r + l];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) x = mfma(-la[64 * s4 + l], lb[64 * s4 + l], x);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) blk[64 * r + l] = x[r];
+      }
+      if (tid < NB && tid >= (jb + 1) * 16) {
+        const double* lb = sm + blk_idx(tid >> 4, jb) * 256;
+        double t = rvec[tid];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t = fma(-lb[q * 16 + (tid & 15)], avec[jb * 16 + q], t);
+        rvec[tid] = t;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write L(k,k) (upper part zero), alpha_k, partials, info ----
+  for (int bi = 0; bi < NSB * NSB; ++bi) {
+    const int rb = bi >> 3, cb = bi & 7;
+    const int c = tid >> 4, r = tid & 15;
+    const double v = (rb >= cb) ? sm[blk_idx(rb, cb) * 256 + tid] : 0.0;
+    Tt[(long long)(cb * 16 + c) * NB + rb * 16 + r] = v;
+  }
+  if (tid < NB) vecp[tk * NB + tid] = avec[tid];
+  if (w == 0) {
+    double ss = avec[l] * avec[l] + avec[l + 64] * avec[l + 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    if (l == 0) {
+      double* pp = a.partial + ((long long)p * a.nt + tk) * 2;
+      pp[0] = logdet;
+      pp[1] = ss;
+      if (bad != 0 && a.info[p] == 0) a.info[p] = bad;
+    }
+  }
+}
+
+// T — L(i,k) = C(i,k) L(k,k)^-T for the tiles below the diagonal of block column k.
+// One workgroup per tile; each wave solves two 16-row strips in MFMA registers.
+__global__ __launch_bounds__(256, 2) void k_chol_trsm(CholArgs a) {
+  const int b = blockIdx.x;
+  const int xcd = b & 7, qq = b >> 3;
+  const int T = a.nt - a.k - 1;
+  const int pl = qq / T, tl = qq - pl * T;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const int ti = a.k + 1 + tl;
+
+  const int tid = threadIdx.x;
+  const int l = tid & 63, w = tid >> 6;
+  const int l15 = l & 15, lq = l >> 4;
+
+  double* __restrict__ Ap = a.A + (long long)p * a.strideA;
+  const double* __restrict__ Lkk = Ap + tile_off(a.k, a.k);
+  double* __restrict__ Tt = Ap + tile_off(ti, a.k);
+  const double* __restrict__ Wg = a.W + (long long)p * NSB * 256;
+
+  d4 X[2][NSB];
+#pragma unroll
+  for (int jb = 0; jb < NSB; ++jb) {
+    d4 acc[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int R0 = (2 * w + st) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[st][r] = Tt[(long long)(jb * 16 + 4 * r + lq) * NB + R0 + l15];
+    }
+#pragma unroll
+    for (int lb = 0; lb < jb; ++lb) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        // -L(k,k)[jb*16 + l15][lb*16 + 4 s4 + lq]
+        const double fl = -Lkk[(long long)(lb * 16 + 4 * s4 + lq) * NB + jb * 16 + l15];
+        acc[0] = mfma(fl, X[0][lb][s4], acc[0]);
+        acc[1] = mfma(fl, X[1][lb][s4], acc[1]);
+      }
+    }
+    d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const double fw = Wg[jb * 256 + 64 * s4 + l];   // W_jb[l15][4 s4 + lq]
+      x0 = mfma(fw, acc[0][s4], x0);
+      x1 = mfma(fw, acc[1][s4], x1);
+    }
+    X[0][jb] = x0;
+    X[1][jb] = x1;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const int R0 = (2 * w + st) * 16;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        Tt[(long long)(jb * 16 + 4 * r + lq) * NB + R0 + l15] = X[st][jb][r];
+    }
+  }
+}
+
+// logpdf = -1/2 (n log 2pi + log|K| + alpha'alpha)   (Gen.mvnormal logpdf, src/Model.jl:136)
+__global__ void k_finish_logpdf(const double* partial, const int* info, int nt, int P, int n,
+                                double* out_logpdf, int* out_info) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  double ld = 0.0, ss = 0.0;
+  for (int k = 0; k < nt; ++k) {
+    ld += partial[((long long)p * nt + k) * 2];
+    ss += partial[((long long)p * nt + k) * 2 + 1];
+  }
+  const int inf = info[p];
+  const double lp = -0.5 * ((double)n * 1.8378770664093454835606594728112 + ld + ss);
+  out_logpdf[p] = (inf != 0) ? __builtin_nan("") : lp;
+  out_info[p] = inf;
+}
+
+// x (minus the mean function on the training segment), zero elsewhere; clears info.
+__global__ void k_init_vec(double* vec, int ldv, int P, const double* xs, const double* mu1, int n1,
+                           int* info) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (g == 0) info[p] = 0;
+  if (g >= ldv) return;
+  double v = 0.0;
+  if (g < n1) v = xs[g] - (mu1 ? mu1[g] : 0.0);
+  vec[(long long)p * ldv + g] = v;
+}
+
+// Predictive read-out (src/GP.jl:753-757): mean = mu2 + K21 K11^-1 (x - mu1),
+// cov = sym(K22 - K21 K11^-1 K12) + noise_pred I, var = diag(cov).
+struct PredArgs {
+  const double* A; long long strideA;
+  const double* vec; int ldv;
+  const double* mu2;        // [m] or null
+  const double* noise_pred; // [P]
+  int nt1, n1_pad, m, P;
+  double* out_mean;         // [P][m]
+  double* out_var;          // [P][m]
+  double* out_cov;          // [P][m*m] or null
+};
+
+__global__ void k_pred_extract(PredArgs a) {
+  const int p = blockIdx.y;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const double* Ap = a.A + (long long)p * a.strideA;
+  const double np = a.noise_pred[p];
+  if (idx < a.m) {
+    const int g = (int)idx;
+    const double r = a.vec[(long long)p * a.ldv + a.n1_pad + g];
+    a.out_mean[(long long)p * a.m + g] = (a.mu2 ? a.mu2[g] : 0.0) - r;
+    const int t = a.nt1 + g / NB, o = g % NB;
+    a.out_var[(long long)p * a.m + g] = Ap[tile_off(t, t) + (long long)o * NB + o] + np;
+  }
+  if (a.out_cov) {
+    const long long mm = (long long)a.m * a.m;
+    if (idx < mm) {
+      int r = (int)(idx % a.m), c = (int)(idx / a.m);
+      const int hi = r > c ? r : c, lo = r > c ? c : r;
+      const int ti = a.nt1 + hi / NB, tj = a.nt1 + lo / NB;
+      double v = Ap[tile_off(ti, tj) + (long long)(lo % NB) * NB + (hi % NB)];
+      if (r == c) v += np;
+      a.out_cov[(long long)p * mm + idx] = v;
+    }
+  }
+}
+
+// packed tiles <-> dense column-major (debug / parity entries)
+__global__ void k_unpack_dense(const double* A, int n, int lower_only, double* out) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)n * n) return;
+  const int r = (int)(idx % n), c = (int)(idx / n);
+  const int hi = r > c ? r : c, lo = r > c ? c : r;
+  double v = A[tile_off(hi / NB, lo / NB) + (long long)(lo % NB) * NB + (hi % NB)];
+  if (lower_only && c > r) v = 0.0;
+  out[idx] = v;
+}
+
+__global__ void k_pack_dense(const double* K, int n, int nt, double* A) {
+  // one thread per element of the packed lower tiles; identity on the padding
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long tot = (long long)nt * (nt + 1) / 2 * NB2;
+  if (idx >= tot) return;
+  const int t = (int)(idx / NB2), e = (int)(idx % NB2);
+  int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > t) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  const int tj = t - ti * (ti + 1) / 2;
+  const int r = ti * NB + e % NB, c = tj * NB + e / NB;
+  double v;
+  if (r < n && c < n) v = K[(long long)c * n + r];
+  else v = (r == c) ? 1.0 : 0.0;
+  A[idx] = v;
+}
+
+// fp64 MFMA layout probe: D(16x16) = A(16x4) B(4x16), host arrays row-major.
+__global__ void k_mfma_probe(const double* A, const double* B, double* D) {
+  const int l = threadIdx.x;
+  const double a = A[(l & 15) * 4 + (l >> 4)];    // A[i = l%16][k = l/16]
+  const double b = B[(l >> 4) * 16 + (l & 15)];   // B[k = l/16][j = l%16]
+  d4 c = d4{0.0, 0.0, 0.0, 0.0};
+  c = mfma(a, b, c);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) D[(4 * r + (l >> 4)) * 16 + (l & 15)] = c[r];   // row = 4r + l/16, col = l%16
+}
+
+}  // namespace agp

@@ -1,0 +1,41 @@
+// Shared definitions for the gfx950 GP engine (device + host).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace agp {
+
+// ---- tiling constants -------------------------------------------------------------------
+// The covariance matrix of one particle lives in HBM as PACKED LOWER TILES: tile (i,j), i>=j,
+// is a contiguous column-major NB x NB block at offset (i(i+1)/2 + j) * NB*NB doubles.
+// A 16-column slab of a tile is therefore one contiguous 16 KiB run (what the update kernel
+// streams), and only the triangle the Cholesky touches is ever stored.
+constexpr int NB = 128;          // tile edge
+constexpr int NB2 = NB * NB;     // doubles per tile
+constexpr int BS = 16;           // MFMA sub-block edge (v_mfma_f64_16x16x4)
+constexpr int NSB = NB / BS;     // 8 sub-blocks per tile edge
+constexpr int KB = 16;           // slab depth of the update GEMM
+constexpr int LDS_STRIDE = 144;  // 128 + 16 doubles: k-rows 32 banks apart -> conflict-free ds_read_b64
+
+// ---- device program opcodes (after host-side compilation) ----------------------------------
+// 0..8 equal the C-ABI / GPConfig codes; 9 is ChangePoint with its operands evaluated in
+// swapped order (the host reorders children so the deeper subtree is evaluated first, which
+// bounds the evaluation stack by the tree's Strahler number).
+enum : int { OP_WN = 0, OP_CONST = 1, OP_LIN = 2, OP_SE = 3, OP_GE = 4, OP_PER = 5,
+             OP_PLUS = 6, OP_TIMES = 7, OP_CP = 8, OP_CP_SWAP = 9 };
+
+struct ProgHdr {
+  int32_t op_off;   // offset into device ops[]
+  int32_t prm_off;  // offset into device prm[]
+  int32_t n_ops;
+  int32_t n_cp;     // number of ChangePoint nodes
+};
+
+__host__ __device__ inline long long tile_off(int i, int j) {
+  return ((long long)i * (i + 1) / 2 + j) * (long long)NB2;
+}
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+}  // namespace agp

@@ -1,0 +1,763 @@
+// Host side of the C ABI (include/autogp_hip.h): program compilation, workspace slots,
+// launch orchestration.  gfx950 only; no CPU fallback — every compute entry fails loudly if
+// the HIP runtime / device is unavailable.
+#include "../../include/autogp_hip.h"
+#include "agp_common.hpp"
+#include "agp_cov_kernel.hpp"
+#include "agp_chol_kernel.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace agp;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { e = hipMalloc(&p, bytes); want = bytes; }
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <typename T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+struct Slot {
+  hipStream_t stream = nullptr;
+  DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
+      pred_mean, pred_var, pred_cov, dense;
+  std::vector<hipEvent_t> events;
+  bool busy = false;
+  void release() {
+    for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
+                      &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense})
+      b->release();
+    for (auto e : events) (void)hipEventDestroy(e);
+    events.clear();
+    if (stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+  }
+};
+
+}  // namespace
+
+struct agp_ctx {
+  int device = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<Slot*> slots;
+  int max_slots = 16;
+  std::string err;
+  // resident data
+  double* d_ts = nullptr;
+  double* d_xs = nullptr;
+  int64_t n_max = 0;
+  std::vector<double> h_ts;   // host copy (prediction builds a joint point list)
+  // config
+  int64_t ws_limit = 0;
+  size_t total_mem = 0;
+  bool profiling = false;
+  double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+thread_local std::string g_err_noctx;
+
+int fail(agp_ctx* c, int code, const std::string& msg) {
+  if (c) { std::lock_guard<std::mutex> g(c->mu); c->err = msg; }
+  else g_err_noctx = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      char buf_[512];                                                                       \
+      snprintf(buf_, sizeof buf_, "HIP error %d (%s) at %s:%d: %s", (int)e_,                \
+               hipGetErrorString(e_), __FILE__, __LINE__, #expr);                           \
+      return fail(ctx, AGP_ERR_HIP, buf_);                                                  \
+    }                                                                                       \
+  } while (0)
+
+Slot* acquire_slot(agp_ctx* c) {
+  std::unique_lock<std::mutex> g(c->mu);
+  for (;;) {
+    for (Slot* s : c->slots)
+      if (!s->busy) { s->busy = true; return s; }
+    if ((int)c->slots.size() < c->max_slots) {
+      Slot* s = new Slot();
+      s->busy = true;
+      c->slots.push_back(s);
+      return s;
+    }
+    c->cv.wait(g);
+  }
+}
+
+void release_slot(agp_ctx* c, Slot* s) {
+  { std::lock_guard<std::mutex> g(c->mu); s->busy = false; }
+  c->cv.notify_one();
+}
+
+struct SlotGuard {
+  agp_ctx* c; Slot* s;
+  SlotGuard(agp_ctx* c_) : c(c_), s(acquire_slot(c_)) {}
+  ~SlotGuard() { release_slot(c, s); }
+};
+
+// ------------------------------------------------------------------------------------------
+// Program compilation: reference-order postfix (include/autogp_hip.h) -> device program.
+//  * children of every binary node are re-ordered so the subtree needing the deeper evaluation
+//    stack runs first (+ and * commute exactly in IEEE arithmetic; ChangePoint gets OP_CP_SWAP),
+//    bounding the stack by the Strahler number of the tree;
+//  * per-element divisions are turned into multiplications by host-computed reciprocals
+//    (SE: 1/l^2, GE: 1/l, Periodic: -2/l^2 and pi/p exactly as the reference's scalars).
+// ------------------------------------------------------------------------------------------
+struct CNode {
+  int op; int left = -1, right = -1; double prm[3] = {0, 0, 0}; int need = 1;
+};
+
+struct Compiled {
+  std::vector<uint8_t> ops;
+  std::vector<double> prm;
+  int n_cp = 0;
+  int depth_need = 1;
+};
+
+int leaf_nprm(int op) {
+  switch (op) {
+    case OP_WN: case OP_CONST: return 1;
+    case OP_SE: return 2;
+    case OP_LIN: case OP_GE: case OP_PER: return 3;
+    default: return -1;
+  }
+}
+
+void emit(const std::vector<CNode>& nodes, int id, Compiled& out) {
+  const CNode& nd = nodes[id];
+  if (nd.left < 0) {
+    out.ops.push_back((uint8_t)nd.op);
+    switch (nd.op) {
+      case OP_WN: case OP_CONST: out.prm.push_back(nd.prm[0]); break;
+      case OP_LIN: out.prm.insert(out.prm.end(), {nd.prm[0], nd.prm[1], nd.prm[2]}); break;
+      case OP_SE: out.prm.insert(out.prm.end(), {1.0 / (nd.prm[0] * nd.prm[0]), nd.prm[1]}); break;
+      case OP_GE: out.prm.insert(out.prm.end(), {1.0 / nd.prm[0], nd.prm[1], nd.prm[2]}); break;
+      case OP_PER:
+        out.prm.insert(out.prm.end(), {-2.0 / (nd.prm[0] * nd.prm[0]), M_PI / nd.prm[1], nd.prm[2]});
+        break;
+    }
+    return;
+  }
+  const bool swap = nodes[nd.right].need > nodes[nd.left].need;
+  emit(nodes, swap ? nd.right : nd.left, out);
+  emit(nodes, swap ? nd.left : nd.right, out);
+  if (nd.op == OP_CP) {
+    out.ops.push_back((uint8_t)(swap ? OP_CP_SWAP : OP_CP));
+    out.prm.push_back(nd.prm[0]);
+    out.prm.push_back(nd.prm[1]);
+    out.n_cp++;
+  } else {
+    out.ops.push_back((uint8_t)nd.op);
+  }
+}
+
+// returns 0 or an error string
+const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, int n_prm, Compiled& out) {
+  if (n_ops <= 0 || n_ops > AGP_MAX_OPS) return "program length out of range";
+  std::vector<CNode> nodes;
+  nodes.reserve(n_ops);
+  std::vector<int> stack;
+  int ip = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    const int op = ops[i];
+    CNode nd; nd.op = op;
+    if (op <= OP_PER) {
+      const int k = leaf_nprm(op);
+      if (ip + k > n_prm) return "parameter array too short";
+      for (int q = 0; q < k; ++q) nd.prm[q] = prm[ip + q];
+      ip += k;
+      nd.need = 1;
+    } else if (op == OP_PLUS || op == OP_TIMES || op == OP_CP) {
+      if (stack.size() < 2) return "postfix stack underflow";
+      nd.right = stack.back(); stack.pop_back();
+      nd.left = stack.back(); stack.pop_back();
+      if (op == OP_CP) {
+        if (ip + 2 > n_prm) return "parameter array too short";
+        nd.prm[0] = prm[ip]; nd.prm[1] = prm[ip + 1]; ip += 2;
+      }
+      const int a = nodes[nd.left].need, b = nodes[nd.right].need;
+      nd.need = (a == b) ? a + 1 : std::max(a, b);
+    } else {
+      return "unknown opcode";
+    }
+    nodes.push_back(nd);
+    stack.push_back((int)nodes.size() - 1);
+  }
+  if (stack.size() != 1) return "postfix program does not reduce to one kernel";
+  if (ip != n_prm) return "parameter count mismatch";
+  out.depth_need = nodes[stack[0]].need;
+  if (out.depth_need > 8) return "kernel tree needs an evaluation stack deeper than 8";
+  emit(nodes, stack[0], out);
+  return nullptr;
+}
+
+struct Batch {
+  std::vector<ProgHdr> hdr;
+  std::vector<uint8_t> ops;
+  std::vector<double> prm;
+  int max_cp = 0;
+  int max_depth = 1;
+};
+
+int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
+                  const double* prm, Batch& bt) {
+  bt.hdr.resize(P);
+  for (int p = 0; p < P; ++p) {
+    Compiled cp;
+    const char* e = compile_program(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p],
+                                    prm_off[p + 1] - prm_off[p], cp);
+    if (e) {
+      char buf[256];
+      snprintf(buf, sizeof buf, "particle %d: %s", p, e);
+      return fail(c, AGP_ERR_PROGRAM, buf);
+    }
+    ProgHdr h;
+    h.op_off = (int32_t)bt.ops.size();
+    h.prm_off = (int32_t)bt.prm.size();
+    h.n_ops = (int32_t)cp.ops.size();
+    h.n_cp = cp.n_cp;
+    bt.hdr[p] = h;
+    bt.ops.insert(bt.ops.end(), cp.ops.begin(), cp.ops.end());
+    bt.prm.insert(bt.prm.end(), cp.prm.begin(), cp.prm.end());
+    bt.max_cp = std::max(bt.max_cp, cp.n_cp);
+    bt.max_depth = std::max(bt.max_depth, cp.depth_need);
+  }
+  // keep ops 4-byte padded
+  while (bt.ops.size() % 4) bt.ops.push_back(0);
+  return AGP_OK;
+}
+
+inline int round_up(int64_t n, int m) { return (int)(((n + m - 1) / m) * m); }
+
+int64_t ws_limit_bytes(agp_ctx* c) {
+  if (c->ws_limit > 0) return c->ws_limit;
+  int64_t lim = (int64_t)(c->total_mem * 0.55);
+  const int64_t cap = 96LL << 30;
+  return std::min(lim, cap);
+}
+
+hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int max_cp, int depth) {
+  const size_t lds = (256 + (size_t)max_cp * 256) * sizeof(double);
+  dim3 grid(ntiles, P), block(256);
+  if (depth <= 4) {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cov_tiles<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_cov_tiles<4>, grid, block, lds, st, ca);
+  } else {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cov_tiles<8>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_cov_tiles<8>, grid, block, lds, st, ca);
+  }
+  return hipGetLastError();
+}
+
+struct Prof {
+  agp_ctx* c; Slot* s; hipStream_t st; bool on; size_t next = 0;
+  std::vector<std::pair<int, std::pair<size_t, size_t>>> spans;  // (kind, (ev0, ev1))
+  hipEvent_t ev() {
+    if (next >= s->events.size()) {
+      hipEvent_t e; (void)hipEventCreate(&e); s->events.push_back(e);
+    }
+    return s->events[next++];
+  }
+  size_t mark() {
+    if (!on) return 0;
+    size_t i = next; hipEvent_t e = ev(); (void)hipEventRecord(e, st); return i;
+  }
+  void span(int kind, size_t a, size_t b) { if (on) spans.push_back({kind, {a, b}}); }
+  void collect(double* acc) {   // after stream sync
+    if (!on) return;
+    for (auto& sp : spans) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, s->events[sp.second.first], s->events[sp.second.second]);
+      acc[sp.first] += ms;
+    }
+  }
+};
+
+// Factor block columns [0, nfac) of the joint (nt x nt tiles) matrices of Pc particles.
+hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, Prof* pf, double* counts) {
+  for (int k = 0; k < nfac; ++k) {
+    ca.k = k;
+    const int Pg = (ca.P + 7) / 8;
+    {
+      const int T = ca.nt - k;
+      size_t e0 = pf ? pf->mark() : 0;
+      hipLaunchKernelGGL(k_chol_update<true>, dim3(8 * Pg * T), dim3(256), 0, st, ca);
+      size_t e1 = pf ? pf->mark() : 0;
+      if (pf) pf->span(2, e0, e1);
+      if (counts) counts[0] += 1;
+    }
+    const int T2 = ca.nt - k - 1;
+    if (T2 > 0) {
+      size_t e0 = pf ? pf->mark() : 0;
+      hipLaunchKernelGGL(k_chol_trsm, dim3(8 * Pg * T2), dim3(256), 0, st, ca);
+      size_t e1 = pf ? pf->mark() : 0;
+      if (pf) pf->span(3, e0, e1);
+      if (counts) counts[1] += 1;
+    }
+  }
+  return hipGetLastError();
+}
+
+// Core of agp_logpdf_batch{,_device}.  d_out_* may be caller device buffers (user_stream path)
+// or null (results copied to host h_out_*).
+int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
+                      const int32_t* prm_off, const double* prm, const double* noise,
+                      double* h_out_lp, int32_t* h_out_info, double* d_user_lp, int32_t* d_user_info,
+                      hipStream_t user_stream, bool use_user_stream) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (P < 0 || n < 0) return fail(c, AGP_ERR_ARG, "negative size");
+  if (P == 0) return AGP_OK;
+  if (!op_off || !ops || !prm_off || !prm || !noise) return fail(c, AGP_ERR_ARG, "null program/noise pointer");
+  if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
+  HIPCHK(c, hipSetDevice(c->device));
+
+  Batch bt;
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt);
+  if (rc) return rc;
+
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = use_user_stream ? user_stream : s->stream;
+
+  double* d_lp = d_user_lp;
+  int32_t* d_info_out = d_user_info;
+  if (!d_lp) { HIPCHK(c, s->out_lp.ensure(sizeof(double) * P)); d_lp = s->out_lp.as<double>(); }
+  if (!d_info_out) { HIPCHK(c, s->out_info.ensure(sizeof(int32_t) * P)); d_info_out = s->out_info.as<int32_t>(); }
+
+  if (n == 0) {
+    // 0 x 0 covariance: logpdf = 0, info = 0 (src/inference_smc_anneal_data.jl:185-187)
+    HIPCHK(c, hipMemsetAsync(d_lp, 0, sizeof(double) * P, st));
+    HIPCHK(c, hipMemsetAsync(d_info_out, 0, sizeof(int32_t) * P, st));
+  } else {
+    const int n_pad = round_up(n, NB);
+    const int nt = n_pad / NB;
+    const int ntiles = nt * (nt + 1) / 2;
+    const long long strideA = (long long)ntiles * NB2;
+    const int64_t bytes_pp = strideA * 8;
+    int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(P, ws_limit_bytes(c) / bytes_pp));
+
+    HIPCHK(c, s->A.ensure((size_t)bytes_pp * chunk));
+    HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256 * (size_t)chunk));
+    HIPCHK(c, s->vec.ensure(sizeof(double) * (size_t)n_pad * chunk));
+    HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
+    HIPCHK(c, s->info.ensure(sizeof(int) * (size_t)chunk));
+    HIPCHK(c, s->hdr.ensure(sizeof(ProgHdr) * (size_t)P));
+    HIPCHK(c, s->ops.ensure(bt.ops.size()));
+    HIPCHK(c, s->prm.ensure(sizeof(double) * std::max<size_t>(1, bt.prm.size())));
+    HIPCHK(c, s->noise.ensure(sizeof(double) * (size_t)P));
+
+    Prof pf{c, s, st, c->profiling};
+    double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    size_t ev_begin = pf.mark();
+    HIPCHK(c, hipMemcpyAsync(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr) * P, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(s->ops.p, bt.ops.data(), bt.ops.size(), hipMemcpyHostToDevice, st));
+    if (!bt.prm.empty())
+      HIPCHK(c, hipMemcpyAsync(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(s->noise.p, noise, sizeof(double) * P, hipMemcpyHostToDevice, st));
+    size_t ev_h2d = pf.mark();
+    pf.span(7, ev_begin, ev_h2d);
+
+    for (int p0 = 0; p0 < P; p0 += chunk) {
+      const int Pc = std::min(chunk, P - p0);
+      hipLaunchKernelGGL(k_init_vec, dim3((n_pad + 255) / 256, Pc), dim3(256), 0, st, s->vec.as<double>(),
+                         n_pad, Pc, c->d_xs, (const double*)nullptr, (int)n, s->info.as<int>());
+      CovArgs cv;
+      cv.tt = c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
+      cv.hdr = s->hdr.as<ProgHdr>() + p0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
+      cv.noise = s->noise.as<double>() + p0; cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = Pc;
+      size_t e0 = pf.mark();
+      HIPCHK(c, launch_cov(st, cv, ntiles, Pc, bt.max_cp, bt.max_depth));
+      size_t e1 = pf.mark();
+      pf.span(1, e0, e1);
+
+      CholArgs ca;
+      ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>();
+      ca.vec = s->vec.as<double>(); ca.ldv = n_pad; ca.partial = s->partial.as<double>();
+      ca.info = s->info.as<int>(); ca.P = Pc; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
+      HIPCHK(c, run_factor(st, ca, nt, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr));
+
+      size_t e2 = pf.mark();
+      hipLaunchKernelGGL(k_finish_logpdf, dim3((Pc + 63) / 64), dim3(64), 0, st, s->partial.as<double>(),
+                         s->info.as<int>(), nt, Pc, (int)n, d_lp + p0, d_info_out + p0);
+      size_t e3 = pf.mark();
+      pf.span(4, e2, e3);
+      HIPCHK(c, hipGetLastError());
+    }
+    size_t ev_end = pf.mark();
+    pf.span(0, ev_begin, ev_end);
+    if (c->profiling) {
+      HIPCHK(c, hipStreamSynchronize(st));
+      pf.collect(tacc);
+      std::lock_guard<std::mutex> g(c->mu);
+      for (int i = 0; i < 8; ++i) c->timing[i] = tacc[i];
+    }
+  }
+
+  if (h_out_lp) HIPCHK(c, hipMemcpyAsync(h_out_lp, d_lp, sizeof(double) * P, hipMemcpyDeviceToHost, st));
+  if (h_out_info) HIPCHK(c, hipMemcpyAsync(h_out_info, d_info_out, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
+  // The slot's buffers are reused by the next caller, so the work must be complete before the
+  // slot is released even on the user-stream path.
+  HIPCHK(c, hipStreamSynchronize(st));
+  return AGP_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+extern "C" {
+
+const char* agp_version(void) { return "autogp-hip 0.1.0 (gfx950)"; }
+
+int agp_init(agp_ctx** out, int device_id) {
+  if (!out) return fail(nullptr, AGP_ERR_ARG, "null out pointer");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, AGP_ERR_HIP, "no HIP device available (this engine has no CPU fallback)");
+  if (device_id < 0 || device_id >= ndev) return fail(nullptr, AGP_ERR_ARG, "device id out of range");
+  if (hipSetDevice(device_id) != hipSuccess) return fail(nullptr, AGP_ERR_HIP, "hipSetDevice failed");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess)
+    return fail(nullptr, AGP_ERR_HIP, "hipGetDeviceProperties failed");
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+    std::string m = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+    return fail(nullptr, AGP_ERR_HIP, m);
+  }
+  agp_ctx* c = new agp_ctx();
+  c->device = device_id;
+  size_t free_b = 0, tot_b = 0;
+  (void)hipMemGetInfo(&free_b, &tot_b);
+  c->total_mem = free_b ? free_b : tot_b;
+  *out = c;
+  return AGP_OK;
+}
+
+void agp_destroy(agp_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (Slot* s : c->slots) { s->release(); delete s; }
+  if (c->d_ts) (void)hipFree(c->d_ts);
+  if (c->d_xs) (void)hipFree(c->d_xs);
+  delete c;
+}
+
+const char* agp_last_error(agp_ctx* c) {
+  if (!c) return g_err_noctx.c_str();
+  std::lock_guard<std::mutex> g(c->mu);
+  return c->err.c_str();
+}
+
+int agp_set_workspace_limit(agp_ctx* c, int64_t bytes) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  c->ws_limit = bytes;
+  return AGP_OK;
+}
+
+int agp_set_profiling(agp_ctx* c, int enabled) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  c->profiling = enabled != 0;
+  return AGP_OK;
+}
+
+int agp_get_timing(agp_ctx* c, double* out, int32_t n_out) {
+  if (!c || !out) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  for (int i = 0; i < n_out && i < 8; ++i) out[i] = c->timing[i];
+  return AGP_OK;
+}
+
+int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (n_max < 0 || (n_max > 0 && (!ts || !xs))) return fail(c, AGP_ERR_ARG, "bad data arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  if (c->d_ts) { HIPCHK(c, hipFree(c->d_ts)); c->d_ts = nullptr; }
+  if (c->d_xs) { HIPCHK(c, hipFree(c->d_xs)); c->d_xs = nullptr; }
+  // padded to a whole tile so kernels may read (and ignore) the tail
+  const int64_t npad = ((n_max + NB - 1) / NB) * NB + NB;
+  HIPCHK(c, hipMalloc((void**)&c->d_ts, sizeof(double) * npad));
+  HIPCHK(c, hipMalloc((void**)&c->d_xs, sizeof(double) * npad));
+  HIPCHK(c, hipMemset(c->d_ts, 0, sizeof(double) * npad));
+  HIPCHK(c, hipMemset(c->d_xs, 0, sizeof(double) * npad));
+  if (n_max > 0) {
+    HIPCHK(c, hipMemcpy(c->d_ts, ts, sizeof(double) * n_max, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_xs, xs, sizeof(double) * n_max, hipMemcpyHostToDevice));
+  }
+  c->h_ts.assign(ts, ts + n_max);
+  c->n_max = n_max;
+  return AGP_OK;
+}
+
+int agp_logpdf_batch(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
+                     const int32_t* prm_off, const double* prm, const double* noise, double* out_logpdf,
+                     int32_t* out_info) {
+  if (c && P > 0 && (!out_logpdf || !out_info)) return fail(c, AGP_ERR_ARG, "null output pointer");
+  return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr, nullptr,
+                           nullptr, false);
+}
+
+int agp_logpdf_batch_device(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
+                            const int32_t* prm_off, const double* prm, const double* noise,
+                            double* d_out_logpdf, int32_t* d_out_info, void* hip_stream) {
+  if (c && P > 0 && (!d_out_logpdf || !d_out_info)) return fail(c, AGP_ERR_ARG, "null output pointer");
+  return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, nullptr, nullptr, d_out_logpdf,
+                           d_out_info, (hipStream_t)hip_stream, hip_stream != nullptr);
+}
+
+int agp_logpdf(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
+               double noise, double* out_logpdf, int32_t* out_info) {
+  const int32_t op_off[2] = {0, n_ops}, prm_off[2] = {0, n_prm};
+  double dummy = 0.0;
+  return agp_logpdf_batch(c, n, 1, op_off, ops, prm_off, prm ? prm : &dummy, &noise, out_logpdf, out_info);
+}
+
+int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P,
+                      const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                      const double* noise, const double* noise_pred, const double* mean_train,
+                      const double* mean_pred, double* out_mean, double* out_var, double* out_cov,
+                      int32_t* out_info) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (P < 0 || n < 0 || m < 0) return fail(c, AGP_ERR_ARG, "negative size");
+  if (P == 0 || m == 0) return AGP_OK;
+  if (!op_off || !ops || !prm_off || !prm || !noise || !ts_pred || !out_mean || !out_var)
+    return fail(c, AGP_ERR_ARG, "null pointer argument");
+  if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
+  HIPCHK(c, hipSetDevice(c->device));
+
+  Batch bt;
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt);
+  if (rc) return rc;
+
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+
+  const int n1_pad = round_up(n, NB);           // 0 when n == 0
+  const int m_pad = round_up(m, NB);
+  const int nt1 = n1_pad / NB, nt2 = m_pad / NB, nt = nt1 + nt2;
+  const int ntot = n1_pad + m_pad;
+  const int ntiles = nt * (nt + 1) / 2;
+  const long long strideA = (long long)ntiles * NB2;
+  const int64_t bytes_pp = strideA * 8;
+  const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(P, ws_limit_bytes(c) / bytes_pp));
+
+  // joint point list [ts(1:n), pad, ts_pred, pad]
+  std::vector<double> tt((size_t)ntot, 0.0);
+  std::copy(c->h_ts.begin(), c->h_ts.begin() + n, tt.begin());
+  std::copy(ts_pred, ts_pred + m, tt.begin() + n1_pad);
+  std::vector<double> npred(P);
+  for (int p = 0; p < P; ++p) npred[p] = noise_pred ? noise_pred[p] : noise[p];
+
+  HIPCHK(c, s->A.ensure((size_t)bytes_pp * chunk));
+  HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256 * (size_t)chunk));
+  HIPCHK(c, s->vec.ensure(sizeof(double) * (size_t)ntot * chunk));
+  HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
+  HIPCHK(c, s->info.ensure(sizeof(int) * (size_t)P));
+  HIPCHK(c, s->hdr.ensure(sizeof(ProgHdr) * (size_t)P));
+  HIPCHK(c, s->ops.ensure(bt.ops.size()));
+  HIPCHK(c, s->prm.ensure(sizeof(double) * std::max<size_t>(1, bt.prm.size())));
+  HIPCHK(c, s->noise.ensure(sizeof(double) * (size_t)P));
+  HIPCHK(c, s->noise_pred.ensure(sizeof(double) * (size_t)P));
+  HIPCHK(c, s->tt.ensure(sizeof(double) * (size_t)ntot));
+  HIPCHK(c, s->pred_mean.ensure(sizeof(double) * (size_t)m * chunk));
+  HIPCHK(c, s->pred_var.ensure(sizeof(double) * (size_t)m * chunk));
+  if (out_cov) HIPCHK(c, s->pred_cov.ensure(sizeof(double) * (size_t)m * m * chunk));
+  if (mean_train && n > 0) {
+    HIPCHK(c, s->mu1.ensure(sizeof(double) * (size_t)n));
+    HIPCHK(c, hipMemcpyAsync(s->mu1.p, mean_train, sizeof(double) * n, hipMemcpyHostToDevice, st));
+  }
+  if (mean_pred) {
+    HIPCHK(c, s->mu2.ensure(sizeof(double) * (size_t)m));
+    HIPCHK(c, hipMemcpyAsync(s->mu2.p, mean_pred, sizeof(double) * m, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(c, hipMemcpyAsync(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr) * P, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->ops.p, bt.ops.data(), bt.ops.size(), hipMemcpyHostToDevice, st));
+  if (!bt.prm.empty())
+    HIPCHK(c, hipMemcpyAsync(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->noise.p, noise, sizeof(double) * P, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->noise_pred.p, npred.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->tt.p, tt.data(), sizeof(double) * ntot, hipMemcpyHostToDevice, st));
+
+  for (int p0 = 0; p0 < P; p0 += chunk) {
+    const int Pc = std::min(chunk, P - p0);
+    hipLaunchKernelGGL(k_init_vec, dim3((ntot + 255) / 256, Pc), dim3(256), 0, st, s->vec.as<double>(), ntot,
+                       Pc, c->d_xs, (mean_train && n > 0) ? s->mu1.as<double>() : (const double*)nullptr, (int)n,
+                       s->info.as<int>() + p0);
+    CovArgs cv;
+    cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n1_pad; cv.m2 = (int)m; cv.nt = nt;
+    cv.hdr = s->hdr.as<ProgHdr>() + p0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
+    cv.noise = s->noise.as<double>() + p0; cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = Pc;
+    HIPCHK(c, launch_cov(st, cv, ntiles, Pc, bt.max_cp, bt.max_depth));
+
+    CholArgs ca;
+    ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>();
+    ca.vec = s->vec.as<double>(); ca.ldv = ntot; ca.partial = s->partial.as<double>();
+    ca.info = s->info.as<int>() + p0; ca.P = Pc; ca.nt = nt; ca.k = 0; ca.nt1 = nt1;
+    HIPCHK(c, run_factor(st, ca, nt1, nullptr, nullptr));
+    {
+      // Schur complement of the prediction block + (-V^T alpha); with nt1 == 0 this just
+      // passes K22 through.
+      const int T = nt2 * (nt2 + 1) / 2;
+      const int Pg = (Pc + 7) / 8;
+      hipLaunchKernelGGL(k_chol_update<false>, dim3(8 * Pg * T), dim3(256), 0, st, ca);
+    }
+    PredArgs pa;
+    pa.A = s->A.as<double>(); pa.strideA = strideA; pa.vec = s->vec.as<double>(); pa.ldv = ntot;
+    pa.mu2 = mean_pred ? s->mu2.as<double>() : nullptr; pa.noise_pred = s->noise_pred.as<double>() + p0;
+    pa.nt1 = nt1; pa.n1_pad = n1_pad; pa.m = (int)m; pa.P = Pc;
+    pa.out_mean = s->pred_mean.as<double>(); pa.out_var = s->pred_var.as<double>();
+    pa.out_cov = out_cov ? s->pred_cov.as<double>() : nullptr;
+    const long long nel = out_cov ? (long long)m * m : (long long)m;
+    hipLaunchKernelGGL(k_pred_extract, dim3((unsigned)((nel + 255) / 256), Pc), dim3(256), 0, st, pa);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out_mean + (size_t)p0 * m, s->pred_mean.p, sizeof(double) * m * Pc, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(out_var + (size_t)p0 * m, s->pred_var.p, sizeof(double) * m * Pc, hipMemcpyDeviceToHost, st));
+    if (out_cov)
+      HIPCHK(c, hipMemcpyAsync(out_cov + (size_t)p0 * m * m, s->pred_cov.p, sizeof(double) * m * m * Pc, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
+  if (out_info) {
+    HIPCHK(c, hipMemcpyAsync(out_info, s->info.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int p = 0; p < P; ++p)
+      if (out_info[p] != 0) {
+        const double nanv = std::nan("");
+        for (int64_t g = 0; g < m; ++g) { out_mean[(size_t)p * m + g] = nanv; out_var[(size_t)p * m + g] = nanv; }
+      }
+  }
+  return AGP_OK;
+}
+
+int agp_cov_matrix(agp_ctx* c, const double* ts, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm,
+                   int32_t n_prm, double noise, double* out_K) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (n < 0) return fail(c, AGP_ERR_ARG, "negative size");
+  if (n == 0) return AGP_OK;
+  if (!ts || !ops || !out_K) return fail(c, AGP_ERR_ARG, "null pointer argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int32_t op_off[2] = {0, n_ops}, prm_off[2] = {0, n_prm};
+  double dummy = 0.0;
+  Batch bt;
+  int rc = compile_batch(c, 1, op_off, ops, prm_off, prm ? prm : &dummy, bt);
+  if (rc) return rc;
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+  const int n_pad = round_up(n, NB), nt = n_pad / NB, ntiles = nt * (nt + 1) / 2;
+  const long long strideA = (long long)ntiles * NB2;
+  std::vector<double> tt((size_t)n_pad, 0.0);
+  std::copy(ts, ts + n, tt.begin());
+  HIPCHK(c, s->A.ensure((size_t)strideA * 8));
+  HIPCHK(c, s->hdr.ensure(sizeof(ProgHdr)));
+  HIPCHK(c, s->ops.ensure(bt.ops.size()));
+  HIPCHK(c, s->prm.ensure(sizeof(double) * std::max<size_t>(1, bt.prm.size())));
+  HIPCHK(c, s->noise.ensure(sizeof(double)));
+  HIPCHK(c, s->tt.ensure(sizeof(double) * (size_t)n_pad));
+  HIPCHK(c, s->dense.ensure(sizeof(double) * (size_t)n * n));
+  HIPCHK(c, hipMemcpyAsync(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->ops.p, bt.ops.data(), bt.ops.size(), hipMemcpyHostToDevice, st));
+  if (!bt.prm.empty())
+    HIPCHK(c, hipMemcpyAsync(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->noise.p, &noise, sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->tt.p, tt.data(), sizeof(double) * n_pad, hipMemcpyHostToDevice, st));
+  CovArgs cv;
+  cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
+  cv.hdr = s->hdr.as<ProgHdr>(); cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
+  cv.noise = s->noise.as<double>(); cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = 1;
+  HIPCHK(c, launch_cov(st, cv, ntiles, 1, bt.max_cp, bt.max_depth));
+  const long long nel = (long long)n * n;
+  hipLaunchKernelGGL(k_unpack_dense, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, s->A.as<double>(),
+                     (int)n, 0, s->dense.as<double>());
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out_K, s->dense.p, sizeof(double) * nel, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return AGP_OK;
+}
+
+int agp_debug_cholesky(agp_ctx* c, const double* K, int64_t n, double* out_L, int32_t* out_info) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (n <= 0 || !K || !out_L) return fail(c, AGP_ERR_ARG, "bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+  const int n_pad = round_up(n, NB), nt = n_pad / NB, ntiles = nt * (nt + 1) / 2;
+  const long long strideA = (long long)ntiles * NB2;
+  const long long nel = (long long)n * n;
+  HIPCHK(c, s->A.ensure((size_t)strideA * 8));
+  HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256));
+  HIPCHK(c, s->vec.ensure(sizeof(double) * (size_t)n_pad));
+  HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt));
+  HIPCHK(c, s->info.ensure(sizeof(int)));
+  HIPCHK(c, s->dense.ensure(sizeof(double) * (size_t)nel));
+  HIPCHK(c, hipMemcpyAsync(s->dense.p, K, sizeof(double) * nel, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(s->vec.p, 0, sizeof(double) * n_pad, st));
+  HIPCHK(c, hipMemsetAsync(s->info.p, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_pack_dense, dim3((unsigned)((strideA + 255) / 256)), dim3(256), 0, st, s->dense.as<double>(),
+                     (int)n, nt, s->A.as<double>());
+  CholArgs ca;
+  ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>(); ca.vec = s->vec.as<double>();
+  ca.ldv = n_pad; ca.partial = s->partial.as<double>(); ca.info = s->info.as<int>(); ca.P = 1; ca.nt = nt;
+  ca.k = 0; ca.nt1 = nt;
+  HIPCHK(c, run_factor(st, ca, nt, nullptr, nullptr));
+  hipLaunchKernelGGL(k_unpack_dense, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, s->A.as<double>(),
+                     (int)n, 1, s->dense.as<double>());
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out_L, s->dense.p, sizeof(double) * nel, hipMemcpyDeviceToHost, st));
+  if (out_info) HIPCHK(c, hipMemcpyAsync(out_info, s->info.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return AGP_OK;
+}
+
+int agp_debug_mfma_probe(agp_ctx* c, const double* A, const double* B, double* D) {
+  if (!c || !A || !B || !D) return fail(c, AGP_ERR_ARG, "null pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  double *dA = nullptr, *dB = nullptr, *dD = nullptr;
+  HIPCHK(c, hipMalloc((void**)&dA, 64 * 8));
+  HIPCHK(c, hipMalloc((void**)&dB, 64 * 8));
+  HIPCHK(c, hipMalloc((void**)&dD, 256 * 8));
+  HIPCHK(c, hipMemcpy(dA, A, 64 * 8, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dB, B, 64 * 8, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_mfma_probe, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpy(D, dD, 256 * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
+  return AGP_OK;
+}
+
+}  // extern "C"

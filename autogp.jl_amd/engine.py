@@ -1,0 +1,299 @@
+"""ctypes binding of the C ABI (include/autogp_hip.h) + the call sites of the reference that
+it replaces, under the reference's own names:
+
+  compute_cov_matrix_vectorized(node, noise, ts)          src/GP.jl:666-668
+  eval_cov(node, ts)                                      src/GP.jl:54-61
+  mvnormal_logpdf / GPEngine.logpdf_batch                 src/Model.jl:134-136 (xs ~ mvnormal(0, K))
+  MvNormal(node, noise, ts, xs, ts_pred; noise_pred, mean) src/GP.jl:731-758
+  quantile(dist, p)                                       src/GP.jl:1006-1012
+
+There is NO CPU fallback: if the HIP library is missing, or no gfx950 device is visible,
+construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+from . import gp as _gp
+
+_PKG_DIR = Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / "lib" / "libautogp_hip.so"
+
+EXPORTED_SYMBOLS = [
+    "agp_init", "agp_destroy", "agp_last_error", "agp_version", "agp_set_data", "agp_logpdf",
+    "agp_logpdf_batch", "agp_logpdf_batch_device", "agp_predict_batch", "agp_cov_matrix",
+    "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_set_profiling", "agp_get_timing",
+    "agp_set_workspace_limit",
+]
+
+
+class AGPError(RuntimeError):
+    pass
+
+
+class PosDefException(ArithmeticError):
+    """Mirror of LinearAlgebra.PosDefException raised by the reference on a non-PD matrix."""
+
+    def __init__(self, info, particle=None):
+        where = "" if particle is None else f" (particle {particle})"
+        super().__init__(f"matrix is not positive definite; Cholesky factorization failed at minor {info}{where}")
+        self.info = int(info)
+        self.particle = particle
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the engine. Raises AGPError (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise AGPError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(str(p))
+    dp, ip, u8p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+    vp = C.c_void_p
+    lib.agp_init.argtypes = [C.POINTER(vp), C.c_int]; lib.agp_init.restype = C.c_int
+    lib.agp_destroy.argtypes = [vp]; lib.agp_destroy.restype = None
+    lib.agp_last_error.argtypes = [vp]; lib.agp_last_error.restype = C.c_char_p
+    lib.agp_version.argtypes = []; lib.agp_version.restype = C.c_char_p
+    lib.agp_set_data.argtypes = [vp, dp, dp, C.c_int64]; lib.agp_set_data.restype = C.c_int
+    lib.agp_logpdf.argtypes = [vp, C.c_int64, u8p, C.c_int32, dp, C.c_int32, C.c_double, dp, ip]
+    lib.agp_logpdf.restype = C.c_int
+    lib.agp_logpdf_batch.argtypes = [vp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, ip]
+    lib.agp_logpdf_batch.restype = C.c_int
+    lib.agp_logpdf_batch_device.argtypes = [vp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, vp, vp, vp]
+    lib.agp_logpdf_batch_device.restype = C.c_int
+    lib.agp_predict_batch.argtypes = [vp, C.c_int64, dp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, dp, dp,
+                                      dp, dp, dp, ip]
+    lib.agp_predict_batch.restype = C.c_int
+    lib.agp_cov_matrix.argtypes = [vp, dp, C.c_int64, u8p, C.c_int32, dp, C.c_int32, C.c_double, dp]
+    lib.agp_cov_matrix.restype = C.c_int
+    lib.agp_debug_cholesky.argtypes = [vp, dp, C.c_int64, dp, ip]; lib.agp_debug_cholesky.restype = C.c_int
+    lib.agp_debug_mfma_probe.argtypes = [vp, dp, dp, dp]; lib.agp_debug_mfma_probe.restype = C.c_int
+    lib.agp_set_profiling.argtypes = [vp, C.c_int]; lib.agp_set_profiling.restype = C.c_int
+    lib.agp_get_timing.argtypes = [vp, dp, C.c_int32]; lib.agp_get_timing.restype = C.c_int
+    lib.agp_set_workspace_limit.argtypes = [vp, C.c_int64]; lib.agp_set_workspace_limit.restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32)) if a is not None else None
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class GPEngine:
+    """One engine context per GPU (the C ABI's agp_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        rc = self._lib.agp_init(C.byref(self._ctx), int(device))
+        if rc != 0:
+            msg = self._lib.agp_last_error(None)
+            raise AGPError(f"agp_init failed ({rc}): {msg.decode() if msg else ''}")
+        self.device = int(device)
+        self.n_max = 0
+
+    # -- lifetime --------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            self._lib.agp_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.agp_last_error(self._ctx)
+            raise AGPError(f"engine call failed ({rc}): {msg.decode() if msg else ''}")
+
+    @property
+    def version(self):
+        return self._lib.agp_version().decode()
+
+    # -- data ------------------------------------------------------------------------------
+    def set_data(self, ts, xs):
+        ts, xs = _f64(ts), _f64(xs)
+        if ts.shape != xs.shape or ts.ndim != 1:
+            raise ValueError("ts and xs must be equal-length vectors")
+        self._check(self._lib.agp_set_data(self._ctx, _dp(ts), _dp(xs), ts.shape[0]))
+        self.n_max = ts.shape[0]
+
+    # -- value path (src/Model.jl:135-136) ---------------------------------------------------
+    def logpdf(self, node, noise, n=None, check=True):
+        ops, prm = _gp.encode(node)
+        n = self.n_max if n is None else int(n)
+        out = C.c_double(); info = C.c_int32()
+        prm_arg = prm if prm.size else np.zeros(1)
+        self._check(self._lib.agp_logpdf(self._ctx, n, _u8(ops), ops.size, _dp(prm_arg), prm.size, float(noise),
+                                         C.byref(out), C.byref(info)))
+        if check and info.value > 0:
+            raise PosDefException(info.value)
+        return out.value
+
+    def logpdf_batch(self, nodes, noises, n=None, check=True, programs=None):
+        """log N(xs[1:n]; 0, K_p + noise_p I) for every particle p.  Returns (logpdf[P], info[P])."""
+        n = self.n_max if n is None else int(n)
+        op_off, ops, prm_off, prm = programs if programs is not None else _gp.encode_batch(nodes)
+        P = op_off.shape[0] - 1
+        noises = _f64(noises)
+        if noises.shape != (P,):
+            raise ValueError("one noise per particle required")
+        out = np.empty(P, dtype=np.float64); info = np.empty(P, dtype=np.int32)
+        self._check(self._lib.agp_logpdf_batch(self._ctx, n, P, _ip(op_off), _u8(ops), _ip(prm_off), _dp(prm),
+                                               _dp(noises), _dp(out), _ip(info)))
+        if check and (info > 0).any():
+            p = int(np.argmax(info > 0))
+            raise PosDefException(int(info[p]), p)
+        return out, info
+
+    def logpdf_batch_device(self, programs, noises, n, d_out_ptr, d_info_ptr, stream_ptr=0):
+        """Results stay in device memory (raw pointers, e.g. torch tensors' data_ptr())."""
+        op_off, ops, prm_off, prm = programs
+        P = op_off.shape[0] - 1
+        noises = _f64(noises)
+        self._check(self._lib.agp_logpdf_batch_device(self._ctx, int(n), P, _ip(op_off), _u8(ops), _ip(prm_off),
+                                                      _dp(prm), _dp(noises), C.c_void_p(d_out_ptr),
+                                                      C.c_void_p(d_info_ptr), C.c_void_p(stream_ptr)))
+
+    # -- predictive path (src/GP.jl:731-758) -------------------------------------------------
+    def predict_batch(self, nodes, noises, ts_pred, n=None, noise_pred=None, mean_train=None, mean_pred=None,
+                      want_cov=False, check=True):
+        n = self.n_max if n is None else int(n)
+        op_off, ops, prm_off, prm = _gp.encode_batch(nodes)
+        P = op_off.shape[0] - 1
+        noises = _f64(noises); ts_pred = _f64(ts_pred); m = ts_pred.shape[0]
+        npred = None if noise_pred is None else _f64(np.broadcast_to(noise_pred, (P,)))
+        mt = None if mean_train is None else _f64(mean_train)
+        mp_ = None if mean_pred is None else _f64(mean_pred)
+        mean = np.empty((P, m)); var = np.empty((P, m))
+        cov = np.empty((P, m, m)) if want_cov else None
+        info = np.zeros(P, dtype=np.int32)
+        self._check(self._lib.agp_predict_batch(self._ctx, n, _dp(ts_pred), m, P, _ip(op_off), _u8(ops),
+                                                _ip(prm_off), _dp(prm), _dp(noises), _dp(npred), _dp(mt), _dp(mp_),
+                                                _dp(mean), _dp(var), _dp(cov), _ip(info)))
+        if check and (info > 0).any():
+            p = int(np.argmax(info > 0))
+            raise PosDefException(int(info[p]), p)
+        return mean, var, cov, info
+
+    # -- matrix assembly (src/GP.jl:666-668) -------------------------------------------------
+    def cov_matrix(self, node, noise, ts):
+        ts = _f64(ts); n = ts.shape[0]
+        ops, prm = _gp.encode(node)
+        out = np.empty((n, n), dtype=np.float64, order="F")
+        prm_arg = prm if prm.size else np.zeros(1)
+        self._check(self._lib.agp_cov_matrix(self._ctx, _dp(ts), n, _u8(ops), ops.size, _dp(prm_arg), prm.size,
+                                             float(noise), _dp(out)))
+        return np.asarray(out)
+
+    # -- measurement / debug hooks -----------------------------------------------------------
+    def debug_cholesky(self, K):
+        K = np.asfortranarray(np.asarray(K, dtype=np.float64)); n = K.shape[0]
+        L = np.empty((n, n), dtype=np.float64, order="F"); info = C.c_int32()
+        self._check(self._lib.agp_debug_cholesky(self._ctx, _dp(K), n, _dp(L), C.byref(info)))
+        return np.asarray(L), info.value
+
+    def debug_mfma_probe(self, A, B):
+        A = _f64(A).reshape(16, 4); B = _f64(B).reshape(4, 16); D = np.empty((16, 16))
+        self._check(self._lib.agp_debug_mfma_probe(self._ctx, _dp(A), _dp(B), _dp(D)))
+        return D
+
+    def set_profiling(self, on: bool):
+        self._check(self._lib.agp_set_profiling(self._ctx, 1 if on else 0))
+
+    def timing(self):
+        out = np.zeros(8)
+        self._check(self._lib.agp_get_timing(self._ctx, _dp(out), 8))
+        keys = ["total_ms", "cov_build_ms", "chol_update_ms", "chol_trsm_ms", "finish_ms", "n_update_launches",
+                "n_trsm_launches", "h2d_ms"]
+        return dict(zip(keys, out.tolist()))
+
+    def set_workspace_limit(self, nbytes: int):
+        self._check(self._lib.agp_set_workspace_limit(self._ctx, int(nbytes)))
+
+
+# ------------------------------------------------------------------------------------------
+# module-level functions with the reference's names; they use a lazily created default engine
+# ------------------------------------------------------------------------------------------
+_default_engine = None
+
+
+def default_engine() -> GPEngine:
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = GPEngine(int(os.environ.get("AGP_DEVICE", "0")))
+    return _default_engine
+
+
+def compute_cov_matrix_vectorized(node, noise, ts, engine=None):
+    """K = eval_cov(node, ts) + noise*I  (src/GP.jl:666-668), evaluated on the GPU."""
+    return (engine or default_engine()).cov_matrix(node, noise, ts)
+
+
+def eval_cov(node, ts, engine=None):
+    """eval_cov(node, ts::Vector{Float64}) (src/GP.jl:55), evaluated on the GPU."""
+    return (engine or default_engine()).cov_matrix(node, 0.0, ts)
+
+
+def mvnormal_logpdf(node, noise, ts, xs, engine=None):
+    """Score of `xs ~ mvnormal(zeros(n), compute_cov_matrix_vectorized(node, noise, ts))`
+    (src/Model.jl:135-136).  Raises PosDefException like the reference."""
+    eng = engine or default_engine()
+    eng.set_data(ts, xs)
+    return eng.logpdf(node, noise)
+
+
+class MvNormal:
+    """Posterior predictive of src/GP.jl:731-758 (mean / cov of Distributions.MvNormal)."""
+
+    def __init__(self, node, noise, ts, xs, ts_pred, noise_pred=None, mean=None, engine=None):
+        eng = engine or default_engine()
+        ts = _f64(ts); xs = _f64(xs); ts_pred = _f64(ts_pred)
+        eng.set_data(ts, xs)
+        mt = mp_ = None
+        if mean is not None:
+            mt = np.array([mean(t) for t in ts], dtype=np.float64)
+            mp_ = np.array([mean(t) for t in ts_pred], dtype=np.float64)
+        mu, var, cov, _ = eng.predict_batch([node], [noise], ts_pred, noise_pred=noise_pred, mean_train=mt,
+                                            mean_pred=mp_, want_cov=True)
+        self.mu, self.var, self.Sigma = mu[0], var[0], cov[0]
+
+    def mean(self):
+        return self.mu
+
+    def cov(self):
+        return self.Sigma
+
+
+def quantile(dist: MvNormal, p):
+    """Marginal quantiles mu + sqrt(diag(cov)) * Phi^-1(p): m x len(p)  (src/GP.jl:1006-1012)."""
+    from statistics import NormalDist
+    p = np.atleast_1d(np.asarray(p, dtype=np.float64))
+    z = np.array([NormalDist().inv_cdf(float(v)) for v in p])
+    return dist.mu[:, None] + np.sqrt(dist.var)[:, None] * z[None, :]

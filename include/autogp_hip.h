@@ -1,0 +1,140 @@
+/*
+ * autogp_hip.h — C ABI of the MI355X-native GP marginal-likelihood engine.
+ *
+ * Drop-in boundary for the hot path of probsys/AutoGP.jl (reference paths are
+ * relative to the upstream repo):
+ *
+ *   value path       src/Model.jl:134-136   noise+JITTER, GP.compute_cov_matrix_vectorized,
+ *                                           xs ~ mvnormal(zeros(n), K)  (Cholesky/logdet/solve
+ *                                           happen inside Gen/Distributions/PDMats -> dpotrf)
+ *   matrix assembly  src/GP.jl:666-668      eval_cov(node, ts) + noise*I
+ *   predictive path  src/GP.jl:731-758      Distributions.MvNormal(node, noise, ts, xs, ts_pred;
+ *                                           noise_pred, mean), called from
+ *                                           src/inference_utils.jl:174-196
+ *
+ * The reference has no FFI for this path (it is pure Julia); these entry points are what a
+ * `ccall` shim replacing those two call sites binds.  Plain pointers and
+ * sizes only; all arrays are Julia-native: column-major, Float64 / Int32 / UInt8.
+ *
+ * Kernel program encoding (one per particle): POSTFIX over the kernel tree, i.e. the order of
+ * `unroll(node)` (src/GP.jl:112-113: left, right, node).  Opcodes are the GPConfig node codes
+ * (src/GP.jl:1101-1108) plus 0 for WhiteNoise:
+ *     0 WhiteNoise{value}                         (src/GP.jl:131-140)
+ *     1 Constant{value}                           (src/GP.jl:157-166)
+ *     2 Linear{intercept,bias,amplitude}          (src/GP.jl:185-203)
+ *     3 SquaredExponential{lengthscale,amplitude} (src/GP.jl:228-245)
+ *     4 GammaExponential{lengthscale,gamma,amplitude} (src/GP.jl:269-289)
+ *     5 Periodic{lengthscale,period,amplitude}    (src/GP.jl:315-336)
+ *     6 Plus   7 Times                            (src/GP.jl:358-377, 404-423)
+ *     8 ChangePoint{location,scale}               (src/GP.jl:466-503)
+ * Parameters are the TRANSFORMED values in struct-field order, concatenated in program order
+ * (ChangePoint contributes location, scale at its own position).
+ *
+ * Error convention: every call returns 0 on success, <0 on API/HIP failure (text via
+ * agp_last_error).  Numerical failure is per particle, LAPACK dpotrf style:
+ * out_info[p] = k > 0  => leading minor k is not positive definite, out_logpdf[p] = NaN
+ * (the Julia shim rethrows LinearAlgebra.PosDefException(k), reproducing the reference's
+ * abort-on-non-PD behaviour).  n = 0 => logpdf = 0, info = 0
+ * (src/inference_smc_anneal_data.jl:185-187 initialises the particle filter on 0 points).
+ *
+ * Threading: agp_logpdf / agp_logpdf_batch / agp_predict_batch / agp_cov_matrix are safe for
+ * concurrent callers on one context (one call per Julia `Threads.@threads` iteration,
+ * src/inference_smc_anneal_data.jl:133,240); each call takes a private stream+workspace slot.
+ * agp_init / agp_destroy / agp_set_data are called from one thread between parallel regions.
+ *
+ * Ownership: the caller owns every host buffer; the library copies what it needs before
+ * returning and owns all device memory.
+ */
+#ifndef AUTOGP_HIP_H
+#define AUTOGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct agp_ctx agp_ctx;
+
+#define AGP_OK               0
+#define AGP_ERR_ARG         -1
+#define AGP_ERR_HIP         -2
+#define AGP_ERR_PROGRAM     -3   /* malformed postfix program / unsupported tree shape */
+#define AGP_ERR_NODATA      -4
+
+#define AGP_MAX_OPS        255   /* nodes per kernel tree (depth-6 full tree = 63) */
+
+/* One context per GPU (one process per GPU in the multi-GPU deployment). */
+int  agp_init(agp_ctx** out, int device_id);
+void agp_destroy(agp_ctx* ctx);
+const char* agp_last_error(agp_ctx* ctx);
+const char* agp_version(void);
+
+/* Upload the (already rescaled) observations once; later calls use the prefix n <= n_max —
+ * the data-annealing schedule evaluates on ts[1:step] (src/inference_smc_anneal_data.jl:206-217). */
+int agp_set_data(agp_ctx* ctx, const double* ts, const double* xs, int64_t n_max);
+
+/* Single particle — what Gen's interpreter calls at src/Model.jl:135-136.  Re-entrant. */
+int agp_logpdf(agp_ctx* ctx, int64_t n,
+               const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
+               double noise, double* out_logpdf, int32_t* out_info);
+
+/* P particles in one sweep.  op_off / prm_off have P+1 entries (CSR offsets into ops / prm).
+ * noise[p] is the value after `transform_param(:noise, z) + JITTER` (src/Model.jl:134). */
+int agp_logpdf_batch(agp_ctx* ctx, int64_t n, int32_t P,
+                     const int32_t* op_off, const uint8_t* ops,
+                     const int32_t* prm_off, const double* prm,
+                     const double* noise,
+                     double* out_logpdf /* P */, int32_t* out_info /* P */);
+
+/* Same sweep, results left in DEVICE memory (d_out_logpdf: P doubles, d_out_info: P int32,
+ * both device pointers) and enqueued on `hip_stream` (a hipStream_t; NULL = the slot's own
+ * stream, synchronised before return).  This is the entry the multi-GPU driver uses so that the
+ * log-weight all-gather (src/inference_smc_anneal_data.jl:22-31,232) consumes device buffers. */
+int agp_logpdf_batch_device(agp_ctx* ctx, int64_t n, int32_t P,
+                            const int32_t* op_off, const uint8_t* ops,
+                            const int32_t* prm_off, const double* prm,
+                            const double* noise,
+                            double* d_out_logpdf, int32_t* d_out_info, void* hip_stream);
+
+/* Posterior predictive of src/GP.jl:731-758 for P particles on the resident (ts, xs)[1:n].
+ * mean_train (n) / mean_pred (m) are the values of the `mean` function (NULL = 0).
+ * noise_pred may be NULL (= noise, src/GP.jl:739).  out_mean, out_var: m x P column-major;
+ * out_cov: m x m x P (each slice symmetric) or NULL.  out_var = diag(out_cov) — the only part
+ * Distributions.quantile consumes (src/GP.jl:1006-1012). */
+int agp_predict_batch(agp_ctx* ctx, int64_t n, const double* ts_pred, int64_t m, int32_t P,
+                      const int32_t* op_off, const uint8_t* ops,
+                      const int32_t* prm_off, const double* prm,
+                      const double* noise, const double* noise_pred,
+                      const double* mean_train, const double* mean_pred,
+                      double* out_mean, double* out_var, double* out_cov,
+                      int32_t* out_info);
+
+/* compute_cov_matrix_vectorized(node, noise, ts) (src/GP.jl:666-668) on explicit ts:
+ * out_K is n x n column-major (full symmetric).  Parity / debugging entry. */
+int agp_cov_matrix(agp_ctx* ctx, const double* ts, int64_t n,
+                   const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
+                   double noise, double* out_K);
+
+/* ---- measurement / debugging hooks (not part of the reference surface) ---- */
+
+/* Factor a caller-supplied dense SPD matrix (n x n column-major) with the device Cholesky;
+ * out_L receives the lower factor (n x n column-major, upper part zero). */
+int agp_debug_cholesky(agp_ctx* ctx, const double* K, int64_t n, double* out_L, int32_t* out_info);
+
+/* Probe of the fp64 MFMA fragment layout: D = A(16x4) * B(4x16), row-major host arrays. */
+int agp_debug_mfma_probe(agp_ctx* ctx, const double* A, const double* B, double* D);
+
+/* When enabled, batch calls bracket their phases with HIP events on the launch stream.
+ * agp_get_timing fills out[0..7] = { total_ms, cov_build_ms, chol_update_ms, chol_trsm_ms,
+ * finish_ms, n_update_launches, n_trsm_launches, h2d_d2h_ms } for the last batch call. */
+int agp_set_profiling(agp_ctx* ctx, int enabled);
+int agp_get_timing(agp_ctx* ctx, double* out, int32_t n_out);
+
+/* Cap (bytes) on matrix workspace per call; larger batches are processed in chunks. 0 = default. */
+int agp_set_workspace_limit(agp_ctx* ctx, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUTOGP_HIP_H */
