@@ -1,0 +1,361 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X).  Every call goes through the C ABI
+(include/autogp_hip.h) via ctypes; the oracle is only the checker.
+
+Tolerances (fp64, stated by BASELINE.json / SURVEY.md §8c):
+    logpdf            |gpu - ref| <= 1e-8 * max(1, |ref|)
+    predictive        |gpu - ref|_inf <= 1e-8 * max(1, |ref|_inf)
+    covariance entry  |gpu - ref| <= 1e-13 * max(1, |K|_inf)   (few ulp of exp/sin/pow argument error)
+"""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+from conftest import to_tuple
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LP_TOL = 1e-8
+K_TOL = 1e-13
+
+
+def lp_err(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+def base_kernels(G):
+    return [G.WhiteNoise(1), G.Constant(0.5), G.Linear(0.1, 1.3, 0.7), G.SquaredExponential(0.47, 0.13),
+            G.GammaExponential(0.42, 0.58, 3.2), G.Periodic(0.96, 0.21, 1.1)]      # test/test_GP.jl:24-33
+
+
+# ---------------------------------------------------------------------------------------------
+def test_native_library_loaded(pkg, engine):
+    """The HIP extension is what runs: the .so is mapped in this process and reports gfx950."""
+    assert "gfx950" in engine.version
+    maps = open("/proc/self/maps").read()
+    assert "libautogp_hip.so" in maps
+
+
+def test_mfma_f64_layout(engine):
+    """A=asymmetric probe of v_mfma_f64_16x16x4: C/D row = 4*reg + lane/16, col = lane%16."""
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((16, 4)); B = rng.standard_normal((4, 16))
+    assert np.allclose(engine.debug_mfma_probe(A, B), A @ B, rtol=0, atol=1e-14)
+
+
+def test_cov_matrix_fixture_kernels(pkg, engine):
+    """eval_cov / compute_cov_matrix_vectorized for the six fixture kernels and all 6x6x3 composites
+    on range(-10,10,100) scaled and raw (test/test_GP.jl:35-68 uses both spaces)."""
+    G = pkg
+    raw = np.linspace(-10, 10, 100)
+    scaled = (raw - raw.min()) / (raw.max() - raw.min())
+    base = base_kernels(G)
+    kernels = list(base)
+    for x in base:
+        for y in base:
+            kernels += [x + y, x * y, G.ChangePoint(x, y, 0.5, 0.95)]
+    worst = 0.0
+    for ts in (scaled, raw):
+        for k in kernels:
+            Kd = engine.cov_matrix(k, 0.37, ts)
+            Ko = O.compute_cov_matrix_vectorized(k.to_tuple(), 0.37, ts)
+            err = np.abs(Kd - Ko).max() / max(1.0, np.abs(Ko).max())
+            worst = max(worst, err)
+            assert err <= K_TOL, (k, err)
+            assert np.array_equal(Kd, Kd.T)
+    # scalar twin (src/GP.jl:674-684) on a subset
+    for k in kernels[::7]:
+        Kd = engine.cov_matrix(k, 0.1, scaled[:40])
+        assert np.allclose(Kd, O.compute_cov_matrix(k.to_tuple(), 0.1, scaled[:40]), rtol=1e-13, atol=1e-14)
+
+
+def test_cov_matrix_edge_cases(pkg, engine):
+    G = pkg
+    # duplicate time points with WhiteNoise (src/GP.jl:137-140), ts outside [0,1] (add_data!), n = 1, 2, 129
+    ts = np.array([0.3, 0.3, -0.5, 1.7, 0.3, 0.9])
+    k = G.WhiteNoise(0.8) + G.SquaredExponential(0.2, 1.5)
+    assert np.allclose(engine.cov_matrix(k, 0.05, ts), O.compute_cov_matrix_vectorized(k.to_tuple(), 0.05, ts), atol=1e-15)
+    for n in (1, 2, 127, 128, 129, 257):
+        t = np.linspace(0, 1, n) if n > 1 else np.array([0.4])
+        k = G.ChangePoint(G.GammaExponential(0.1, 2.0, 1.0), G.Periodic(0.3, 0.1, 2.0), 0.5, 0.001)   # tanh saturates
+        Kd = engine.cov_matrix(k, 1e-5, t)
+        assert np.abs(Kd - O.compute_cov_matrix_vectorized(k.to_tuple(), 1e-5, t)).max() <= K_TOL * max(1, np.abs(Kd).max())
+    # Int-typed parameters (test/test_GP.jl:109)
+    assert np.allclose(engine.cov_matrix(G.Linear(1), 0, np.array([0., 1., 2.])),
+                       O.compute_cov_matrix_vectorized(("LIN", 1, 1, 1), 0, np.array([0., 1., 2.])))
+
+
+def test_deep_trees_and_stack_reordering(pkg, engine):
+    """Right-deep chains (worst case for a naive postfix stack) and a full depth-6 tree."""
+    G = pkg
+    ts = np.linspace(0, 1, 150)
+    leafs = base_kernels(G)[1:]
+    chain = leafs[0]
+    for i in range(1, 40):                      # right-deep: Strahler number 2, naive stack depth 40
+        chain = (leafs[i % 5] + chain) if i % 2 else (leafs[i % 5] * chain)
+    Kd = engine.cov_matrix(chain, 0.1, ts)
+    Ko = O.compute_cov_matrix_vectorized(chain.to_tuple(), 0.1, ts)
+    assert np.abs(Kd - Ko).max() <= 1e-12 * np.abs(Ko).max()
+
+    def full(d, i=0):
+        if d == 1:
+            return leafs[i % 5]
+        l, r = full(d - 1, 2 * i + 1), full(d - 1, 2 * i + 2)
+        return G.ChangePoint(l, r, 0.3 + 0.05 * d, 0.01 * d) if d >= 5 else (l + r if (d + i) % 2 else l * r)
+    k = full(6)                                  # 63 nodes, 32 leaves, needs the depth-8 stack kernel
+    assert k.size() == 63
+    Kd = engine.cov_matrix(k, 0.1, ts)
+    Ko = O.compute_cov_matrix_vectorized(k.to_tuple(), 0.1, ts)
+    assert np.abs(Kd - Ko).max() <= 1e-12 * max(1.0, np.abs(Ko).max())
+
+
+def test_golden_vectors_logpdf_and_predictive(pkg, engine, golden):
+    """All committed golden vectors through agp_logpdf_batch / agp_predict_batch."""
+    G = pkg
+    from collections import defaultdict
+    groups = defaultdict(list)
+    for c in golden["cases"]:
+        groups[(tuple(c["ts"]), tuple(c["xs"]))].append(c)
+    n_checked = 0
+    for (ts, xs), cases in groups.items():
+        ts = np.array(ts); xs = np.array(xs)
+        engine.set_data(ts, xs)
+        nodes = [G.from_tuple(to_tuple(c["tree"])) for c in cases]
+        noises = np.array([c["noise"] for c in cases])
+        lp, info = engine.logpdf_batch(nodes, noises)
+        ref = np.array([c["logpdf"] for c in cases])
+        assert (info == 0).all()
+        err = lp_err(lp, ref)
+        assert err.max() <= LP_TOL, (cases[int(err.argmax())]["name"], err.max())
+        for c, v in zip(cases, lp):
+            if "logpdf_mp" in c:
+                assert abs(v - float(c["logpdf_mp"])) <= LP_TOL * max(1.0, abs(v)), c["name"]
+        # predictive, grouped by identical query set
+        pg = defaultdict(list)
+        for c, nd in zip(cases, nodes):
+            if "ts_pred" in c:
+                pg[tuple(c["ts_pred"])].append((c, nd))
+        for tp, items in pg.items():
+            tp = np.array(tp)
+            mean, var, _, info = engine.predict_batch([nd for _, nd in items], [c["noise"] for c, _ in items], tp)
+            for i, (c, _) in enumerate(items):
+                mu_ref = np.array(c["pred_mean"]); var_ref = np.array(c["pred_var"])
+                assert np.abs(mean[i] - mu_ref).max() <= LP_TOL * max(1.0, np.abs(mu_ref).max()), c["name"]
+                assert np.abs(var[i] - var_ref).max() <= LP_TOL * max(1.0, np.abs(var_ref).max()), c["name"]
+                q = mean[i][:, None] + np.sqrt(var[i])[:, None] * O.ndtri(np.array([0.025, 0.5, 0.975]))[None, :]
+                assert np.abs(q - np.array(c["pred_q"])).max() <= LP_TOL * max(1.0, np.abs(q).max()), c["name"]
+        n_checked += len(cases)
+    assert n_checked == golden["n_cases"]
+
+
+@pytest.mark.parametrize("n,P,max_depth", [(1, 4, 2), (2, 4, 2), (17, 6, 3), (127, 8, 3), (128, 8, 3), (129, 8, 3),
+                                            (256, 8, 3), (700, 12, 4), (1024, 16, 3)])
+def test_logpdf_batch_vs_oracle(pkg, engine, n, P, max_depth):
+    """Seeded prior particles; sizes cover n=1,2, tile boundaries, config 1 (256) and config 2 (1024)."""
+    ts, xs = pkg.prior.synthetic_series(max(n, 2), seed=n, shuffle=(n % 2 == 0))
+    ts, xs = ts[:n], xs[:n]
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(n), P, max_depth=max_depth)
+    engine.set_data(ts, xs)
+    lp, info = engine.logpdf_batch(nodes, noises)
+    ref = np.array([O.gp_logpdf(nd.to_tuple(), float(nz), ts, xs) for nd, nz in zip(nodes, noises)])
+    assert (info == 0).all()
+    assert lp_err(lp, ref).max() <= LP_TOL
+    # single-particle entry (what Gen calls) agrees with the batch entry bit for bit
+    one = engine.logpdf(nodes[0], float(noises[0]))
+    assert one == lp[0]
+
+
+def test_config1_se_plus_linear(pkg, engine):
+    """BASELINE config 1: n=256, 8 particles, fixed SE+Linear kernel."""
+    G = pkg
+    ts, xs = pkg.prior.synthetic_series(256, seed=161)
+    rng = np.random.default_rng(161)
+    nodes = [G.SquaredExponential(*np.exp(-1.5 + rng.standard_normal(2))) + G.Linear(*np.exp(-1.5 + rng.standard_normal(3)))
+             for _ in range(8)]
+    noises = np.exp(-1.5 + rng.standard_normal(8)) + 1e-5
+    engine.set_data(ts, xs)
+    lp, info = engine.logpdf_batch(nodes, noises)
+    ref = np.array([O.gp_logpdf(nd.to_tuple(), float(nz), ts, xs) for nd, nz in zip(nodes, noises)])
+    assert (info == 0).all() and lp_err(lp, ref).max() <= LP_TOL
+    tp = np.concatenate([ts, np.linspace(1.0, 1.2, 44)])
+    mean, var, _, _ = engine.predict_batch(nodes, noises, tp)
+    for i in range(8):
+        mu, cov = O.predict_mvn(nodes[i].to_tuple(), float(noises[i]), ts, xs, tp)
+        assert np.abs(mean[i] - mu).max() <= LP_TOL * max(1.0, np.abs(mu).max())
+        assert np.abs(var[i] - np.diag(cov)).max() <= LP_TOL * max(1.0, np.abs(cov).max())
+
+
+def test_annealing_prefixes_and_n0(pkg, engine):
+    """Data-annealing evaluates on ts[1:step] of the resident data (src/inference_smc_anneal_data.jl:206-217);
+    n = 0 returns 0 (ibid. :185-187)."""
+    ts, xs = pkg.prior.synthetic_series(600, seed=9, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(9), 6, max_depth=3)
+    engine.set_data(ts, xs)
+    for n in [0] + pkg.schedule.linear_schedule(600, 0.2):
+        lp, info = engine.logpdf_batch(nodes, noises, n=n)
+        ref = np.array([O.gp_logpdf(nd.to_tuple(), float(nz), ts[:n], xs[:n]) for nd, nz in zip(nodes, noises)])
+        assert lp_err(lp, ref).max() <= LP_TOL, n
+    with pytest.raises(pkg.AGPError):
+        engine.logpdf_batch(nodes, noises, n=601)
+
+
+def test_predictive_shapes_and_mean_function(pkg, engine):
+    """m > n with queries duplicating the training times (the usual API call, src/api.jl:497-522),
+    m < n, n = 0, noise_pred = 0 and a non-zero mean function (test/test_api.jl:62-69)."""
+    G = pkg
+    k = G.Linear(0.3, 0.2, 0.5) + G.Periodic(0.4, 0.25, 0.6) * G.SquaredExponential(0.5, 1.0)
+    for n, tp in ((50, np.linspace(0, 1.2, 30)), (128, None), (200, None), (0, np.linspace(0, 1, 40)), (300, np.array([0.5]))):
+        ts, xs = pkg.prior.synthetic_series(max(n, 2), seed=5 + n)
+        ts, xs = ts[:n], xs[:n]
+        if tp is None:
+            tp = np.concatenate([ts, np.linspace(1.0, 1.3, n // 2 + 7)])
+        engine.set_data(ts, xs)
+        for npred, meanf in ((None, None), (0.0, None), (None, lambda t: 0.3 + 0.1 * t)):
+            mt = None if meanf is None else np.array([meanf(t) for t in ts])
+            mp_ = None if meanf is None else np.array([meanf(t) for t in tp])
+            mean, var, cov, info = engine.predict_batch([k], [0.08], tp, noise_pred=npred, mean_train=mt, mean_pred=mp_,
+                                                        want_cov=True)
+            mu, cv = O.predict_mvn(k.to_tuple(), 0.08, ts, xs, tp, noise_pred=npred, mean=meanf)
+            sc = max(1.0, np.abs(cv).max())
+            assert np.abs(mean[0] - mu).max() <= LP_TOL * max(1.0, np.abs(mu).max())
+            assert np.abs(cov[0] - cv).max() <= LP_TOL * sc
+            assert np.array_equal(cov[0], cov[0].T) and np.array_equal(np.diag(cov[0]), var[0])
+    # module-level mirror of Distributions.MvNormal(node, ...) + quantile (src/GP.jl:731-758, 1006-1012)
+    ts, xs = pkg.prior.synthetic_series(80, seed=1)
+    d = G.MvNormal(k, 0.08, ts, xs, np.linspace(0, 1.1, 9), engine=engine)
+    mu, cv = O.predict_mvn(k.to_tuple(), 0.08, ts, xs, np.linspace(0, 1.1, 9))
+    assert np.allclose(G.quantile(d, [0.1, 0.5, 0.9]), O.quantile(mu, cv, [0.1, 0.5, 0.9]), atol=1e-8)
+
+
+def test_predictive_likelihood_identity_on_gpu(pkg, engine):
+    """logpdf(joint) - logpdf(obs) = logpdf(predictive, xs_test) with every term from the GPU
+    (test/experiment_hmc.jl:111-132)."""
+    G = pkg
+    rng = np.random.default_rng(3)
+    ts, xs = pkg.prior.synthetic_series(500, seed=77, shuffle=True)
+    n_obs = 380
+    for k in [G.SquaredExponential(0.2, 1.0), G.Linear(0.5) + G.Periodic(0.3, 0.25, 1.0),
+              G.ChangePoint(G.Linear(0.5), G.Linear(1.5), 0.5, 0.001)]:
+        engine.set_data(ts, xs)
+        lj = engine.logpdf(k, 0.1)
+        lo = engine.logpdf(k, 0.1, n=n_obs)
+        mean, var, cov, _ = engine.predict_batch([k], [0.1], ts[n_obs:], n=n_obs, want_cov=True)
+        lpred = O.mvnormal_logpdf(xs[n_obs:], cov[0], mean[0])
+        assert abs((lj - lo) - lpred) <= 1e-7 * max(1.0, abs(lpred))
+
+
+def test_debug_cholesky_and_nonpd(pkg, engine):
+    rng = np.random.default_rng(2)
+    for n in (16, 100, 128, 200, 384, 1000):
+        M = rng.standard_normal((n, n)); K = M @ M.T / n + 0.5 * np.eye(n)
+        L, info = engine.debug_cholesky(K)
+        assert info == 0
+        Lr = sla.cholesky(K, lower=True)
+        assert np.abs(L - Lr).max() <= 1e-12 * np.abs(Lr).max()
+        assert np.array_equal(L, np.tril(L))
+    K = np.eye(300); K[150, 150] = -1.0
+    _, info = engine.debug_cholesky(K)
+    assert info == 151                                      # LAPACK dpotrf convention
+    # through the likelihood entry: PosDefException like the reference (no try/catch upstream)
+    ts = np.array([0.1, 0.1, 0.5]); xs = np.zeros(3)
+    engine.set_data(ts, xs)
+    k = pkg.Constant(1.0) * pkg.Linear(0.0, -5.0, 0.0)       # negative "bias" makes K indefinite
+    lp, info = engine.logpdf_batch([k, pkg.Constant(1.0)], [1e-5, 0.1], check=False)
+    assert info[0] > 0 and np.isnan(lp[0]) and info[1] == 0 and np.isfinite(lp[1])
+    with pytest.raises(pkg.PosDefException):
+        engine.logpdf_batch([k], [1e-5])
+
+
+def test_bad_programs_are_rejected(pkg, engine):
+    lib, ctx = engine._lib, engine._ctx
+    ts, xs = pkg.prior.synthetic_series(10, seed=1)
+    engine.set_data(ts, xs)
+    out = ctypes.c_double(); info = ctypes.c_int32()
+
+    def call(ops, prm):
+        ops = np.asarray(ops, dtype=np.uint8); prm = np.asarray(prm, dtype=np.float64)
+        return lib.agp_logpdf(ctx, 10, ops.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), ops.size,
+                              prm.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), prm.size, 0.1,
+                              ctypes.byref(out), ctypes.byref(info))
+    assert call([1], [0.5]) == 0
+    assert call([6], [0.5]) == -3                    # operator without operands
+    assert call([1, 1], [0.5, 0.5]) == -3            # two kernels left on the stack
+    assert call([1], [0.5, 0.7]) == -3               # parameter count mismatch
+    assert call([42], [0.5]) == -3                   # unknown opcode
+    assert b"particle 0" in lib.agp_last_error(ctx)
+
+
+def test_workspace_chunking_is_invisible(pkg, engine):
+    ts, xs = pkg.prior.synthetic_series(300, seed=8)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(8), 13, max_depth=3)
+    engine.set_data(ts, xs)
+    a, _ = engine.logpdf_batch(nodes, noises)
+    engine.set_workspace_limit(3 * 6 * 128 * 128 * 8)      # room for 3 particles per chunk (nt=3 -> 6 tiles)
+    try:
+        b, _ = engine.logpdf_batch(nodes, noises)
+        tp = np.linspace(0, 1.1, 20)
+        m1, v1, _, _ = engine.predict_batch(nodes, noises, tp)
+    finally:
+        engine.set_workspace_limit(0)
+    m2, v2, _, _ = engine.predict_batch(nodes, noises, tp)
+    assert np.array_equal(a, b) and np.array_equal(m1, m2) and np.array_equal(v1, v2)
+
+
+def test_concurrent_callers(pkg, engine):
+    """P host threads calling the single-particle entry at once — the reference's call pattern
+    (Threads.@threads over particles, src/inference_smc_anneal_data.jl:133-135)."""
+    ts, xs = pkg.prior.synthetic_series(400, seed=12)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(12), 24, max_depth=3)
+    engine.set_data(ts, xs)
+    ref, _ = engine.logpdf_batch(nodes, noises)
+    out = np.zeros(24)
+
+    def work(i):
+        for _ in range(3):
+            out[i] = engine.logpdf(nodes[i], float(noises[i]))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(24)]
+    [t.start() for t in th]; [t.join() for t in th]
+    assert np.array_equal(out, ref)
+
+
+def test_device_output_entry(pkg, engine):
+    """agp_logpdf_batch_device leaves results in caller-provided device memory on the caller's stream."""
+    import torch
+    ts, xs = pkg.prior.synthetic_series(256, seed=3)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(3), 9, max_depth=3)
+    engine.set_data(ts, xs)
+    ref, _ = engine.logpdf_batch(nodes, noises)
+    d_lp = torch.full((9,), float("nan"), dtype=torch.float64, device="cuda:0")
+    d_info = torch.full((9,), -7, dtype=torch.int32, device="cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    engine.logpdf_batch_device(pkg.encode_batch(nodes), noises, 256, d_lp.data_ptr(), d_info.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_lp.cpu().numpy(), ref) and (d_info.cpu().numpy() == 0).all()
+
+
+# ---- full-size, size-independent properties (n = 2048: no oracle run needed for most) -------------
+def test_full_size_properties(pkg, engine):
+    """BASELINE config 3 size (n=2048).  (1) spot parity vs the oracle on 3 particles;
+    (2) invariance of the logpdf under a permutation of the observations; (3) joint/marginal/
+    predictive identity; (4) batch composition does not change a particle's value."""
+    n = 2048
+    ts, xs = pkg.prior.synthetic_series(n, seed=2048)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(2048), 24, max_depth=4, max_size=31)
+    engine.set_data(ts, xs)
+    lp, info = engine.logpdf_batch(nodes, noises, check=False)
+    ok = info == 0
+    assert ok.sum() >= 20
+    for i in np.flatnonzero(ok)[:3]:
+        ref = O.gp_logpdf(nodes[i].to_tuple(), float(noises[i]), ts, xs)
+        assert abs(lp[i] - ref) <= LP_TOL * max(1.0, abs(ref))
+    perm = np.random.default_rng(1).permutation(n)
+    engine.set_data(ts[perm], xs[perm])
+    lp2, info2 = engine.logpdf_batch(nodes, noises, check=False)
+    assert np.array_equal(info2 == 0, ok)
+    assert lp_err(lp2[ok], lp[ok]).max() <= LP_TOL
+    sub = [int(i) for i in np.flatnonzero(ok)[:5]]
+    lp3, _ = engine.logpdf_batch([nodes[i] for i in sub[::-1]], noises[sub[::-1]])
+    assert np.array_equal(lp3[::-1], lp2[sub])

@@ -1,0 +1,163 @@
+"""CPU tests that PIN THE ORACLE (oracle/oracle.py) — the reference ships no numeric goldens for
+this path (test/test_GP.jl, test/test_api.jl hold relational checks only) and cannot be executed
+here, so the oracle is checked against: the scalar/vectorised twin the reference keeps
+(src/GP.jl:666-684), closed forms, a 60-digit mpmath restatement, the committed golden vectors and
+the reference's relational tests restated (test/test_GP.jl:150-240, test/experiment_hmc.jl:111-132)."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import to_tuple
+from oracle import oracle as O
+from oracle import oracle_mp as M
+
+BASE = [("WN", 1.0), ("C", 0.5), ("LIN", 0.1, 1.3, 0.7), ("SE", 0.47, 0.13), ("GE", 0.42, 0.58, 3.2),
+        ("PER", 0.96, 0.21, 1.1)]   # test/test_GP.jl:24-33
+
+
+def composites():
+    for x in BASE:
+        for y in BASE:
+            yield ("+", x, y)
+            yield ("*", x, y)
+            yield ("CP", x, y, 0.5, 0.95)
+
+
+def test_scalar_vectorised_twin():
+    """compute_cov_matrix == compute_cov_matrix_vectorized (src/GP.jl:666-684)."""
+    raw = np.linspace(-10, 10, 40)
+    ts = (raw - raw.min()) / (raw.max() - raw.min())
+    ts[7] = ts[6]   # duplicate time point exercises WhiteNoise
+    for tree in list(BASE) + list(composites()):
+        Kv = O.compute_cov_matrix_vectorized(tree, 0.3, ts)
+        Ks = O.compute_cov_matrix(tree, 0.3, ts)
+        assert np.allclose(Kv, Ks, rtol=1e-14, atol=1e-15), tree
+        assert np.array_equal(Kv, Kv.T), tree
+
+
+def test_program_roundtrip():
+    for tree in composites():
+        ops, prm = O.tree_to_program(tree)
+        assert O.program_to_tree(ops, prm) == tree
+    deep = ("CP", ("+", BASE[2], ("*", BASE[3], BASE[4])), ("CP", BASE[5], BASE[1], 0.2, 0.001), 0.6, 0.001)
+    ops, prm = O.tree_to_program(deep)
+    assert list(ops) == [2, 3, 4, 7, 6, 5, 1, 8, 8]          # postfix = unroll order, src/GP.jl:112-113
+    assert O.program_to_tree(ops, prm) == deep
+    assert O.tree_size(deep) == 9 and O.tree_leaves(deep) == 5
+
+
+def test_closed_forms():
+    rng = np.random.default_rng(1)
+    ts = np.sort(rng.random(12)); xs = rng.standard_normal(12)
+    n, a, s2 = 12, 0.7, 0.3
+    lp = O.gp_logpdf(("C", a), s2, ts, xs)
+    logdet = (n - 1) * math.log(s2) + math.log(s2 + n * a)
+    quad = (xs @ xs - a * xs.sum() ** 2 / (s2 + n * a)) / s2
+    assert lp == pytest.approx(-0.5 * (n * math.log(2 * math.pi) + logdet + quad), rel=1e-13)
+    lp = O.gp_logpdf(("WN", 0.4), 0.2, ts, xs)
+    assert lp == pytest.approx(-0.5 * (n * math.log(2 * math.pi) + n * math.log(0.6) + xs @ xs / 0.6), rel=1e-13)
+    # n = 1 and n = 0 (src/inference_smc_anneal_data.jl:185-187 generates on zero observations)
+    lp = O.gp_logpdf(("SE", 0.3, 2.0), 0.5, ts[:1], xs[:1])
+    assert lp == pytest.approx(-0.5 * (math.log(2 * math.pi) + math.log(2.5) + xs[0] ** 2 / 2.5), rel=1e-14)
+    assert O.gp_logpdf(("SE", 0.3, 2.0), 0.5, ts[:0], xs[:0]) == 0.0
+
+
+def test_mpmath_arbitration_live():
+    """fp64 oracle vs 60-digit restatement on a fresh case (not only through the fixtures)."""
+    rng = np.random.default_rng(5)
+    ts = np.sort(rng.random(20)); xs = 0.4 * rng.standard_normal(20)
+    tree = ("CP", ("+", BASE[2], BASE[5]), ("*", BASE[3], BASE[4]), 0.45, 0.05)
+    lp = O.gp_logpdf(tree, 0.07, ts, xs)
+    lpm = float(M.gp_logpdf_mp(tree, 0.07, ts, xs))
+    assert abs(lp - lpm) <= 1e-10 * max(1.0, abs(lpm))
+    tp = np.array([0.1, 0.5, 0.9, 1.2])
+    mu, cov = O.predict_mvn(tree, 0.07, ts, xs, tp)
+    mum, covm = M.predict_mvn_mp(tree, 0.07, ts, xs, tp)
+    assert np.allclose(mu, [float(v) for v in mum], rtol=0, atol=1e-10)
+    assert np.allclose(cov, np.array([[float(covm[i, j]) for j in range(4)] for i in range(4)]), atol=1e-10)
+
+
+def test_golden_vectors(golden):
+    """Every committed vector: fp64 oracle reproduces itself, agrees with the mpmath value and the
+    closed form where the fixture has one."""
+    n_mp = 0
+    for c in golden["cases"]:
+        tree = to_tuple(c["tree"]); ts = np.array(c["ts"]); xs = np.array(c["xs"])
+        lp = O.gp_logpdf(tree, c["noise"], ts, xs)
+        assert abs(lp - c["logpdf"]) <= 1e-12 * max(1.0, abs(lp)), c["name"]
+        if "logpdf_mp" in c:
+            n_mp += 1
+            assert abs(lp - float(c["logpdf_mp"])) <= 1e-9 * max(1.0, abs(lp)), c["name"]
+        if "closed_form" in c:
+            assert abs(lp - c["closed_form"]) <= 1e-12 * max(1.0, abs(lp)), c["name"]
+        if "ts_pred" in c:
+            mu, cov = O.predict_mvn(tree, c["noise"], ts, xs, np.array(c["ts_pred"]))
+            assert np.allclose(mu, c["pred_mean"], rtol=0, atol=1e-10 * max(1.0, np.abs(mu).max())), c["name"]
+            assert np.allclose(np.diag(cov), c["pred_var"], rtol=0, atol=1e-10), c["name"]
+    assert n_mp >= 100
+
+
+def test_predictive_likelihood_agrees():
+    """logpdf(joint) - logpdf(obs) == logpdf(predictive, xs_test) — test/experiment_hmc.jl:111-132."""
+    rng = np.random.default_rng(3)
+    ts_all = np.sort(rng.random(60)); xs_all = 0.5 * rng.standard_normal(60)
+    idx = rng.permutation(60); obs, tst = np.sort(idx[:40]), np.sort(idx[40:])
+    for tree in [("SE", 0.2, 1.0), ("+", ("LIN", 0.5, 1.0, 1.0), ("PER", 0.3, 0.25, 1.0)),
+                 ("CP", ("LIN", 0.5, 1, 1), ("LIN", 1.5, 1, 1), 0.5, 0.001)]:
+        noise = 0.1
+        t_joint = np.concatenate([ts_all[obs], ts_all[tst]]); x_joint = np.concatenate([xs_all[obs], xs_all[tst]])
+        lj = O.gp_logpdf(tree, noise, t_joint, x_joint)
+        lo = O.gp_logpdf(tree, noise, ts_all[obs], xs_all[obs])
+        mu, cov = O.predict_mvn(tree, noise, ts_all[obs], xs_all[obs], ts_all[tst])
+        lpred = O.mvnormal_logpdf(xs_all[tst], cov, mu)
+        assert lj - lo == pytest.approx(lpred, rel=1e-9, abs=1e-9)
+
+
+def test_infer_gp_sum_matches_mvnormal():
+    """Covariance / mean of the observable block of infer_gp_sum equal the single-kernel predictive
+    (test/test_GP.jl:150-240, atol 1e-5 there)."""
+    rng = np.random.default_rng(9)
+    ts = np.sort(rng.random(30)); xs = 0.3 * rng.standard_normal(30); tp = np.linspace(0, 1.2, 9)
+    k1, k2 = ("SE", 0.3, 0.8), ("PER", 0.5, 0.2, 0.4)
+    mu_a, S_a, idxF, idxX = O.infer_gp_sum([k1, k2], 0.1, ts, xs, tp)
+    mu, cov = O.predict_mvn(("+", k1, k2), 0.1, ts, xs, tp)
+    assert np.allclose(mu_a[idxX], mu, atol=1e-8)
+    assert np.allclose(S_a[idxX, idxX], cov, atol=1e-6)
+    # sum of latent covariances = observable covariance when noise_pred = 0 (test/test_GP.jl:228-237)
+    mu_a, S_a, idxF, idxX = O.infer_gp_sum([k1, k2], 0.1, ts, xs, tp, noise_pred=0.0)
+    lat = sum(S_a[a, b] for a in idxF for b in idxF)
+    assert np.allclose(lat, S_a[idxX, idxX], atol=1e-6)
+
+
+def test_quantile_and_weights():
+    mu = np.array([0.0, 1.0, 2.0]); cov = np.diag([1.0, 4.0, 0.25])
+    q = O.quantile(mu, cov, [0.5, 0.975])
+    assert q.shape == (3, 2) and np.allclose(q[:, 0], mu)
+    assert q[1, 1] == pytest.approx(1.0 + 2.0 * 1.959963984540054, rel=1e-12)
+    lw = np.array([-1.0, -1.0, -1.0, -1.0])
+    assert O.effective_sample_size(lw) == pytest.approx(4.0)
+    assert np.allclose(O.particle_weights(np.array([0.0, math.log(3.0)])), [0.25, 0.75])
+
+
+def test_c_oracle_matches_numpy():
+    """The plain-C restatement (oracle/agp_oracle.c) against the NumPy oracle, when it is built."""
+    import ctypes
+    from pathlib import Path
+    so = Path(__file__).resolve().parent.parent / "oracle" / "_build" / "libagp_oracle.so"
+    if not so.exists():
+        pytest.skip("C oracle not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(str(so))
+    lib.agp_oracle_logpdf.restype = ctypes.c_double
+    rng = np.random.default_rng(11)
+    ts = np.sort(rng.random(90)); xs = 0.4 * rng.standard_normal(90)
+    for tree in list(composites())[::5]:
+        ops, prm = O.tree_to_program(tree)
+        info = ctypes.c_int(0)
+        lp = lib.agp_oracle_logpdf(ops.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(ops.size),
+                                   prm.ctypes.data_as(ctypes.c_void_p), ctypes.c_double(0.05),
+                                   ts.ctypes.data_as(ctypes.c_void_p), xs.ctypes.data_as(ctypes.c_void_p),
+                                   ctypes.c_int(90), ctypes.byref(info))
+        ref = O.gp_logpdf(tree, 0.05, ts, xs)
+        assert info.value == 0
+        assert abs(lp - ref) <= 1e-10 * max(1.0, abs(ref)), tree
