@@ -40,6 +40,7 @@ struct CholArgs {
   int nt;               // tile rows of the (joint) matrix
   int k;                // factor mode: block column; Schur mode: unused
   int nt1;              // Schur mode: number of factored block columns
+  int tiles;            // factor mode: tiles per particle in this launch (nt-k, or 1 for k = 0)
 };
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   int T, ti, tk, jmax;
   int pl, tl;
   if (FACTOR) {
-    T = a.nt - a.k;
+    T = a.tiles;
     pl = qq / T; tl = qq - pl * T;
     tk = a.k; ti = a.k + tl; jmax = a.k;
   } else {
@@ -216,7 +217,6 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   if (tid < NB) rvec[tid] = rv;
   __syncthreads();
 
-  double logdet = 0.0;   // wave 0, uniform
   int bad = 0;           // first non-positive pivot (1-based global index), 0 = none
 
   for (int jb = 0; jb < NSB; ++jb) {
@@ -230,7 +230,6 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       for (int c = 0; c < 16; ++c) {
         const double pc = readlane_d(s[c], c);
         if (!(pc > 0.0) && bad == 0) bad = a.k * NB + jb * 16 + c + 1;
-        logdet += log(pc);
         const double rinv = rsqrt(pc);
         rinvs[c] = rinv;
         const double lrc = s[c] * rinv;
@@ -319,14 +318,21 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     const double v = (rb >= cb) ? sm[blk_idx(rb, cb) * 256 + tid] : 0.0;
     Tt[(long long)(cb * 16 + c) * NB + rb * 16 + r] = v;
   }
-  if (tid < NB) vecp[tk * NB + tid] = avec[tid];
+  if (tid < NB) {
+    vecp[tk * NB + tid] = avec[tid];
+    // log|K_kk-block| = 2 sum log L_ii, all 128 logs in parallel (diag of block (b,b) at 17*i)
+    const double dii = sm[blk_idx(tid >> 4, tid >> 4) * 256 + 17 * (tid & 15)];
+    Wl[tid] = 2.0 * log(dii);
+  }
+  __syncthreads();
   if (w == 0) {
     double ss = avec[l] * avec[l] + avec[l + 64] * avec[l + 64];
+    double ld = Wl[l] + Wl[l + 64];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); ld += __shfl_xor(ld, off); }
     if (l == 0) {
       double* pp = a.partial + ((long long)p * a.nt + tk) * 2;
-      pp[0] = logdet;
+      pp[0] = ld;
       pp[1] = ss;
       if (bad != 0 && a.info[p] == 0) a.info[p] = bad;
     }
@@ -496,6 +502,26 @@ __global__ void k_mfma_probe(const double* A, const double* B, double* D) {
   c = mfma(a, b, c);
 #pragma unroll
   for (int r = 0; r < 4; ++r) D[(4 * r + (l >> 4)) * 16 + (l & 15)] = c[r];   // row = 4r + l/16, col = l%16
+}
+
+
+// fp64 MFMA issue-rate microbenchmark: every wave keeps 16 independent accumulators busy.
+__global__ __launch_bounds__(256, 2) void k_mfma_peak(double* out, long long* cycles, int iters) {
+  d4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  const long long t0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = mfma(a, b, acc[i]);
+  }
+  const long long t1 = clock64();
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[(long long)blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
 }  // namespace agp

@@ -308,7 +308,9 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, Prof* pf, double* c
     ca.k = k;
     const int Pg = (ca.P + 7) / 8;
     {
-      const int T = ca.nt - k;
+      // block column 0 has nothing to subtract: only the diagonal tiles need a workgroup
+      const int T = (k == 0) ? 1 : ca.nt - k;
+      ca.tiles = T;
       size_t e0 = pf ? pf->mark() : 0;
       hipLaunchKernelGGL(k_chol_update<true>, dim3(8 * Pg * T), dim3(256), 0, st, ca);
       size_t e1 = pf ? pf->mark() : 0;
@@ -741,6 +743,34 @@ int agp_debug_cholesky(agp_ctx* c, const double* K, int64_t n, double* out_L, in
   HIPCHK(c, hipMemcpyAsync(out_L, s->dense.p, sizeof(double) * nel, hipMemcpyDeviceToHost, st));
   if (out_info) HIPCHK(c, hipMemcpyAsync(out_info, s->info.p, sizeof(int), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
+  return AGP_OK;
+}
+
+int agp_debug_mfma_peak(agp_ctx* c, int32_t iters, int32_t wg_per_cu, double* out_tflops, double* out_ghz) {
+  if (!c || !out_tflops || !out_ghz) return fail(c, AGP_ERR_ARG, "null pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipDeviceProp_t prop;
+  HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+  const int nblk = prop.multiProcessorCount * (wg_per_cu > 0 ? wg_per_cu : 2);
+  double* d_out = nullptr; long long* d_cyc = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_out, sizeof(double) * 256 * (size_t)nblk));
+  HIPCHK(c, hipMalloc((void**)&d_cyc, sizeof(long long) * (size_t)nblk));
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, d_out, d_cyc, 64);   // warm-up
+  HIPCHK(c, hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, d_out, d_cyc, iters);
+  HIPCHK(c, hipEventRecord(e1, 0));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  std::vector<long long> cyc(nblk);
+  HIPCHK(c, hipMemcpy(cyc.data(), d_cyc, sizeof(long long) * nblk, hipMemcpyDeviceToHost));
+  double mean_cyc = 0; for (auto v : cyc) mean_cyc += (double)v; mean_cyc /= nblk;
+  const double flops = (double)nblk * 4.0 * 16.0 * (double)iters * 2048.0;
+  *out_tflops = flops / (ms * 1e-3) / 1e12;
+  *out_ghz = mean_cyc / (ms * 1e-3) / 1e9;     // shader cycles per second while the kernel ran
+  (void)hipFree(d_out); (void)hipFree(d_cyc); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return AGP_OK;
 }
 

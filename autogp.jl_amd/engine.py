@@ -26,7 +26,7 @@ LIB_PATH = _PKG_DIR / "lib" / "libautogp_hip.so"
 EXPORTED_SYMBOLS = [
     "agp_init", "agp_destroy", "agp_last_error", "agp_version", "agp_set_data", "agp_logpdf",
     "agp_logpdf_batch", "agp_logpdf_batch_device", "agp_predict_batch", "agp_cov_matrix",
-    "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_set_profiling", "agp_get_timing",
+    "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_debug_mfma_peak", "agp_set_profiling", "agp_get_timing",
     "agp_set_workspace_limit",
 ]
 
@@ -48,6 +48,26 @@ class PosDefException(ArithmeticError):
 _lib = None
 
 
+def _preload_shared_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP runtimes
+    in one process cannot both own the GPU, so when PyTorch is installed but not yet imported we map
+    ITS runtime first; the engine then binds to it and a later `import torch` reuses the same copy.
+    Without PyTorch the engine uses the system ROCm runtime from its RUNPATH."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+        if cand.exists():
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load_library(path=None):
     """dlopen the engine. Raises AGPError (never falls back) when it has not been built."""
     global _lib
@@ -57,6 +77,7 @@ def load_library(path=None):
     if not p.exists():
         raise AGPError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    _preload_shared_hip_runtime()
     lib = C.CDLL(str(p))
     dp, ip, u8p = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
     vp = C.c_void_p
@@ -78,6 +99,7 @@ def load_library(path=None):
     lib.agp_cov_matrix.restype = C.c_int
     lib.agp_debug_cholesky.argtypes = [vp, dp, C.c_int64, dp, ip]; lib.agp_debug_cholesky.restype = C.c_int
     lib.agp_debug_mfma_probe.argtypes = [vp, dp, dp, dp]; lib.agp_debug_mfma_probe.restype = C.c_int
+    lib.agp_debug_mfma_peak.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]; lib.agp_debug_mfma_peak.restype = C.c_int
     lib.agp_set_profiling.argtypes = [vp, C.c_int]; lib.agp_set_profiling.restype = C.c_int
     lib.agp_get_timing.argtypes = [vp, dp, C.c_int32]; lib.agp_get_timing.restype = C.c_int
     lib.agp_set_workspace_limit.argtypes = [vp, C.c_int64]; lib.agp_set_workspace_limit.restype = C.c_int
@@ -223,6 +245,11 @@ class GPEngine:
         A = _f64(A).reshape(16, 4); B = _f64(B).reshape(4, 16); D = np.empty((16, 16))
         self._check(self._lib.agp_debug_mfma_probe(self._ctx, _dp(A), _dp(B), _dp(D)))
         return D
+
+    def debug_mfma_peak(self, iters=20000, wg_per_cu=2):
+        tf = C.c_double(); ghz = C.c_double()
+        self._check(self._lib.agp_debug_mfma_peak(self._ctx, int(iters), int(wg_per_cu), C.byref(tf), C.byref(ghz)))
+        return tf.value, ghz.value
 
     def set_profiling(self, on: bool):
         self._check(self._lib.agp_set_profiling(self._ctx, 1 if on else 0))

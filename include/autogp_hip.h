@@ -125,6 +125,10 @@ int agp_debug_cholesky(agp_ctx* ctx, const double* K, int64_t n, double* out_L, 
 /* Probe of the fp64 MFMA fragment layout: D = A(16x4) * B(4x16), row-major host arrays. */
 int agp_debug_mfma_probe(agp_ctx* ctx, const double* A, const double* B, double* D);
 
+/* fp64 MFMA issue-rate microbenchmark (16 independent accumulators per wave, wg_per_cu
+ * workgroups of 4 waves per CU): sustained TFLOP/s and the shader clock while it ran. */
+int agp_debug_mfma_peak(agp_ctx* ctx, int32_t iters, int32_t wg_per_cu, double* out_tflops, double* out_ghz);
+
 /* When enabled, batch calls bracket their phases with HIP events on the launch stream.
  * agp_get_timing fills out[0..7] = { total_ms, cov_build_ms, chol_update_ms, chol_trsm_ms,
  * finish_ms, n_update_launches, n_trsm_launches, h2d_d2h_ms } for the last batch call. */
