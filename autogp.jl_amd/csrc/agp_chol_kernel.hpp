@@ -25,6 +25,7 @@
 // lane%16 index runs along the ROWS of C, which are contiguous in the column-major tile.
 #pragma once
 #include "agp_common.hpp"
+#include "agp_cov_kernel.hpp"
 
 namespace agp {
 
@@ -41,6 +42,14 @@ struct CholArgs {
   int k;                // factor mode: block column; Schur mode: unused
   int nt1;              // Schur mode: number of factored block columns
   int tiles;            // factor mode: tiles per particle in this launch (nt-k, or 1 for k = 0)
+  // fused covariance evaluation (DCOV > 0): the tile is computed from the particle's program
+  const double* tt;     // time points, padded joint layout
+  int n1, n1_pad, m2;
+  const ProgHdr* hdr;
+  const uint8_t* ops;
+  const double* prm;
+  const double* noise;
+  int n_fused;          // particles [0, n_fused) evaluate their tiles; the rest have them prebuilt in A
 };
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -65,7 +74,11 @@ constexpr int U_LDS_BYTES = (U_MAIN_DOUBLES + U_EXTRA_DOUBLES) * 8;
 
 __device__ __forceinline__ int blk_idx(int rb, int cb) { return rb * (rb + 1) / 2 + cb; }
 
-template <bool FACTOR>
+// Largest number of ChangePoint nodes whose sigma tables fit the (aliased) LDS of the fused path.
+// LDS map of the fused phase (aliases the slab buffers): tpt[256] | sig[n_cp][256] | prm[n_prm] | ops[n_ops] (int)
+constexpr int U_MAX_CP = (U_MAIN_DOUBLES - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_OPS_DEV / 2 - 8) / 256;
+
+template <bool FACTOR, int DCOV>
 __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
   double* rvec = sm + U_MAIN_DOUBLES;
@@ -75,15 +88,25 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 
   // ---- XCD-aware block -> (particle, tile) map: block b runs on XCD b%8; all tiles of one
   //      particle go to the same XCD so the shared L(k,j) panel stays in that XCD's L2. ----
-  const int b = blockIdx.x;
-  const int xcd = b & 7, qq = b >> 3;
+  int b = blockIdx.x;
+  int xcd, qq;
   int T, ti, tk, jmax;
   int pl, tl;
   if (FACTOR) {
+    // diagonal tiles occupy the first 8*ceil(P/8) blocks of the grid: their serial 128x128
+    // factorisation then overlaps the bulk of the launch instead of forming its tail
     T = a.tiles;
-    pl = qq / T; tl = qq - pl * T;
+    const int ndiag = 8 * ((a.P + 7) / 8);
+    if (b < ndiag) {
+      xcd = b & 7; pl = b >> 3; tl = 0;
+    } else {
+      b -= ndiag;
+      xcd = b & 7; qq = b >> 3;
+      pl = qq / (T - 1); tl = 1 + (qq - pl * (T - 1));
+    }
     tk = a.k; ti = a.k + tl; jmax = a.k;
   } else {
+    xcd = b & 7; qq = b >> 3;
     const int nt2 = a.nt - a.nt1;
     T = nt2 * (nt2 + 1) / 2;
     pl = qq / T; tl = qq - pl * T;
@@ -106,11 +129,59 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   double* __restrict__ Ap = a.A + (long long)p * a.strideA;
   double* vecp = a.vec + (long long)p * a.ldv;
 
+  // DCOV > 0: accumulators start at -A(i,k), the K-loop adds L(i,j) L(k,j)^T on top and the epilogue is
+  // a pure store of -acc (no read-modify-write tail).  The tile is never read from HBM: it is
+  // evaluated from the particle's kernel program straight into the accumulator layout (4 elements
+  // per interpreter pass: one row, four columns), and this fp64-VALU phase overlaps the co-resident
+  // workgroup's MFMA phase.  DCOV == 0 (agp_debug_cholesky, >35 ChangePoints) keeps resident tiles.
+  double* __restrict__ Tt = Ap + tile_off(ti, tk);
   d4 acc[4][4];
+  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused);
+  if (!prebuilt) {
+    const ProgHdr h = a.hdr[p];
+    double* tpt = sm;
+    double* sig = sm + 256;
+    // Stage the program in LDS: this kernel also stores to global memory, so the compiler cannot
+    // keep the opcode / parameter fetches on the scalar cache; from LDS they are broadcast reads.
+    double* prm = sig + h.n_cp * 256;
+    int* ops = reinterpret_cast<int*>(prm + h.n_prm + 2);
+    for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
+    for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
+    __syncthreads();
+    cov_prologue(a.tt, ti, tk, h, ops, prm, tpt, sig, tid);
+    const double noise = a.noise[p];
+#pragma unroll 1
+    for (int t = 0; t < 16; ++t) {
+      const int mi = t >> 2, ni = t & 3;
+      const int rslot = wr * 64 + ni * 16 + l15;
+      double tr[4], tc[4], out[4];
+      int ri[4], ci[4];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+      for (int r = 0; r < 4; ++r) {
+        const int cslot = wc * 64 + mi * 16 + 4 * r + lq;
+        tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
+        ri[r] = rslot; ci[r] = NB + cslot;
+      }
+      eval_program<(DCOV > 0 ? DCOV : 4), 4>(h, ops, prm, sig, tr, tc, ri, ci, out);
+      d4 v;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+      for (int r = 0; r < 4; ++r)
+        v[r] = -cov_finalize(out[r], ti * NB + rslot, tk * NB + wc * 64 + mi * 16 + 4 * r + lq, a.n1, a.n1_pad, a.m2, noise);
+      switch (t) {   // wave-uniform scalar dispatch keeps every accumulator index static
+        case 0: acc[0][0] = v; break;  case 1: acc[0][1] = v; break;  case 2: acc[0][2] = v; break;  case 3: acc[0][3] = v; break;
+        case 4: acc[1][0] = v; break;  case 5: acc[1][1] = v; break;  case 6: acc[1][2] = v; break;  case 7: acc[1][3] = v; break;
+        case 8: acc[2][0] = v; break;  case 9: acc[2][1] = v; break;  case 10: acc[2][2] = v; break; case 11: acc[2][3] = v; break;
+        case 12: acc[3][0] = v; break; case 13: acc[3][1] = v; break; case 14: acc[3][2] = v; break; default: acc[3][3] = v; break;
+      }
+    }
+    __syncthreads();   // the sigma tables alias the GEMM slab buffers
+  } else {
+    // resident-tile path: accumulate from zero, subtract from the stored tile in the epilogue
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+  }
 
   double rv = 0.0;
   if (is_diag && tid < NB) rv = vecp[tk * NB + tid];
@@ -154,6 +225,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       if (s + 1 < nslab) gload(s + 1);
       const double* As = sm + buf * U_SLAB;
       const double* Bs = sm + (2 + buf) * U_SLAB;
+      // waves inside their MFMA block outrank the co-resident workgroup's load/store/barrier phase
+      __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < KB / 4; ++kk) {
         const int krow = (kk * 4 + lq) * LDS_STRIDE;
@@ -167,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 #pragma unroll
           for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma(fa[mi], fb[ni], acc[mi][ni]);
       }
+      __builtin_amdgcn_s_setprio(0);
       if (is_diag && tid < NB) {
         // r -= L(k,j)[:, slab] * alpha_j[slab]
         const double* xs_ = xv + buf * 16;
@@ -178,10 +252,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     }
   }
 
-  double* __restrict__ Tt = Ap + tile_off(ti, tk);
-
   if (!(FACTOR && is_diag)) {
-    // ---- plain epilogue: C = A - acc, in place ----
+    // ---- plain epilogue: C = A - sum = -acc ----
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -190,8 +262,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int col = wc * 64 + mi * 16 + 4 * r + lq;
           const int row = wr * 64 + ni * 16 + l15;
-          double* ptr = Tt + (long long)col * NB + row;
-          *ptr = *ptr - acc[mi][ni][r];
+          Tt[col * NB + row] = prebuilt ? Tt[col * NB + row] - acc[mi][ni][r] : -acc[mi][ni][r];
         }
     if (is_diag && tid < NB) vecp[tk * NB + tid] = rv;   // Schur mode: -(V^T alpha) (+x = 0)
     return;
@@ -207,11 +278,9 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       if (rb >= cb) {
         double* blk = sm + blk_idx(rb, cb) * 256;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = cb * 16 + 4 * r + lq;
-          const int row = rb * 16 + l15;
-          blk[64 * r + l] = Tt[(long long)col * NB + row] - acc[mi][ni][r];
-        }
+        for (int r = 0; r < 4; ++r)
+          blk[64 * r + l] = prebuilt ? Tt[(cb * 16 + 4 * r + lq) * NB + rb * 16 + l15] - acc[mi][ni][r]
+                                     : -acc[mi][ni][r];
       }
     }
   if (tid < NB) rvec[tid] = rv;
@@ -316,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     const int rb = bi >> 3, cb = bi & 7;
     const int c = tid >> 4, r = tid & 15;
     const double v = (rb >= cb) ? sm[blk_idx(rb, cb) * 256 + tid] : 0.0;
-    Tt[(long long)(cb * 16 + c) * NB + rb * 16 + r] = v;
+    Tt[(cb * 16 + c) * NB + rb * 16 + r] = v;
   }
   if (tid < NB) {
     vecp[tk * NB + tid] = avec[tid];
@@ -368,14 +437,14 @@ __global__ __launch_bounds__(256, 2) void k_chol_trsm(CholArgs a) {
       const int R0 = (2 * w + st) * 16;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        acc[st][r] = Tt[(long long)(jb * 16 + 4 * r + lq) * NB + R0 + l15];
+        acc[st][r] = Tt[(jb * 16 + 4 * r + lq) * NB + R0 + l15];
     }
 #pragma unroll
     for (int lb = 0; lb < jb; ++lb) {
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         // -L(k,k)[jb*16 + l15][lb*16 + 4 s4 + lq]
-        const double fl = -Lkk[(long long)(lb * 16 + 4 * s4 + lq) * NB + jb * 16 + l15];
+        const double fl = -Lkk[(lb * 16 + 4 * s4 + lq) * NB + jb * 16 + l15];
         acc[0] = mfma(fl, X[0][lb][s4], acc[0]);
         acc[1] = mfma(fl, X[1][lb][s4], acc[1]);
       }
@@ -394,14 +463,14 @@ __global__ __launch_bounds__(256, 2) void k_chol_trsm(CholArgs a) {
       const int R0 = (2 * w + st) * 16;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        Tt[(long long)(jb * 16 + 4 * r + lq) * NB + R0 + l15] = X[st][jb][r];
+        Tt[(jb * 16 + 4 * r + lq) * NB + R0 + l15] = X[st][jb][r];
     }
   }
 }
 
 // logpdf = -1/2 (n log 2pi + log|K| + alpha'alpha)   (Gen.mvnormal logpdf, src/Model.jl:136)
 __global__ void k_finish_logpdf(const double* partial, const int* info, int nt, int P, int n,
-                                double* out_logpdf, int* out_info) {
+                                const int* map, double* out_logpdf, int* out_info) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   double ld = 0.0, ss = 0.0;
@@ -411,8 +480,9 @@ __global__ void k_finish_logpdf(const double* partial, const int* info, int nt, 
   }
   const int inf = info[p];
   const double lp = -0.5 * ((double)n * 1.8378770664093454835606594728112 + ld + ss);
-  out_logpdf[p] = (inf != 0) ? __builtin_nan("") : lp;
-  out_info[p] = inf;
+  const int o = map[p];          // un-sort: position in the caller's particle order
+  out_logpdf[o] = (inf != 0) ? __builtin_nan("") : lp;
+  out_info[o] = inf;
 }
 
 // x (minus the mean function on the training segment), zero elsewhere; clears info.
@@ -504,6 +574,18 @@ __global__ void k_mfma_probe(const double* A, const double* B, double* D) {
   for (int r = 0; r < 4; ++r) D[(4 * r + (l >> 4)) * 16 + (l & 15)] = c[r];   // row = 4r + l/16, col = l%16
 }
 
+
+// element-wise probe of csrc/agp_math.hpp on the device: which = 0 exp_f, 1 sin2_f, 2 log_f, 3 pow_f(x, g)
+__global__ void k_math_probe(int which, const double* x, const double* g, double* y, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r;
+  if (which == 0) r = fm::exp_f(x[i]);
+  else if (which == 1) r = fm::sin2_f(x[i]);
+  else if (which == 2) r = fm::log_f(x[i]);
+  else r = fm::pow_f(x[i], g[i]);
+  y[i] = r;
+}
 
 // fp64 MFMA issue-rate microbenchmark: every wave keeps 16 independent accumulators busy.
 __global__ __launch_bounds__(256, 2) void k_mfma_peak(double* out, long long* cycles, int iters) {

@@ -15,6 +15,7 @@ constexpr int NB2 = NB * NB;     // doubles per tile
 constexpr int BS = 16;           // MFMA sub-block edge (v_mfma_f64_16x16x4)
 constexpr int NSB = NB / BS;     // 8 sub-blocks per tile edge
 constexpr int KB = 16;           // slab depth of the update GEMM
+constexpr int AGP_MAX_OPS_DEV = 256;   // >= AGP_MAX_OPS of the C ABI
 constexpr int LDS_STRIDE = 144;  // 128 + 16 doubles: k-rows 32 banks apart -> conflict-free ds_read_b64
 
 // ---- device program opcodes (after host-side compilation) ----------------------------------
@@ -29,6 +30,8 @@ struct ProgHdr {
   int32_t prm_off;  // offset into device prm[]
   int32_t n_ops;
   int32_t n_cp;     // number of ChangePoint nodes
+  int32_t n_prm;    // device parameters of this program
+  int32_t pad_;
 };
 
 __host__ __device__ inline long long tile_off(int i, int j) {

@@ -1,16 +1,22 @@
-// K1 — covariance build.  One workgroup (256 threads) evaluates one 128x128 packed tile of one
-// particle's K = eval_cov(node, ts) + noise*I  (reference: src/GP.jl:666-668; leaves
+// K1 — covariance evaluation: K = eval_cov(node, ts) + noise*I  (reference: src/GP.jl:666-668; leaves
 // src/GP.jl:137-140,163-166,199-203,241-245,285-289,331-336; combinators 375-377,421-423,493-503).
 //
 // The per-particle kernel expression is a postfix program executed by a wave-uniform interpreter:
-// control flow (opcode fetch, switch) is scalar, every lane evaluates 8 matrix elements per pass
-// (2 consecutive rows x 4 columns) on a register-resident evaluation stack of depth D that is
-// implemented as a shift register so every access has a compile-time index (no scratch).
-// ChangePoint sigmoids depend on one time point only, so they are evaluated once per tile row /
-// column into LDS (256 tanh per ChangePoint node instead of 2 per element).
-// Stores are 16 B per lane, 1 KiB contiguous per wave instruction (column-major tile, rows fastest).
+// control flow (opcode fetch, switch) is scalar, every lane evaluates E matrix elements per pass on a
+// register-resident evaluation stack of depth D that is implemented as a shift register so every
+// access has a compile-time index (no scratch).  ChangePoint sigmoids depend on one time point only,
+// so they are tabulated once per tile row / column in LDS (256 tanh per ChangePoint node per tile
+// instead of 2 per element).
+//
+// Two users:
+//   * k_cov_tiles   — stand-alone tile builder (block column 0 of a factorisation, agp_cov_matrix);
+//                     8 elements per lane and pass, 16 B stores, 1 KiB contiguous per wave instruction.
+//   * k_chol_update — evaluates its own tile straight into the MFMA accumulators (4 elements per
+//                     pass in the accumulator layout), so K never round-trips through HBM and the
+//                     fp64 transcendental work overlaps the co-resident workgroup's MFMA phase.
 #pragma once
 #include "agp_common.hpp"
+#include "agp_math.hpp"
 
 namespace agp {
 
@@ -27,6 +33,8 @@ struct CovArgs {
   double* A;             // packed tiles, per-particle stride strideA
   long long strideA;
   int P;
+  int col0_only;         // 1: grid.x enumerates tiles (1+tix, 0) only
+  int p_off;             // first particle (blockIdx.y is relative to it)
 };
 
 __device__ __forceinline__ int prm_count(int o) {
@@ -35,36 +43,21 @@ __device__ __forceinline__ int prm_count(int o) {
          : (o == OP_PLUS || o == OP_TIMES) ? 0 : 3;
 }
 
-template <int D>
-__global__ __launch_bounds__(256) void k_cov_tiles(CovArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* tpt = smem;         // [256]: rows 0..127, cols 128..255
-  double* sig = smem + 256;   // [n_cp][256]
-
-  const int p = blockIdx.y;
-  const int tix = blockIdx.x;
-  // lower-triangular tile index -> (ti, tj)
-  int ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
-  while (ti * (ti + 1) / 2 > tix) --ti;
-  while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
-  const int tj = tix - ti * (ti + 1) / 2;
-
-  const int tid = threadIdx.x;
-  const ProgHdr h = a.hdr[p];
-  const uint8_t* __restrict__ ops = a.ops + h.op_off;
-  const double* __restrict__ prm = a.prm + h.prm_off;
-
-  // ---- prologue: time points of this tile's rows / columns, ChangePoint sigmoid tables ----
+// LDS scratch of the evaluator: tpt[256] (row times 0..127, column times 128..255) then sig[n_cp][256].
+template <typename OpT>
+__device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, int ti, int tj, const ProgHdr& h,
+                                             const OpT* __restrict__ ops, const double* __restrict__ prm,
+                                             double* tpt, double* sig, int tid) {
   {
     const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
-    tpt[tid] = a.tt[g];
+    tpt[tid] = tt[g];
   }
   __syncthreads();
   if (h.n_cp > 0) {
     const double t = tpt[tid];
     int q = 0, c = 0;
     for (int ip = 0; ip < h.n_ops; ++ip) {
-      const int o = ops[ip];
+      const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
       if (o == OP_CP || o == OP_CP_SWAP) {
         const double loc = prm[q], sc = prm[q + 1];
         sig[c * 256 + tid] = 0.5 * (1.0 + tanh((loc - t) / sc));   // sigma_cp, src/GP.jl:481-483
@@ -74,130 +67,159 @@ __global__ __launch_bounds__(256) void k_cov_tiles(CovArgs a) {
     }
     __syncthreads();
   }
+}
+
+// Evaluate the program at E (row, column) pairs.  tr/tc: time values; ri/ci: indices into the sigma
+// tables (row slot 0..127, column slot 128..255).  All arrays are statically indexed registers.
+template <int D, int E, typename OpT>
+__device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __restrict__ ops,
+                                             const double* __restrict__ prm, const double* sig,
+                                             const double (&tr)[E], const double (&tc)[E],
+                                             const int (&ri)[E], const int (&ci)[E], double (&out)[E]) {
+  double st[D][E];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int e = 0; e < E; ++e) st[d][e] = 0.0;
+
+  int q = 0, cpi = 0;
+  for (int ip = 0; ip < h.n_ops; ++ip) {
+    // the opcode is wave-uniform: keep it (and the dispatch on it) on the scalar unit
+    const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
+    if (o <= OP_PER) {
+      // ---------------- leaf: push ----------------
+      // every leaf's (up to three) parameters are fetched unconditionally — the parameter buffers
+      // carry two doubles of tail padding — and picked by opcode afterwards
+      const double p0 = prm[q], p1 = prm[q + 1], p2 = prm[q + 2];
+      double v[E];
+      if (o == OP_WN) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = (tr[e] == tc[e]) ? p0 : 0.0;
+      } else if (o == OP_CONST) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = p0;
+      } else if (o == OP_LIN) {
+        // bias + amp * (ti - c)(tj - c)
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = p1 + p2 * ((tr[e] - p0) * (tc[e] - p0));
+      } else {
+        // stationary leaves: amp * exp(arg)
+        double arg[E];
+        const double amp = (o == OP_SE) ? p1 : p2;
+        if (o == OP_SE) {          // p0 = 1/l^2
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const double dx = tr[e] - tc[e];
+            arg[e] = ((-0.5 * dx) * dx) * p0;
+          }
+        } else if (o == OP_GE) {   // p0 = 1/l, p1 = gamma
+#pragma unroll
+          for (int e = 0; e < E; ++e) arg[e] = -fm::pow_f(fabs(tr[e] - tc[e]) * p0, p1);
+        } else {                   // OP_PER: p0 = -2/l^2, p1 = pi/p
+#pragma unroll
+          for (int e = 0; e < E; ++e) arg[e] = p0 * fm::sin2_f(p1 * fabs(tr[e] - tc[e]));
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = amp * fm::exp_f(arg[e]);
+      }
+#pragma unroll
+      for (int d = D - 1; d > 0; --d)
+#pragma unroll
+        for (int e = 0; e < E; ++e) st[d][e] = st[d - 1][e];
+#pragma unroll
+      for (int e = 0; e < E; ++e) st[0][e] = v[e];
+    } else {
+      // ---------------- binary: combine st[1] (first evaluated) and st[0], pop ----------------
+      if (o == OP_PLUS) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) st[0][e] = st[1][e] + st[0][e];
+      } else if (o == OP_TIMES) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) st[0][e] = st[1][e] * st[0][e];
+      } else {
+        const double* sg = sig + cpi * 256;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double si = sg[ri[e]];
+          const double sj = sg[ci[e]];
+          const double kl = (o == OP_CP) ? st[1][e] : st[0][e];
+          const double kr = (o == OP_CP) ? st[0][e] : st[1][e];
+          // K = sig_1 .* k_1 + sig_2 .* k_2   (src/GP.jl:494-501)
+          st[0][e] = (si * sj) * kl + ((1.0 - si) * (1.0 - sj)) * kr;
+        }
+        ++cpi;
+      }
+#pragma unroll
+      for (int d = 1; d < D - 1; ++d)
+#pragma unroll
+        for (int e = 0; e < E; ++e) st[d][e] = st[d + 1][e];
+    }
+    q += prm_count(o);
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) out[e] = st[0][e];
+}
+
+// noise on the training diagonal (src/GP.jl:667), identity on padding rows / columns
+__device__ __forceinline__ double cov_finalize(double v, int gi, int gj, int n1, int n1_pad, int m2, double noise) {
+  const bool vi = (gi < n1) || (gi >= n1_pad && gi < n1_pad + m2);
+  const bool vj = (gj < n1) || (gj >= n1_pad && gj < n1_pad + m2);
+  double r = (vi && vj) ? v : 0.0;
+  if (gi == gj) r = vi ? (r + (gi < n1 ? noise : 0.0)) : 1.0;
+  return r;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_cov_tiles(CovArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* tpt = smem;         // [256]
+  double* sig = smem + 256;   // [n_cp][256]
+
+  const int p = blockIdx.y + a.p_off;
+  const int tix = blockIdx.x;
+  int ti, tj;
+  if (a.col0_only) {
+    ti = 1 + tix; tj = 0;
+  } else {
+    // lower-triangular tile index -> (ti, tj)
+    ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > tix) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
+    tj = tix - ti * (ti + 1) / 2;
+  }
+  const int tid = threadIdx.x;
+  const ProgHdr h = a.hdr[p];
+  const uint8_t* __restrict__ ops = a.ops + h.op_off;
+  const double* __restrict__ prm = a.prm + h.prm_off;
+  cov_prologue(a.tt, ti, tj, h, ops, prm, tpt, sig, tid);
 
   const int rp = tid & 63;        // row pair: rows 2rp, 2rp+1
   const int cq = tid >> 6;        // column group: 32 columns
   const int r0 = 2 * rp;
   const double tr0 = tpt[r0], tr1 = tpt[r0 + 1];
   const int gi0 = ti * NB + r0;
-  const bool vi0 = (gi0 < a.n1) || (gi0 >= a.n1_pad && gi0 < a.n1_pad + a.m2);
-  const bool vi1 = (gi0 + 1 < a.n1) || (gi0 + 1 >= a.n1_pad && gi0 + 1 < a.n1_pad + a.m2);
   const double noise = a.noise[p];
   double* __restrict__ T = a.A + (long long)p * a.strideA + tile_off(ti, tj);
 
   for (int pass = 0; pass < 8; ++pass) {
     const int c0 = cq * 32 + pass * 4;
-    double tc[4];
+    double tr[8], tc[8], out[8];
+    int ri[8], ci[8];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) tc[cc] = tpt[NB + c0 + cc];
-
-    double st[D][8];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) st[d][e] = 0.0;
-
-    int q = 0, cpi = 0;
-    for (int ip = 0; ip < h.n_ops; ++ip) {
-      const int o = ops[ip];
-      if (o <= OP_PER) {
-        // ---------------- leaf: push ----------------
-        double v[8];
-        if (o == OP_WN) {
-          const double th = prm[q];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (((e & 1) ? tr1 : tr0) == tc[e >> 1]) ? th : 0.0;
-        } else if (o == OP_CONST) {
-          const double th = prm[q];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = th;
-        } else if (o == OP_LIN) {
-          const double c = prm[q], bias = prm[q + 1], amp = prm[q + 2];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const double tr = (e & 1) ? tr1 : tr0;
-            v[e] = bias + amp * ((tr - c) * (tc[e >> 1] - c));
-          }
-        } else {
-          // stationary leaves: amp * exp(arg)
-          double arg[8];
-          double amp;
-          if (o == OP_SE) {
-            const double inv_l2 = prm[q];
-            amp = prm[q + 1];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const double dx = ((e & 1) ? tr1 : tr0) - tc[e >> 1];
-              arg[e] = ((-0.5 * dx) * dx) * inv_l2;
-            }
-          } else if (o == OP_GE) {
-            const double inv_l = prm[q], gam = prm[q + 1];
-            amp = prm[q + 2];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const double dt = fabs(((e & 1) ? tr1 : tr0) - tc[e >> 1]);
-              arg[e] = -pow(dt * inv_l, gam);
-            }
-          } else {  // OP_PER
-            const double cf = prm[q], freq = prm[q + 1];
-            amp = prm[q + 2];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              const double dx = fabs(((e & 1) ? tr1 : tr0) - tc[e >> 1]);
-              const double s = sin(freq * dx);
-              arg[e] = cf * (s * s);
-            }
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = amp * exp(arg[e]);
-        }
-#pragma unroll
-        for (int d = D - 1; d > 0; --d)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) st[d][e] = st[d - 1][e];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) st[0][e] = v[e];
-      } else {
-        // ---------------- binary: combine st[1] (first evaluated) and st[0], pop ----------------
-        if (o == OP_PLUS) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) st[0][e] = st[1][e] + st[0][e];
-        } else if (o == OP_TIMES) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) st[0][e] = st[1][e] * st[0][e];
-        } else {
-          const double* sg = sig + cpi * 256;
-          const double sr0 = sg[r0], sr1 = sg[r0 + 1];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const double si = (e & 1) ? sr1 : sr0;
-            const double sj = sg[NB + c0 + (e >> 1)];
-            const double kl = (o == OP_CP) ? st[1][e] : st[0][e];
-            const double kr = (o == OP_CP) ? st[0][e] : st[1][e];
-            // K = sig_1 .* k_1 + sig_2 .* k_2   (src/GP.jl:494-501)
-            st[0][e] = (si * sj) * kl + ((1.0 - si) * (1.0 - sj)) * kr;
-          }
-          ++cpi;
-        }
-#pragma unroll
-        for (int d = 1; d < D - 1; ++d)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) st[d][e] = st[d + 1][e];
-      }
-      q += prm_count(o);
+    for (int e = 0; e < 8; ++e) {
+      tr[e] = (e & 1) ? tr1 : tr0;
+      tc[e] = tpt[NB + c0 + (e >> 1)];
+      ri[e] = r0 + (e & 1);
+      ci[e] = NB + c0 + (e >> 1);
     }
-
-    // ---- noise on the training diagonal, identity on padding, store ----
+    eval_program<D, 8>(h, ops, prm, sig, tr, tc, ri, ci, out);
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
       const int gj = tj * NB + c0 + cc;
-      const bool vj = (gj < a.n1) || (gj >= a.n1_pad && gj < a.n1_pad + a.m2);
-      double v0 = (vi0 && vj) ? st[0][2 * cc] : 0.0;
-      double v1 = (vi1 && vj) ? st[0][2 * cc + 1] : 0.0;
-      if (gi0 == gj) v0 = vi0 ? (v0 + (gi0 < a.n1 ? noise : 0.0)) : 1.0;
-      if (gi0 + 1 == gj) v1 = vi1 ? (v1 + (gi0 + 1 < a.n1 ? noise : 0.0)) : 1.0;
-      d2 out; out.x = v0; out.y = v1;
-      *reinterpret_cast<d2*>(T + (long long)(c0 + cc) * NB + r0) = out;
+      d2 o2;
+      o2.x = cov_finalize(out[2 * cc], gi0, gj, a.n1, a.n1_pad, a.m2, noise);
+      o2.y = cov_finalize(out[2 * cc + 1], gi0 + 1, gj, a.n1, a.n1_pad, a.m2, noise);
+      *reinterpret_cast<d2*>(T + (long long)(c0 + cc) * NB + r0) = o2;
     }
   }
 }

@@ -5,11 +5,13 @@
 #include "agp_common.hpp"
 #include "agp_cov_kernel.hpp"
 #include "agp_chol_kernel.hpp"
+#include "agp_experiments.hpp"
 
 #include <algorithm>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -38,12 +40,12 @@ struct DevBuf {
 struct Slot {
   hipStream_t stream = nullptr;
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
-      pred_mean, pred_var, pred_cov, dense;
+      pred_mean, pred_var, pred_cov, dense, map;
   std::vector<hipEvent_t> events;
   bool busy = false;
   void release() {
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
-                      &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense})
+                      &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map})
       b->release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
@@ -70,7 +72,9 @@ struct agp_ctx {
   int64_t ws_limit = 0;
   size_t total_mem = 0;
   bool profiling = false;
+  int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
 };
 
 namespace {
@@ -217,38 +221,80 @@ const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, in
 }
 
 struct Batch {
-  std::vector<ProgHdr> hdr;
+  std::vector<ProgHdr> hdr;       // in SORTED order
   std::vector<uint8_t> ops;
   std::vector<double> prm;
+  std::vector<int32_t> order;     // sorted position -> caller's particle index
+  int n_fused = 0;                // sorted positions [0, n_fused) are evaluated inside k_chol_update
   int max_cp = 0;
   int max_depth = 1;
+  int max_cp_fused = 0, max_depth_fused = 1;
 };
+
+// Measured cost of evaluating one 128x128 tile of a leaf inside k_chol_update (microseconds, MI355X).
+double op_cost_us(int op) {
+  switch (op) {
+    case OP_GE: return 76.0;
+    case OP_PER: return 30.0;
+    case OP_SE: return 9.0;
+    case OP_LIN: return 2.0;
+    case OP_CP: case OP_CP_SWAP: return 2.0;
+    default: return 0.6;
+  }
+}
+// A tile evaluation longer than this is not hidden by the co-resident workgroup's GEMM phase and
+// would set the duration of the short launches; such particles get their tiles from k_cov_tiles.
+constexpr double FUSE_MAX_TILE_US = 160.0;
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                   const double* prm, Batch& bt) {
-  bt.hdr.resize(P);
+  std::vector<Compiled> cps(P);
+  std::vector<double> cost(P, 0.0);
   for (int p = 0; p < P; ++p) {
-    Compiled cp;
     const char* e = compile_program(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p],
-                                    prm_off[p + 1] - prm_off[p], cp);
+                                    prm_off[p + 1] - prm_off[p], cps[p]);
     if (e) {
       char buf[256];
       snprintf(buf, sizeof buf, "particle %d: %s", p, e);
       return fail(c, AGP_ERR_PROGRAM, buf);
     }
+    for (uint8_t o : cps[p].ops) cost[p] += op_cost_us(o);
+  }
+  // Sort: fused particles first, most expensive evaluation first (their workgroups are dispatched
+  // first inside every launch); particles whose tiles are prebuilt go last.
+  const bool fuse_on = c->fuse_mode == 1 || (c->fuse_mode < 0 && P >= 256);
+  auto fusable = [&](int p) { return fuse_on && cost[p] <= FUSE_MAX_TILE_US && cps[p].n_cp <= U_MAX_CP; };
+  bt.order.resize(P);
+  for (int p = 0; p < P; ++p) bt.order[p] = p;
+  std::stable_sort(bt.order.begin(), bt.order.end(), [&](int a, int b) {
+    const bool fa = fusable(a), fb = fusable(b);
+    if (fa != fb) return fa;
+    return fa ? cost[a] > cost[b] : false;
+  });
+  bt.hdr.resize(P);
+  for (int q = 0; q < P; ++q) {
+    const Compiled& cp = cps[bt.order[q]];
     ProgHdr h;
     h.op_off = (int32_t)bt.ops.size();
     h.prm_off = (int32_t)bt.prm.size();
     h.n_ops = (int32_t)cp.ops.size();
     h.n_cp = cp.n_cp;
-    bt.hdr[p] = h;
+    h.n_prm = (int32_t)cp.prm.size();
+    h.pad_ = 0;
+    bt.hdr[q] = h;
     bt.ops.insert(bt.ops.end(), cp.ops.begin(), cp.ops.end());
     bt.prm.insert(bt.prm.end(), cp.prm.begin(), cp.prm.end());
     bt.max_cp = std::max(bt.max_cp, cp.n_cp);
     bt.max_depth = std::max(bt.max_depth, cp.depth_need);
+    if (fusable(bt.order[q])) {
+      bt.n_fused = q + 1;
+      bt.max_cp_fused = std::max(bt.max_cp_fused, cp.n_cp);
+      bt.max_depth_fused = std::max(bt.max_depth_fused, cp.depth_need);
+    }
   }
-  // keep ops 4-byte padded
+  // keep ops 4-byte padded; the evaluator reads three parameters per leaf unconditionally
   while (bt.ops.size() % 4) bt.ops.push_back(0);
+  bt.prm.push_back(0.0); bt.prm.push_back(0.0);
   return AGP_OK;
 }
 
@@ -262,6 +308,7 @@ int64_t ws_limit_bytes(agp_ctx* c) {
 }
 
 hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int max_cp, int depth) {
+  if (ntiles <= 0 || P <= 0) return hipSuccess;
   const size_t lds = (256 + (size_t)max_cp * 256) * sizeof(double);
   dim3 grid(ntiles, P), block(256);
   if (depth <= 4) {
@@ -276,6 +323,20 @@ hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int 
     hipLaunchKernelGGL(k_cov_tiles<8>, grid, block, lds, st, ca);
   }
   return hipGetLastError();
+}
+
+// DCOV selection: 0 = tiles are resident (agp_debug_cholesky / unfused fallback), 4 / 8 = evaluate the
+// kernel program in the update kernel with that evaluation-stack depth.
+template <bool FACTOR>
+void launch_update(int dcov, int grid, hipStream_t st, const CholArgs& ca) {
+  if (dcov == 0) hipLaunchKernelGGL((k_chol_update<FACTOR, 0>), dim3(grid), dim3(256), 0, st, ca);
+  else if (dcov <= 4) hipLaunchKernelGGL((k_chol_update<FACTOR, 4>), dim3(grid), dim3(256), 0, st, ca);
+  else hipLaunchKernelGGL((k_chol_update<FACTOR, 8>), dim3(grid), dim3(256), 0, st, ca);
+}
+
+inline void set_cov(CholArgs& ca, const CovArgs& cv) {
+  ca.tt = cv.tt; ca.n1 = cv.n1; ca.n1_pad = cv.n1_pad; ca.m2 = cv.m2;
+  ca.hdr = cv.hdr; ca.ops = cv.ops; ca.prm = cv.prm; ca.noise = cv.noise;
 }
 
 struct Prof {
@@ -294,16 +355,21 @@ struct Prof {
   void span(int kind, size_t a, size_t b) { if (on) spans.push_back({kind, {a, b}}); }
   void collect(double* acc) {   // after stream sync
     if (!on) return;
+    std::vector<double> u, t;
     for (auto& sp : spans) {
       float ms = 0.f;
       (void)hipEventElapsedTime(&ms, s->events[sp.second.first], s->events[sp.second.second]);
       acc[sp.first] += ms;
+      if (sp.first == 2) u.push_back(ms);
+      if (sp.first == 3) t.push_back(ms);
     }
+    std::lock_guard<std::mutex> g(c->mu);
+    c->upd_ms.swap(u); c->trsm_ms.swap(t);
   }
 };
 
 // Factor block columns [0, nfac) of the joint (nt x nt tiles) matrices of Pc particles.
-hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, Prof* pf, double* counts) {
+hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, Prof* pf, double* counts) {
   for (int k = 0; k < nfac; ++k) {
     ca.k = k;
     const int Pg = (ca.P + 7) / 8;
@@ -312,7 +378,7 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, Prof* pf, double* c
       const int T = (k == 0) ? 1 : ca.nt - k;
       ca.tiles = T;
       size_t e0 = pf ? pf->mark() : 0;
-      hipLaunchKernelGGL(k_chol_update<true>, dim3(8 * Pg * T), dim3(256), 0, st, ca);
+      launch_update<true>(dcov, 8 * Pg * T, st, ca);
       size_t e1 = pf ? pf->mark() : 0;
       if (pf) pf->span(2, e0, e1);
       if (counts) counts[0] += 1;
@@ -385,7 +451,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     HIPCHK(c, hipMemcpyAsync(s->ops.p, bt.ops.data(), bt.ops.size(), hipMemcpyHostToDevice, st));
     if (!bt.prm.empty())
       HIPCHK(c, hipMemcpyAsync(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(s->noise.p, noise, sizeof(double) * P, hipMemcpyHostToDevice, st));
+    std::vector<double> noise_sorted(P);
+    for (int q = 0; q < P; ++q) noise_sorted[q] = noise[bt.order[q]];
+    HIPCHK(c, s->map.ensure(sizeof(int32_t) * (size_t)P));
+    HIPCHK(c, hipMemcpyAsync(s->noise.p, noise_sorted.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(s->map.p, bt.order.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
     size_t ev_h2d = pf.mark();
     pf.span(7, ev_begin, ev_h2d);
 
@@ -397,8 +467,17 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       cv.tt = c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
       cv.hdr = s->hdr.as<ProgHdr>() + p0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
       cv.noise = s->noise.as<double>() + p0; cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = Pc;
+      // Hybrid build.  Sorted particles [0, n_fused) evaluate their own tiles inside k_chol_update
+      // (only the sub-diagonal tiles of block column 0, which k_chol_trsm(0) reads, are
+      // materialised); the few expensive particles behind them get every tile from k_cov_tiles,
+      // where 136 tiles per particle absorb the cost instead of one workgroup per launch.
+      const int nf = std::max(0, std::min(Pc, bt.n_fused - p0));
+      const int dcov = nf > 0 ? bt.max_depth_fused : 0;
       size_t e0 = pf.mark();
-      HIPCHK(c, launch_cov(st, cv, ntiles, Pc, bt.max_cp, bt.max_depth));
+      cv.col0_only = 1; cv.p_off = 0;
+      HIPCHK(c, launch_cov(st, cv, nt - 1, nf, bt.max_cp_fused, bt.max_depth_fused));
+      cv.col0_only = 0; cv.p_off = nf;
+      HIPCHK(c, launch_cov(st, cv, ntiles, Pc - nf, bt.max_cp, bt.max_depth));
       size_t e1 = pf.mark();
       pf.span(1, e0, e1);
 
@@ -406,11 +485,13 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>();
       ca.vec = s->vec.as<double>(); ca.ldv = n_pad; ca.partial = s->partial.as<double>();
       ca.info = s->info.as<int>(); ca.P = Pc; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
-      HIPCHK(c, run_factor(st, ca, nt, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr));
+      set_cov(ca, cv);
+      ca.n_fused = nf;
+      HIPCHK(c, run_factor(st, ca, nt, dcov, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr));
 
       size_t e2 = pf.mark();
       hipLaunchKernelGGL(k_finish_logpdf, dim3((Pc + 63) / 64), dim3(64), 0, st, s->partial.as<double>(),
-                         s->info.as<int>(), nt, Pc, (int)n, d_lp + p0, d_info_out + p0);
+                         s->info.as<int>(), nt, Pc, (int)n, s->map.as<int>() + p0, d_lp, d_info_out);
       size_t e3 = pf.mark();
       pf.span(4, e2, e3);
       HIPCHK(c, hipGetLastError());
@@ -434,6 +515,12 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
 }
 
 }  // namespace
+
+template <int VAR>
+static void launch_variant(hipStream_t st, int grid, const CholArgs& ca) {
+  hipLaunchKernelGGL(k_gemm_variant<VAR>, dim3(grid), dim3(256), 0, st, ca);
+}
+
 
 // ==========================================================================================
 extern "C" {
@@ -461,6 +548,7 @@ int agp_init(agp_ctx** out, int device_id) {
   size_t free_b = 0, tot_b = 0;
   (void)hipMemGetInfo(&free_b, &tot_b);
   c->total_mem = free_b ? free_b : tot_b;
+  if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
   *out = c;
   return AGP_OK;
 }
@@ -498,6 +586,14 @@ int agp_get_timing(agp_ctx* c, double* out, int32_t n_out) {
   std::lock_guard<std::mutex> g(c->mu);
   for (int i = 0; i < n_out && i < 8; ++i) out[i] = c->timing[i];
   return AGP_OK;
+}
+
+int agp_get_launch_times(agp_ctx* c, int32_t which, double* out, int32_t n_out) {
+  if (!c || !out) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  const std::vector<double>& v = which == 0 ? c->upd_ms : c->trsm_ms;
+  for (int i = 0; i < n_out; ++i) out[i] = i < (int)v.size() ? v[i] : -1.0;
+  return (int)v.size();
 }
 
 int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) {
@@ -580,8 +676,12 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   std::vector<double> tt((size_t)ntot, 0.0);
   std::copy(c->h_ts.begin(), c->h_ts.begin() + n, tt.begin());
   std::copy(ts_pred, ts_pred + m, tt.begin() + n1_pad);
-  std::vector<double> npred(P);
-  for (int p = 0; p < P; ++p) npred[p] = noise_pred ? noise_pred[p] : noise[p];
+  std::vector<double> npred(P), noise_sorted(P);
+  for (int q = 0; q < P; ++q) {
+    const int p = bt.order[q];
+    noise_sorted[q] = noise[p];
+    npred[q] = noise_pred ? noise_pred[p] : noise[p];
+  }
 
   HIPCHK(c, s->A.ensure((size_t)bytes_pp * chunk));
   HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256 * (size_t)chunk));
@@ -609,10 +709,11 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   HIPCHK(c, hipMemcpyAsync(s->ops.p, bt.ops.data(), bt.ops.size(), hipMemcpyHostToDevice, st));
   if (!bt.prm.empty())
     HIPCHK(c, hipMemcpyAsync(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(s->noise.p, noise, sizeof(double) * P, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->noise.p, noise_sorted.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(s->noise_pred.p, npred.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(s->tt.p, tt.data(), sizeof(double) * ntot, hipMemcpyHostToDevice, st));
 
+  std::vector<double> h_mean, h_var;
   for (int p0 = 0; p0 < P; p0 += chunk) {
     const int Pc = std::min(chunk, P - p0);
     hipLaunchKernelGGL(k_init_vec, dim3((ntot + 255) / 256, Pc), dim3(256), 0, st, s->vec.as<double>(), ntot,
@@ -622,19 +723,26 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
     cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n1_pad; cv.m2 = (int)m; cv.nt = nt;
     cv.hdr = s->hdr.as<ProgHdr>() + p0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
     cv.noise = s->noise.as<double>() + p0; cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = Pc;
-    HIPCHK(c, launch_cov(st, cv, ntiles, Pc, bt.max_cp, bt.max_depth));
+    const int nf = std::max(0, std::min(Pc, bt.n_fused - p0));
+    const int dcov = nf > 0 ? bt.max_depth_fused : 0;
+    cv.col0_only = 1; cv.p_off = 0;
+    HIPCHK(c, launch_cov(st, cv, nt1 > 0 ? nt - 1 : 0, nf, bt.max_cp_fused, bt.max_depth_fused));
+    cv.col0_only = 0; cv.p_off = nf;
+    HIPCHK(c, launch_cov(st, cv, ntiles, Pc - nf, bt.max_cp, bt.max_depth));
 
     CholArgs ca;
     ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>();
     ca.vec = s->vec.as<double>(); ca.ldv = ntot; ca.partial = s->partial.as<double>();
     ca.info = s->info.as<int>() + p0; ca.P = Pc; ca.nt = nt; ca.k = 0; ca.nt1 = nt1;
-    HIPCHK(c, run_factor(st, ca, nt1, nullptr, nullptr));
+    set_cov(ca, cv);
+    ca.n_fused = nf;
+    HIPCHK(c, run_factor(st, ca, nt1, dcov, nullptr, nullptr));
     {
       // Schur complement of the prediction block + (-V^T alpha); with nt1 == 0 this just
       // passes K22 through.
       const int T = nt2 * (nt2 + 1) / 2;
       const int Pg = (Pc + 7) / 8;
-      hipLaunchKernelGGL(k_chol_update<false>, dim3(8 * Pg * T), dim3(256), 0, st, ca);
+      launch_update<false>(dcov, 8 * Pg * T, st, ca);
     }
     PredArgs pa;
     pa.A = s->A.as<double>(); pa.strideA = strideA; pa.vec = s->vec.as<double>(); pa.ldv = ntot;
@@ -645,15 +753,26 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
     const long long nel = out_cov ? (long long)m * m : (long long)m;
     hipLaunchKernelGGL(k_pred_extract, dim3((unsigned)((nel + 255) / 256), Pc), dim3(256), 0, st, pa);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(out_mean + (size_t)p0 * m, s->pred_mean.p, sizeof(double) * m * Pc, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(out_var + (size_t)p0 * m, s->pred_var.p, sizeof(double) * m * Pc, hipMemcpyDeviceToHost, st));
-    if (out_cov)
-      HIPCHK(c, hipMemcpyAsync(out_cov + (size_t)p0 * m * m, s->pred_cov.p, sizeof(double) * m * m * Pc, hipMemcpyDeviceToHost, st));
+    // results come back in sorted order: scatter to the caller's particle order
+    h_mean.resize((size_t)m * Pc); h_var.resize((size_t)m * Pc);
+    HIPCHK(c, hipMemcpyAsync(h_mean.data(), s->pred_mean.p, sizeof(double) * m * Pc, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_var.data(), s->pred_var.p, sizeof(double) * m * Pc, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int q = 0; q < Pc; ++q) {
+      const size_t o = (size_t)bt.order[p0 + q];
+      std::memcpy(out_mean + o * m, h_mean.data() + (size_t)q * m, sizeof(double) * m);
+      std::memcpy(out_var + o * m, h_var.data() + (size_t)q * m, sizeof(double) * m);
+      if (out_cov)
+        HIPCHK(c, hipMemcpyAsync(out_cov + o * m * m, s->pred_cov.as<double>() + (size_t)q * m * m,
+                                 sizeof(double) * m * m, hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(c, hipStreamSynchronize(st));
   }
   if (out_info) {
-    HIPCHK(c, hipMemcpyAsync(out_info, s->info.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
+    std::vector<int32_t> info_sorted(P);
+    HIPCHK(c, hipMemcpyAsync(info_sorted.data(), s->info.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    for (int q = 0; q < P; ++q) out_info[bt.order[q]] = info_sorted[q];
     for (int p = 0; p < P; ++p)
       if (out_info[p] != 0) {
         const double nanv = std::nan("");
@@ -700,6 +819,7 @@ int agp_cov_matrix(agp_ctx* c, const double* ts, int64_t n, const uint8_t* ops, 
   cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
   cv.hdr = s->hdr.as<ProgHdr>(); cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
   cv.noise = s->noise.as<double>(); cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = 1;
+  cv.col0_only = 0; cv.p_off = 0;
   HIPCHK(c, launch_cov(st, cv, ntiles, 1, bt.max_cp, bt.max_depth));
   const long long nel = (long long)n * n;
   hipLaunchKernelGGL(k_unpack_dense, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, s->A.as<double>(),
@@ -736,7 +856,8 @@ int agp_debug_cholesky(agp_ctx* c, const double* K, int64_t n, double* out_L, in
   ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>(); ca.vec = s->vec.as<double>();
   ca.ldv = n_pad; ca.partial = s->partial.as<double>(); ca.info = s->info.as<int>(); ca.P = 1; ca.nt = nt;
   ca.k = 0; ca.nt1 = nt;
-  HIPCHK(c, run_factor(st, ca, nt, nullptr, nullptr));
+  ca.tt = nullptr; ca.hdr = nullptr; ca.ops = nullptr; ca.prm = nullptr; ca.noise = nullptr; ca.n1 = ca.n1_pad = ca.m2 = 0; ca.n_fused = 0;
+  HIPCHK(c, run_factor(st, ca, nt, 0, nullptr, nullptr));
   hipLaunchKernelGGL(k_unpack_dense, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, s->A.as<double>(),
                      (int)n, 1, s->dense.as<double>());
   HIPCHK(c, hipGetLastError());
@@ -771,6 +892,67 @@ int agp_debug_mfma_peak(agp_ctx* c, int32_t iters, int32_t wg_per_cu, double* ou
   *out_tflops = flops / (ms * 1e-3) / 1e12;
   *out_ghz = mean_cyc / (ms * 1e-3) / 1e9;     // shader cycles per second while the kernel ran
   (void)hipFree(d_out); (void)hipFree(d_cyc); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return AGP_OK;
+}
+
+int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t variant, int32_t reps, double* out_ms) {
+  if (!c || !out_ms || P <= 0 || nt < 2 || k < 1 || k >= nt - 0) return fail(c, AGP_ERR_ARG, "bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+  const int ntiles = nt * (nt + 1) / 2;
+  const long long strideA = (long long)ntiles * NB2;
+  HIPCHK(c, s->A.ensure((size_t)strideA * 8 * P));
+  hipLaunchKernelGGL(k_fill_pseudo, dim3(4096), dim3(256), 0, st, s->A.as<double>(), strideA * P);
+  CholArgs ca;
+  ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = nullptr; ca.vec = nullptr; ca.ldv = 0; ca.partial = nullptr;
+  ca.info = nullptr; ca.P = P; ca.nt = nt; ca.k = k; ca.nt1 = nt; ca.tiles = nt - k - 1;
+  if (ca.tiles < 1) return fail(c, AGP_ERR_ARG, "no off-diagonal tiles");
+  const int grid = 8 * ((P + 7) / 8) * ca.tiles;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  for (int r = 0; r < reps + 1; ++r) {
+    if (r == 1) HIPCHK(c, hipEventRecord(e0, st));
+    switch (variant) {
+      case 0: launch_variant<0>(st, grid, ca); break;
+      case 1: launch_variant<1>(st, grid, ca); break;
+      case 3: launch_variant<3>(st, grid, ca); break;
+      case 7: launch_variant<7>(st, grid, ca); break;
+      case 8: launch_variant<8>(st, grid, ca); break;
+      case 16: launch_variant<16>(st, grid, ca); break;
+      case 19: launch_variant<19>(st, grid, ca); break;
+      case 23: launch_variant<23>(st, grid, ca); break;
+      case 24: launch_variant<24>(st, grid, ca); break;
+      case 40: launch_variant<40>(st, grid, ca); break;
+      case 104: launch_variant<104>(st, grid, ca); break;
+      default: return fail(c, AGP_ERR_ARG, "unknown variant");
+    }
+  }
+  HIPCHK(c, hipEventRecord(e1, st));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  *out_ms = ms / reps;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  HIPCHK(c, hipGetLastError());
+  return AGP_OK;
+}
+
+int agp_debug_math(agp_ctx* c, int32_t which, const double* x, const double* g, double* y, int32_t n) {
+  if (!c || !x || !y || n <= 0 || (which == 3 && !g)) return fail(c, AGP_ERR_ARG, "bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  double *dx = nullptr, *dg = nullptr, *dy = nullptr;
+  HIPCHK(c, hipMalloc((void**)&dx, sizeof(double) * n));
+  HIPCHK(c, hipMalloc((void**)&dg, sizeof(double) * n));
+  HIPCHK(c, hipMalloc((void**)&dy, sizeof(double) * n));
+  HIPCHK(c, hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  if (g) HIPCHK(c, hipMemcpy(dg, g, sizeof(double) * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_math_probe, dim3((n + 255) / 256), dim3(256), 0, 0, which, dx, dg, dy, n);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpy(y, dy, sizeof(double) * n, hipMemcpyDeviceToHost));
+  (void)hipFree(dx); (void)hipFree(dg); (void)hipFree(dy);
   return AGP_OK;
 }
 

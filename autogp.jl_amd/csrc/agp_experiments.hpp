@@ -1,0 +1,158 @@
+// Ablation / variant harness for the update GEMM (measurement only; reached through
+// agp_debug_gemm_variant).  Same tile walk as k_chol_update for the off-diagonal tiles of one block
+// column, with parts of the pipeline switched off to see what each costs.
+#pragma once
+#include "agp_chol_kernel.hpp"
+
+namespace agp {
+
+// VAR bits: 1 = skip global loads, 2 = skip LDS stores + barrier, 4 = constant MFMA operands (no ds_read),
+//           8 = raise priority around the MFMA block, 16 = skip the epilogue read-modify-write
+template <int VAR>
+__global__ __launch_bounds__(256, 2) void k_gemm_variant(CholArgs a) {
+  __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
+  const int b = blockIdx.x;
+  const int xcd = b & 7, qq = b >> 3;
+  const int T = a.tiles;
+  const int pl = qq / T, tl = qq - pl * T;
+  const int tk = a.k, ti = a.k + 1 + tl, jmax = a.k;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, wr = w & 1, wc = w >> 1, l15 = l & 15, lq = l >> 4;
+  double* __restrict__ Ap = a.A + (long long)p * a.strideA;
+  d4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+  double* __restrict__ Tt0 = Ap + tile_off(ti, tk);
+  if (VAR & 32) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[mi][ni][r] = -Tt0[(long long)(wc * 64 + mi * 16 + 4 * r + lq) * NB + wr * 64 + ni * 16 + l15];
+  }
+  const int nslab = jmax * (NB / KB);
+  const int scol0 = tid >> 6, srow = 2 * (tid & 63);
+  d2 ra[4], rb[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) { ra[u] = d2{1e-3 * tid, 2e-3}; rb[u] = d2{3e-3, 1e-3 * tid}; }
+  auto gload = [&](int s) {
+    const int j = s >> 3, cs = (s & 7) * KB;
+    const double* __restrict__ srcA = Ap + tile_off(ti, j) + (long long)cs * NB;
+    const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int off = (scol0 + 4 * u) * NB + srow;
+      ra[u] = *reinterpret_cast<const d2*>(srcA + off);
+      rb[u] = *reinterpret_cast<const d2*>(srcB + off);
+    }
+  };
+  auto lstore = [&](int buf) {
+    double* As = sm + buf * U_SLAB;
+    double* Bs = sm + (2 + buf) * U_SLAB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int off = (scol0 + 4 * u) * LDS_STRIDE + srow;
+      *reinterpret_cast<d2*>(As + off) = ra[u];
+      *reinterpret_cast<d2*>(Bs + off) = rb[u];
+    }
+  };
+  if (!(VAR & 1)) gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (!(VAR & 1) && s + 1 < nslab) gload(s + 1);
+    const double* As = sm + buf * U_SLAB;
+    const double* Bs = sm + (2 + buf) * U_SLAB;
+    if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < KB / 4; ++kk) {
+      const int krow = (kk * 4 + lq) * LDS_STRIDE;
+      double fa[4], fb[4];
+      if (VAR & 4) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) { fa[mi] = 1.0 + 1e-9 * (tid + mi + s); fb[mi] = 1.0 - 1e-9 * (tid + mi + kk); }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa[mi] = Bs[krow + wc * 64 + mi * 16 + l15];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fb[ni] = As[krow + wr * 64 + ni * 16 + l15];
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma(fa[mi], fb[ni], acc[mi][ni]);
+    }
+    if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+    if (!(VAR & 2)) {
+      if (s + 1 < nslab) lstore(buf ^ 1);
+      __syncthreads();
+    }
+  }
+  double* __restrict__ Tt = Ap + tile_off(ti, tk);
+  if (VAR & 16) {
+    double s = 0.0;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) s += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+    if (s == 1.234567) Tt[tid] = s;
+    return;
+  }
+  if (VAR & 64) {
+    // LDS-transposed store: accumulators -> LDS (column-major 128 x 64 half tile, stride 130) -> 16 B stores
+    __syncthreads();
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (wc == half) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              sm[(mi * 16 + 4 * r + lq) * 130 + wr * 64 + ni * 16 + l15] = -acc[mi][ni][r];
+      }
+      __syncthreads();
+      // 64 columns x 128 rows = 4096 d2; 256 threads x 16
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int e = tid + 256 * u;          // d2 index
+        const int c = e >> 6, r2 = (e & 63) * 2;
+        d2 v; v.x = sm[c * 130 + r2]; v.y = sm[c * 130 + r2 + 1];
+        *reinterpret_cast<d2*>(Tt + (long long)(half * 64 + c) * NB + r2) = v;
+      }
+      __syncthreads();
+    }
+    return;
+  }
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int col = wc * 64 + mi * 16 + 4 * r + lq;
+        const int row = wr * 64 + ni * 16 + l15;
+        double* ptr = Tt + (long long)col * NB + row;
+        if (VAR & 32) *ptr = -acc[mi][ni][r];
+        else *ptr = *ptr - acc[mi][ni][r];
+      }
+}
+
+__global__ void k_fill_pseudo(double* A, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    unsigned long long x = (unsigned long long)i * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    A[i] = ((double)(x & 0xFFFFFF) / 16777216.0 - 0.5) * 0.0625;
+  }
+}
+
+}  // namespace agp

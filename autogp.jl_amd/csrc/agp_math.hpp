@@ -1,0 +1,116 @@
+// fp64 elementary functions specialised for the covariance kernels (host + device).
+//
+// The stationary leaves of the reference are amp*exp(arg) with arg <= 0 built from
+//   SE        arg = -0.5 dx^2 / l^2                      (src/GP.jl:241-245)
+//   GammaExp  arg = -(|dx|/l)^gamma, 0 < gamma <= 2      (src/GP.jl:285-289)
+//   Periodic  arg = (-2/l^2) sin(pi/p |dx|)^2            (src/GP.jl:331-336)
+// The generic libm routines spend most of their instructions on ranges and special cases that
+// cannot occur here (negative bases, huge trig arguments, NaN plumbing).  These versions keep
+// double-precision accuracy on the domain that does occur:
+//   exp_f   |rel err| <~ 1.5 ulp for x in [-745, 700]      (Cody-Waite + degree-13 Horner, 1 ldexp)
+//   sin2_f  sin(x)^2, |rel err| <~ 3 ulp for 0 <= x < 2^20 (2-term FMA reduction by pi)
+//   pow_f   u^g for u >= 0, 0 < g: exp(g*log u), rel err <~ (2 + |g log u|) ulp
+// which keeps every covariance entry within ~1e-15*max(1,|arg|) relative of the reference's
+// libm-based value — the reference's own result carries the same |arg|*ulp uncertainty from the
+// rounding of its argument.  Validated against mpmath in tests/test_fastmath.py (CPU build of
+// this header) and through the covariance parity tests on the GPU.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define AGP_HD __host__ __device__ __forceinline__
+#else
+#define AGP_HD inline
+#endif
+
+namespace agp {
+namespace fm {
+
+AGP_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+AGP_HD uint64_t bits_(double x) { return __builtin_bit_cast(uint64_t, x); }
+AGP_HD double dbl_(uint64_t b) { return __builtin_bit_cast(double, b); }
+
+// exp(x).  x*log2(e) rounded to the nearest integer k, r = x - k ln2 in two FMA steps
+// (ln2_hi has 32 trailing zero bits, so k*ln2_hi is exact), e^r by Horner, scale by 2^k.
+AGP_HD double exp_f(double x) {
+  const double L2E = 1.44269504088896338700e+00;
+  const double LN2_HI = 6.93147180369123816490e-01;
+  const double LN2_LO = 1.90821492927058770002e-10;
+  x = x < -800.0 ? -800.0 : x;               // everything below underflows to 0 anyway
+  const double kf = __builtin_rint(x * L2E);
+  double r = fma_(-kf, LN2_HI, x);
+  r = fma_(-kf, LN2_LO, r);
+  double p = 1.6059043836821613e-10;          // 1/13!
+  p = fma_(p, r, 2.08767569878681e-09);       // 1/12!
+  p = fma_(p, r, 2.505210838544172e-08);      // 1/11!
+  p = fma_(p, r, 2.755731922398589e-07);      // 1/10!
+  p = fma_(p, r, 2.7557319223985893e-06);     // 1/9!
+  p = fma_(p, r, 2.48015873015873e-05);       // 1/8!
+  p = fma_(p, r, 1.984126984126984e-04);      // 1/7!
+  p = fma_(p, r, 1.388888888888889e-03);      // 1/6!
+  p = fma_(p, r, 8.333333333333333e-03);      // 1/5!
+  p = fma_(p, r, 4.1666666666666664e-02);     // 1/4!
+  p = fma_(p, r, 1.6666666666666666e-01);     // 1/3!
+  p = fma_(p, r, 0.5);
+  p = fma_(p, r, 1.0);
+  p = fma_(p, r, 1.0);
+  return __builtin_ldexp(p, (int)kf);
+}
+
+// sin(x)^2 for x >= 0: period pi, so reduce to r in [-pi/2, pi/2] and square an odd polynomial.
+AGP_HD double sin2_f(double x) {
+  const double INV_PI = 3.18309886183790691216e-01;
+  const double PI_HI = 3.14159265358979311600e+00;
+  const double PI_LO = 1.22464679914735320717e-16;
+  const double kf = __builtin_rint(x * INV_PI);
+  double r = fma_(-kf, PI_HI, x);
+  r = fma_(-kf, PI_LO, r);
+  const double z = r * r;
+  double p = 3.868170170630684e-23;           //  1/23!
+  p = fma_(p, z, -1.9572941063391263e-20);    // -1/21!
+  p = fma_(p, z, 8.22063524662433e-18);       //  1/19!
+  p = fma_(p, z, -2.8114572543455206e-15);    // -1/17!
+  p = fma_(p, z, 7.647163731819816e-13);      //  1/15!
+  p = fma_(p, z, -1.6059043836821613e-10);    // -1/13!
+  p = fma_(p, z, 2.505210838544172e-08);      //  1/11!
+  p = fma_(p, z, -2.7557319223985893e-06);    // -1/9!
+  p = fma_(p, z, 1.984126984126984e-04);      //  1/7!
+  p = fma_(p, z, -8.333333333333333e-03);     // -1/5!
+  p = fma_(p, z, 1.6666666666666666e-01);     //  1/3!  (applied with a minus below)
+  // sin r = r - r z (1/6 - z(...))  -> s = r * (1 - z*p) with p built with alternating signs above
+  const double s = fma_(-(r * z), p, r);
+  return s * s;
+}
+
+// log(u) for finite u > 0 (fdlibm __ieee754_log kernel, ~1 ulp).
+AGP_HD double log_f(double u) {
+  const double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  int e = 0;
+  if (u < 2.2250738585072014e-308) { u *= 18014398509481984.0; e = -54; }   // subnormal: scale by 2^54
+  const uint64_t b = bits_(u);
+  e += (int)(b >> 52) - 1023;
+  double m = dbl_((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull);       // [1, 2)
+  if (m > 1.41421356237309514547) { m *= 0.5; e += 1; }                       // [sqrt(1/2), sqrt(2))
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma_(w, fma_(w, Lg6, Lg4), Lg2);
+  const double t2 = z * fma_(w, fma_(w, fma_(w, Lg7, Lg5), Lg3), Lg1);
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  return dk * LN2_HI - ((hfsq - (s * (hfsq + R) + dk * LN2_LO)) - f);
+}
+
+// u^g for u >= 0 (0^g = 0 for g > 0, the only zero case the kernels produce: dt = 0).
+AGP_HD double pow_f(double u, double g) {
+  const double y = g * log_f(u > 0.0 ? u : 1.0);
+  const double t = exp_f(y);
+  return u > 0.0 ? t : 0.0;
+}
+
+}  // namespace fm
+}  // namespace agp

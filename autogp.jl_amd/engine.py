@@ -26,7 +26,7 @@ LIB_PATH = _PKG_DIR / "lib" / "libautogp_hip.so"
 EXPORTED_SYMBOLS = [
     "agp_init", "agp_destroy", "agp_last_error", "agp_version", "agp_set_data", "agp_logpdf",
     "agp_logpdf_batch", "agp_logpdf_batch_device", "agp_predict_batch", "agp_cov_matrix",
-    "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_debug_mfma_peak", "agp_set_profiling", "agp_get_timing",
+    "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_debug_mfma_peak", "agp_debug_math", "agp_debug_gemm_variant", "agp_set_profiling", "agp_get_timing", "agp_get_launch_times",
     "agp_set_workspace_limit",
 ]
 
@@ -100,8 +100,11 @@ def load_library(path=None):
     lib.agp_debug_cholesky.argtypes = [vp, dp, C.c_int64, dp, ip]; lib.agp_debug_cholesky.restype = C.c_int
     lib.agp_debug_mfma_probe.argtypes = [vp, dp, dp, dp]; lib.agp_debug_mfma_probe.restype = C.c_int
     lib.agp_debug_mfma_peak.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]; lib.agp_debug_mfma_peak.restype = C.c_int
+    lib.agp_debug_math.argtypes = [vp, C.c_int32, dp, dp, dp, C.c_int32]; lib.agp_debug_math.restype = C.c_int
+    lib.agp_debug_gemm_variant.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp]; lib.agp_debug_gemm_variant.restype = C.c_int
     lib.agp_set_profiling.argtypes = [vp, C.c_int]; lib.agp_set_profiling.restype = C.c_int
     lib.agp_get_timing.argtypes = [vp, dp, C.c_int32]; lib.agp_get_timing.restype = C.c_int
+    lib.agp_get_launch_times.argtypes = [vp, C.c_int32, dp, C.c_int32]; lib.agp_get_launch_times.restype = C.c_int
     lib.agp_set_workspace_limit.argtypes = [vp, C.c_int64]; lib.agp_set_workspace_limit.restype = C.c_int
     if path is None:
         _lib = lib
@@ -251,6 +254,17 @@ class GPEngine:
         self._check(self._lib.agp_debug_mfma_peak(self._ctx, int(iters), int(wg_per_cu), C.byref(tf), C.byref(ghz)))
         return tf.value, ghz.value
 
+    def debug_math(self, which, x, g=None):
+        x = _f64(x); y = np.empty_like(x)
+        g = None if g is None else _f64(g)
+        self._check(self._lib.agp_debug_math(self._ctx, int(which), _dp(x), _dp(g), _dp(y), x.size))
+        return y
+
+    def debug_gemm_variant(self, P, nt, k, variant, reps=5):
+        ms = C.c_double()
+        self._check(self._lib.agp_debug_gemm_variant(self._ctx, P, nt, k, variant, reps, C.byref(ms)))
+        return ms.value
+
     def set_profiling(self, on: bool):
         self._check(self._lib.agp_set_profiling(self._ctx, 1 if on else 0))
 
@@ -260,6 +274,11 @@ class GPEngine:
         keys = ["total_ms", "cov_build_ms", "chol_update_ms", "chol_trsm_ms", "finish_ms", "n_update_launches",
                 "n_trsm_launches", "h2d_ms"]
         return dict(zip(keys, out.tolist()))
+
+    def launch_times(self, which=0, n=64):
+        out = np.zeros(n)
+        cnt = self._lib.agp_get_launch_times(self._ctx, which, _dp(out), n)
+        return out[:max(0, min(cnt, n))]
 
     def set_workspace_limit(self, nbytes: int):
         self._check(self._lib.agp_set_workspace_limit(self._ctx, int(nbytes)))

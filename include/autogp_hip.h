@@ -125,15 +125,26 @@ int agp_debug_cholesky(agp_ctx* ctx, const double* K, int64_t n, double* out_L, 
 /* Probe of the fp64 MFMA fragment layout: D = A(16x4) * B(4x16), row-major host arrays. */
 int agp_debug_mfma_probe(agp_ctx* ctx, const double* A, const double* B, double* D);
 
+/* Element-wise probe of the device math used by the covariance kernels (csrc/agp_math.hpp):
+ * which = 0 exp, 1 sin^2, 2 log, 3 pow(x, g). */
+int agp_debug_math(agp_ctx* ctx, int32_t which, const double* x, const double* g, double* y, int32_t n);
+
 /* fp64 MFMA issue-rate microbenchmark (16 independent accumulators per wave, wg_per_cu
  * workgroups of 4 waves per CU): sustained TFLOP/s and the shader clock while it ran. */
 int agp_debug_mfma_peak(agp_ctx* ctx, int32_t iters, int32_t wg_per_cu, double* out_tflops, double* out_ghz);
+
+/* Ablation harness for the update GEMM (off-diagonal tiles of block column k on pseudo-random data):
+ * average milliseconds per launch for `variant` (see csrc/agp_experiments.hpp). */
+int agp_debug_gemm_variant(agp_ctx* ctx, int32_t P, int32_t nt, int32_t k, int32_t variant, int32_t reps, double* out_ms);
 
 /* When enabled, batch calls bracket their phases with HIP events on the launch stream.
  * agp_get_timing fills out[0..7] = { total_ms, cov_build_ms, chol_update_ms, chol_trsm_ms,
  * finish_ms, n_update_launches, n_trsm_launches, h2d_d2h_ms } for the last batch call. */
 int agp_set_profiling(agp_ctx* ctx, int enabled);
 int agp_get_timing(agp_ctx* ctx, double* out, int32_t n_out);
+/* per-launch durations (ms) of the last profiled batch call: which = 0 update kernel, 1 trsm kernel;
+ * returns the number of launches recorded (>= 0). */
+int agp_get_launch_times(agp_ctx* ctx, int32_t which, double* out, int32_t n_out);
 
 /* Cap (bytes) on matrix workspace per call; larger batches are processed in chunks. 0 = default. */
 int agp_set_workspace_limit(agp_ctx* ctx, int64_t bytes);

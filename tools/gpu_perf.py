@@ -35,4 +35,9 @@ for n, P in ((2048, 512), (2048, 64), (1024, 64), (4096, 128), (256, 8)):
     print(f"n={n} P={P}: {dt*1e3:.2f} ms  {P/dt:.0f} evals/s  {P*n**3/3/dt/1e12:.1f} TF/s  npd={(info>0).sum()} avg_leaves={leaves:.2f} "
           f"cov={tm['cov_build_ms']:.2f} upd={tm['chol_update_ms']:.2f} trsm={tm['chol_trsm_ms']:.2f}")
     res[f"n{n}_P{P}"] = {"ms": dt * 1e3, **tm}
+    if "--launches" in sys.argv:
+        u = eng.launch_times(0); t = eng.launch_times(1); nt = (n + 127) // 128
+        for k in range(len(u)):
+            fl = P * (nt - k) * 2 * 128 * 128 * (k * 128)
+            print(f"   k={k:2d} upd {u[k]*1e3:8.1f} us {fl/u[k]/1e9 if u[k]>0 else 0:6.1f} TF/s" + (f"   trsm {t[k]*1e3:7.1f} us" if k < len(t) else ""))
 (ROOT / "gpurun_out" / "perf.json").write_text(json.dumps(res, indent=1))
