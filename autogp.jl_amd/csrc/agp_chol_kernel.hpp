@@ -409,8 +409,17 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 }
 
 // T — L(i,k) = C(i,k) L(k,k)^-T for the tiles below the diagonal of block column k.
-// One workgroup per tile; each wave solves two 16-row strips in MFMA registers.
+// One workgroup per tile; each wave solves two 16-row strips in MFMA registers.  The 28 strictly
+// lower 16x16 blocks of L(k,k) (negated) and the 8 diagonal-block inverses are staged once per
+// workgroup in LDS in A-operand order (column-major 16x16 blocks: fragment s of lane l sits at
+// 64 s + l, conflict-free), so no MFMA waits on a global load.
+constexpr int T_NBLK = NSB * (NSB - 1) / 2;              // 28 strictly-lower blocks
+constexpr int T_LDS_DOUBLES = (T_NBLK + NSB) * 256;      // + 8 inverse blocks = 72 KiB
+
+__device__ __forceinline__ int sblk_idx(int jb, int lb) { return jb * (jb - 1) / 2 + lb; }   // lb < jb
+
 __global__ __launch_bounds__(256, 2) void k_chol_trsm(CholArgs a) {
+  __shared__ __attribute__((aligned(16))) double ls[T_LDS_DOUBLES];
   const int b = blockIdx.x;
   const int xcd = b & 7, qq = b >> 3;
   const int T = a.nt - a.k - 1;
@@ -428,23 +437,45 @@ __global__ __launch_bounds__(256, 2) void k_chol_trsm(CholArgs a) {
   double* __restrict__ Tt = Ap + tile_off(ti, a.k);
   const double* __restrict__ Wg = a.W + (long long)p * NSB * 256;
 
+  // ---- stage -L(k,k) blocks and W blocks ----
+  {
+    const int c = tid >> 4, r = tid & 15;
+#pragma unroll
+    for (int jb = 1; jb < NSB; ++jb)
+#pragma unroll
+      for (int lb = 0; lb < jb; ++lb)
+        ls[sblk_idx(jb, lb) * 256 + tid] = -Lkk[(lb * 16 + c) * NB + jb * 16 + r];
+    double* lw = ls + T_NBLK * 256;
+#pragma unroll
+    for (int u = 0; u < NSB; ++u) lw[u * 256 + tid] = Wg[u * 256 + tid];
+  }
+  // right-hand-side blocks are fetched one block column ahead of their use (the first one while
+  // the staging loads are still in flight)
   d4 X[2][NSB];
+  d4 nxt[2];
+#pragma unroll
+  for (int st = 0; st < 2; ++st)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nxt[st][r] = Tt[(4 * r + lq) * NB + (2 * w + st) * 16 + l15];
+  __syncthreads();
+  const double* lw = ls + T_NBLK * 256;
+
 #pragma unroll
   for (int jb = 0; jb < NSB; ++jb) {
-    d4 acc[2];
+    d4 acc[2] = {nxt[0], nxt[1]};
+    if (jb + 1 < NSB) {
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-      const int R0 = (2 * w + st) * 16;
+      for (int st = 0; st < 2; ++st)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[st][r] = Tt[(jb * 16 + 4 * r + lq) * NB + R0 + l15];
+        for (int r = 0; r < 4; ++r)
+          nxt[st][r] = Tt[((jb + 1) * 16 + 4 * r + lq) * NB + (2 * w + st) * 16 + l15];
     }
 #pragma unroll
     for (int lb = 0; lb < jb; ++lb) {
+      const double* blk = ls + sblk_idx(jb, lb) * 256;
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        // -L(k,k)[jb*16 + l15][lb*16 + 4 s4 + lq]
-        const double fl = -Lkk[(lb * 16 + 4 * s4 + lq) * NB + jb * 16 + l15];
+        const double fl = blk[64 * s4 + l];      // -L(k,k)[jb*16 + l15][lb*16 + 4 s4 + lq]
         acc[0] = mfma(fl, X[0][lb][s4], acc[0]);
         acc[1] = mfma(fl, X[1][lb][s4], acc[1]);
       }
@@ -452,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_trsm(CholArgs a) {
     d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      const double fw = Wg[jb * 256 + 64 * s4 + l];   // W_jb[l15][4 s4 + lq]
+      const double fw = lw[jb * 256 + 64 * s4 + l];   // W_jb[l15][4 s4 + lq]
       x0 = mfma(fw, acc[0][s4], x0);
       x1 = mfma(fw, acc[1][s4], x1);
     }

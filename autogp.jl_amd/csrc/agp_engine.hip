@@ -42,6 +42,8 @@ struct Slot {
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map;
   std::vector<hipEvent_t> events;
+  std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
+  std::vector<hipEvent_t> sub_ev;     // fork / join events
   bool busy = false;
   void release() {
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
@@ -49,6 +51,10 @@ struct Slot {
       b->release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
+    for (auto e : sub_ev) (void)hipEventDestroy(e);
+    sub_ev.clear();
+    for (auto q : sub) (void)hipStreamDestroy(q);
+    sub.clear();
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
   }
@@ -72,6 +78,7 @@ struct agp_ctx {
   int64_t ws_limit = 0;
   size_t total_mem = 0;
   bool profiling = false;
+  int n_streams = 1;    // sub-batches of one call run on this many streams (env AGP_STREAMS)
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
@@ -348,9 +355,10 @@ struct Prof {
     }
     return s->events[next++];
   }
-  size_t mark() {
+  size_t mark() { return mark(st); }
+  size_t mark(hipStream_t q) {
     if (!on) return 0;
-    size_t i = next; hipEvent_t e = ev(); (void)hipEventRecord(e, st); return i;
+    size_t i = next; hipEvent_t e = ev(); (void)hipEventRecord(e, q); return i;
   }
   void span(int kind, size_t a, size_t b) { if (on) spans.push_back({kind, {a, b}}); }
   void collect(double* acc) {   // after stream sync
@@ -370,6 +378,7 @@ struct Prof {
 
 // Factor block columns [0, nfac) of the joint (nt x nt tiles) matrices of Pc particles.
 hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, Prof* pf, double* counts) {
+  // (profiling marks are recorded on the stream the kernels are launched on)
   for (int k = 0; k < nfac; ++k) {
     ca.k = k;
     const int Pg = (ca.P + 7) / 8;
@@ -377,17 +386,17 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, Prof* pf,
       // block column 0 has nothing to subtract: only the diagonal tiles need a workgroup
       const int T = (k == 0) ? 1 : ca.nt - k;
       ca.tiles = T;
-      size_t e0 = pf ? pf->mark() : 0;
+      size_t e0 = pf ? pf->mark(st) : 0;
       launch_update<true>(dcov, 8 * Pg * T, st, ca);
-      size_t e1 = pf ? pf->mark() : 0;
+      size_t e1 = pf ? pf->mark(st) : 0;
       if (pf) pf->span(2, e0, e1);
       if (counts) counts[0] += 1;
     }
     const int T2 = ca.nt - k - 1;
     if (T2 > 0) {
-      size_t e0 = pf ? pf->mark() : 0;
+      size_t e0 = pf ? pf->mark(st) : 0;
       hipLaunchKernelGGL(k_chol_trsm, dim3(8 * Pg * T2), dim3(256), 0, st, ca);
-      size_t e1 = pf ? pf->mark() : 0;
+      size_t e1 = pf ? pf->mark(st) : 0;
       if (pf) pf->span(3, e0, e1);
       if (counts) counts[1] += 1;
     }
@@ -459,42 +468,70 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     size_t ev_h2d = pf.mark();
     pf.span(7, ev_begin, ev_h2d);
 
+    // Sub-batches of a chunk run on separate streams so that the tail of one sub-batch's launch
+    // (few workgroups left, serial diagonal factorisations) is filled by another sub-batch's bulk.
+    const int S = std::max(1, std::min(c->n_streams, (P + 63) / 64));
+    if (S > 1) {
+      while ((int)s->sub.size() < S - 1) {
+        hipStream_t q; HIPCHK(c, hipStreamCreateWithFlags(&q, hipStreamNonBlocking)); s->sub.push_back(q);
+      }
+      while ((int)s->sub_ev.size() < S) {
+        hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); s->sub_ev.push_back(e);
+      }
+    }
     for (int p0 = 0; p0 < P; p0 += chunk) {
       const int Pc = std::min(chunk, P - p0);
-      hipLaunchKernelGGL(k_init_vec, dim3((n_pad + 255) / 256, Pc), dim3(256), 0, st, s->vec.as<double>(),
-                         n_pad, Pc, c->d_xs, (const double*)nullptr, (int)n, s->info.as<int>());
-      CovArgs cv;
-      cv.tt = c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
-      cv.hdr = s->hdr.as<ProgHdr>() + p0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
-      cv.noise = s->noise.as<double>() + p0; cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = Pc;
-      // Hybrid build.  Sorted particles [0, n_fused) evaluate their own tiles inside k_chol_update
-      // (only the sub-diagonal tiles of block column 0, which k_chol_trsm(0) reads, are
-      // materialised); the few expensive particles behind them get every tile from k_cov_tiles,
-      // where 136 tiles per particle absorb the cost instead of one workgroup per launch.
-      const int nf = std::max(0, std::min(Pc, bt.n_fused - p0));
-      const int dcov = nf > 0 ? bt.max_depth_fused : 0;
-      size_t e0 = pf.mark();
-      cv.col0_only = 1; cv.p_off = 0;
-      HIPCHK(c, launch_cov(st, cv, nt - 1, nf, bt.max_cp_fused, bt.max_depth_fused));
-      cv.col0_only = 0; cv.p_off = nf;
-      HIPCHK(c, launch_cov(st, cv, ntiles, Pc - nf, bt.max_cp, bt.max_depth));
-      size_t e1 = pf.mark();
-      pf.span(1, e0, e1);
+      if (S > 1) {
+        HIPCHK(c, hipEventRecord(s->sub_ev[0], st));
+        for (int g = 1; g < S; ++g) HIPCHK(c, hipStreamWaitEvent(s->sub[g - 1], s->sub_ev[0], 0));
+      }
+      for (int g = 0; g < S; ++g) {
+        const int g0 = (int)((long long)Pc * g / S), g1 = (int)((long long)Pc * (g + 1) / S);
+        const int Pg = g1 - g0;
+        if (Pg <= 0) continue;
+        hipStream_t q = (g == 0) ? st : s->sub[g - 1];
+        hipLaunchKernelGGL(k_init_vec, dim3((n_pad + 255) / 256, Pg), dim3(256), 0, q,
+                           s->vec.as<double>() + (size_t)g0 * n_pad, n_pad, Pg, c->d_xs, (const double*)nullptr, (int)n,
+                           s->info.as<int>() + g0);
+        CovArgs cv;
+        cv.tt = c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
+        cv.hdr = s->hdr.as<ProgHdr>() + p0 + g0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
+        cv.noise = s->noise.as<double>() + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
+        cv.strideA = strideA; cv.P = Pg;
+        // Hybrid build.  Sorted particles [0, n_fused) evaluate their own tiles inside k_chol_update
+        // (only the sub-diagonal tiles of block column 0, which k_chol_trsm(0) reads, are
+        // materialised); the few expensive particles behind them get every tile from k_cov_tiles,
+        // where 136 tiles per particle absorb the cost instead of one workgroup per launch.
+        const int nf = std::max(0, std::min(Pg, bt.n_fused - p0 - g0));
+        const int dcov = nf > 0 ? bt.max_depth_fused : 0;
+        size_t e0 = pf.mark(q);
+        cv.col0_only = 1; cv.p_off = 0;
+        HIPCHK(c, launch_cov(q, cv, nt - 1, nf, bt.max_cp_fused, bt.max_depth_fused));
+        cv.col0_only = 0; cv.p_off = nf;
+        HIPCHK(c, launch_cov(q, cv, ntiles, Pg - nf, bt.max_cp, bt.max_depth));
+        size_t e1 = pf.mark(q);
+        pf.span(1, e0, e1);
 
-      CholArgs ca;
-      ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>();
-      ca.vec = s->vec.as<double>(); ca.ldv = n_pad; ca.partial = s->partial.as<double>();
-      ca.info = s->info.as<int>(); ca.P = Pc; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
-      set_cov(ca, cv);
-      ca.n_fused = nf;
-      HIPCHK(c, run_factor(st, ca, nt, dcov, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr));
+        CholArgs ca;
+        ca.A = cv.A; ca.strideA = strideA; ca.W = s->W.as<double>() + (size_t)g0 * NSB * 256;
+        ca.vec = s->vec.as<double>() + (size_t)g0 * n_pad; ca.ldv = n_pad;
+        ca.partial = s->partial.as<double>() + (size_t)g0 * 2 * nt;
+        ca.info = s->info.as<int>() + g0; ca.P = Pg; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
+        set_cov(ca, cv);
+        ca.n_fused = nf;
+        HIPCHK(c, run_factor(q, ca, nt, dcov, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr));
 
-      size_t e2 = pf.mark();
-      hipLaunchKernelGGL(k_finish_logpdf, dim3((Pc + 63) / 64), dim3(64), 0, st, s->partial.as<double>(),
-                         s->info.as<int>(), nt, Pc, (int)n, s->map.as<int>() + p0, d_lp, d_info_out);
-      size_t e3 = pf.mark();
-      pf.span(4, e2, e3);
-      HIPCHK(c, hipGetLastError());
+        size_t e2 = pf.mark(q);
+        hipLaunchKernelGGL(k_finish_logpdf, dim3((Pg + 63) / 64), dim3(64), 0, q, ca.partial, ca.info, nt, Pg, (int)n,
+                           s->map.as<int>() + p0 + g0, d_lp, d_info_out);
+        size_t e3 = pf.mark(q);
+        pf.span(4, e2, e3);
+        HIPCHK(c, hipGetLastError());
+        if (g > 0) {
+          HIPCHK(c, hipEventRecord(s->sub_ev[g], q));
+          HIPCHK(c, hipStreamWaitEvent(st, s->sub_ev[g], 0));
+        }
+      }
     }
     size_t ev_end = pf.mark();
     pf.span(0, ev_begin, ev_end);
@@ -549,6 +586,7 @@ int agp_init(agp_ctx** out, int device_id) {
   (void)hipMemGetInfo(&free_b, &tot_b);
   c->total_mem = free_b ? free_b : tot_b;
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
+  if (const char* e = getenv("AGP_STREAMS")) c->n_streams = std::max(1, std::min(8, atoi(e)));
   *out = c;
   return AGP_OK;
 }
@@ -927,6 +965,8 @@ int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t
       case 24: launch_variant<24>(st, grid, ca); break;
       case 40: launch_variant<40>(st, grid, ca); break;
       case 104: launch_variant<104>(st, grid, ca); break;
+      case 168: launch_variant<168>(st, grid, ca); break;
+      case 152: launch_variant<152>(st, grid, ca); break;
       default: return fail(c, AGP_ERR_ARG, "unknown variant");
     }
   }

@@ -61,6 +61,49 @@ __global__ __launch_bounds__(256, 2) void k_gemm_variant(CholArgs a) {
       *reinterpret_cast<d2*>(Bs + off) = rb[u];
     }
   };
+  if (VAR & 128) {
+    // direct global -> LDS staging: each wave instruction moves one 1 KiB slab column (128 rows)
+    auto glds = [&](int s, int buf) {
+      const int j = s >> 3, cs = (s & 7) * KB;
+      const double* srcA = Ap + tile_off(ti, j) + (long long)cs * NB;
+      const double* srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
+      double* As = sm + buf * U_SLAB;
+      double* Bs = sm + (2 + buf) * U_SLAB;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int col = w + 4 * u;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA + col * NB + 2 * l),
+                                         (__attribute__((address_space(3))) void*)(As + col * LDS_STRIDE), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB + col * NB + 2 * l),
+                                         (__attribute__((address_space(3))) void*)(Bs + col * LDS_STRIDE), 16, 0, 0);
+      }
+    };
+    glds(0, 0);
+    for (int s = 0; s < nslab; ++s) {
+      const int buf = s & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (s + 1 < nslab) glds(s + 1, buf ^ 1);
+      const double* As = sm + buf * U_SLAB;
+      const double* Bs = sm + (2 + buf) * U_SLAB;
+      if (VAR & 8) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < KB / 4; ++kk) {
+        const int krow = (kk * 4 + lq) * LDS_STRIDE;
+        double fa[4], fb[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) fa[mi] = Bs[krow + wc * 64 + mi * 16 + l15];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fb[ni] = As[krow + wr * 64 + ni * 16 + l15];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma(fa[mi], fb[ni], acc[mi][ni]);
+      }
+      if (VAR & 8) __builtin_amdgcn_s_setprio(0);
+    }
+    __syncthreads();
+  } else {
   if (!(VAR & 1)) gload(0);
   lstore(0);
   __syncthreads();
@@ -93,6 +136,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_variant(CholArgs a) {
       if (s + 1 < nslab) lstore(buf ^ 1);
       __syncthreads();
     }
+  }
   }
   double* __restrict__ Tt = Ap + tile_off(ti, tk);
   if (VAR & 16) {

@@ -50,7 +50,7 @@ for name, col in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 txt = "\n".join(out)
 (ROOT / f"profiles/{tag}_pmc_summary.txt").write_text(txt)
 print(txt)
-upd = [k for k in res if "k_chol_update<true>" in k or "k_chol_step" in k]
+upd = [k for k in res if "k_chol_update<true" in k]
 if upd and "fetch" in res[upd[0]] and "write" in res[upd[0]]:
     tot = res[upd[0]]["fetch"] + res[upd[0]]["write"]
     (ROOT / "profiles/hbm_traffic.json").write_text(json.dumps({

@@ -23,7 +23,7 @@ def main():
     for k, v in res.items():
         lines.append(f"{k[:70]:70s} {v}")
     NB = 128; nt = (a.n + NB - 1) // NB; P = a.particles
-    upd = [r for r in rows if "k_chol_update" in r[0] or "k_chol_step" in r[0]]
+    upd = [r for r in rows if "k_chol_update<true" in r[0]]
     trs = [r for r in rows if "k_chol_trsm" in r[0]]
     if len(upd) >= nt and len(upd) % nt == 0:
         lines += ["", f"# last sweep, per block column k (P={P}, n={a.n}): update-kernel duration and GEMM TF/s "
