@@ -116,10 +116,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    # AGP_BENCH_SHARE_GPU=1 (tests only): all ranks use cuda:0 and the collective runs over gloo, so the
+    # multi-rank control flow can be exercised on a one-GPU box.  The real run is one rank per GPU on RCCL.
+    share = os.environ.get("AGP_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
     pkg = g.load_package()
     eng = pkg.GPEngine(local_rank)
@@ -143,7 +151,9 @@ def main():
         eng.logpdf_batch_device(programs, noises, n, d_lp.data_ptr(), d_info.data_ptr(), stream)
         if world > 1:
             # the only collective of the path: log-weights for ESS / resampling
-            if len(set(pkg.dist.shard_sizes(P_total, world))) == 1:
+            if share:
+                d_all.copy_(pkg.dist.allgather_logweights(d_lp.cpu(), P_total))
+            elif len(set(pkg.dist.shard_sizes(P_total, world))) == 1:
                 dist.all_gather_into_tensor(d_all, d_lp)
             else:
                 d_all.copy_(pkg.dist.allgather_logweights(d_lp, P_total))
@@ -168,18 +178,23 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     eng.set_profiling(False)
+    cdev = torch.device("cpu") if share else dev
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     lp = d_lp.cpu().numpy(); info = d_info.cpu().numpy()
     n_bad = int((info != 0).sum())
     if world > 1:
-        nb = torch.tensor([n_bad], dtype=torch.int64, device=dev)
+        nb = torch.tensor([n_bad], dtype=torch.int64, device=cdev)
         dist.all_reduce(nb)
         n_bad = int(nb.item())
 
+    gather_ok = None
+    if world > 1:
+        full = d_all.cpu().numpy()
+        gather_ok = bool(np.array_equal(full[lo:hi], lp, equal_nan=True) and np.isfinite(full).sum() >= np.isfinite(lp).sum())
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         evals_s = P_total * args.steps / dt
@@ -204,7 +219,8 @@ def main():
                                    f"({P_total} total), kernel trees sampled from the restated AutoGP prior, one logpdf sweep "
                                    f"(+ RCCL all-gather of log-weights when n_gpus>1)",
                        "n": n, "particles_per_gpu": P, "particles_total": P_total, "tile": NB,
-                       "not_positive_definite": n_bad, "parallelism": f"particle-shard x{world}"},
+                       "not_positive_definite": n_bad, "parallelism": f"particle-shard x{world}",
+                       "allgather_selfcheck": gather_ok},
             "cholesky_gflops": evals_s * cholesky_flops(n) / 1e9,
             "phase_ms_per_step": {k: acc[k] / args.steps for k in ("total_ms", "cov_build_ms", "chol_update_ms", "chol_trsm_ms",
                                                                     "finish_ms", "h2d_ms")},
