@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -62,6 +63,16 @@ struct Slot {
 
 }  // namespace
 
+// One pending single-particle call (agp_logpdf) waiting in the coalescing queue.
+struct LpRequest {
+  int64_t n;
+  const uint8_t* ops; int32_t n_ops;
+  const double* prm; int32_t n_prm;
+  double noise;
+  double lp = 0.0; int32_t info = 0; int rc = 0;
+  bool done = false;
+};
+
 struct agp_ctx {
   int device = 0;
   std::mutex mu;
@@ -82,6 +93,14 @@ struct agp_ctx {
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
+  // ---- coalescing of concurrent single-particle callers (agp_logpdf) ----
+  std::mutex qmu;
+  std::condition_variable qcv;
+  std::vector<LpRequest*> queue;
+  bool leader_active = false;
+  int coalesce_us = 300;     // how long a leader waits for followers; 0 = every call runs alone (env AGP_COALESCE_US)
+  int batch_hint = 1;        // size of the last coalesced batch
+  long long n_coalesced_calls = 0, n_coalesced_batches = 0;
 };
 
 namespace {
@@ -586,6 +605,7 @@ int agp_init(agp_ctx** out, int device_id) {
   (void)hipMemGetInfo(&free_b, &tot_b);
   c->total_mem = free_b ? free_b : tot_b;
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
+  if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_STREAMS")) c->n_streams = std::max(1, std::min(8, atoi(e)));
   *out = c;
   return AGP_OK;
@@ -672,11 +692,96 @@ int agp_logpdf_batch_device(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_
                            d_out_info, (hipStream_t)hip_stream, hip_stream != nullptr);
 }
 
+// Run one coalesced batch (all requests share n) through the batched sweep.
+static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
+  const int P = (int)batch.size();
+  std::vector<int32_t> op_off(P + 1, 0), prm_off(P + 1, 0);
+  std::vector<uint8_t> ops; std::vector<double> prm, noise(P), lp(P);
+  std::vector<int32_t> info(P);
+  for (int i = 0; i < P; ++i) {
+    const LpRequest* r = batch[i];
+    ops.insert(ops.end(), r->ops, r->ops + r->n_ops);
+    if (r->n_prm > 0) prm.insert(prm.end(), r->prm, r->prm + r->n_prm);
+    op_off[i + 1] = (int32_t)ops.size(); prm_off[i + 1] = (int32_t)prm.size();
+    noise[i] = r->noise;
+  }
+  if (prm.empty()) prm.push_back(0.0);
+  int rc = agp_logpdf_batch(c, batch[0]->n, P, op_off.data(), ops.data(), prm_off.data(), prm.data(), noise.data(),
+                            lp.data(), info.data());
+  if (rc == AGP_ERR_PROGRAM && P > 1) {
+    // one malformed program must not fail its neighbours: fall back to individual sweeps
+    for (int i = 0; i < P; ++i) {
+      LpRequest* r = batch[i];
+      const int32_t oo[2] = {0, r->n_ops}, po[2] = {0, r->n_prm};
+      double dummy = 0.0;
+      r->rc = agp_logpdf_batch(c, r->n, 1, oo, r->ops, po, r->n_prm > 0 ? r->prm : &dummy, &r->noise, &r->lp, &r->info);
+    }
+    return;
+  }
+  for (int i = 0; i < P; ++i) { batch[i]->rc = rc; batch[i]->lp = lp[i]; batch[i]->info = info[i]; }
+}
+
+// Single particle — the call Gen's interpreter makes at src/Model.jl:135-136, from up to nthreads()
+// Julia threads at once (src/inference_smc_anneal_data.jl:133-135).  Concurrent callers are
+// coalesced: the first arrival becomes the leader, waits up to `coalesce_us` for as many followers
+// as the previous batch had, runs ONE batched sweep for everyone with the same n, and hands the
+// results back.  Callers that arrive while a sweep is running form the next batch.
 int agp_logpdf(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
                double noise, double* out_logpdf, int32_t* out_info) {
-  const int32_t op_off[2] = {0, n_ops}, prm_off[2] = {0, n_prm};
-  double dummy = 0.0;
-  return agp_logpdf_batch(c, n, 1, op_off, ops, prm_off, prm ? prm : &dummy, &noise, out_logpdf, out_info);
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (!ops || !out_logpdf || !out_info || n_ops <= 0 || n_prm < 0 || (n_prm > 0 && !prm))
+    return fail(c, AGP_ERR_ARG, "bad program arguments");
+  if (c->coalesce_us <= 0) {
+    const int32_t op_off[2] = {0, n_ops}, prm_off[2] = {0, n_prm};
+    double dummy = 0.0;
+    return agp_logpdf_batch(c, n, 1, op_off, ops, prm_off, n_prm > 0 ? prm : &dummy, &noise, out_logpdf, out_info);
+  }
+  LpRequest req;
+  req.n = n; req.ops = ops; req.n_ops = n_ops; req.prm = prm; req.n_prm = n_prm; req.noise = noise;
+  std::unique_lock<std::mutex> lk(c->qmu);
+  c->queue.push_back(&req);
+  c->qcv.notify_all();                       // a waiting leader may have reached its hint
+  while (!req.done) {
+    if (!c->leader_active) {
+      // ---- become the leader ----
+      c->leader_active = true;
+      const size_t want = (size_t)std::max(1, c->batch_hint);
+      if (c->queue.size() < want)
+        c->qcv.wait_for(lk, std::chrono::microseconds(c->coalesce_us), [&] { return c->queue.size() >= want; });
+      std::vector<LpRequest*> batch, rest;
+      for (LpRequest* r : c->queue) (r->n == req.n ? batch : rest).push_back(r);
+      c->queue.swap(rest);
+      c->batch_hint = (int)batch.size();
+      c->n_coalesced_calls += (long long)batch.size();
+      c->n_coalesced_batches += 1;
+      lk.unlock();
+      run_coalesced(c, batch);
+      lk.lock();
+      for (LpRequest* r : batch) r->done = true;
+      c->leader_active = false;
+      c->qcv.notify_all();
+    } else {
+      c->qcv.wait(lk);
+    }
+  }
+  lk.unlock();
+  *out_logpdf = req.lp;
+  *out_info = req.info;
+  return req.rc;
+}
+
+int agp_get_coalesce_stats(agp_ctx* c, int64_t* n_calls, int64_t* n_batches) {
+  if (!c || !n_calls || !n_batches) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->qmu);
+  *n_calls = c->n_coalesced_calls; *n_batches = c->n_coalesced_batches;
+  return AGP_OK;
+}
+
+int agp_set_coalesce_window(agp_ctx* c, int32_t microseconds) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  std::lock_guard<std::mutex> g(c->qmu);
+  c->coalesce_us = std::max(0, (int)microseconds);
+  return AGP_OK;
 }
 
 int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P,

@@ -74,7 +74,10 @@ const char* agp_version(void);
  * the data-annealing schedule evaluates on ts[1:step] (src/inference_smc_anneal_data.jl:206-217). */
 int agp_set_data(agp_ctx* ctx, const double* ts, const double* xs, int64_t n_max);
 
-/* Single particle — what Gen's interpreter calls at src/Model.jl:135-136.  Re-entrant. */
+/* Single particle — what Gen's interpreter calls at src/Model.jl:135-136.  Re-entrant.  Concurrent
+ * callers (one per Julia thread, src/inference_smc_anneal_data.jl:133-135) are coalesced inside the
+ * library into one batched sweep: the first arrival waits up to the coalescing window (default 300 us,
+ * env AGP_COALESCE_US, agp_set_coalesce_window; 0 disables) for the others. */
 int agp_logpdf(agp_ctx* ctx, int64_t n,
                const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
                double noise, double* out_logpdf, int32_t* out_info);
@@ -145,6 +148,10 @@ int agp_get_timing(agp_ctx* ctx, double* out, int32_t n_out);
 /* per-launch durations (ms) of the last profiled batch call: which = 0 update kernel, 1 trsm kernel;
  * returns the number of launches recorded (>= 0). */
 int agp_get_launch_times(agp_ctx* ctx, int32_t which, double* out, int32_t n_out);
+
+/* Coalescing of concurrent agp_logpdf callers: window in microseconds (0 = off) and counters. */
+int agp_set_coalesce_window(agp_ctx* ctx, int32_t microseconds);
+int agp_get_coalesce_stats(agp_ctx* ctx, int64_t* n_calls, int64_t* n_batches);
 
 /* Cap (bytes) on matrix workspace per call; larger batches are processed in chunks. 0 = default. */
 int agp_set_workspace_limit(agp_ctx* ctx, int64_t bytes);

@@ -321,6 +321,45 @@ def test_concurrent_callers(pkg, engine):
     assert np.array_equal(out, ref)
 
 
+def test_coalescing_of_single_particle_callers(pkg, engine):
+    """Concurrent agp_logpdf callers are merged into batched sweeps inside the library; callers with a
+    different n (an annealing step change mid-flight) are served by a later batch; a malformed program
+    only fails its own caller."""
+    ts, xs = pkg.prior.synthetic_series(300, seed=21)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(21), 32, max_depth=3)
+    engine.set_data(ts, xs)
+    ref_a, _ = engine.logpdf_batch(nodes, noises, n=300)
+    ref_b, _ = engine.logpdf_batch(nodes, noises, n=170)
+    engine.set_coalesce_window(20000)
+    c0, b0 = engine.coalesce_stats()
+    out = np.zeros(32); errs = []
+    barrier = threading.Barrier(33)
+
+    def work(i):
+        barrier.wait()
+        try:
+            out[i] = engine.logpdf(nodes[i], float(noises[i]), n=300 if i % 2 == 0 else 170)
+        except Exception as ex:   # noqa: BLE001
+            errs.append(ex)
+
+    def bad():
+        barrier.wait()
+        ops = np.array([6], dtype=np.uint8); prm = np.zeros(1)
+        o = ctypes.c_double(); inf = ctypes.c_int32()
+        rc = engine._lib.agp_logpdf(engine._ctx, 300, ops.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), 1,
+                                    prm.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 0, 0.1, ctypes.byref(o), ctypes.byref(inf))
+        if rc != -3:
+            errs.append(AssertionError(f"bad program returned {rc}"))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(32)] + [threading.Thread(target=bad)]
+    [t.start() for t in th]; [t.join() for t in th]
+    engine.set_coalesce_window(300)
+    assert not errs, errs
+    exp = np.where(np.arange(32) % 2 == 0, ref_a, ref_b)
+    assert np.array_equal(out, exp)
+    c1, b1 = engine.coalesce_stats()
+    assert c1 - c0 == 33 and b1 - b0 <= 12, (c1 - c0, b1 - b0)     # 33 calls served by a handful of sweeps
+
+
 def test_device_output_entry(pkg, engine):
     """agp_logpdf_batch_device leaves results in caller-provided device memory on the caller's stream."""
     import torch
