@@ -50,6 +50,7 @@ struct CholArgs {
   const double* prm;
   const double* noise;
   int n_fused;          // particles [0, n_fused) evaluate their tiles; the rest have them prebuilt in A
+  int* ready;           // [P] block columns whose L(k,k) is published (in-kernel solve); zeroed per sweep
 };
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -78,7 +79,29 @@ __device__ __forceinline__ int blk_idx(int rb, int cb) { return rb * (rb + 1) / 
 // LDS map of the fused phase (aliases the slab buffers): tpt[256] | sig[n_cp][256] | prm[n_prm] | ops[n_ops] (int)
 constexpr int U_MAX_CP = (U_MAIN_DOUBLES - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_OPS_DEV / 2 - 8) / 256;
 
-template <bool FACTOR, int DCOV>
+// Wave tiling: wave w owns rows [32w, 32w+32) of the tile across all 128 columns (accumulators
+// acc[cb][st]: column block cb = 0..7, strip st = 0 / 1 = the even / odd rows of the wave's 32).
+// Owning complete rows is what lets the triangular solve of an off-diagonal tile run in the same
+// registers with no cross-wave exchange, and it makes the row operand of the GEMM — the slab of tile
+// (i,j) — private to the wave: it never goes through LDS.  With the strips interleaved, one 16-byte
+// global load per k-step delivers both strips' MFMA fragments, and tile stores are 16 bytes wide.
+// Only the column operand (the slab of tile (k,j), shared by the four waves) is staged in LDS.
+//
+// FACTOR = false: Schur pass of the prediction path.  FACTOR = true: one block column k of the
+// factorisation; with INTRSM the off-diagonal tiles also finish L(i,k) = C(i,k) L(k,k)^-T in place:
+// the workgroup waits on the particle's `ready` word (published by the diagonal-tile workgroup, which
+// is dispatched first), stages +L(k,k) blocks and -W blocks in LDS and runs the blocked substitution
+// on its accumulators — one launch per block column, no panel round trip through HBM.
+#ifndef AGP_A_DIRECT
+#define AGP_A_DIRECT 1
+#endif
+constexpr bool A_DIRECT = AGP_A_DIRECT != 0;   // row operand: 1 = global -> registers, 0 = through LDS
+constexpr int T_NBLK = NSB * (NSB - 1) / 2;              // 28 strictly-lower 16x16 blocks
+constexpr int T_LDS_DOUBLES = (T_NBLK + NSB) * 256;      // + 8 inverse blocks = 72 KiB
+static_assert(T_LDS_DOUBLES <= U_MAIN_DOUBLES, "solve staging must fit the aliased slab buffers");
+__device__ __forceinline__ int sblk_idx(int jb, int lb) { return jb * (jb - 1) / 2 + lb; }   // lb < jb
+
+template <bool FACTOR, int DCOV, bool INTRSM>
 __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
   double* rvec = sm + U_MAIN_DOUBLES;
@@ -94,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   int pl, tl;
   if (FACTOR) {
     // diagonal tiles occupy the first 8*ceil(P/8) blocks of the grid: their serial 128x128
-    // factorisation then overlaps the bulk of the launch instead of forming its tail
+    // factorisation overlaps the bulk of the launch, and (INTRSM) they are resident before any
+    // workgroup that waits for them
     T = a.tiles;
     const int ndiag = 8 * ((a.P + 7) / 8);
     if (b < ndiag) {
@@ -123,19 +147,20 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   const int tid = threadIdx.x;
   const int l = tid & 63;
   const int w = tid >> 6;
-  const int wr = w & 1, wc = w >> 1;
   const int l15 = l & 15, lq = l >> 4;
+  const int row0 = 32 * w + 2 * l15;   // this lane's row in strip 0 (even); strip 1 is row0 + 1
 
   double* __restrict__ Ap = a.A + (long long)p * a.strideA;
   double* vecp = a.vec + (long long)p * a.ldv;
 
-  // DCOV > 0: accumulators start at -A(i,k), the K-loop adds L(i,j) L(k,j)^T on top and the epilogue is
-  // a pure store of -acc (no read-modify-write tail).  The tile is never read from HBM: it is
-  // evaluated from the particle's kernel program straight into the accumulator layout (4 elements
-  // per interpreter pass: one row, four columns), and this fp64-VALU phase overlaps the co-resident
-  // workgroup's MFMA phase.  DCOV == 0 (agp_debug_cholesky, >35 ChangePoints) keeps resident tiles.
+  // Accumulators hold -C(i,k) throughout: they start at -A(i,k), the K-loop adds L(i,j) L(k,j)^T.
+  // Fused particles evaluate A(i,k) from their kernel program straight into the accumulator layout
+  // (4 elements per interpreter pass: one row, four columns) — the tile is never read from HBM and
+  // this fp64-VALU phase shares the CU with the co-resident workgroup's MFMA phase.  Particles with
+  // prebuilt tiles (DCOV == 0, or the expensive tail of a hybrid batch) start from zero and subtract
+  // the stored tile after the loop.
   double* __restrict__ Tt = Ap + tile_off(ti, tk);
-  d4 acc[4][4];
+  d4 acc[NSB][2];
   const bool prebuilt = (DCOV == 0) || (p >= a.n_fused);
   if (!prebuilt) {
     const ProgHdr h = a.hdr[p];
@@ -152,13 +177,13 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     const double noise = a.noise[p];
 #pragma unroll 1
     for (int t = 0; t < 16; ++t) {
-      const int mi = t >> 2, ni = t & 3;
-      const int rslot = wr * 64 + ni * 16 + l15;
+      const int cb = t >> 1, st = t & 1;
+      const int rslot = row0 + st;
       double tr[4], tc[4], out[4];
       int ri[4], ci[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int cslot = wc * 64 + mi * 16 + 4 * r + lq;
+        const int cslot = cb * 16 + 4 * r + lq;
         tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
         ri[r] = rslot; ci[r] = NB + cslot;
       }
@@ -166,21 +191,18 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       d4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        v[r] = -cov_finalize(out[r], ti * NB + rslot, tk * NB + wc * 64 + mi * 16 + 4 * r + lq, a.n1, a.n1_pad, a.m2, noise);
+        v[r] = -cov_finalize(out[r], ti * NB + rslot, tk * NB + cb * 16 + 4 * r + lq, a.n1, a.n1_pad, a.m2, noise);
       switch (t) {   // wave-uniform scalar dispatch keeps every accumulator index static
-        case 0: acc[0][0] = v; break;  case 1: acc[0][1] = v; break;  case 2: acc[0][2] = v; break;  case 3: acc[0][3] = v; break;
-        case 4: acc[1][0] = v; break;  case 5: acc[1][1] = v; break;  case 6: acc[1][2] = v; break;  case 7: acc[1][3] = v; break;
-        case 8: acc[2][0] = v; break;  case 9: acc[2][1] = v; break;  case 10: acc[2][2] = v; break; case 11: acc[2][3] = v; break;
-        case 12: acc[3][0] = v; break; case 13: acc[3][1] = v; break; case 14: acc[3][2] = v; break; default: acc[3][3] = v; break;
+        case 0: acc[0][0] = v; break;  case 1: acc[0][1] = v; break;  case 2: acc[1][0] = v; break;  case 3: acc[1][1] = v; break;
+        case 4: acc[2][0] = v; break;  case 5: acc[2][1] = v; break;  case 6: acc[3][0] = v; break;  case 7: acc[3][1] = v; break;
+        case 8: acc[4][0] = v; break;  case 9: acc[4][1] = v; break;  case 10: acc[5][0] = v; break; case 11: acc[5][1] = v; break;
+        case 12: acc[6][0] = v; break; case 13: acc[6][1] = v; break; case 14: acc[7][0] = v; break; default: acc[7][1] = v; break;
       }
     }
     __syncthreads();   // the sigma tables alias the GEMM slab buffers
   } else {
-    // resident-tile path: accumulate from zero, subtract from the stored tile in the epilogue
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
   }
 
   double rv = 0.0;
@@ -188,7 +210,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 
   const int nslab = jmax * (NB / KB);
   if (nslab > 0) {
-    // thread's staging pattern: 4 x 16 B of each slab; element e = 2*(tid + 256u)
+    // column operand: 256 threads stage the 16 KiB slab of tile (k,j), 4 x 16 B each (element 2*(tid+256u));
+    // row operand: each lane fetches its own two rows of tile (i,j) for k-step kk at column 4kk + lq
     const int scol0 = tid >> 6;        // + 4u
     const int srow = 2 * (tid & 63);
     d2 ra[4], rb[4];
@@ -199,46 +222,46 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int off = (scol0 + 4 * u) * NB + srow;
-        ra[u] = *reinterpret_cast<const d2*>(srcA + off);
-        rb[u] = *reinterpret_cast<const d2*>(srcB + off);
+        ra[u] = A_DIRECT ? *reinterpret_cast<const d2*>(srcA + (4 * u + lq) * NB + row0)
+                         : *reinterpret_cast<const d2*>(srcA + (scol0 + 4 * u) * NB + srow);
+        rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 4 * u) * NB + srow);
       }
       if (is_diag && tid < KB) rx = vecp[j * NB + cs + tid];
     };
     auto lstore = [&](int buf) {
-      double* As = sm + buf * U_SLAB;
-      double* Bs = sm + (2 + buf) * U_SLAB;
+      double* Bs = sm + buf * U_SLAB;
+      double* As = sm + (2 + buf) * U_SLAB;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int off = (scol0 + 4 * u) * LDS_STRIDE + srow;
-        *reinterpret_cast<d2*>(As + off) = ra[u];
-        *reinterpret_cast<d2*>(Bs + off) = rb[u];
+        *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb[u];
+        if (!A_DIRECT) *reinterpret_cast<d2*>(As + (scol0 + 4 * u) * LDS_STRIDE + srow) = ra[u];
       }
       if (is_diag && tid < KB) xv[buf * 16 + tid] = rx;
     };
 
     gload(0);
     lstore(0);
+    d2 fr[4] = {ra[0], ra[1], ra[2], ra[3]};     // row fragments of the slab being multiplied
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
       const int buf = s & 1;
       if (s + 1 < nslab) gload(s + 1);
-      const double* As = sm + buf * U_SLAB;
-      const double* Bs = sm + (2 + buf) * U_SLAB;
+      const double* Bs = sm + buf * U_SLAB;
+      const double* As = sm + (2 + buf) * U_SLAB;
       // waves inside their MFMA block outrank the co-resident workgroup's load/store/barrier phase
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int kk = 0; kk < KB / 4; ++kk) {
         const int krow = (kk * 4 + lq) * LDS_STRIDE;
-        double fa[4], fb[4];
+        double fa[NSB];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) fa[mi] = Bs[krow + wc * 64 + mi * 16 + l15];
+        for (int cb = 0; cb < NSB; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];     // columns of C: tile (k,j)
+        const d2 fb = A_DIRECT ? fr[kk] : *reinterpret_cast<const d2*>(As + krow + row0);   // rows of C: tile (i,j)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) fb[ni] = As[krow + wr * 64 + ni * 16 + l15];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma(fa[mi], fb[ni], acc[mi][ni]);
+        for (int cb = 0; cb < NSB; ++cb) {
+          acc[cb][0] = mfma(fa[cb], fb.x, acc[cb][0]);
+          acc[cb][1] = mfma(fa[cb], fb.y, acc[cb][1]);
+        }
       }
       __builtin_amdgcn_s_setprio(0);
       if (is_diag && tid < NB) {
@@ -247,42 +270,120 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 #pragma unroll
         for (int kk = 0; kk < KB; ++kk) rv = fma(-Bs[kk * LDS_STRIDE + tid], xs_[kk], rv);
       }
-      if (s + 1 < nslab) lstore(buf ^ 1);
+      if (s + 1 < nslab) {
+        lstore(buf ^ 1);
+        if (A_DIRECT) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) fr[u] = ra[u];
+        }
+      }
       __syncthreads();
     }
   }
 
-  if (!(FACTOR && is_diag)) {
-    // ---- plain epilogue: C = A - sum = -acc ----
+  if (prebuilt) {
+    // resident tile: bring the accumulators to the same -C representation (one column block at a
+    // time — the scheduling fence stops the compiler from hoisting all 64 loads, which would spill)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int cb = 0; cb < NSB; ++cb) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
+      for (int r = 0; r < 4; ++r) {
+        const d2 t2 = *reinterpret_cast<const d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0);
+        acc[cb][0][r] -= t2.x;
+        acc[cb][1][r] -= t2.y;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  if (!FACTOR || (!is_diag && !INTRSM)) {
+    // ---- plain epilogue: C = -acc ----
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int col = wc * 64 + mi * 16 + 4 * r + lq;
-          const int row = wr * 64 + ni * 16 + l15;
-          Tt[col * NB + row] = prebuilt ? Tt[col * NB + row] - acc[mi][ni][r] : -acc[mi][ni][r];
-        }
+    for (int cb = 0; cb < NSB; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d2 o2; o2.x = -acc[cb][0][r]; o2.y = -acc[cb][1][r];
+        *reinterpret_cast<d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (is_diag && tid < NB) vecp[tk * NB + tid] = rv;   // Schur mode: -(V^T alpha) (+x = 0)
     return;
   }
 
+  if (!is_diag) {
+    // =====================  off-diagonal tile: L(i,k) = C(i,k) L(k,k)^-T in registers  =====================
+    if (tid == 0) {
+      const int want = a.k + 1;
+      int spins = 0;
+      while (__hip_atomic_load(a.ready + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1 << 22)) { a.info[p] = -7; break; }   // bounded (~1 s): never hang the device
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    // stage +L(k,k) strictly-lower blocks and -W blocks in A-operand order (fragment s of lane l at 64 s + l)
+    {
+      const double* __restrict__ Lkk = Ap + tile_off(a.k, a.k);
+      const double* __restrict__ Wg = a.W + (long long)p * NSB * 256;
+      const int c = tid >> 4, r = tid & 15;
+#pragma unroll
+      for (int jb = 1; jb < NSB; ++jb)
+#pragma unroll
+        for (int lb = 0; lb < jb; ++lb)
+          sm[sblk_idx(jb, lb) * 256 + tid] = Lkk[(lb * 16 + c) * NB + jb * 16 + r];
+#pragma unroll
+      for (int u = 0; u < NSB; ++u) sm[(T_NBLK + u) * 256 + tid] = -Wg[u * 256 + tid];
+    }
+    __syncthreads();
+    // With acc = -C:  t = acc_jb + sum_lb L(jb,lb) X_lb = -(C_jb - sum L X),  X_jb = (-W_jb) t.
+#pragma unroll
+    for (int jb = 0; jb < NSB; ++jb) {
+#pragma unroll
+      for (int lb = 0; lb < jb; ++lb) {
+        const double* blk = sm + sblk_idx(jb, lb) * 256;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const double fl = blk[64 * s4 + l];            // L(k,k)[jb*16 + l15][lb*16 + 4 s4 + lq]
+          acc[jb][0] = mfma(fl, acc[lb][0][s4], acc[jb][0]);
+          acc[jb][1] = mfma(fl, acc[lb][1][s4], acc[jb][1]);
+        }
+      }
+      d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const double fw = sm[(T_NBLK + jb) * 256 + 64 * s4 + l];   // -W_jb[l15][4 s4 + lq]
+        x0 = mfma(fw, acc[jb][0][s4], x0);
+        x1 = mfma(fw, acc[jb][1][s4], x1);
+      }
+      acc[jb][0] = x0;
+      acc[jb][1] = x1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d2 o2; o2.x = x0[r]; o2.y = x1[r];
+        *reinterpret_cast<d2*>(Tt + (jb * 16 + 4 * r + lq) * NB + row0) = o2;
+      }
+    }
+    return;
+  }
+
   // =====================  diagonal tile: factor C(k,k) in LDS  =====================
-  // S = A(k,k) - acc into 16x16 blocks (lower block triangle), each block column-major.
+  // S = -acc into 16x16 blocks (lower block triangle), each block column-major.
+  {
+    const int rb = 2 * w + (l15 >> 3);          // 16-row block of this lane's two rows
+    const int rr = (2 * l15) & 15;              // row of strip 0 inside the block (strip 1: rr + 1)
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int cb = wc * 4 + mi, rb = wr * 4 + ni;
+    for (int cb = 0; cb < NSB; ++cb)
       if (rb >= cb) {
         double* blk = sm + blk_idx(rb, cb) * 256;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          blk[64 * r + l] = prebuilt ? Tt[(cb * 16 + 4 * r + lq) * NB + rb * 16 + l15] - acc[mi][ni][r]
-                                     : -acc[mi][ni][r];
+        for (int r = 0; r < 4; ++r) {
+          d2 o2; o2.x = -acc[cb][0][r]; o2.y = -acc[cb][1][r];
+          *reinterpret_cast<d2*>(blk + (4 * r + lq) * 16 + rr) = o2;
+        }
       }
-    }
+  }
   if (tid < NB) rvec[tid] = rv;
   __syncthreads();
 
@@ -406,6 +507,17 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       if (bad != 0 && a.info[p] == 0) a.info[p] = bad;
     }
   }
+  if (INTRSM) {
+    // publish L(k,k) and its block inverses to the workgroups solving this particle's panel:
+    // every wave drains its stores, one lane releases at agent scope, then sets the ready word
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a.ready + p, a.k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // T — L(i,k) = C(i,k) L(k,k)^-T for the tiles below the diagonal of block column k.
@@ -413,11 +525,6 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 // lower 16x16 blocks of L(k,k) (negated) and the 8 diagonal-block inverses are staged once per
 // workgroup in LDS in A-operand order (column-major 16x16 blocks: fragment s of lane l sits at
 // 64 s + l, conflict-free), so no MFMA waits on a global load.
-constexpr int T_NBLK = NSB * (NSB - 1) / 2;              // 28 strictly-lower blocks
-constexpr int T_LDS_DOUBLES = (T_NBLK + NSB) * 256;      // + 8 inverse blocks = 72 KiB
-
-__device__ __forceinline__ int sblk_idx(int jb, int lb) { return jb * (jb - 1) / 2 + lb; }   // lb < jb
-
 __global__ __launch_bounds__(256, 2) void k_chol_trsm(CholArgs a) {
   __shared__ __attribute__((aligned(16))) double ls[T_LDS_DOUBLES];
   const int b = blockIdx.x;
@@ -518,10 +625,10 @@ __global__ void k_finish_logpdf(const double* partial, const int* info, int nt, 
 
 // x (minus the mean function on the training segment), zero elsewhere; clears info.
 __global__ void k_init_vec(double* vec, int ldv, int P, const double* xs, const double* mu1, int n1,
-                           int* info) {
+                           int* info, int* ready) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   const int p = blockIdx.y;
-  if (g == 0) info[p] = 0;
+  if (g == 0) { info[p] = 0; ready[p] = 0; }
   if (g >= ldv) return;
   double v = 0.0;
   if (g < n1) v = xs[g] - (mu1 ? mu1[g] : 0.0);

@@ -41,14 +41,14 @@ struct DevBuf {
 struct Slot {
   hipStream_t stream = nullptr;
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
-      pred_mean, pred_var, pred_cov, dense, map;
+      pred_mean, pred_var, pred_cov, dense, map, ready;
   std::vector<hipEvent_t> events;
   std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
   std::vector<hipEvent_t> sub_ev;     // fork / join events
   bool busy = false;
   void release() {
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
-                      &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map})
+                      &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready})
       b->release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
@@ -89,6 +89,7 @@ struct agp_ctx {
   int64_t ws_limit = 0;
   size_t total_mem = 0;
   bool profiling = false;
+  int intrsm = 1;       // 1: triangular solve inside k_chol_update (one launch per block column); env AGP_INTRSM
   int n_streams = 1;    // sub-batches of one call run on this many streams (env AGP_STREAMS)
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -353,11 +354,11 @@ hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int 
 
 // DCOV selection: 0 = tiles are resident (agp_debug_cholesky / unfused fallback), 4 / 8 = evaluate the
 // kernel program in the update kernel with that evaluation-stack depth.
-template <bool FACTOR>
+template <bool FACTOR, bool INTRSM>
 void launch_update(int dcov, int grid, hipStream_t st, const CholArgs& ca) {
-  if (dcov == 0) hipLaunchKernelGGL((k_chol_update<FACTOR, 0>), dim3(grid), dim3(256), 0, st, ca);
-  else if (dcov <= 4) hipLaunchKernelGGL((k_chol_update<FACTOR, 4>), dim3(grid), dim3(256), 0, st, ca);
-  else hipLaunchKernelGGL((k_chol_update<FACTOR, 8>), dim3(grid), dim3(256), 0, st, ca);
+  if (dcov == 0) hipLaunchKernelGGL((k_chol_update<FACTOR, 0, INTRSM>), dim3(grid), dim3(256), 0, st, ca);
+  else if (dcov <= 4) hipLaunchKernelGGL((k_chol_update<FACTOR, 4, INTRSM>), dim3(grid), dim3(256), 0, st, ca);
+  else hipLaunchKernelGGL((k_chol_update<FACTOR, 8, INTRSM>), dim3(grid), dim3(256), 0, st, ca);
 }
 
 inline void set_cov(CholArgs& ca, const CovArgs& cv) {
@@ -396,17 +397,29 @@ struct Prof {
 };
 
 // Factor block columns [0, nfac) of the joint (nt x nt tiles) matrices of Pc particles.
-hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, Prof* pf, double* counts) {
+// Factor block columns [0, nfac) of the joint (nt x nt tiles) matrices of ca.P particles.
+// intrsm: one launch per block column (the panel solve runs inside k_chol_update behind the
+// per-particle ready word); otherwise update + k_chol_trsm launches.
+hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intrsm, Prof* pf, double* counts) {
   // (profiling marks are recorded on the stream the kernels are launched on)
+  const int Pg = (ca.P + 7) / 8;
   for (int k = 0; k < nfac; ++k) {
     ca.k = k;
-    const int Pg = (ca.P + 7) / 8;
+    if (intrsm) {
+      ca.tiles = ca.nt - k;
+      size_t e0 = pf ? pf->mark(st) : 0;
+      launch_update<true, true>(dcov, 8 * Pg * ca.tiles, st, ca);
+      size_t e1 = pf ? pf->mark(st) : 0;
+      if (pf) pf->span(2, e0, e1);
+      if (counts) counts[0] += 1;
+      continue;
+    }
     {
       // block column 0 has nothing to subtract: only the diagonal tiles need a workgroup
       const int T = (k == 0) ? 1 : ca.nt - k;
       ca.tiles = T;
       size_t e0 = pf ? pf->mark(st) : 0;
-      launch_update<true>(dcov, 8 * Pg * T, st, ca);
+      launch_update<true, false>(dcov, 8 * Pg * T, st, ca);
       size_t e1 = pf ? pf->mark(st) : 0;
       if (pf) pf->span(2, e0, e1);
       if (counts) counts[0] += 1;
@@ -467,6 +480,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     HIPCHK(c, s->vec.ensure(sizeof(double) * (size_t)n_pad * chunk));
     HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
     HIPCHK(c, s->info.ensure(sizeof(int) * (size_t)chunk));
+    HIPCHK(c, s->ready.ensure(sizeof(int) * (size_t)chunk));
     HIPCHK(c, s->hdr.ensure(sizeof(ProgHdr) * (size_t)P));
     HIPCHK(c, s->ops.ensure(bt.ops.size()));
     HIPCHK(c, s->prm.ensure(sizeof(double) * std::max<size_t>(1, bt.prm.size())));
@@ -511,7 +525,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         hipStream_t q = (g == 0) ? st : s->sub[g - 1];
         hipLaunchKernelGGL(k_init_vec, dim3((n_pad + 255) / 256, Pg), dim3(256), 0, q,
                            s->vec.as<double>() + (size_t)g0 * n_pad, n_pad, Pg, c->d_xs, (const double*)nullptr, (int)n,
-                           s->info.as<int>() + g0);
+                           s->info.as<int>() + g0, s->ready.as<int>() + g0);
         CovArgs cv;
         cv.tt = c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
         cv.hdr = s->hdr.as<ProgHdr>() + p0 + g0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
@@ -523,9 +537,12 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         // where 136 tiles per particle absorb the cost instead of one workgroup per launch.
         const int nf = std::max(0, std::min(Pg, bt.n_fused - p0 - g0));
         const int dcov = nf > 0 ? bt.max_depth_fused : 0;
+        const bool intrsm = c->intrsm != 0;
         size_t e0 = pf.mark(q);
-        cv.col0_only = 1; cv.p_off = 0;
-        HIPCHK(c, launch_cov(q, cv, nt - 1, nf, bt.max_cp_fused, bt.max_depth_fused));
+        if (!intrsm) {      // separate solve launches: k_chol_trsm(0) reads the sub-diagonal tiles of column 0
+          cv.col0_only = 1; cv.p_off = 0;
+          HIPCHK(c, launch_cov(q, cv, nt - 1, nf, bt.max_cp_fused, bt.max_depth_fused));
+        }
         cv.col0_only = 0; cv.p_off = nf;
         HIPCHK(c, launch_cov(q, cv, ntiles, Pg - nf, bt.max_cp, bt.max_depth));
         size_t e1 = pf.mark(q);
@@ -538,7 +555,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         ca.info = s->info.as<int>() + g0; ca.P = Pg; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
         set_cov(ca, cv);
         ca.n_fused = nf;
-        HIPCHK(c, run_factor(q, ca, nt, dcov, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr));
+        ca.ready = s->ready.as<int>() + g0;
+        HIPCHK(c, run_factor(q, ca, nt, dcov, intrsm, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr));
 
         size_t e2 = pf.mark(q);
         hipLaunchKernelGGL(k_finish_logpdf, dim3((Pg + 63) / 64), dim3(64), 0, q, ca.partial, ca.info, nt, Pg, (int)n,
@@ -563,10 +581,15 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   }
 
   if (h_out_lp) HIPCHK(c, hipMemcpyAsync(h_out_lp, d_lp, sizeof(double) * P, hipMemcpyDeviceToHost, st));
-  if (h_out_info) HIPCHK(c, hipMemcpyAsync(h_out_info, d_info_out, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
+  std::vector<int32_t> info_chk;
+  int32_t* h_info = h_out_info;
+  if (!h_info) { info_chk.resize(P); h_info = info_chk.data(); }
+  HIPCHK(c, hipMemcpyAsync(h_info, d_info_out, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
   // The slot's buffers are reused by the next caller, so the work must be complete before the
   // slot is released even on the user-stream path.
   HIPCHK(c, hipStreamSynchronize(st));
+  for (int p = 0; p < P; ++p)
+    if (h_info[p] < 0) return fail(c, AGP_ERR_HIP, "in-kernel panel solve timed out waiting for its diagonal factor");
   return AGP_OK;
 }
 
@@ -605,6 +628,7 @@ int agp_init(agp_ctx** out, int device_id) {
   (void)hipMemGetInfo(&free_b, &tot_b);
   c->total_mem = free_b ? free_b : tot_b;
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
+  if (const char* e = getenv("AGP_INTRSM")) c->intrsm = atoi(e) != 0;
   if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_STREAMS")) c->n_streams = std::max(1, std::min(8, atoi(e)));
   *out = c;
@@ -831,6 +855,7 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   HIPCHK(c, s->vec.ensure(sizeof(double) * (size_t)ntot * chunk));
   HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
   HIPCHK(c, s->info.ensure(sizeof(int) * (size_t)P));
+  HIPCHK(c, s->ready.ensure(sizeof(int) * (size_t)P));
   HIPCHK(c, s->hdr.ensure(sizeof(ProgHdr) * (size_t)P));
   HIPCHK(c, s->ops.ensure(bt.ops.size()));
   HIPCHK(c, s->prm.ensure(sizeof(double) * std::max<size_t>(1, bt.prm.size())));
@@ -861,15 +886,18 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
     const int Pc = std::min(chunk, P - p0);
     hipLaunchKernelGGL(k_init_vec, dim3((ntot + 255) / 256, Pc), dim3(256), 0, st, s->vec.as<double>(), ntot,
                        Pc, c->d_xs, (mean_train && n > 0) ? s->mu1.as<double>() : (const double*)nullptr, (int)n,
-                       s->info.as<int>() + p0);
+                       s->info.as<int>() + p0, s->ready.as<int>() + p0);
     CovArgs cv;
     cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n1_pad; cv.m2 = (int)m; cv.nt = nt;
     cv.hdr = s->hdr.as<ProgHdr>() + p0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
     cv.noise = s->noise.as<double>() + p0; cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = Pc;
     const int nf = std::max(0, std::min(Pc, bt.n_fused - p0));
     const int dcov = nf > 0 ? bt.max_depth_fused : 0;
-    cv.col0_only = 1; cv.p_off = 0;
-    HIPCHK(c, launch_cov(st, cv, nt1 > 0 ? nt - 1 : 0, nf, bt.max_cp_fused, bt.max_depth_fused));
+    const bool intrsm = c->intrsm != 0;
+    if (!intrsm) {
+      cv.col0_only = 1; cv.p_off = 0;
+      HIPCHK(c, launch_cov(st, cv, nt1 > 0 ? nt - 1 : 0, nf, bt.max_cp_fused, bt.max_depth_fused));
+    }
     cv.col0_only = 0; cv.p_off = nf;
     HIPCHK(c, launch_cov(st, cv, ntiles, Pc - nf, bt.max_cp, bt.max_depth));
 
@@ -879,13 +907,14 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
     ca.info = s->info.as<int>() + p0; ca.P = Pc; ca.nt = nt; ca.k = 0; ca.nt1 = nt1;
     set_cov(ca, cv);
     ca.n_fused = nf;
-    HIPCHK(c, run_factor(st, ca, nt1, dcov, nullptr, nullptr));
+    ca.ready = s->ready.as<int>() + p0;
+    HIPCHK(c, run_factor(st, ca, nt1, dcov, intrsm, nullptr, nullptr));
     {
       // Schur complement of the prediction block + (-V^T alpha); with nt1 == 0 this just
       // passes K22 through.
       const int T = nt2 * (nt2 + 1) / 2;
       const int Pg = (Pc + 7) / 8;
-      launch_update<false>(dcov, 8 * Pg * T, st, ca);
+      launch_update<false, false>(dcov, 8 * Pg * T, st, ca);
     }
     PredArgs pa;
     pa.A = s->A.as<double>(); pa.strideA = strideA; pa.vec = s->vec.as<double>(); pa.ldv = ntot;
@@ -915,7 +944,10 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
     std::vector<int32_t> info_sorted(P);
     HIPCHK(c, hipMemcpyAsync(info_sorted.data(), s->info.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
-    for (int q = 0; q < P; ++q) out_info[bt.order[q]] = info_sorted[q];
+    for (int q = 0; q < P; ++q) {
+      if (info_sorted[q] < 0) return fail(c, AGP_ERR_HIP, "in-kernel panel solve timed out waiting for its diagonal factor");
+      out_info[bt.order[q]] = info_sorted[q];
+    }
     for (int p = 0; p < P; ++p)
       if (out_info[p] != 0) {
         const double nanv = std::nan("");
@@ -993,14 +1025,16 @@ int agp_debug_cholesky(agp_ctx* c, const double* K, int64_t n, double* out_L, in
   HIPCHK(c, hipMemcpyAsync(s->dense.p, K, sizeof(double) * nel, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemsetAsync(s->vec.p, 0, sizeof(double) * n_pad, st));
   HIPCHK(c, hipMemsetAsync(s->info.p, 0, sizeof(int), st));
+  HIPCHK(c, s->ready.ensure(sizeof(int)));
+  HIPCHK(c, hipMemsetAsync(s->ready.p, 0, sizeof(int), st));
   hipLaunchKernelGGL(k_pack_dense, dim3((unsigned)((strideA + 255) / 256)), dim3(256), 0, st, s->dense.as<double>(),
                      (int)n, nt, s->A.as<double>());
   CholArgs ca;
   ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>(); ca.vec = s->vec.as<double>();
   ca.ldv = n_pad; ca.partial = s->partial.as<double>(); ca.info = s->info.as<int>(); ca.P = 1; ca.nt = nt;
   ca.k = 0; ca.nt1 = nt;
-  ca.tt = nullptr; ca.hdr = nullptr; ca.ops = nullptr; ca.prm = nullptr; ca.noise = nullptr; ca.n1 = ca.n1_pad = ca.m2 = 0; ca.n_fused = 0;
-  HIPCHK(c, run_factor(st, ca, nt, 0, nullptr, nullptr));
+  ca.tt = nullptr; ca.hdr = nullptr; ca.ops = nullptr; ca.prm = nullptr; ca.noise = nullptr; ca.n1 = ca.n1_pad = ca.m2 = 0; ca.n_fused = 0; ca.ready = s->ready.as<int>();
+  HIPCHK(c, run_factor(st, ca, nt, 0, c->intrsm != 0, nullptr, nullptr));
   hipLaunchKernelGGL(k_unpack_dense, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, s->A.as<double>(),
                      (int)n, 1, s->dense.as<double>());
   HIPCHK(c, hipGetLastError());
