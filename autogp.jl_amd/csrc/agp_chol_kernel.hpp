@@ -95,11 +95,25 @@ constexpr int U_MAX_CP = (U_MAIN_DOUBLES - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_O
 #ifndef AGP_A_DIRECT
 #define AGP_A_DIRECT 1
 #endif
+#ifndef AGP_INTERLEAVE
+#define AGP_INTERLEAVE 1
+#endif
+constexpr bool ILV = AGP_INTERLEAVE != 0;      // strips = even/odd rows (1) or rows [0,16) / [16,32) of the wave (0)
 constexpr bool A_DIRECT = AGP_A_DIRECT != 0;   // row operand: 1 = global -> registers, 0 = through LDS
 constexpr int T_NBLK = NSB * (NSB - 1) / 2;              // 28 strictly-lower 16x16 blocks
 constexpr int T_LDS_DOUBLES = (T_NBLK + NSB) * 256;      // + 8 inverse blocks = 72 KiB
 static_assert(T_LDS_DOUBLES <= U_MAIN_DOUBLES, "solve staging must fit the aliased slab buffers");
 __device__ __forceinline__ int sblk_idx(int jb, int lb) { return jb * (jb - 1) / 2 + lb; }   // lb < jb
+
+// the two strip values of one tile column for this lane (rows rowA and rowB of column `col`)
+__device__ __forceinline__ d2 ld_pair(const double* T, int col, int rowA, int rowB) {
+  if (ILV) return *reinterpret_cast<const d2*>(T + col * NB + rowA);
+  d2 v; v.x = T[col * NB + rowA]; v.y = T[col * NB + rowB]; return v;
+}
+__device__ __forceinline__ void st_pair(double* T, int col, int rowA, int rowB, double a0, double a1) {
+  if (ILV) { d2 v; v.x = a0; v.y = a1; *reinterpret_cast<d2*>(T + col * NB + rowA) = v; }
+  else { T[col * NB + rowA] = a0; T[col * NB + rowB] = a1; }
+}
 
 template <bool FACTOR, int DCOV, bool INTRSM>
 __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
@@ -148,7 +162,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   const int l = tid & 63;
   const int w = tid >> 6;
   const int l15 = l & 15, lq = l >> 4;
-  const int row0 = 32 * w + 2 * l15;   // this lane's row in strip 0 (even); strip 1 is row0 + 1
+  const int row0 = ILV ? 32 * w + 2 * l15 : 32 * w + l15;   // this lane's row in strip 0
+  const int row1 = ILV ? row0 + 1 : row0 + 16;              // ... and in strip 1
 
   double* __restrict__ Ap = a.A + (long long)p * a.strideA;
   double* vecp = a.vec + (long long)p * a.ldv;
@@ -178,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 #pragma unroll 1
     for (int t = 0; t < 16; ++t) {
       const int cb = t >> 1, st = t & 1;
-      const int rslot = row0 + st;
+      const int rslot = st ? row1 : row0;
       double tr[4], tc[4], out[4];
       int ri[4], ci[4];
 #pragma unroll
@@ -222,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        ra[u] = A_DIRECT ? *reinterpret_cast<const d2*>(srcA + (4 * u + lq) * NB + row0)
+        ra[u] = A_DIRECT ? ld_pair(srcA, 4 * u + lq, row0, row1)
                          : *reinterpret_cast<const d2*>(srcA + (scol0 + 4 * u) * NB + srow);
         rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 4 * u) * NB + srow);
       }
@@ -256,7 +271,10 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
         double fa[NSB];
 #pragma unroll
         for (int cb = 0; cb < NSB; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];     // columns of C: tile (k,j)
-        const d2 fb = A_DIRECT ? fr[kk] : *reinterpret_cast<const d2*>(As + krow + row0);   // rows of C: tile (i,j)
+        d2 fb;                                                                   // rows of C: tile (i,j)
+        if (A_DIRECT) fb = fr[kk];
+        else if (ILV) fb = *reinterpret_cast<const d2*>(As + krow + row0);
+        else { fb.x = As[krow + row0]; fb.y = As[krow + row1]; }
 #pragma unroll
         for (int cb = 0; cb < NSB; ++cb) {
           acc[cb][0] = mfma(fa[cb], fb.x, acc[cb][0]);
@@ -288,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     for (int cb = 0; cb < NSB; ++cb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const d2 t2 = *reinterpret_cast<const d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0);
+        const d2 t2 = ld_pair(Tt, cb * 16 + 4 * r + lq, row0, row1);
         acc[cb][0][r] -= t2.x;
         acc[cb][1][r] -= t2.y;
       }
@@ -302,8 +320,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     for (int cb = 0; cb < NSB; ++cb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        d2 o2; o2.x = -acc[cb][0][r]; o2.y = -acc[cb][1][r];
-        *reinterpret_cast<d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
+        st_pair(Tt, cb * 16 + 4 * r + lq, row0, row1, -acc[cb][0][r], -acc[cb][1][r]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -361,8 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       acc[jb][1] = x1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        d2 o2; o2.x = x0[r]; o2.y = x1[r];
-        *reinterpret_cast<d2*>(Tt + (jb * 16 + 4 * r + lq) * NB + row0) = o2;
+        st_pair(Tt, jb * 16 + 4 * r + lq, row0, row1, x0[r], x1[r]);
       }
     }
     return;
@@ -370,18 +386,16 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 
   // =====================  diagonal tile: factor C(k,k) in LDS  =====================
   // S = -acc into 16x16 blocks (lower block triangle), each block column-major.
-  {
-    const int rb = 2 * w + (l15 >> 3);          // 16-row block of this lane's two rows
-    const int rr = (2 * l15) & 15;              // row of strip 0 inside the block (strip 1: rr + 1)
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    const int rw = st ? row1 : row0;
+    const int rb = rw >> 4, rr = rw & 15;       // 16-row block and row inside it
 #pragma unroll
     for (int cb = 0; cb < NSB; ++cb)
       if (rb >= cb) {
         double* blk = sm + blk_idx(rb, cb) * 256;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          d2 o2; o2.x = -acc[cb][0][r]; o2.y = -acc[cb][1][r];
-          *reinterpret_cast<d2*>(blk + (4 * r + lq) * 16 + rr) = o2;
-        }
+        for (int r = 0; r < 4; ++r) blk[(4 * r + lq) * 16 + rr] = -acc[cb][st][r];
       }
   }
   if (tid < NB) rvec[tid] = rv;

@@ -44,11 +44,13 @@ def cholesky_flops(n):          # LAPACK convention, SURVEY.md §8(d)
     return n ** 3 / 3.0
 
 
-def update_kernel_flops(n):
-    """Algorithmic flops of k_chol_update per particle and sweep: the n^3/3 of the factorisation
-    minus the triangular-solve share done by k_chol_trsm (NB^2 per row of every sub-diagonal tile)."""
+def update_kernel_flops(n, solve_in_kernel=True):
+    """Algorithmic flops of k_chol_update per particle and sweep.  With the panel solve inside the
+    kernel (default build) that is the whole n^3/3 of the factorisation; with separate k_chol_trsm
+    launches (AGP_INTRSM=0) the triangular-solve share (NB^2 per row of every sub-diagonal tile) is
+    subtracted."""
     nt = (n + NB - 1) // NB
-    return cholesky_flops(n) - (NB ** 3) * nt * (nt - 1) / 2.0
+    return cholesky_flops(n) - (0.0 if solve_in_kernel else (NB ** 3) * nt * (nt - 1) / 2.0)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -201,7 +203,8 @@ def main():
         n_upd = max(1.0, acc["n_update_launches"])
         upd_ms = acc["chol_update_ms"] / n_upd                      # average launch duration of k_chol_update
         nt = (n + NB - 1) // NB
-        upd_flops_launch = P * update_kernel_flops(n) / nt           # algorithmic flops per launch
+        solve_in_kernel = acc.get("n_trsm_launches", 0.0) == 0.0
+        upd_flops_launch = P * update_kernel_flops(n, solve_in_kernel) / nt           # algorithmic flops per launch
         achieved = upd_flops_launch / (upd_ms * 1e-3) / 1e12
         traffic = None
         tf = ROOT / "profiles" / "hbm_traffic.json"
@@ -224,7 +227,7 @@ def main():
             "cholesky_gflops": evals_s * cholesky_flops(n) / 1e9,
             "phase_ms_per_step": {k: acc[k] / args.steps for k in ("total_ms", "cov_build_ms", "chol_update_ms", "chol_trsm_ms",
                                                                     "finish_ms", "h2d_ms")},
-            "roofline": {"kernel": "k_chol_update<true>", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": "k_chol_update<true,DCOV,true>" if solve_in_kernel else "k_chol_update<true,DCOV,false>", "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
                          "traffic": traffic, "avg_launch_ms": upd_ms, "launches_per_step": n_upd / args.steps,
                          "algorithmic_flops_per_launch": upd_flops_launch},
