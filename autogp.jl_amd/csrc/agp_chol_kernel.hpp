@@ -49,6 +49,7 @@ struct CholArgs {
   const uint8_t* ops;
   const double* prm;
   const double* noise;
+  const uint8_t* code;  // per-point component codes (infer_gp_sum) or null
   int n_fused;          // particles [0, n_fused) evaluate their tiles; the rest have them prebuilt in A
   int* ready;           // [P] block columns whose L(k,k) is published (in-kernel solve); zeroed per sweep
 };
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
     for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
     __syncthreads();
-    cov_prologue(a.tt, ti, tk, h, ops, prm, tpt, sig, tid);
+    cov_prologue(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid);
     const double noise = a.noise[p];
 #pragma unroll 1
     for (int t = 0; t < 16; ++t) {
@@ -656,6 +657,7 @@ struct PredArgs {
   const double* vec; int ldv;
   const double* mu2;        // [m] or null
   const double* noise_pred; // [P]
+  const double* diag_add;   // [m] extra diagonal term per prediction point (infer_gp_sum) or null
   int nt1, n1_pad, m, P;
   double* out_mean;         // [P][m]
   double* out_var;          // [P][m]
@@ -672,7 +674,7 @@ __global__ void k_pred_extract(PredArgs a) {
     const double r = a.vec[(long long)p * a.ldv + a.n1_pad + g];
     a.out_mean[(long long)p * a.m + g] = (a.mu2 ? a.mu2[g] : 0.0) - r;
     const int t = a.nt1 + g / NB, o = g % NB;
-    a.out_var[(long long)p * a.m + g] = Ap[tile_off(t, t) + (long long)o * NB + o] + np;
+    a.out_var[(long long)p * a.m + g] = Ap[tile_off(t, t) + (long long)o * NB + o] + np + (a.diag_add ? a.diag_add[g] : 0.0);
   }
   if (a.out_cov) {
     const long long mm = (long long)a.m * a.m;
@@ -681,7 +683,7 @@ __global__ void k_pred_extract(PredArgs a) {
       const int hi = r > c ? r : c, lo = r > c ? c : r;
       const int ti = a.nt1 + hi / NB, tj = a.nt1 + lo / NB;
       double v = Ap[tile_off(ti, tj) + (long long)(lo % NB) * NB + (hi % NB)];
-      if (r == c) v += np;
+      if (r == c) v += np + (a.diag_add ? a.diag_add[r] : 0.0);
       a.out_cov[(long long)p * mm + idx] = v;
     }
   }

@@ -22,14 +22,16 @@ constexpr int LDS_STRIDE = 144;  // 128 + 16 doubles: k-rows 32 banks apart -> c
 // 0..8 equal the C-ABI / GPConfig codes; 9 is ChangePoint with its operands evaluated in
 // swapped order (the host reorders children so the deeper subtree is evaluated first, which
 // bounds the evaluation stack by the tree's Strahler number).
+// 10 is internal to infer_gp_sum: a component selector leaf, value s(a) s(b) with s(x) = 1 when point x is
+// an observable (code 0) or the latent of that component (code == id), else 0.
 enum : int { OP_WN = 0, OP_CONST = 1, OP_LIN = 2, OP_SE = 3, OP_GE = 4, OP_PER = 5,
-             OP_PLUS = 6, OP_TIMES = 7, OP_CP = 8, OP_CP_SWAP = 9 };
+             OP_PLUS = 6, OP_TIMES = 7, OP_CP = 8, OP_CP_SWAP = 9, OP_SEL = 10 };
 
 struct ProgHdr {
   int32_t op_off;   // offset into device ops[]
   int32_t prm_off;  // offset into device prm[]
   int32_t n_ops;
-  int32_t n_cp;     // number of ChangePoint nodes
+  int32_t n_cp;     // number of per-point LDS tables: ChangePoint nodes + selector leaves
   int32_t n_prm;    // device parameters of this program
   int32_t pad_;
 };

@@ -35,32 +35,37 @@ struct CovArgs {
   int P;
   int col0_only;         // 1: grid.x enumerates tiles (1+tix, 0) only
   int p_off;             // first particle (blockIdx.y is relative to it)
+  const uint8_t* code;   // per joint point: 0 observable, i latent of component i (infer_gp_sum); null = all 0
 };
 
 __device__ __forceinline__ int prm_count(int o) {
   // WN, CONST, LIN, SE, GE, PER, PLUS, TIMES, CP, CP_SWAP
-  return (o == OP_WN || o == OP_CONST) ? 1 : (o == OP_SE || o == OP_CP || o == OP_CP_SWAP) ? 2
+  return (o == OP_WN || o == OP_CONST || o == OP_SEL) ? 1 : (o == OP_SE || o == OP_CP || o == OP_CP_SWAP) ? 2
          : (o == OP_PLUS || o == OP_TIMES) ? 0 : 3;
 }
 
 // LDS scratch of the evaluator: tpt[256] (row times 0..127, column times 128..255) then sig[n_cp][256].
 template <typename OpT>
-__device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, int ti, int tj, const ProgHdr& h,
+__device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, const uint8_t* __restrict__ code,
+                                             int ti, int tj, const ProgHdr& h,
                                              const OpT* __restrict__ ops, const double* __restrict__ prm,
                                              double* tpt, double* sig, int tid) {
-  {
-    const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
-    tpt[tid] = tt[g];
-  }
+  const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
+  tpt[tid] = tt[g];
   __syncthreads();
   if (h.n_cp > 0) {
     const double t = tpt[tid];
+    const int cd = code ? (int)code[g] : 0;
     int q = 0, c = 0;
     for (int ip = 0; ip < h.n_ops; ++ip) {
       const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
       if (o == OP_CP || o == OP_CP_SWAP) {
         const double loc = prm[q], sc = prm[q + 1];
         sig[c * 256 + tid] = 0.5 * (1.0 + tanh((loc - t) / sc));   // sigma_cp, src/GP.jl:481-483
+        ++c;
+      } else if (o == OP_SEL) {
+        const int id = (int)prm[q];
+        sig[c * 256 + tid] = (cd == 0 || cd == id) ? 1.0 : 0.0;
         ++c;
       }
       q += prm_count(o);
@@ -86,13 +91,18 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
   for (int ip = 0; ip < h.n_ops; ++ip) {
     // the opcode is wave-uniform: keep it (and the dispatch on it) on the scalar unit
     const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
-    if (o <= OP_PER) {
+    if (o <= OP_PER || o == OP_SEL) {
       // ---------------- leaf: push ----------------
       // every leaf's (up to three) parameters are fetched unconditionally — the parameter buffers
       // carry two doubles of tail padding — and picked by opcode afterwards
       const double p0 = prm[q], p1 = prm[q + 1], p2 = prm[q + 2];
       double v[E];
-      if (o == OP_WN) {
+      if (o == OP_SEL) {
+        const double* sg = sig + cpi * 256;
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = sg[ri[e]] * sg[ci[e]];
+        ++cpi;
+      } else if (o == OP_WN) {
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = (tr[e] == tc[e]) ? p0 : 0.0;
       } else if (o == OP_CONST) {
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(256) void k_cov_tiles(CovArgs a) {
   const ProgHdr h = a.hdr[p];
   const uint8_t* __restrict__ ops = a.ops + h.op_off;
   const double* __restrict__ prm = a.prm + h.prm_off;
-  cov_prologue(a.tt, ti, tj, h, ops, prm, tpt, sig, tid);
+  cov_prologue(a.tt, a.code, ti, tj, h, ops, prm, tpt, sig, tid);
 
   const int rp = tid & 63;        // row pair: rows 2rp, 2rp+1
   const int cq = tid >> 6;        // column group: 32 columns

@@ -41,14 +41,14 @@ struct DevBuf {
 struct Slot {
   hipStream_t stream = nullptr;
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
-      pred_mean, pred_var, pred_cov, dense, map, ready;
+      pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add;
   std::vector<hipEvent_t> events;
   std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
   std::vector<hipEvent_t> sub_ev;     // fork / join events
   bool busy = false;
   void release() {
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
-                      &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready})
+                      &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add})
       b->release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
@@ -172,7 +172,7 @@ struct Compiled {
 
 int leaf_nprm(int op) {
   switch (op) {
-    case OP_WN: case OP_CONST: return 1;
+    case OP_WN: case OP_CONST: case OP_SEL: return 1;
     case OP_SE: return 2;
     case OP_LIN: case OP_GE: case OP_PER: return 3;
     default: return -1;
@@ -185,6 +185,7 @@ void emit(const std::vector<CNode>& nodes, int id, Compiled& out) {
     out.ops.push_back((uint8_t)nd.op);
     switch (nd.op) {
       case OP_WN: case OP_CONST: out.prm.push_back(nd.prm[0]); break;
+      case OP_SEL: out.prm.push_back(nd.prm[0]); out.n_cp++; break;     // uses one per-point LDS table
       case OP_LIN: out.prm.insert(out.prm.end(), {nd.prm[0], nd.prm[1], nd.prm[2]}); break;
       case OP_SE: out.prm.insert(out.prm.end(), {1.0 / (nd.prm[0] * nd.prm[0]), nd.prm[1]}); break;
       case OP_GE: out.prm.insert(out.prm.end(), {1.0 / nd.prm[0], nd.prm[1], nd.prm[2]}); break;
@@ -208,7 +209,8 @@ void emit(const std::vector<CNode>& nodes, int id, Compiled& out) {
 }
 
 // returns 0 or an error string
-const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, int n_prm, Compiled& out) {
+const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, int n_prm, Compiled& out,
+                            bool allow_sel = false) {
   if (n_ops <= 0 || n_ops > AGP_MAX_OPS) return "program length out of range";
   std::vector<CNode> nodes;
   nodes.reserve(n_ops);
@@ -217,7 +219,7 @@ const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, in
   for (int i = 0; i < n_ops; ++i) {
     const int op = ops[i];
     CNode nd; nd.op = op;
-    if (op <= OP_PER) {
+    if (op <= OP_PER || (allow_sel && op == OP_SEL)) {
       const int k = leaf_nprm(op);
       if (ip + k > n_prm) return "parameter array too short";
       for (int q = 0; q < k; ++q) nd.prm[q] = prm[ip + q];
@@ -274,12 +276,12 @@ double op_cost_us(int op) {
 constexpr double FUSE_MAX_TILE_US = 160.0;
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
-                  const double* prm, Batch& bt) {
+                  const double* prm, Batch& bt, bool allow_sel = false) {
   std::vector<Compiled> cps(P);
   std::vector<double> cost(P, 0.0);
   for (int p = 0; p < P; ++p) {
     const char* e = compile_program(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p],
-                                    prm_off[p + 1] - prm_off[p], cps[p]);
+                                    prm_off[p + 1] - prm_off[p], cps[p], allow_sel);
     if (e) {
       char buf[256];
       snprintf(buf, sizeof buf, "particle %d: %s", p, e);
@@ -363,7 +365,7 @@ void launch_update(int dcov, int grid, hipStream_t st, const CholArgs& ca) {
 
 inline void set_cov(CholArgs& ca, const CovArgs& cv) {
   ca.tt = cv.tt; ca.n1 = cv.n1; ca.n1_pad = cv.n1_pad; ca.m2 = cv.m2;
-  ca.hdr = cv.hdr; ca.ops = cv.ops; ca.prm = cv.prm; ca.noise = cv.noise;
+  ca.hdr = cv.hdr; ca.ops = cv.ops; ca.prm = cv.prm; ca.noise = cv.noise; ca.code = cv.code;
 }
 
 struct Prof {
@@ -526,7 +528,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         hipLaunchKernelGGL(k_init_vec, dim3((n_pad + 255) / 256, Pg), dim3(256), 0, q,
                            s->vec.as<double>() + (size_t)g0 * n_pad, n_pad, Pg, c->d_xs, (const double*)nullptr, (int)n,
                            s->info.as<int>() + g0, s->ready.as<int>() + g0);
-        CovArgs cv;
+        CovArgs cv = {};
         cv.tt = c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
         cv.hdr = s->hdr.as<ProgHdr>() + p0 + g0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
         cv.noise = s->noise.as<double>() + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
@@ -548,7 +550,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         size_t e1 = pf.mark(q);
         pf.span(1, e0, e1);
 
-        CholArgs ca;
+        CholArgs ca = {};
         ca.A = cv.A; ca.strideA = strideA; ca.W = s->W.as<double>() + (size_t)g0 * NSB * 256;
         ca.vec = s->vec.as<double>() + (size_t)g0 * n_pad; ca.ldv = n_pad;
         ca.partial = s->partial.as<double>() + (size_t)g0 * 2 * nt;
@@ -808,23 +810,16 @@ int agp_set_coalesce_window(agp_ctx* c, int32_t microseconds) {
   return AGP_OK;
 }
 
-int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P,
-                      const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
-                      const double* noise, const double* noise_pred, const double* mean_train,
-                      const double* mean_pred, double* out_mean, double* out_var, double* out_cov,
-                      int32_t* out_info) {
-  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
-  if (P < 0 || n < 0 || m < 0) return fail(c, AGP_ERR_ARG, "negative size");
-  if (P == 0 || m == 0) return AGP_OK;
-  if (!op_off || !ops || !prm_off || !prm || !noise || !ts_pred || !out_mean || !out_var)
-    return fail(c, AGP_ERR_ARG, "null pointer argument");
-  if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
-  HIPCHK(c, hipSetDevice(c->device));
+}  // extern "C"
 
-  Batch bt;
-  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt);
-  if (rc) return rc;
-
+namespace {
+// Core of the predictive path (src/GP.jl:739-757) for a compiled batch.  `pred_code` / `diag_add`
+// (both per prediction point, nullable) are what infer_gp_sum adds: component codes of the query
+// points and an extra diagonal term.
+int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P, Batch& bt,
+                 const double* noise, const double* noise_pred, const uint8_t* pred_code, const double* diag_add,
+                 const double* mean_train, const double* mean_pred, double* out_mean, double* out_var,
+                 double* out_cov, int32_t* out_info) {
   SlotGuard sg(c);
   Slot* s = sg.s;
   if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -880,6 +875,17 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   HIPCHK(c, hipMemcpyAsync(s->noise.p, noise_sorted.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(s->noise_pred.p, npred.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(s->tt.p, tt.data(), sizeof(double) * ntot, hipMemcpyHostToDevice, st));
+  if (pred_code) {
+    std::vector<uint8_t> code((size_t)ntot, 0);
+    std::copy(pred_code, pred_code + m, code.begin() + n1_pad);
+    HIPCHK(c, s->code.ensure((size_t)ntot));
+    HIPCHK(c, hipMemcpyAsync(s->code.p, code.data(), (size_t)ntot, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));     // `code` is a local
+  }
+  if (diag_add) {
+    HIPCHK(c, s->diag_add.ensure(sizeof(double) * (size_t)m));
+    HIPCHK(c, hipMemcpyAsync(s->diag_add.p, diag_add, sizeof(double) * m, hipMemcpyHostToDevice, st));
+  }
 
   std::vector<double> h_mean, h_var;
   for (int p0 = 0; p0 < P; p0 += chunk) {
@@ -887,10 +893,11 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
     hipLaunchKernelGGL(k_init_vec, dim3((ntot + 255) / 256, Pc), dim3(256), 0, st, s->vec.as<double>(), ntot,
                        Pc, c->d_xs, (mean_train && n > 0) ? s->mu1.as<double>() : (const double*)nullptr, (int)n,
                        s->info.as<int>() + p0, s->ready.as<int>() + p0);
-    CovArgs cv;
+    CovArgs cv = {};
     cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n1_pad; cv.m2 = (int)m; cv.nt = nt;
     cv.hdr = s->hdr.as<ProgHdr>() + p0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
     cv.noise = s->noise.as<double>() + p0; cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = Pc;
+    cv.code = pred_code ? s->code.as<uint8_t>() : nullptr;
     const int nf = std::max(0, std::min(Pc, bt.n_fused - p0));
     const int dcov = nf > 0 ? bt.max_depth_fused : 0;
     const bool intrsm = c->intrsm != 0;
@@ -901,7 +908,7 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
     cv.col0_only = 0; cv.p_off = nf;
     HIPCHK(c, launch_cov(st, cv, ntiles, Pc - nf, bt.max_cp, bt.max_depth));
 
-    CholArgs ca;
+    CholArgs ca = {};
     ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>();
     ca.vec = s->vec.as<double>(); ca.ldv = ntot; ca.partial = s->partial.as<double>();
     ca.info = s->info.as<int>() + p0; ca.P = Pc; ca.nt = nt; ca.k = 0; ca.nt1 = nt1;
@@ -916,10 +923,11 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
       const int Pg = (Pc + 7) / 8;
       launch_update<false, false>(dcov, 8 * Pg * T, st, ca);
     }
-    PredArgs pa;
+    PredArgs pa = {};
     pa.A = s->A.as<double>(); pa.strideA = strideA; pa.vec = s->vec.as<double>(); pa.ldv = ntot;
     pa.mu2 = mean_pred ? s->mu2.as<double>() : nullptr; pa.noise_pred = s->noise_pred.as<double>() + p0;
     pa.nt1 = nt1; pa.n1_pad = n1_pad; pa.m = (int)m; pa.P = Pc;
+    pa.diag_add = diag_add ? s->diag_add.as<double>() : nullptr;
     pa.out_mean = s->pred_mean.as<double>(); pa.out_var = s->pred_var.as<double>();
     pa.out_cov = out_cov ? s->pred_cov.as<double>() : nullptr;
     const long long nel = out_cov ? (long long)m * m : (long long)m;
@@ -957,6 +965,78 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   return AGP_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P,
+                      const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                      const double* noise, const double* noise_pred, const double* mean_train,
+                      const double* mean_pred, double* out_mean, double* out_var, double* out_cov,
+                      int32_t* out_info) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (P < 0 || n < 0 || m < 0) return fail(c, AGP_ERR_ARG, "negative size");
+  if (P == 0 || m == 0) return AGP_OK;
+  if (!op_off || !ops || !prm_off || !prm || !noise || !ts_pred || !out_mean || !out_var)
+    return fail(c, AGP_ERR_ARG, "null pointer argument");
+  if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
+  HIPCHK(c, hipSetDevice(c->device));
+  Batch bt;
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt);
+  if (rc) return rc;
+  return predict_core(c, n, ts_pred, m, P, bt, noise, noise_pred, nullptr, nullptr, mean_train, mean_pred, out_mean,
+                      out_var, out_cov, out_info);
+}
+
+// infer_gp_sum (src/GP.jl:904-993): posterior over Z = [F_1(T*); ...; F_M(T*); X(T*)] given X(T) = xs, for the
+// sum-of-GPs model X = sum_i F_i + noise.  The joint prior covariance over [X(T); Z] is the single program
+// sum_i SEL_i * K_i evaluated on coded points (SEL_i(a,b) = 1 when both points are the observable or the
+// latent of component i), so the whole computation is one pass of the predictive machinery:
+// Cholesky of Sigma_bb = S_tt + noise I (src/GP.jl:982), Schur complement (984), + JITTER I (986).
+int agp_infer_gp_sum(agp_ctx* c, int64_t n, const double* ts_pred, int64_t p, int32_t M,
+                     const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                     double noise, double noise_pred, double* out_mean, double* out_cov, int32_t* out_info) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (n < 0 || p <= 0 || M <= 0 || M > 200) return fail(c, AGP_ERR_ARG, "bad sizes");
+  if (!op_off || !ops || !prm_off || !prm || !ts_pred || !out_mean) return fail(c, AGP_ERR_ARG, "null pointer argument");
+  if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
+  HIPCHK(c, hipSetDevice(c->device));
+  // composite program: K_1 SEL_1 *  K_2 SEL_2 * +  ...  K_M SEL_M * +
+  std::vector<uint8_t> cops; std::vector<double> cprm;
+  for (int i = 0; i < M; ++i) {
+    for (int q = op_off[i]; q < op_off[i + 1]; ++q) {
+      if (ops[q] > OP_CP) return fail(c, AGP_ERR_PROGRAM, "unknown opcode");
+      cops.push_back(ops[q]);
+    }
+    cprm.insert(cprm.end(), prm + prm_off[i], prm + prm_off[i + 1]);
+    cops.push_back((uint8_t)OP_SEL); cprm.push_back((double)(i + 1));
+    cops.push_back((uint8_t)OP_TIMES);
+    if (i > 0) cops.push_back((uint8_t)OP_PLUS);
+  }
+  if ((int)cops.size() > AGP_MAX_OPS) return fail(c, AGP_ERR_PROGRAM, "composite program too long");
+  const int32_t coff[2] = {0, (int32_t)cops.size()}, cpoff[2] = {0, (int32_t)cprm.size()};
+  Batch bt;
+  int rc = compile_batch(c, 1, coff, cops.data(), cpoff, cprm.data(), bt, /*allow_sel=*/true);
+  if (rc) return rc;
+  // query points: F_1(T*) ... F_M(T*) (codes 1..M), then X(T*) (code 0)
+  const int64_t ma = (int64_t)(M + 1) * p;
+  std::vector<double> tq((size_t)ma), dadd((size_t)ma), mean((size_t)ma), var((size_t)ma);
+  std::vector<uint8_t> code((size_t)ma);
+  for (int i = 0; i <= M; ++i)
+    for (int64_t j = 0; j < p; ++j) {
+      const size_t g = (size_t)i * p + j;
+      tq[g] = ts_pred[j];
+      code[g] = (uint8_t)(i < M ? i + 1 : 0);
+      dadd[g] = 1e-8 + (i == M ? noise_pred : 0.0);       // JITTER (src/GP.jl:760,986) + noise_pred on X(T*)
+    }
+  const double zero = 0.0;
+  int32_t info = 0;
+  rc = predict_core(c, n, tq.data(), ma, 1, bt, &noise, &zero, code.data(), dadd.data(), nullptr, nullptr, out_mean,
+                    var.data(), out_cov, &info);
+  if (out_info) *out_info = info;
+  return rc;
+}
+
 int agp_cov_matrix(agp_ctx* c, const double* ts, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm,
                    int32_t n_prm, double noise, double* out_K) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
@@ -990,7 +1070,7 @@ int agp_cov_matrix(agp_ctx* c, const double* ts, int64_t n, const uint8_t* ops, 
     HIPCHK(c, hipMemcpyAsync(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size(), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(s->noise.p, &noise, sizeof(double), hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(s->tt.p, tt.data(), sizeof(double) * n_pad, hipMemcpyHostToDevice, st));
-  CovArgs cv;
+  CovArgs cv = {};
   cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
   cv.hdr = s->hdr.as<ProgHdr>(); cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
   cv.noise = s->noise.as<double>(); cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = 1;
@@ -1029,7 +1109,7 @@ int agp_debug_cholesky(agp_ctx* c, const double* K, int64_t n, double* out_L, in
   HIPCHK(c, hipMemsetAsync(s->ready.p, 0, sizeof(int), st));
   hipLaunchKernelGGL(k_pack_dense, dim3((unsigned)((strideA + 255) / 256)), dim3(256), 0, st, s->dense.as<double>(),
                      (int)n, nt, s->A.as<double>());
-  CholArgs ca;
+  CholArgs ca = {};
   ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>(); ca.vec = s->vec.as<double>();
   ca.ldv = n_pad; ca.partial = s->partial.as<double>(); ca.info = s->info.as<int>(); ca.P = 1; ca.nt = nt;
   ca.k = 0; ca.nt1 = nt;
@@ -1083,7 +1163,7 @@ int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t
   const long long strideA = (long long)ntiles * NB2;
   HIPCHK(c, s->A.ensure((size_t)strideA * 8 * P));
   hipLaunchKernelGGL(k_fill_pseudo, dim3(4096), dim3(256), 0, st, s->A.as<double>(), strideA * P);
-  CholArgs ca;
+  CholArgs ca = {};
   ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = nullptr; ca.vec = nullptr; ca.ldv = 0; ca.partial = nullptr;
   ca.info = nullptr; ca.P = P; ca.nt = nt; ca.k = k; ca.nt1 = nt; ca.tiles = nt - k - 1;
   if (ca.tiles < 1) return fail(c, AGP_ERR_ARG, "no off-diagonal tiles");

@@ -25,7 +25,7 @@ LIB_PATH = _PKG_DIR / "lib" / "libautogp_hip.so"
 
 EXPORTED_SYMBOLS = [
     "agp_init", "agp_destroy", "agp_last_error", "agp_version", "agp_set_data", "agp_logpdf",
-    "agp_logpdf_batch", "agp_logpdf_batch_device", "agp_predict_batch", "agp_cov_matrix",
+    "agp_logpdf_batch", "agp_logpdf_batch_device", "agp_predict_batch", "agp_infer_gp_sum", "agp_cov_matrix",
     "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_debug_mfma_peak", "agp_debug_math", "agp_debug_gemm_variant", "agp_set_profiling", "agp_get_timing", "agp_get_launch_times",
     "agp_set_workspace_limit", "agp_set_coalesce_window", "agp_get_coalesce_stats",
 ]
@@ -95,6 +95,8 @@ def load_library(path=None):
     lib.agp_predict_batch.argtypes = [vp, C.c_int64, dp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, dp, dp,
                                       dp, dp, dp, ip]
     lib.agp_predict_batch.restype = C.c_int
+    lib.agp_infer_gp_sum.argtypes = [vp, C.c_int64, dp, C.c_int64, C.c_int32, ip, u8p, ip, dp, C.c_double, C.c_double, dp, dp, ip]
+    lib.agp_infer_gp_sum.restype = C.c_int
     lib.agp_cov_matrix.argtypes = [vp, dp, C.c_int64, u8p, C.c_int32, dp, C.c_int32, C.c_double, dp]
     lib.agp_cov_matrix.restype = C.c_int
     lib.agp_debug_cholesky.argtypes = [vp, dp, C.c_int64, dp, ip]; lib.agp_debug_cholesky.restype = C.c_int
@@ -229,6 +231,21 @@ class GPEngine:
             raise PosDefException(int(info[p]), p)
         return mean, var, cov, info
 
+    # -- sum-of-GPs posterior (src/GP.jl:904-993) ---------------------------------------------
+    def infer_gp_sum(self, nodes, noise, ts_pred, n=None, noise_pred=None, check=True):
+        """Returns (mean[(M+1)p], cov[(M+1)p, (M+1)p], indexes_F (list of slices), indexes_X (slice))."""
+        n = self.n_max if n is None else int(n)
+        op_off, ops, prm_off, prm = _gp.encode_batch(nodes)
+        M = len(nodes); ts_pred = _f64(ts_pred); p = ts_pred.shape[0]
+        ma = (M + 1) * p
+        mean = np.empty(ma); cov = np.empty((ma, ma)); info = C.c_int32()
+        npred = float(noise) if noise_pred is None else float(noise_pred)
+        self._check(self._lib.agp_infer_gp_sum(self._ctx, n, _dp(ts_pred), p, M, _ip(op_off), _u8(ops), _ip(prm_off), _dp(prm),
+                                               float(noise), npred, _dp(mean), _dp(cov), C.byref(info)))
+        if check and info.value > 0:
+            raise PosDefException(info.value)
+        return mean, cov, [slice(i * p, (i + 1) * p) for i in range(M)], slice(M * p, ma)
+
     # -- matrix assembly (src/GP.jl:666-668) -------------------------------------------------
     def cov_matrix(self, node, noise, ts):
         ts = _f64(ts); n = ts.shape[0]
@@ -345,6 +362,15 @@ class MvNormal:
 
     def cov(self):
         return self.Sigma
+
+
+def infer_gp_sum(nodes, noise, ts, xs, ts_pred, noise_pred=None, engine=None):
+    """GP.infer_gp_sum(nodes, noise, ts, xs, ts_pred; noise_pred) (src/GP.jl:904-993) on the GPU.
+    Returns (mean, cov, indexes) with indexes = {"F": [slice...], "X": slice} like the reference's tuple."""
+    eng = engine or default_engine()
+    eng.set_data(ts, xs)
+    mean, cov, iF, iX = eng.infer_gp_sum(nodes, noise, ts_pred, noise_pred=noise_pred)
+    return mean, cov, {"F": iF, "X": iX}
 
 
 def quantile(dist: MvNormal, p):

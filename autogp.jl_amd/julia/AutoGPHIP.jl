@@ -116,6 +116,26 @@ function predict_mvn(eng::Engine, node::GP.Node, noise::Float64, ts_pred::Vector
     return Distributions.MvNormal(mu, LinearAlgebra.Symmetric(cov))
 end
 
+"Sum-of-GPs posterior — replaces GP.infer_gp_sum (src/GP.jl:904-993); returns the same named tuple."
+function infer_gp_sum(eng::Engine, nodes::Vector{<:GP.Node}, noise::Float64, ts_pred::Vector{Float64};
+        n::Integer=eng.n_max, noise_pred::Union{Nothing,Float64}=nothing)
+    M = length(nodes); p = length(ts_pred); ma = (M + 1) * p
+    op_off = Int32[0]; prm_off = Int32[0]; ops = UInt8[]; prm = Float64[]
+    for nd in nodes
+        o, q = encode(nd); append!(ops, o); append!(prm, q)
+        push!(op_off, length(ops)); push!(prm_off, length(prm))
+    end
+    isempty(prm) && push!(prm, 0.0)
+    mu = Vector{Float64}(undef, ma); cov = Matrix{Float64}(undef, ma, ma); info = Ref{Int32}(0)
+    GC.@preserve op_off ops prm_off prm ts_pred mu cov check(eng, ccall((:agp_infer_gp_sum, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64},
+         Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
+        eng.ptr, n, ts_pred, p, M, op_off, ops, prm_off, prm, noise, isnothing(noise_pred) ? noise : noise_pred,
+        mu, cov, info))
+    mvn = Distributions.MvNormal(mu, LinearAlgebra.Symmetric(cov))
+    return (mvn=mvn, indexes=(F=[((i-1)*p+1):(i*p) for i in 1:M], X=(M*p+1):(M*p+p)))
+end
+
 # ---- Gen distribution: the trace-score term of src/Model.jl:136 evaluated on the GPU ------------
 struct GPMarginal <: Gen.Distribution{Vector{Float64}} end
 const gp_marginal = GPMarginal()

@@ -113,6 +113,15 @@ int agp_predict_batch(agp_ctx* ctx, int64_t n, const double* ts_pred, int64_t m,
                       double* out_mean, double* out_var, double* out_cov,
                       int32_t* out_info);
 
+/* infer_gp_sum(nodes, noise, ts, xs, ts_pred; noise_pred) (src/GP.jl:904-993) on the resident (ts, xs)[1:n]:
+ * posterior of Z = [F_1(T*); ...; F_M(T*); X(T*)] for the sum-of-GPs model.  The M component kernels are
+ * given as CSR-packed postfix programs (op_off / prm_off have M+1 entries).  out_mean: (M+1)*p;
+ * out_cov: ((M+1)*p)^2 column-major symmetric (may be NULL); latent block i is rows [i*p, (i+1)*p),
+ * the observable block is the last p rows — the index ranges the reference returns as (F, X). */
+int agp_infer_gp_sum(agp_ctx* ctx, int64_t n, const double* ts_pred, int64_t p, int32_t M,
+                     const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                     double noise, double noise_pred, double* out_mean, double* out_cov, int32_t* out_info);
+
 /* compute_cov_matrix_vectorized(node, noise, ts) (src/GP.jl:666-668) on explicit ts:
  * out_K is n x n column-major (full symmetric).  Parity / debugging entry. */
 int agp_cov_matrix(agp_ctx* ctx, const double* ts, int64_t n,

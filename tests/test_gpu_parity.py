@@ -247,6 +247,42 @@ def test_predictive_likelihood_identity_on_gpu(pkg, engine):
         assert abs((lj - lo) - lpred) <= 1e-7 * max(1.0, abs(lpred))
 
 
+def test_infer_gp_sum(pkg, engine):
+    """GP.infer_gp_sum (src/GP.jl:904-993) against the oracle restatement, plus the reference's own
+    relational checks (test/test_GP.jl:150-240): the observable block equals the single-kernel
+    predictive of the summed kernel, and with noise_pred = 0 the latent covariances add up to it."""
+    G = pkg
+    rng = np.random.default_rng(9)
+    k1, k2, k3 = G.SquaredExponential(0.3, 0.8), G.Periodic(0.5, 0.2, 0.4), G.Linear(0.2, 0.1, 0.6) * G.GammaExponential(0.4, 1.3, 0.7)
+    for n, p, kernels in ((30, 9, [k1, k2]), (150, 40, [k1, k2, k3]), (200, 130, [k3, G.ChangePoint(k1, k2, 0.5, 0.02)]), (64, 5, [k2])):
+        ts = np.sort(rng.random(n)); xs = 0.3 * rng.standard_normal(n); tp = np.linspace(0, 1.2, p)
+        engine.set_data(ts, xs)
+        for npred in (None, 0.0):
+            mean, cov, iF, iX = engine.infer_gp_sum(kernels, 0.1, tp, noise_pred=npred)
+            mu_o, S_o, iF_o, iX_o = O.infer_gp_sum([k.to_tuple() for k in kernels], 0.1, ts, xs, tp, noise_pred=npred)
+            assert iX == iX_o and iF == iF_o
+            assert np.abs(mean - mu_o).max() <= LP_TOL * max(1.0, np.abs(mu_o).max())
+            assert np.abs(cov - S_o).max() <= LP_TOL * max(1.0, np.abs(S_o).max())
+            assert np.array_equal(cov, cov.T)
+        # observable block == predictive MvNormal of the summed kernel (+ the 1e-8 jitter of infer_gp_sum)
+        ksum = kernels[0]
+        for k in kernels[1:]:
+            ksum = ksum + k
+        mean, cov, iF, iX = engine.infer_gp_sum(kernels, 0.1, tp)
+        pm, pv, pc, _ = engine.predict_batch([ksum], [0.1], tp, want_cov=True)
+        assert np.abs(mean[iX] - pm[0]).max() <= 1e-8
+        assert np.abs(cov[iX, iX] - (pc[0] + 1e-8 * np.eye(p))).max() <= 1e-8
+        # sum of latent covariances = observable covariance when noise_pred = 0 (test/test_GP.jl:228-237)
+        mean0, cov0, iF, iX = engine.infer_gp_sum(kernels, 0.1, tp, noise_pred=0.0)
+        lat = sum(cov0[a, b] for a in iF for b in iF)
+        M = len(kernels)
+        assert np.abs(lat - (cov0[iX, iX] + (M * M - 1) * 0 * np.eye(p))).max() <= 1e-6
+        assert np.abs(sum(mean0[a] for a in iF) - mean0[iX]).max() <= 1e-8
+    # module-level mirror
+    mean, cov, idx = G.infer_gp_sum([k1, k2], 0.1, ts, xs, tp, engine=engine)
+    assert mean.shape == (3 * 5,) and idx["X"] == slice(10, 15)
+
+
 def test_debug_cholesky_and_nonpd(pkg, engine):
     rng = np.random.default_rng(2)
     for n in (16, 100, 128, 200, 384, 1000):

@@ -1,0 +1,19 @@
+import sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as g
+pkg = g.load_package(); eng = pkg.GPEngine(0)
+for n, m_extra, P in ((256, 64, 8), (1024, 256, 64), (2048, 512, 64), (2048, 512, 256)):
+    ts, xs = pkg.prior.synthetic_series(n, seed=n)
+    tp = np.concatenate([ts, np.linspace(1.0, 1.25, m_extra)])      # queries = train U future (src/api.jl usage)
+    m = tp.size
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(n + P), P, max_depth=-1, max_size=31)
+    eng.set_data(ts, xs)
+    eng.predict_batch(nodes, noises, tp, check=False)
+    t0 = time.time(); reps = 3
+    for _ in range(reps): mean, var, _, info = eng.predict_batch(nodes, noises, tp, check=False)
+    dt = (time.time() - t0) / reps
+    fl = P * ((n + m) ** 3 / 3 - m ** 3 / 3)      # factor n columns of the joint matrix + Schur update of the m block
+    print(f"predict n={n} m={m} P={P}: {dt*1e3:8.2f} ms  {P/dt:8.0f} particles/s  ~{fl/dt/1e12:5.1f} TF/s  npd={(info>0).sum()}")
