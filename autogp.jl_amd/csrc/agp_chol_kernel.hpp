@@ -52,6 +52,7 @@ struct CholArgs {
   const uint8_t* code;  // per-point component codes (infer_gp_sum) or null
   int n_fused;          // particles [0, n_fused) evaluate their tiles; the rest have them prebuilt in A
   int* ready;           // [P] block columns whose L(k,k) is published (in-kernel solve); zeroed per sweep
+  int wsteps;           // 1: W holds the current step's inverses only; nt: W keeps every step (gradient path)
 };
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     // stage +L(k,k) strictly-lower blocks and -W blocks in A-operand order (fragment s of lane l at 64 s + l)
     {
       const double* __restrict__ Lkk = Ap + tile_off(a.k, a.k);
-      const double* __restrict__ Wg = a.W + (long long)p * NSB * 256;
+      const double* __restrict__ Wg = a.W + ((long long)p * a.wsteps + (a.wsteps > 1 ? a.k : 0)) * NSB * 256;
       const int c = tid >> 4, r = tid & 15;
 #pragma unroll
       for (int jb = 1; jb < NSB; ++jb)
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
         wv[r] = t * rinvs[r];
       }
       if (l < 16) {
-        double* Wg = a.W + ((long long)p * NSB + jb) * 256;
+        double* Wg = a.W + (((long long)p * a.wsteps + (a.wsteps > 1 ? a.k : 0)) * NSB + jb) * 256;
 #pragma unroll
         for (int c = 0; c < 16; ++c) blk[c * 16 + l] = (c <= l) ? s[c] : 0.0;
 #pragma unroll
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_trsm(CholArgs a) {
   double* __restrict__ Ap = a.A + (long long)p * a.strideA;
   const double* __restrict__ Lkk = Ap + tile_off(a.k, a.k);
   double* __restrict__ Tt = Ap + tile_off(ti, a.k);
-  const double* __restrict__ Wg = a.W + (long long)p * NSB * 256;
+  const double* __restrict__ Wg = a.W + ((long long)p * a.wsteps + (a.wsteps > 1 ? a.k : 0)) * NSB * 256;
 
   // ---- stage -L(k,k) blocks and W blocks ----
   {

@@ -6,6 +6,7 @@
 #include "agp_cov_kernel.hpp"
 #include "agp_chol_kernel.hpp"
 #include "agp_experiments.hpp"
+#include "agp_grad_kernel.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -41,14 +42,16 @@ struct DevBuf {
 struct Slot {
   hipStream_t stream = nullptr;
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
-      pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add;
+      pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
+      Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise;
   std::vector<hipEvent_t> events;
   std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
   std::vector<hipEvent_t> sub_ev;     // fork / join events
   bool busy = false;
   void release() {
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
-                      &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add})
+                      &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
+                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise})
       b->release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
@@ -161,6 +164,7 @@ struct SlotGuard {
 // ------------------------------------------------------------------------------------------
 struct CNode {
   int op; int left = -1, right = -1; double prm[3] = {0, 0, 0}; int need = 1;
+  int prm_idx = 0;     // position of this node's first parameter in the caller's parameter array
 };
 
 struct Compiled {
@@ -168,6 +172,9 @@ struct Compiled {
   std::vector<double> prm;
   int n_cp = 0;
   int depth_need = 1;
+  std::vector<CNode> nodes;   // parsed tree (kept for the gradient program)
+  int root = -1;
+  int n_prm_caller = 0;
 };
 
 int leaf_nprm(int op) {
@@ -223,6 +230,7 @@ const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, in
       const int k = leaf_nprm(op);
       if (ip + k > n_prm) return "parameter array too short";
       for (int q = 0; q < k; ++q) nd.prm[q] = prm[ip + q];
+      nd.prm_idx = ip;
       ip += k;
       nd.need = 1;
     } else if (op == OP_PLUS || op == OP_TIMES || op == OP_CP) {
@@ -231,7 +239,7 @@ const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, in
       nd.left = stack.back(); stack.pop_back();
       if (op == OP_CP) {
         if (ip + 2 > n_prm) return "parameter array too short";
-        nd.prm[0] = prm[ip]; nd.prm[1] = prm[ip + 1]; ip += 2;
+        nd.prm[0] = prm[ip]; nd.prm[1] = prm[ip + 1]; nd.prm_idx = ip; ip += 2;
       }
       const int a = nodes[nd.left].need, b = nodes[nd.right].need;
       nd.need = (a == b) ? a + 1 : std::max(a, b);
@@ -246,6 +254,9 @@ const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, in
   out.depth_need = nodes[stack[0]].need;
   if (out.depth_need > 8) return "kernel tree needs an evaluation stack deeper than 8";
   emit(nodes, stack[0], out);
+  out.root = stack[0];
+  out.n_prm_caller = n_prm;
+  out.nodes.swap(nodes);
   return nullptr;
 }
 
@@ -258,6 +269,12 @@ struct Batch {
   int max_cp = 0;
   int max_depth = 1;
   int max_cp_fused = 0, max_depth_fused = 1;
+  // gradient programs (sorted order), built on request
+  std::vector<GProgHdr> ghdr;
+  std::vector<uint8_t> gops, glc, grc;
+  std::vector<int32_t> gpoff, gmap;
+  std::vector<double> gprm;
+  int g_max_nodes = 0, g_max_prm = 0, g_max_cp = 0;
 };
 
 // Measured cost of evaluating one 128x128 tile of a leaf inside k_chol_update (microseconds, MI355X).
@@ -275,8 +292,28 @@ double op_cost_us(int op) {
 // would set the duration of the short launches; such particles get their tiles from k_cov_tiles.
 constexpr double FUSE_MAX_TILE_US = 160.0;
 
+// Gradient program of one tree: nodes in evaluation (post-)order with TRUE left/right child indices, the
+// original parameter values and, per parameter slot, its index in the caller's parameter array.
+int emit_grad(const std::vector<CNode>& nodes, int id, Batch& bt, int prm_base, int node_base) {
+  const CNode& nd = nodes[id];
+  int li = 0, ri = 0;
+  if (nd.left >= 0) {
+    const bool swap = nodes[nd.right].need > nodes[nd.left].need;   // same evaluation order as the value program
+    if (swap) { ri = emit_grad(nodes, nd.right, bt, prm_base, node_base); li = emit_grad(nodes, nd.left, bt, prm_base, node_base); }
+    else { li = emit_grad(nodes, nd.left, bt, prm_base, node_base); ri = emit_grad(nodes, nd.right, bt, prm_base, node_base); }
+  }
+  const int me = (int)bt.gops.size() - node_base;
+  bt.gops.push_back((uint8_t)nd.op);
+  bt.glc.push_back((uint8_t)li);
+  bt.grc.push_back((uint8_t)ri);
+  bt.gpoff.push_back((int32_t)bt.gprm.size() - prm_base);
+  const int k = nd.left < 0 ? leaf_nprm(nd.op) : (nd.op == OP_CP ? 2 : 0);
+  for (int q = 0; q < k; ++q) { bt.gprm.push_back(nd.prm[q]); bt.gmap.push_back(nd.prm_idx + q); }
+  return me;
+}
+
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
-                  const double* prm, Batch& bt, bool allow_sel = false) {
+                  const double* prm, Batch& bt, bool allow_sel = false, bool want_grad = false) {
   std::vector<Compiled> cps(P);
   std::vector<double> cost(P, 0.0);
   for (int p = 0; p < P; ++p) {
@@ -320,6 +357,22 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
       bt.max_cp_fused = std::max(bt.max_cp_fused, cp.n_cp);
       bt.max_depth_fused = std::max(bt.max_depth_fused, cp.depth_need);
     }
+  }
+  if (want_grad) {
+    bt.ghdr.resize(P);
+    for (int q = 0; q < P; ++q) {
+      const Compiled& cp = cps[bt.order[q]];
+      GProgHdr g;
+      g.node_off = (int32_t)bt.gops.size(); g.prm_off = (int32_t)bt.gprm.size();
+      emit_grad(cp.nodes, cp.root, bt, g.prm_off, g.node_off);
+      g.n_ops = (int32_t)bt.gops.size() - g.node_off; g.n_prm = (int32_t)bt.gprm.size() - g.prm_off;
+      g.n_cp = cp.n_cp; g.pad_ = 0;
+      bt.ghdr[q] = g;
+      bt.g_max_nodes = std::max(bt.g_max_nodes, g.n_ops);
+      bt.g_max_prm = std::max(bt.g_max_prm, g.n_prm);
+      bt.g_max_cp = std::max(bt.g_max_cp, g.n_cp);
+    }
+    bt.gprm.push_back(0.0); bt.gprm.push_back(0.0); bt.gprm.push_back(0.0);
   }
   // keep ops 4-byte padded; the evaluator reads three parameters per leaf unconditionally
   while (bt.ops.size() % 4) bt.ops.push_back(0);
@@ -404,6 +457,7 @@ struct Prof {
 // per-particle ready word); otherwise update + k_chol_trsm launches.
 hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intrsm, Prof* pf, double* counts) {
   // (profiling marks are recorded on the stream the kernels are launched on)
+  if (ca.wsteps < 1) ca.wsteps = 1;
   const int Pg = (ca.P + 7) / 8;
   for (int k = 0; k < nfac; ++k) {
     ca.k = k;
@@ -438,12 +492,25 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intr
   return hipGetLastError();
 }
 
-// Core of agp_logpdf_batch{,_device}.  d_out_* may be caller device buffers (user_stream path)
-// or null (results copied to host h_out_*).
+struct GradOut {
+  double* grad;      // host, caller's parameter layout (prm_off), d logpdf / d parameter
+  double* gnoise;    // host [P], d logpdf / d noise
+};
+
+template <int MAXS>
+hipError_t launch_grad_tiles(hipStream_t st, const GradArgs& ga, int ntiles, int P, size_t lds) {
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grad_tiles<MAXS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_grad_tiles<MAXS>, dim3(ntiles, P), dim3(256), lds, st, ga);
+  return hipGetLastError();
+}
+
+// Core of agp_logpdf_batch{,_device} and agp_logpdf_grad_batch.  d_out_* may be caller device
+// buffers (user_stream path) or null (results copied to host h_out_*).
 int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
                       const int32_t* prm_off, const double* prm, const double* noise,
                       double* h_out_lp, int32_t* h_out_info, double* d_user_lp, int32_t* d_user_info,
-                      hipStream_t user_stream, bool use_user_stream) {
+                      hipStream_t user_stream, bool use_user_stream, GradOut* go = nullptr) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   if (P < 0 || n < 0) return fail(c, AGP_ERR_ARG, "negative size");
   if (P == 0) return AGP_OK;
@@ -452,8 +519,14 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   HIPCHK(c, hipSetDevice(c->device));
 
   Batch bt;
-  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt);
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr);
   if (rc) return rc;
+  if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
+  const int n_prm_total = prm_off[P];
+  if (go && n == 0) {
+    for (int i = 0; i < n_prm_total; ++i) go->grad[i] = 0.0;
+    for (int p = 0; p < P; ++p) go->gnoise[p] = 0.0;
+  }
 
   SlotGuard sg(c);
   Slot* s = sg.s;
@@ -474,11 +547,26 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     const int nt = n_pad / NB;
     const int ntiles = nt * (nt + 1) / 2;
     const long long strideA = (long long)ntiles * NB2;
-    const int64_t bytes_pp = strideA * 8;
+    const int64_t bytes_pp = strideA * 8 * (go ? 2 : 1);      // + Z = L^-T for the gradient
     int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(P, ws_limit_bytes(c) / bytes_pp));
+    const int wsteps = go ? nt : 1;
+    const int gstride = go ? bt.g_max_prm + 1 : 0;
 
-    HIPCHK(c, s->A.ensure((size_t)bytes_pp * chunk));
-    HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256 * (size_t)chunk));
+    HIPCHK(c, s->A.ensure((size_t)strideA * 8 * chunk));
+    HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256 * (size_t)chunk * wsteps));
+    if (go) {
+      HIPCHK(c, s->Z.ensure((size_t)strideA * 8 * chunk));
+      HIPCHK(c, s->alpha.ensure(sizeof(double) * (size_t)n_pad * chunk));
+      HIPCHK(c, s->gpart.ensure(sizeof(double) * (size_t)chunk * ntiles * gstride));
+      HIPCHK(c, s->ghdr.ensure(sizeof(GProgHdr) * (size_t)P));
+      HIPCHK(c, s->gops.ensure(bt.gops.size() + 4)); HIPCHK(c, s->glc.ensure(bt.glc.size() + 4)); HIPCHK(c, s->grc.ensure(bt.grc.size() + 4));
+      HIPCHK(c, s->gpoff.ensure(sizeof(int32_t) * (bt.gpoff.size() + 1)));
+      HIPCHK(c, s->gprm.ensure(sizeof(double) * bt.gprm.size()));
+      HIPCHK(c, s->gmap.ensure(sizeof(int32_t) * (bt.gmap.size() + 1)));
+      HIPCHK(c, s->goff.ensure(sizeof(int32_t) * (size_t)P));
+      HIPCHK(c, s->dgrad.ensure(sizeof(double) * (size_t)std::max(1, n_prm_total)));
+      HIPCHK(c, s->dgnoise.ensure(sizeof(double) * (size_t)P));
+    }
     HIPCHK(c, s->vec.ensure(sizeof(double) * (size_t)n_pad * chunk));
     HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
     HIPCHK(c, s->info.ensure(sizeof(int) * (size_t)chunk));
@@ -500,6 +588,21 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     HIPCHK(c, s->map.ensure(sizeof(int32_t) * (size_t)P));
     HIPCHK(c, hipMemcpyAsync(s->noise.p, noise_sorted.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(s->map.p, bt.order.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+    std::vector<int32_t> goff_sorted;
+    if (go) {
+      goff_sorted.resize(P);
+      for (int q = 0; q < P; ++q) goff_sorted[q] = prm_off[bt.order[q]];
+      HIPCHK(c, hipMemcpyAsync(s->ghdr.p, bt.ghdr.data(), sizeof(GProgHdr) * P, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(s->gops.p, bt.gops.data(), bt.gops.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(s->glc.p, bt.glc.data(), bt.glc.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(s->grc.p, bt.grc.data(), bt.grc.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(s->gpoff.p, bt.gpoff.data(), sizeof(int32_t) * bt.gpoff.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(s->gprm.p, bt.gprm.data(), sizeof(double) * bt.gprm.size(), hipMemcpyHostToDevice, st));
+      if (!bt.gmap.empty())
+        HIPCHK(c, hipMemcpyAsync(s->gmap.p, bt.gmap.data(), sizeof(int32_t) * bt.gmap.size(), hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipMemcpyAsync(s->goff.p, goff_sorted.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+      HIPCHK(c, hipStreamSynchronize(st));     // goff_sorted is a local
+    }
     size_t ev_h2d = pf.mark();
     pf.span(7, ev_begin, ev_h2d);
 
@@ -551,7 +654,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         pf.span(1, e0, e1);
 
         CholArgs ca = {};
-        ca.A = cv.A; ca.strideA = strideA; ca.W = s->W.as<double>() + (size_t)g0 * NSB * 256;
+        ca.A = cv.A; ca.strideA = strideA; ca.W = s->W.as<double>() + (size_t)g0 * NSB * 256 * wsteps;
+        ca.wsteps = wsteps;
         ca.vec = s->vec.as<double>() + (size_t)g0 * n_pad; ca.ldv = n_pad;
         ca.partial = s->partial.as<double>() + (size_t)g0 * 2 * nt;
         ca.info = s->info.as<int>() + g0; ca.P = Pg; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
@@ -566,6 +670,29 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         size_t e3 = pf.mark(q);
         pf.span(4, e2, e3);
         HIPCHK(c, hipGetLastError());
+        if (go) {
+          // ---- gradient: Z = L^-T, alpha = Z beta, per-tile contraction, fixed-order reduction ----
+          GradArgs ga = {};
+          ga.A = cv.A; ga.Z = s->Z.as<double>() + (size_t)g0 * strideA; ga.strideA = strideA; ga.W = ca.W;
+          ga.beta = ca.vec; ga.alpha = s->alpha.as<double>() + (size_t)g0 * n_pad; ga.ldv = n_pad;
+          ga.P = Pg; ga.nt = nt; ga.n = (int)n;
+          ga.ghdr = s->ghdr.as<GProgHdr>() + p0 + g0; ga.gops = s->gops.as<uint8_t>(); ga.glc = s->glc.as<uint8_t>();
+          ga.grc = s->grc.as<uint8_t>(); ga.gpoff = s->gpoff.as<int32_t>(); ga.gprm = s->gprm.as<double>();
+          ga.tt = c->d_ts; ga.gpart = s->gpart.as<double>() + (size_t)g0 * ntiles * gstride; ga.gstride = gstride;
+          ga.gmap = s->gmap.as<int32_t>(); ga.out_off = s->goff.as<int32_t>() + p0 + g0;
+          ga.pmap = s->map.as<int32_t>() + p0 + g0; ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
+          const int Pg8 = (Pg + 7) / 8;
+          for (int i = 0; i < nt; ++i) {
+            ga.step = i;
+            hipLaunchKernelGGL(k_trtri_step, dim3(8 * Pg8 * (i + 1)), dim3(256), 0, q, ga);
+          }
+          hipLaunchKernelGGL(k_alpha, dim3(nt, Pg), dim3(256), 0, q, ga);
+          const size_t lds = sizeof(double) * std::max<size_t>(2 * U_SLAB, 256 + 256 * (size_t)bt.g_max_cp);
+          if (bt.g_max_nodes <= 16) HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, Pg, lds));
+          else HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, Pg, lds));
+          hipLaunchKernelGGL(k_grad_finish, dim3(Pg), dim3(64), 0, q, ga);
+          HIPCHK(c, hipGetLastError());
+        }
         if (g > 0) {
           HIPCHK(c, hipEventRecord(s->sub_ev[g], q));
           HIPCHK(c, hipStreamWaitEvent(st, s->sub_ev[g], 0));
@@ -583,6 +710,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   }
 
   if (h_out_lp) HIPCHK(c, hipMemcpyAsync(h_out_lp, d_lp, sizeof(double) * P, hipMemcpyDeviceToHost, st));
+  if (go && n > 0) {
+    if (n_prm_total > 0)
+      HIPCHK(c, hipMemcpyAsync(go->grad, s->dgrad.p, sizeof(double) * n_prm_total, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(go->gnoise, s->dgnoise.p, sizeof(double) * P, hipMemcpyDeviceToHost, st));
+  }
   std::vector<int32_t> info_chk;
   int32_t* h_info = h_out_info;
   if (!h_info) { info_chk.resize(P); h_info = info_chk.data(); }
@@ -708,6 +840,15 @@ int agp_logpdf_batch(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, co
   if (c && P > 0 && (!out_logpdf || !out_info)) return fail(c, AGP_ERR_ARG, "null output pointer");
   return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr, nullptr,
                            nullptr, false);
+}
+
+int agp_logpdf_grad_batch(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
+                          const int32_t* prm_off, const double* prm, const double* noise, double* out_logpdf,
+                          double* out_grad, double* out_grad_noise, int32_t* out_info) {
+  if (c && P > 0 && (!out_logpdf || !out_info || !out_grad || !out_grad_noise)) return fail(c, AGP_ERR_ARG, "null output pointer");
+  GradOut go{out_grad, out_grad_noise};
+  return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr, nullptr, nullptr,
+                           false, &go);
 }
 
 int agp_logpdf_batch_device(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,

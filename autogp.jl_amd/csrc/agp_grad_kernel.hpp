@@ -1,0 +1,401 @@
+// Gradient of the log marginal likelihood w.r.t. every kernel parameter and the noise
+// (SURVEY.md §8 f1).  Replaces what Gen.choice_gradients obtains today by ReverseDiff through the
+// eval_cov broadcasts of src/GP.jl plus Gen.mvnormal.logpdf_grad (a full inverse), driven by Gen.hmc
+// (src/inference_smc_anneal_data.jl:63-67) and Gen.map_optimize (src/Greedy.jl:95,370).
+//
+//   d logpdf / d theta = sum_ab G_ab dK_ab/dtheta,   G = 1/2 (alpha alpha' - K^-1),  alpha = K^-1 x,
+//   d logpdf / d noise = tr G.
+//
+// After the Cholesky sweep (L in the packed lower tiles, beta = L^-1 x in the vector):
+//   k_trtri_step(i)  Z = L^-T, one block column per launch, Z(j,i) = [d_ji I - sum_{k=j}^{i-1} Z(j,k) L(i,k)^T] L(i,i)^-T:
+//                    the same "128x128xK MFMA GEMM + in-register blocked solve" as the factorisation
+//                    (the per-step 16x16 inverses W are kept for this).  Z(r,k), r <= k, is stored in the
+//                    slot of lower tile (k,r) of a second packed buffer, so both K^-1 = Z Z^T and the
+//                    recurrence contract over contiguous 16-column slabs exactly like L L^T does.
+//   k_alpha          alpha_j = sum_{k>=j} Z(j,k) beta_k
+//   k_grad_tiles     per lower tile (i,j): K^-1(i,j) = sum_{k>=i} Z(i,k) Z(j,k)^T in MFMA accumulators (never
+//                    written to HBM), G on the fly, then a reverse-mode pass over the kernel program per
+//                    element accumulates G_ab dK_ab/dtheta; per-tile partial sums go to a small buffer
+//   k_grad_finish    fixed-order sum over tiles (deterministic), scatter to the caller's parameter order
+#pragma once
+#include "agp_chol_kernel.hpp"
+
+namespace agp {
+
+// ---- shared building blocks (same wave tiling as k_chol_update: wave w owns rows [32w, 32w+32),
+//      strips = even / odd rows, 8 column blocks) ------------------------------------------------------
+
+// acc += sum_s rowop(s) colop(s)^T over `nslab` 16-column slabs.  colop slabs are staged through LDS
+// (double buffered, shared by the 4 waves), rowop fragments go global -> registers.
+template <typename FR, typename FC>
+__device__ __forceinline__ void gemm_slabs(d4 (&acc)[NSB][2], int nslab, FR rowslab, FC colslab, double* sm,
+                                           int tid, int l15, int lq, int row0) {
+  if (nslab <= 0) return;
+  const int scol0 = tid >> 6, srow = 2 * (tid & 63);
+  d2 ra[4], rb[4];
+  auto gload = [&](int s) {
+    const double* __restrict__ srcA = rowslab(s);
+    const double* __restrict__ srcB = colslab(s);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      ra[u] = *reinterpret_cast<const d2*>(srcA + (4 * u + lq) * NB + row0);
+      rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 4 * u) * NB + srow);
+    }
+  };
+  auto lstore = [&](int buf) {
+    double* Bs = sm + buf * U_SLAB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb[u];
+  };
+  gload(0);
+  lstore(0);
+  d2 fr[4] = {ra[0], ra[1], ra[2], ra[3]};
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) gload(s + 1);
+    const double* Bs = sm + buf * U_SLAB;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < KB / 4; ++kk) {
+      const int krow = (kk * 4 + lq) * LDS_STRIDE;
+      double fa[NSB];
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb) {
+        acc[cb][0] = mfma(fa[cb], fr[kk].x, acc[cb][0]);
+        acc[cb][1] = mfma(fa[cb], fr[kk].y, acc[cb][1]);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (s + 1 < nslab) {
+      lstore(buf ^ 1);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fr[u] = ra[u];
+    }
+    __syncthreads();
+  }
+}
+
+// Stage +L(k,k) strictly-lower 16x16 blocks and -W blocks in LDS (A-operand order) and solve
+// X L(k,k)^T = C in place on acc = -C (see k_chol_update).  Caller syncs before (LDS reuse).
+__device__ __forceinline__ void solve_in_regs(d4 (&acc)[NSB][2], const double* __restrict__ Lkk,
+                                              const double* __restrict__ Wg, double* sm, int tid, int l) {
+  {
+    const int c = tid >> 4, r = tid & 15;
+#pragma unroll
+    for (int jb = 1; jb < NSB; ++jb)
+#pragma unroll
+      for (int lb = 0; lb < jb; ++lb) sm[sblk_idx(jb, lb) * 256 + tid] = Lkk[(lb * 16 + c) * NB + jb * 16 + r];
+#pragma unroll
+    for (int u = 0; u < NSB; ++u) sm[(T_NBLK + u) * 256 + tid] = -Wg[u * 256 + tid];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int jb = 0; jb < NSB; ++jb) {
+#pragma unroll
+    for (int lb = 0; lb < jb; ++lb) {
+      const double* blk = sm + sblk_idx(jb, lb) * 256;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const double fl = blk[64 * s4 + l];
+        acc[jb][0] = mfma(fl, acc[lb][0][s4], acc[jb][0]);
+        acc[jb][1] = mfma(fl, acc[lb][1][s4], acc[jb][1]);
+      }
+    }
+    d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const double fw = sm[(T_NBLK + jb) * 256 + 64 * s4 + l];
+      x0 = mfma(fw, acc[jb][0][s4], x0);
+      x1 = mfma(fw, acc[jb][1][s4], x1);
+    }
+    acc[jb][0] = x0;
+    acc[jb][1] = x1;
+  }
+}
+
+struct GradArgs {
+  const double* A;       // packed lower tiles of L
+  double* Z;             // packed buffer holding Z(r,k), r <= k, in the slot of lower tile (k,r)
+  long long strideA;
+  const double* W;       // [P][nt][NSB][256] per-step 16x16 inverses
+  const double* beta;    // [P][ldv]  L^-1 x
+  double* alpha;         // [P][ldv]  K^-1 x
+  int ldv;
+  int P, nt, n;          // n = valid points (no prediction segment here)
+  int step;              // k_trtri_step: block column i
+  // gradient programs (device order; see GProgHdr)
+  const struct GProgHdr* ghdr;
+  const uint8_t* gops;   // opcode per node
+  const uint8_t* glc;    // left / right child node index per node (binary nodes)
+  const uint8_t* grc;
+  const int32_t* gpoff;  // per node: offset of its parameters inside the particle's parameter block
+  const double* gprm;    // ORIGINAL (untransformed-by-us) parameter values, device node order
+  const double* tt;      // time points (padded)
+  double* gpart;         // [P][ntiles][gstride] per-tile partial sums (slot 0..n_prm-1 params, n_prm = noise)
+  int gstride;
+  const int32_t* gmap;   // per particle parameter slot -> index in the caller's parameter array
+  const int32_t* out_off;   // [P] offset of the particle's gradient block in out_grad (caller order, via map)
+  const int32_t* pmap;   // sorted particle -> caller particle
+  double* out_grad;
+  double* out_gnoise;
+};
+
+struct GProgHdr {
+  int32_t node_off;   // offset into gops / glc / grc / gpoff
+  int32_t prm_off;    // offset into gprm / gmap
+  int32_t n_ops;
+  int32_t n_prm;
+  int32_t n_cp;
+  int32_t pad_;
+};
+
+__device__ __forceinline__ long long zoff(int r, int k) { return tile_off(k, r); }   // r <= k
+
+// ---- Z = L^-T, block column `step` -------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_trtri_step(GradArgs a) {
+  __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES];
+  const int i = a.step;
+  const int T = i + 1;
+  const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
+  const int pl = qq / T, j = qq - pl * T;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  const int row0 = 32 * w + 2 * l15;
+  const double* __restrict__ Lp = a.A + (long long)p * a.strideA;
+  double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
+
+  // acc = -C,  C = d_ji I - sum_k Z(j,k) L(i,k)^T
+  d4 acc[NSB][2];
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[cb][st][r] = (j == i && (cb * 16 + 4 * r + lq) == row0 + st) ? -1.0 : 0.0;
+  const int nslab = (i - j) * (NB / KB);
+  gemm_slabs(acc, nslab,
+             [&](int s) { return Zp + zoff(j, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+             [&](int s) { return Lp + tile_off(i, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+             sm, tid, l15, lq, row0);
+  solve_in_regs(acc, Lp + tile_off(i, i), a.W + ((long long)p * a.nt + i) * NSB * 256, sm, tid, l);
+  double* __restrict__ Tt = Zp + zoff(j, i);
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d2 o2; o2.x = acc[cb][0][r]; o2.y = acc[cb][1][r];
+      *reinterpret_cast<d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
+    }
+}
+
+// ---- alpha_j = sum_{k >= j} Z(j,k) beta_k --------------------------------------------------------
+__global__ __launch_bounds__(256) void k_alpha(GradArgs a) {
+  __shared__ double part[256];
+  const int j = blockIdx.x, p = blockIdx.y;
+  const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;     // two column halves
+  const double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
+  const double* __restrict__ bp = a.beta + (long long)p * a.ldv;
+  double s = 0.0;
+  for (int k = j; k < a.nt; ++k) {
+    const double* __restrict__ Zt = Zp + zoff(j, k);
+    const double* __restrict__ bk = bp + k * NB;
+#pragma unroll 8
+    for (int c = h * 64; c < h * 64 + 64; ++c) s = fma(Zt[c * NB + r], bk[c], s);
+  }
+  part[tid] = s;
+  __syncthreads();
+  if (tid < 128) a.alpha[(long long)p * a.ldv + j * NB + tid] = part[tid] + part[tid + 128];
+}
+
+// ---- reverse-mode pass over one element --------------------------------------------------------
+// tape: per node {value, aux1, aux2}; adj: per node adjoint; gacc: per parameter slot accumulator.
+// All three are runtime-indexed per-lane arrays (private memory, lane-interleaved -> coalesced).
+template <int MAXS>
+__device__ __forceinline__ void grad_element(const GProgHdr& h, const uint8_t* __restrict__ ops,
+                                             const uint8_t* __restrict__ lc, const uint8_t* __restrict__ rc,
+                                             const int32_t* __restrict__ poff, const double* __restrict__ prm,
+                                             const double* sig, int ri, int ci, double ta, double tb, double wgt,
+                                             double (&tape)[3 * MAXS], double (&adj)[MAXS], double (&gacc)[3 * MAXS + 2]) {
+  const double PI = 3.14159265358979323846;
+  // ---------------- forward ----------------
+  int cpi = 0;
+  for (int ip = 0; ip < h.n_ops; ++ip) {
+    const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
+    const double* q = prm + poff[ip];
+    double v = 0.0, x1 = 0.0, x2 = 0.0;
+    if (o == OP_WN) { x1 = (ta == tb) ? 1.0 : 0.0; v = x1 * q[0]; }
+    else if (o == OP_CONST) { v = q[0]; }
+    else if (o == OP_LIN) { x1 = (ta - q[0]) * (tb - q[0]); v = q[1] + q[2] * x1; }
+    else if (o == OP_SE) { const double d = ta - tb; x1 = d * d; x2 = fm::exp_f(-0.5 * x1 / (q[0] * q[0])); v = q[1] * x2; }
+    else if (o == OP_GE) {
+      const double u = fabs(ta - tb) / q[0];
+      x1 = fm::pow_f(u, q[1]);                                   // u^gamma
+      x2 = u > 0.0 ? x1 * fm::log_f(u) : 0.0;                    // u^gamma ln u  (-> 0 at u = 0)
+      v = q[2] * fm::exp_f(-x1);
+    } else if (o == OP_PER) {
+      const double ang = PI / q[1] * fabs(ta - tb);
+      double sn, cs;
+      sincos(ang, &sn, &cs);
+      x1 = sn * sn; x2 = sn * cs * fabs(ta - tb);
+      v = q[2] * fm::exp_f(-2.0 * x1 / (q[0] * q[0]));
+    } else if (o == OP_PLUS) { v = tape[3 * lc[ip]] + tape[3 * rc[ip]]; }
+    else if (o == OP_TIMES) { v = tape[3 * lc[ip]] * tape[3 * rc[ip]]; }
+    else {   // OP_CP (children by true left / right index)
+      const double sa = sig[cpi * 256 + ri], sb = sig[cpi * 256 + ci];
+      x1 = sa; x2 = sb;
+      v = (sa * sb) * tape[3 * lc[ip]] + ((1.0 - sa) * (1.0 - sb)) * tape[3 * rc[ip]];
+      ++cpi;
+    }
+    tape[3 * ip] = v; tape[3 * ip + 1] = x1; tape[3 * ip + 2] = x2;
+  }
+  // ---------------- backward ----------------
+  adj[h.n_ops - 1] = wgt;
+  for (int ip = h.n_ops - 1; ip >= 0; --ip) {
+    const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
+    const int po = poff[ip];
+    const double* q = prm + po;
+    const double ad = adj[ip];
+    const double v = tape[3 * ip], x1 = tape[3 * ip + 1], x2 = tape[3 * ip + 2];
+    if (o == OP_WN) { gacc[po] += ad * x1; }
+    else if (o == OP_CONST) { gacc[po] += ad; }
+    else if (o == OP_LIN) {
+      gacc[po] += ad * (-q[2] * (ta + tb - 2.0 * q[0]));
+      gacc[po + 1] += ad;
+      gacc[po + 2] += ad * x1;
+    } else if (o == OP_SE) {
+      gacc[po] += ad * v * x1 / (q[0] * q[0] * q[0]);
+      gacc[po + 1] += ad * x2;
+    } else if (o == OP_GE) {
+      gacc[po] += ad * v * q[1] * x1 / q[0];
+      gacc[po + 1] += ad * (-v * x2);
+      gacc[po + 2] += ad * v / q[2];
+    } else if (o == OP_PER) {
+      const double l2 = q[0] * q[0];
+      gacc[po] += ad * v * 4.0 * x1 / (l2 * q[0]);
+      gacc[po + 1] += ad * v * 4.0 * x2 * PI / (l2 * q[1] * q[1]);
+      gacc[po + 2] += ad * v / q[2];
+    } else if (o == OP_PLUS) { adj[lc[ip]] = ad; adj[rc[ip]] = ad; }
+    else if (o == OP_TIMES) { adj[lc[ip]] = ad * tape[3 * rc[ip]]; adj[rc[ip]] = ad * tape[3 * lc[ip]]; }
+    else {   // OP_CP: q = {location, scale}; x1 = sigma_a, x2 = sigma_b
+      const double kl = tape[3 * lc[ip]], kr = tape[3 * rc[ip]];
+      adj[lc[ip]] = ad * (x1 * x2);
+      adj[rc[ip]] = ad * ((1.0 - x1) * (1.0 - x2));
+      // d sigma / d loc = 2 sigma (1 - sigma) / scale;  d sigma / d scale = -(loc - t)/scale * that
+      const double da = 2.0 * x1 * (1.0 - x1) / q[1], db = 2.0 * x2 * (1.0 - x2) / q[1];
+      const double dl = (da * x2 + x1 * db) * kl - (da * (1.0 - x2) + (1.0 - x1) * db) * kr;
+      const double das = -da * (q[0] - ta) / q[1], dbs = -db * (q[0] - tb) / q[1];
+      const double ds = (das * x2 + x1 * dbs) * kl - (das * (1.0 - x2) + (1.0 - x1) * dbs) * kr;
+      gacc[po] += ad * dl;
+      gacc[po + 1] += ad * ds;
+    }
+  }
+}
+
+// GE amplitude: v / q[2] = exp part (q[2] = amplitude != 0 by the prior); same for Periodic.
+
+template <int MAXS>
+__global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];   // slab buffers, then tpt | sig | reduction
+  const int tix = blockIdx.x, p = blockIdx.y;
+  int ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tix) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
+  const int tj = tix - ti * (ti + 1) / 2;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  const int row0 = 32 * w + 2 * l15;
+  const double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
+
+  // ---- K^-1(ti,tj) = sum_{k >= ti} Z(ti,k) Z(tj,k)^T ----
+  d4 acc[NSB][2];
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
+  gemm_slabs(acc, (a.nt - ti) * (NB / KB),
+             [&](int s) { return Zp + zoff(ti, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+             [&](int s) { return Zp + zoff(tj, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+             smem, tid, l15, lq, row0);
+
+  // ---- per-element reverse-mode contraction ----
+  const GProgHdr h = a.ghdr[p];
+  const uint8_t* __restrict__ ops = a.gops + h.node_off;
+  const uint8_t* __restrict__ lc = a.glc + h.node_off;
+  const uint8_t* __restrict__ rc = a.grc + h.node_off;
+  const int32_t* __restrict__ poff = a.gpoff + h.node_off;
+  const double* __restrict__ prm = a.gprm + h.prm_off;
+  double* tpt = smem;
+  double* sig = smem + 256;
+  {
+    const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
+    tpt[tid] = a.tt[g];
+    __syncthreads();
+    if (h.n_cp > 0) {
+      const double t = tpt[tid];
+      int c = 0;
+      for (int ip = 0; ip < h.n_ops; ++ip)
+        if (ops[ip] == OP_CP) {
+          const double* q = prm + poff[ip];
+          sig[c * 256 + tid] = 0.5 * (1.0 + tanh((q[0] - t) / q[1]));
+          ++c;
+        }
+    }
+    __syncthreads();
+  }
+  double tape[3 * MAXS], adj[MAXS], gacc[3 * MAXS + 2];
+  for (int q = 0; q <= h.n_prm; ++q) gacc[q] = 0.0;
+  const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
+  const double wfac = (ti == tj) ? 1.0 : 2.0;
+#pragma unroll 1
+  for (int t = 0; t < 16; ++t) {
+    const int cb = t >> 1, st = t & 1;
+    d4 v;
+    switch (t) {
+      case 0: v = acc[0][0]; break;  case 1: v = acc[0][1]; break;  case 2: v = acc[1][0]; break;  case 3: v = acc[1][1]; break;
+      case 4: v = acc[2][0]; break;  case 5: v = acc[2][1]; break;  case 6: v = acc[3][0]; break;  case 7: v = acc[3][1]; break;
+      case 8: v = acc[4][0]; break;  case 9: v = acc[4][1]; break;  case 10: v = acc[5][0]; break; case 11: v = acc[5][1]; break;
+      case 12: v = acc[6][0]; break; case 13: v = acc[6][1]; break; case 14: v = acc[7][0]; break; default: v = acc[7][1]; break;
+    }
+    const int rslot = row0 + st;
+    const int ga = ti * NB + rslot;
+#pragma unroll 1
+    for (int r = 0; r < 4; ++r) {
+      const int cslot = cb * 16 + 4 * r + lq;
+      const int gb = tj * NB + cslot;
+      if (ga < a.n && gb < a.n) {     // padding rows / columns carry no parameter dependence
+        const double kinv = (r == 0) ? v[0] : (r == 1) ? v[1] : (r == 2) ? v[2] : v[3];
+        const double G = 0.5 * (al[ga] * al[gb] - kinv);
+        if (ga == gb) gacc[h.n_prm] += G;                      // d/d noise = tr G
+        grad_element<MAXS>(h, ops, lc, rc, poff, prm, sig, rslot, NB + cslot, tpt[rslot], tpt[NB + cslot], wfac * G,
+                           tape, adj, gacc);
+      }
+    }
+  }
+  // ---- reduce over the 256 threads, one parameter slot at a time ----
+  __syncthreads();
+  double* red = smem;      // [4] per-wave sums
+  for (int q = 0; q <= h.n_prm; ++q) {
+    double s = gacc[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (l == 0) red[w] = s;
+    __syncthreads();
+    if (tid == 0) a.gpart[((long long)p * (a.nt * (a.nt + 1) / 2) + tix) * a.gstride + q] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+}
+
+__global__ void k_grad_finish(GradArgs a) {
+  const int p = blockIdx.x;
+  const GProgHdr h = a.ghdr[p];
+  const int ntiles = a.nt * (a.nt + 1) / 2;
+  for (int q = threadIdx.x; q <= h.n_prm; q += blockDim.x) {
+    double s = 0.0;
+    for (int t = 0; t < ntiles; ++t) s += a.gpart[((long long)p * ntiles + t) * a.gstride + q];
+    if (q < h.n_prm) a.out_grad[a.out_off[p] + a.gmap[h.prm_off + q]] = s;
+    else a.out_gnoise[a.pmap[p]] = s;
+  }
+}
+
+}  // namespace agp

@@ -25,7 +25,7 @@ LIB_PATH = _PKG_DIR / "lib" / "libautogp_hip.so"
 
 EXPORTED_SYMBOLS = [
     "agp_init", "agp_destroy", "agp_last_error", "agp_version", "agp_set_data", "agp_logpdf",
-    "agp_logpdf_batch", "agp_logpdf_batch_device", "agp_predict_batch", "agp_infer_gp_sum", "agp_cov_matrix",
+    "agp_logpdf_batch", "agp_logpdf_grad_batch", "agp_logpdf_batch_device", "agp_predict_batch", "agp_infer_gp_sum", "agp_cov_matrix",
     "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_debug_mfma_peak", "agp_debug_math", "agp_debug_gemm_variant", "agp_set_profiling", "agp_get_timing", "agp_get_launch_times",
     "agp_set_workspace_limit", "agp_set_coalesce_window", "agp_get_coalesce_stats",
 ]
@@ -90,6 +90,8 @@ def load_library(path=None):
     lib.agp_logpdf.restype = C.c_int
     lib.agp_logpdf_batch.argtypes = [vp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, ip]
     lib.agp_logpdf_batch.restype = C.c_int
+    lib.agp_logpdf_grad_batch.argtypes = [vp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, dp, dp, ip]
+    lib.agp_logpdf_grad_batch.restype = C.c_int
     lib.agp_logpdf_batch_device.argtypes = [vp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, vp, vp, vp]
     lib.agp_logpdf_batch_device.restype = C.c_int
     lib.agp_predict_batch.argtypes = [vp, C.c_int64, dp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, dp, dp,
@@ -200,6 +202,22 @@ class GPEngine:
             p = int(np.argmax(info > 0))
             raise PosDefException(int(info[p]), p)
         return out, info
+
+    def logpdf_grad_batch(self, nodes, noises, n=None, check=True, programs=None):
+        """(logpdf[P], grads, grad_noise[P], info[P]); grads[p] is d logpdf / d theta in the order of
+        gp.encode(node)[1] (transformed parameters; ChangePoint contributes location, scale)."""
+        n = self.n_max if n is None else int(n)
+        op_off, ops, prm_off, prm = programs if programs is not None else _gp.encode_batch(nodes)
+        P = op_off.shape[0] - 1
+        noises = _f64(noises)
+        out = np.empty(P); info = np.empty(P, dtype=np.int32); gn = np.empty(P)
+        grad = np.zeros(max(1, int(prm_off[-1])))
+        self._check(self._lib.agp_logpdf_grad_batch(self._ctx, n, P, _ip(op_off), _u8(ops), _ip(prm_off), _dp(prm), _dp(noises),
+                                                    _dp(out), _dp(grad), _dp(gn), _ip(info)))
+        if check and (info > 0).any():
+            p = int(np.argmax(info > 0))
+            raise PosDefException(int(info[p]), p)
+        return out, [grad[prm_off[i]:prm_off[i + 1]] for i in range(P)], gn, info
 
     def logpdf_batch_device(self, programs, noises, n, d_out_ptr, d_info_ptr, stream_ptr=0):
         """Results stay in device memory (raw pointers, e.g. torch tensors' data_ptr())."""

@@ -90,6 +90,18 @@ int agp_logpdf_batch(agp_ctx* ctx, int64_t n, int32_t P,
                      const double* noise,
                      double* out_logpdf /* P */, int32_t* out_info /* P */);
 
+/* Value AND gradient: d logpdf / d theta for every (transformed) kernel parameter — out_grad has the
+ * layout of `prm` (prm_off offsets; ChangePoint contributes d/dlocation, d/dscale) — and d logpdf / d noise.
+ * This is what Gen.choice_gradients needs from the model body for Gen.hmc / Gen.map_optimize
+ * (src/inference_smc_anneal_data.jl:63-67, src/Greedy.jl:95,370); the chain rule through
+ * transform_param (src/Model.jl:24-48) stays on the host.  Kernel trees of up to 64 nodes. */
+int agp_logpdf_grad_batch(agp_ctx* ctx, int64_t n, int32_t P,
+                          const int32_t* op_off, const uint8_t* ops,
+                          const int32_t* prm_off, const double* prm,
+                          const double* noise,
+                          double* out_logpdf /* P */, double* out_grad /* prm_off[P] */,
+                          double* out_grad_noise /* P */, int32_t* out_info /* P */);
+
 /* Same sweep, results left in DEVICE memory (d_out_logpdf: P doubles, d_out_info: P int32,
  * both device pointers) and enqueued on `hip_stream` (a hipStream_t; NULL = the slot's own
  * stream, synchronised before return).  This is the entry the multi-GPU driver uses so that the

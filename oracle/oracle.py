@@ -319,3 +319,84 @@ def particle_weights(log_weights):
 def effective_sample_size(log_weights):
     w = particle_weights(log_weights)
     return 1.0 / float(np.sum(w * w))
+
+
+# --------------------------------------------------------------------------
+# gradient of the log marginal likelihood ("next" row f1): what Gen.choice_gradients obtains today
+# by ReverseDiff through eval_cov (src/GP.jl, all broadcasts) + Gen.mvnormal.logpdf_grad, driven by
+# Gen.hmc (src/inference_smc_anneal_data.jl:63-67) and Gen.map_optimize (src/Greedy.jl:95,370).
+# Restated analytically: d logpdf / d theta = 1/2 tr((alpha alpha' - K^-1) dK/dtheta), alpha = K^-1 x,
+# with dK/dtheta from the closed forms of the leaves (forward-mode over whole matrices; O(n^2 #params),
+# test sizes only).  Parameters are the TRANSFORMED ones, ordered as in the postfix parameter array of
+# tree_to_program (ChangePoint contributes d/dlocation, d/dscale at its own position).
+# --------------------------------------------------------------------------
+def eval_cov_grad(tree, ts):
+    """Returns (K, [dK/dtheta_0, dK/dtheta_1, ...]) with theta in program-parameter order."""
+    ts = np.asarray(ts, dtype=np.float64)
+    n = ts.shape[0]
+    tag = tree[0]
+    ta, tb = ts[:, None], ts[None, :]
+    if tag == "WN":
+        E = (ta == tb).astype(np.float64)
+        return E * float(tree[1]), [E]
+    if tag == "C":
+        return np.full((n, n), float(tree[1])), [np.ones((n, n))]
+    if tag == "LIN":
+        c, b, a = float(tree[1]), float(tree[2]), float(tree[3])
+        P = (ta - c) * (tb - c)
+        return b + a * P, [-a * (ta + tb - 2 * c), np.ones((n, n)), P]
+    if tag == "SE":
+        l, a = float(tree[1]), float(tree[2])
+        d2 = (ta - tb) ** 2
+        e = np.exp(-0.5 * d2 / l ** 2)
+        return a * e, [a * e * d2 / l ** 3, e]
+    if tag == "GE":
+        l, g, a = float(tree[1]), float(tree[2]), float(tree[3])
+        u = np.abs(ta - tb) / l
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ug = u ** g
+            lu = np.where(u > 0, np.log(np.where(u > 0, u, 1.0)), 0.0)
+        e = np.exp(-ug)
+        return a * e, [a * e * g * ug / l, -a * e * ug * lu, e]
+    if tag == "PER":
+        l, p, a = float(tree[1]), float(tree[2]), float(tree[3])
+        d = np.abs(ta - tb)
+        s, c = np.sin(np.pi * d / p), np.cos(np.pi * d / p)
+        e = np.exp(-2 * s * s / l ** 2)
+        return a * e, [a * e * 4 * s * s / l ** 3, a * e * 4 * s * c * np.pi * d / (l ** 2 * p ** 2), e]
+    if tag == "+":
+        Kl, Gl = eval_cov_grad(tree[1], ts); Kr, Gr = eval_cov_grad(tree[2], ts)
+        return Kl + Kr, Gl + Gr
+    if tag == "*":
+        Kl, Gl = eval_cov_grad(tree[1], ts); Kr, Gr = eval_cov_grad(tree[2], ts)
+        return Kl * Kr, [g * Kr for g in Gl] + [g * Kl for g in Gr]
+    if tag == "CP":
+        loc, sc = float(tree[3]), float(tree[4])
+        Kl, Gl = eval_cov_grad(tree[1], ts); Kr, Gr = eval_cov_grad(tree[2], ts)
+        z = (loc - ts) / sc
+        sg = 0.5 * (1 + np.tanh(z))
+        dsg_dloc = 0.5 * (1 - np.tanh(z) ** 2) / sc
+        dsg_dsc = -dsg_dloc * (loc - ts) / sc
+        S1 = sg[:, None] * sg[None, :]; S2 = (1 - sg)[:, None] * (1 - sg)[None, :]
+        K = S1 * Kl + S2 * Kr
+
+        def dS(dv):
+            d1 = dv[:, None] * sg[None, :] + sg[:, None] * dv[None, :]
+            d2 = -dv[:, None] * (1 - sg)[None, :] - (1 - sg)[:, None] * dv[None, :]
+            return d1 * Kl + d2 * Kr
+        return K, [S1 * g for g in Gl] + [S2 * g for g in Gr] + [dS(dsg_dloc), dS(dsg_dsc)]
+    raise ValueError(tag)
+
+
+def gp_logpdf_grad(tree, noise, ts, xs):
+    """(logpdf, d/dtheta [program-parameter order], d/dnoise) of `xs ~ mvnormal(0, eval_cov + noise I)`."""
+    ts = np.asarray(ts, dtype=np.float64); xs = np.asarray(xs, dtype=np.float64)
+    n = ts.shape[0]
+    K, dKs = eval_cov_grad(tree, ts)
+    K = K + noise * np.eye(n)
+    cf = sla.cho_factor(K, lower=True, check_finite=False)
+    alpha = sla.cho_solve(cf, xs)
+    Kinv = sla.cho_solve(cf, np.eye(n))
+    G = 0.5 * (np.outer(alpha, alpha) - Kinv)
+    lp = float(-0.5 * (n * math.log(2 * math.pi) + 2 * np.sum(np.log(np.diag(cf[0]))) + xs @ alpha))
+    return lp, np.array([float(np.sum(G * dK)) for dK in dKs]), float(np.trace(G))

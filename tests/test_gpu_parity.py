@@ -247,6 +247,49 @@ def test_predictive_likelihood_identity_on_gpu(pkg, engine):
         assert abs((lj - lo) - lpred) <= 1e-7 * max(1.0, abs(lpred))
 
 
+GRAD_TOL = 1e-7     # |g_gpu - g_ref| <= GRAD_TOL * max(1, |g_ref|_inf): both sides form K^-1 in fp64
+
+
+def test_logpdf_gradient(pkg, engine):
+    """d logpdf / d theta and d / d noise against the analytic oracle (itself pinned by finite
+    differences and mpmath in tests/test_oracle.py): fixture kernels, composites, ChangePoints, a duplicate
+    time point, n not a multiple of the tile, and a batch large enough for the fused build."""
+    G = pkg
+    base = base_kernels(G)
+    kernels = list(base) + [base[2] + base[5], base[3] * base[4], G.ChangePoint(base[2], base[5], 0.5, 0.05),
+                            G.ChangePoint(base[3] + base[4], base[2] * base[5], 0.3, 0.2),
+                            (base[2] + base[3]) * (base[4] + base[5]) + G.ChangePoint(base[1], base[0], 0.6, 0.1)]
+    rng = np.random.default_rng(23)
+    for n in (40, 200, 300):
+        ts = np.sort(rng.random(n)); ts[n // 2] = ts[n // 2 - 1]; xs = 0.4 * rng.standard_normal(n)
+        engine.set_data(ts, xs)
+        noises = np.full(len(kernels), 0.2)
+        lp, grads, gn, info = engine.logpdf_grad_batch(kernels, noises)
+        lp2, _ = engine.logpdf_batch(kernels, noises)
+        assert (info == 0).all() and np.array_equal(lp, lp2)
+        for k, g, gnz in zip(kernels, grads, gn):
+            lpo, go, gno = O.gp_logpdf_grad(k.to_tuple(), 0.2, ts, xs)
+            sc = max(1.0, np.abs(go).max(), abs(gno))
+            assert g.shape == go.shape
+            assert np.abs(g - go).max() <= GRAD_TOL * sc, (n, k, g, go)
+            assert abs(gnz - gno) <= GRAD_TOL * sc, (n, k)
+    # prior-sampled population, P >= 256 (fused build + cost sorting + scatter back to caller order)
+    ts, xs = pkg.prior.synthetic_series(256, seed=5, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(5), 260, max_depth=4, max_size=15)
+    engine.set_data(ts, xs)
+    lp, grads, gn, info = engine.logpdf_grad_batch(nodes, noises, check=False)
+    for i in list(range(0, 260, 13)) + [259]:
+        if info[i] != 0:
+            continue
+        lpo, go, gno = O.gp_logpdf_grad(nodes[i].to_tuple(), float(noises[i]), ts, xs)
+        sc = max(1.0, np.abs(go).max(), abs(gno))
+        assert abs(lp[i] - lpo) <= LP_TOL * max(1.0, abs(lpo))
+        assert np.abs(grads[i] - go).max() <= 1e-6 * sc and abs(gn[i] - gno) <= 1e-6 * sc, (i, nodes[i])
+    # n = 0: zero gradient
+    lp, grads, gn, info = engine.logpdf_grad_batch(kernels[:3], [0.1] * 3, n=0)
+    assert (lp == 0).all() and all((g == 0).all() for g in grads) and (gn == 0).all()
+
+
 def test_infer_gp_sum(pkg, engine):
     """GP.infer_gp_sum (src/GP.jl:904-993) against the oracle restatement, plus the reference's own
     relational checks (test/test_GP.jl:150-240): the observable block equals the single-kernel

@@ -161,3 +161,38 @@ def test_c_oracle_matches_numpy():
         ref = O.gp_logpdf(tree, 0.05, ts, xs)
         assert info.value == 0
         assert abs(lp - ref) <= 1e-10 * max(1.0, abs(ref)), tree
+
+
+def test_gradient_oracle_vs_finite_differences():
+    """The analytic gradient restatement against central differences of the pinned logpdf (and mpmath at n=12)."""
+    rng = np.random.default_rng(17)
+    ts = np.sort(rng.random(40)); ts[5] = ts[4]; xs = 0.4 * rng.standard_normal(40)
+    trees = list(BASE) + [("+", BASE[2], BASE[5]), ("*", BASE[3], BASE[4]), ("CP", BASE[2], BASE[5], 0.5, 0.05),
+                          ("CP", ("+", BASE[3], BASE[4]), ("*", BASE[2], BASE[5]), 0.3, 0.2),
+                          ("+", ("*", ("+", BASE[2], BASE[3]), ("+", BASE[4], BASE[5])), ("CP", BASE[1], BASE[0], 0.6, 0.1))]
+    for tree in trees:
+        lp, g, gn = O.gp_logpdf_grad(tree, 0.2, ts, xs)
+        assert lp == pytest.approx(O.gp_logpdf(tree, 0.2, ts, xs), rel=1e-12)
+        ops, prm = O.tree_to_program(tree)
+        assert g.shape == prm.shape
+        for k in range(prm.size):
+            h = 1e-6 * max(1.0, abs(prm[k]))
+            pp = prm.copy(); pp[k] += h; pm = prm.copy(); pm[k] -= h
+            fd = (O.gp_logpdf(O.program_to_tree(ops, pp), 0.2, ts, xs) - O.gp_logpdf(O.program_to_tree(ops, pm), 0.2, ts, xs)) / (2 * h)
+            assert g[k] == pytest.approx(fd, rel=2e-5, abs=2e-6), (tree, k)
+        fdn = (O.gp_logpdf(tree, 0.2 + 1e-6, ts, xs) - O.gp_logpdf(tree, 0.2 - 1e-6, ts, xs)) / 2e-6
+        assert gn == pytest.approx(fdn, rel=2e-5, abs=2e-6)
+    # mpmath central difference (h = 1e-12 is affordable at 60 digits)
+    import mpmath as mp
+    tree = ("*", ("GE", 0.42, 0.58, 3.2), ("PER", 0.96, 0.21, 1.1))
+    t12, x12 = ts[:12], xs[:12]
+    lp, g, gn = O.gp_logpdf_grad(tree, 0.1, t12, x12)
+    ops, prm = O.tree_to_program(tree)
+    for k in range(prm.size):
+        def f(v):
+            q = [mp.mpf(float(z)) for z in prm]; q[k] = v
+            tr = ("*", ("GE", q[0], q[1], q[2]), ("PER", q[3], q[4], q[5]))
+            return M.gp_logpdf_mp(tr, 0.1, t12, x12)
+        h = mp.mpf("1e-15")
+        fd = (f(mp.mpf(float(prm[k])) + h) - f(mp.mpf(float(prm[k])) - h)) / (2 * h)
+        assert abs(g[k] - float(fd)) <= 1e-8 * max(1.0, abs(float(fd))), k
