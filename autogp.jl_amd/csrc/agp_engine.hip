@@ -43,7 +43,7 @@ struct Slot {
   hipStream_t stream = nullptr;
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
-      Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise;
+      Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist;
   std::vector<hipEvent_t> events;
   std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
   std::vector<hipEvent_t> sub_ev;     // fork / join events
@@ -51,7 +51,7 @@ struct Slot {
   void release() {
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
-                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise})
+                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist})
       b->release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
@@ -566,6 +566,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       HIPCHK(c, s->goff.ensure(sizeof(int32_t) * (size_t)P));
       HIPCHK(c, s->dgrad.ensure(sizeof(double) * (size_t)std::max(1, n_prm_total)));
       HIPCHK(c, s->dgnoise.ensure(sizeof(double) * (size_t)P));
+      HIPCHK(c, s->plist.ensure(sizeof(int32_t) * (size_t)P));
     }
     HIPCHK(c, s->vec.ensure(sizeof(double) * (size_t)n_pad * chunk));
     HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
@@ -687,9 +688,16 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             hipLaunchKernelGGL(k_trtri_step, dim3(8 * Pg8 * (i + 1)), dim3(256), 0, q, ga);
           }
           hipLaunchKernelGGL(k_alpha, dim3(nt, Pg), dim3(256), 0, q, ga);
-          const size_t lds = sizeof(double) * std::max<size_t>(2 * U_SLAB, 256 + 256 * (size_t)bt.g_max_cp);
-          if (bt.g_max_nodes <= 16) HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, Pg, lds));
-          else HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, Pg, lds));
+          // small trees (<= 16 nodes) run the 800 B-scratch variant, the rest the 64-node one
+          std::vector<int32_t> pl_small, pl_large;
+          for (int r = 0; r < Pg; ++r) (bt.ghdr[p0 + g0 + r].n_ops <= 16 ? pl_small : pl_large).push_back(r);
+          std::vector<int32_t> pl(pl_small); pl.insert(pl.end(), pl_large.begin(), pl_large.end());
+          int32_t* d_pl = s->plist.as<int32_t>() + p0 + g0;
+          HIPCHK(c, hipMemcpyAsync(d_pl, pl.data(), sizeof(int32_t) * Pg, hipMemcpyHostToDevice, q));
+          HIPCHK(c, hipStreamSynchronize(q));     // `pl` is a local
+          const size_t lds = sizeof(double) * std::max<size_t>(2 * U_SLAB, 256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes);
+          if (!pl_small.empty()) { ga.plist = d_pl; HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, (int)pl_small.size(), lds)); }
+          if (!pl_large.empty()) { ga.plist = d_pl + pl_small.size(); HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, (int)pl_large.size(), lds)); }
           hipLaunchKernelGGL(k_grad_finish, dim3(Pg), dim3(64), 0, q, ga);
           HIPCHK(c, hipGetLastError());
         }

@@ -85,9 +85,11 @@ __device__ __forceinline__ void solve_in_regs(d4 (&acc)[NSB][2], const double* _
   {
     const int c = tid >> 4, r = tid & 15;
 #pragma unroll
-    for (int jb = 1; jb < NSB; ++jb)
+    for (int jb = 1; jb < NSB; ++jb) {
 #pragma unroll
       for (int lb = 0; lb < jb; ++lb) sm[sblk_idx(jb, lb) * 256 + tid] = Lkk[(lb * 16 + c) * NB + jb * 16 + r];
+      __builtin_amdgcn_sched_barrier(0);     // at most 7 staging loads in flight: the accumulators are live
+    }
 #pragma unroll
     for (int u = 0; u < NSB; ++u) sm[(T_NBLK + u) * 256 + tid] = -Wg[u * 256 + tid];
   }
@@ -139,6 +141,7 @@ struct GradArgs {
   const int32_t* gmap;   // per particle parameter slot -> index in the caller's parameter array
   const int32_t* out_off;   // [P] offset of the particle's gradient block in out_grad (caller order, via map)
   const int32_t* pmap;   // sorted particle -> caller particle
+  const int32_t* plist;  // k_grad_tiles: particles of this launch (indices into the sorted group)
   double* out_grad;
   double* out_gnoise;
 };
@@ -211,96 +214,106 @@ __global__ __launch_bounds__(256) void k_alpha(GradArgs a) {
   if (tid < 128) a.alpha[(long long)p * a.ldv + j * NB + tid] = part[tid] + part[tid + 128];
 }
 
-// ---- reverse-mode pass over one element --------------------------------------------------------
+// ---- reverse-mode pass over E elements in lockstep ----------------------------------------------
 // tape: per node {value, aux1, aux2}; adj: per node adjoint; gacc: per parameter slot accumulator.
-// All three are runtime-indexed per-lane arrays (private memory, lane-interleaved -> coalesced).
-template <int MAXS>
-__device__ __forceinline__ void grad_element(const GProgHdr& h, const uint8_t* __restrict__ ops,
-                                             const uint8_t* __restrict__ lc, const uint8_t* __restrict__ rc,
-                                             const int32_t* __restrict__ poff, const double* __restrict__ prm,
-                                             const double* sig, int ri, int ci, double ta, double tb, double wgt,
-                                             double (&tape)[3 * MAXS], double (&adj)[MAXS], double (&gacc)[3 * MAXS + 2]) {
+// All three are runtime-indexed per-lane arrays (private memory, lane-interleaved -> coalesced); the
+// E elements share one walk over the program, so their memory latencies overlap.
+template <int MAXS, int E>
+__device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* ops, const uint8_t* lc, const uint8_t* rc,
+                                              const int32_t* poff, const double* prm, const double* sig,
+                                              const int (&ri)[E], const int (&ci)[E], const double (&ta)[E],
+                                              const double (&tb)[E], const double (&wgt)[E],
+                                              double (&tape)[3 * MAXS][E], double (&adj)[MAXS][E], double (&gacc)[3 * MAXS + 2]) {
   const double PI = 3.14159265358979323846;
   // ---------------- forward ----------------
   int cpi = 0;
   for (int ip = 0; ip < h.n_ops; ++ip) {
     const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
     const double* q = prm + poff[ip];
-    double v = 0.0, x1 = 0.0, x2 = 0.0;
-    if (o == OP_WN) { x1 = (ta == tb) ? 1.0 : 0.0; v = x1 * q[0]; }
-    else if (o == OP_CONST) { v = q[0]; }
-    else if (o == OP_LIN) { x1 = (ta - q[0]) * (tb - q[0]); v = q[1] + q[2] * x1; }
-    else if (o == OP_SE) { const double d = ta - tb; x1 = d * d; x2 = fm::exp_f(-0.5 * x1 / (q[0] * q[0])); v = q[1] * x2; }
-    else if (o == OP_GE) {
-      const double u = fabs(ta - tb) / q[0];
-      x1 = fm::pow_f(u, q[1]);                                   // u^gamma
-      x2 = u > 0.0 ? x1 * fm::log_f(u) : 0.0;                    // u^gamma ln u  (-> 0 at u = 0)
-      v = q[2] * fm::exp_f(-x1);
-    } else if (o == OP_PER) {
-      const double ang = PI / q[1] * fabs(ta - tb);
-      double sn, cs;
-      sincos(ang, &sn, &cs);
-      x1 = sn * sn; x2 = sn * cs * fabs(ta - tb);
-      v = q[2] * fm::exp_f(-2.0 * x1 / (q[0] * q[0]));
-    } else if (o == OP_PLUS) { v = tape[3 * lc[ip]] + tape[3 * rc[ip]]; }
-    else if (o == OP_TIMES) { v = tape[3 * lc[ip]] * tape[3 * rc[ip]]; }
-    else {   // OP_CP (children by true left / right index)
-      const double sa = sig[cpi * 256 + ri], sb = sig[cpi * 256 + ci];
-      x1 = sa; x2 = sb;
-      v = (sa * sb) * tape[3 * lc[ip]] + ((1.0 - sa) * (1.0 - sb)) * tape[3 * rc[ip]];
-      ++cpi;
+    const double q0 = q[0], q1 = q[1], q2 = q[2];
+    const int il = lc[ip], ir = rc[ip];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      double v = 0.0, x1 = 0.0, x2 = 0.0;
+      if (o == OP_WN) { x1 = (ta[e] == tb[e]) ? 1.0 : 0.0; v = x1 * q0; }
+      else if (o == OP_CONST) { v = q0; }
+      else if (o == OP_LIN) { x1 = (ta[e] - q0) * (tb[e] - q0); v = q1 + q2 * x1; }
+      else if (o == OP_SE) { const double d = ta[e] - tb[e]; x1 = d * d; x2 = fm::exp_f(-0.5 * x1 / (q0 * q0)); v = q1 * x2; }
+      else if (o == OP_GE) {
+        const double u = fabs(ta[e] - tb[e]) / q0;
+        x1 = fm::pow_f(u, q1);                                     // u^gamma
+        x2 = u > 0.0 ? x1 * fm::log_f(u) : 0.0;                    // u^gamma ln u  (-> 0 at u = 0)
+        v = q2 * fm::exp_f(-x1);
+      } else if (o == OP_PER) {
+        const double dd = fabs(ta[e] - tb[e]);
+        double sn, cs;
+        sincos(PI / q1 * dd, &sn, &cs);
+        x1 = sn * sn; x2 = sn * cs * dd;
+        v = q2 * fm::exp_f(-2.0 * x1 / (q0 * q0));
+      } else if (o == OP_PLUS) { v = tape[3 * il][e] + tape[3 * ir][e]; }
+      else if (o == OP_TIMES) { v = tape[3 * il][e] * tape[3 * ir][e]; }
+      else {   // OP_CP (children by true left / right index)
+        const double sa = sig[cpi * 256 + ri[e]], sb = sig[cpi * 256 + ci[e]];
+        x1 = sa; x2 = sb;
+        v = (sa * sb) * tape[3 * il][e] + ((1.0 - sa) * (1.0 - sb)) * tape[3 * ir][e];
+      }
+      tape[3 * ip][e] = v; tape[3 * ip + 1][e] = x1; tape[3 * ip + 2][e] = x2;
     }
-    tape[3 * ip] = v; tape[3 * ip + 1] = x1; tape[3 * ip + 2] = x2;
+    if (o == OP_CP) ++cpi;
   }
   // ---------------- backward ----------------
-  adj[h.n_ops - 1] = wgt;
+#pragma unroll
+  for (int e = 0; e < E; ++e) adj[h.n_ops - 1][e] = wgt[e];
   for (int ip = h.n_ops - 1; ip >= 0; --ip) {
     const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
     const int po = poff[ip];
     const double* q = prm + po;
-    const double ad = adj[ip];
-    const double v = tape[3 * ip], x1 = tape[3 * ip + 1], x2 = tape[3 * ip + 2];
-    if (o == OP_WN) { gacc[po] += ad * x1; }
-    else if (o == OP_CONST) { gacc[po] += ad; }
-    else if (o == OP_LIN) {
-      gacc[po] += ad * (-q[2] * (ta + tb - 2.0 * q[0]));
-      gacc[po + 1] += ad;
-      gacc[po + 2] += ad * x1;
-    } else if (o == OP_SE) {
-      gacc[po] += ad * v * x1 / (q[0] * q[0] * q[0]);
-      gacc[po + 1] += ad * x2;
-    } else if (o == OP_GE) {
-      gacc[po] += ad * v * q[1] * x1 / q[0];
-      gacc[po + 1] += ad * (-v * x2);
-      gacc[po + 2] += ad * v / q[2];
-    } else if (o == OP_PER) {
-      const double l2 = q[0] * q[0];
-      gacc[po] += ad * v * 4.0 * x1 / (l2 * q[0]);
-      gacc[po + 1] += ad * v * 4.0 * x2 * PI / (l2 * q[1] * q[1]);
-      gacc[po + 2] += ad * v / q[2];
-    } else if (o == OP_PLUS) { adj[lc[ip]] = ad; adj[rc[ip]] = ad; }
-    else if (o == OP_TIMES) { adj[lc[ip]] = ad * tape[3 * rc[ip]]; adj[rc[ip]] = ad * tape[3 * lc[ip]]; }
-    else {   // OP_CP: q = {location, scale}; x1 = sigma_a, x2 = sigma_b
-      const double kl = tape[3 * lc[ip]], kr = tape[3 * rc[ip]];
-      adj[lc[ip]] = ad * (x1 * x2);
-      adj[rc[ip]] = ad * ((1.0 - x1) * (1.0 - x2));
-      // d sigma / d loc = 2 sigma (1 - sigma) / scale;  d sigma / d scale = -(loc - t)/scale * that
-      const double da = 2.0 * x1 * (1.0 - x1) / q[1], db = 2.0 * x2 * (1.0 - x2) / q[1];
-      const double dl = (da * x2 + x1 * db) * kl - (da * (1.0 - x2) + (1.0 - x1) * db) * kr;
-      const double das = -da * (q[0] - ta) / q[1], dbs = -db * (q[0] - tb) / q[1];
-      const double ds = (das * x2 + x1 * dbs) * kl - (das * (1.0 - x2) + (1.0 - x1) * dbs) * kr;
-      gacc[po] += ad * dl;
-      gacc[po + 1] += ad * ds;
+    const double q0 = q[0], q1 = q[1], q2 = q[2];
+    const int il = lc[ip], ir = rc[ip];
+    double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const double ad = adj[ip][e];
+      const double v = tape[3 * ip][e], x1 = tape[3 * ip + 1][e], x2 = tape[3 * ip + 2][e];
+      if (o == OP_WN) { g0 += ad * x1; }
+      else if (o == OP_CONST) { g0 += ad; }
+      else if (o == OP_LIN) {
+        g0 += ad * (-q2 * (ta[e] + tb[e] - 2.0 * q0));
+        g1 += ad;
+        g2 += ad * x1;
+      } else if (o == OP_SE) {
+        g0 += ad * v * x1 / (q0 * q0 * q0);
+        g1 += ad * x2;
+      } else if (o == OP_GE) {
+        g0 += ad * v * q1 * x1 / q0;
+        g1 += ad * (-v * x2);
+        g2 += ad * v / q2;
+      } else if (o == OP_PER) {
+        const double l2 = q0 * q0;
+        g0 += ad * v * 4.0 * x1 / (l2 * q0);
+        g1 += ad * v * 4.0 * x2 * PI / (l2 * q1 * q1);
+        g2 += ad * v / q2;
+      } else if (o == OP_PLUS) { adj[il][e] = ad; adj[ir][e] = ad; }
+      else if (o == OP_TIMES) { adj[il][e] = ad * tape[3 * ir][e]; adj[ir][e] = ad * tape[3 * il][e]; }
+      else {   // OP_CP: q = {location, scale}; x1 = sigma_a, x2 = sigma_b
+        const double kl = tape[3 * il][e], kr = tape[3 * ir][e];
+        adj[il][e] = ad * (x1 * x2);
+        adj[ir][e] = ad * ((1.0 - x1) * (1.0 - x2));
+        // d sigma / d loc = 2 sigma (1 - sigma) / scale;  d sigma / d scale = -(loc - t)/scale * that
+        const double da = 2.0 * x1 * (1.0 - x1) / q1, db = 2.0 * x2 * (1.0 - x2) / q1;
+        g0 += ad * ((da * x2 + x1 * db) * kl - (da * (1.0 - x2) + (1.0 - x1) * db) * kr);
+        const double das = -da * (q0 - ta[e]) / q1, dbs = -db * (q0 - tb[e]) / q1;
+        g1 += ad * ((das * x2 + x1 * dbs) * kl - (das * (1.0 - x2) + (1.0 - x1) * dbs) * kr);
+      }
     }
+    if (o <= OP_PER || o == OP_CP) { gacc[po] += g0; gacc[po + 1] += g1; gacc[po + 2] += g2; }
   }
 }
-
-// GE amplitude: v / q[2] = exp part (q[2] = amplitude != 0 by the prior); same for Periodic.
 
 template <int MAXS>
 __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];   // slab buffers, then tpt | sig | reduction
-  const int tix = blockIdx.x, p = blockIdx.y;
+  const int tix = blockIdx.x, p = a.plist[blockIdx.y];
   int ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
   while (ti * (ti + 1) / 2 > tix) --ti;
   while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
@@ -319,15 +332,21 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
              smem, tid, l15, lq, row0);
 
   // ---- per-element reverse-mode contraction ----
+  // LDS map (aliases the slab buffers): tpt[256] | sig[n_cp][256] | prm[n_prm+3] | poff[n_ops] | ops/lc/rc[n_ops] bytes
   const GProgHdr h = a.ghdr[p];
-  const uint8_t* __restrict__ ops = a.gops + h.node_off;
-  const uint8_t* __restrict__ lc = a.glc + h.node_off;
-  const uint8_t* __restrict__ rc = a.grc + h.node_off;
-  const int32_t* __restrict__ poff = a.gpoff + h.node_off;
-  const double* __restrict__ prm = a.gprm + h.prm_off;
   double* tpt = smem;
   double* sig = smem + 256;
+  double* prm = sig + h.n_cp * 256;
+  int32_t* poff = reinterpret_cast<int32_t*>(prm + h.n_prm + 3);
+  uint8_t* ops = reinterpret_cast<uint8_t*>(poff + h.n_ops);
+  uint8_t* lc = ops + h.n_ops;
+  uint8_t* rc = lc + h.n_ops;
   {
+    for (int i = tid; i < h.n_prm + 3; i += 256) prm[i] = a.gprm[h.prm_off + i];
+    for (int i = tid; i < h.n_ops; i += 256) {
+      poff[i] = a.gpoff[h.node_off + i];
+      ops[i] = a.gops[h.node_off + i]; lc[i] = a.glc[h.node_off + i]; rc[i] = a.grc[h.node_off + i];
+    }
     const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
     tpt[tid] = a.tt[g];
     __syncthreads();
@@ -343,10 +362,12 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
     }
     __syncthreads();
   }
-  double tape[3 * MAXS], adj[MAXS], gacc[3 * MAXS + 2];
-  for (int q = 0; q <= h.n_prm; ++q) gacc[q] = 0.0;
+  constexpr int E = (MAXS <= 16) ? 4 : 1;     // elements walked in lockstep (bounded by private-memory footprint)
+  double tape[3 * MAXS][E], adj[MAXS][E], gacc[3 * MAXS + 2];
+  for (int q = 0; q <= h.n_prm + 2; ++q) gacc[q] = 0.0;     // (+2: leaves add three slots unconditionally)
   const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
   const double wfac = (ti == tj) ? 1.0 : 2.0;
+  double gnoise = 0.0;
 #pragma unroll 1
   for (int t = 0; t < 16; ++t) {
     const int cb = t >> 1, st = t & 1;
@@ -360,21 +381,27 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
     const int rslot = row0 + st;
     const int ga = ti * NB + rslot;
 #pragma unroll 1
-    for (int r = 0; r < 4; ++r) {
-      const int cslot = cb * 16 + 4 * r + lq;
-      const int gb = tj * NB + cslot;
-      if (ga < a.n && gb < a.n) {     // padding rows / columns carry no parameter dependence
+    for (int r0 = 0; r0 < 4; r0 += E) {
+      int ri[E], ci[E];
+      double ta[E], tb[E], wg[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int r = r0 + e;
+        const int cslot = cb * 16 + 4 * r + lq;
+        const int gb = tj * NB + cslot;
+        const bool valid = ga < a.n && gb < a.n;       // padding rows / columns carry no parameter dependence
         const double kinv = (r == 0) ? v[0] : (r == 1) ? v[1] : (r == 2) ? v[2] : v[3];
-        const double G = 0.5 * (al[ga] * al[gb] - kinv);
-        if (ga == gb) gacc[h.n_prm] += G;                      // d/d noise = tr G
-        grad_element<MAXS>(h, ops, lc, rc, poff, prm, sig, rslot, NB + cslot, tpt[rslot], tpt[NB + cslot], wfac * G,
-                           tape, adj, gacc);
+        const double G = valid ? 0.5 * (al[valid ? ga : 0] * al[valid ? gb : 0] - kinv) : 0.0;
+        if (ga == gb) gnoise += G;                       // d/d noise = tr G
+        ri[e] = rslot; ci[e] = NB + cslot; ta[e] = tpt[rslot]; tb[e] = tpt[NB + cslot]; wg[e] = wfac * G;
       }
+      grad_elements<MAXS, E>(h, ops, lc, rc, poff, prm, sig, ri, ci, ta, tb, wg, tape, adj, gacc);
     }
   }
+  gacc[h.n_prm] = gnoise;       // overwrites whatever the unconditional three-slot adds left there
   // ---- reduce over the 256 threads, one parameter slot at a time ----
   __syncthreads();
-  double* red = smem;      // [4] per-wave sums
+  double* red = smem + 256;      // [4] per-wave sums (tpt no longer needed; sig/prm region is free too)
   for (int q = 0; q <= h.n_prm; ++q) {
     double s = gacc[q];
 #pragma unroll

@@ -97,6 +97,25 @@ function logpdf_batch(eng::Engine, nodes::Vector{<:GP.Node}, noises::Vector{Floa
     return out, info
 end
 
+"""
+Value and gradient in one sweep: (logpdf, d/dθ in `encode(node)[2]` order — transformed parameters, ChangePoint
+contributes location and scale — and d/dnoise).  Chain through `Model.transform_param` on the Julia side:
+log-normal θ = exp(μ+σz) → ∂/∂z = σ θ ∂/∂θ;  gamma = s/(1+exp(-(μ+σz))) → ∂/∂z = σ γ (1 - γ/s) ∂/∂γ.
+"""
+function logpdf_grad(eng::Engine, node::GP.Node, noise::Float64, n::Integer=eng.n_max)
+    ops, prm = encode(node)
+    np_ = length(prm)
+    isempty(prm) && push!(prm, 0.0)
+    op_off = Int32[0, length(ops)]; prm_off = Int32[0, np_]
+    lp = [0.0]; grad = zeros(max(np_, 1)); gn = [0.0]; info = Int32[0]; nz = [noise]
+    GC.@preserve ops prm lp grad gn info nz check(eng, ccall((:agp_logpdf_grad_batch, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+        eng.ptr, n, 1, op_off, ops, prm_off, prm, nz, lp, grad, gn, info))
+    info[1] > 0 && throw(LinearAlgebra.PosDefException(info[1]))
+    return lp[1], grad[1:np_], gn[1]
+end
+
 "Posterior predictive — replaces Distributions.MvNormal(node, noise, ts, xs, ts_pred; ...) (src/GP.jl:731-758)."
 function predict_mvn(eng::Engine, node::GP.Node, noise::Float64, ts_pred::Vector{Float64};
         n::Integer=eng.n_max, noise_pred::Union{Nothing,Float64}=nothing,
