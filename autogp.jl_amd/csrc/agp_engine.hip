@@ -1335,6 +1335,9 @@ int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t
       case 104: launch_variant<104>(st, grid, ca); break;
       case 168: launch_variant<168>(st, grid, ca); break;
       case 152: launch_variant<152>(st, grid, ca); break;
+      case 1016: hipLaunchKernelGGL((k_gemm_strip<16, true>), dim3(grid), dim3(256), 0, st, ca); break;
+      case 1032: hipLaunchKernelGGL((k_gemm_strip<32, true>), dim3(grid), dim3(256), 0, st, ca); break;
+      case 1008: hipLaunchKernelGGL((k_gemm_strip<8, true>), dim3(grid), dim3(256), 0, st, ca); break;
       default: return fail(c, AGP_ERR_ARG, "unknown variant");
     }
   }

@@ -189,6 +189,81 @@ __global__ __launch_bounds__(256, 2) void k_gemm_variant(CholArgs a) {
       }
 }
 
+// Variant: 32x128 wave strips, row operand global->registers, column operand in LDS with slab depth KBX.
+template <int KBX, bool PRIO>
+__global__ __launch_bounds__(256, 2) void k_gemm_strip(CholArgs a) {
+  __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
+  constexpr int SLAB = KBX * LDS_STRIDE;
+  const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
+  const int T = a.tiles, pl = qq / T, tl = qq - pl * T;
+  const int tk = a.k, ti = a.k + 1 + tl, jmax = a.k;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  const int row0 = 32 * w + 2 * l15;
+  double* __restrict__ Ap = a.A + (long long)p * a.strideA;
+  d4 acc[NSB][2];
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
+  constexpr int NU = KBX / 4;                 // loads per thread per slab for each operand
+  const int nslab = jmax * (NB / KBX);
+  const int scol0 = tid >> 6, srow = 2 * (tid & 63);
+  d2 ra[NU], rb[NU], fr[NU];
+  auto gload = [&](int s) {
+    const int per = NB / KBX;
+    const int j = s / per, cs = (s % per) * KBX;
+    const double* __restrict__ srcA = Ap + tile_off(ti, j) + (long long)cs * NB;
+    const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      ra[u] = *reinterpret_cast<const d2*>(srcA + (4 * u + lq) * NB + row0);
+      rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 4 * u) * NB + srow);
+    }
+  };
+  auto lstore = [&](int buf) {
+    double* Bs = sm + buf * SLAB;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb[u];
+  };
+  gload(0); lstore(0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) fr[u] = ra[u];
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) gload(s + 1);
+    const double* Bs = sm + buf * SLAB;
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < KBX / 4; ++kk) {
+      const int krow = (kk * 4 + lq) * LDS_STRIDE;
+      double fa[NSB];
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb) {
+        acc[cb][0] = mfma(fa[cb], fr[kk].x, acc[cb][0]);
+        acc[cb][1] = mfma(fa[cb], fr[kk].y, acc[cb][1]);
+      }
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    if (s + 1 < nslab) {
+      lstore(buf ^ 1);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) fr[u] = ra[u];
+    }
+    __syncthreads();
+  }
+  double* __restrict__ Tt = Ap + tile_off(ti, tk);
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d2 o2; o2.x = -acc[cb][0][r]; o2.y = -acc[cb][1][r];
+      *reinterpret_cast<d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
+    }
+}
+
 __global__ void k_fill_pseudo(double* A, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
