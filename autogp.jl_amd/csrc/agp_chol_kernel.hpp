@@ -94,6 +94,10 @@ constexpr int U_MAX_CP = (U_MAIN_DOUBLES - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_O
 // the workgroup waits on the particle's `ready` word (published by the diagonal-tile workgroup, which
 // is dispatched first), stages +L(k,k) blocks and -W blocks in LDS and runs the blocked substitution
 // on its accumulators — one launch per block column, no panel round trip through HBM.
+#ifndef AGP_XCD_PIN
+#define AGP_XCD_PIN 1
+#endif
+constexpr bool XCD_PIN = AGP_XCD_PIN != 0;     // 1: all tiles of a particle on one XCD; 0: spread over the 8 XCDs
 #ifndef AGP_A_DIRECT
 #define AGP_A_DIRECT 1
 #endif
@@ -139,10 +143,16 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     const int ndiag = 8 * ((a.P + 7) / 8);
     if (b < ndiag) {
       xcd = b & 7; pl = b >> 3; tl = 0;
-    } else {
+    } else if (XCD_PIN) {
       b -= ndiag;
       xcd = b & 7; qq = b >> 3;
       pl = qq / (T - 1); tl = 1 + (qq - pl * (T - 1));
+    } else {
+      // particle-major over all XCDs: consecutive blocks are the tiles of one particle
+      b -= ndiag;
+      const int pp = b / (T - 1);
+      tl = 1 + (b - pp * (T - 1));
+      xcd = pp & 7; pl = pp >> 3;
     }
     tk = a.k; ti = a.k + tl; jmax = a.k;
   } else {

@@ -696,8 +696,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           HIPCHK(c, hipMemcpyAsync(d_pl, pl.data(), sizeof(int32_t) * Pg, hipMemcpyHostToDevice, q));
           HIPCHK(c, hipStreamSynchronize(q));     // `pl` is a local
           const size_t lds = sizeof(double) * std::max<size_t>(2 * U_SLAB, 256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes);
-          if (!pl_small.empty()) { ga.plist = d_pl; HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, (int)pl_small.size(), lds)); }
-          if (!pl_large.empty()) { ga.plist = d_pl + pl_small.size(); HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, (int)pl_large.size(), lds)); }
+          const int Pall = ga.P;
+          if (!pl_small.empty()) { ga.plist = d_pl; ga.P = (int)pl_small.size(); HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, ga.P, lds)); }
+          if (!pl_large.empty()) { ga.plist = d_pl + pl_small.size(); ga.P = (int)pl_large.size(); HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, ga.P, lds)); }
+          ga.P = Pall;
           hipLaunchKernelGGL(k_grad_finish, dim3(Pg), dim3(64), 0, q, ga);
           HIPCHK(c, hipGetLastError());
         }

@@ -160,6 +160,8 @@ __device__ __forceinline__ long long zoff(int r, int k) { return tile_off(k, r);
 // ---- Z = L^-T, block column `step` -------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_trtri_step(GradArgs a) {
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES];
+  // grid: particle-major (a particle's tiles run together and share its Z / L panels in one XCD's L2 —
+  // measured 10 % faster than a longest-contraction-first order); block b -> XCD b%8, particle = pl*8 + xcd
   const int i = a.step;
   const int T = i + 1;
   const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
@@ -313,7 +315,11 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
 template <int MAXS>
 __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];   // slab buffers, then tpt | sig | reduction
-  const int tix = blockIdx.x, p = a.plist[blockIdx.y];
+  // grid (tile, particle): consecutive blocks are tiles of ONE particle spread over all 8 XCDs.  Measured
+  // faster than pinning a particle to one XCD (163 vs 171 ms per sweep): its Z panels (17.8 MB) overflow a
+  // single 4 MiB L2 but mostly fit the 8 L2s together, and faster than a longest-tile-first order (179 ms).
+  const int tix = blockIdx.x;
+  const int p = a.plist[blockIdx.y];
   int ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
   while (ti * (ti + 1) / 2 > tix) --ti;
   while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
