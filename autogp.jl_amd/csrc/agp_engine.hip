@@ -92,6 +92,7 @@ struct agp_ctx {
   int64_t ws_limit = 0;
   size_t total_mem = 0;
   bool profiling = false;
+  int grad_split = 1;   // 1: K^-1 tiles to memory + lean contraction kernel; 0: fused tile kernel (env AGP_GRAD_SPLIT)
   int intrsm = 1;       // 1: triangular solve inside k_chol_update (one launch per block column); env AGP_INTRSM
   int n_streams = 1;    // sub-batches of one call run on this many streams (env AGP_STREAMS)
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
@@ -498,6 +499,14 @@ struct GradOut {
 };
 
 template <int MAXS>
+hipError_t launch_grad_contract(hipStream_t st, const GradArgs& ga, int ntiles, int P, size_t lds) {
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grad_contract<MAXS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_grad_contract<MAXS>, dim3(ntiles, P), dim3(256), lds, st, ga);
+  return hipGetLastError();
+}
+
+template <int MAXS>
 hipError_t launch_grad_tiles(hipStream_t st, const GradArgs& ga, int ntiles, int P, size_t lds) {
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grad_tiles<MAXS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -697,8 +706,15 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           HIPCHK(c, hipStreamSynchronize(q));     // `pl` is a local
           const size_t lds = sizeof(double) * std::max<size_t>(2 * U_SLAB, 256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes);
           const int Pall = ga.P;
-          if (!pl_small.empty()) { ga.plist = d_pl; ga.P = (int)pl_small.size(); HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, ga.P, lds)); }
-          if (!pl_large.empty()) { ga.plist = d_pl + pl_small.size(); ga.P = (int)pl_large.size(); HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, ga.P, lds)); }
+          if (c->grad_split) {
+            hipLaunchKernelGGL(k_kinv_tiles, dim3(ntiles, Pg), dim3(256), 0, q, ga);
+            const size_t lds2 = sizeof(double) * (256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes + 8);
+            if (!pl_small.empty()) { ga.plist = d_pl; HIPCHK(c, launch_grad_contract<16>(q, ga, ntiles, (int)pl_small.size(), lds2)); }
+            if (!pl_large.empty()) { ga.plist = d_pl + pl_small.size(); HIPCHK(c, launch_grad_contract<64>(q, ga, ntiles, (int)pl_large.size(), lds2)); }
+          } else {
+            if (!pl_small.empty()) { ga.plist = d_pl; ga.P = (int)pl_small.size(); HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, ga.P, lds)); }
+            if (!pl_large.empty()) { ga.plist = d_pl + pl_small.size(); ga.P = (int)pl_large.size(); HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, ga.P, lds)); }
+          }
           ga.P = Pall;
           hipLaunchKernelGGL(k_grad_finish, dim3(Pg), dim3(64), 0, q, ga);
           HIPCHK(c, hipGetLastError());
@@ -772,6 +788,7 @@ int agp_init(agp_ctx** out, int device_id) {
   (void)hipMemGetInfo(&free_b, &tot_b);
   c->total_mem = free_b ? free_b : tot_b;
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
+  if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
   if (const char* e = getenv("AGP_INTRSM")) c->intrsm = atoi(e) != 0;
   if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_STREAMS")) c->n_streams = std::max(1, std::min(8, atoi(e)));

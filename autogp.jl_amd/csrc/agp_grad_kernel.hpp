@@ -217,17 +217,19 @@ __global__ __launch_bounds__(256) void k_alpha(GradArgs a) {
 }
 
 // ---- reverse-mode pass over E elements in lockstep ----------------------------------------------
-// tape: per node {value, aux1, aux2}; adj: per node adjoint; gacc: per parameter slot accumulator.
-// All three are runtime-indexed per-lane arrays (private memory, lane-interleaved -> coalesced); the
-// E elements share one walk over the program, so their memory latencies overlap.
+// One private-memory slot per node and element: it holds the node's VALUE after the forward pass and is
+// overwritten by the node's ADJOINT when its parent is visited in the backward pass (a binary node only
+// needs its children's values, never its own; a leaf recomputes its intermediates — arithmetic is cheap
+// here, private-memory traffic is what bounds this kernel).  gacc: per parameter slot accumulator.
+// The E elements share one walk over the program, so their memory latencies overlap.
 template <int MAXS, int E>
 __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* ops, const uint8_t* lc, const uint8_t* rc,
                                               const int32_t* poff, const double* prm, const double* sig,
                                               const int (&ri)[E], const int (&ci)[E], const double (&ta)[E],
                                               const double (&tb)[E], const double (&wgt)[E],
-                                              double (&tape)[3 * MAXS][E], double (&adj)[MAXS][E], double (&gacc)[3 * MAXS + 2]) {
+                                              double (&tape)[MAXS][E], double (&gacc)[3 * MAXS + 2]) {
   const double PI = 3.14159265358979323846;
-  // ---------------- forward ----------------
+  // ---------------- forward: node values ----------------
   int cpi = 0;
   for (int ip = 0; ip < h.n_ops; ++ip) {
     const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
@@ -236,71 +238,73 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
     const int il = lc[ip], ir = rc[ip];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      double v = 0.0, x1 = 0.0, x2 = 0.0;
-      if (o == OP_WN) { x1 = (ta[e] == tb[e]) ? 1.0 : 0.0; v = x1 * q0; }
-      else if (o == OP_CONST) { v = q0; }
-      else if (o == OP_LIN) { x1 = (ta[e] - q0) * (tb[e] - q0); v = q1 + q2 * x1; }
-      else if (o == OP_SE) { const double d = ta[e] - tb[e]; x1 = d * d; x2 = fm::exp_f(-0.5 * x1 / (q0 * q0)); v = q1 * x2; }
-      else if (o == OP_GE) {
-        const double u = fabs(ta[e] - tb[e]) / q0;
-        x1 = fm::pow_f(u, q1);                                     // u^gamma
-        x2 = u > 0.0 ? x1 * fm::log_f(u) : 0.0;                    // u^gamma ln u  (-> 0 at u = 0)
-        v = q2 * fm::exp_f(-x1);
-      } else if (o == OP_PER) {
-        const double dd = fabs(ta[e] - tb[e]);
-        double sn, cs;
-        sincos(PI / q1 * dd, &sn, &cs);
-        x1 = sn * sn; x2 = sn * cs * dd;
-        v = q2 * fm::exp_f(-2.0 * x1 / (q0 * q0));
-      } else if (o == OP_PLUS) { v = tape[3 * il][e] + tape[3 * ir][e]; }
-      else if (o == OP_TIMES) { v = tape[3 * il][e] * tape[3 * ir][e]; }
+      double v;
+      if (o == OP_WN) v = (ta[e] == tb[e]) ? q0 : 0.0;
+      else if (o == OP_CONST) v = q0;
+      else if (o == OP_LIN) v = q1 + q2 * ((ta[e] - q0) * (tb[e] - q0));
+      else if (o == OP_SE) { const double d = ta[e] - tb[e]; v = q1 * fm::exp_f(-0.5 * d * d / (q0 * q0)); }
+      else if (o == OP_GE) v = q2 * fm::exp_f(-fm::pow_f(fabs(ta[e] - tb[e]) / q0, q1));
+      else if (o == OP_PER) v = q2 * fm::exp_f(-2.0 * fm::sin2_f(PI / q1 * fabs(ta[e] - tb[e])) / (q0 * q0));
+      else if (o == OP_PLUS) v = tape[il][e] + tape[ir][e];
+      else if (o == OP_TIMES) v = tape[il][e] * tape[ir][e];
       else {   // OP_CP (children by true left / right index)
         const double sa = sig[cpi * 256 + ri[e]], sb = sig[cpi * 256 + ci[e]];
-        x1 = sa; x2 = sb;
-        v = (sa * sb) * tape[3 * il][e] + ((1.0 - sa) * (1.0 - sb)) * tape[3 * ir][e];
+        v = (sa * sb) * tape[il][e] + ((1.0 - sa) * (1.0 - sb)) * tape[ir][e];
       }
-      tape[3 * ip][e] = v; tape[3 * ip + 1][e] = x1; tape[3 * ip + 2][e] = x2;
+      tape[ip][e] = v;
     }
     if (o == OP_CP) ++cpi;
   }
-  // ---------------- backward ----------------
+  // ---------------- backward: adjoints replace values top-down ----------------
 #pragma unroll
-  for (int e = 0; e < E; ++e) adj[h.n_ops - 1][e] = wgt[e];
+  for (int e = 0; e < E; ++e) tape[h.n_ops - 1][e] = wgt[e];
   for (int ip = h.n_ops - 1; ip >= 0; --ip) {
     const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
     const int po = poff[ip];
     const double* q = prm + po;
     const double q0 = q[0], q1 = q[1], q2 = q[2];
     const int il = lc[ip], ir = rc[ip];
+    if (o == OP_CP) --cpi;
     double g0 = 0.0, g1 = 0.0, g2 = 0.0;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const double ad = adj[ip][e];
-      const double v = tape[3 * ip][e], x1 = tape[3 * ip + 1][e], x2 = tape[3 * ip + 2][e];
-      if (o == OP_WN) { g0 += ad * x1; }
+      const double ad = tape[ip][e];
+      if (o == OP_WN) { g0 += (ta[e] == tb[e]) ? ad : 0.0; }
       else if (o == OP_CONST) { g0 += ad; }
       else if (o == OP_LIN) {
         g0 += ad * (-q2 * (ta[e] + tb[e] - 2.0 * q0));
         g1 += ad;
-        g2 += ad * x1;
+        g2 += ad * ((ta[e] - q0) * (tb[e] - q0));
       } else if (o == OP_SE) {
-        g0 += ad * v * x1 / (q0 * q0 * q0);
-        g1 += ad * x2;
+        const double d = ta[e] - tb[e], d2 = d * d;
+        const double ex = fm::exp_f(-0.5 * d2 / (q0 * q0));
+        g0 += ad * q1 * ex * d2 / (q0 * q0 * q0);
+        g1 += ad * ex;
       } else if (o == OP_GE) {
-        g0 += ad * v * q1 * x1 / q0;
-        g1 += ad * (-v * x2);
-        g2 += ad * v / q2;
+        const double u = fabs(ta[e] - tb[e]) / q0;
+        const double ug = fm::pow_f(u, q1);
+        const double ex = fm::exp_f(-ug);
+        g0 += ad * q2 * ex * q1 * ug / q0;
+        g1 += u > 0.0 ? ad * (-q2 * ex * ug * fm::log_f(u)) : 0.0;      // u^g ln u -> 0 at u = 0
+        g2 += ad * ex;
       } else if (o == OP_PER) {
+        const double dd = fabs(ta[e] - tb[e]);
+        double sn, cs;
+        sincos(PI / q1 * dd, &sn, &cs);
         const double l2 = q0 * q0;
-        g0 += ad * v * 4.0 * x1 / (l2 * q0);
-        g1 += ad * v * 4.0 * x2 * PI / (l2 * q1 * q1);
-        g2 += ad * v / q2;
-      } else if (o == OP_PLUS) { adj[il][e] = ad; adj[ir][e] = ad; }
-      else if (o == OP_TIMES) { adj[il][e] = ad * tape[3 * ir][e]; adj[ir][e] = ad * tape[3 * il][e]; }
-      else {   // OP_CP: q = {location, scale}; x1 = sigma_a, x2 = sigma_b
-        const double kl = tape[3 * il][e], kr = tape[3 * ir][e];
-        adj[il][e] = ad * (x1 * x2);
-        adj[ir][e] = ad * ((1.0 - x1) * (1.0 - x2));
+        const double ex = fm::exp_f(-2.0 * sn * sn / l2);
+        g0 += ad * q2 * ex * 4.0 * sn * sn / (l2 * q0);
+        g1 += ad * q2 * ex * 4.0 * sn * cs * dd * PI / (l2 * q1 * q1);
+        g2 += ad * ex;
+      } else if (o == OP_PLUS) { tape[il][e] = ad; tape[ir][e] = ad; }
+      else if (o == OP_TIMES) {
+        const double kl = tape[il][e], kr = tape[ir][e];
+        tape[il][e] = ad * kr; tape[ir][e] = ad * kl;
+      } else {   // OP_CP: q = {location, scale}
+        const double x1 = sig[cpi * 256 + ri[e]], x2 = sig[cpi * 256 + ci[e]];
+        const double kl = tape[il][e], kr = tape[ir][e];
+        tape[il][e] = ad * (x1 * x2);
+        tape[ir][e] = ad * ((1.0 - x1) * (1.0 - x2));
         // d sigma / d loc = 2 sigma (1 - sigma) / scale;  d sigma / d scale = -(loc - t)/scale * that
         const double da = 2.0 * x1 * (1.0 - x1) / q1, db = 2.0 * x2 * (1.0 - x2) / q1;
         g0 += ad * ((da * x2 + x1 * db) * kl - (da * (1.0 - x2) + (1.0 - x1) * db) * kr);
@@ -368,8 +372,8 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
     }
     __syncthreads();
   }
-  constexpr int E = (MAXS <= 16) ? 4 : 1;     // elements walked in lockstep (bounded by private-memory footprint)
-  double tape[3 * MAXS][E], adj[MAXS][E], gacc[3 * MAXS + 2];
+  constexpr int E = 4;     // elements walked in lockstep
+  double tape[MAXS][E], gacc[3 * MAXS + 2];
   for (int q = 0; q <= h.n_prm + 2; ++q) gacc[q] = 0.0;     // (+2: leaves add three slots unconditionally)
   const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
   const double wfac = (ti == tj) ? 1.0 : 2.0;
@@ -401,13 +405,121 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
         if (ga == gb) gnoise += G;                       // d/d noise = tr G
         ri[e] = rslot; ci[e] = NB + cslot; ta[e] = tpt[rslot]; tb[e] = tpt[NB + cslot]; wg[e] = wfac * G;
       }
-      grad_elements<MAXS, E>(h, ops, lc, rc, poff, prm, sig, ri, ci, ta, tb, wg, tape, adj, gacc);
+      grad_elements<MAXS, E>(h, ops, lc, rc, poff, prm, sig, ri, ci, ta, tb, wg, tape, gacc);
     }
   }
   gacc[h.n_prm] = gnoise;       // overwrites whatever the unconditional three-slot adds left there
   // ---- reduce over the 256 threads, one parameter slot at a time ----
   __syncthreads();
   double* red = smem + 256;      // [4] per-wave sums (tpt no longer needed; sig/prm region is free too)
+  for (int q = 0; q <= h.n_prm; ++q) {
+    double s = gacc[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (l == 0) red[w] = s;
+    __syncthreads();
+    if (tid == 0) a.gpart[((long long)p * (a.nt * (a.nt + 1) / 2) + tix) * a.gstride + q] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+}
+
+// ---- split variant: K^-1 tiles to memory (over the L buffer, dead by now), then a lean contraction ----
+__global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
+  __shared__ __attribute__((aligned(16))) double sm[2 * U_SLAB];
+  const int tix = blockIdx.x, p = blockIdx.y;
+  int ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tix) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
+  const int tj = tix - ti * (ti + 1) / 2;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  const int row0 = 32 * w + 2 * l15;
+  const double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
+  d4 acc[NSB][2];
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
+  gemm_slabs(acc, (a.nt - ti) * (NB / KB),
+             [&](int s) { return Zp + zoff(ti, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+             [&](int s) { return Zp + zoff(tj, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+             sm, tid, l15, lq, row0);
+  double* __restrict__ Kt = const_cast<double*>(a.A) + (long long)p * a.strideA + tile_off(ti, tj);
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d2 o2; o2.x = acc[cb][0][r]; o2.y = acc[cb][1][r];
+      *reinterpret_cast<d2*>(Kt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
+    }
+}
+
+template <int MAXS>
+__global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tix = blockIdx.x;
+  const int p = a.plist[blockIdx.y];
+  int ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tix) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
+  const int tj = tix - ti * (ti + 1) / 2;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const GProgHdr h = a.ghdr[p];
+  double* tpt = smem;
+  double* sig = smem + 256;
+  double* prm = sig + h.n_cp * 256;
+  int32_t* poff = reinterpret_cast<int32_t*>(prm + h.n_prm + 3);
+  uint8_t* ops = reinterpret_cast<uint8_t*>(poff + h.n_ops);
+  uint8_t* lc = ops + h.n_ops;
+  uint8_t* rc = lc + h.n_ops;
+  {
+    for (int i = tid; i < h.n_prm + 3; i += 256) prm[i] = a.gprm[h.prm_off + i];
+    for (int i = tid; i < h.n_ops; i += 256) {
+      poff[i] = a.gpoff[h.node_off + i];
+      ops[i] = a.gops[h.node_off + i]; lc[i] = a.glc[h.node_off + i]; rc[i] = a.grc[h.node_off + i];
+    }
+    const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
+    tpt[tid] = a.tt[g];
+    __syncthreads();
+    if (h.n_cp > 0) {
+      const double t = tpt[tid];
+      int c = 0;
+      for (int ip = 0; ip < h.n_ops; ++ip)
+        if (ops[ip] == OP_CP) {
+          const double* q = prm + poff[ip];
+          sig[c * 256 + tid] = 0.5 * (1.0 + tanh((q[0] - t) / q[1]));
+          ++c;
+        }
+    }
+    __syncthreads();
+  }
+  constexpr int E = 4;
+  double tape[MAXS][E], gacc[3 * MAXS + 2];
+  for (int q = 0; q <= h.n_prm + 2; ++q) gacc[q] = 0.0;
+  const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
+  const double* __restrict__ Kt = a.A + (long long)p * a.strideA + tile_off(ti, tj);
+  const double wfac = (ti == tj) ? 1.0 : 2.0;
+  double gnoise = 0.0;
+  // thread = one row (tid & 127) x 64 columns (half tid >> 7), 4 columns per lockstep pass
+  const int rslot = tid & 127, chalf = (tid >> 7) * 64;
+  const int ga = ti * NB + rslot;
+  const double ar = ga < a.n ? al[ga] : 0.0;
+#pragma unroll 1
+  for (int c0 = 0; c0 < 64; c0 += E) {
+    int ri[E], ci[E];
+    double ta[E], tb[E], wg[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int cslot = chalf + c0 + e;
+      const int gb = tj * NB + cslot;
+      const bool valid = ga < a.n && gb < a.n;
+      const double kinv = Kt[cslot * NB + rslot];
+      const double G = valid ? 0.5 * (ar * al[valid ? gb : 0] - kinv) : 0.0;
+      if (ga == gb) gnoise += G;
+      ri[e] = rslot; ci[e] = NB + cslot; ta[e] = tpt[rslot]; tb[e] = tpt[NB + cslot]; wg[e] = wfac * G;
+    }
+    grad_elements<MAXS, E>(h, ops, lc, rc, poff, prm, sig, ri, ci, ta, tb, wg, tape, gacc);
+  }
+  gacc[h.n_prm] = gnoise;
+  __syncthreads();
+  double* red = smem + 256;
   for (int q = 0; q <= h.n_prm; ++q) {
     double s = gacc[q];
 #pragma unroll
