@@ -290,6 +290,45 @@ def test_logpdf_gradient(pkg, engine):
     assert (lp == 0).all() and all((g == 0).all() for g in grads) and (gn == 0).all()
 
 
+def test_logpdf_gradient_large_trees_and_chunks(pkg, engine):
+    """Trees above 16 nodes take the 64-node kernel variant (mixed with small ones in one batch); a tight
+    workspace limit forces several chunks; trees above 64 nodes are rejected, not mis-evaluated."""
+    G = pkg
+    leafs = base_kernels(G)[1:]
+
+    def full(d, i=0):
+        if d == 1:
+            return leafs[i % 5]
+        l, r = full(d - 1, 2 * i + 1), full(d - 1, 2 * i + 2)
+        return G.ChangePoint(l, r, 0.3 + 0.05 * d, 0.05 * d) if d == 5 else (l + r if (d + i) % 2 else l * r)
+    big = full(5)                      # 31 nodes, 16 leaves, one ChangePoint at the root
+    mid = full(4, 3)                   # 15 nodes
+    chain = leafs[0]
+    for i in range(1, 12):             # right-deep chain, 23 nodes
+        chain = (leafs[i % 5] + chain) if i % 2 else (leafs[i % 5] * chain)
+    kernels = [leafs[1], big, mid, chain, leafs[3] * leafs[4], big + leafs[2]]
+    assert big.size() == 31 and (big + leafs[2]).size() == 33
+    rng = np.random.default_rng(31)
+    n = 200
+    ts = np.sort(rng.random(n)); xs = 0.4 * rng.standard_normal(n)
+    engine.set_data(ts, xs)
+    noises = np.full(len(kernels), 0.3)
+    lp, grads, gn, info = engine.logpdf_grad_batch(kernels, noises)
+    refs = [O.gp_logpdf_grad(k.to_tuple(), 0.3, ts, xs) for k in kernels]
+    for k, g, gnz, (lpo, go, gno) in zip(kernels, grads, gn, refs):
+        sc = max(1.0, np.abs(go).max(), abs(gno))
+        assert np.abs(g - go).max() <= 1e-6 * sc and abs(gnz - gno) <= 1e-6 * sc, k
+    # chunked workspace: L + Z for two particles at a time (nt = 2 -> 3 tiles)
+    engine.set_workspace_limit(2 * 2 * 3 * 128 * 128 * 8)
+    try:
+        lp2, grads2, gn2, _ = engine.logpdf_grad_batch(kernels, noises)
+    finally:
+        engine.set_workspace_limit(0)
+    assert np.array_equal(lp, lp2) and np.array_equal(gn, gn2) and all(np.array_equal(a, b) for a, b in zip(grads, grads2))
+    with pytest.raises(pkg.AGPError, match="64 nodes"):
+        engine.logpdf_grad_batch([full(7)], [0.3])             # 127 nodes
+
+
 def test_infer_gp_sum(pkg, engine):
     """GP.infer_gp_sum (src/GP.jl:904-993) against the oracle restatement, plus the reference's own
     relational checks (test/test_GP.jl:150-240): the observable block equals the single-kernel
