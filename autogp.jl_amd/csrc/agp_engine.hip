@@ -95,6 +95,10 @@ struct agp_ctx {
   int grad_split = 1;   // 1: K^-1 tiles to memory + lean contraction kernel; 0: fused tile kernel (env AGP_GRAD_SPLIT)
   int intrsm = 1;       // 1: triangular solve inside k_chol_update (one launch per block column); env AGP_INTRSM
   int n_streams = 1;    // sub-batches of one call run on this many streams (env AGP_STREAMS)
+  // A tile evaluation longer than this (cost model op_cost_us, measured per-leaf cost of one 128x128 tile
+  // with two workgroups per CU) is not hidden by the co-resident workgroup's GEMM phase and would set the
+  // duration of the short launches; such particles get their tiles from k_cov_tiles.  env AGP_FUSE_MAX_US
+  double fuse_max_us = 50.0;
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
@@ -281,17 +285,14 @@ struct Batch {
 // Measured cost of evaluating one 128x128 tile of a leaf inside k_chol_update (microseconds, MI355X).
 double op_cost_us(int op) {
   switch (op) {
-    case OP_GE: return 76.0;
-    case OP_PER: return 30.0;
-    case OP_SE: return 9.0;
+    case OP_GE: return 36.0;
+    case OP_PER: return 12.0;
+    case OP_SE: return 7.0;
     case OP_LIN: return 2.0;
     case OP_CP: case OP_CP_SWAP: return 2.0;
     default: return 0.6;
   }
 }
-// A tile evaluation longer than this is not hidden by the co-resident workgroup's GEMM phase and
-// would set the duration of the short launches; such particles get their tiles from k_cov_tiles.
-constexpr double FUSE_MAX_TILE_US = 160.0;
 
 // Gradient program of one tree: nodes in evaluation (post-)order with TRUE left/right child indices, the
 // original parameter values and, per parameter slot, its index in the caller's parameter array.
@@ -330,7 +331,7 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   // Sort: fused particles first, most expensive evaluation first (their workgroups are dispatched
   // first inside every launch); particles whose tiles are prebuilt go last.
   const bool fuse_on = c->fuse_mode == 1 || (c->fuse_mode < 0 && P >= 256);
-  auto fusable = [&](int p) { return fuse_on && cost[p] <= FUSE_MAX_TILE_US && cps[p].n_cp <= U_MAX_CP; };
+  auto fusable = [&](int p) { return fuse_on && cost[p] <= c->fuse_max_us && cps[p].n_cp <= U_MAX_CP; };
   bt.order.resize(P);
   for (int p = 0; p < P; ++p) bt.order[p] = p;
   std::stable_sort(bt.order.begin(), bt.order.end(), [&](int a, int b) {
@@ -788,6 +789,7 @@ int agp_init(agp_ctx** out, int device_id) {
   (void)hipMemGetInfo(&free_b, &tot_b);
   c->total_mem = free_b ? free_b : tot_b;
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
+  if (const char* e = getenv("AGP_FUSE_MAX_US")) c->fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
   if (const char* e = getenv("AGP_INTRSM")) c->intrsm = atoi(e) != 0;
   if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));
