@@ -17,6 +17,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace agp;
@@ -99,6 +100,8 @@ struct agp_ctx {
   // with two workgroups per CU) is not hidden by the co-resident workgroup's GEMM phase and would set the
   // duration of the short launches; such particles get their tiles from k_cov_tiles.  env AGP_FUSE_MAX_US
   double fuse_max_us = 50.0;
+  int dedup = 1;        // evaluate identical particles of a host-output sweep once; env AGP_DEDUP
+  int64_t n_particles_seen = 0, n_particles_run = 0;
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
@@ -789,6 +792,7 @@ int agp_init(agp_ctx** out, int device_id) {
   (void)hipMemGetInfo(&free_b, &tot_b);
   c->total_mem = free_b ? free_b : tot_b;
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
+  if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
   if (const char* e = getenv("AGP_FUSE_MAX_US")) c->fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
   if (const char* e = getenv("AGP_INTRSM")) c->intrsm = atoi(e) != 0;
@@ -863,12 +867,75 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
   return AGP_OK;
 }
 
+// Host-output sweeps evaluate each DISTINCT (program, parameters, noise) once: after an SMC resampling
+// step the population holds many copies of the surviving particles (src/inference_smc_anneal_data.jl:198-204
+// resamples, then extends every particle with the new observations), and copies score identically.
+static int logpdf_batch_dedup(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
+                              const int32_t* prm_off, const double* prm, const double* noise, double* out_logpdf,
+                              int32_t* out_info, GradOut* go) {
+  if (!c || !c->dedup || P < 2 || !op_off || !ops || !prm_off || !prm || !noise)
+    return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr, nullptr,
+                             nullptr, false, go);
+  for (int p = 0; p < P; ++p)     // malformed offsets are diagnosed by the sweep itself
+    if (op_off[p + 1] < op_off[p] || prm_off[p + 1] < prm_off[p] || op_off[p] < 0 || prm_off[p] < 0)
+      return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr, nullptr,
+                               nullptr, false, go);
+  std::unordered_map<std::string, int> seen;
+  seen.reserve((size_t)P * 2);
+  std::vector<int> rep(P), uniq;
+  std::string key;
+  for (int p = 0; p < P; ++p) {
+    const int no = op_off[p + 1] - op_off[p], np = prm_off[p + 1] - prm_off[p];
+    key.assign(reinterpret_cast<const char*>(ops + op_off[p]), (size_t)no);
+    key.append(reinterpret_cast<const char*>(prm + prm_off[p]), sizeof(double) * (size_t)np);
+    key.append(reinterpret_cast<const char*>(noise + p), sizeof(double));
+    auto it = seen.find(key);
+    if (it == seen.end()) { seen.emplace(key, (int)uniq.size()); rep[p] = (int)uniq.size(); uniq.push_back(p); }
+    else rep[p] = it->second;
+  }
+  const int U = (int)uniq.size();
+  { std::lock_guard<std::mutex> g(c->mu); c->n_particles_seen += P; c->n_particles_run += U; }
+  if (U == P)
+    return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr, nullptr,
+                             nullptr, false, go);
+  std::vector<int32_t> uo(U + 1, 0), up(U + 1, 0), uinfo(U);
+  std::vector<uint8_t> uops; std::vector<double> uprm, unoise(U), ulp(U), ugn(go ? U : 0);
+  for (int u = 0; u < U; ++u) {
+    const int p = uniq[u];
+    uops.insert(uops.end(), ops + op_off[p], ops + op_off[p + 1]);
+    uprm.insert(uprm.end(), prm + prm_off[p], prm + prm_off[p + 1]);
+    uo[u + 1] = (int32_t)uops.size(); up[u + 1] = (int32_t)uprm.size();
+    unoise[u] = noise[p];
+  }
+  std::vector<double> ugrad(go ? std::max<size_t>(1, uprm.size()) : 0);
+  if (uprm.empty()) uprm.push_back(0.0);
+  GradOut ugo{ugrad.data(), ugn.data()};
+  const int rc = logpdf_batch_impl(c, n, U, uo.data(), uops.data(), up.data(), uprm.data(), unoise.data(), ulp.data(),
+                                   uinfo.data(), nullptr, nullptr, nullptr, false, go ? &ugo : nullptr);
+  if (rc) return rc;
+  for (int p = 0; p < P; ++p) {
+    const int u = rep[p];
+    out_logpdf[p] = ulp[u]; out_info[p] = uinfo[u];
+    if (go) {
+      go->gnoise[p] = ugn[u];
+      std::copy(ugrad.begin() + up[u], ugrad.begin() + up[u + 1], go->grad + prm_off[p]);
+    }
+  }
+  return AGP_OK;
+}
+
 int agp_logpdf_batch(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
                      const int32_t* prm_off, const double* prm, const double* noise, double* out_logpdf,
                      int32_t* out_info) {
   if (c && P > 0 && (!out_logpdf || !out_info)) return fail(c, AGP_ERR_ARG, "null output pointer");
-  return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr, nullptr,
-                           nullptr, false);
+  return logpdf_batch_dedup(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr);
+}
+
+int agp_get_dedup_stats(agp_ctx* c, int64_t* n_particles, int64_t* n_evaluated) {
+  if (!c || !n_particles || !n_evaluated) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  *n_particles = c->n_particles_seen; *n_evaluated = c->n_particles_run;
+  return AGP_OK;
 }
 
 int agp_logpdf_grad_batch(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
@@ -876,8 +943,7 @@ int agp_logpdf_grad_batch(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_of
                           double* out_grad, double* out_grad_noise, int32_t* out_info) {
   if (c && P > 0 && (!out_logpdf || !out_info || !out_grad || !out_grad_noise)) return fail(c, AGP_ERR_ARG, "null output pointer");
   GradOut go{out_grad, out_grad_noise};
-  return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr, nullptr, nullptr,
-                           false, &go);
+  return logpdf_batch_dedup(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, &go);
 }
 
 int agp_logpdf_batch_device(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "agp_init", "agp_destroy", "agp_last_error", "agp_version", "agp_set_data", "agp_logpdf",
     "agp_logpdf_batch", "agp_logpdf_grad_batch", "agp_logpdf_batch_device", "agp_predict_batch", "agp_infer_gp_sum", "agp_cov_matrix",
     "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_debug_mfma_peak", "agp_debug_math", "agp_debug_gemm_variant", "agp_set_profiling", "agp_get_timing", "agp_get_launch_times",
-    "agp_set_workspace_limit", "agp_set_coalesce_window", "agp_get_coalesce_stats",
+    "agp_set_workspace_limit", "agp_set_coalesce_window", "agp_get_coalesce_stats", "agp_get_dedup_stats",
 ]
 
 
@@ -112,6 +112,7 @@ def load_library(path=None):
     lib.agp_set_workspace_limit.argtypes = [vp, C.c_int64]; lib.agp_set_workspace_limit.restype = C.c_int
     lib.agp_set_coalesce_window.argtypes = [vp, C.c_int32]; lib.agp_set_coalesce_window.restype = C.c_int
     lib.agp_get_coalesce_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.agp_get_coalesce_stats.restype = C.c_int
+    lib.agp_get_dedup_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.agp_get_dedup_stats.restype = C.c_int
     if path is None:
         _lib = lib
     return lib
@@ -323,6 +324,12 @@ class GPEngine:
     def coalesce_stats(self):
         a = C.c_int64(); b = C.c_int64()
         self._check(self._lib.agp_get_coalesce_stats(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def dedup_stats(self):
+        """(particles submitted, particles evaluated) over the host-output batch calls so far."""
+        a = C.c_int64(); b = C.c_int64()
+        self._check(self._lib.agp_get_dedup_stats(self._ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def set_workspace_limit(self, nbytes: int):

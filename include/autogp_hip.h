@@ -174,6 +174,11 @@ int agp_get_launch_times(agp_ctx* ctx, int32_t which, double* out, int32_t n_out
 int agp_set_coalesce_window(agp_ctx* ctx, int32_t microseconds);
 int agp_get_coalesce_stats(agp_ctx* ctx, int64_t* n_calls, int64_t* n_batches);
 
+/* agp_logpdf_batch / agp_logpdf_grad_batch evaluate each distinct (program, parameters, noise) once and copy
+ * the result to its duplicates (a resampled SMC population, src/inference_smc_anneal_data.jl:198-204, holds
+ * many copies).  Counters: particles submitted / particles actually evaluated.  env AGP_DEDUP=0 disables. */
+int agp_get_dedup_stats(agp_ctx* ctx, int64_t* n_particles, int64_t* n_evaluated);
+
 /* Cap (bytes) on matrix workspace per call; larger batches are processed in chunks. 0 = default. */
 int agp_set_workspace_limit(agp_ctx* ctx, int64_t bytes);
 

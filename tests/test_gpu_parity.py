@@ -406,6 +406,37 @@ def test_bad_programs_are_rejected(pkg, engine):
     assert b"particle 0" in lib.agp_last_error(ctx)
 
 
+def test_resampled_population_is_evaluated_once(pkg, engine):
+    """A resampled SMC population (src/inference_smc_anneal_data.jl:198-204) holds copies: the host-output sweeps
+    evaluate each distinct (kernel, noise) once and every copy gets bit-identical value, info and gradient;
+    particles that differ only in noise or in one parameter bit are NOT merged."""
+    G = pkg
+    ts, xs = pkg.prior.synthetic_series(200, seed=11, shuffle=True)
+    engine.set_data(ts, xs)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(11), 12, max_depth=3, max_size=15)
+    idx = np.random.default_rng(12).integers(0, 12, size=300)          # multinomial resampling
+    pop = [nodes[i] for i in idx]; pnz = noises[idx].copy()
+    pop += [nodes[0], nodes[0], G.SquaredExponential(0.3, 1.0), G.SquaredExponential(np.nextafter(0.3, 1.0), 1.0)]
+    pnz = np.concatenate([pnz, [noises[0], noises[0] * 1.5, 0.2, 0.2]])
+    s0 = engine.dedup_stats()
+    lp, info = engine.logpdf_batch(pop, pnz, check=False)
+    s1 = engine.dedup_stats()
+    n_unique = len(set(idx.tolist())) + 3            # + nodes[0] at another noise + the two SE kernels
+    assert s1[0] - s0[0] == len(pop) and s1[1] - s0[1] == n_unique
+    ref, rinfo = engine.logpdf_batch(nodes, noises, check=False)
+    assert np.array_equal(lp[:300], ref[idx]) and np.array_equal(info[:300], rinfo[idx])
+    assert lp[300] == ref[0] and lp[301] != ref[0]
+    for i in (0, 150, 301, 303):
+        if info[i] == 0:
+            lpo = O.gp_logpdf(pop[i].to_tuple(), float(pnz[i]), ts, xs)
+            assert abs(lp[i] - lpo) <= LP_TOL * max(1.0, abs(lpo))
+    lpg, grads, gn, ginfo = engine.logpdf_grad_batch(pop, pnz, check=False)
+    rlp, rgrads, rgn, _ = engine.logpdf_grad_batch(nodes, noises, check=False)
+    assert np.array_equal(lpg, lp)
+    for j, i in enumerate(idx):
+        assert np.array_equal(grads[j], rgrads[i]) and gn[j] == rgn[i]
+
+
 def test_workspace_chunking_is_invisible(pkg, engine):
     ts, xs = pkg.prior.synthetic_series(300, seed=8)
     nodes, noises = pkg.prior.sample_particles(np.random.default_rng(8), 13, max_depth=3)
