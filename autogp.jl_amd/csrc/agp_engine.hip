@@ -532,6 +532,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   HIPCHK(c, hipSetDevice(c->device));
 
   Batch bt;
+  std::vector<std::vector<int32_t>> pls;     // per-group particle orders of the gradient contraction
+  pls.reserve(64);
   int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr);
   if (rc) return rc;
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
@@ -701,23 +703,26 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             hipLaunchKernelGGL(k_trtri_step, dim3(8 * Pg8 * (i + 1)), dim3(256), 0, q, ga);
           }
           hipLaunchKernelGGL(k_alpha, dim3(nt, Pg), dim3(256), 0, q, ga);
-          // small trees (<= 16 nodes) run the 800 B-scratch variant, the rest the 64-node one
-          std::vector<int32_t> pl_small, pl_large;
-          for (int r = 0; r < Pg; ++r) (bt.ghdr[p0 + g0 + r].n_ops <= 16 ? pl_small : pl_large).push_back(r);
-          std::vector<int32_t> pl(pl_small); pl.insert(pl.end(), pl_large.begin(), pl_large.end());
+          // One contraction launch per group, largest trees first (their workgroups run longest); the 16-node
+          // (800 B private memory) variant serves groups without a larger tree.
+          pls.emplace_back(Pg);
+          std::vector<int32_t>& pl = pls.back();          // outlives the async upload (synchronised at the end of the call)
+          int max_nodes = 0;
+          for (int r = 0; r < Pg; ++r) { pl[r] = r; max_nodes = std::max(max_nodes, (int)bt.ghdr[p0 + g0 + r].n_ops); }
+          std::stable_sort(pl.begin(), pl.end(), [&](int a_, int b_) { return bt.ghdr[p0 + g0 + a_].n_ops > bt.ghdr[p0 + g0 + b_].n_ops; });
           int32_t* d_pl = s->plist.as<int32_t>() + p0 + g0;
           HIPCHK(c, hipMemcpyAsync(d_pl, pl.data(), sizeof(int32_t) * Pg, hipMemcpyHostToDevice, q));
-          HIPCHK(c, hipStreamSynchronize(q));     // `pl` is a local
+          ga.plist = d_pl;
           const size_t lds = sizeof(double) * std::max<size_t>(2 * U_SLAB, 256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes);
           const int Pall = ga.P;
           if (c->grad_split) {
             hipLaunchKernelGGL(k_kinv_tiles, dim3(ntiles, Pg), dim3(256), 0, q, ga);
             const size_t lds2 = sizeof(double) * (256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes + 8);
-            if (!pl_small.empty()) { ga.plist = d_pl; HIPCHK(c, launch_grad_contract<16>(q, ga, ntiles, (int)pl_small.size(), lds2)); }
-            if (!pl_large.empty()) { ga.plist = d_pl + pl_small.size(); HIPCHK(c, launch_grad_contract<64>(q, ga, ntiles, (int)pl_large.size(), lds2)); }
+            if (max_nodes <= 16) HIPCHK(c, launch_grad_contract<16>(q, ga, ntiles, Pg, lds2));
+            else HIPCHK(c, launch_grad_contract<64>(q, ga, ntiles, Pg, lds2));
           } else {
-            if (!pl_small.empty()) { ga.plist = d_pl; ga.P = (int)pl_small.size(); HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, ga.P, lds)); }
-            if (!pl_large.empty()) { ga.plist = d_pl + pl_small.size(); ga.P = (int)pl_large.size(); HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, ga.P, lds)); }
+            if (max_nodes <= 16) HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, Pg, lds));
+            else HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, Pg, lds));
           }
           ga.P = Pall;
           hipLaunchKernelGGL(k_grad_finish, dim3(Pg), dim3(64), 0, q, ga);

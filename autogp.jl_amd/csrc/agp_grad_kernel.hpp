@@ -158,14 +158,32 @@ struct GProgHdr {
 __device__ __forceinline__ long long zoff(int r, int k) { return tile_off(k, r); }   // r <= k
 
 // ---- Z = L^-T, block column `step` -------------------------------------------------------------
+#ifndef AGP_TRTRI_TAIL_GROUPS
+#define AGP_TRTRI_TAIL_GROUPS 8
+#endif
+constexpr int TRTRI_TAIL_GROUPS = AGP_TRTRI_TAIL_GROUPS;
 __global__ __launch_bounds__(256, 2) void k_trtri_step(GradArgs a) {
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES];
   // grid: particle-major (a particle's tiles run together and share its Z / L panels in one XCD's L2 —
   // measured 10 % faster than a longest-contraction-first order); block b -> XCD b%8, particle = pl*8 + xcd
+  // The tiles of a block column differ in length (tile j contracts over i-j tiles), so the launch would end with
+  // the last particle's longest tile running alone; the last TRTRI_TAIL_GROUPS x 8 particles are therefore laid
+  // out tile-major (all their j = 0 tiles, then j = 1, ...) and the launch drains on the short tiles.
   const int i = a.step;
   const int T = i + 1;
-  const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
-  const int pl = qq / T, j = qq - pl * T;
+  const int npl = (a.P + 7) / 8;
+  const int tailg = npl < TRTRI_TAIL_GROUPS ? npl : TRTRI_TAIL_GROUPS;
+  const int maing = npl - tailg;
+  int b = blockIdx.x;
+  int pl, j;
+  const int xcd = b & 7;
+  if (b < 8 * maing * T) {
+    const int qq = b >> 3;
+    pl = qq / T; j = qq - pl * T;
+  } else {
+    const int qq = (b - 8 * maing * T) >> 3;
+    j = qq / tailg; pl = maing + (qq - j * tailg);
+  }
   const int p = pl * 8 + xcd;
   if (p >= a.P) return;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
@@ -219,12 +237,12 @@ __global__ __launch_bounds__(256) void k_alpha(GradArgs a) {
 // ---- reverse-mode pass over E elements in lockstep ----------------------------------------------
 // One private-memory slot per node and element: it holds the node's VALUE after the forward pass and is
 // overwritten by the node's ADJOINT when its parent is visited in the backward pass (a binary node only
-// needs its children's values, never its own; a leaf recomputes its intermediates — arithmetic is cheap
-// here, private-memory traffic is what bounds this kernel).  gacc: per parameter slot accumulator.
+// needs its children's values, never its own; a stationary leaf is handed adjoint x value so that it does not
+// evaluate its exponential again).  gacc: per parameter slot accumulator.
 // The E elements share one walk over the program, so their memory latencies overlap.
 template <int MAXS, int E>
 __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* ops, const uint8_t* lc, const uint8_t* rc,
-                                              const int32_t* poff, const double* prm, const double* sig,
+                                              const uint8_t* mv, const int32_t* poff, const double* prm, const double* sig,
                                               const int (&ri)[E], const int (&ci)[E], const double (&ta)[E],
                                               const double (&tb)[E], const double (&wgt)[E],
                                               double (&tape)[MAXS][E], double (&gacc)[3 * MAXS + 2]) {
@@ -256,63 +274,124 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
     if (o == OP_CP) ++cpi;
   }
   // ---------------- backward: adjoints replace values top-down ----------------
+  // A stationary leaf with a non-zero amplitude (mv[node] = 1) receives adjoint * VALUE instead of the
+  // adjoint: its derivatives are that product times a factor free of the exponential
+  // (SE: d/d amp = s/amp, d/d l = s d^2/l^3, ...), so the backward pass re-evaluates no exp.
+  {
+    const int root = h.n_ops - 1;
+    const bool m = __builtin_amdgcn_readfirstlane((int)mv[root]) != 0;
 #pragma unroll
-  for (int e = 0; e < E; ++e) tape[h.n_ops - 1][e] = wgt[e];
+    for (int e = 0; e < E; ++e) tape[root][e] = m ? wgt[e] * tape[root][e] : wgt[e];
+  }
   for (int ip = h.n_ops - 1; ip >= 0; --ip) {
     const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
     const int po = poff[ip];
     const double* q = prm + po;
     const double q0 = q[0], q1 = q[1], q2 = q[2];
     const int il = lc[ip], ir = rc[ip];
+    const bool m = __builtin_amdgcn_readfirstlane((int)mv[ip]) != 0;
     if (o == OP_CP) --cpi;
     double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    if (o <= OP_PER) {
+      if (o == OP_WN) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const double ad = tape[ip][e];
-      if (o == OP_WN) { g0 += (ta[e] == tb[e]) ? ad : 0.0; }
-      else if (o == OP_CONST) { g0 += ad; }
-      else if (o == OP_LIN) {
-        g0 += ad * (-q2 * (ta[e] + tb[e] - 2.0 * q0));
-        g1 += ad;
-        g2 += ad * ((ta[e] - q0) * (tb[e] - q0));
+        for (int e = 0; e < E; ++e) g0 += (ta[e] == tb[e]) ? tape[ip][e] : 0.0;
+      } else if (o == OP_CONST) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) g0 += tape[ip][e];
+      } else if (o == OP_LIN) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double ad = tape[ip][e];
+          g0 += ad * (-q2 * (ta[e] + tb[e] - 2.0 * q0));
+          g1 += ad;
+          g2 += ad * ((ta[e] - q0) * (tb[e] - q0));
+        }
       } else if (o == OP_SE) {
-        const double d = ta[e] - tb[e], d2 = d * d;
-        const double ex = fm::exp_f(-0.5 * d2 / (q0 * q0));
-        g0 += ad * q1 * ex * d2 / (q0 * q0 * q0);
-        g1 += ad * ex;
+        if (m) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const double sv = tape[ip][e], d = ta[e] - tb[e];
+            g0 += sv * (d * d);
+            g1 += sv;
+          }
+          g0 *= 1.0 / (q0 * q0 * q0);
+          g1 *= 1.0 / q1;
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const double ad = tape[ip][e], d = ta[e] - tb[e], d2 = d * d;
+            const double ex = fm::exp_f(-0.5 * d2 / (q0 * q0));
+            g0 += ad * q1 * ex * d2 / (q0 * q0 * q0);
+            g1 += ad * ex;
+          }
+        }
       } else if (o == OP_GE) {
-        const double u = fabs(ta[e] - tb[e]) / q0;
-        const double ug = fm::pow_f(u, q1);
-        const double ex = fm::exp_f(-ug);
-        g0 += ad * q2 * ex * q1 * ug / q0;
-        g1 += u > 0.0 ? ad * (-q2 * ex * ug * fm::log_f(u)) : 0.0;      // u^g ln u -> 0 at u = 0
-        g2 += ad * ex;
-      } else if (o == OP_PER) {
-        const double dd = fabs(ta[e] - tb[e]);
-        double sn, cs;
-        sincos(PI / q1 * dd, &sn, &cs);
-        const double l2 = q0 * q0;
-        const double ex = fm::exp_f(-2.0 * sn * sn / l2);
-        g0 += ad * q2 * ex * 4.0 * sn * sn / (l2 * q0);
-        g1 += ad * q2 * ex * 4.0 * sn * cs * dd * PI / (l2 * q1 * q1);
-        g2 += ad * ex;
-      } else if (o == OP_PLUS) { tape[il][e] = ad; tape[ir][e] = ad; }
-      else if (o == OP_TIMES) {
-        const double kl = tape[il][e], kr = tape[ir][e];
-        tape[il][e] = ad * kr; tape[ir][e] = ad * kl;
+        const double rl = 1.0 / q0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double u = fabs(ta[e] - tb[e]) * rl;
+          const double lu = fm::log_f(u > 0.0 ? u : 1.0);             // u^g ln u -> 0 at u = 0
+          const double ug = u > 0.0 ? fm::exp_f(q1 * lu) : 0.0;
+          const double sv = m ? tape[ip][e] : tape[ip][e] * fm::exp_f(-ug);   // adjoint * amp * exp  |  adjoint * exp
+          g0 += sv * ug;
+          g1 -= sv * (ug * lu);
+          g2 += sv;
+        }
+        if (m) { g0 *= q1 * rl; g2 *= 1.0 / q2; }
+        else { g0 *= q2 * q1 * rl; g1 *= q2; }
+      } else {   // OP_PER
+        const double l2 = q0 * q0, wq = PI / q1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double dd = fabs(ta[e] - tb[e]);
+          double sn, cs;
+          fm::sincos_pi_f(wq * dd, &sn, &cs);
+          const double sv = m ? tape[ip][e] : tape[ip][e] * fm::exp_f(-2.0 * sn * sn / l2);
+          g0 += sv * (sn * sn);
+          g1 += sv * (sn * cs * dd);
+          g2 += sv;
+        }
+        const double f0 = 4.0 / (l2 * q0), f1 = 4.0 * PI / (l2 * q1 * q1);
+        if (m) { g0 *= f0; g1 *= f1; g2 *= 1.0 / q2; }
+        else { g0 *= q2 * f0; g1 *= q2 * f1; }
+      }
+      gacc[po] += g0; gacc[po + 1] += g1; gacc[po + 2] += g2;
+    } else {
+      const bool ml = __builtin_amdgcn_readfirstlane((int)mv[il]) != 0, mr = __builtin_amdgcn_readfirstlane((int)mv[ir]) != 0;
+      if (o == OP_PLUS) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double ad = tape[ip][e];
+          tape[il][e] = ml ? ad * tape[il][e] : ad;
+          tape[ir][e] = mr ? ad * tape[ir][e] : ad;
+        }
+      } else if (o == OP_TIMES) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double ad = tape[ip][e], kl = tape[il][e], kr = tape[ir][e];
+          const double al_ = ad * kr, ar_ = ad * kl;
+          tape[il][e] = ml ? al_ * kl : al_;
+          tape[ir][e] = mr ? ar_ * kr : ar_;
+        }
       } else {   // OP_CP: q = {location, scale}
-        const double x1 = sig[cpi * 256 + ri[e]], x2 = sig[cpi * 256 + ci[e]];
-        const double kl = tape[il][e], kr = tape[ir][e];
-        tape[il][e] = ad * (x1 * x2);
-        tape[ir][e] = ad * ((1.0 - x1) * (1.0 - x2));
-        // d sigma / d loc = 2 sigma (1 - sigma) / scale;  d sigma / d scale = -(loc - t)/scale * that
-        const double da = 2.0 * x1 * (1.0 - x1) / q1, db = 2.0 * x2 * (1.0 - x2) / q1;
-        g0 += ad * ((da * x2 + x1 * db) * kl - (da * (1.0 - x2) + (1.0 - x1) * db) * kr);
-        const double das = -da * (q0 - ta[e]) / q1, dbs = -db * (q0 - tb[e]) / q1;
-        g1 += ad * ((das * x2 + x1 * dbs) * kl - (das * (1.0 - x2) + (1.0 - x1) * dbs) * kr);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const double ad = tape[ip][e];
+          const double x1 = sig[cpi * 256 + ri[e]], x2 = sig[cpi * 256 + ci[e]];
+          const double kl = tape[il][e], kr = tape[ir][e];
+          const double al_ = ad * (x1 * x2), ar_ = ad * ((1.0 - x1) * (1.0 - x2));
+          tape[il][e] = ml ? al_ * kl : al_;
+          tape[ir][e] = mr ? ar_ * kr : ar_;
+          // d sigma / d loc = 2 sigma (1 - sigma) / scale;  d sigma / d scale = -(loc - t)/scale * that
+          const double da = 2.0 * x1 * (1.0 - x1) / q1, db = 2.0 * x2 * (1.0 - x2) / q1;
+          g0 += ad * ((da * x2 + x1 * db) * kl - (da * (1.0 - x2) + (1.0 - x1) * db) * kr);
+          const double das = -da * (q0 - ta[e]) / q1, dbs = -db * (q0 - tb[e]) / q1;
+          g1 += ad * ((das * x2 + x1 * dbs) * kl - (das * (1.0 - x2) + (1.0 - x1) * dbs) * kr);
+        }
+        gacc[po] += g0; gacc[po + 1] += g1;
       }
     }
-    if (o <= OP_PER || o == OP_CP) { gacc[po] += g0; gacc[po + 1] += g1; gacc[po + 2] += g2; }
   }
 }
 
@@ -342,7 +421,7 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
              smem, tid, l15, lq, row0);
 
   // ---- per-element reverse-mode contraction ----
-  // LDS map (aliases the slab buffers): tpt[256] | sig[n_cp][256] | prm[n_prm+3] | poff[n_ops] | ops/lc/rc[n_ops] bytes
+  // LDS map (aliases the slab buffers): tpt[256] | sig[n_cp][256] | prm[n_prm+3] | poff[n_ops] | ops/lc/rc/mv[n_ops] bytes
   const GProgHdr h = a.ghdr[p];
   double* tpt = smem;
   double* sig = smem + 256;
@@ -351,11 +430,16 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
   uint8_t* ops = reinterpret_cast<uint8_t*>(poff + h.n_ops);
   uint8_t* lc = ops + h.n_ops;
   uint8_t* rc = lc + h.n_ops;
+  uint8_t* mv = rc + h.n_ops;     // 1: stationary leaf with non-zero amplitude (see grad_elements)
   {
     for (int i = tid; i < h.n_prm + 3; i += 256) prm[i] = a.gprm[h.prm_off + i];
     for (int i = tid; i < h.n_ops; i += 256) {
-      poff[i] = a.gpoff[h.node_off + i];
-      ops[i] = a.gops[h.node_off + i]; lc[i] = a.glc[h.node_off + i]; rc[i] = a.grc[h.node_off + i];
+      const int po = a.gpoff[h.node_off + i];
+      const int o = a.gops[h.node_off + i];
+      poff[i] = po;
+      ops[i] = (uint8_t)o; lc[i] = a.glc[h.node_off + i]; rc[i] = a.grc[h.node_off + i];
+      const bool stat = (o == OP_SE || o == OP_GE || o == OP_PER);
+      mv[i] = (stat && a.gprm[h.prm_off + po + (o == OP_SE ? 1 : 2)] != 0.0) ? 1 : 0;
     }
     const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
     tpt[tid] = a.tt[g];
@@ -405,7 +489,7 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
         if (ga == gb) gnoise += G;                       // d/d noise = tr G
         ri[e] = rslot; ci[e] = NB + cslot; ta[e] = tpt[rslot]; tb[e] = tpt[NB + cslot]; wg[e] = wfac * G;
       }
-      grad_elements<MAXS, E>(h, ops, lc, rc, poff, prm, sig, ri, ci, ta, tb, wg, tape, gacc);
+      grad_elements<MAXS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, tape, gacc);
     }
   }
   gacc[h.n_prm] = gnoise;       // overwrites whatever the unconditional three-slot adds left there
@@ -469,11 +553,16 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
   uint8_t* ops = reinterpret_cast<uint8_t*>(poff + h.n_ops);
   uint8_t* lc = ops + h.n_ops;
   uint8_t* rc = lc + h.n_ops;
+  uint8_t* mv = rc + h.n_ops;     // 1: stationary leaf with non-zero amplitude (see grad_elements)
   {
     for (int i = tid; i < h.n_prm + 3; i += 256) prm[i] = a.gprm[h.prm_off + i];
     for (int i = tid; i < h.n_ops; i += 256) {
-      poff[i] = a.gpoff[h.node_off + i];
-      ops[i] = a.gops[h.node_off + i]; lc[i] = a.glc[h.node_off + i]; rc[i] = a.grc[h.node_off + i];
+      const int po = a.gpoff[h.node_off + i];
+      const int o = a.gops[h.node_off + i];
+      poff[i] = po;
+      ops[i] = (uint8_t)o; lc[i] = a.glc[h.node_off + i]; rc[i] = a.grc[h.node_off + i];
+      const bool stat = (o == OP_SE || o == OP_GE || o == OP_PER);
+      mv[i] = (stat && a.gprm[h.prm_off + po + (o == OP_SE ? 1 : 2)] != 0.0) ? 1 : 0;
     }
     const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
     tpt[tid] = a.tt[g];
@@ -515,7 +604,7 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
       if (ga == gb) gnoise += G;
       ri[e] = rslot; ci[e] = NB + cslot; ta[e] = tpt[rslot]; tb[e] = tpt[NB + cslot]; wg[e] = wfac * G;
     }
-    grad_elements<MAXS, E>(h, ops, lc, rc, poff, prm, sig, ri, ci, ta, tb, wg, tape, gacc);
+    grad_elements<MAXS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, tape, gacc);
   }
   gacc[h.n_prm] = gnoise;
   __syncthreads();

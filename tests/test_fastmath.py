@@ -14,6 +14,7 @@ SRC = r'''
 extern "C" {
 void v_exp(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = agp::fm::exp_f(x[i]); }
 void v_sin2(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = agp::fm::sin2_f(x[i]); }
+void v_sincos(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) agp::fm::sincos_pi_f(x[i], y + 2 * i, y + 2 * i + 1); }
 void v_log(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = agp::fm::log_f(x[i]); }
 void v_pow(const double* x, const double* g, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = agp::fm::pow_f(x[i], g[i]); }
 }
@@ -66,6 +67,20 @@ def test_sin2(lib):
     rel = abs_err / np.maximum(np.array([float(r) for r in ref]), 1e-300)
     good = np.array([float(r) for r in ref]) > 1e-6
     assert rel[good].max() < 1e-15 * 3 and abs_err.max() < 1e-15, (rel[good].max(), abs_err.max())
+
+
+def test_sincos_pi(lib):
+    """sin(x)^2 = s^2 and sin(x) cos(x) = s c after the reduction by pi (Periodic-kernel derivatives)."""
+    mp.mp.dps = 60
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.random(2000) * 4, rng.random(2000) * 700, rng.random(500) * 1e5, [0.0, 1e-9, np.pi, np.pi / 2]])
+    y = np.empty(2 * x.size)
+    lib.v_sincos(x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(x.size))
+    s, c = y[0::2], y[1::2]
+    e2 = max(float(abs(mp.mpf(float(a)) ** 2 - mp.sin(mp.mpf(float(v))) ** 2)) for a, v in zip(s, x))
+    esc = max(float(abs(mp.mpf(float(a)) * mp.mpf(float(b)) - mp.sin(mp.mpf(float(v))) * mp.cos(mp.mpf(float(v)))))
+              for a, b, v in zip(s, c, x))
+    assert e2 < 1e-15 and esc < 1e-15, (e2, esc)
 
 
 def test_log_pow(lib):
