@@ -102,6 +102,7 @@ struct agp_ctx {
   double fuse_max_us = 50.0;
   int dedup = 1;        // evaluate identical particles of a host-output sweep once; env AGP_DEDUP
   int64_t n_particles_seen = 0, n_particles_run = 0;
+  int trtri_chain = 1;  // Z = L^-T as independent per-row chains in one launch (0: one launch per block column); env AGP_TRTRI_CHAIN
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
@@ -698,9 +699,13 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           ga.gmap = s->gmap.as<int32_t>(); ga.out_off = s->goff.as<int32_t>() + p0 + g0;
           ga.pmap = s->map.as<int32_t>() + p0 + g0; ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
           const int Pg8 = (Pg + 7) / 8;
-          for (int i = 0; i < nt; ++i) {
-            ga.step = i;
-            hipLaunchKernelGGL(k_trtri_step, dim3(8 * Pg8 * (i + 1)), dim3(256), 0, q, ga);
+          if (c->trtri_chain) {
+            hipLaunchKernelGGL(k_trtri_chain, dim3(8 * Pg8 * nt), dim3(256), 0, q, ga);
+          } else {
+            for (int i = 0; i < nt; ++i) {
+              ga.step = i;
+              hipLaunchKernelGGL(k_trtri_step, dim3(8 * Pg8 * (i + 1)), dim3(256), 0, q, ga);
+            }
           }
           hipLaunchKernelGGL(k_alpha, dim3(nt, Pg), dim3(256), 0, q, ga);
           // One contraction launch per group, largest trees first (their workgroups run longest); the 16-node
@@ -797,6 +802,7 @@ int agp_init(agp_ctx** out, int device_id) {
   (void)hipMemGetInfo(&free_b, &tot_b);
   c->total_mem = free_b ? free_b : tot_b;
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
+  if (const char* e = getenv("AGP_TRTRI_CHAIN")) c->trtri_chain = atoi(e) != 0;
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
   if (const char* e = getenv("AGP_FUSE_MAX_US")) c->fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;

@@ -215,6 +215,49 @@ __global__ __launch_bounds__(256, 2) void k_trtri_step(GradArgs a) {
     }
 }
 
+// ---- Z = L^-T, one workgroup per (particle, block ROW j of Z): the whole chain Z(j,j), Z(j,j+1), ... in one launch.
+// Row j of Z only depends on itself (Z(j,i) needs Z(j,k), k < i, and row i of L), so the nt rows of a particle are
+// independent chains and no workgroup ever waits for another: one launch instead of nt, no launch tails, and the
+// row operand of every contraction is a tile this workgroup wrote itself (each lane re-reads exactly the elements it
+// stored).  Longest chains (j = 0: nt(nt-1)/2 tile contractions) are dispatched first.
+__global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
+  __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES];
+  const int npl = (a.P + 7) / 8;
+  const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
+  const int j = qq / npl, pl = qq - j * npl;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  const int row0 = 32 * w + 2 * l15;
+  const double* __restrict__ Lp = a.A + (long long)p * a.strideA;
+  double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
+#pragma unroll 1
+  for (int i = j; i < a.nt; ++i) {
+    // acc = -C,  C = d_ji I - sum_{k=j}^{i-1} Z(j,k) L(i,k)^T
+    d4 acc[NSB][2];
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+      for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[cb][st][r] = (j == i && (cb * 16 + 4 * r + lq) == row0 + st) ? -1.0 : 0.0;
+    gemm_slabs(acc, (i - j) * (NB / KB),
+               [&](int s) { return Zp + zoff(j, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+               [&](int s) { return Lp + tile_off(i, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+               sm, tid, l15, lq, row0);
+    solve_in_regs(acc, Lp + tile_off(i, i), a.W + ((long long)p * a.nt + i) * NSB * 256, sm, tid, l);
+    double* __restrict__ Tt = Zp + zoff(j, i);
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d2 o2; o2.x = acc[cb][0][r]; o2.y = acc[cb][1][r];
+        *reinterpret_cast<d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
+      }
+    __syncthreads();      // the solve's LDS blocks are overwritten by the next contraction's first slab
+  }
+}
+
 // ---- alpha_j = sum_{k >= j} Z(j,k) beta_k --------------------------------------------------------
 __global__ __launch_bounds__(256) void k_alpha(GradArgs a) {
   __shared__ double part[256];
