@@ -98,6 +98,11 @@ constexpr int U_MAX_CP = (U_MAIN_DOUBLES - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_O
 #define AGP_XCD_PIN 1
 #endif
 constexpr bool XCD_PIN = AGP_XCD_PIN != 0;     // 1: all tiles of a particle on one XCD; 0: spread over the 8 XCDs
+// Timing diagnostics only (results are wrong): bit 0 skip the in-register solve arithmetic, bit 1 skip the
+// diagonal-tile factorisation loop, bit 2 skip the GEMM loop, bit 3 skip the solve's staging + flag wait too.
+#ifndef AGP_DBG_SKIP
+#define AGP_DBG_SKIP 0
+#endif
 #ifndef AGP_A_DIRECT
 #define AGP_A_DIRECT 1
 #endif
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   double rv = 0.0;
   if (is_diag && tid < NB) rv = vecp[tk * NB + tid];
 
-  const int nslab = jmax * (NB / KB);
+  const int nslab = (AGP_DBG_SKIP & 4) ? 0 : jmax * (NB / KB);
   if (nslab > 0) {
     // column operand: 256 threads stage the 16 KiB slab of tile (k,j), 4 x 16 B each (element 2*(tid+256u));
     // row operand: each lane fetches its own two rows of tile (i,j) for k-step kk at column 4kk + lq
@@ -342,6 +347,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 
   if (!is_diag) {
     // =====================  off-diagonal tile: L(i,k) = C(i,k) L(k,k)^-T in registers  =====================
+    if (!(AGP_DBG_SKIP & 8)) {
     if (tid == 0) {
       const int want = a.k + 1;
       int spins = 0;
@@ -366,9 +372,15 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       for (int u = 0; u < NSB; ++u) sm[(T_NBLK + u) * 256 + tid] = -Wg[u * 256 + tid];
     }
     __syncthreads();
+    }
     // With acc = -C:  t = acc_jb + sum_lb L(jb,lb) X_lb = -(C_jb - sum L X),  X_jb = (-W_jb) t.
 #pragma unroll
     for (int jb = 0; jb < NSB; ++jb) {
+      if (AGP_DBG_SKIP & 9) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) st_pair(Tt, jb * 16 + 4 * r + lq, row0, row1, acc[jb][0][r], acc[jb][1][r]);
+        continue;
+      }
 #pragma unroll
       for (int lb = 0; lb < jb; ++lb) {
         const double* blk = sm + sblk_idx(jb, lb) * 256;
@@ -415,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 
   int bad = 0;           // first non-positive pivot (1-based global index), 0 = none
 
-  for (int jb = 0; jb < NSB; ++jb) {
+  for (int jb = 0; jb < ((AGP_DBG_SKIP & 2) ? 0 : NSB); ++jb) {
     // ---- (a) wave 0: 16x16 Cholesky of block (jb,jb) + its inverse, on lane broadcasts ----
     if (w == 0) {
       double* blk = sm + blk_idx(jb, jb) * 256;

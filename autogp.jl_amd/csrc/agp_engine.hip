@@ -1417,9 +1417,24 @@ int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t
   const int grid = 8 * ((P + 7) / 8) * ca.tiles;
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  const int Pg8 = 8 * ((P + 7) / 8);
   for (int r = 0; r < reps + 1; ++r) {
     if (r == 1) HIPCHK(c, hipEventRecord(e0, st));
     switch (variant) {
+      case 2000: {   // every block column 1..nt-2 in ONE launch (k is ignored)
+        int blocks = 0;
+        for (int kk = 1; kk < nt - 1; ++kk) blocks += Pg8 * (nt - kk - 1);
+        hipLaunchKernelGGL((k_gemm_strip<16, true, true>), dim3(blocks), dim3(256), 0, st, ca);
+        break;
+      }
+      case 2001: {   // the same tiles, one launch per block column
+        CholArgs cb = ca;
+        for (int kk = 1; kk < nt - 1; ++kk) {
+          cb.k = kk; cb.tiles = nt - kk - 1;
+          hipLaunchKernelGGL((k_gemm_strip<16, true, false>), dim3(Pg8 * cb.tiles), dim3(256), 0, st, cb);
+        }
+        break;
+      }
       case 0: launch_variant<0>(st, grid, ca); break;
       case 1: launch_variant<1>(st, grid, ca); break;
       case 3: launch_variant<3>(st, grid, ca); break;

@@ -190,13 +190,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_variant(CholArgs a) {
 }
 
 // Variant: 32x128 wave strips, row operand global->registers, column operand in LDS with slab depth KBX.
-template <int KBX, bool PRIO>
+// ALL: one launch holds the sub-diagonal tiles of every block column 1..nt-1 (column after column), to measure what
+// the launch boundaries of the one-launch-per-column schedule cost (no dependencies are honoured: timing only).
+template <int KBX, bool PRIO, bool ALL = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_strip(CholArgs a) {
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
   constexpr int SLAB = KBX * LDS_STRIDE;
-  const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
-  const int T = a.tiles, pl = qq / T, tl = qq - pl * T;
-  const int tk = a.k, ti = a.k + 1 + tl, jmax = a.k;
+  int b = blockIdx.x;
+  int kcol = a.k, T = a.tiles;
+  if (ALL) {
+    const int npl8 = 8 * ((a.P + 7) / 8);
+    kcol = 1;
+    while (kcol < a.nt - 1 && b >= npl8 * (a.nt - kcol - 1)) { b -= npl8 * (a.nt - kcol - 1); ++kcol; }
+    T = a.nt - kcol - 1;
+  }
+  const int xcd = b & 7, qq = b >> 3;
+  const int pl = qq / T, tl = qq - pl * T;
+  const int tk = kcol, ti = kcol + 1 + tl, jmax = kcol;
   const int p = pl * 8 + xcd;
   if (p >= a.P) return;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;

@@ -73,7 +73,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    p = Path(path) if path else Path(os.environ.get("AUTOGP_HIP_LIB", LIB_PATH))   # same override as AutoGPHIP.jl
     if not p.exists():
         raise AGPError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
