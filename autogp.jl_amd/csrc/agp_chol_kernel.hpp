@@ -42,6 +42,7 @@ struct CholArgs {
   int k;                // factor mode: block column; Schur mode: unused
   int nt1;              // Schur mode: number of factored block columns
   int tiles;            // factor mode: tiles per particle in this launch (nt-k, or 1 for k = 0)
+  int t0;               // sub-diagonal-only launches (DM = 2): the first of them is tile (k + t0, k)
   // fused covariance evaluation (DCOV > 0): the tile is computed from the particle's program
   const double* tt;     // time points, padded joint layout
   int n1, n1_pad, m2;
@@ -116,18 +117,27 @@ constexpr int T_LDS_DOUBLES = (T_NBLK + NSB) * 256;      // + 8 inverse blocks =
 static_assert(T_LDS_DOUBLES <= U_MAIN_DOUBLES, "solve staging must fit the aliased slab buffers");
 __device__ __forceinline__ int sblk_idx(int jb, int lb) { return jb * (jb - 1) / 2 + lb; }   // lb < jb
 
-// the two strip values of one tile column for this lane (rows rowA and rowB of column `col`)
+// the two strip values of one tile column for this lane (rows rowA and rowB of column `col`); ADJ: rowB = rowA + 1
+template <bool ADJ = ILV>
 __device__ __forceinline__ d2 ld_pair(const double* T, int col, int rowA, int rowB) {
-  if (ILV) return *reinterpret_cast<const d2*>(T + col * NB + rowA);
+  if (ADJ) return *reinterpret_cast<const d2*>(T + col * NB + rowA);
   d2 v; v.x = T[col * NB + rowA]; v.y = T[col * NB + rowB]; return v;
 }
+template <bool ADJ = ILV>
 __device__ __forceinline__ void st_pair(double* T, int col, int rowA, int rowB, double a0, double a1) {
-  if (ILV) { d2 v; v.x = a0; v.y = a1; *reinterpret_cast<d2*>(T + col * NB + rowA) = v; }
+  if (ADJ) { d2 v; v.x = a0; v.y = a1; *reinterpret_cast<d2*>(T + col * NB + rowA) = v; }
   else { T[col * NB + rowA] = a0; T[col * NB + rowB] = a1; }
 }
 
-template <bool FACTOR, int DCOV, bool INTRSM>
+// DM (factor mode with INTRSM): 0 = diagonal and sub-diagonal tiles in one launch (legacy / fallback paths);
+// 1 = diagonal tiles only; 2 = sub-diagonal tiles only.  The diagonal-only instantiation gives wave w the 16-row
+// blocks w and 7-w, so every wave holds the same share (9 of 16) of the lower block triangle and the MFMAs,
+// the evaluations and the row-operand loads of the blocks above the diagonal are skipped (44 % of the tile);
+// its row operand is the column operand (same tile), read from the LDS slab.
+template <bool FACTOR, int DCOV, bool INTRSM, int DM = 0>
 __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
+  static_assert(DM == 0 || (FACTOR && INTRSM), "split launches exist for the in-kernel-solve factorisation only");
+  constexpr bool ADJ = (DM == 1) ? false : ILV;       // strips are adjacent rows
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;
@@ -140,7 +150,15 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   int xcd, qq;
   int T, ti, tk, jmax;
   int pl, tl;
-  if (FACTOR) {
+  if (DM == 1) {
+    T = 1; xcd = b & 7; pl = b >> 3; tl = 0;
+    tk = a.k; ti = a.k; jmax = a.k;
+  } else if (DM == 2) {
+    T = a.tiles;            // sub-diagonal tiles of block column k
+    xcd = b & 7; qq = b >> 3;
+    pl = qq / T; tl = a.t0 + (qq - pl * T);
+    tk = a.k; ti = a.k + tl; jmax = a.k;
+  } else if (FACTOR) {
     // diagonal tiles occupy the first 8*ceil(P/8) blocks of the grid: their serial 128x128
     // factorisation overlaps the bulk of the launch, and (INTRSM) they are resident before any
     // workgroup that waits for them
@@ -173,14 +191,17 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   }
   const int p = pl * 8 + xcd;
   if (p >= a.P) return;
-  const bool is_diag = (ti == tk);
+  const bool is_diag = (DM == 1) ? true : (DM == 2) ? false : (ti == tk);
 
   const int tid = threadIdx.x;
   const int l = tid & 63;
   const int w = tid >> 6;
   const int l15 = l & 15, lq = l >> 4;
-  const int row0 = ILV ? 32 * w + 2 * l15 : 32 * w + l15;   // this lane's row in strip 0
-  const int row1 = ILV ? row0 + 1 : row0 + 16;              // ... and in strip 1
+  const int row0 = (DM == 1) ? 16 * w + l15 : (ILV ? 32 * w + 2 * l15 : 32 * w + l15);   // this lane's row in strip 0
+  const int row1 = (DM == 1) ? 16 * (NSB - 1 - w) + l15 : (ILV ? row0 + 1 : row0 + 16);  // ... and in strip 1
+  // diagonal-only: last column block each strip needs (wave-uniform scalars)
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const int cmax0 = (DM == 1) ? wu : NSB - 1, cmax1 = (DM == 1) ? NSB - 1 - wu : NSB - 1;
 
   double* __restrict__ Ap = a.A + (long long)p * a.strideA;
   double* vecp = a.vec + (long long)p * a.ldv;
@@ -207,9 +228,14 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     __syncthreads();
     cov_prologue(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid);
     const double noise = a.noise[p];
+    if (DM == 1) {
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
+    }
 #pragma unroll 1
     for (int t = 0; t < 16; ++t) {
       const int cb = t >> 1, st = t & 1;
+      if (DM == 1 && cb > (st ? cmax1 : cmax0)) continue;      // block above the diagonal
       const int rslot = st ? row1 : row0;
       double tr[4], tc[4], out[4];
       int ri[4], ci[4];
@@ -254,8 +280,9 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        ra[u] = A_DIRECT ? ld_pair(srcA, 4 * u + lq, row0, row1)
-                         : *reinterpret_cast<const d2*>(srcA + (scol0 + 4 * u) * NB + srow);
+        if (DM != 1)
+          ra[u] = A_DIRECT ? ld_pair<ADJ>(srcA, 4 * u + lq, row0, row1)
+                           : *reinterpret_cast<const d2*>(srcA + (scol0 + 4 * u) * NB + srow);
         rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 4 * u) * NB + srow);
       }
       if (is_diag && tid < KB) rx = vecp[j * NB + cs + tid];
@@ -266,14 +293,15 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb[u];
-        if (!A_DIRECT) *reinterpret_cast<d2*>(As + (scol0 + 4 * u) * LDS_STRIDE + srow) = ra[u];
+        if (!A_DIRECT && DM != 1) *reinterpret_cast<d2*>(As + (scol0 + 4 * u) * LDS_STRIDE + srow) = ra[u];
       }
       if (is_diag && tid < KB) xv[buf * 16 + tid] = rx;
     };
 
     gload(0);
     lstore(0);
-    d2 fr[4] = {ra[0], ra[1], ra[2], ra[3]};     // row fragments of the slab being multiplied
+    d2 fr[4];                                    // row fragments of the slab being multiplied
+    if (DM != 1) { fr[0] = ra[0]; fr[1] = ra[1]; fr[2] = ra[2]; fr[3] = ra[3]; }
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
       const int buf = s & 1;
@@ -289,13 +317,14 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 #pragma unroll
         for (int cb = 0; cb < NSB; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];     // columns of C: tile (k,j)
         d2 fb;                                                                   // rows of C: tile (i,j)
-        if (A_DIRECT) fb = fr[kk];
+        if (DM == 1) { fb.x = Bs[krow + row0]; fb.y = Bs[krow + row1]; }         // tile (k,j) is both operands
+        else if (A_DIRECT) fb = fr[kk];
         else if (ILV) fb = *reinterpret_cast<const d2*>(As + krow + row0);
         else { fb.x = As[krow + row0]; fb.y = As[krow + row1]; }
 #pragma unroll
         for (int cb = 0; cb < NSB; ++cb) {
-          acc[cb][0] = mfma(fa[cb], fb.x, acc[cb][0]);
-          acc[cb][1] = mfma(fa[cb], fb.y, acc[cb][1]);
+          if (DM != 1 || cb <= cmax0) acc[cb][0] = mfma(fa[cb], fb.x, acc[cb][0]);
+          if (DM != 1 || cb <= cmax1) acc[cb][1] = mfma(fa[cb], fb.y, acc[cb][1]);
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -307,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       }
       if (s + 1 < nslab) {
         lstore(buf ^ 1);
-        if (A_DIRECT) {
+        if (A_DIRECT && DM != 1) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) fr[u] = ra[u];
         }
@@ -323,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     for (int cb = 0; cb < NSB; ++cb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const d2 t2 = ld_pair(Tt, cb * 16 + 4 * r + lq, row0, row1);
+        const d2 t2 = ld_pair<ADJ>(Tt, cb * 16 + 4 * r + lq, row0, row1);
         acc[cb][0][r] -= t2.x;
         acc[cb][1][r] -= t2.y;
       }
@@ -337,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     for (int cb = 0; cb < NSB; ++cb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        st_pair(Tt, cb * 16 + 4 * r + lq, row0, row1, -acc[cb][0][r], -acc[cb][1][r]);
+        st_pair<ADJ>(Tt, cb * 16 + 4 * r + lq, row0, row1, -acc[cb][0][r], -acc[cb][1][r]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -361,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     // stage +L(k,k) strictly-lower blocks and -W blocks in A-operand order (fragment s of lane l at 64 s + l)
     {
       const double* __restrict__ Lkk = Ap + tile_off(a.k, a.k);
-      const double* __restrict__ Wg = a.W + ((long long)p * a.wsteps + (a.wsteps > 1 ? a.k : 0)) * NSB * 256;
+      const double* __restrict__ Wg = a.W + ((long long)p * a.wsteps + a.k % a.wsteps) * NSB * 256;
       const int c = tid >> 4, r = tid & 15;
 #pragma unroll
       for (int jb = 1; jb < NSB; ++jb)
@@ -454,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
         wv[r] = t * rinvs[r];
       }
       if (l < 16) {
-        double* Wg = a.W + (((long long)p * a.wsteps + (a.wsteps > 1 ? a.k : 0)) * NSB + jb) * 256;
+        double* Wg = a.W + (((long long)p * a.wsteps + a.k % a.wsteps) * NSB + jb) * 256;
 #pragma unroll
         for (int c = 0; c < 16; ++c) blk[c * 16 + l] = (c <= l) ? s[c] : 0.0;
 #pragma unroll
@@ -580,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_trsm(CholArgs a) {
   double* __restrict__ Ap = a.A + (long long)p * a.strideA;
   const double* __restrict__ Lkk = Ap + tile_off(a.k, a.k);
   double* __restrict__ Tt = Ap + tile_off(ti, a.k);
-  const double* __restrict__ Wg = a.W + ((long long)p * a.wsteps + (a.wsteps > 1 ? a.k : 0)) * NSB * 256;
+  const double* __restrict__ Wg = a.W + ((long long)p * a.wsteps + a.k % a.wsteps) * NSB * 256;
 
   // ---- stage -L(k,k) blocks and W blocks ----
   {

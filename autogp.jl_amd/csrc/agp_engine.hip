@@ -103,6 +103,7 @@ struct agp_ctx {
   int dedup = 1;        // evaluate identical particles of a host-output sweep once; env AGP_DEDUP
   int64_t n_particles_seen = 0, n_particles_run = 0;
   int trtri_chain = 1;  // Z = L^-T as independent per-row chains in one launch (0: one launch per block column); env AGP_TRTRI_CHAIN
+  int split_diag = -1;  // diagonal tiles in their own specialised launch: -1 auto (when they fill the GPU), 0, 1; env AGP_SPLIT_DIAG
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
@@ -415,11 +416,11 @@ hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int 
 
 // DCOV selection: 0 = tiles are resident (agp_debug_cholesky / unfused fallback), 4 / 8 = evaluate the
 // kernel program in the update kernel with that evaluation-stack depth.
-template <bool FACTOR, bool INTRSM>
+template <bool FACTOR, bool INTRSM, int DM = 0>
 void launch_update(int dcov, int grid, hipStream_t st, const CholArgs& ca) {
-  if (dcov == 0) hipLaunchKernelGGL((k_chol_update<FACTOR, 0, INTRSM>), dim3(grid), dim3(256), 0, st, ca);
-  else if (dcov <= 4) hipLaunchKernelGGL((k_chol_update<FACTOR, 4, INTRSM>), dim3(grid), dim3(256), 0, st, ca);
-  else hipLaunchKernelGGL((k_chol_update<FACTOR, 8, INTRSM>), dim3(grid), dim3(256), 0, st, ca);
+  if (dcov == 0) hipLaunchKernelGGL((k_chol_update<FACTOR, 0, INTRSM, DM>), dim3(grid), dim3(256), 0, st, ca);
+  else if (dcov <= 4) hipLaunchKernelGGL((k_chol_update<FACTOR, 4, INTRSM, DM>), dim3(grid), dim3(256), 0, st, ca);
+  else hipLaunchKernelGGL((k_chol_update<FACTOR, 8, INTRSM, DM>), dim3(grid), dim3(256), 0, st, ca);
 }
 
 inline void set_cov(CholArgs& ca, const CovArgs& cv) {
@@ -461,12 +462,32 @@ struct Prof {
 // Factor block columns [0, nfac) of the joint (nt x nt tiles) matrices of ca.P particles.
 // intrsm: one launch per block column (the panel solve runs inside k_chol_update behind the
 // per-particle ready word); otherwise update + k_chol_trsm launches.
-hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intrsm, Prof* pf, double* counts) {
+hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intrsm, Prof* pf, double* counts,
+                      bool split_diag = false) {
   // (profiling marks are recorded on the stream the kernels are launched on)
   if (ca.wsteps < 1) ca.wsteps = 1;
   const int Pg = (ca.P + 7) / 8;
   for (int k = 0; k < nfac; ++k) {
     ca.k = k;
+    if (intrsm && split_diag) {
+      ca.t0 = 1;
+      // diagonal tiles in their own (specialised, lower-triangle-only) launch, then the sub-diagonal tiles, which
+      // wait on the per-particle ready word only formally: stream order has already completed the diagonal launch
+      size_t e0 = pf ? pf->mark(st) : 0;
+      ca.tiles = 1;
+      launch_update<true, true, 1>(dcov, 8 * Pg, st, ca);
+      size_t e1 = pf ? pf->mark(st) : 0;
+      if (pf) pf->span(3, e0, e1);
+      if (counts) counts[1] += 1;
+      ca.tiles = ca.nt - k - 1;
+      if (ca.tiles > 0) {
+        launch_update<true, true, 2>(dcov, 8 * Pg * ca.tiles, st, ca);
+        size_t e2 = pf ? pf->mark(st) : 0;
+        if (pf) pf->span(2, e1, e2);
+        if (counts) counts[0] += 1;
+      }
+      continue;
+    }
     if (intrsm) {
       ca.tiles = ca.nt - k;
       size_t e0 = pf ? pf->mark(st) : 0;
@@ -496,6 +517,13 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intr
     }
   }
   return hipGetLastError();
+}
+
+// The specialised diagonal-tile launch pays off when the diagonal tiles alone fill the GPU (two workgroups per
+// CU); with fewer particles the mixed launch lets sub-diagonal tiles run beside the diagonal factorisations.
+constexpr int SPLIT_DIAG_MIN_PARTICLES = 256;
+inline bool use_split_diag(const agp_ctx* c, int P) {
+  return c->split_diag > 0 || (c->split_diag < 0 && P >= SPLIT_DIAG_MIN_PARTICLES);
 }
 
 struct GradOut {
@@ -679,7 +707,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         set_cov(ca, cv);
         ca.n_fused = nf;
         ca.ready = s->ready.as<int>() + g0;
-        HIPCHK(c, run_factor(q, ca, nt, dcov, intrsm, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr));
+        HIPCHK(c, run_factor(q, ca, nt, dcov, intrsm, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr, use_split_diag(c, ca.P)));
 
         size_t e2 = pf.mark(q);
         hipLaunchKernelGGL(k_finish_logpdf, dim3((Pg + 63) / 64), dim3(64), 0, q, ca.partial, ca.info, nt, Pg, (int)n,
@@ -803,6 +831,7 @@ int agp_init(agp_ctx** out, int device_id) {
   c->total_mem = free_b ? free_b : tot_b;
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
   if (const char* e = getenv("AGP_TRTRI_CHAIN")) c->trtri_chain = atoi(e) != 0;
+  if (const char* e = getenv("AGP_SPLIT_DIAG")) c->split_diag = atoi(e);
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
   if (const char* e = getenv("AGP_FUSE_MAX_US")) c->fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
@@ -1162,7 +1191,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     set_cov(ca, cv);
     ca.n_fused = nf;
     ca.ready = s->ready.as<int>() + p0;
-    HIPCHK(c, run_factor(st, ca, nt1, dcov, intrsm, nullptr, nullptr));
+    HIPCHK(c, run_factor(st, ca, nt1, dcov, intrsm, nullptr, nullptr, use_split_diag(c, ca.P)));
     {
       // Schur complement of the prediction block + (-V^T alpha); with nt1 == 0 this just
       // passes K22 through.
@@ -1361,7 +1390,7 @@ int agp_debug_cholesky(agp_ctx* c, const double* K, int64_t n, double* out_L, in
   ca.ldv = n_pad; ca.partial = s->partial.as<double>(); ca.info = s->info.as<int>(); ca.P = 1; ca.nt = nt;
   ca.k = 0; ca.nt1 = nt;
   ca.tt = nullptr; ca.hdr = nullptr; ca.ops = nullptr; ca.prm = nullptr; ca.noise = nullptr; ca.n1 = ca.n1_pad = ca.m2 = 0; ca.n_fused = 0; ca.ready = s->ready.as<int>();
-  HIPCHK(c, run_factor(st, ca, nt, 0, c->intrsm != 0, nullptr, nullptr));
+  HIPCHK(c, run_factor(st, ca, nt, 0, c->intrsm != 0, nullptr, nullptr, use_split_diag(c, ca.P)));
   hipLaunchKernelGGL(k_unpack_dense, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, s->A.as<double>(),
                      (int)n, 1, s->dense.as<double>());
   HIPCHK(c, hipGetLastError());

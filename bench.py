@@ -44,6 +44,14 @@ def cholesky_flops(n):          # LAPACK convention, SURVEY.md §8(d)
     return n ** 3 / 3.0
 
 
+def subdiag_kernel_flops(n):
+    """Algorithmic flops per particle and sweep of the dominant kernel of the default build,
+    k_chol_update<true,DCOV,true,2>: for every block column k the nt-k-1 sub-diagonal tiles, each a
+    128 x 128 x (128 k) update (2 flops per multiply-add) plus the 128^3 triangular solve against L(k,k)."""
+    nt = (n + NB - 1) // NB
+    return float(sum((nt - k - 1) * (2.0 * NB * NB * (k * NB) + NB ** 3) for k in range(nt)))
+
+
 def update_kernel_flops(n, solve_in_kernel=True):
     """Algorithmic flops of k_chol_update per particle and sweep.  With the panel solve inside the
     kernel (default build) that is the whole n^3/3 of the factorisation; with separate k_chol_trsm
@@ -203,8 +211,17 @@ def main():
         n_upd = max(1.0, acc["n_update_launches"])
         upd_ms = acc["chol_update_ms"] / n_upd                      # average launch duration of k_chol_update
         nt = (n + NB - 1) // NB
-        solve_in_kernel = acc.get("n_trsm_launches", 0.0) == 0.0
-        upd_flops_launch = P * update_kernel_flops(n, solve_in_kernel) / nt           # algorithmic flops per launch
+        # default build: diagonal tiles in their own launch (reported under the "trsm" keys of the engine's
+        # timing), sub-diagonal tiles (update + in-register solve) in the dominant kernel, nt-1 launches per sweep
+        intrsm = os.environ.get("AGP_INTRSM", "1") != "0"
+        split_diag = intrsm and os.environ.get("AGP_SPLIT_DIAG", "1") != "0"
+        solve_in_kernel = intrsm
+        if split_diag:
+            kernel_name = "k_chol_update<true,DCOV,true,2>"
+            upd_flops_launch = P * subdiag_kernel_flops(n) / max(1, nt - 1)
+        else:
+            kernel_name = "k_chol_update<true,DCOV,true,0>" if solve_in_kernel else "k_chol_update<true,DCOV,false,0>"
+            upd_flops_launch = P * update_kernel_flops(n, solve_in_kernel) / nt       # algorithmic flops per launch
         achieved = upd_flops_launch / (upd_ms * 1e-3) / 1e12
         traffic = None
         tf = ROOT / "profiles" / "hbm_traffic.json"
@@ -225,9 +242,10 @@ def main():
                        "not_positive_definite": n_bad, "parallelism": f"particle-shard x{world}",
                        "allgather_selfcheck": gather_ok},
             "cholesky_gflops": evals_s * cholesky_flops(n) / 1e9,
-            "phase_ms_per_step": {k: acc[k] / args.steps for k in ("total_ms", "cov_build_ms", "chol_update_ms", "chol_trsm_ms",
-                                                                    "finish_ms", "h2d_ms")},
-            "roofline": {"kernel": "k_chol_update<true,DCOV,true>" if solve_in_kernel else "k_chol_update<true,DCOV,false>", "bound": "mfma", "achieved": achieved,
+            "phase_ms_per_step": {("chol_diag_tiles_ms" if (split_diag and k == "chol_trsm_ms") else
+                                   "chol_subdiag_tiles_ms" if (split_diag and k == "chol_update_ms") else k): acc[k] / args.steps
+                                  for k in ("total_ms", "cov_build_ms", "chol_update_ms", "chol_trsm_ms", "finish_ms", "h2d_ms")},
+            "roofline": {"kernel": kernel_name, "bound": "mfma", "achieved": achieved,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
                          "traffic": traffic, "avg_launch_ms": upd_ms, "launches_per_step": n_upd / args.steps,
                          "algorithmic_flops_per_launch": upd_flops_launch},

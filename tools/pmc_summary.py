@@ -50,11 +50,12 @@ for name, col in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
 txt = "\n".join(out)
 (ROOT / f"profiles/{tag}_pmc_summary.txt").write_text(txt)
 print(txt)
-upd = [k for k in res if "k_chol_update<true" in k]
+# dominant kernel: the sub-diagonal-tile instantiation (last template argument 2) of the default build
+upd = [k for k in res if "k_chol_update<true" in k and k.rstrip().endswith("2>")] or [k for k in res if "k_chol_update<true" in k]
 if upd and "fetch" in res[upd[0]] and "write" in res[upd[0]]:
     tot = res[upd[0]]["fetch"] + res[upd[0]]["write"]
     (ROOT / "profiles/hbm_traffic.json").write_text(json.dumps({
-        "k_chol_update_bytes_per_launch": tot, "fetch_bytes_corrected_x2": res[upd[0]]["fetch"], "write_bytes": res[upd[0]]["write"],
+        "k_chol_update_bytes_per_launch": tot, "kernel": upd[0], "fetch_bytes_corrected_x2": res[upd[0]]["fetch"], "write_bytes": res[upd[0]]["write"],
         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1`, {tag}; "
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM"}))
     print("hbm bytes/launch", tot / 1e6, "MB")

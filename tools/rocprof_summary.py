@@ -23,18 +23,30 @@ def main():
     for k, v in res.items():
         lines.append(f"{k[:70]:70s} {v}")
     NB = 128; nt = (a.n + NB - 1) // NB; P = a.particles
-    upd = [r for r in rows if "k_chol_update<true" in r[0]]
+    dia = [r for r in rows if "k_chol_update<true" in r[0] and r[0].split("(")[0].rstrip().endswith("1>")]
+    upd = [r for r in rows if "k_chol_update<true" in r[0] and r not in dia]
     trs = [r for r in rows if "k_chol_trsm" in r[0]]
-    if len(upd) >= nt and len(upd) % nt == 0:
-        lines += ["", f"# last sweep, per block column k (P={P}, n={a.n}): update-kernel duration and GEMM TF/s "
-                      f"(2*128^2*(k*128) flop per tile, (nt-k) tiles), trsm duration"]
-        last = upd[-nt:]; lt = trs[-(nt - 1):] if len(trs) >= nt - 1 else []
+    split = len(dia) > 0
+    per = (nt - 1) if split else nt
+    if per > 0 and len(upd) >= per and len(upd) % per == 0:
+        lines += ["", f"# last sweep, per block column k (P={P}, n={a.n}): "
+                      + ("diagonal-tile launch, sub-diagonal-tile launch with its TF/s (2*128^2*(k*128) + 128^3 flop per tile, nt-k-1 tiles)"
+                         if split else "update-kernel duration and GEMM TF/s (2*128^2*(k*128) flop per tile, (nt-k) tiles), trsm duration")]
+        last = upd[-per:]; lt = trs[-(nt - 1):] if len(trs) >= nt - 1 else []
+        ld = dia[-nt:] if split and len(dia) >= nt else []
         for k, r in enumerate(last):
-            fl = P * (nt - k) * 2 * NB * NB * (k * NB) + P * NB ** 3 / 3
-            s = f"k={k:2d} grid={r[3] // 256:6d} WGs  update {r[2] / 1e3:9.1f} us  {fl / (r[2] * 1e-9) / 1e12:6.1f} TF/s"
-            if k < len(lt):
-                s += f"   trsm {lt[k][2] / 1e3:8.1f} us"
+            if split:
+                fl = P * (nt - k - 1) * (2 * NB * NB * (k * NB) + NB ** 3)
+                s = (f"k={k:2d} diag {ld[k][2] / 1e3:8.1f} us   sub-diag grid={r[3] // 256:6d} WGs {r[2] / 1e3:9.1f} us  "
+                     f"{fl / (r[2] * 1e-9) / 1e12:6.1f} TF/s") if ld else f"k={k:2d} sub-diag {r[2] / 1e3:9.1f} us"
+            else:
+                fl = P * (nt - k) * 2 * NB * NB * (k * NB) + P * NB ** 3 / 3
+                s = f"k={k:2d} grid={r[3] // 256:6d} WGs  update {r[2] / 1e3:9.1f} us  {fl / (r[2] * 1e-9) / 1e12:6.1f} TF/s"
+                if k < len(lt):
+                    s += f"   trsm {lt[k][2] / 1e3:8.1f} us"
             lines.append(s)
+        if split and len(ld) == nt:
+            lines.append(f"k={nt - 1:2d} diag {ld[nt - 1][2] / 1e3:8.1f} us")
     open(a.out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
