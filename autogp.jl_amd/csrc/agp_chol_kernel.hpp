@@ -73,7 +73,7 @@ constexpr int U_GEMM_DOUBLES = 4 * U_SLAB;             // As[2], Bs[2]      = 92
 constexpr int U_BLK_DOUBLES = (NSB * (NSB + 1) / 2) * 256;  // 36 blocks   = 9216
 constexpr int U_MAIN_DOUBLES = (U_GEMM_DOUBLES > U_BLK_DOUBLES) ? U_GEMM_DOUBLES : U_BLK_DOUBLES;
 // extras: rvec[128], avec[128] (alpha_k), xv[2][16] (alpha_j slab staging), Wl[256]
-constexpr int U_EXTRA_DOUBLES = 128 + 128 + 32 + 256;
+constexpr int U_EXTRA_DOUBLES = 128 + 128 + 64 + 256;
 constexpr int U_LDS_BYTES = (U_MAIN_DOUBLES + U_EXTRA_DOUBLES) * 8;
 
 __device__ __forceinline__ int blk_idx(int rb, int cb) { return rb * (rb + 1) / 2 + cb; }
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;
-  double* xv = avec + 128;     // [2][16]
-  double* Wl = xv + 32;        // [256]
+  double* xv = avec + 128;     // [2][slab depth <= 32]
+  double* Wl = xv + 64;        // [256]
 
   // ---- XCD-aware block -> (particle, tile) map: block b runs on XCD b%8; all tiles of one
   //      particle go to the same XCD so the shared L(k,j) panel stays in that XCD's L2. ----
@@ -266,52 +266,62 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   double rv = 0.0;
   if (is_diag && tid < NB) rv = vecp[tk * NB + tid];
 
-  const int nslab = (AGP_DBG_SKIP & 4) ? 0 : jmax * (NB / KB);
+  // slab depth: 16 columns of the operand tiles per barrier; the diagonal-only kernel (fewer MFMAs per slab, no
+  // row-operand registers) takes 32, which doubles the work and the prefetch distance per barrier
+  constexpr int KS = (DM == 1) ? 2 * KB : KB;
+  constexpr int NU = KS / 4;                         // 16-byte loads per thread and slab
+  constexpr int SLABS_PER_TILE = NB / KS;
+  constexpr int SLAB_DOUBLES = KS * LDS_STRIDE;
+  static_assert(2 * SLAB_DOUBLES <= U_MAIN_DOUBLES && (DM == 1 || 4 * SLAB_DOUBLES <= U_MAIN_DOUBLES), "slab buffers");
+  const int nslab = (AGP_DBG_SKIP & 4) ? 0 : jmax * SLABS_PER_TILE;
   if (nslab > 0) {
-    // column operand: 256 threads stage the 16 KiB slab of tile (k,j), 4 x 16 B each (element 2*(tid+256u));
+    // column operand: 256 threads stage the slab of tile (k,j), NU x 16 B each (element 2*(tid+256u));
     // row operand: each lane fetches its own two rows of tile (i,j) for k-step kk at column 4kk + lq
     const int scol0 = tid >> 6;        // + 4u
     const int srow = 2 * (tid & 63);
-    d2 ra[4], rb[4];
+    d2 ra[NU], rb[NU];
     double rx = 0.0;
     auto gload = [&](int s) {
-      const int j = s >> 3, cs = (s & 7) * KB;
+      const int j = s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
       const double* __restrict__ srcA = Ap + tile_off(ti, j) + (long long)cs * NB;
       const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NU; ++u) {
         if (DM != 1)
           ra[u] = A_DIRECT ? ld_pair<ADJ>(srcA, 4 * u + lq, row0, row1)
                            : *reinterpret_cast<const d2*>(srcA + (scol0 + 4 * u) * NB + srow);
         rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 4 * u) * NB + srow);
       }
-      if (is_diag && tid < KB) rx = vecp[j * NB + cs + tid];
+      if (is_diag && tid < KS) rx = vecp[j * NB + cs + tid];
     };
     auto lstore = [&](int buf) {
-      double* Bs = sm + buf * U_SLAB;
-      double* As = sm + (2 + buf) * U_SLAB;
+      double* Bs = sm + buf * SLAB_DOUBLES;
+      double* As = sm + (2 + buf) * SLAB_DOUBLES;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NU; ++u) {
         *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb[u];
         if (!A_DIRECT && DM != 1) *reinterpret_cast<d2*>(As + (scol0 + 4 * u) * LDS_STRIDE + srow) = ra[u];
       }
-      if (is_diag && tid < KB) xv[buf * 16 + tid] = rx;
+      if (is_diag && tid < KS) xv[buf * KS + tid] = rx;
     };
 
     gload(0);
     lstore(0);
-    d2 fr[4];                                    // row fragments of the slab being multiplied
-    if (DM != 1) { fr[0] = ra[0]; fr[1] = ra[1]; fr[2] = ra[2]; fr[3] = ra[3]; }
+    d2 fr[NU];                                   // row fragments of the slab being multiplied
+    if (DM != 1) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) fr[u] = ra[u];
+    }
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
       const int buf = s & 1;
       if (s + 1 < nslab) gload(s + 1);
-      const double* Bs = sm + buf * U_SLAB;
-      const double* As = sm + (2 + buf) * U_SLAB;
+      const double* Bs = sm + buf * SLAB_DOUBLES;
+      const double* As = sm + (2 + buf) * SLAB_DOUBLES;
       // waves inside their MFMA block outrank the co-resident workgroup's load/store/barrier phase
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int kk = 0; kk < KB / 4; ++kk) {
+      for (int kk = 0; kk < KS / 4; ++kk) {
         const int krow = (kk * 4 + lq) * LDS_STRIDE;
         double fa[NSB];
 #pragma unroll
@@ -330,15 +340,15 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       __builtin_amdgcn_s_setprio(0);
       if (is_diag && tid < NB) {
         // r -= L(k,j)[:, slab] * alpha_j[slab]
-        const double* xs_ = xv + buf * 16;
+        const double* xs_ = xv + buf * KS;
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) rv = fma(-Bs[kk * LDS_STRIDE + tid], xs_[kk], rv);
+        for (int kk = 0; kk < KS; ++kk) rv = fma(-Bs[kk * LDS_STRIDE + tid], xs_[kk], rv);
       }
       if (s + 1 < nslab) {
         lstore(buf ^ 1);
         if (A_DIRECT && DM != 1) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) fr[u] = ra[u];
+          for (int u = 0; u < NU; ++u) fr[u] = ra[u];
         }
       }
       __syncthreads();

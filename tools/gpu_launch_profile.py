@@ -22,12 +22,19 @@ for name, (nodes, noises) in pops.items():
     progs = pkg.encode_batch(nodes)
     for _ in range(2): eng.logpdf_batch(None, noises, check=False, programs=progs)
     eng.set_profiling(True); eng.logpdf_batch(None, noises, check=False, programs=progs); tm = eng.timing(); eng.set_profiling(False)
-    u = eng.launch_times(0)
-    tot = sum(u)
-    print(f"{name}: cov={tm['cov_build_ms']:.2f} ms upd={tm['chol_update_ms']:.2f} ms")
-    for k in range(len(u)):
-        fl = P * (nt - k) * 2 * 128 * 128 * (k * 128)          # GEMM
-        fl += P * (nt - k - 1) * 128 * 128 * 128 + P * 128 ** 3 / 3   # solve + potrf
-        ideal = fl / 78.6e12 * 1e6
-        print(f"   k={k:2d} {u[k]*1e3:8.1f} us   ideal {ideal:7.1f} us  eff {ideal/(u[k]*1e3):.2f}  lost {u[k]*1e3-ideal:6.1f} us")
-    print(f"   total {tot:.2f} ms")
+    u = eng.launch_times(0); d = eng.launch_times(1)
+    split = len(d) == nt and len(u) == nt - 1        # diagonal tiles in their own launches (default for P >= 256)
+    print(f"{name}: cov={tm['cov_build_ms']:.2f} ms sub-diag/update={tm['chol_update_ms']:.2f} ms diag={tm['chol_trsm_ms']:.2f} ms split={split}")
+    for k in range(nt):
+        if split:
+            fo = P * (nt - k - 1) * (2 * 128 * 128 * (k * 128) + 128 ** 3)
+            fd = P * (128 * 136 * (k * 128) + 128 ** 3 / 3)      # lower triangle incl. diagonal blocks (9/16 of the tile is computed)
+            io, idg = fo / 78.6e12 * 1e6, fd / 78.6e12 * 1e6
+            uo = u[k] * 1e3 if k < nt - 1 else 0.0
+            print(f"   k={k:2d} diag {d[k]*1e3:7.1f} us (ideal {idg:6.1f})   sub-diag {uo:8.1f} us (ideal {io:7.1f}, eff {io/uo if uo else 0:.2f})")
+        else:
+            fl = P * (nt - k) * 2 * 128 * 128 * (k * 128)          # GEMM
+            fl += P * (nt - k - 1) * 128 * 128 * 128 + P * 128 ** 3 / 3   # solve + potrf
+            ideal = fl / 78.6e12 * 1e6
+            print(f"   k={k:2d} {u[k]*1e3:8.1f} us   ideal {ideal:7.1f} us  eff {ideal/(u[k]*1e3):.2f}  lost {u[k]*1e3-ideal:6.1f} us")
+    print(f"   total {sum(u) + (sum(d) if split else 0):.2f} ms")
