@@ -29,9 +29,9 @@ if "sq" in tabs:
     t = tabs["sq"]; t = t[t.kernel.str.contains("agp::")]
     g = t.groupby("kernel").sum(numeric_only=True)
     d = pd.DataFrame(index=g.index)
-    d["clock_GHz"] = g["GRBM_GUI_ACTIVE"] / (g["dur_us"] * 1e3)
-    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs... normalise per (CU*4 SIMD) active cycle
-    d["mfma_busy_frac"] = g["SQ_VALU_MFMA_BUSY_CYCLES"] / (g["GRBM_GUI_ACTIVE"] * 256 * 4)
+    # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs
+    d["clock_GHz"] = g["GRBM_GUI_ACTIVE"] / 8 / (g["dur_us"] * 1e3)
+    d["mfma_busy_frac"] = g["SQ_VALU_MFMA_BUSY_CYCLES"] / (g["GRBM_GUI_ACTIVE"] / 8 * 256 * 4)
     d["wait_any/wave_cycles"] = g["SQ_WAIT_ANY"] / g["SQ_WAVE_CYCLES"]
     d["wait_inst/wave_cycles"] = g["SQ_WAIT_INST_ANY"] / g["SQ_WAVE_CYCLES"]
     d["active_inst/wave_cycles"] = g["SQ_ACTIVE_INST_ANY"] / g["SQ_WAVE_CYCLES"]
