@@ -387,7 +387,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   if (!is_diag) {
     // =====================  off-diagonal tile: L(i,k) = C(i,k) L(k,k)^-T in registers  =====================
     if (!(AGP_DBG_SKIP & 8)) {
-    if (tid == 0) {
+    // (the sub-diagonal-only launch follows the diagonal launch of its column in stream order: nothing to wait for)
+    if (DM != 2 && tid == 0) {
       const int want = a.k + 1;
       int spins = 0;
       while (__hip_atomic_load(a.ready + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    __syncthreads();
+    if (DM != 2) __syncthreads();      // (evaluation and GEMM phases both end on a barrier: the LDS region is free)
     // stage +L(k,k) strictly-lower blocks and -W blocks in A-operand order (fragment s of lane l at 64 s + l)
     {
       const double* __restrict__ Lkk = Ap + tile_off(a.k, a.k);

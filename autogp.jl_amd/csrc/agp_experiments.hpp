@@ -192,7 +192,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_variant(CholArgs a) {
 // Variant: 32x128 wave strips, row operand global->registers, column operand in LDS with slab depth KBX.
 // ALL: one launch holds the sub-diagonal tiles of every block column 1..nt-1 (column after column), to measure what
 // the launch boundaries of the one-launch-per-column schedule cost (no dependencies are honoured: timing only).
-template <int KBX, bool PRIO, bool ALL = false>
+// PF2: operands of slab s+2 are requested while slab s is multiplied (two register sets), i.e. twice the
+// prefetch distance of the production loop.
+template <int KBX, bool PRIO, bool ALL = false, bool PF2 = false>
 __global__ __launch_bounds__(256, 2) void k_gemm_strip(CholArgs a) {
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
   constexpr int SLAB = KBX * LDS_STRIDE;
@@ -235,6 +237,68 @@ __global__ __launch_bounds__(256, 2) void k_gemm_strip(CholArgs a) {
 #pragma unroll
     for (int u = 0; u < NU; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb[u];
   };
+  if (PF2) {
+    // register sets: (ra, rb) and (ra2, rb2) alternate; slab s+1 sits in one set while s+2 is loaded into the other
+    d2 ra2[NU], rb2[NU];
+    auto gload2 = [&](int s) {
+      const int per = NB / KBX;
+      const int j = s / per, cs = (s % per) * KBX;
+      const double* __restrict__ srcA = Ap + tile_off(ti, j) + (long long)cs * NB;
+      const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        ra2[u] = *reinterpret_cast<const d2*>(srcA + (4 * u + lq) * NB + row0);
+        rb2[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 4 * u) * NB + srow);
+      }
+    };
+    auto lstore2 = [&](int buf) {
+      double* Bs = sm + buf * SLAB;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb2[u];
+    };
+    auto mma = [&](int buf) {
+      const double* Bs = sm + buf * SLAB;
+      if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < KBX / 4; ++kk) {
+        const int krow = (kk * 4 + lq) * LDS_STRIDE;
+        double fa[NSB];
+#pragma unroll
+        for (int cb = 0; cb < NSB; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];
+#pragma unroll
+        for (int cb = 0; cb < NSB; ++cb) {
+          acc[cb][0] = mfma(fa[cb], fr[kk].x, acc[cb][0]);
+          acc[cb][1] = mfma(fa[cb], fr[kk].y, acc[cb][1]);
+        }
+      }
+      if (PRIO) __builtin_amdgcn_s_setprio(0);
+    };
+    gload(0); lstore(0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) fr[u] = ra[u];
+    if (nslab > 1) gload2(1);
+    __syncthreads();
+    for (int s = 0; s < nslab; s += 2) {      // nslab is a multiple of 8
+      if (s + 2 < nslab) gload(s + 2);
+      mma(0);
+      if (s + 1 < nslab) {
+        lstore2(1);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) fr[u] = ra2[u];
+      }
+      __syncthreads();
+      if (s + 1 < nslab) {
+        if (s + 3 < nslab) gload2(s + 3);
+        mma(1);
+        if (s + 2 < nslab) {
+          lstore(0);
+#pragma unroll
+          for (int u = 0; u < NU; ++u) fr[u] = ra[u];
+        }
+        __syncthreads();
+      }
+    }
+  } else {
   gload(0); lstore(0);
 #pragma unroll
   for (int u = 0; u < NU; ++u) fr[u] = ra[u];
@@ -263,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_strip(CholArgs a) {
       for (int u = 0; u < NU; ++u) fr[u] = ra[u];
     }
     __syncthreads();
+  }
   }
   double* __restrict__ Tt = Ap + tile_off(ti, tk);
 #pragma unroll
