@@ -100,7 +100,8 @@ constexpr int U_MAX_CP = (U_MAIN_DOUBLES - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_O
 #endif
 constexpr bool XCD_PIN = AGP_XCD_PIN != 0;     // 1: all tiles of a particle on one XCD; 0: spread over the 8 XCDs
 // Timing diagnostics only (results are wrong): bit 0 skip the in-register solve arithmetic, bit 1 skip the
-// diagonal-tile factorisation loop, bit 2 skip the GEMM loop, bit 3 skip the solve's staging + flag wait too.
+// diagonal-tile factorisation loop, bit 2 skip the GEMM loop, bit 3 skip the solve's staging + flag wait too,
+// bits 4 / 5 / 6 skip the factorisation's 16x16 diagonal step / panel step / trailing update.
 #ifndef AGP_DBG_SKIP
 #define AGP_DBG_SKIP 0
 #endif
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 
   for (int jb = 0; jb < ((AGP_DBG_SKIP & 2) ? 0 : NSB); ++jb) {
     // ---- (a) wave 0: 16x16 Cholesky of block (jb,jb) + its inverse, on lane broadcasts ----
-    if (w == 0) {
+    if (w == 0 && !(AGP_DBG_SKIP & 16)) {
       double* blk = sm + blk_idx(jb, jb) * 256;
       double s[16], rinvs[16], wv[16];
 #pragma unroll
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     __syncthreads();
 
     // ---- (b) panel: L(ib,jb) = S(ib,jb) W^T for ib > jb (MFMA); alpha_jb = W r_jb ----
-    for (int ib = jb + 1 + w; ib < NSB; ib += 4) {
+    for (int ib = jb + 1 + w; ib < ((AGP_DBG_SKIP & 32) ? 0 : NSB); ib += 4) {
       double* blk = sm + blk_idx(ib, jb) * 256;
       double fw[4], fs[4];
 #pragma unroll
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     {
       const int nrem = NSB - 1 - jb;              // block rows below jb
       const int npair = nrem * (nrem + 1) / 2;
-      for (int e = w; e < npair; e += 4) {
+      for (int e = w; e < ((AGP_DBG_SKIP & 64) ? 0 : npair); e += 4) {
         int ii = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while (ii * (ii + 1) / 2 > e) --ii;
         while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;

@@ -168,6 +168,26 @@ def test_logpdf_batch_vs_oracle(pkg, engine, n, P, max_depth):
     assert one == lp[0]
 
 
+@pytest.mark.parametrize("n,P", [(300, 300), (521, 263), (1000, 257)])
+def test_large_population_path_vs_oracle(pkg, engine, n, P):
+    """Populations of >= 256 particles take the path the benchmark measures: cost-sorted particles, covariance
+    tiles evaluated inside the factorisation kernel (expensive trees prebuilt), diagonal tiles in their own
+    lower-triangle-only launch, sub-diagonal tiles with the in-register solve.  Every particle is checked
+    against the oracle; P is not a multiple of 8 and n not a multiple of the tile."""
+    ts, xs = pkg.prior.synthetic_series(n, seed=n + 1, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(n), P, max_depth=4, max_size=31)
+    engine.set_data(ts, xs)
+    lp, info = engine.logpdf_batch(nodes, noises, check=False)
+    ok = info == 0
+    assert ok.sum() >= P - 3
+    ref = np.array([O.gp_logpdf(nd.to_tuple(), float(nz), ts, xs) if g else np.nan for nd, nz, g in zip(nodes, noises, ok)])
+    assert lp_err(lp[ok], ref[ok]).max() <= LP_TOL
+    # the same particles in small batches (mixed kernel, prebuilt tiles) agree to rounding
+    sub = np.flatnonzero(ok)[:16]
+    lp_small, _ = engine.logpdf_batch([nodes[i] for i in sub], noises[sub], check=False)
+    assert lp_err(lp_small, lp[sub]).max() <= 1e-11
+
+
 def test_config1_se_plus_linear(pkg, engine):
     """BASELINE config 1: n=256, 8 particles, fixed SE+Linear kernel."""
     G = pkg
