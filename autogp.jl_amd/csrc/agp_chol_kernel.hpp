@@ -51,6 +51,7 @@ struct CholArgs {
   const double* prm;
   const double* noise;
   const uint8_t* code;  // per-point component codes (infer_gp_sum) or null
+  const double* logdt;  // log|dt| table of the resident data (see CovArgs)
   int n_fused;          // particles [0, n_fused) evaluate their tiles; the rest have them prebuilt in A
   int* ready;           // [P] block columns whose L(k,k) is published (in-kernel solve); zeroed per sweep
   int wsteps;           // 1: W holds the current step's inverses only; nt: W keeps every step (gradient path)
@@ -135,8 +136,9 @@ __device__ __forceinline__ void st_pair(double* T, int col, int rowA, int rowB, 
 // blocks w and 7-w, so every wave holds the same share (9 of 16) of the lower block triangle and the MFMAs,
 // the evaluations and the row-operand loads of the blocks above the diagonal are skipped (44 % of the tile);
 // its row operand is the column operand (same tile), read from the LDS slab.
-template <bool FACTOR, int DCOV, bool INTRSM, int DM = 0>
+template <bool FACTOR, int DCOV, bool INTRSM, int DM = 0, bool TAB = false>
 __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
+  static_assert(!TAB || DCOV > 0, "the log|dt| table only matters to instantiations that evaluate tiles");
   static_assert(DM == 0 || (FACTOR && INTRSM), "split launches exist for the in-kernel-solve factorisation only");
   constexpr bool ADJ = (DM == 1) ? false : ILV;       // strips are adjacent rows
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
@@ -233,20 +235,29 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 #pragma unroll
       for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
     }
+    // GammaExp leaves read log|dt| from the data set's table (L2 / Infinity-Cache resident: every particle reads
+    // the same 128 KiB tile); the loads are issued at the top of the pass and consumed by the first such leaf
+    const bool use_tab = TAB && (h.flags & 1) != 0;
+    const double* __restrict__ ltile = a.logdt + tile_off(ti, tk);      // only dereferenced when use_tab
 #pragma unroll 1
     for (int t = 0; t < 16; ++t) {
       const int cb = t >> 1, st = t & 1;
       if (DM == 1 && cb > (st ? cmax1 : cmax0)) continue;      // block above the diagonal
       const int rslot = st ? row1 : row0;
       double tr[4], tc[4], out[4];
+      double lt[4] = {0.0, 0.0, 0.0, 0.0};
       int ri[4], ci[4];
+      if (use_tab) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lt[r] = ltile[(cb * 16 + 4 * r + lq) * NB + rslot];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int cslot = cb * 16 + 4 * r + lq;
         tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
         ri[r] = rslot; ci[r] = NB + cslot;
       }
-      eval_program<(DCOV > 0 ? DCOV : 4), 4>(h, ops, prm, sig, tr, tc, ri, ci, out);
+      eval_program<(DCOV > 0 ? DCOV : 4), 4, (TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out);
       d4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -388,8 +399,10 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   if (!is_diag) {
     // =====================  off-diagonal tile: L(i,k) = C(i,k) L(k,k)^-T in registers  =====================
     if (!(AGP_DBG_SKIP & 8)) {
-    // (the sub-diagonal-only launch follows the diagonal launch of its column in stream order: nothing to wait for)
-    if (DM != 2 && tid == 0) {
+    // (for the sub-diagonal-only launch the word is already set — the diagonal launch precedes it in stream order —
+    // but the poll stays: its branch + acquire also keep the staging loads below from being hoisted into the GEMM
+    // epilogue, which costs 30 VGPRs and spills)
+    if (tid == 0) {
       const int want = a.k + 1;
       int spins = 0;
       while (__hip_atomic_load(a.ready + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -398,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
-    if (DM != 2) __syncthreads();      // (evaluation and GEMM phases both end on a barrier: the LDS region is free)
+    __syncthreads();
     // stage +L(k,k) strictly-lower blocks and -W blocks in A-operand order (fragment s of lane l at 64 s + l)
     {
       const double* __restrict__ Lkk = Ap + tile_off(a.k, a.k);

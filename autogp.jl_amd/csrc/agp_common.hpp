@@ -24,8 +24,11 @@ constexpr int LDS_STRIDE = 144;  // 128 + 16 doubles: k-rows 32 banks apart -> c
 // bounds the evaluation stack by the tree's Strahler number).
 // 10 is internal to infer_gp_sum: a component selector leaf, value s(a) s(b) with s(x) = 1 when point x is
 // an observable (code 0) or the latent of that component (code == id), else 0.
+// 11 is GammaExponential evaluated from the data set's log|t_i - t_j| table (agp_set_data builds it once; every
+// particle's GammaExp leaves share it): (|dt|/l)^gamma = exp(gamma (log|dt| - log l)), one exp instead of log + exp.
 enum : int { OP_WN = 0, OP_CONST = 1, OP_LIN = 2, OP_SE = 3, OP_GE = 4, OP_PER = 5,
-             OP_PLUS = 6, OP_TIMES = 7, OP_CP = 8, OP_CP_SWAP = 9, OP_SEL = 10 };
+             OP_PLUS = 6, OP_TIMES = 7, OP_CP = 8, OP_CP_SWAP = 9, OP_SEL = 10, OP_GE_TAB = 11 };
+constexpr double LOGDT_ZERO = -1.0e8;    // table entry for dt = 0: exp(gamma (LOGDT_ZERO - log l)) == 0 exactly
 
 struct ProgHdr {
   int32_t op_off;   // offset into device ops[]
@@ -33,7 +36,7 @@ struct ProgHdr {
   int32_t n_ops;
   int32_t n_cp;     // number of per-point LDS tables: ChangePoint nodes + selector leaves
   int32_t n_prm;    // device parameters of this program
-  int32_t pad_;
+  int32_t flags;    // bit 0: the program has OP_GE_TAB leaves (reads the log|dt| table)
 };
 
 __host__ __device__ inline long long tile_off(int i, int j) {

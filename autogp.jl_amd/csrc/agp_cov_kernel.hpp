@@ -36,12 +36,13 @@ struct CovArgs {
   int col0_only;         // 1: grid.x enumerates tiles (1+tix, 0) only
   int p_off;             // first particle (blockIdx.y is relative to it)
   const uint8_t* code;   // per joint point: 0 observable, i latent of component i (infer_gp_sum); null = all 0
+  const double* logdt;   // packed lower tiles of log|t_i - t_j| over the resident data (programs with flags bit 0)
 };
 
 __device__ __forceinline__ int prm_count(int o) {
   // WN, CONST, LIN, SE, GE, PER, PLUS, TIMES, CP, CP_SWAP
   return (o == OP_WN || o == OP_CONST || o == OP_SEL) ? 1 : (o == OP_SE || o == OP_CP || o == OP_CP_SWAP) ? 2
-         : (o == OP_PLUS || o == OP_TIMES) ? 0 : 3;
+         : (o == OP_PLUS || o == OP_TIMES) ? 0 : 3;     // (LIN, GE, GE_TAB, PER: 3)
 }
 
 // LDS scratch of the evaluator: tpt[256] (row times 0..127, column times 128..255) then sig[n_cp][256].
@@ -76,11 +77,16 @@ __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, cons
 
 // Evaluate the program at E (row, column) pairs.  tr/tc: time values; ri/ci: indices into the sigma
 // tables (row slot 0..127, column slot 128..255).  All arrays are statically indexed registers.
-template <int D, int E, typename OpT>
+// GEMODE: 0 = GammaExp leaves of both kinds (OP_GE computes the power, OP_GE_TAB reads the log|dt| table),
+// 1 = OP_GE only, 2 = OP_GE_TAB only (the instantiations inside the factorisation kernel carry one kind, which
+// keeps the unused power / table code out of their register budget).
+template <int D, int E, int GEMODE = 0, typename OpT>
 __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __restrict__ ops,
                                              const double* __restrict__ prm, const double* sig,
                                              const double (&tr)[E], const double (&tc)[E],
-                                             const int (&ri)[E], const int (&ci)[E], double (&out)[E]) {
+                                             const int (&ri)[E], const int (&ci)[E], const double (&lt)[E],
+                                             double (&out)[E]) {
+  // lt: log|t_row - t_col| of the E elements from the data set's table (only read by OP_GE_TAB leaves)
   double st[D][E];
 #pragma unroll
   for (int d = 0; d < D; ++d)
@@ -91,7 +97,7 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
   for (int ip = 0; ip < h.n_ops; ++ip) {
     // the opcode is wave-uniform: keep it (and the dispatch on it) on the scalar unit
     const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
-    if (o <= OP_PER || o == OP_SEL) {
+    if (o <= OP_PER || o == OP_SEL || o == OP_GE_TAB) {
       // ---------------- leaf: push ----------------
       // every leaf's (up to three) parameters are fetched unconditionally — the parameter buffers
       // carry two doubles of tail padding — and picked by opcode afterwards
@@ -122,9 +128,12 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
             const double dx = tr[e] - tc[e];
             arg[e] = ((-0.5 * dx) * dx) * p0;
           }
-        } else if (o == OP_GE) {   // p0 = 1/l, p1 = gamma
+        } else if (GEMODE != 2 && o == OP_GE) {   // p0 = 1/l, p1 = gamma
 #pragma unroll
           for (int e = 0; e < E; ++e) arg[e] = -fm::pow_f(fabs(tr[e] - tc[e]) * p0, p1);
+        } else if (GEMODE != 1 && (o == OP_GE_TAB || (GEMODE == 2 && o == OP_GE))) {   // p0 = log l, p1 = gamma
+#pragma unroll
+          for (int e = 0; e < E; ++e) arg[e] = -fm::exp_f(p1 * (lt[e] - p0));
         } else {                   // OP_PER: p0 = -2/l^2, p1 = pi/p
 #pragma unroll
           for (int e = 0; e < E; ++e) arg[e] = p0 * fm::sin2_f(p1 * fabs(tr[e] - tc[e]));
@@ -211,10 +220,23 @@ __global__ __launch_bounds__(256) void k_cov_tiles(CovArgs a) {
   const double noise = a.noise[p];
   double* __restrict__ T = a.A + (long long)p * a.strideA + tile_off(ti, tj);
 
+  const bool use_tab = (h.flags & 1) != 0;
+  const double* __restrict__ ltile = a.logdt + tile_off(ti, tj);      // only dereferenced when use_tab
+  d2 ltn[4] = {d2{0.0, 0.0}, d2{0.0, 0.0}, d2{0.0, 0.0}, d2{0.0, 0.0}};
+  if (use_tab) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) ltn[cc] = *reinterpret_cast<const d2*>(ltile + (long long)(cq * 32 + cc) * NB + r0);
+  }
   for (int pass = 0; pass < 8; ++pass) {
     const int c0 = cq * 32 + pass * 4;
-    double tr[8], tc[8], out[8];
+    double tr[8], tc[8], out[8], lt[8];
     int ri[8], ci[8];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) { lt[2 * cc] = ltn[cc].x; lt[2 * cc + 1] = ltn[cc].y; }
+    if (use_tab && pass + 1 < 8) {      // table values of the next pass travel while this one is evaluated
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) ltn[cc] = *reinterpret_cast<const d2*>(ltile + (long long)(c0 + 4 + cc) * NB + r0);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       tr[e] = (e & 1) ? tr1 : tr0;
@@ -222,7 +244,7 @@ __global__ __launch_bounds__(256) void k_cov_tiles(CovArgs a) {
       ri[e] = r0 + (e & 1);
       ci[e] = NB + c0 + (e >> 1);
     }
-    eval_program<D, 8>(h, ops, prm, sig, tr, tc, ri, ci, out);
+    eval_program<D, 8, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out);
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc) {
       const int gj = tj * NB + c0 + cc;
@@ -231,6 +253,22 @@ __global__ __launch_bounds__(256) void k_cov_tiles(CovArgs a) {
       o2.y = cov_finalize(out[2 * cc + 1], gi0 + 1, gj, a.n1, a.n1_pad, a.m2, noise);
       *reinterpret_cast<d2*>(T + (long long)(c0 + cc) * NB + r0) = o2;
     }
+  }
+}
+
+// log|t_i - t_j| for every element of the lower tiles of the resident data (diagonal tiles in full), same packed
+// layout as a particle's matrix; dt = 0 gets LOGDT_ZERO.  One workgroup per tile, run once per agp_set_data.
+__global__ __launch_bounds__(256) void k_logdt_tiles(const double* __restrict__ tt, double* __restrict__ T) {
+  const int tix = blockIdx.x;
+  int ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tix) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
+  const int tj = tix - ti * (ti + 1) / 2;
+  double* __restrict__ out = T + tile_off(ti, tj);
+  for (int e = threadIdx.x; e < NB2; e += 256) {
+    const int r = e & (NB - 1), cidx = e >> 7;
+    const double dt = fabs(tt[ti * NB + r] - tt[tj * NB + cidx]);
+    out[e] = dt > 0.0 ? fm::log_f(dt) : LOGDT_ZERO;
   }
 }
 

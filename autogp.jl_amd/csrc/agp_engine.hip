@@ -99,11 +99,15 @@ struct agp_ctx {
   // A tile evaluation longer than this (cost model op_cost_us, measured per-leaf cost of one 128x128 tile
   // with two workgroups per CU) is not hidden by the co-resident workgroup's GEMM phase and would set the
   // duration of the short launches; such particles get their tiles from k_cov_tiles.  env AGP_FUSE_MAX_US
-  double fuse_max_us = 50.0;
+  double fuse_max_us = 35.0;
   int dedup = 1;        // evaluate identical particles of a host-output sweep once; env AGP_DEDUP
   int64_t n_particles_seen = 0, n_particles_run = 0;
   int trtri_chain = 1;  // Z = L^-T as independent per-row chains in one launch (0: one launch per block column); env AGP_TRTRI_CHAIN
   int split_diag = -1;  // diagonal tiles in their own specialised launch: -1 auto (when they fill the GPU), 0, 1; env AGP_SPLIT_DIAG
+  int ge_table = 1;     // GammaExp leaves read log|dt| from a table built by agp_set_data (env AGP_GE_TABLE)
+  double* d_logdt = nullptr;      // packed lower tiles, covers the resident data
+  size_t logdt_cap = 0;
+  bool logdt_ok = false;
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
@@ -185,6 +189,7 @@ struct Compiled {
   std::vector<CNode> nodes;   // parsed tree (kept for the gradient program)
   int root = -1;
   int n_prm_caller = 0;
+  bool uses_tab = false;      // has OP_GE_TAB leaves
 };
 
 int leaf_nprm(int op) {
@@ -196,7 +201,7 @@ int leaf_nprm(int op) {
   }
 }
 
-void emit(const std::vector<CNode>& nodes, int id, Compiled& out) {
+void emit(const std::vector<CNode>& nodes, int id, Compiled& out, bool ge_tab) {
   const CNode& nd = nodes[id];
   if (nd.left < 0) {
     out.ops.push_back((uint8_t)nd.op);
@@ -205,7 +210,15 @@ void emit(const std::vector<CNode>& nodes, int id, Compiled& out) {
       case OP_SEL: out.prm.push_back(nd.prm[0]); out.n_cp++; break;     // uses one per-point LDS table
       case OP_LIN: out.prm.insert(out.prm.end(), {nd.prm[0], nd.prm[1], nd.prm[2]}); break;
       case OP_SE: out.prm.insert(out.prm.end(), {1.0 / (nd.prm[0] * nd.prm[0]), nd.prm[1]}); break;
-      case OP_GE: out.prm.insert(out.prm.end(), {1.0 / nd.prm[0], nd.prm[1], nd.prm[2]}); break;
+      case OP_GE:
+        if (ge_tab) {       // (|dt|/l)^gamma from the data set's log|dt| table (l <= 0 gives NaN, as a negative base would)
+          out.ops.back() = (uint8_t)OP_GE_TAB;
+          out.uses_tab = true;
+          out.prm.insert(out.prm.end(), {std::log(nd.prm[0]), nd.prm[1], nd.prm[2]});
+        } else {
+          out.prm.insert(out.prm.end(), {1.0 / nd.prm[0], nd.prm[1], nd.prm[2]});
+        }
+        break;
       case OP_PER:
         out.prm.insert(out.prm.end(), {-2.0 / (nd.prm[0] * nd.prm[0]), M_PI / nd.prm[1], nd.prm[2]});
         break;
@@ -213,8 +226,8 @@ void emit(const std::vector<CNode>& nodes, int id, Compiled& out) {
     return;
   }
   const bool swap = nodes[nd.right].need > nodes[nd.left].need;
-  emit(nodes, swap ? nd.right : nd.left, out);
-  emit(nodes, swap ? nd.left : nd.right, out);
+  emit(nodes, swap ? nd.right : nd.left, out, ge_tab);
+  emit(nodes, swap ? nd.left : nd.right, out, ge_tab);
   if (nd.op == OP_CP) {
     out.ops.push_back((uint8_t)(swap ? OP_CP_SWAP : OP_CP));
     out.prm.push_back(nd.prm[0]);
@@ -227,7 +240,7 @@ void emit(const std::vector<CNode>& nodes, int id, Compiled& out) {
 
 // returns 0 or an error string
 const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, int n_prm, Compiled& out,
-                            bool allow_sel = false) {
+                            bool allow_sel = false, bool ge_tab = false) {
   if (n_ops <= 0 || n_ops > AGP_MAX_OPS) return "program length out of range";
   std::vector<CNode> nodes;
   nodes.reserve(n_ops);
@@ -263,7 +276,7 @@ const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, in
   if (ip != n_prm) return "parameter count mismatch";
   out.depth_need = nodes[stack[0]].need;
   if (out.depth_need > 8) return "kernel tree needs an evaluation stack deeper than 8";
-  emit(nodes, stack[0], out);
+  emit(nodes, stack[0], out, ge_tab);
   out.root = stack[0];
   out.n_prm_caller = n_prm;
   out.nodes.swap(nodes);
@@ -291,6 +304,7 @@ struct Batch {
 double op_cost_us(int op) {
   switch (op) {
     case OP_GE: return 36.0;
+    case OP_GE_TAB: return 18.0;
     case OP_PER: return 12.0;
     case OP_SE: return 7.0;
     case OP_LIN: return 2.0;
@@ -320,12 +334,12 @@ int emit_grad(const std::vector<CNode>& nodes, int id, Batch& bt, int prm_base, 
 }
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
-                  const double* prm, Batch& bt, bool allow_sel = false, bool want_grad = false) {
+                  const double* prm, Batch& bt, bool allow_sel = false, bool want_grad = false, bool ge_tab = false) {
   std::vector<Compiled> cps(P);
   std::vector<double> cost(P, 0.0);
   for (int p = 0; p < P; ++p) {
     const char* e = compile_program(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p],
-                                    prm_off[p + 1] - prm_off[p], cps[p], allow_sel);
+                                    prm_off[p + 1] - prm_off[p], cps[p], allow_sel, ge_tab);
     if (e) {
       char buf[256];
       snprintf(buf, sizeof buf, "particle %d: %s", p, e);
@@ -353,7 +367,7 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
     h.n_ops = (int32_t)cp.ops.size();
     h.n_cp = cp.n_cp;
     h.n_prm = (int32_t)cp.prm.size();
-    h.pad_ = 0;
+    h.flags = cp.uses_tab ? 1 : 0;
     bt.hdr[q] = h;
     bt.ops.insert(bt.ops.end(), cp.ops.begin(), cp.ops.end());
     bt.prm.insert(bt.prm.end(), cp.prm.begin(), cp.prm.end());
@@ -416,16 +430,25 @@ hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int 
 
 // DCOV selection: 0 = tiles are resident (agp_debug_cholesky / unfused fallback), 4 / 8 = evaluate the
 // kernel program in the update kernel with that evaluation-stack depth.
+// ca.logdt != nullptr selects the instantiation whose GammaExp leaves read the log|dt| table (the batch was then
+// compiled with OP_GE_TAB leaves only); it exists for the in-kernel-solve factorisation launches.
 template <bool FACTOR, bool INTRSM, int DM = 0>
 void launch_update(int dcov, int grid, hipStream_t st, const CholArgs& ca) {
+  constexpr bool CAN_TAB = FACTOR && INTRSM;
+  const bool tab = CAN_TAB && ca.logdt != nullptr && dcov > 0;
   if (dcov == 0) hipLaunchKernelGGL((k_chol_update<FACTOR, 0, INTRSM, DM>), dim3(grid), dim3(256), 0, st, ca);
-  else if (dcov <= 4) hipLaunchKernelGGL((k_chol_update<FACTOR, 4, INTRSM, DM>), dim3(grid), dim3(256), 0, st, ca);
-  else hipLaunchKernelGGL((k_chol_update<FACTOR, 8, INTRSM, DM>), dim3(grid), dim3(256), 0, st, ca);
+  else if (dcov <= 4) {
+    if (tab) hipLaunchKernelGGL((k_chol_update<FACTOR, 4, INTRSM, DM, CAN_TAB>), dim3(grid), dim3(256), 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_update<FACTOR, 4, INTRSM, DM>), dim3(grid), dim3(256), 0, st, ca);
+  } else {
+    if (tab) hipLaunchKernelGGL((k_chol_update<FACTOR, 8, INTRSM, DM, CAN_TAB>), dim3(grid), dim3(256), 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_update<FACTOR, 8, INTRSM, DM>), dim3(grid), dim3(256), 0, st, ca);
+  }
 }
 
 inline void set_cov(CholArgs& ca, const CovArgs& cv) {
   ca.tt = cv.tt; ca.n1 = cv.n1; ca.n1_pad = cv.n1_pad; ca.m2 = cv.m2;
-  ca.hdr = cv.hdr; ca.ops = cv.ops; ca.prm = cv.prm; ca.noise = cv.noise; ca.code = cv.code;
+  ca.hdr = cv.hdr; ca.ops = cv.ops; ca.prm = cv.prm; ca.noise = cv.noise; ca.code = cv.code; ca.logdt = cv.logdt;
 }
 
 struct Prof {
@@ -563,7 +586,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   Batch bt;
   std::vector<std::vector<int32_t>> pls;     // per-group particle orders of the gradient contraction
   pls.reserve(64);
-  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr);
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, c->logdt_ok);
   if (rc) return rc;
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
   const int n_prm_total = prm_off[P];
@@ -680,7 +703,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         cv.tt = c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
         cv.hdr = s->hdr.as<ProgHdr>() + p0 + g0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
         cv.noise = s->noise.as<double>() + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
-        cv.strideA = strideA; cv.P = Pg;
+        cv.strideA = strideA; cv.P = Pg; cv.logdt = c->logdt_ok ? c->d_logdt : nullptr;
         // Hybrid build.  Sorted particles [0, n_fused) evaluate their own tiles inside k_chol_update
         // (only the sub-diagonal tiles of block column 0, which k_chol_trsm(0) reads, are
         // materialised); the few expensive particles behind them get every tile from k_cov_tiles,
@@ -832,6 +855,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
   if (const char* e = getenv("AGP_TRTRI_CHAIN")) c->trtri_chain = atoi(e) != 0;
   if (const char* e = getenv("AGP_SPLIT_DIAG")) c->split_diag = atoi(e);
+  if (const char* e = getenv("AGP_GE_TABLE")) c->ge_table = atoi(e) != 0;
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
   if (const char* e = getenv("AGP_FUSE_MAX_US")) c->fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
@@ -849,6 +873,7 @@ void agp_destroy(agp_ctx* c) {
   for (Slot* s : c->slots) { s->release(); delete s; }
   if (c->d_ts) (void)hipFree(c->d_ts);
   if (c->d_xs) (void)hipFree(c->d_xs);
+  if (c->d_logdt) (void)hipFree(c->d_logdt);
   delete c;
 }
 
@@ -904,6 +929,24 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
   }
   c->h_ts.assign(ts, ts + n_max);
   c->n_max = n_max;
+  // log|t_i - t_j| over the resident points, shared by the GammaExp leaves of every particle (OP_GE_TAB)
+  c->logdt_ok = false;
+  if (c->ge_table && n_max > 0) {
+    const int64_t nt = (n_max + NB - 1) / NB;
+    const int64_t ntiles = nt * (nt + 1) / 2;
+    const size_t bytes = sizeof(double) * (size_t)ntiles * NB2;
+    if (bytes <= ((size_t)4 << 30)) {
+      if (bytes > c->logdt_cap) {
+        if (c->d_logdt) { HIPCHK(c, hipFree(c->d_logdt)); c->d_logdt = nullptr; c->logdt_cap = 0; }
+        HIPCHK(c, hipMalloc((void**)&c->d_logdt, bytes));
+        c->logdt_cap = bytes;
+      }
+      hipLaunchKernelGGL(k_logdt_tiles, dim3((unsigned)ntiles), dim3(256), 0, 0, c->d_ts, c->d_logdt);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipDeviceSynchronize());
+      c->logdt_ok = true;
+    }
+  }
   return AGP_OK;
 }
 

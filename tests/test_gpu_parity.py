@@ -188,6 +188,39 @@ def test_large_population_path_vs_oracle(pkg, engine, n, P):
     assert lp_err(lp_small, lp[sub]).max() <= 1e-11
 
 
+def test_gamma_exponential_table_path(pkg, engine, monkeypatch):
+    """agp_set_data tabulates log|t_i - t_j| once; GammaExp leaves of the logpdf sweeps then evaluate
+    (|dt|/l)^gamma = exp(gamma (log|dt| - log l)) from it.  Same values as the direct power (engine created with
+    AGP_GE_TABLE=0) and as the oracle, including duplicate time points (dt = 0), prefixes of the data and both
+    the small-batch (k_cov_tiles) and the >= 256-particle (in-kernel evaluation) paths."""
+    G = pkg
+    rng = np.random.default_rng(77)
+    n = 300
+    ts = np.sort(rng.random(n)); ts[100] = ts[99]; ts[200] = ts[199]; xs = 0.5 * rng.standard_normal(n)
+    def ge(): return G.GammaExponential(np.exp(-1.5 + rng.standard_normal()), 2 / (1 + np.exp(-rng.standard_normal())), np.exp(-1 + rng.standard_normal()))
+    small = [ge(), ge() + G.Linear(0.1, 0.3, 0.7), ge() * ge(), G.ChangePoint(ge(), G.Periodic(0.9, 0.2, 1.1), 0.4, 0.1),
+             G.GammaExponential(0.3, 2.0, 1.0), G.GammaExponential(0.3, 0.05, 1.0)]
+    big = small + [ge() + G.Linear(*np.exp(-1 + rng.standard_normal(3))) for _ in range(260)]
+    monkeypatch.setenv("AGP_GE_TABLE", "0")
+    direct = G.GPEngine(0)
+    monkeypatch.delenv("AGP_GE_TABLE")
+    try:
+        for eng_ in (engine, direct):
+            eng_.set_data(ts, xs)
+        for pop in (small, big):
+            nz = np.full(len(pop), 0.15)
+            for m in (n, 170):
+                a, ia = engine.logpdf_batch(pop, nz, n=m, check=False)
+                b, ib = direct.logpdf_batch(pop, nz, n=m, check=False)
+                assert np.array_equal(ia, ib) and (ia == 0).all()
+                assert lp_err(a, b).max() <= 1e-11
+                for i in (0, 2, 3, 5, len(pop) - 1):
+                    ref = O.gp_logpdf(pop[i].to_tuple(), 0.15, ts[:m], xs[:m])
+                    assert abs(a[i] - ref) <= LP_TOL * max(1.0, abs(ref))
+    finally:
+        direct.close()
+
+
 def test_config1_se_plus_linear(pkg, engine):
     """BASELINE config 1: n=256, 8 particles, fixed SE+Linear kernel."""
     G = pkg
