@@ -586,7 +586,9 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   Batch bt;
   std::vector<std::vector<int32_t>> pls;     // per-group particle orders of the gradient contraction
   pls.reserve(64);
-  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, c->logdt_ok);
+  // (the log|dt|-table kernels exist for the in-kernel-solve factorisation launches, see launch_update)
+  const bool ge_tab = c->logdt_ok && c->intrsm != 0;
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab);
   if (rc) return rc;
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
   const int n_prm_total = prm_off[P];
@@ -703,7 +705,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         cv.tt = c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
         cv.hdr = s->hdr.as<ProgHdr>() + p0 + g0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
         cv.noise = s->noise.as<double>() + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
-        cv.strideA = strideA; cv.P = Pg; cv.logdt = c->logdt_ok ? c->d_logdt : nullptr;
+        cv.strideA = strideA; cv.P = Pg; cv.logdt = ge_tab ? c->d_logdt : nullptr;
         // Hybrid build.  Sorted particles [0, n_fused) evaluate their own tiles inside k_chol_update
         // (only the sub-diagonal tiles of block column 0, which k_chol_trsm(0) reads, are
         // materialised); the few expensive particles behind them get every tile from k_cov_tiles,

@@ -221,6 +221,38 @@ def test_gamma_exponential_table_path(pkg, engine, monkeypatch):
         direct.close()
 
 
+@pytest.mark.parametrize("env", [{"AGP_INTRSM": "0"}, {"AGP_SPLIT_DIAG": "0"}, {"AGP_SPLIT_DIAG": "1"}, {"AGP_FUSE": "0"},
+                                 {"AGP_FUSE": "1", "AGP_FUSE_MAX_US": "1000"}, {"AGP_STREAMS": "2"},
+                                 {"AGP_GRAD_SPLIT": "0"}, {"AGP_TRTRI_CHAIN": "0"}, {"AGP_DEDUP": "0", "AGP_GE_TABLE": "0"}])
+def test_runtime_switches_agree_with_default(pkg, engine, monkeypatch, env):
+    """Every documented runtime switch selects a different kernel schedule for the same
+    arithmetic: value, info and gradient agree with the default engine to rounding, on a 260-particle
+    population (in-kernel evaluation, split launches) and on a 12-particle one (mixed launch)."""
+    ts, xs = pkg.prior.synthetic_series(300, seed=9, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(9), 260, max_depth=4, max_size=15)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = pkg.GPEngine(0)
+    for k in env:
+        monkeypatch.delenv(k)
+    try:
+        engine.set_data(ts, xs); other.set_data(ts, xs)
+        for sl in (slice(0, 260), slice(0, 12)):
+            a, ia = engine.logpdf_batch(nodes[sl], noises[sl], check=False)
+            b, ib = other.logpdf_batch(nodes[sl], noises[sl], check=False)
+            ok = ia == 0
+            assert np.array_equal(ia > 0, ib > 0) and ok.sum() >= 10
+            assert lp_err(a[ok], b[ok]).max() <= 1e-11
+        ga = engine.logpdf_grad_batch(nodes[:40], noises[:40], check=False)
+        gb = other.logpdf_grad_batch(nodes[:40], noises[:40], check=False)
+        for i in range(40):
+            if ga[3][i] == 0:
+                sc = max(1.0, np.abs(ga[1][i]).max(), abs(ga[2][i]))
+                assert np.abs(ga[1][i] - gb[1][i]).max() <= 1e-9 * sc and abs(ga[2][i] - gb[2][i]) <= 1e-9 * sc
+    finally:
+        other.close()
+
+
 def test_config1_se_plus_linear(pkg, engine):
     """BASELINE config 1: n=256, 8 particles, fixed SE+Linear kernel."""
     G = pkg
