@@ -10,7 +10,7 @@
 //
 // Two users:
 //   * k_cov_tiles   — stand-alone tile builder (block column 0 of a factorisation, agp_cov_matrix);
-//                     8 elements per lane and pass, 16 B stores, 1 KiB contiguous per wave instruction.
+//                     4 elements per lane and pass at 4 waves/SIMD, 16 B stores, 1 KiB contiguous per wave instruction.
 //   * k_chol_update — evaluates its own tile straight into the MFMA accumulators (4 elements per
 //                     pass in the accumulator layout), so K never round-trips through HBM and the
 //                     fp64 transcendental work overlaps the co-resident workgroup's MFMA phase.
@@ -188,8 +188,17 @@ __device__ __forceinline__ double cov_finalize(double v, int gi, int gj, int n1,
   return r;
 }
 
+#ifndef AGP_COV_E
+#define AGP_COV_E 4
+#endif
+#ifndef AGP_COV_WGS
+#define AGP_COV_WGS 4
+#endif
+// E elements per lane and pass (2 rows x E/2 columns); AGP_COV_WGS workgroups per CU bound the register budget.
+// Measured (all tiles prebuilt, n=2048, 512 particles): E=8 at 2 waves/SIMD 4.27 ms, E=4 at 4 waves/SIMD 4.05 ms.
 template <int D>
-__global__ __launch_bounds__(256) void k_cov_tiles(CovArgs a) {
+__global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
+  constexpr int E = AGP_COV_E, CPP = E / 2, NPASS = 32 / CPP;      // columns per pass, passes over this thread's 32 columns
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* tpt = smem;         // [256]
   double* sig = smem + 256;   // [n_cp][256]
@@ -222,31 +231,33 @@ __global__ __launch_bounds__(256) void k_cov_tiles(CovArgs a) {
 
   const bool use_tab = (h.flags & 1) != 0;
   const double* __restrict__ ltile = a.logdt + tile_off(ti, tj);      // only dereferenced when use_tab
-  d2 ltn[4] = {d2{0.0, 0.0}, d2{0.0, 0.0}, d2{0.0, 0.0}, d2{0.0, 0.0}};
+  d2 ltn[CPP];
+#pragma unroll
+  for (int cc = 0; cc < CPP; ++cc) ltn[cc] = d2{0.0, 0.0};
   if (use_tab) {
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) ltn[cc] = *reinterpret_cast<const d2*>(ltile + (long long)(cq * 32 + cc) * NB + r0);
+    for (int cc = 0; cc < CPP; ++cc) ltn[cc] = *reinterpret_cast<const d2*>(ltile + (long long)(cq * 32 + cc) * NB + r0);
   }
-  for (int pass = 0; pass < 8; ++pass) {
-    const int c0 = cq * 32 + pass * 4;
-    double tr[8], tc[8], out[8], lt[8];
-    int ri[8], ci[8];
+  for (int pass = 0; pass < NPASS; ++pass) {
+    const int c0 = cq * 32 + pass * CPP;
+    double tr[E], tc[E], out[E], lt[E];
+    int ri[E], ci[E];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) { lt[2 * cc] = ltn[cc].x; lt[2 * cc + 1] = ltn[cc].y; }
-    if (use_tab && pass + 1 < 8) {      // table values of the next pass travel while this one is evaluated
+    for (int cc = 0; cc < CPP; ++cc) { lt[2 * cc] = ltn[cc].x; lt[2 * cc + 1] = ltn[cc].y; }
+    if (use_tab && pass + 1 < NPASS) {      // table values of the next pass travel while this one is evaluated
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc) ltn[cc] = *reinterpret_cast<const d2*>(ltile + (long long)(c0 + 4 + cc) * NB + r0);
+      for (int cc = 0; cc < CPP; ++cc) ltn[cc] = *reinterpret_cast<const d2*>(ltile + (long long)(c0 + CPP + cc) * NB + r0);
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
+    for (int e = 0; e < E; ++e) {
       tr[e] = (e & 1) ? tr1 : tr0;
       tc[e] = tpt[NB + c0 + (e >> 1)];
       ri[e] = r0 + (e & 1);
       ci[e] = NB + c0 + (e >> 1);
     }
-    eval_program<D, 8, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out);
+    eval_program<D, E, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out);
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
+    for (int cc = 0; cc < CPP; ++cc) {
       const int gj = tj * NB + c0 + cc;
       d2 o2;
       o2.x = cov_finalize(out[2 * cc], gi0, gj, a.n1, a.n1_pad, a.m2, noise);

@@ -1507,6 +1507,12 @@ int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t
         hipLaunchKernelGGL((k_gemm_strip<16, true, true, true>), dim3(blocks), dim3(256), 0, st, ca);
         break;
       }
+      case 2003: {   // as 2000 without LDS / barriers: both operands global -> registers
+        int blocks = 0;
+        for (int kk = 1; kk < nt - 1; ++kk) blocks += Pg8 * (nt - kk - 1);
+        hipLaunchKernelGGL((k_gemm_nolds<true>), dim3(blocks), dim3(256), 0, st, ca);
+        break;
+      }
       case 2001: {   // the same tiles, one launch per block column
         CholArgs cb = ca;
         for (int kk = 1; kk < nt - 1; ++kk) {

@@ -339,6 +339,66 @@ __global__ __launch_bounds__(256, 2) void k_gemm_strip(CholArgs a) {
     }
 }
 
+// Variant without LDS and without barriers: every wave fetches BOTH operands' MFMA fragments straight from global
+// memory (the column operand is the same for the four waves: L1 / L2 hits), one 4-column k-step at a time into a
+// register ring of four k-steps that is refilled right behind the MFMAs that consumed it.  ALL as in k_gemm_strip.
+template <bool ALL>
+__global__ __launch_bounds__(256, 2) void k_gemm_nolds(CholArgs a) {
+  int b = blockIdx.x;
+  int kcol = a.k, T = a.tiles;
+  if (ALL) {
+    const int npl8 = 8 * ((a.P + 7) / 8);
+    kcol = 1;
+    while (kcol < a.nt - 1 && b >= npl8 * (a.nt - kcol - 1)) { b -= npl8 * (a.nt - kcol - 1); ++kcol; }
+    T = a.nt - kcol - 1;
+  }
+  const int xcd = b & 7, qq = b >> 3;
+  const int pl = qq / T, tl = qq - pl * T;
+  const int tk = kcol, ti = kcol + 1 + tl, jmax = kcol;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  const int row0 = 32 * w + 2 * l15;
+  double* __restrict__ Ap = a.A + (long long)p * a.strideA;
+  d4 acc[NSB][2];
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
+  const int nstep = jmax * (NB / 4);            // 4-column k-steps
+  double fa[4][NSB];
+  d2 fb[4];
+  auto load = [&](int buf, int ks) {
+    const int j = ks >> 5, c = (ks & 31) * 4 + lq;      // tile j, column of this lane's fragment
+    const double* __restrict__ srcA = Ap + tile_off(ti, j) + (long long)c * NB;
+    const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)c * NB;
+    fb[buf] = *reinterpret_cast<const d2*>(srcA + row0);
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb) fa[buf][cb] = srcB[cb * 16 + l15];
+  };
+#pragma unroll
+  for (int u = 0; u < 4; ++u) load(u, u);
+  for (int ks = 0; ks < nstep; ks += 4) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb) {
+        acc[cb][0] = mfma(fa[u][cb], fb[u].x, acc[cb][0]);
+        acc[cb][1] = mfma(fa[u][cb], fb[u].y, acc[cb][1]);
+      }
+      if (ks + 4 + u < nstep) load(u, ks + 4 + u);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+  double* __restrict__ Tt = Ap + tile_off(ti, tk);
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d2 o2; o2.x = -acc[cb][0][r]; o2.y = -acc[cb][1][r];
+      *reinterpret_cast<d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
+    }
+}
+
 __global__ void k_fill_pseudo(double* A, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
