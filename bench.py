@@ -46,7 +46,7 @@ def cholesky_flops(n):          # LAPACK convention, SURVEY.md §8(d)
 
 def subdiag_kernel_flops(n):
     """Algorithmic flops per particle and sweep of the dominant kernel of the default build,
-    k_chol_update<true,DCOV,true,2>: for every block column k the nt-k-1 sub-diagonal tiles, each a
+    k_chol_update<true,DCOV,true,2,TAB>: for every block column k the nt-k-1 sub-diagonal tiles, each a
     128 x 128 x (128 k) update (2 flops per multiply-add) plus the 128^3 triangular solve against L(k,k)."""
     nt = (n + NB - 1) // NB
     return float(sum((nt - k - 1) * (2.0 * NB * NB * (k * NB) + NB ** 3) for k in range(nt)))
@@ -217,10 +217,10 @@ def main():
         split_diag = intrsm and os.environ.get("AGP_SPLIT_DIAG", "1") != "0"
         solve_in_kernel = intrsm
         if split_diag:
-            kernel_name = "k_chol_update<true,DCOV,true,2>"
+            kernel_name = "k_chol_update<true,DCOV,true,2,TAB>"
             upd_flops_launch = P * subdiag_kernel_flops(n) / max(1, nt - 1)
         else:
-            kernel_name = "k_chol_update<true,DCOV,true,0>" if solve_in_kernel else "k_chol_update<true,DCOV,false,0>"
+            kernel_name = "k_chol_update<true,DCOV,true,0,TAB>" if solve_in_kernel else "k_chol_update<true,DCOV,false,0>"
             upd_flops_launch = P * update_kernel_flops(n, solve_in_kernel) / nt       # algorithmic flops per launch
         achieved = upd_flops_launch / (upd_ms * 1e-3) / 1e12
         traffic = None

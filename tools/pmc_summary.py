@@ -51,7 +51,8 @@ txt = "\n".join(out)
 (ROOT / f"profiles/{tag}_pmc_summary.txt").write_text(txt)
 print(txt)
 # dominant kernel: the sub-diagonal-tile instantiation (last template argument 2) of the default build
-upd = [k for k in res if "k_chol_update<true" in k and k.rstrip().endswith("2>")] or [k for k in res if "k_chol_update<true" in k]
+import re
+upd = [k for k in res if re.search(r"k_chol_update<true, \d, true, 2\b", k)] or [k for k in res if "k_chol_update<true" in k]
 if upd and "fetch" in res[upd[0]] and "write" in res[upd[0]]:
     tot = res[upd[0]]["fetch"] + res[upd[0]]["write"]
     (ROOT / "profiles/hbm_traffic.json").write_text(json.dumps({

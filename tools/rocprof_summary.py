@@ -23,7 +23,8 @@ def main():
     for k, v in res.items():
         lines.append(f"{k[:70]:70s} {v}")
     NB = 128; nt = (a.n + NB - 1) // NB; P = a.particles
-    dia = [r for r in rows if "k_chol_update<true" in r[0] and r[0].split("(")[0].rstrip().endswith("1>")]
+    import re
+    dia = [r for r in rows if re.search(r"k_chol_update<true, \d, true, 1\b", r[0])]
     upd = [r for r in rows if "k_chol_update<true" in r[0] and r not in dia]
     trs = [r for r in rows if "k_chol_trsm" in r[0]]
     split = len(dia) > 0
