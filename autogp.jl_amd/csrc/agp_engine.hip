@@ -113,10 +113,16 @@ struct agp_ctx {
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
   // ---- coalescing of concurrent single-particle callers (agp_logpdf) ----
   std::mutex qmu;
-  std::condition_variable qcv;
+  std::condition_variable qcv;          // followers: a batch finished (results ready / a new leader is needed)
+  std::condition_variable qcv_leader;   // the gathering leader: a request arrived
+  bool leader_gathering = false;
+  long long arrivals = 0;              // requests ever queued
+  int batch_prev = 0;                  // size of the batch before the last one
+  double last_sweep_us = 0.0;          // duration of the last coalesced sweep
   std::vector<LpRequest*> queue;
   bool leader_active = false;
-  int coalesce_us = 300;     // how long a leader waits for followers; 0 = every call runs alone (env AGP_COALESCE_US)
+  int coalesce_us = 2000;    // upper bound of a leader's wait for followers (it also never exceeds a quarter of the
+                             // last sweep's duration); 0 = every call runs alone (env AGP_COALESCE_US)
   int batch_hint = 1;        // size of the last coalesced batch
   long long n_coalesced_calls = 0, n_coalesced_batches = 0;
 };
@@ -1070,8 +1076,8 @@ static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
 
 // Single particle — the call Gen's interpreter makes at src/Model.jl:135-136, from up to nthreads()
 // Julia threads at once (src/inference_smc_anneal_data.jl:133-135).  Concurrent callers are
-// coalesced: the first arrival becomes the leader, waits up to `coalesce_us` for as many followers
-// as the previous batch had, runs ONE batched sweep for everyone with the same n, and hands the
+// coalesced: the first arrival becomes the leader, gathers followers (see the budget below) up to the size of the
+// last two batches, runs ONE batched sweep for everyone with the same n, and hands the
 // results back.  Callers that arrive while a sweep is running form the next batch.
 int agp_logpdf(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
                double noise, double* out_logpdf, int32_t* out_info) {
@@ -1087,26 +1093,48 @@ int agp_logpdf(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const d
   req.n = n; req.ops = ops; req.n_ops = n_ops; req.prm = prm; req.n_prm = n_prm; req.noise = noise;
   std::unique_lock<std::mutex> lk(c->qmu);
   c->queue.push_back(&req);
-  c->qcv.notify_all();                       // a waiting leader may have reached its hint
+  ++c->arrivals;
+  if (c->leader_gathering) c->qcv_leader.notify_one();      // only the gathering leader cares about arrivals
   while (!req.done) {
     if (!c->leader_active) {
       // ---- become the leader ----
       c->leader_active = true;
-      const size_t want = (size_t)std::max(1, c->batch_hint);
-      if (c->queue.size() < want)
-        c->qcv.wait_for(lk, std::chrono::microseconds(c->coalesce_us), [&] { return c->queue.size() >= want; });
+      // Gather.  With callers alternating between "in a sweep" and "queued" the population is up to the last TWO
+      // batches together; wait for that many, or until arrivals have stopped for one quiet slice with at least the
+      // last batch's size queued, or until the budget is spent: min(window, a quarter of the last sweep), so
+      // that small problems are not delayed by a window sized for large ones.  A lone caller never waits.
+      const size_t target = (size_t)std::max(1, c->batch_hint + c->batch_prev);
+      if (target > 1 || c->queue.size() > 1) {
+        using clk = std::chrono::steady_clock;
+        const double budget_us = std::min((double)c->coalesce_us, std::max(20.0, 0.25 * c->last_sweep_us));
+        const auto quiet = std::chrono::microseconds(std::max(5, (int)std::min(40.0, budget_us / 4)));
+        const auto t_start = clk::now();
+        c->leader_gathering = true;
+        while (c->queue.size() < target) {
+          const long long seen = c->arrivals;
+          c->qcv_leader.wait_for(lk, quiet);
+          const double waited = std::chrono::duration<double, std::micro>(clk::now() - t_start).count();
+          if (waited >= budget_us) break;
+          if (c->arrivals == seen && c->queue.size() >= (size_t)std::max(1, c->batch_hint)) break;
+        }
+        c->leader_gathering = false;
+      }
       std::vector<LpRequest*> batch, rest;
       for (LpRequest* r : c->queue) (r->n == req.n ? batch : rest).push_back(r);
       c->queue.swap(rest);
+      c->batch_prev = c->batch_hint;
       c->batch_hint = (int)batch.size();
       c->n_coalesced_calls += (long long)batch.size();
       c->n_coalesced_batches += 1;
       lk.unlock();
+      const auto t0 = std::chrono::steady_clock::now();
       run_coalesced(c, batch);
+      const double sweep_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
       lk.lock();
+      c->last_sweep_us = sweep_us;
       for (LpRequest* r : batch) r->done = true;
       c->leader_active = false;
-      c->qcv.notify_all();
+      c->qcv.notify_all();               // finished followers return; one of the queued callers leads the next batch
     } else {
       c->qcv.wait(lk);
     }

@@ -76,8 +76,9 @@ int agp_set_data(agp_ctx* ctx, const double* ts, const double* xs, int64_t n_max
 
 /* Single particle — what Gen's interpreter calls at src/Model.jl:135-136.  Re-entrant.  Concurrent
  * callers (one per Julia thread, src/inference_smc_anneal_data.jl:133-135) are coalesced inside the
- * library into one batched sweep: the first arrival waits up to the coalescing window (default 300 us,
- * env AGP_COALESCE_US, agp_set_coalesce_window; 0 disables) for the others. */
+ * library into one batched sweep: the first arrival gathers the others for at most the coalescing window
+ * (default 2000 us, and never more than a quarter of the previous sweep's duration; env AGP_COALESCE_US,
+ * agp_set_coalesce_window; 0 disables).  A lone caller never waits. */
 int agp_logpdf(agp_ctx* ctx, int64_t n,
                const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
                double noise, double* out_logpdf, int32_t* out_info);
