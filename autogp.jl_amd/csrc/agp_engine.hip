@@ -73,6 +73,8 @@ struct LpRequest {
   const uint8_t* ops; int32_t n_ops;
   const double* prm; int32_t n_prm;
   double noise;
+  double* grad = nullptr;        // value + gradient request: d logpdf / d prm[0..n_prm), caller's storage
+  double gnoise = 0.0;
   double lp = 0.0; int32_t info = 0; int rc = 0;
   bool done = false;
 };
@@ -1045,11 +1047,12 @@ int agp_logpdf_batch_device(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_
                            d_out_info, (hipStream_t)hip_stream, hip_stream != nullptr);
 }
 
-// Run one coalesced batch (all requests share n) through the batched sweep.
+// Run one coalesced batch (all requests share n and the kind: value only / value + gradient) through the batched sweep.
 static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
   const int P = (int)batch.size();
+  const bool want_grad = batch[0]->grad != nullptr;
   std::vector<int32_t> op_off(P + 1, 0), prm_off(P + 1, 0);
-  std::vector<uint8_t> ops; std::vector<double> prm, noise(P), lp(P);
+  std::vector<uint8_t> ops; std::vector<double> prm, noise(P), lp(P), gn(want_grad ? P : 0);
   std::vector<int32_t> info(P);
   for (int i = 0; i < P; ++i) {
     const LpRequest* r = batch[i];
@@ -1058,20 +1061,34 @@ static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
     op_off[i + 1] = (int32_t)ops.size(); prm_off[i + 1] = (int32_t)prm.size();
     noise[i] = r->noise;
   }
+  std::vector<double> grad(want_grad ? std::max<size_t>(1, prm.size()) : 0);
   if (prm.empty()) prm.push_back(0.0);
-  int rc = agp_logpdf_batch(c, batch[0]->n, P, op_off.data(), ops.data(), prm_off.data(), prm.data(), noise.data(),
-                            lp.data(), info.data());
+  auto sweep = [&](int64_t n, int32_t Pn, const int32_t* oo, const uint8_t* o, const int32_t* po, const double* q,
+                   const double* nz, double* out_lp, double* out_g, double* out_gn, int32_t* out_info) {
+    return want_grad ? agp_logpdf_grad_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_g, out_gn, out_info)
+                     : agp_logpdf_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_info);
+  };
+  int rc = sweep(batch[0]->n, P, op_off.data(), ops.data(), prm_off.data(), prm.data(), noise.data(), lp.data(),
+                 grad.data(), gn.data(), info.data());
   if (rc == AGP_ERR_PROGRAM && P > 1) {
-    // one malformed program must not fail its neighbours: fall back to individual sweeps
+    // one malformed (or, for gradients, oversized) program must not fail its neighbours: individual sweeps
     for (int i = 0; i < P; ++i) {
       LpRequest* r = batch[i];
       const int32_t oo[2] = {0, r->n_ops}, po[2] = {0, r->n_prm};
-      double dummy = 0.0;
-      r->rc = agp_logpdf_batch(c, r->n, 1, oo, r->ops, po, r->n_prm > 0 ? r->prm : &dummy, &r->noise, &r->lp, &r->info);
+      double dummy = 0.0, gdummy = 0.0;
+      r->rc = sweep(r->n, 1, oo, r->ops, po, r->n_prm > 0 ? r->prm : &dummy, &r->noise, &r->lp,
+                    r->n_prm > 0 ? r->grad : &gdummy, &r->gnoise, &r->info);
     }
     return;
   }
-  for (int i = 0; i < P; ++i) { batch[i]->rc = rc; batch[i]->lp = lp[i]; batch[i]->info = info[i]; }
+  for (int i = 0; i < P; ++i) {
+    LpRequest* r = batch[i];
+    r->rc = rc; r->lp = lp[i]; r->info = info[i];
+    if (want_grad && rc == AGP_OK) {
+      r->gnoise = gn[i];
+      std::copy(grad.begin() + prm_off[i], grad.begin() + prm_off[i + 1], r->grad);
+    }
+  }
 }
 
 // Single particle — the call Gen's interpreter makes at src/Model.jl:135-136, from up to nthreads()
@@ -1079,18 +1096,25 @@ static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
 // coalesced: the first arrival becomes the leader, gathers followers (see the budget below) up to the size of the
 // last two batches, runs ONE batched sweep for everyone with the same n, and hands the
 // results back.  Callers that arrive while a sweep is running form the next batch.
-int agp_logpdf(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
-               double noise, double* out_logpdf, int32_t* out_info) {
+static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
+                      double noise, double* out_logpdf, double* out_grad, double* out_grad_noise, int32_t* out_info) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   if (!ops || !out_logpdf || !out_info || n_ops <= 0 || n_prm < 0 || (n_prm > 0 && !prm))
     return fail(c, AGP_ERR_ARG, "bad program arguments");
+  const bool want_grad = out_grad_noise != nullptr;
+  if (want_grad && n_prm > 0 && !out_grad) return fail(c, AGP_ERR_ARG, "null gradient pointer");
+  double gdummy = 0.0;
   if (c->coalesce_us <= 0) {
     const int32_t op_off[2] = {0, n_ops}, prm_off[2] = {0, n_prm};
     double dummy = 0.0;
+    if (want_grad)
+      return agp_logpdf_grad_batch(c, n, 1, op_off, ops, prm_off, n_prm > 0 ? prm : &dummy, &noise, out_logpdf,
+                                   n_prm > 0 ? out_grad : &gdummy, out_grad_noise, out_info);
     return agp_logpdf_batch(c, n, 1, op_off, ops, prm_off, n_prm > 0 ? prm : &dummy, &noise, out_logpdf, out_info);
   }
   LpRequest req;
   req.n = n; req.ops = ops; req.n_ops = n_ops; req.prm = prm; req.n_prm = n_prm; req.noise = noise;
+  if (want_grad) req.grad = n_prm > 0 ? out_grad : &gdummy;
   std::unique_lock<std::mutex> lk(c->qmu);
   c->queue.push_back(&req);
   ++c->arrivals;
@@ -1120,7 +1144,7 @@ int agp_logpdf(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const d
         c->leader_gathering = false;
       }
       std::vector<LpRequest*> batch, rest;
-      for (LpRequest* r : c->queue) (r->n == req.n ? batch : rest).push_back(r);
+      for (LpRequest* r : c->queue) ((r->n == req.n && (r->grad != nullptr) == want_grad) ? batch : rest).push_back(r);
       c->queue.swap(rest);
       c->batch_prev = c->batch_hint;
       c->batch_hint = (int)batch.size();
@@ -1142,7 +1166,22 @@ int agp_logpdf(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const d
   lk.unlock();
   *out_logpdf = req.lp;
   *out_info = req.info;
+  if (want_grad) *out_grad_noise = req.gnoise;
   return req.rc;
+}
+
+int agp_logpdf(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
+               double noise, double* out_logpdf, int32_t* out_info) {
+  return logpdf_one(c, n, ops, n_ops, prm, n_prm, noise, out_logpdf, nullptr, nullptr, out_info);
+}
+
+// Value + gradient of one particle — what Gen.choice_gradients needs per trace (Gen.hmc,
+// src/inference_smc_anneal_data.jl:63-67; Gen.map_optimize, src/Greedy.jl:95,370), called from one thread per
+// particle.  Coalesced exactly like agp_logpdf (gradient callers form their own batches).
+int agp_logpdf_grad(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
+                    double noise, double* out_logpdf, double* out_grad, double* out_grad_noise, int32_t* out_info) {
+  if (c && !out_grad_noise) return fail(c, AGP_ERR_ARG, "null gradient pointer");
+  return logpdf_one(c, n, ops, n_ops, prm, n_prm, noise, out_logpdf, out_grad, out_grad_noise, out_info);
 }
 
 int agp_get_coalesce_stats(agp_ctx* c, int64_t* n_calls, int64_t* n_batches) {

@@ -25,7 +25,7 @@ LIB_PATH = _PKG_DIR / "lib" / "libautogp_hip.so"
 
 EXPORTED_SYMBOLS = [
     "agp_init", "agp_destroy", "agp_last_error", "agp_version", "agp_set_data", "agp_logpdf",
-    "agp_logpdf_batch", "agp_logpdf_grad_batch", "agp_logpdf_batch_device", "agp_predict_batch", "agp_infer_gp_sum", "agp_cov_matrix",
+    "agp_logpdf_batch", "agp_logpdf_grad_batch", "agp_logpdf_grad", "agp_logpdf_batch_device", "agp_predict_batch", "agp_infer_gp_sum", "agp_cov_matrix",
     "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_debug_mfma_peak", "agp_debug_math", "agp_debug_gemm_variant", "agp_set_profiling", "agp_get_timing", "agp_get_launch_times",
     "agp_set_workspace_limit", "agp_set_coalesce_window", "agp_get_coalesce_stats", "agp_get_dedup_stats",
 ]
@@ -92,6 +92,8 @@ def load_library(path=None):
     lib.agp_logpdf_batch.restype = C.c_int
     lib.agp_logpdf_grad_batch.argtypes = [vp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, dp, dp, ip]
     lib.agp_logpdf_grad_batch.restype = C.c_int
+    lib.agp_logpdf_grad.argtypes = [vp, C.c_int64, u8p, C.c_int32, dp, C.c_int32, C.c_double, dp, dp, dp, ip]
+    lib.agp_logpdf_grad.restype = C.c_int
     lib.agp_logpdf_batch_device.argtypes = [vp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, vp, vp, vp]
     lib.agp_logpdf_batch_device.restype = C.c_int
     lib.agp_predict_batch.argtypes = [vp, C.c_int64, dp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, dp, dp,
@@ -187,6 +189,20 @@ class GPEngine:
         if check and info.value > 0:
             raise PosDefException(info.value)
         return out.value
+
+    def logpdf_grad(self, node, noise, n=None, check=True):
+        """(logpdf, d logpdf / d theta in encode(node) parameter order, d logpdf / d noise) of ONE particle — the call a
+        per-thread differentiating caller (Gen.choice_gradients) makes; concurrent callers are coalesced."""
+        ops, prm = _gp.encode(node)
+        n = self.n_max if n is None else int(n)
+        out = C.c_double(); gn = C.c_double(); info = C.c_int32()
+        prm_arg = prm if prm.size else np.zeros(1)
+        grad = np.zeros(max(1, prm.size))
+        self._check(self._lib.agp_logpdf_grad(self._ctx, n, _u8(ops), ops.size, _dp(prm_arg), prm.size, float(noise),
+                                              C.byref(out), _dp(grad), C.byref(gn), C.byref(info)))
+        if check and info.value > 0:
+            raise PosDefException(info.value)
+        return out.value, grad[:prm.size], gn.value
 
     def logpdf_batch(self, nodes, noises, n=None, check=True, programs=None):
         """log N(xs[1:n]; 0, K_p + noise_p I) for every particle p.  Returns (logpdf[P], info[P])."""

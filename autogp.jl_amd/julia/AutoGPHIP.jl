@@ -106,14 +106,13 @@ function logpdf_grad(eng::Engine, node::GP.Node, noise::Float64, n::Integer=eng.
     ops, prm = encode(node)
     np_ = length(prm)
     isempty(prm) && push!(prm, 0.0)
-    op_off = Int32[0, length(ops)]; prm_off = Int32[0, np_]
-    lp = [0.0]; grad = zeros(max(np_, 1)); gn = [0.0]; info = Int32[0]; nz = [noise]
-    GC.@preserve ops prm lp grad gn info nz check(eng, ccall((:agp_logpdf_grad_batch, LIB), Cint,
-        (Ptr{Cvoid}, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64},
-         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
-        eng.ptr, n, 1, op_off, ops, prm_off, prm, nz, lp, grad, gn, info))
-    info[1] > 0 && throw(LinearAlgebra.PosDefException(info[1]))
-    return lp[1], grad[1:np_], gn[1]
+    lp = Ref{Float64}(0.0); gn = Ref{Float64}(0.0); info = Ref{Int32}(0); grad = zeros(max(np_, 1))
+    # single-particle entry: calls from Threads.@threads loops are coalesced into batched gradient sweeps by the library
+    GC.@preserve ops prm grad check(eng, ccall((:agp_logpdf_grad, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{UInt8}, Int32, Ptr{Float64}, Int32, Float64, Ref{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Int32}),
+        eng.ptr, n, ops, length(ops), prm, np_, noise, lp, grad, gn, info))
+    info[] > 0 && throw(LinearAlgebra.PosDefException(info[]))
+    return lp[], grad[1:np_], gn[]
 end
 
 "Posterior predictive — replaces Distributions.MvNormal(node, noise, ts, xs, ts_pred; ...) (src/GP.jl:731-758)."

@@ -103,6 +103,14 @@ int agp_logpdf_grad_batch(agp_ctx* ctx, int64_t n, int32_t P,
                           double* out_logpdf /* P */, double* out_grad /* prm_off[P] */,
                           double* out_grad_noise /* P */, int32_t* out_info /* P */);
 
+/* The same for ONE particle, for callers that differentiate one trace per thread (Gen.choice_gradients inside
+ * Gen.hmc / Gen.map_optimize, one particle per Julia thread): re-entrant, concurrent callers are coalesced into
+ * batched gradient sweeps exactly like agp_logpdf.  out_grad has n_prm entries (may be null when n_prm == 0). */
+int agp_logpdf_grad(agp_ctx* ctx, int64_t n,
+                    const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
+                    double noise, double* out_logpdf, double* out_grad /* n_prm */,
+                    double* out_grad_noise, int32_t* out_info);
+
 /* Same sweep, results left in DEVICE memory (d_out_logpdf: P doubles, d_out_info: P int32,
  * both device pointers) and enqueued on `hip_stream` (a hipStream_t; NULL = the slot's own
  * stream, synchronised before return).  This is the entry the multi-GPU driver uses so that the

@@ -594,6 +594,32 @@ def test_coalescing_of_single_particle_callers(pkg, engine):
     assert c1 - c0 == 33 and b1 - b0 <= 12, (c1 - c0, b1 - b0)     # 33 calls served by a handful of sweeps
 
 
+def test_coalescing_of_single_particle_gradient_callers(pkg, engine):
+    """agp_logpdf_grad from many threads (one trace per thread, as Gen.choice_gradients is driven): the library
+    forms batched gradient sweeps; every caller gets exactly what the batch entry returns for its particle, and
+    value-only callers running at the same time are batched separately."""
+    ts, xs = pkg.prior.synthetic_series(300, seed=21, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(21), 24, max_depth=3, max_size=15)
+    engine.set_data(ts, xs)
+    ref = engine.logpdf_grad_batch(nodes, noises, check=False)
+    out = [None] * 48
+    def work(i):
+        j = i % 24
+        if i < 24:
+            out[i] = engine.logpdf_grad(nodes[j], float(noises[j]), check=False)
+        else:
+            out[i] = engine.logpdf(nodes[j], float(noises[j]), check=False)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(48)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for i in range(24):
+        if ref[3][i] != 0:
+            continue
+        lp, g, gn = out[i]
+        assert lp == ref[0][i] and gn == ref[2][i] and np.array_equal(g, ref[1][i])
+        assert out[24 + i] == ref[0][i]
+
+
 def test_device_output_entry(pkg, engine):
     """agp_logpdf_batch_device leaves results in caller-provided device memory on the caller's stream."""
     import torch

@@ -3,7 +3,7 @@
 // the call Gen makes at src/Model.jl:135-136).  The library coalesces the concurrent callers into batched
 // sweeps; this measures that path without a Python GIL in the way.  Test/measurement infrastructure only.
 //   build: g++ -O2 -std=c++17 -pthread -I include tools/native/threads_bench.cpp -L autogp.jl_amd/lib -lautogp_hip
-//   run:   threads_bench <n> <threads> <iters>
+//   run:   threads_bench <n> <threads> <iters> [grad]      (grad: agp_logpdf_grad instead of agp_logpdf)
 #include "autogp_hip.h"
 
 #include <atomic>
@@ -37,6 +37,7 @@ int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 2048;
   const int T = argc > 2 ? atoi(argv[2]) : 256;
   const int iters = argc > 3 ? atoi(argv[3]) : 8;
+  const bool grad = argc > 4 && argv[4][0] == 'g';
   agp_ctx* ctx = nullptr;
   if (agp_init(&ctx, 0) != 0) { fprintf(stderr, "agp_init: %s\n", agp_last_error(nullptr)); return 1; }
   std::mt19937_64 g(7);
@@ -56,8 +57,11 @@ int main(int argc, char** argv) {
         for (int r = 0; r < reps; ++r) {
           int32_t info = 0;
           const Particle& p = ps[t];
-          const int rc = agp_logpdf(ctx, n, p.ops.data(), (int32_t)p.ops.size(), p.prm.data(), (int32_t)p.prm.size(),
-                                    p.noise, &lp[t], &info);
+          double g[64], gn = 0.0;       // trees of depth <= 2: at most 4 leaves x 3 parameters
+          const int rc = grad ? agp_logpdf_grad(ctx, n, p.ops.data(), (int32_t)p.ops.size(), p.prm.data(), (int32_t)p.prm.size(),
+                                                p.noise, &lp[t], g, &gn, &info)
+                              : agp_logpdf(ctx, n, p.ops.data(), (int32_t)p.ops.size(), p.prm.data(), (int32_t)p.prm.size(),
+                                           p.noise, &lp[t], &info);
           if (rc != 0 || info != 0) bad.fetch_add(1);
         }
       });
@@ -80,9 +84,9 @@ int main(int argc, char** argv) {
   agp_logpdf_batch(ctx, n, T, oo.data(), ops.data(), po.data(), prm.data(), nz.data(), ref.data(), info.data());
   double maxd = 0.0;
   for (int t = 0; t < T; ++t) if (info[t] == 0) maxd = std::fmax(maxd, std::fabs(ref[t] - lp[t]) / std::fmax(1.0, std::fabs(ref[t])));
-  printf("{\"n\": %d, \"threads\": %d, \"calls\": %lld, \"seconds\": %.4f, \"evals_per_s\": %.1f, \"batches\": %lld, "
+  printf("{\"entry\": \"%s\", \"n\": %d, \"threads\": %d, \"calls\": %lld, \"seconds\": %.4f, \"evals_per_s\": %.1f, \"batches\": %lld, "
          "\"mean_batch\": %.1f, \"not_pd_or_failed\": %d, \"max_rel_diff_vs_batch_entry\": %.3g}\n",
-         n, T, (long long)(c1 - c0), dt, (double)T * iters / dt, (long long)(b1 - b0),
+         grad ? "agp_logpdf_grad" : "agp_logpdf", n, T, (long long)(c1 - c0), dt, (double)T * iters / dt, (long long)(b1 - b0),
          (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), bad.load(), maxd);
   agp_destroy(ctx);
   return 0;
