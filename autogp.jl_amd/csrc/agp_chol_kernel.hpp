@@ -55,6 +55,8 @@ struct CholArgs {
   int n_fused;          // particles [0, n_fused) evaluate their tiles; the rest have them prebuilt in A
   int* ready;           // [P] block columns whose L(k,k) is published (in-kernel solve); zeroed per sweep
   int wsteps;           // 1: W holds the current step's inverses only; nt: W keeps every step (gradient path)
+  int rl;               // factor mode, right-looking schedule: the tile already holds C(k,k) (no left-looking sum)
+  int j0;               // Schur mode: the sum runs over block columns [j0, nt1) (right-looking: one column)
 };
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       tl = 1 + (b - pp * (T - 1));
       xcd = pp & 7; pl = pp >> 3;
     }
-    tk = a.k; ti = a.k + tl; jmax = a.k;
+    tk = a.k; ti = a.k + tl; jmax = a.rl ? 0 : a.k;
   } else {
     xcd = b & 7; qq = b >> 3;
     const int nt2 = a.nt - a.nt1;
@@ -285,7 +287,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   constexpr int SLABS_PER_TILE = NB / KS;
   constexpr int SLAB_DOUBLES = KS * LDS_STRIDE;
   static_assert(2 * SLAB_DOUBLES <= U_MAIN_DOUBLES && (DM == 1 || 4 * SLAB_DOUBLES <= U_MAIN_DOUBLES), "slab buffers");
-  const int nslab = (AGP_DBG_SKIP & 4) ? 0 : jmax * SLABS_PER_TILE;
+  const int jfirst = FACTOR ? 0 : a.j0;          // first block column of the sum
+  const int nslab = (AGP_DBG_SKIP & 4) ? 0 : (jmax - jfirst) * SLABS_PER_TILE;
   if (nslab > 0) {
     // column operand: 256 threads stage the slab of tile (k,j), NU x 16 B each (element 2*(tid+256u));
     // row operand: each lane fetches its own two rows of tile (i,j) for k-step kk at column 4kk + lq
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     d2 ra[NU], rb[NU];
     double rx = 0.0;
     auto gload = [&](int s) {
-      const int j = s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
+      const int j = jfirst + s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
       const double* __restrict__ srcA = Ap + tile_off(ti, j) + (long long)cs * NB;
       const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
 #pragma unroll

@@ -110,6 +110,7 @@ struct agp_ctx {
   double* d_logdt = nullptr;      // packed lower tiles, covers the resident data
   size_t logdt_cap = 0;
   bool logdt_ok = false;
+  int right_looking = -1;   // right-looking factorisation for small populations: -1 auto, 0, 1; env AGP_RIGHT_LOOKING
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
@@ -494,12 +495,37 @@ struct Prof {
 // intrsm: one launch per block column (the panel solve runs inside k_chol_update behind the
 // per-particle ready word); otherwise update + k_chol_trsm launches.
 hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intrsm, Prof* pf, double* counts,
-                      bool split_diag = false) {
+                      bool split_diag = false, bool right_looking = false) {
+  if (dcov != 0 || nfac != ca.nt) right_looking = false;      // needs resident tiles and a full factorisation
   // (profiling marks are recorded on the stream the kernels are launched on)
   if (ca.wsteps < 1) ca.wsteps = 1;
   const int Pg = (ca.P + 7) / 8;
   for (int k = 0; k < nfac; ++k) {
     ca.k = k;
+    if (right_looking) {
+      // Right-looking schedule for small populations (all tiles prebuilt): factor the diagonal tile, solve the
+      // panel, then subtract the panel's outer product from EVERY trailing tile at once — (nt-k-1)(nt-k)/2
+      // independent 128x128x128 updates per particle and column instead of one long K-loop per tile, so a handful
+      // of particles still fills the GPU and the critical path per block column is one potrf + one solve + one
+      // 8-slab update.  (More HBM traffic than left-looking: every trailing tile is read and written each column.)
+      ca.rl = 1; ca.tiles = 1; ca.j0 = 0;
+      size_t e0 = pf ? pf->mark(st) : 0;
+      launch_update<true, false>(0, 8 * Pg, st, ca);
+      size_t e1 = pf ? pf->mark(st) : 0;
+      if (pf) pf->span(3, e0, e1);
+      if (counts) counts[1] += 1;
+      const int T2 = ca.nt - k - 1;
+      if (T2 > 0) {
+        hipLaunchKernelGGL(k_chol_trsm, dim3(8 * Pg * T2), dim3(256), 0, st, ca);
+        CholArgs cu = ca;
+        cu.rl = 0; cu.nt1 = k + 1; cu.j0 = k;
+        launch_update<false, false>(0, 8 * Pg * (T2 * (T2 + 1) / 2), st, cu);
+        size_t e2 = pf ? pf->mark(st) : 0;
+        if (pf) pf->span(2, e1, e2);
+        if (counts) counts[0] += 1;
+      }
+      continue;
+    }
     if (intrsm && split_diag) {
       ca.t0 = 1;
       // diagonal tiles in their own (specialised, lower-triangle-only) launch, then the sub-diagonal tiles, which
@@ -555,6 +581,12 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intr
 constexpr int SPLIT_DIAG_MIN_PARTICLES = 256;
 inline bool use_split_diag(const agp_ctx* c, int P) {
   return c->split_diag > 0 || (c->split_diag < 0 && P >= SPLIT_DIAG_MIN_PARTICLES);
+}
+
+// Right-looking schedule (see run_factor): below this many particles the left-looking launches cannot fill the GPU.
+constexpr int RIGHT_LOOKING_MAX_PARTICLES = 48;
+inline bool use_right_looking(const agp_ctx* c, int P) {
+  return c->right_looking > 0 || (c->right_looking < 0 && P <= RIGHT_LOOKING_MAX_PARTICLES);
 }
 
 struct GradOut {
@@ -740,7 +772,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         set_cov(ca, cv);
         ca.n_fused = nf;
         ca.ready = s->ready.as<int>() + g0;
-        HIPCHK(c, run_factor(q, ca, nt, dcov, intrsm, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr, use_split_diag(c, ca.P)));
+        HIPCHK(c, run_factor(q, ca, nt, dcov, intrsm, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr, use_split_diag(c, ca.P),
+                             use_right_looking(c, ca.P)));
 
         size_t e2 = pf.mark(q);
         hipLaunchKernelGGL(k_finish_logpdf, dim3((Pg + 63) / 64), dim3(64), 0, q, ca.partial, ca.info, nt, Pg, (int)n,
@@ -866,6 +899,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_TRTRI_CHAIN")) c->trtri_chain = atoi(e) != 0;
   if (const char* e = getenv("AGP_SPLIT_DIAG")) c->split_diag = atoi(e);
   if (const char* e = getenv("AGP_GE_TABLE")) c->ge_table = atoi(e) != 0;
+  if (const char* e = getenv("AGP_RIGHT_LOOKING")) c->right_looking = atoi(e);
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
   if (const char* e = getenv("AGP_FUSE_MAX_US")) c->fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
