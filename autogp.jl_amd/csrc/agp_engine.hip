@@ -110,6 +110,7 @@ struct agp_ctx {
   double* d_logdt = nullptr;      // packed lower tiles, covers the resident data
   size_t logdt_cap = 0;
   bool logdt_ok = false;
+  int hybrid_blocks = 512;  // medium populations: switch to right-looking once a column has fewer workgroups; 0 = never; env AGP_HYBRID_BLOCKS
   int right_looking = -1;   // right-looking factorisation for small populations: -1 auto, 0, 1; env AGP_RIGHT_LOOKING
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -495,13 +496,34 @@ struct Prof {
 // intrsm: one launch per block column (the panel solve runs inside k_chol_update behind the
 // per-particle ready word); otherwise update + k_chol_trsm launches.
 hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intrsm, Prof* pf, double* counts,
-                      bool split_diag = false, bool right_looking = false) {
+                      bool split_diag = false, bool right_looking = false, int hybrid_blocks = 0) {
   if (dcov != 0 || nfac != ca.nt) right_looking = false;      // needs resident tiles and a full factorisation
   // (profiling marks are recorded on the stream the kernels are launched on)
   if (ca.wsteps < 1) ca.wsteps = 1;
   const int Pg = (ca.P + 7) / 8;
+  // Hybrid for medium populations: left-looking while a block column still offers >= hybrid_blocks workgroups,
+  // then ONE catch-up launch brings the whole trailing block up to date with the columns factored so far (the
+  // Schur-mode update) and the remaining columns run right-looking, where every trailing tile is an independent
+  // short update instead of a few long K-loops on a mostly idle GPU.
+  int k_switch = nfac;
+  if (!right_looking && hybrid_blocks > 0 && dcov == 0 && nfac == ca.nt && !split_diag) {
+    for (int k = 1; k < nfac; ++k)
+      if ((long long)ca.P * (ca.nt - k) < hybrid_blocks) { k_switch = k; break; }
+    if (k_switch >= nfac - 1) k_switch = nfac;       // a single trailing column gains nothing
+  }
   for (int k = 0; k < nfac; ++k) {
     ca.k = k;
+    if (k == k_switch) {
+      CholArgs cu = ca;
+      cu.rl = 0; cu.nt1 = k; cu.j0 = 0;
+      const int T2 = ca.nt - k;
+      size_t e0 = pf ? pf->mark(st) : 0;
+      launch_update<false, false>(0, 8 * Pg * (T2 * (T2 + 1) / 2), st, cu);
+      size_t e1 = pf ? pf->mark(st) : 0;
+      if (pf) pf->span(2, e0, e1);
+      if (counts) counts[0] += 1;
+      right_looking = true;
+    }
     if (right_looking) {
       // Right-looking schedule for small populations (all tiles prebuilt): factor the diagonal tile, solve the
       // panel, then subtract the panel's outer product from EVERY trailing tile at once — (nt-k-1)(nt-k)/2
@@ -773,7 +795,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         ca.n_fused = nf;
         ca.ready = s->ready.as<int>() + g0;
         HIPCHK(c, run_factor(q, ca, nt, dcov, intrsm, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr, use_split_diag(c, ca.P),
-                             use_right_looking(c, ca.P)));
+                             use_right_looking(c, ca.P), c->hybrid_blocks));
 
         size_t e2 = pf.mark(q);
         hipLaunchKernelGGL(k_finish_logpdf, dim3((Pg + 63) / 64), dim3(64), 0, q, ca.partial, ca.info, nt, Pg, (int)n,
@@ -900,6 +922,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_SPLIT_DIAG")) c->split_diag = atoi(e);
   if (const char* e = getenv("AGP_GE_TABLE")) c->ge_table = atoi(e) != 0;
   if (const char* e = getenv("AGP_RIGHT_LOOKING")) c->right_looking = atoi(e);
+  if (const char* e = getenv("AGP_HYBRID_BLOCKS")) c->hybrid_blocks = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
   if (const char* e = getenv("AGP_FUSE_MAX_US")) c->fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
