@@ -488,27 +488,32 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     // ---- (a) wave 0: 16x16 Cholesky of block (jb,jb) + its inverse, on lane broadcasts ----
     if (w == 0 && !(AGP_DBG_SKIP & 16)) {
       double* blk = sm + blk_idx(jb, jb) * 256;
-      double s[16], rinvs[16], wv[16];
+      // Lane r (= l15) holds row r of the block in s[] and column r of X in wv[] (X starts as I, ends as L^-1).
+      // Column c of L, once scaled, is broadcast lane by lane (v_readlane -> scalar pair); each scalar drives the
+      // trailing update of the block AND the forward substitution L X = I in the same step, so it is consumed at
+      // once (factoring first and inverting afterwards needs every broadcast twice, or parks 240 scalars in
+      // spill lanes).  This step is instruction-issue bound (one wave, 4 cycles per instruction).
+      double s[16], wv[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) s[c] = blk[c * 16 + l15];
+      for (int c = 0; c < 16; ++c) { s[c] = blk[c * 16 + l15]; wv[c] = (c == l15) ? 1.0 : 0.0; }
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         const double pc = readlane_d(s[c], c);
         if (!(pc > 0.0) && bad == 0) bad = a.k * NB + jb * 16 + c + 1;
         const double rinv = rsqrt(pc);
-        rinvs[c] = rinv;
         const double lrc = s[c] * rinv;
         s[c] = lrc;
+        const double xc = wv[c] * rinv;
+        wv[c] = xc;
 #pragma unroll
-        for (int c2 = c + 1; c2 < 16; ++c2) s[c2] = fma(-lrc, readlane_d(lrc, c2), s[c2]);
-      }
-      // W = L^-1: lane `col` owns column `col`; W[r][col] for r = 0..15
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        double t = (r == l15) ? 1.0 : 0.0;
-#pragma unroll
-        for (int q = 0; q < r; ++q) t = fma(-readlane_d(s[q], r), wv[q], t);
-        wv[r] = t * rinvs[r];
+        for (int c2 = c + 1; c2 < 16; ++c2) {
+          const double v = readlane_d(lrc, c2);      // L[c2][c] as a wave-uniform scalar
+          s[c2] = fma(-lrc, v, s[c2]);
+          wv[c2] = fma(-v, xc, wv[c2]);
+          // pin the substitution update here: left alone, the optimiser sinks all of them behind the factorisation
+          // chain and keeps every scalar alive (in spill lanes) until then
+          asm volatile("" : "+v"(wv[c2]));
+        }
       }
       if (l < 16) {
         double* Wg = a.W + (((long long)p * a.wsteps + a.k % a.wsteps) * NSB + jb) * 256;
