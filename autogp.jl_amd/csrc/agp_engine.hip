@@ -40,8 +40,25 @@ struct DevBuf {
   template <typename T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
+// pinned host staging (truly asynchronous copies, one per direction and call)
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct Slot {
   hipStream_t stream = nullptr;
+  DevBuf stage;             // one upload per sweep: [hdr | prm | noise | map | ops]
+  HostBuf h_stage, h_out;   // its pinned source, and the pinned landing zone of [logpdf | info]
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
       Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist;
@@ -54,6 +71,7 @@ struct Slot {
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
                       &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist})
       b->release();
+    stage.release(); h_stage.release(); h_out.release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
     for (auto e : sub_ev) (void)hipEventDestroy(e);
@@ -666,6 +684,13 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
 
   double* d_lp = d_user_lp;
   int32_t* d_info_out = d_user_info;
+  // engine-owned results live in ONE buffer [logpdf (P doubles) | info (P ints)] so that they come back in one copy
+  const bool own_out = !d_lp && !d_info_out;
+  if (own_out) {
+    HIPCHK(c, s->out_lp.ensure(sizeof(double) * P + sizeof(int32_t) * P));
+    d_lp = s->out_lp.as<double>();
+    d_info_out = reinterpret_cast<int32_t*>(d_lp + P);
+  }
   if (!d_lp) { HIPCHK(c, s->out_lp.ensure(sizeof(double) * P)); d_lp = s->out_lp.as<double>(); }
   if (!d_info_out) { HIPCHK(c, s->out_info.ensure(sizeof(int32_t) * P)); d_info_out = s->out_info.as<int32_t>(); }
 
@@ -703,23 +728,36 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
     HIPCHK(c, s->info.ensure(sizeof(int) * (size_t)chunk));
     HIPCHK(c, s->ready.ensure(sizeof(int) * (size_t)chunk));
-    HIPCHK(c, s->hdr.ensure(sizeof(ProgHdr) * (size_t)P));
-    HIPCHK(c, s->ops.ensure(bt.ops.size()));
-    HIPCHK(c, s->prm.ensure(sizeof(double) * std::max<size_t>(1, bt.prm.size())));
-    HIPCHK(c, s->noise.ensure(sizeof(double) * (size_t)P));
+    // ---- one pinned-memory upload: [hdr | prm | noise (sorted) | map | ops], 16-byte aligned sections ----
+    auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_hdr = 0;
+    const size_t o_prm = al16(o_hdr + sizeof(ProgHdr) * (size_t)P);
+    const size_t o_noise = al16(o_prm + sizeof(double) * std::max<size_t>(1, bt.prm.size()));
+    const size_t o_map = al16(o_noise + sizeof(double) * (size_t)P);
+    const size_t o_ops = al16(o_map + sizeof(int32_t) * (size_t)P);
+    const size_t stage_bytes = al16(o_ops + bt.ops.size() + 4);
+    HIPCHK(c, s->stage.ensure(stage_bytes));
+    HIPCHK(c, s->h_stage.ensure(stage_bytes));
+    {
+      char* h = static_cast<char*>(s->h_stage.p);
+      std::memcpy(h + o_hdr, bt.hdr.data(), sizeof(ProgHdr) * (size_t)P);
+      if (!bt.prm.empty()) std::memcpy(h + o_prm, bt.prm.data(), sizeof(double) * bt.prm.size());
+      double* hn = reinterpret_cast<double*>(h + o_noise);
+      for (int q = 0; q < P; ++q) hn[q] = noise[bt.order[q]];
+      std::memcpy(h + o_map, bt.order.data(), sizeof(int32_t) * (size_t)P);
+      std::memcpy(h + o_ops, bt.ops.data(), bt.ops.size());
+    }
+    char* dstage = static_cast<char*>(s->stage.p);
+    ProgHdr* d_hdr = reinterpret_cast<ProgHdr*>(dstage + o_hdr);
+    double* d_prm = reinterpret_cast<double*>(dstage + o_prm);
+    double* d_noise = reinterpret_cast<double*>(dstage + o_noise);
+    int32_t* d_map = reinterpret_cast<int32_t*>(dstage + o_map);
+    uint8_t* d_ops = reinterpret_cast<uint8_t*>(dstage + o_ops);
 
     Prof pf{c, s, st, c->profiling};
     double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     size_t ev_begin = pf.mark();
-    HIPCHK(c, hipMemcpyAsync(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr) * P, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(s->ops.p, bt.ops.data(), bt.ops.size(), hipMemcpyHostToDevice, st));
-    if (!bt.prm.empty())
-      HIPCHK(c, hipMemcpyAsync(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size(), hipMemcpyHostToDevice, st));
-    std::vector<double> noise_sorted(P);
-    for (int q = 0; q < P; ++q) noise_sorted[q] = noise[bt.order[q]];
-    HIPCHK(c, s->map.ensure(sizeof(int32_t) * (size_t)P));
-    HIPCHK(c, hipMemcpyAsync(s->noise.p, noise_sorted.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(s->map.p, bt.order.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(dstage, s->h_stage.p, stage_bytes, hipMemcpyHostToDevice, st));
     std::vector<int32_t> goff_sorted;
     if (go) {
       goff_sorted.resize(P);
@@ -765,8 +803,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
                            s->info.as<int>() + g0, s->ready.as<int>() + g0);
         CovArgs cv = {};
         cv.tt = c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
-        cv.hdr = s->hdr.as<ProgHdr>() + p0 + g0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
-        cv.noise = s->noise.as<double>() + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
+        cv.hdr = d_hdr + p0 + g0; cv.ops = d_ops; cv.prm = d_prm;
+        cv.noise = d_noise + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
         cv.strideA = strideA; cv.P = Pg; cv.logdt = ge_tab ? c->d_logdt : nullptr;
         // Hybrid build.  Sorted particles [0, n_fused) evaluate their own tiles inside k_chol_update
         // (only the sub-diagonal tiles of block column 0, which k_chol_trsm(0) reads, are
@@ -799,7 +837,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
 
         size_t e2 = pf.mark(q);
         hipLaunchKernelGGL(k_finish_logpdf, dim3((Pg + 63) / 64), dim3(64), 0, q, ca.partial, ca.info, nt, Pg, (int)n,
-                           s->map.as<int>() + p0 + g0, d_lp, d_info_out);
+                           d_map + p0 + g0, d_lp, d_info_out);
         size_t e3 = pf.mark(q);
         pf.span(4, e2, e3);
         HIPCHK(c, hipGetLastError());
@@ -813,7 +851,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           ga.grc = s->grc.as<uint8_t>(); ga.gpoff = s->gpoff.as<int32_t>(); ga.gprm = s->gprm.as<double>();
           ga.tt = c->d_ts; ga.gpart = s->gpart.as<double>() + (size_t)g0 * ntiles * gstride; ga.gstride = gstride;
           ga.gmap = s->gmap.as<int32_t>(); ga.out_off = s->goff.as<int32_t>() + p0 + g0;
-          ga.pmap = s->map.as<int32_t>() + p0 + g0; ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
+          ga.pmap = d_map + p0 + g0; ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
           const int Pg8 = (Pg + 7) / 8;
           if (c->trtri_chain) {
             hipLaunchKernelGGL(k_trtri_chain, dim3(8 * Pg8 * nt), dim3(256), 0, q, ga);
@@ -865,7 +903,13 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     }
   }
 
-  if (h_out_lp) HIPCHK(c, hipMemcpyAsync(h_out_lp, d_lp, sizeof(double) * P, hipMemcpyDeviceToHost, st));
+  const size_t out_bytes = sizeof(double) * P + sizeof(int32_t) * P;
+  if (own_out) {
+    HIPCHK(c, s->h_out.ensure(out_bytes));
+    HIPCHK(c, hipMemcpyAsync(s->h_out.p, d_lp, out_bytes, hipMemcpyDeviceToHost, st));
+  } else if (h_out_lp) {
+    HIPCHK(c, hipMemcpyAsync(h_out_lp, d_lp, sizeof(double) * P, hipMemcpyDeviceToHost, st));
+  }
   if (go && n > 0) {
     if (n_prm_total > 0)
       HIPCHK(c, hipMemcpyAsync(go->grad, s->dgrad.p, sizeof(double) * n_prm_total, hipMemcpyDeviceToHost, st));
@@ -874,10 +918,15 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   std::vector<int32_t> info_chk;
   int32_t* h_info = h_out_info;
   if (!h_info) { info_chk.resize(P); h_info = info_chk.data(); }
-  HIPCHK(c, hipMemcpyAsync(h_info, d_info_out, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
+  if (!own_out) HIPCHK(c, hipMemcpyAsync(h_info, d_info_out, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
   // The slot's buffers are reused by the next caller, so the work must be complete before the
   // slot is released even on the user-stream path.
   HIPCHK(c, hipStreamSynchronize(st));
+  if (own_out) {
+    const double* hl = static_cast<const double*>(s->h_out.p);
+    if (h_out_lp) std::memcpy(h_out_lp, hl, sizeof(double) * P);
+    std::memcpy(h_info, hl + P, sizeof(int32_t) * P);
+  }
   for (int p = 0; p < P; ++p)
     if (h_info[p] < 0) return fail(c, AGP_ERR_HIP, "in-kernel panel solve timed out waiting for its diagonal factor");
   return AGP_OK;
