@@ -1234,7 +1234,8 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
       // last batch's size queued, or until the budget is spent: min(window, a quarter of the last sweep), so
       // that small problems are not delayed by a window sized for large ones.  A lone caller never waits.
       const size_t target = (size_t)std::max(1, c->batch_hint + c->batch_prev);
-      if (target > 1 || c->queue.size() > 1) {
+      const bool lone = c->batch_hint <= 1 && c->batch_prev <= 1 && c->queue.size() == 1;   // no concurrency seen lately
+      if (!lone) {
         using clk = std::chrono::steady_clock;
         const double budget_us = std::min((double)c->coalesce_us, std::max(20.0, 0.25 * c->last_sweep_us));
         const auto quiet = std::chrono::microseconds(std::max(5, (int)std::min(40.0, budget_us / 4)));
