@@ -121,6 +121,158 @@ constexpr int T_LDS_DOUBLES = (T_NBLK + NSB) * 256;      // + 8 inverse blocks =
 static_assert(T_LDS_DOUBLES <= U_MAIN_DOUBLES, "solve staging must fit the aliased slab buffers");
 __device__ __forceinline__ int sblk_idx(int jb, int lb) { return jb * (jb - 1) / 2 + lb; }   // lb < jb
 
+// Factor the 128x128 diagonal tile whose -C(k,k) lower 16x16 blocks have been staged in `sm` (block (rb,cb) at
+// blk_idx(rb,cb)*256, column-major): 16x16-blocked right-looking Cholesky with the diagonal 16x16 step in one wave
+// and panel / trailing updates on MFMA; carries the forward solve (rv = this thread's entry of r_k, tid < 128),
+// writes L(k,k), alpha_k, the log-det / alpha'alpha partials, LAPACK info and the block inverses W, and (INTRSM)
+// publishes ready[p] = k+1.  Shared by the mixed and the diagonal-only kernels.
+template <bool INTRSM>
+__device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int tk, double* __restrict__ Tt,
+                                                 double* vecp, double* sm, double* rvec, double* avec, double* Wl,
+                                                 double rv, int tid) {
+  const int l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  (void)lq;
+  if (tid < NB) rvec[tid] = rv;
+  __syncthreads();
+
+  int bad = 0;           // first non-positive pivot (1-based global index), 0 = none
+
+  for (int jb = 0; jb < ((AGP_DBG_SKIP & 2) ? 0 : NSB); ++jb) {
+    // ---- (a) wave 0: 16x16 Cholesky of block (jb,jb) + its inverse, on lane broadcasts ----
+    if (w == 0 && !(AGP_DBG_SKIP & 16)) {
+      double* blk = sm + blk_idx(jb, jb) * 256;
+      // Lane r (= l15) holds row r of the block in s[] and column r of X in wv[] (X starts as I, ends as L^-1).
+      // Column c of L, once scaled, is broadcast lane by lane (v_readlane -> scalar pair); each scalar drives the
+      // trailing update of the block AND the forward substitution L X = I in the same step, so it is consumed at
+      // once (factoring first and inverting afterwards needs every broadcast twice, or parks 240 scalars in
+      // spill lanes).  This step is instruction-issue bound (one wave, 4 cycles per instruction).
+      double s[16], wv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) { s[c] = blk[c * 16 + l15]; wv[c] = (c == l15) ? 1.0 : 0.0; }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double pc = readlane_d(s[c], c);
+        if (!(pc > 0.0) && bad == 0) bad = a.k * NB + jb * 16 + c + 1;
+        const double rinv = rsqrt(pc);
+        const double lrc = s[c] * rinv;
+        s[c] = lrc;
+        const double xc = wv[c] * rinv;
+        wv[c] = xc;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; ++c2) {
+          const double v = readlane_d(lrc, c2);      // L[c2][c] as a wave-uniform scalar
+          s[c2] = fma(-lrc, v, s[c2]);
+          wv[c2] = fma(-v, xc, wv[c2]);
+          // pin the substitution update here: left alone, the optimiser sinks all of them behind the factorisation
+          // chain and keeps every scalar alive (in spill lanes) until then
+          asm volatile("" : "+v"(wv[c2]));
+        }
+      }
+      if (l < 16) {
+        double* Wg = a.W + (((long long)p * a.wsteps + a.k % a.wsteps) * NSB + jb) * 256;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) blk[c * 16 + l] = (c <= l) ? s[c] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          Wl[l * 16 + r] = wv[r];
+          Wg[l * 16 + r] = wv[r];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- (b) panel: L(ib,jb) = S(ib,jb) W^T for ib > jb (MFMA); alpha_jb = W r_jb ----
+    for (int ib = jb + 1 + w; ib < ((AGP_DBG_SKIP & 32) ? 0 : NSB); ib += 4) {
+      double* blk = sm + blk_idx(ib, jb) * 256;
+      double fw[4], fs[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) { fw[s4] = Wl[64 * s4 + l]; fs[s4] = blk[64 * s4 + l]; }
+      d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) x = mfma(fw[s4], fs[s4], x);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) blk[64 * r + l] = x[r];
+    }
+    if (w == 3 && l < 16) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) t = fma(Wl[q * 16 + l], rvec[jb * 16 + q], t);
+      avec[jb * 16 + l] = t;
+    }
+    __syncthreads();
+
+    // ---- (c) trailing blocks (ib,cb), jb < cb <= ib: S(ib,cb) -= L(ib,jb) L(cb,jb)^T;
+    //      r_ib -= L(ib,jb) alpha_jb ----
+    {
+      const int nrem = NSB - 1 - jb;              // block rows below jb
+      const int npair = nrem * (nrem + 1) / 2;
+      for (int e = w; e < ((AGP_DBG_SKIP & 64) ? 0 : npair); e += 4) {
+        int ii = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+        while (ii * (ii + 1) / 2 > e) --ii;
+        while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
+        const int cc = e - ii * (ii + 1) / 2;
+        const int ib = jb + 1 + ii, cb = jb + 1 + cc;
+        double* blk = sm + blk_idx(ib, cb) * 256;
+        const double* la = sm + blk_idx(cb, jb) * 256;
+        const double* lb = sm + blk_idx(ib, jb) * 256;
+        d4 x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[r] = blk[64 * r + l];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) x = mfma(-la[64 * s4 + l], lb[64 * s4 + l], x);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) blk[64 * r + l] = x[r];
+      }
+      if (tid < NB && tid >= (jb + 1) * 16) {
+        const double* lb = sm + blk_idx(tid >> 4, jb) * 256;
+        double t = rvec[tid];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t = fma(-lb[q * 16 + (tid & 15)], avec[jb * 16 + q], t);
+        rvec[tid] = t;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write L(k,k) (upper part zero), alpha_k, partials, info ----
+  for (int bi = 0; bi < NSB * NSB; ++bi) {
+    const int rb = bi >> 3, cb = bi & 7;
+    const int c = tid >> 4, r = tid & 15;
+    const double v = (rb >= cb) ? sm[blk_idx(rb, cb) * 256 + tid] : 0.0;
+    Tt[(cb * 16 + c) * NB + rb * 16 + r] = v;
+  }
+  if (tid < NB) {
+    vecp[tk * NB + tid] = avec[tid];
+    // log|K_kk-block| = 2 sum log L_ii, all 128 logs in parallel (diag of block (b,b) at 17*i)
+    const double dii = sm[blk_idx(tid >> 4, tid >> 4) * 256 + 17 * (tid & 15)];
+    Wl[tid] = 2.0 * log(dii);
+  }
+  __syncthreads();
+  if (w == 0) {
+    double ss = avec[l] * avec[l] + avec[l + 64] * avec[l + 64];
+    double ld = Wl[l] + Wl[l + 64];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); ld += __shfl_xor(ld, off); }
+    if (l == 0) {
+      double* pp = a.partial + ((long long)p * a.nt + tk) * 2;
+      pp[0] = ld;
+      pp[1] = ss;
+      if (bad != 0 && a.info[p] == 0) a.info[p] = bad;
+    }
+  }
+  if (INTRSM) {
+    // publish L(k,k) and its block inverses to the workgroups solving this particle's panel:
+    // every wave drains its stores, one lane releases at agent scope, then sets the ready word
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a.ready + p, a.k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // the two strip values of one tile column for this lane (rows rowA and rowB of column `col`); ADJ: rowB = rowA + 1
 template <bool ADJ = ILV>
 __device__ __forceinline__ d2 ld_pair(const double* T, int col, int rowA, int rowB) {
@@ -479,145 +631,197 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
         for (int r = 0; r < 4; ++r) blk[(4 * r + lq) * 16 + rr] = -acc[cb][st][r];
       }
   }
-  if (tid < NB) rvec[tid] = rv;
-  __syncthreads();
+  factor_diag_tile<INTRSM>(a, p, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid);
+}
 
-  int bad = 0;           // first non-positive pivot (1-based global index), 0 = none
+// K2a — the diagonal tiles of block column k, one workgroup per particle.  Only the lower block triangle of
+// C(k,k) = A(k,k) - sum_j L(k,j) L(k,j)^T is formed: wave w owns the 16-row blocks w (strip 0) and 7-w (strip 1),
+// i.e. NINE 16x16 accumulator blocks per wave whatever w is — entry e of the wave's list is (strip 0, column block
+// e) for e <= w and (strip 1, column block e-w-1) after that.  The list index is static, so every accumulator
+// has a compile-time register and the MFMA loop is branch-free; which column block / which strip an entry stands
+// for only enters through wave-uniform LDS offsets and selects.  Both operands of the update are the same tile
+// (k,j): its 32-column slab is staged once in LDS and read as row fragments and as column fragments.
+template <int DCOV, bool TAB>
+__global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
+  static_assert(!TAB || DCOV > 0, "the log|dt| table only matters to instantiations that evaluate tiles");
+  __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
+  double* rvec = sm + U_MAIN_DOUBLES;
+  double* avec = rvec + 128;
+  double* xv = avec + 128;     // [2][32]
+  double* Wl = xv + 64;        // [256]
+  constexpr int NE = NSB + 1;  // accumulator blocks per wave
 
-  for (int jb = 0; jb < ((AGP_DBG_SKIP & 2) ? 0 : NSB); ++jb) {
-    // ---- (a) wave 0: 16x16 Cholesky of block (jb,jb) + its inverse, on lane broadcasts ----
-    if (w == 0 && !(AGP_DBG_SKIP & 16)) {
-      double* blk = sm + blk_idx(jb, jb) * 256;
-      // Lane r (= l15) holds row r of the block in s[] and column r of X in wv[] (X starts as I, ends as L^-1).
-      // Column c of L, once scaled, is broadcast lane by lane (v_readlane -> scalar pair); each scalar drives the
-      // trailing update of the block AND the forward substitution L X = I in the same step, so it is consumed at
-      // once (factoring first and inverting afterwards needs every broadcast twice, or parks 240 scalars in
-      // spill lanes).  This step is instruction-issue bound (one wave, 4 cycles per instruction).
-      double s[16], wv[16];
+  const int b = blockIdx.x, xcd = b & 7, pl = b >> 3;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const int tk = a.k;
+  const int jmax = a.rl ? 0 : a.k;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const int row0 = 16 * w + l15, row1 = 16 * (NSB - 1 - w) + l15;
+  // wave-uniform description of the nine entries
+  int cbe[NE];
+  bool st1[NE];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) { s[c] = blk[c * 16 + l15]; wv[c] = (c == l15) ? 1.0 : 0.0; }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const double pc = readlane_d(s[c], c);
-        if (!(pc > 0.0) && bad == 0) bad = a.k * NB + jb * 16 + c + 1;
-        const double rinv = rsqrt(pc);
-        const double lrc = s[c] * rinv;
-        s[c] = lrc;
-        const double xc = wv[c] * rinv;
-        wv[c] = xc;
-#pragma unroll
-        for (int c2 = c + 1; c2 < 16; ++c2) {
-          const double v = readlane_d(lrc, c2);      // L[c2][c] as a wave-uniform scalar
-          s[c2] = fma(-lrc, v, s[c2]);
-          wv[c2] = fma(-v, xc, wv[c2]);
-          // pin the substitution update here: left alone, the optimiser sinks all of them behind the factorisation
-          // chain and keeps every scalar alive (in spill lanes) until then
-          asm volatile("" : "+v"(wv[c2]));
-        }
-      }
-      if (l < 16) {
-        double* Wg = a.W + (((long long)p * a.wsteps + a.k % a.wsteps) * NSB + jb) * 256;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) blk[c * 16 + l] = (c <= l) ? s[c] : 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          Wl[l * 16 + r] = wv[r];
-          Wg[l * 16 + r] = wv[r];
-        }
-      }
-    }
+  for (int e = 0; e < NE; ++e) { st1[e] = e > wu; cbe[e] = st1[e] ? e - (wu + 1) : e; }
+
+  double* __restrict__ Ap = a.A + (long long)p * a.strideA;
+  double* vecp = a.vec + (long long)p * a.ldv;
+  double* __restrict__ Tt = Ap + tile_off(tk, tk);
+  d4 acc[NE];
+  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused);
+  if (!prebuilt) {
+    const ProgHdr h = a.hdr[p];
+    double* tpt = sm;
+    double* sig = sm + 256;
+    double* prm = sig + h.n_cp * 256;
+    int* ops = reinterpret_cast<int*>(prm + h.n_prm + 2);
+    for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
+    for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
     __syncthreads();
-
-    // ---- (b) panel: L(ib,jb) = S(ib,jb) W^T for ib > jb (MFMA); alpha_jb = W r_jb ----
-    for (int ib = jb + 1 + w; ib < ((AGP_DBG_SKIP & 32) ? 0 : NSB); ib += 4) {
-      double* blk = sm + blk_idx(ib, jb) * 256;
-      double fw[4], fs[4];
+    cov_prologue(a.tt, a.code, tk, tk, h, ops, prm, tpt, sig, tid);
+    const double noise = a.noise[p];
+    const bool use_tab = TAB && (h.flags & 1) != 0;
+    const double* __restrict__ ltile = a.logdt + tile_off(tk, tk);      // only dereferenced when use_tab
+#pragma unroll 1
+    for (int e = 0; e < NE; ++e) {
+      const bool s1 = e > wu;
+      const int cb = s1 ? e - (wu + 1) : e;
+      const int rslot = s1 ? row1 : row0;
+      double tr[4], tc[4], out[4];
+      double lt[4] = {0.0, 0.0, 0.0, 0.0};
+      int ri[4], ci[4];
+      if (use_tab) {
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) { fw[s4] = Wl[64 * s4 + l]; fs[s4] = blk[64 * s4 + l]; }
-      d4 x = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) x = mfma(fw[s4], fs[s4], x);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) blk[64 * r + l] = x[r];
-    }
-    if (w == 3 && l < 16) {
-      double t = 0.0;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) t = fma(Wl[q * 16 + l], rvec[jb * 16 + q], t);
-      avec[jb * 16 + l] = t;
-    }
-    __syncthreads();
-
-    // ---- (c) trailing blocks (ib,cb), jb < cb <= ib: S(ib,cb) -= L(ib,jb) L(cb,jb)^T;
-    //      r_ib -= L(ib,jb) alpha_jb ----
-    {
-      const int nrem = NSB - 1 - jb;              // block rows below jb
-      const int npair = nrem * (nrem + 1) / 2;
-      for (int e = w; e < ((AGP_DBG_SKIP & 64) ? 0 : npair); e += 4) {
-        int ii = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        while (ii * (ii + 1) / 2 > e) --ii;
-        while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
-        const int cc = e - ii * (ii + 1) / 2;
-        const int ib = jb + 1 + ii, cb = jb + 1 + cc;
-        double* blk = sm + blk_idx(ib, cb) * 256;
-        const double* la = sm + blk_idx(cb, jb) * 256;
-        const double* lb = sm + blk_idx(ib, jb) * 256;
-        d4 x;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[r] = blk[64 * r + l];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) x = mfma(-la[64 * s4 + l], lb[64 * s4 + l], x);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) blk[64 * r + l] = x[r];
+        for (int r = 0; r < 4; ++r) lt[r] = ltile[(cb * 16 + 4 * r + lq) * NB + rslot];
       }
-      if (tid < NB && tid >= (jb + 1) * 16) {
-        const double* lb = sm + blk_idx(tid >> 4, jb) * 256;
-        double t = rvec[tid];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t = fma(-lb[q * 16 + (tid & 15)], avec[jb * 16 + q], t);
-        rvec[tid] = t;
+      for (int r = 0; r < 4; ++r) {
+        const int cslot = cb * 16 + 4 * r + lq;
+        tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
+        ri[r] = rslot; ci[r] = NB + cslot;
+      }
+      eval_program<(DCOV > 0 ? DCOV : 4), 4, (TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out);
+      d4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        v[r] = -cov_finalize(out[r], tk * NB + rslot, tk * NB + cb * 16 + 4 * r + lq, a.n1, a.n1_pad, a.m2, noise);
+      switch (e) {   // wave-uniform scalar dispatch keeps every accumulator index static
+        case 0: acc[0] = v; break; case 1: acc[1] = v; break; case 2: acc[2] = v; break;
+        case 3: acc[3] = v; break; case 4: acc[4] = v; break; case 5: acc[5] = v; break;
+        case 6: acc[6] = v; break; case 7: acc[7] = v; break; default: acc[8] = v; break;
       }
     }
-    __syncthreads();
+    __syncthreads();   // the sigma tables alias the slab buffers
+  } else {
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[e] = d4{0.0, 0.0, 0.0, 0.0};
   }
 
-  // ---- write L(k,k) (upper part zero), alpha_k, partials, info ----
-  for (int bi = 0; bi < NSB * NSB; ++bi) {
-    const int rb = bi >> 3, cb = bi & 7;
-    const int c = tid >> 4, r = tid & 15;
-    const double v = (rb >= cb) ? sm[blk_idx(rb, cb) * 256 + tid] : 0.0;
-    Tt[(cb * 16 + c) * NB + rb * 16 + r] = v;
-  }
-  if (tid < NB) {
-    vecp[tk * NB + tid] = avec[tid];
-    // log|K_kk-block| = 2 sum log L_ii, all 128 logs in parallel (diag of block (b,b) at 17*i)
-    const double dii = sm[blk_idx(tid >> 4, tid >> 4) * 256 + 17 * (tid & 15)];
-    Wl[tid] = 2.0 * log(dii);
-  }
-  __syncthreads();
-  if (w == 0) {
-    double ss = avec[l] * avec[l] + avec[l + 64] * avec[l + 64];
-    double ld = Wl[l] + Wl[l + 64];
+  double rv = 0.0;
+  if (tid < NB) rv = vecp[tk * NB + tid];
+
+  constexpr int KS = 2 * KB;                      // 32-column slabs
+  constexpr int NU = KS / 4;
+  constexpr int SLABS_PER_TILE = NB / KS;
+  constexpr int SLAB_DOUBLES = KS * LDS_STRIDE;
+  static_assert(2 * SLAB_DOUBLES <= U_MAIN_DOUBLES, "slab buffers");
+  const int nslab = jmax * SLABS_PER_TILE;
+  if (nslab > 0) {
+    const int scol0 = tid >> 6, srow = 2 * (tid & 63);
+    d2 rb[NU];
+    double rx = 0.0;
+    auto gload = [&](int s) {
+      const int j = s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
+      const double* __restrict__ src = Ap + tile_off(tk, j) + (long long)cs * NB;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); ld += __shfl_xor(ld, off); }
-    if (l == 0) {
-      double* pp = a.partial + ((long long)p * a.nt + tk) * 2;
-      pp[0] = ld;
-      pp[1] = ss;
-      if (bad != 0 && a.info[p] == 0) a.info[p] = bad;
-    }
-  }
-  if (INTRSM) {
-    // publish L(k,k) and its block inverses to the workgroups solving this particle's panel:
-    // every wave drains its stores, one lane releases at agent scope, then sets the ready word
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int u = 0; u < NU; ++u) rb[u] = *reinterpret_cast<const d2*>(src + (scol0 + 4 * u) * NB + srow);
+      if (tid < KS) rx = vecp[j * NB + cs + tid];
+    };
+    auto lstore = [&](int buf) {
+      double* Bs = sm + buf * SLAB_DOUBLES;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb[u];
+      if (tid < KS) xv[buf * KS + tid] = rx;
+    };
+    // per-lane LDS offsets of the nine column fragments and of the two row fragments (k-step 0)
+    int fao[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) fao[e] = lq * LDS_STRIDE + cbe[e] * 16 + l15;
+    const int fb0 = lq * LDS_STRIDE + row0, fb1 = lq * LDS_STRIDE + row1;
+
+    // Two slabs are in flight beyond the one being multiplied (two register sets): this kernel streams its row
+    // panel once at 18 flop/B, so what bounds it is how many bytes it keeps outstanding, not the MFMA rate.
+    d2 rb2[NU];
+    double rx2 = 0.0;
+    auto gload2 = [&](int s) {
+      const int j = s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
+      const double* __restrict__ src = Ap + tile_off(tk, j) + (long long)cs * NB;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) rb2[u] = *reinterpret_cast<const d2*>(src + (scol0 + 4 * u) * NB + srow);
+      if (tid < KS) rx2 = vecp[j * NB + cs + tid];
+    };
+    auto lstore2 = [&](int buf) {
+      double* Bs = sm + buf * SLAB_DOUBLES;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb2[u];
+      if (tid < KS) xv[buf * KS + tid] = rx2;
+    };
+    auto slab = [&](int buf) {
+      const double* Bs = sm + buf * SLAB_DOUBLES;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < KS / 4; ++kk) {
+        const double* Bk = Bs + kk * 4 * LDS_STRIDE;
+        const double f0 = Bk[fb0], f1 = Bk[fb1];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) acc[e] = mfma(Bk[fao[e]], st1[e] ? f1 : f0, acc[e]);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (tid < NB) {
+        // r -= L(k,j)[:, slab] * alpha_j[slab]
+        const double* xs_ = xv + buf * KS;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) rv = fma(-Bs[kk * LDS_STRIDE + tid], xs_[kk], rv);
+      }
+    };
+    // nslab is a multiple of 4: slabs 2i go through (rb, buffer 0), slabs 2i+1 through (rb2, buffer 1)
+    gload(0);
+    lstore(0);
+    gload2(1);
     __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a.ready + p, a.k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int s = 0; s < nslab; s += 2) {
+      if (s + 2 < nslab) gload(s + 2);
+      slab(0);
+      lstore2(1);
+      __syncthreads();
+      if (s + 3 < nslab) gload2(s + 3);
+      slab(1);
+      if (s + 2 < nslab) lstore(0);
+      __syncthreads();
     }
   }
+
+  if (prebuilt) {
+    // resident tile: bring the accumulators to the -C representation
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int rw = st1[e] ? row1 : row0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[e][r] -= Tt[(cbe[e] * 16 + 4 * r + lq) * NB + rw];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+
+  // S = -acc into the 16x16 blocks of the lower block triangle (column-major blocks)
+#pragma unroll
+  for (int e = 0; e < NE; ++e) {
+    const int rbk = st1[e] ? NSB - 1 - wu : wu;           // 16-row block of this entry's rows
+    double* blk = sm + blk_idx(rbk, cbe[e]) * 256;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) blk[(4 * r + lq) * 16 + l15] = -acc[e][r];
+  }
+  factor_diag_tile<true>(a, p, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid);
 }
 
 // T — L(i,k) = C(i,k) L(k,k)^-T for the tiles below the diagonal of block column k.

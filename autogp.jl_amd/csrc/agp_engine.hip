@@ -474,6 +474,20 @@ void launch_update(int dcov, int grid, hipStream_t st, const CholArgs& ca) {
   }
 }
 
+// diagonal tiles of block column ca.k (k_chol_diag), one workgroup per particle
+inline void launch_diag(int dcov, int Pg8, hipStream_t st, const CholArgs& ca) {
+  const bool tab = ca.logdt != nullptr && dcov > 0;
+  const dim3 grid(Pg8), block(256);
+  if (dcov == 0) hipLaunchKernelGGL((k_chol_diag<0, false>), grid, block, 0, st, ca);
+  else if (dcov <= 4) {
+    if (tab) hipLaunchKernelGGL((k_chol_diag<4, true>), grid, block, 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_diag<4, false>), grid, block, 0, st, ca);
+  } else {
+    if (tab) hipLaunchKernelGGL((k_chol_diag<8, true>), grid, block, 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_diag<8, false>), grid, block, 0, st, ca);
+  }
+}
+
 inline void set_cov(CholArgs& ca, const CovArgs& cv) {
   ca.tt = cv.tt; ca.n1 = cv.n1; ca.n1_pad = cv.n1_pad; ca.m2 = cv.m2;
   ca.hdr = cv.hdr; ca.ops = cv.ops; ca.prm = cv.prm; ca.noise = cv.noise; ca.code = cv.code; ca.logdt = cv.logdt;
@@ -550,7 +564,7 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intr
       // 8-slab update.  (More HBM traffic than left-looking: every trailing tile is read and written each column.)
       ca.rl = 1; ca.tiles = 1; ca.j0 = 0;
       size_t e0 = pf ? pf->mark(st) : 0;
-      launch_update<true, false>(0, 8 * Pg, st, ca);
+      launch_diag(0, 8 * Pg, st, ca);
       size_t e1 = pf ? pf->mark(st) : 0;
       if (pf) pf->span(3, e0, e1);
       if (counts) counts[1] += 1;
@@ -572,7 +586,7 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intr
       // wait on the per-particle ready word only formally: stream order has already completed the diagonal launch
       size_t e0 = pf ? pf->mark(st) : 0;
       ca.tiles = 1;
-      launch_update<true, true, 1>(dcov, 8 * Pg, st, ca);
+      launch_diag(dcov, 8 * Pg, st, ca);
       size_t e1 = pf ? pf->mark(st) : 0;
       if (pf) pf->span(3, e0, e1);
       if (counts) counts[1] += 1;
