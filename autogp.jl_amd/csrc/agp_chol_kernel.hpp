@@ -285,16 +285,14 @@ __device__ __forceinline__ void st_pair(double* T, int col, int rowA, int rowB, 
   else { T[col * NB + rowA] = a0; T[col * NB + rowB] = a1; }
 }
 
-// DM (factor mode with INTRSM): 0 = diagonal and sub-diagonal tiles in one launch (legacy / fallback paths);
-// 1 = diagonal tiles only; 2 = sub-diagonal tiles only.  The diagonal-only instantiation gives wave w the 16-row
-// blocks w and 7-w, so every wave holds the same share (9 of 16) of the lower block triangle and the MFMAs,
-// the evaluations and the row-operand loads of the blocks above the diagonal are skipped (44 % of the tile);
-// its row operand is the column operand (same tile), read from the LDS slab.
+// DM (factor mode with INTRSM): 0 = diagonal and sub-diagonal tiles in one launch (medium populations, fallback
+// paths); 2 = sub-diagonal tiles only (the diagonal tiles of that block column then come from k_chol_diag).
 template <bool FACTOR, int DCOV, bool INTRSM, int DM = 0, bool TAB = false>
 __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   static_assert(!TAB || DCOV > 0, "the log|dt| table only matters to instantiations that evaluate tiles");
   static_assert(DM == 0 || (FACTOR && INTRSM), "split launches exist for the in-kernel-solve factorisation only");
-  constexpr bool ADJ = (DM == 1) ? false : ILV;       // strips are adjacent rows
+  static_assert(DM == 0 || DM == 2, "the diagonal-only launch is k_chol_diag");
+  constexpr bool ADJ = ILV;       // strips are adjacent rows
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;
@@ -307,10 +305,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   int xcd, qq;
   int T, ti, tk, jmax;
   int pl, tl;
-  if (DM == 1) {
-    T = 1; xcd = b & 7; pl = b >> 3; tl = 0;
-    tk = a.k; ti = a.k; jmax = a.k;
-  } else if (DM == 2) {
+  if (DM == 2) {
     T = a.tiles;            // sub-diagonal tiles of block column k
     xcd = b & 7; qq = b >> 3;
     pl = qq / T; tl = a.t0 + (qq - pl * T);
@@ -348,17 +343,14 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   }
   const int p = pl * 8 + xcd;
   if (p >= a.P) return;
-  const bool is_diag = (DM == 1) ? true : (DM == 2) ? false : (ti == tk);
+  const bool is_diag = (DM == 2) ? false : (ti == tk);
 
   const int tid = threadIdx.x;
   const int l = tid & 63;
   const int w = tid >> 6;
   const int l15 = l & 15, lq = l >> 4;
-  const int row0 = (DM == 1) ? 16 * w + l15 : (ILV ? 32 * w + 2 * l15 : 32 * w + l15);   // this lane's row in strip 0
-  const int row1 = (DM == 1) ? 16 * (NSB - 1 - w) + l15 : (ILV ? row0 + 1 : row0 + 16);  // ... and in strip 1
-  // diagonal-only: last column block each strip needs (wave-uniform scalars)
-  const int wu = __builtin_amdgcn_readfirstlane(w);
-  const int cmax0 = (DM == 1) ? wu : NSB - 1, cmax1 = (DM == 1) ? NSB - 1 - wu : NSB - 1;
+  const int row0 = ILV ? 32 * w + 2 * l15 : 32 * w + l15;   // this lane's row in strip 0
+  const int row1 = ILV ? row0 + 1 : row0 + 16;              // ... and in strip 1
 
   double* __restrict__ Ap = a.A + (long long)p * a.strideA;
   double* vecp = a.vec + (long long)p * a.ldv;
@@ -385,10 +377,6 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     __syncthreads();
     cov_prologue(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid);
     const double noise = a.noise[p];
-    if (DM == 1) {
-#pragma unroll
-      for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
-    }
     // GammaExp leaves read log|dt| from the data set's table (L2 / Infinity-Cache resident: every particle reads
     // the same 128 KiB tile); the loads are issued at the top of the pass and consumed by the first such leaf
     const bool use_tab = TAB && (h.flags & 1) != 0;
@@ -396,7 +384,6 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 #pragma unroll 1
     for (int t = 0; t < 16; ++t) {
       const int cb = t >> 1, st = t & 1;
-      if (DM == 1 && cb > (st ? cmax1 : cmax0)) continue;      // block above the diagonal
       const int rslot = st ? row1 : row0;
       double tr[4], tc[4], out[4];
       double lt[4] = {0.0, 0.0, 0.0, 0.0};
@@ -434,11 +421,11 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 
   // slab depth: 16 columns of the operand tiles per barrier; the diagonal-only kernel (fewer MFMAs per slab, no
   // row-operand registers) takes 32, which doubles the work and the prefetch distance per barrier
-  constexpr int KS = (DM == 1) ? 2 * KB : KB;
+  constexpr int KS = KB;
   constexpr int NU = KS / 4;                         // 16-byte loads per thread and slab
   constexpr int SLABS_PER_TILE = NB / KS;
   constexpr int SLAB_DOUBLES = KS * LDS_STRIDE;
-  static_assert(2 * SLAB_DOUBLES <= U_MAIN_DOUBLES && (DM == 1 || 4 * SLAB_DOUBLES <= U_MAIN_DOUBLES), "slab buffers");
+  static_assert(4 * SLAB_DOUBLES <= U_MAIN_DOUBLES, "slab buffers");
   const int jfirst = FACTOR ? 0 : a.j0;          // first block column of the sum
   const int nslab = (AGP_DBG_SKIP & 4) ? 0 : (jmax - jfirst) * SLABS_PER_TILE;
   if (nslab > 0) {
@@ -454,9 +441,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        if (DM != 1)
-          ra[u] = A_DIRECT ? ld_pair<ADJ>(srcA, 4 * u + lq, row0, row1)
-                           : *reinterpret_cast<const d2*>(srcA + (scol0 + 4 * u) * NB + srow);
+        ra[u] = A_DIRECT ? ld_pair<ADJ>(srcA, 4 * u + lq, row0, row1)
+                         : *reinterpret_cast<const d2*>(srcA + (scol0 + 4 * u) * NB + srow);
         rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 4 * u) * NB + srow);
       }
       if (is_diag && tid < KS) rx = vecp[j * NB + cs + tid];
@@ -467,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb[u];
-        if (!A_DIRECT && DM != 1) *reinterpret_cast<d2*>(As + (scol0 + 4 * u) * LDS_STRIDE + srow) = ra[u];
+        if (!A_DIRECT) *reinterpret_cast<d2*>(As + (scol0 + 4 * u) * LDS_STRIDE + srow) = ra[u];
       }
       if (is_diag && tid < KS) xv[buf * KS + tid] = rx;
     };
@@ -475,10 +461,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     gload(0);
     lstore(0);
     d2 fr[NU];                                   // row fragments of the slab being multiplied
-    if (DM != 1) {
 #pragma unroll
-      for (int u = 0; u < NU; ++u) fr[u] = ra[u];
-    }
+    for (int u = 0; u < NU; ++u) fr[u] = ra[u];
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
       const int buf = s & 1;
@@ -494,14 +478,13 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 #pragma unroll
         for (int cb = 0; cb < NSB; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];     // columns of C: tile (k,j)
         d2 fb;                                                                   // rows of C: tile (i,j)
-        if (DM == 1) { fb.x = Bs[krow + row0]; fb.y = Bs[krow + row1]; }         // tile (k,j) is both operands
-        else if (A_DIRECT) fb = fr[kk];
+        if (A_DIRECT) fb = fr[kk];
         else if (ILV) fb = *reinterpret_cast<const d2*>(As + krow + row0);
         else { fb.x = As[krow + row0]; fb.y = As[krow + row1]; }
 #pragma unroll
         for (int cb = 0; cb < NSB; ++cb) {
-          if (DM != 1 || cb <= cmax0) acc[cb][0] = mfma(fa[cb], fb.x, acc[cb][0]);
-          if (DM != 1 || cb <= cmax1) acc[cb][1] = mfma(fa[cb], fb.y, acc[cb][1]);
+          acc[cb][0] = mfma(fa[cb], fb.x, acc[cb][0]);
+          acc[cb][1] = mfma(fa[cb], fb.y, acc[cb][1]);
         }
       }
       __builtin_amdgcn_s_setprio(0);
@@ -513,7 +496,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       }
       if (s + 1 < nslab) {
         lstore(buf ^ 1);
-        if (A_DIRECT && DM != 1) {
+        if (A_DIRECT) {
 #pragma unroll
           for (int u = 0; u < NU; ++u) fr[u] = ra[u];
         }
