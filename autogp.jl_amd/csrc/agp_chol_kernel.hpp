@@ -104,7 +104,8 @@ constexpr int U_MAX_CP = (U_MAIN_DOUBLES - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_O
 constexpr bool XCD_PIN = AGP_XCD_PIN != 0;     // 1: all tiles of a particle on one XCD; 0: spread over the 8 XCDs
 // Timing diagnostics only (results are wrong): bit 0 skip the in-register solve arithmetic, bit 1 skip the
 // diagonal-tile factorisation loop, bit 2 skip the GEMM loop, bit 3 skip the solve's staging + flag wait too,
-// bits 4 / 5 / 6 skip the factorisation's 16x16 diagonal step / panel step / trailing update.
+// bits 4 / 5 / 6 skip the factorisation's 16x16 diagonal step / panel step / trailing update, bits 7 / 8 skip the
+// diagonal kernel's forward-solve accumulation / its MFMAs.
 #ifndef AGP_DBG_SKIP
 #define AGP_DBG_SKIP 0
 #endif
@@ -758,10 +759,10 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
         const double* Bk = Bs + kk * 4 * LDS_STRIDE;
         const double f0 = Bk[fb0], f1 = Bk[fb1];
 #pragma unroll
-        for (int e = 0; e < NE; ++e) acc[e] = mfma(Bk[fao[e]], st1[e] ? f1 : f0, acc[e]);
+        for (int e = 0; e < ((AGP_DBG_SKIP & 256) ? 0 : NE); ++e) acc[e] = mfma(Bk[fao[e]], st1[e] ? f1 : f0, acc[e]);
       }
       __builtin_amdgcn_s_setprio(0);
-      if (tid < NB) {
+      if (tid < NB && !(AGP_DBG_SKIP & 128)) {
         // r -= L(k,j)[:, slab] * alpha_j[slab]
         const double* xs_ = xv + buf * KS;
 #pragma unroll
