@@ -622,6 +622,17 @@ def test_coalescing_of_single_particle_gradient_callers(pkg, engine):
         assert out[24 + i] == ref[0][i]
 
 
+def test_randomised_soak(pkg, engine):
+    """tools/gpu_fuzz.py: random (n, P, depth) configurations straddling every schedule threshold — oracle parity,
+    run-to-run bitwise reproducibility, value agreement between the logpdf and gradient sweeps."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("gpu_fuzz", Path(__file__).resolve().parent.parent / "tools" / "gpu_fuzz.py")
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    msg = mod.run(pkg, engine, cases=40, seed=5)
+    assert msg.startswith("fuzz ok"), msg
+
+
 def test_device_output_entry(pkg, engine):
     """agp_logpdf_batch_device leaves results in caller-provided device memory on the caller's stream."""
     import torch

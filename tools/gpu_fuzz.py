@@ -1,0 +1,57 @@
+"""Randomised soak test on the GPU box: random (n, P, tree depth) configurations straddling every schedule threshold
+(right-looking <= 48 particles, hybrid, mixed, split >= 256; tile boundaries of n), each checked against the oracle
+on a few particles, for run-to-run bitwise reproducibility, and value+gradient consistency.  Usage: gpu_fuzz.py [cases] [seed]"""
+import sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as g
+from oracle import oracle as O
+
+
+def run(pkg, eng, cases=60, seed=1):
+    rng = np.random.default_rng(seed)
+    worst = 0.0; worst_g = 0.0; t0 = time.time(); nbad = 0
+    for c in range(cases):
+        n = int(rng.choice([1, 2, 63, 127, 128, 129, 255, 256, 257, 383, 385, 500, 640, 777, 900]))
+        P = int(rng.choice([1, 2, 7, 8, 9, 47, 48, 49, 63, 100, 129, 255, 256, 257, 300, 513]))
+        if n * n * P > 640 * 640 * 300: P = max(1, (640 * 640 * 300) // (n * n))
+        depth = int(rng.integers(1, 5))
+        ts, xs = pkg.prior.synthetic_series(max(n, 2), seed=int(rng.integers(1 << 30)), shuffle=bool(rng.integers(2)))
+        ts, xs = ts[:n], xs[:n]
+        if n > 4 and rng.random() < 0.3: ts[n // 2] = ts[n // 2 - 1]          # duplicate time point
+        nodes, noises = pkg.prior.sample_particles(rng, P, max_depth=depth, max_size=31)
+        eng.set_data(ts, xs)
+        lp, info = eng.logpdf_batch(nodes, noises, check=False)
+        lp2, info2 = eng.logpdf_batch(nodes, noises, check=False)
+        assert np.array_equal(info, info2) and np.array_equal(lp, lp2, equal_nan=True), ("not reproducible", n, P)
+        idx = rng.choice(P, size=min(P, 3), replace=False)
+        for i in idx:
+            if info[i] != 0:
+                nbad += 1
+                continue
+            ref = O.gp_logpdf(nodes[i].to_tuple(), float(noises[i]), ts, xs)
+            e = abs(lp[i] - ref) / max(1.0, abs(ref)); worst = max(worst, e)
+            assert e <= 1e-8, ("parity", n, P, depth, i, lp[i], ref)
+        if n >= 2 and c % 3 == 0:
+            m = min(P, 40)
+            sel = [j for j in range(m) if nodes[j].size() <= 63]
+            lg, gr, gn, ig = eng.logpdf_grad_batch([nodes[j] for j in sel], noises[sel], check=False)
+            for q, j in enumerate(sel):
+                assert (ig[q] == 0) == (info[j] == 0)
+                if ig[q] == 0:
+                    assert abs(lg[q] - lp[j]) <= 1e-10 * max(1.0, abs(lp[j])), ("value via gradient path", n, P, j)
+            if sel and ig[0] == 0:
+                lo, go, gno = O.gp_logpdf_grad(nodes[sel[0]].to_tuple(), float(noises[sel[0]]), ts, xs)
+                sc = max(1.0, np.abs(go).max(), abs(gno))
+                eg = max(np.abs(gr[0] - go).max() if go.size else 0.0, abs(gn[0] - gno)) / sc; worst_g = max(worst_g, eg)
+                assert eg <= 1e-6, ("gradient", n, P, eg)
+    msg = f"fuzz ok: {cases} cases, worst logpdf rel err {worst:.2e}, worst gradient rel err {worst_g:.2e}, not-PD particles skipped {nbad}, {time.time()-t0:.0f}s"
+    return msg
+
+
+
+if __name__ == "__main__":
+    pkg_ = g.load_package()
+    print(run(pkg_, pkg_.GPEngine(0), int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
