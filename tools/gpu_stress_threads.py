@@ -1,0 +1,54 @@
+"""Thread-safety soak: 32 host threads hammer one engine with a random mix of single-particle values, single-particle
+gradients, small batches and predictions at different prefix lengths; every result must equal the one computed
+beforehand by a single thread."""
+import sys, threading, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as g
+pkg = g.load_package()
+eng = pkg.GPEngine(0)
+rng = np.random.default_rng(3)
+n_max = 700
+ts, xs = pkg.prior.synthetic_series(n_max, seed=4, shuffle=True); eng.set_data(ts, xs)
+nodes, noises = pkg.prior.sample_particles(rng, 40, max_depth=3, max_size=15)
+ns = [130, 300, 515, 700]
+tp = np.linspace(0.0, 1.2, 40)
+ref = {}
+for n in ns:
+    lp, info = eng.logpdf_batch(nodes, noises, n=n, check=False)
+    lg, gr, gn, ig = eng.logpdf_grad_batch(nodes, noises, n=n, check=False)
+    mean, var, _, pinfo = eng.predict_batch(nodes[:6], noises[:6], tp, n=n, check=False)
+    ref[n] = (lp, info, gr, gn, mean, var)
+errors = []
+stop = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 8.0)
+count = [0]
+def worker(seed):
+    r = np.random.default_rng(seed)
+    while time.time() < stop:
+        n = ns[int(r.integers(len(ns)))]; i = int(r.integers(40)); kind = int(r.integers(4))
+        lp, info, gr, gn, mean, var = ref[n]
+        try:
+            if kind == 0:
+                v = eng.logpdf(nodes[i], float(noises[i]), n=n, check=False)
+                ok = (v == lp[i]) or (np.isnan(v) and np.isnan(lp[i]))
+            elif kind == 1:
+                v, g_, gn_ = eng.logpdf_grad(nodes[i], float(noises[i]), n=n, check=False)
+                ok = info[i] != 0 or (v == lp[i] and np.array_equal(g_, gr[i]) and gn_ == gn[i])
+            elif kind == 2:
+                j = int(r.integers(30)); sl = slice(j, j + 9)
+                v, inf = eng.logpdf_batch(nodes[sl], noises[sl], n=n, check=False)
+                ok = np.array_equal(v, lp[sl], equal_nan=True) and np.array_equal(inf, info[sl])
+            else:
+                m_, v_, _, _ = eng.predict_batch(nodes[:6], noises[:6], tp, n=n, check=False)
+                ok = np.allclose(m_, mean, rtol=0, atol=1e-12, equal_nan=True) and np.allclose(v_, var, rtol=0, atol=1e-12, equal_nan=True)
+            if not ok: errors.append((kind, n, i))
+        except Exception as e:          # noqa: BLE001
+            errors.append((kind, n, i, repr(e)))
+        count[0] += 1
+th = [threading.Thread(target=worker, args=(s,)) for s in range(32)]
+for t in th: t.start()
+for t in th: t.join()
+print(f"stress: {count[0]} calls from 32 threads, {len(errors)} mismatches", errors[:5])
+sys.exit(1 if errors else 0)
