@@ -415,7 +415,8 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
       g.node_off = (int32_t)bt.gops.size(); g.prm_off = (int32_t)bt.gprm.size();
       emit_grad(cp.nodes, cp.root, bt, g.prm_off, g.node_off);
       g.n_ops = (int32_t)bt.gops.size() - g.node_off; g.n_prm = (int32_t)bt.gprm.size() - g.prm_off;
-      g.n_cp = cp.n_cp; g.pad_ = 0;
+      g.n_cp = cp.n_cp; g.flags = 0;
+      for (int i2 = g.node_off; i2 < (int)bt.gops.size(); ++i2) if (bt.gops[i2] == OP_GE) g.flags = 1;
       bt.ghdr[q] = g;
       bt.g_max_nodes = std::max(bt.g_max_nodes, g.n_ops);
       bt.g_max_prm = std::max(bt.g_max_prm, g.n_prm);
@@ -863,7 +864,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           ga.P = Pg; ga.nt = nt; ga.n = (int)n;
           ga.ghdr = s->ghdr.as<GProgHdr>() + p0 + g0; ga.gops = s->gops.as<uint8_t>(); ga.glc = s->glc.as<uint8_t>();
           ga.grc = s->grc.as<uint8_t>(); ga.gpoff = s->gpoff.as<int32_t>(); ga.gprm = s->gprm.as<double>();
-          ga.tt = c->d_ts; ga.gpart = s->gpart.as<double>() + (size_t)g0 * ntiles * gstride; ga.gstride = gstride;
+          ga.tt = c->d_ts; ga.logdt = c->logdt_ok ? c->d_logdt : nullptr; ga.gpart = s->gpart.as<double>() + (size_t)g0 * ntiles * gstride; ga.gstride = gstride;
           ga.gmap = s->gmap.as<int32_t>(); ga.out_off = s->goff.as<int32_t>() + p0 + g0;
           ga.pmap = d_map + p0 + g0; ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
           const int Pg8 = (Pg + 7) / 8;

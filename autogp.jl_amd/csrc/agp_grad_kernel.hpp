@@ -136,6 +136,7 @@ struct GradArgs {
   const int32_t* gpoff;  // per node: offset of its parameters inside the particle's parameter block
   const double* gprm;    // ORIGINAL (untransformed-by-us) parameter values, device node order
   const double* tt;      // time points (padded)
+  const double* logdt;   // log|dt| table of the resident data (null: GammaExp leaves compute the power); see CovArgs
   double* gpart;         // [P][ntiles][gstride] per-tile partial sums (slot 0..n_prm-1 params, n_prm = noise)
   int gstride;
   const int32_t* gmap;   // per particle parameter slot -> index in the caller's parameter array
@@ -152,7 +153,7 @@ struct GProgHdr {
   int32_t n_ops;
   int32_t n_prm;
   int32_t n_cp;
-  int32_t pad_;
+  int32_t flags;      // bit 0: the tree has GammaExp leaves (reads the log|dt| table when there is one)
 };
 
 __device__ __forceinline__ long long zoff(int r, int k) { return tile_off(k, r); }   // r <= k
@@ -288,6 +289,7 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
                                               const uint8_t* mv, const int32_t* poff, const double* prm, const double* sig,
                                               const int (&ri)[E], const int (&ci)[E], const double (&ta)[E],
                                               const double (&tb)[E], const double (&wgt)[E],
+                                              const double (&lt)[E], bool use_tab,
                                               double (&tape)[MAXS][E], double (&gacc)[3 * MAXS + 2]) {
   const double PI = 3.14159265358979323846;
   // ---------------- forward: node values ----------------
@@ -297,6 +299,7 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
     const double* q = prm + poff[ip];
     const double q0 = q[0], q1 = q[1], q2 = q[2];
     const int il = lc[ip], ir = rc[ip];
+    const double lgl = (use_tab && o == OP_GE) ? fm::log_f(q0) : 0.0;      // once per node visit, not per element
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       double v;
@@ -304,7 +307,11 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
       else if (o == OP_CONST) v = q0;
       else if (o == OP_LIN) v = q1 + q2 * ((ta[e] - q0) * (tb[e] - q0));
       else if (o == OP_SE) { const double d = ta[e] - tb[e]; v = q1 * fm::exp_f(-0.5 * d * d / (q0 * q0)); }
-      else if (o == OP_GE) v = q2 * fm::exp_f(-fm::pow_f(fabs(ta[e] - tb[e]) / q0, q1));
+      else if (o == OP_GE) {
+        // with the data set's log|dt| table (lt): (|dt|/l)^g = exp(g (log|dt| - log l)), no per-element log
+        const double ug = use_tab ? fm::exp_f(q1 * (lt[e] - lgl)) : fm::pow_f(fabs(ta[e] - tb[e]) / q0, q1);
+        v = q2 * fm::exp_f(-ug);
+      }
       else if (o == OP_PER) v = q2 * fm::exp_f(-2.0 * fm::sin2_f(PI / q1 * fabs(ta[e] - tb[e])) / (q0 * q0));
       else if (o == OP_PLUS) v = tape[il][e] + tape[ir][e];
       else if (o == OP_TIMES) v = tape[il][e] * tape[ir][e];
@@ -371,11 +378,18 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
         }
       } else if (o == OP_GE) {
         const double rl = 1.0 / q0;
+        const double lgl = use_tab ? fm::log_f(q0) : 0.0;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          const double u = fabs(ta[e] - tb[e]) * rl;
-          const double lu = fm::log_f(u > 0.0 ? u : 1.0);             // u^g ln u -> 0 at u = 0
-          const double ug = u > 0.0 ? fm::exp_f(q1 * lu) : 0.0;
+          double lu, ug;
+          if (use_tab) {
+            lu = lt[e] - lgl;                                        // dt = 0: table sentinel, exp -> 0 exactly, 0 * lu = -0
+            ug = fm::exp_f(q1 * lu);
+          } else {
+            const double u = fabs(ta[e] - tb[e]) * rl;
+            lu = fm::log_f(u > 0.0 ? u : 1.0);                       // u^g ln u -> 0 at u = 0
+            ug = u > 0.0 ? fm::exp_f(q1 * lu) : 0.0;
+          }
           const double sv = m ? tape[ip][e] : tape[ip][e] * fm::exp_f(-ug);   // adjoint * amp * exp  |  adjoint * exp
           g0 += sv * ug;
           g1 -= sv * (ug * lu);
@@ -505,6 +519,8 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
   const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
   const double wfac = (ti == tj) ? 1.0 : 2.0;
   double gnoise = 0.0;
+  const bool use_tab = a.logdt != nullptr && (h.flags & 1) != 0;
+  const double* __restrict__ ltile = a.logdt + tile_off(ti, tj);       // only dereferenced when use_tab
 #pragma unroll 1
   for (int t = 0; t < 16; ++t) {
     const int cb = t >> 1, st = t & 1;
@@ -520,11 +536,12 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
 #pragma unroll 1
     for (int r0 = 0; r0 < 4; r0 += E) {
       int ri[E], ci[E];
-      double ta[E], tb[E], wg[E];
+      double ta[E], tb[E], wg[E], lt[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int r = r0 + e;
         const int cslot = cb * 16 + 4 * r + lq;
+        lt[e] = use_tab ? ltile[cslot * NB + rslot] : 0.0;
         const int gb = tj * NB + cslot;
         const bool valid = ga < a.n && gb < a.n;       // padding rows / columns carry no parameter dependence
         const double kinv = (r == 0) ? v[0] : (r == 1) ? v[1] : (r == 2) ? v[2] : v[3];
@@ -532,7 +549,7 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
         if (ga == gb) gnoise += G;                       // d/d noise = tr G
         ri[e] = rslot; ci[e] = NB + cslot; ta[e] = tpt[rslot]; tb[e] = tpt[NB + cslot]; wg[e] = wfac * G;
       }
-      grad_elements<MAXS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, tape, gacc);
+      grad_elements<MAXS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, lt, use_tab, tape, gacc);
     }
   }
   gacc[h.n_prm] = gnoise;       // overwrites whatever the unconditional three-slot adds left there
@@ -633,10 +650,12 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
   const int rslot = tid & 127, chalf = (tid >> 7) * 64;
   const int ga = ti * NB + rslot;
   const double ar = ga < a.n ? al[ga] : 0.0;
+  const bool use_tab = a.logdt != nullptr && (h.flags & 1) != 0;
+  const double* __restrict__ ltile = a.logdt + tile_off(ti, tj);       // only dereferenced when use_tab
 #pragma unroll 1
   for (int c0 = 0; c0 < 64; c0 += E) {
     int ri[E], ci[E];
-    double ta[E], tb[E], wg[E];
+    double ta[E], tb[E], wg[E], lt[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int cslot = chalf + c0 + e;
@@ -646,8 +665,9 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
       const double G = valid ? 0.5 * (ar * al[valid ? gb : 0] - kinv) : 0.0;
       if (ga == gb) gnoise += G;
       ri[e] = rslot; ci[e] = NB + cslot; ta[e] = tpt[rslot]; tb[e] = tpt[NB + cslot]; wg[e] = wfac * G;
+      lt[e] = use_tab ? ltile[cslot * NB + rslot] : 0.0;
     }
-    grad_elements<MAXS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, tape, gacc);
+    grad_elements<MAXS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, lt, use_tab, tape, gacc);
   }
   gacc[h.n_prm] = gnoise;
   __syncthreads();
