@@ -5,8 +5,11 @@
 #include "agp_common.hpp"
 #include "agp_cov_kernel.hpp"
 #include "agp_chol_kernel.hpp"
-#include "agp_experiments.hpp"
+#ifdef AGP_EXPERIMENTS
+#include "agp_experiments.hpp"   // ablation kernels of the update GEMM (measurement builds only)
+#endif
 #include "agp_grad_kernel.hpp"
+#include "agp_comm.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -17,6 +20,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -66,7 +70,12 @@ struct Slot {
   std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
   std::vector<hipEvent_t> sub_ev;     // fork / join events
   bool busy = false;
+  // asynchronous hand-back (agp_logpdf_batch_device on a caller stream): the slot stays reserved until `done`,
+  // recorded behind the call's last launch, has completed
+  hipEvent_t done = nullptr;
+  bool pending = false;
   void release() {
+    if (done) { (void)hipEventDestroy(done); done = nullptr; }
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
                       &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist})
@@ -147,6 +156,12 @@ struct agp_ctx {
                              // last sweep's duration); 0 = every call runs alone (env AGP_COALESCE_US)
   int batch_hint = 1;        // size of the last coalesced batch
   long long n_coalesced_calls = 0, n_coalesced_batches = 0;
+  // ---- RCCL communicator of the particle-sharded deployment (agp_comm_init_rank / agp_init_multi) ----
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
+  hipStream_t comm_stream = nullptr;
+  std::mutex comm_mu;                   // one collective at a time per context
+  DevBuf comm_in, comm_out, comm_all;   // padded shard, padded gather, compact vector
 };
 
 namespace {
@@ -173,27 +188,42 @@ int fail(agp_ctx* c, int code, const std::string& msg) {
 Slot* acquire_slot(agp_ctx* c) {
   std::unique_lock<std::mutex> g(c->mu);
   for (;;) {
-    for (Slot* s : c->slots)
+    Slot* waiting = nullptr;
+    for (Slot* s : c->slots) {
       if (!s->busy) { s->busy = true; return s; }
+      if (s->pending) {                    // handed back asynchronously: free once its event has completed
+        if (hipEventQuery(s->done) == hipSuccess) { s->pending = false; return s; }
+        waiting = s;
+      }
+    }
     if ((int)c->slots.size() < c->max_slots) {
       Slot* s = new Slot();
       s->busy = true;
       c->slots.push_back(s);
       return s;
     }
+    if (waiting) {
+      // every slot is taken and at least one only waits for the GPU: claim it (pending -> false keeps other
+      // acquirers away) and wait for its work outside the lock
+      waiting->pending = false;
+      g.unlock();
+      (void)hipEventSynchronize(waiting->done);
+      return waiting;
+    }
     c->cv.wait(g);
   }
 }
 
-void release_slot(agp_ctx* c, Slot* s) {
-  { std::lock_guard<std::mutex> g(c->mu); s->busy = false; }
+void release_slot(agp_ctx* c, Slot* s, bool async_done = false) {
+  { std::lock_guard<std::mutex> g(c->mu); if (async_done) s->pending = true; else s->busy = false; }
   c->cv.notify_one();
 }
 
 struct SlotGuard {
   agp_ctx* c; Slot* s;
+  bool async_done = false;    // the call recorded s->done behind its work and returns without waiting for it
   SlotGuard(agp_ctx* c_) : c(c_), s(acquire_slot(c_)) {}
-  ~SlotGuard() { release_slot(c, s); }
+  ~SlotGuard() { release_slot(c, s, async_done); }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -219,6 +249,11 @@ struct Compiled {
   int n_prm_caller = 0;
   bool uses_tab = false;      // has OP_GE_TAB leaves
 };
+
+// k_cov_tiles / the gradient contraction keep one 256-entry table per ChangePoint node / selector leaf in LDS next to
+// the 256 time points (+ parameters and a tape in the gradient kernel): 160 KiB per workgroup on gfx950.
+constexpr int DYN_LDS_MAX_BYTES = 160 * 1024;
+constexpr int COV_MAX_TABLES = (DYN_LDS_MAX_BYTES / 8 - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_OPS_DEV - 16) / 256;   // 75
 
 int leaf_nprm(int op) {
   switch (op) {
@@ -305,6 +340,7 @@ const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, in
   out.depth_need = nodes[stack[0]].need;
   if (out.depth_need > 8) return "kernel tree needs an evaluation stack deeper than 8";
   emit(nodes, stack[0], out, ge_tab);
+  if (out.n_cp > COV_MAX_TABLES) return "kernel tree needs more per-point LDS tables (ChangePoint nodes + component selectors) than fit 160 KiB";
   out.root = stack[0];
   out.n_prm_caller = n_prm;
   out.nodes.swap(nodes);
@@ -443,17 +479,9 @@ hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int 
   if (ntiles <= 0 || P <= 0) return hipSuccess;
   const size_t lds = (256 + (size_t)max_cp * 256) * sizeof(double);
   dim3 grid(ntiles, P), block(256);
-  if (depth <= 4) {
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cov_tiles<4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_cov_tiles<4>, grid, block, lds, st, ca);
-  } else {
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cov_tiles<8>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_cov_tiles<8>, grid, block, lds, st, ca);
-  }
+  // (the dynamic-LDS ceiling of these kernels is raised once, in agp_init; compile_program bounds max_cp)
+  if (depth <= 4) hipLaunchKernelGGL(k_cov_tiles<4>, grid, block, lds, st, ca);
+  else hipLaunchKernelGGL(k_cov_tiles<8>, grid, block, lds, st, ca);
   return hipGetLastError();
 }
 
@@ -651,16 +679,12 @@ struct GradOut {
 
 template <int MAXS>
 hipError_t launch_grad_contract(hipStream_t st, const GradArgs& ga, int ntiles, int P, size_t lds) {
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grad_contract<MAXS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_grad_contract<MAXS>, dim3(ntiles, P), dim3(256), lds, st, ga);
   return hipGetLastError();
 }
 
 template <int MAXS>
 hipError_t launch_grad_tiles(hipStream_t st, const GradArgs& ga, int ntiles, int P, size_t lds) {
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_grad_tiles<MAXS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_grad_tiles<MAXS>, dim3(ntiles, P), dim3(256), lds, st, ga);
   return hipGetLastError();
 }
@@ -918,6 +942,15 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     }
   }
 
+  if (use_user_stream && !go && !c->profiling && !h_out_lp && !h_out_info) {
+    // Device-output entry on the caller's stream: everything is enqueued, nothing is waited for — the caller chains
+    // its consumer (the log-weight all-gather) on the same stream.  The slot stays reserved until the event fires.
+    // (The -7 in-kernel-timeout marker then only reaches the caller through d_out_info.)
+    if (!s->done) HIPCHK(c, hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(s->done, st));
+    sg.async_done = true;
+    return AGP_OK;
+  }
   const size_t out_bytes = sizeof(double) * P + sizeof(int32_t) * P;
   if (own_out) {
     HIPCHK(c, s->h_out.ensure(out_bytes));
@@ -949,10 +982,12 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
 
 }  // namespace
 
+#ifdef AGP_EXPERIMENTS
 template <int VAR>
 static void launch_variant(hipStream_t st, int grid, const CholArgs& ca) {
   hipLaunchKernelGGL(k_gemm_variant<VAR>, dim3(grid), dim3(256), 0, st, ca);
 }
+#endif
 
 
 // ==========================================================================================
@@ -975,6 +1010,22 @@ int agp_init(agp_ctx** out, int device_id) {
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
     std::string m = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
     return fail(nullptr, AGP_ERR_HIP, m);
+  }
+  {
+    // raise the dynamic-LDS ceiling of the table-carrying kernels once (launches then never touch function attributes)
+    const void* fns[] = {reinterpret_cast<const void*>(&k_cov_tiles<4>), reinterpret_cast<const void*>(&k_cov_tiles<8>),
+                         reinterpret_cast<const void*>(&k_grad_contract<16>), reinterpret_cast<const void*>(&k_grad_contract<64>),
+                         reinterpret_cast<const void*>(&k_grad_tiles<16>), reinterpret_cast<const void*>(&k_grad_tiles<64>)};
+    for (const void* f : fns) {
+      hipFuncAttributes fa;
+      hipError_t ea = hipFuncGetAttributes(&fa, f);
+      if (ea == hipSuccess)
+        ea = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, DYN_LDS_MAX_BYTES - (int)fa.sharedSizeBytes);
+      if (ea != hipSuccess) {
+        std::string m = std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: ") + hipGetErrorString(ea);
+        return fail(nullptr, AGP_ERR_HIP, m);
+      }
+    }
   }
   agp_ctx* c = new agp_ctx();
   c->device = device_id;
@@ -1002,6 +1053,9 @@ void agp_destroy(agp_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (Slot* s : c->slots) { s->release(); delete s; }
+  if (c->comm && rccl().ok()) (void)rccl().CommDestroy(c->comm);
+  if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+  c->comm_in.release(); c->comm_out.release(); c->comm_all.release();
   if (c->d_ts) (void)hipFree(c->d_ts);
   if (c->d_xs) (void)hipFree(c->d_xs);
   if (c->d_logdt) (void)hipFree(c->d_logdt);
@@ -1010,8 +1064,10 @@ void agp_destroy(agp_ctx* c) {
 
 const char* agp_last_error(agp_ctx* c) {
   if (!c) return g_err_noctx.c_str();
-  std::lock_guard<std::mutex> g(c->mu);
-  return c->err.c_str();
+  // concurrent failing callers rewrite c->err: hand out a per-thread copy made under the lock
+  thread_local std::string copy;
+  { std::lock_guard<std::mutex> g(c->mu); copy = c->err; }
+  return copy.c_str();
 }
 
 int agp_set_workspace_limit(agp_ctx* c, int64_t bytes) {
@@ -1100,7 +1156,9 @@ static int logpdf_batch_dedup(agp_ctx* c, int64_t n, int32_t P, const int32_t* o
   std::string key;
   for (int p = 0; p < P; ++p) {
     const int no = op_off[p + 1] - op_off[p], np = prm_off[p + 1] - prm_off[p];
-    key.assign(reinterpret_cast<const char*>(ops + op_off[p]), (size_t)no);
+    const int32_t lens[2] = {no, np};          // length-delimited fields: (a ops, b prm) never collides with (a+8, b-1)
+    key.assign(reinterpret_cast<const char*>(lens), sizeof lens);
+    key.append(reinterpret_cast<const char*>(ops + op_off[p]), (size_t)no);
     key.append(reinterpret_cast<const char*>(prm + prm_off[p]), sizeof(double) * (size_t)np);
     key.append(reinterpret_cast<const char*>(noise + p), sizeof(double));
     auto it = seen.find(key);
@@ -1458,19 +1516,21 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     }
     HIPCHK(c, hipStreamSynchronize(st));
   }
-  if (out_info) {
+  {
+    // always inspected: a caller that passes out_info = NULL must still never receive unmarked garbage
     std::vector<int32_t> info_sorted(P);
     HIPCHK(c, hipMemcpyAsync(info_sorted.data(), s->info.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     for (int q = 0; q < P; ++q) {
       if (info_sorted[q] < 0) return fail(c, AGP_ERR_HIP, "in-kernel panel solve timed out waiting for its diagonal factor");
-      out_info[bt.order[q]] = info_sorted[q];
-    }
-    for (int p = 0; p < P; ++p)
-      if (out_info[p] != 0) {
+      const int p = bt.order[q];
+      if (out_info) out_info[p] = info_sorted[q];
+      if (info_sorted[q] != 0) {
         const double nanv = std::nan("");
         for (int64_t g = 0; g < m; ++g) { out_mean[(size_t)p * m + g] = nanv; out_var[(size_t)p * m + g] = nanv; }
+        if (out_cov) for (int64_t g = 0; g < m * m; ++g) out_cov[(size_t)p * m * m + g] = nanv;
       }
+    }
   }
   return AGP_OK;
 }
@@ -1663,6 +1723,10 @@ int agp_debug_mfma_peak(agp_ctx* c, int32_t iters, int32_t wg_per_cu, double* ou
 }
 
 int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t variant, int32_t reps, double* out_ms) {
+#ifndef AGP_EXPERIMENTS
+  (void)P; (void)nt; (void)k; (void)variant; (void)reps; (void)out_ms;
+  return fail(c, AGP_ERR_ARG, "ablation kernels are compiled only with -DAGP_EXPERIMENTS (python __graft_entry__.py --experiments)");
+#else
   if (!c || !out_ms || P <= 0 || nt < 2 || k < 1 || k >= nt - 0) return fail(c, AGP_ERR_ARG, "bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   SlotGuard sg(c);
@@ -1737,6 +1801,7 @@ int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   HIPCHK(c, hipGetLastError());
   return AGP_OK;
+#endif
 }
 
 int agp_debug_math(agp_ctx* c, int32_t which, const double* x, const double* g, double* y, int32_t n) {
@@ -1768,6 +1833,260 @@ int agp_debug_mfma_probe(agp_ctx* c, const double* A, const double* B, double* D
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpy(D, dD, 256 * 8, hipMemcpyDeviceToHost));
   (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
+  return AGP_OK;
+}
+
+}  // extern "C"
+
+// ==========================================================================================
+// Multi-GPU: particles are block-sharded over the ranks (independent units, matrices never leave their GPU); the
+// only exchange of the path is the all-gather of the per-particle log-weights before ESS / resampling
+// (src/inference_smc_anneal_data.jl:22-31,232).  RCCL over xGMI, on the engine's own stream or the caller's.
+// ==========================================================================================
+namespace {
+
+#define NCCLCHK(ctx, expr)                                                                   \
+  do {                                                                                       \
+    ncclResult_t r_ = (expr);                                                                \
+    if (r_ != ncclSuccess) {                                                                 \
+      char buf_[512];                                                                        \
+      snprintf(buf_, sizeof buf_, "RCCL error %d (%s) at %s:%d: %s", (int)r_,                \
+               rccl().GetErrorString ? rccl().GetErrorString(r_) : "?", __FILE__, __LINE__, #expr); \
+      return fail(ctx, AGP_ERR_COMM, buf_);                                                  \
+    }                                                                                        \
+  } while (0)
+
+int need_rccl(agp_ctx* c) {
+  if (!rccl().ok()) return fail(c, AGP_ERR_COMM, rccl().error.empty() ? "librccl unavailable" : rccl().error);
+  return AGP_OK;
+}
+
+// Enqueue the all-gather of this rank's shard (device, hi - lo doubles) into d_all (device, P doubles) on `st`.
+// Equal shards go straight through ncclAllGather; uneven ones travel padded to the largest shard and are compacted.
+// `in_group`: the caller brackets several contexts' gathers in one ncclGroupStart/End (single-process multi-device),
+// the compaction is then enqueued by finish_gather after the group has been issued.
+int enqueue_gather(agp_ctx* c, const double* d_local, int P, double* d_all, hipStream_t st) {
+  int lo, hi;
+  shard_range(P, c->comm_rank, c->comm_size, &lo, &hi);
+  const int R = c->comm_size, mx = (P + R - 1) / R;
+  if (P % R == 0) {
+    NCCLCHK(c, rccl().AllGather(d_local, d_all, (size_t)mx, ncclDouble, c->comm, st));
+    return AGP_OK;
+  }
+  HIPCHK(c, c->comm_in.ensure(sizeof(double) * (size_t)mx));
+  HIPCHK(c, c->comm_out.ensure(sizeof(double) * (size_t)mx * R));
+  HIPCHK(c, hipMemsetAsync(c->comm_in.p, 0, sizeof(double) * (size_t)mx, st));
+  if (hi > lo) HIPCHK(c, hipMemcpyAsync(c->comm_in.p, d_local, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, st));
+  NCCLCHK(c, rccl().AllGather(c->comm_in.p, c->comm_out.p, (size_t)mx, ncclDouble, c->comm, st));
+  return AGP_OK;
+}
+int finish_gather(agp_ctx* c, int P, double* d_all, hipStream_t st) {
+  const int R = c->comm_size, mx = (P + R - 1) / R;
+  if (P % R == 0) return AGP_OK;
+  hipLaunchKernelGGL(k_compact_shards, dim3((P + 255) / 256), dim3(256), 0, st, c->comm_out.as<double>(), mx, P, R, d_all);
+  HIPCHK(c, hipGetLastError());
+  return AGP_OK;
+}
+
+int ensure_comm_stream(agp_ctx* c) {
+  if (!c->comm_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  return AGP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void agp_shard_range(int32_t P, int32_t rank, int32_t n_ranks, int32_t* lo, int32_t* hi) {
+  int l = 0, h = 0;
+  if (n_ranks > 0 && rank >= 0 && rank < n_ranks && P >= 0) shard_range(P, rank, n_ranks, &l, &h);
+  if (lo) *lo = l;
+  if (hi) *hi = h;
+}
+
+int agp_comm_get_unique_id(void* out_id) {
+  if (!out_id) return fail(nullptr, AGP_ERR_ARG, "null id pointer");
+  int rc = need_rccl(nullptr);
+  if (rc) return rc;
+  static_assert(sizeof(ncclUniqueId) == AGP_COMM_ID_BYTES, "AGP_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+  ncclUniqueId id;
+  NCCLCHK(nullptr, rccl().GetUniqueId(&id));
+  std::memcpy(out_id, &id, sizeof id);
+  return AGP_OK;
+}
+
+int agp_comm_init_rank(agp_ctx* c, const void* id_bytes, int32_t n_ranks, int32_t rank) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (!id_bytes || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, AGP_ERR_ARG, "bad communicator arguments");
+  int rc = need_rccl(c);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> g(c->comm_mu);
+  if (c->comm) return fail(c, AGP_ERR_ARG, "this context already has a communicator");
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes, sizeof id);
+  NCCLCHK(c, rccl().CommInitRank(&c->comm, n_ranks, id, rank));
+  c->comm_rank = rank; c->comm_size = n_ranks;
+  return ensure_comm_stream(c);
+}
+
+int agp_comm_info(agp_ctx* c, int32_t* rank, int32_t* n_ranks) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (rank) *rank = c->comm_rank;
+  if (n_ranks) *n_ranks = c->comm_size;
+  return c->comm ? 1 : 0;
+}
+
+int agp_init_multi(agp_ctx** out, const int32_t* device_ids, int32_t n_dev) {
+  if (!out || !device_ids || n_dev < 1) return fail(nullptr, AGP_ERR_ARG, "bad arguments");
+  for (int i = 0; i < n_dev; ++i) out[i] = nullptr;
+  for (int i = 0; i < n_dev; ++i)
+    for (int j = 0; j < i; ++j)
+      if (device_ids[i] == device_ids[j]) return fail(nullptr, AGP_ERR_ARG, "duplicate device id");
+  int rc = need_rccl(nullptr);
+  if (rc) return rc;
+  auto undo = [&]() { for (int i = 0; i < n_dev; ++i) { if (out[i]) agp_destroy(out[i]); out[i] = nullptr; } };
+  for (int i = 0; i < n_dev; ++i) {
+    rc = agp_init(&out[i], device_ids[i]);
+    if (rc) { undo(); return rc; }
+  }
+  std::vector<ncclComm_t> comms((size_t)n_dev, nullptr);
+  std::vector<int> devs(device_ids, device_ids + n_dev);
+  ncclResult_t r = rccl().CommInitAll(comms.data(), n_dev, devs.data());
+  if (r != ncclSuccess) {
+    undo();
+    return fail(nullptr, AGP_ERR_COMM, std::string("ncclCommInitAll failed: ") + rccl().GetErrorString(r));
+  }
+  for (int i = 0; i < n_dev; ++i) {
+    out[i]->comm = comms[i]; out[i]->comm_rank = i; out[i]->comm_size = n_dev;
+    if (hipSetDevice(device_ids[i]) != hipSuccess || ensure_comm_stream(out[i]) != AGP_OK) { undo(); return fail(nullptr, AGP_ERR_HIP, "stream creation failed"); }
+  }
+  return AGP_OK;
+}
+
+int agp_set_data_multi(agp_ctx* const* ctxs, int32_t n_dev, const double* ts, const double* xs, int64_t n_max) {
+  if (!ctxs || n_dev < 1) return fail(nullptr, AGP_ERR_ARG, "bad arguments");
+  for (int i = 0; i < n_dev; ++i) {
+    const int rc = agp_set_data(ctxs[i], ts, xs, n_max);
+    if (rc) return rc;
+  }
+  return AGP_OK;
+}
+
+int agp_allgather_logweights_device(agp_ctx* c, const double* d_local, int32_t P, double* d_all, void* hip_stream) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (P < 0 || (P > 0 && !d_all)) return fail(c, AGP_ERR_ARG, "bad arguments");
+  if (P == 0) return AGP_OK;
+  int lo, hi;
+  shard_range(P, c->comm_rank, c->comm_size, &lo, &hi);
+  if (hi > lo && !d_local) return fail(c, AGP_ERR_ARG, "null shard pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::lock_guard<std::mutex> g(c->comm_mu);
+  if (!c->comm) {
+    // no communicator: a population that lives on this GPU alone
+    if (c->comm_size != 1) return fail(c, AGP_ERR_COMM, "no communicator");
+    int rc = ensure_comm_stream(c);
+    if (rc) return rc;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->comm_stream;
+    if (d_all != d_local) HIPCHK(c, hipMemcpyAsync(d_all, d_local, sizeof(double) * (size_t)P, hipMemcpyDeviceToDevice, st));
+    if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
+    return AGP_OK;
+  }
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->comm_stream;
+  int rc = enqueue_gather(c, d_local, P, d_all, st);
+  if (rc) return rc;
+  rc = finish_gather(c, P, d_all, st);
+  if (rc) return rc;
+  if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
+  return AGP_OK;
+}
+
+int agp_allgather_logweights(agp_ctx* c, double* inout_lw, int32_t P) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (P < 0 || (P > 0 && !inout_lw)) return fail(c, AGP_ERR_ARG, "bad arguments");
+  if (P == 0 || c->comm_size == 1) return AGP_OK;          // a one-rank population is already complete
+  if (!c->comm) return fail(c, AGP_ERR_COMM, "no communicator: call agp_comm_init_rank or agp_init_multi first");
+  HIPCHK(c, hipSetDevice(c->device));
+  int lo, hi;
+  shard_range(P, c->comm_rank, c->comm_size, &lo, &hi);
+  {
+    std::lock_guard<std::mutex> g(c->comm_mu);
+    HIPCHK(c, c->comm_all.ensure(sizeof(double) * (size_t)P * 2));
+  }
+  double* d_all = c->comm_all.as<double>();
+  double* d_loc = d_all + P;
+  if (hi > lo) HIPCHK(c, hipMemcpyAsync(d_loc, inout_lw + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyHostToDevice, c->comm_stream));
+  int rc = agp_allgather_logweights_device(c, d_loc, P, d_all, c->comm_stream);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(inout_lw, d_all, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, c->comm_stream));
+  HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+  return AGP_OK;
+}
+
+// One host process driving every GPU of the node (the deployment of a single Julia process): block-shard the P
+// particles over the contexts of agp_init_multi, run each shard's sweep from its own host thread with the results
+// left on its device, all-gather the log-weights over RCCL (one group call over the node's communicators), and
+// hand the complete vector back from device 0.  Every device ends up holding the full vector.
+int agp_logpdf_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off,
+                           const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
+                           double* out_logpdf, int32_t* out_info) {
+  if (!ctxs || n_dev < 1 || !ctxs[0]) return fail(nullptr, AGP_ERR_ARG, "bad context list");
+  agp_ctx* c0 = ctxs[0];
+  if (P < 0 || n < 0) return fail(c0, AGP_ERR_ARG, "negative size");
+  if (P == 0) return AGP_OK;
+  if (!op_off || !ops || !prm_off || !prm || !noise || !out_logpdf || !out_info) return fail(c0, AGP_ERR_ARG, "null pointer argument");
+  for (int d = 0; d < n_dev; ++d)
+    if (!ctxs[d] || ctxs[d]->comm_size != n_dev || ctxs[d]->comm_rank != d || (n_dev > 1 && !ctxs[d]->comm))
+      return fail(c0, AGP_ERR_ARG, "contexts must come from agp_init_multi, in order");
+  const int mx = (P + n_dev - 1) / n_dev;
+  std::vector<int> rcs((size_t)n_dev, AGP_OK);
+  std::vector<std::thread> th;
+  for (int d = 0; d < n_dev; ++d) {
+    th.emplace_back([&, d]() {
+      agp_ctx* c = ctxs[d];
+      int lo, hi;
+      shard_range(P, d, n_dev, &lo, &hi);
+      if (hipSetDevice(c->device) != hipSuccess) { rcs[d] = fail(c, AGP_ERR_HIP, "hipSetDevice failed"); return; }
+      {
+        std::lock_guard<std::mutex> g(c->comm_mu);
+        if (c->comm_all.ensure(sizeof(double) * ((size_t)P + mx)) != hipSuccess) { rcs[d] = fail(c, AGP_ERR_HIP, "allocation failed"); return; }
+      }
+      if (hi == lo) return;
+      const int Pl = hi - lo;
+      std::vector<int32_t> oo((size_t)Pl + 1), po((size_t)Pl + 1);
+      for (int i = 0; i <= Pl; ++i) { oo[i] = op_off[lo + i] - op_off[lo]; po[i] = prm_off[lo + i] - prm_off[lo]; }
+      double* d_loc = c->comm_all.as<double>() + P;
+      rcs[d] = logpdf_batch_impl(c, n, Pl, oo.data(), ops + op_off[lo], po.data(), prm + prm_off[lo], noise + lo, nullptr,
+                                 out_info + lo, d_loc, nullptr, nullptr, false);
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int d = 0; d < n_dev; ++d)
+    if (rcs[d]) { if (d) fail(c0, rcs[d], agp_last_error(ctxs[d])); return rcs[d]; }
+  if (n_dev == 1) {
+    HIPCHK(c0, hipSetDevice(c0->device));
+    HIPCHK(c0, hipMemcpy(out_logpdf, c0->comm_all.as<double>() + P, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost));
+    return AGP_OK;
+  }
+  NCCLCHK(c0, rccl().GroupStart());
+  for (int d = 0; d < n_dev; ++d) {
+    agp_ctx* c = ctxs[d];
+    HIPCHK(c0, hipSetDevice(c->device));
+    const int rc = enqueue_gather(c, c->comm_all.as<double>() + P, P, c->comm_all.as<double>(), c->comm_stream);
+    if (rc) { (void)rccl().GroupEnd(); return rc; }
+  }
+  NCCLCHK(c0, rccl().GroupEnd());
+  for (int d = 0; d < n_dev; ++d) {
+    agp_ctx* c = ctxs[d];
+    HIPCHK(c0, hipSetDevice(c->device));
+    const int rc = finish_gather(c, P, c->comm_all.as<double>(), c->comm_stream);
+    if (rc) return rc;
+  }
+  for (int d = n_dev - 1; d >= 0; --d) {
+    HIPCHK(c0, hipSetDevice(ctxs[d]->device));
+    if (d == 0) HIPCHK(c0, hipMemcpyAsync(out_logpdf, c0->comm_all.p, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, c0->comm_stream));
+    HIPCHK(c0, hipStreamSynchronize(ctxs[d]->comm_stream));
+  }
   return AGP_OK;
 }
 

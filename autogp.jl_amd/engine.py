@@ -28,7 +28,10 @@ EXPORTED_SYMBOLS = [
     "agp_logpdf_batch", "agp_logpdf_grad_batch", "agp_logpdf_grad", "agp_logpdf_batch_device", "agp_predict_batch", "agp_infer_gp_sum", "agp_cov_matrix",
     "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_debug_mfma_peak", "agp_debug_math", "agp_debug_gemm_variant", "agp_set_profiling", "agp_get_timing", "agp_get_launch_times",
     "agp_set_workspace_limit", "agp_set_coalesce_window", "agp_get_coalesce_stats", "agp_get_dedup_stats",
+    "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
+    "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi",
 ]
+COMM_ID_BYTES = 128
 
 
 class AGPError(RuntimeError):
@@ -115,6 +118,17 @@ def load_library(path=None):
     lib.agp_set_coalesce_window.argtypes = [vp, C.c_int32]; lib.agp_set_coalesce_window.restype = C.c_int
     lib.agp_get_coalesce_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.agp_get_coalesce_stats.restype = C.c_int
     lib.agp_get_dedup_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.agp_get_dedup_stats.restype = C.c_int
+    i32p = C.POINTER(C.c_int32)
+    lib.agp_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32p, i32p]; lib.agp_shard_range.restype = None
+    lib.agp_comm_get_unique_id.argtypes = [vp]; lib.agp_comm_get_unique_id.restype = C.c_int
+    lib.agp_comm_init_rank.argtypes = [vp, vp, C.c_int32, C.c_int32]; lib.agp_comm_init_rank.restype = C.c_int
+    lib.agp_comm_info.argtypes = [vp, i32p, i32p]; lib.agp_comm_info.restype = C.c_int
+    lib.agp_init_multi.argtypes = [C.POINTER(vp), i32p, C.c_int32]; lib.agp_init_multi.restype = C.c_int
+    lib.agp_set_data_multi.argtypes = [C.POINTER(vp), C.c_int32, dp, dp, C.c_int64]; lib.agp_set_data_multi.restype = C.c_int
+    lib.agp_allgather_logweights.argtypes = [vp, dp, C.c_int32]; lib.agp_allgather_logweights.restype = C.c_int
+    lib.agp_allgather_logweights_device.argtypes = [vp, vp, C.c_int32, vp, vp]; lib.agp_allgather_logweights_device.restype = C.c_int
+    lib.agp_logpdf_batch_multi.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, ip]
+    lib.agp_logpdf_batch_multi.restype = C.c_int
     if path is None:
         _lib = lib
     return lib
@@ -139,15 +153,51 @@ def _f64(a):
 class GPEngine:
     """One engine context per GPU (the C ABI's agp_ctx)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, _ctx=None):
         self._lib = load_library()
-        self._ctx = C.c_void_p()
-        rc = self._lib.agp_init(C.byref(self._ctx), int(device))
-        if rc != 0:
-            msg = self._lib.agp_last_error(None)
-            raise AGPError(f"agp_init failed ({rc}): {msg.decode() if msg else ''}")
+        if _ctx is not None:          # a context created by agp_init_multi
+            self._ctx = _ctx
+        else:
+            self._ctx = C.c_void_p()
+            rc = self._lib.agp_init(C.byref(self._ctx), int(device))
+            if rc != 0:
+                msg = self._lib.agp_last_error(None)
+                raise AGPError(f"agp_init failed ({rc}): {msg.decode() if msg else ''}")
         self.device = int(device)
         self.n_max = 0
+
+    # -- multi-GPU: communicator + the log-weight all-gather (RCCL behind the C ABI) ----------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """128-byte RCCL id created on rank 0; hand it to the other ranks over any host channel."""
+        lib = load_library()
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        rc = lib.agp_comm_get_unique_id(C.cast(buf, C.c_void_p))
+        if rc != 0:
+            msg = lib.agp_last_error(None)
+            raise AGPError(f"agp_comm_get_unique_id failed ({rc}): {msg.decode() if msg else ''}")
+        return buf.raw
+
+    def comm_init_rank(self, comm_id: bytes, n_ranks: int, rank: int):
+        if len(comm_id) != COMM_ID_BYTES:
+            raise ValueError("communicator id must be 128 bytes")
+        buf = C.create_string_buffer(comm_id, COMM_ID_BYTES)
+        self._check(self._lib.agp_comm_init_rank(self._ctx, C.cast(buf, C.c_void_p), int(n_ranks), int(rank)))
+
+    def comm_info(self):
+        r = C.c_int32(); n = C.c_int32()
+        has = self._lib.agp_comm_info(self._ctx, C.byref(r), C.byref(n))
+        return bool(has), r.value, n.value
+
+    def allgather_logweights(self, lw):
+        """Host form: `lw` (P float64) with this rank's block filled; returns the complete vector."""
+        lw = np.ascontiguousarray(np.asarray(lw, dtype=np.float64)).copy()
+        self._check(self._lib.agp_allgather_logweights(self._ctx, _dp(lw), lw.shape[0]))
+        return lw
+
+    def allgather_logweights_device(self, d_local_ptr, P, d_all_ptr, stream_ptr=0):
+        self._check(self._lib.agp_allgather_logweights_device(self._ctx, C.c_void_p(d_local_ptr), int(P),
+                                                              C.c_void_p(d_all_ptr), C.c_void_p(stream_ptr)))
 
     # -- lifetime --------------------------------------------------------------------------
     def close(self):
@@ -350,6 +400,60 @@ class GPEngine:
 
     def set_workspace_limit(self, nbytes: int):
         self._check(self._lib.agp_set_workspace_limit(self._ctx, int(nbytes)))
+
+
+def shard_range(P: int, rank: int, n_ranks: int):
+    """agp_shard_range: block [lo, hi) of rank `rank` (the C ABI's partition; equals dist.shard_range)."""
+    lo = C.c_int32(); hi = C.c_int32()
+    load_library().agp_shard_range(int(P), int(rank), int(n_ranks), C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+class GPEngineMulti:
+    """One host process driving several GPUs (agp_init_multi): what a single Julia process would hold.
+    `engines[i]` is the per-device GPEngine (rank i of the node communicator)."""
+
+    def __init__(self, device_ids):
+        self._lib = load_library()
+        ids = np.ascontiguousarray(np.asarray(device_ids, dtype=np.int32))
+        self._n = int(ids.shape[0])
+        self._arr = (C.c_void_p * self._n)()
+        rc = self._lib.agp_init_multi(self._arr, _ip(ids), self._n)
+        if rc != 0:
+            msg = self._lib.agp_last_error(None)
+            raise AGPError(f"agp_init_multi failed ({rc}): {msg.decode() if msg else ''}")
+        self.engines = [GPEngine(int(d), _ctx=C.c_void_p(self._arr[i])) for i, d in enumerate(ids)]
+        self.n_max = 0
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.engines = []
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._lib.agp_last_error(C.c_void_p(self._arr[0]))
+            raise AGPError(f"engine call failed ({rc}): {msg.decode() if msg else ''}")
+
+    def set_data(self, ts, xs):
+        ts, xs = _f64(ts), _f64(xs)
+        self._check(self._lib.agp_set_data_multi(self._arr, self._n, _dp(ts), _dp(xs), ts.shape[0]))
+        self.n_max = ts.shape[0]
+        for e in self.engines:
+            e.n_max = self.n_max
+
+    def logpdf_batch(self, nodes, noises, n=None, check=True, programs=None):
+        n = self.n_max if n is None else int(n)
+        op_off, ops, prm_off, prm = programs if programs is not None else _gp.encode_batch(nodes)
+        P = op_off.shape[0] - 1
+        noises = _f64(noises)
+        out = np.empty(P); info = np.empty(P, dtype=np.int32)
+        self._check(self._lib.agp_logpdf_batch_multi(self._arr, self._n, n, P, _ip(op_off), _u8(ops), _ip(prm_off), _dp(prm),
+                                                     _dp(noises), _dp(out), _ip(info)))
+        if check and (info > 0).any():
+            p = int(np.argmax(info > 0))
+            raise PosDefException(int(info[p]), p)
+        return out, info
 
 
 # ------------------------------------------------------------------------------------------

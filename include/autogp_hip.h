@@ -61,10 +61,12 @@ typedef struct agp_ctx agp_ctx;
 #define AGP_ERR_HIP         -2
 #define AGP_ERR_PROGRAM     -3   /* malformed postfix program / unsupported tree shape */
 #define AGP_ERR_NODATA      -4
+#define AGP_ERR_COMM        -5   /* RCCL unavailable / collective failed */
 
 #define AGP_MAX_OPS        255   /* nodes per kernel tree (depth-6 full tree = 63) */
 
-/* One context per GPU (one process per GPU in the multi-GPU deployment). */
+/* One context per GPU.  Multi-GPU deployments: one process per GPU (agp_init + agp_comm_init_rank), or one host
+ * process driving every GPU of the node (agp_init_multi) — see the multi-GPU section below. */
 int  agp_init(agp_ctx** out, int device_id);
 void agp_destroy(agp_ctx* ctx);
 const char* agp_last_error(agp_ctx* ctx);
@@ -113,8 +115,10 @@ int agp_logpdf_grad(agp_ctx* ctx, int64_t n,
 
 /* Same sweep, results left in DEVICE memory (d_out_logpdf: P doubles, d_out_info: P int32,
  * both device pointers) and enqueued on `hip_stream` (a hipStream_t; NULL = the slot's own
- * stream, synchronised before return).  This is the entry the multi-GPU driver uses so that the
- * log-weight all-gather (src/inference_smc_anneal_data.jl:22-31,232) consumes device buffers. */
+ * stream, synchronised before return).  With a caller stream the call RETURNS AS SOON AS THE WORK IS ENQUEUED
+ * (no host wait; the workspace stays reserved behind an event), so the caller chains its consumer — the
+ * log-weight all-gather, agp_allgather_logweights_device — on the same stream and synchronises once.  This is the
+ * entry the multi-GPU driver uses (src/inference_smc_anneal_data.jl:22-31,232 consume the gathered vector). */
 int agp_logpdf_batch_device(agp_ctx* ctx, int64_t n, int32_t P,
                             const int32_t* op_off, const uint8_t* ops,
                             const int32_t* prm_off, const double* prm,
@@ -149,6 +153,45 @@ int agp_cov_matrix(agp_ctx* ctx, const double* ts, int64_t n,
                    const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
                    double noise, double* out_K);
 
+/* ---- multi-GPU: particle sharding + the log-weight all-gather (RCCL over xGMI) --------------------------------
+ * Particles are independent units: rank r of R evaluates the block [lo, hi) = agp_shard_range(P, r, R) of the
+ * population on its own GPU (ts / xs replicated by agp_set_data, matrices never leave the GPU).  The only exchange
+ * is the all-gather of the P log-weights that ESS / resampling consume on every rank
+ * (compute_particle_weights / effective_sample_size, src/inference_smc_anneal_data.jl:22-31; Gen.maybe_resample!
+ * at :232).  librccl is loaded on first use (dlopen, soname librccl.so.1; env AGP_RCCL_LIB overrides): single-GPU
+ * users never need it. */
+#define AGP_COMM_ID_BYTES 128    /* == sizeof(ncclUniqueId) */
+
+/* first P % R ranks hold one particle more; identical on every rank */
+void agp_shard_range(int32_t P, int32_t rank, int32_t n_ranks, int32_t* lo, int32_t* hi);
+
+/* One process (or thread) per GPU: rank 0 creates the id, hands the 128 bytes to the other ranks over any host
+ * channel (MPI, a file, Julia's Distributed, torch.distributed), every rank then joins with its own context. */
+int agp_comm_get_unique_id(void* out_id /* AGP_COMM_ID_BYTES */);
+int agp_comm_init_rank(agp_ctx* ctx, const void* id, int32_t n_ranks, int32_t rank);
+/* returns 1 when the context has a communicator, 0 otherwise; rank / n_ranks may be NULL */
+int agp_comm_info(agp_ctx* ctx, int32_t* rank, int32_t* n_ranks);
+
+/* One host process driving n_dev GPUs (a single Julia process): n_dev contexts + one communicator over them
+ * (ncclCommInitAll).  out[i] is the context of device_ids[i] and rank i; destroy each with agp_destroy. */
+int agp_init_multi(agp_ctx** out /* n_dev */, const int32_t* device_ids, int32_t n_dev);
+int agp_set_data_multi(agp_ctx* const* ctxs, int32_t n_dev, const double* ts, const double* xs, int64_t n_max);
+
+/* All-gather of the log-weight vector.  Host form: inout_lw has P entries, this rank's block [lo, hi) filled on
+ * entry, all P filled on return (every rank calls it; n_ranks == 1 is a no-op).  Device form: d_local holds the
+ * hi - lo values of this rank (e.g. the d_out_logpdf of agp_logpdf_batch_device), d_all receives all P; enqueued on
+ * hip_stream (NULL = engine stream, synchronised before return).  Blocks of unequal length are handled inside. */
+int agp_allgather_logweights(agp_ctx* ctx, double* inout_lw, int32_t P);
+int agp_allgather_logweights_device(agp_ctx* ctx, const double* d_local, int32_t P, double* d_all, void* hip_stream);
+
+/* agp_logpdf_batch over the contexts of agp_init_multi: shards the P particles by agp_shard_range, runs every
+ * shard's sweep concurrently (one host thread per device), all-gathers the log-weights over RCCL in one group call
+ * and returns the complete vector (every device also keeps it).  out_logpdf / out_info: P entries, caller order. */
+int agp_logpdf_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P,
+                           const int32_t* op_off, const uint8_t* ops,
+                           const int32_t* prm_off, const double* prm,
+                           const double* noise, double* out_logpdf /* P */, int32_t* out_info /* P */);
+
 /* ---- measurement / debugging hooks (not part of the reference surface) ---- */
 
 /* Factor a caller-supplied dense SPD matrix (n x n column-major) with the device Cholesky;
@@ -167,7 +210,8 @@ int agp_debug_math(agp_ctx* ctx, int32_t which, const double* x, const double* g
 int agp_debug_mfma_peak(agp_ctx* ctx, int32_t iters, int32_t wg_per_cu, double* out_tflops, double* out_ghz);
 
 /* Ablation harness for the update GEMM (off-diagonal tiles of block column k on pseudo-random data):
- * average milliseconds per launch for `variant` (see csrc/agp_experiments.hpp). */
+ * average milliseconds per launch for `variant` (see csrc/agp_experiments.hpp).  Compiled only into measurement
+ * builds (-DAGP_EXPERIMENTS, `python __graft_entry__.py --experiments`); the product library returns AGP_ERR_ARG. */
 int agp_debug_gemm_variant(agp_ctx* ctx, int32_t P, int32_t nt, int32_t k, int32_t variant, int32_t reps, double* out_ms);
 
 /* When enabled, batch calls bracket their phases with HIP events on the launch stream.

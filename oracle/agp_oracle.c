@@ -58,6 +58,17 @@ void agp_oracle_cov(const uint8_t* ops, int n_ops, const double* prm, double noi
     }
 }
 
+/* Lower triangle only (column-major, upper part untouched): the input LAPACK dpotrf(uplo = 'L') wants.
+ * Used by oracle/fast.py (C assembly + LAPACK factorisation), the large-n checker and the bench's CPU baseline. */
+void agp_oracle_cov_lower(const uint8_t* ops, int n_ops, const double* prm, double noise, const double* ts, int n,
+                          double* K) {
+  for (int j = 0; j < n; ++j) {
+    double* cj = K + (size_t)j * n;
+    for (int i = j; i < n; ++i) cj[i] = eval_program(ops, n_ops, prm, ts[i], ts[j]);
+    cj[j] += noise;
+  }
+}
+
 /* in-place lower Cholesky, column-major; returns LAPACK-style info */
 static int cholesky_lower(double* A, int n) {
   for (int j = 0; j < n; ++j) {
