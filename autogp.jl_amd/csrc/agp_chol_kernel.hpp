@@ -57,6 +57,12 @@ struct CholArgs {
   int wsteps;           // 1: W holds the current step's inverses only; nt: W keeps every step (gradient path)
   int rl;               // factor mode, right-looking schedule: the tile already holds C(k,k) (no left-looking sum)
   int j0;               // Schur mode: the sum runs over block columns [j0, nt1) (right-looking: one column)
+  // Block-extension sweeps over the resident factor store (agp_logpdf_batch_extend): particle p's storage (A, W, vec,
+  // partial, info, ready) is slot[p] instead of p, and tile rows below i0[p] already hold its factor from an earlier
+  // sweep on a shorter prefix of the data — their workgroups leave at once.  Both null in ordinary sweeps.
+  const int* slot;
+  const int* i0;
+  int ntp;              // row stride of `partial` per storage index (0: nt)
 };
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -255,7 +261,7 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { ss += __shfl_xor(ss, off); ld += __shfl_xor(ld, off); }
     if (l == 0) {
-      double* pp = a.partial + ((long long)p * a.nt + tk) * 2;
+      double* pp = a.partial + ((long long)p * (a.ntp ? a.ntp : a.nt) + tk) * 2;
       pp[0] = ld;
       pp[1] = ss;
       if (bad != 0 && a.info[p] == 0) a.info[p] = bad;
@@ -344,6 +350,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   }
   const int p = pl * 8 + xcd;
   if (p >= a.P) return;
+  if (FACTOR && a.i0 != nullptr && ti < a.i0[p]) return;    // extension sweep: this tile row is already factored
+  const int ps = (FACTOR && a.slot != nullptr) ? a.slot[p] : p;    // storage index
   const bool is_diag = (DM == 2) ? false : (ti == tk);
 
   const int tid = threadIdx.x;
@@ -353,8 +361,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   const int row0 = ILV ? 32 * w + 2 * l15 : 32 * w + l15;   // this lane's row in strip 0
   const int row1 = ILV ? row0 + 1 : row0 + 16;              // ... and in strip 1
 
-  double* __restrict__ Ap = a.A + (long long)p * a.strideA;
-  double* vecp = a.vec + (long long)p * a.ldv;
+  double* __restrict__ Ap = a.A + (long long)ps * a.strideA;
+  double* vecp = a.vec + (long long)ps * a.ldv;
 
   // Accumulators hold -C(i,k) throughout: they start at -A(i,k), the K-loop adds L(i,j) L(k,j)^T.
   // Fused particles evaluate A(i,k) from their kernel program straight into the accumulator layout
@@ -544,9 +552,9 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     if (tid == 0) {
       const int want = a.k + 1;
       int spins = 0;
-      while (__hip_atomic_load(a.ready + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      while (__hip_atomic_load(a.ready + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
         __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1 << 22)) { a.info[p] = -7; break; }   // bounded (~1 s): never hang the device
+        if (++spins > (1 << 22)) { a.info[ps] = -7; break; }   // bounded (~1 s): never hang the device
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     // stage +L(k,k) strictly-lower blocks and -W blocks in A-operand order (fragment s of lane l at 64 s + l)
     {
       const double* __restrict__ Lkk = Ap + tile_off(a.k, a.k);
-      const double* __restrict__ Wg = a.W + ((long long)p * a.wsteps + a.k % a.wsteps) * NSB * 256;
+      const double* __restrict__ Wg = a.W + ((long long)ps * a.wsteps + a.k % a.wsteps) * NSB * 256;
       const int c = tid >> 4, r = tid & 15;
 #pragma unroll
       for (int jb = 1; jb < NSB; ++jb)
@@ -615,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
         for (int r = 0; r < 4; ++r) blk[(4 * r + lq) * 16 + rr] = -acc[cb][st][r];
       }
   }
-  factor_diag_tile<INTRSM>(a, p, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid);
+  factor_diag_tile<INTRSM>(a, ps, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid);
 }
 
 // K2a — the diagonal tiles of block column k, one workgroup per particle.  Only the lower block triangle of
@@ -639,6 +647,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
   const int p = pl * 8 + xcd;
   if (p >= a.P) return;
   const int tk = a.k;
+  if (a.i0 != nullptr && tk < a.i0[p]) return;              // extension sweep: column already factored
+  const int ps = a.slot != nullptr ? a.slot[p] : p;         // storage index
   const int jmax = a.rl ? 0 : a.k;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   const int wu = __builtin_amdgcn_readfirstlane(w);
@@ -649,8 +659,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
 #pragma unroll
   for (int e = 0; e < NE; ++e) { st1[e] = e > wu; cbe[e] = st1[e] ? e - (wu + 1) : e; }
 
-  double* __restrict__ Ap = a.A + (long long)p * a.strideA;
-  double* vecp = a.vec + (long long)p * a.ldv;
+  double* __restrict__ Ap = a.A + (long long)ps * a.strideA;
+  double* vecp = a.vec + (long long)ps * a.ldv;
   double* __restrict__ Tt = Ap + tile_off(tk, tk);
   d4 acc[NE];
   const bool prebuilt = (DCOV == 0) || (p >= a.n_fused);
@@ -805,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) blk[(4 * r + lq) * 16 + l15] = -acc[e][r];
   }
-  factor_diag_tile<true>(a, p, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid);
+  factor_diag_tile<true>(a, ps, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid);
 }
 
 // T — L(i,k) = C(i,k) L(k,k)^-T for the tiles below the diagonal of block column k.
@@ -895,20 +905,36 @@ __global__ __launch_bounds__(256, 2) void k_chol_trsm(CholArgs a) {
 }
 
 // logpdf = -1/2 (n log 2pi + log|K| + alpha'alpha)   (Gen.mvnormal logpdf, src/Model.jl:136)
+// (extension sweeps: particle p's partials / info live at storage index slot[p] with row stride ntp >= nt)
 __global__ void k_finish_logpdf(const double* partial, const int* info, int nt, int P, int n,
-                                const int* map, double* out_logpdf, int* out_info) {
+                                const int* map, double* out_logpdf, int* out_info,
+                                const int* slot = nullptr, int ntp = 0) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
+  const int ps = slot ? slot[p] : p;
+  if (ntp == 0) ntp = nt;
   double ld = 0.0, ss = 0.0;
   for (int k = 0; k < nt; ++k) {
-    ld += partial[((long long)p * nt + k) * 2];
-    ss += partial[((long long)p * nt + k) * 2 + 1];
+    ld += partial[((long long)ps * ntp + k) * 2];
+    ss += partial[((long long)ps * ntp + k) * 2 + 1];
   }
-  const int inf = info[p];
+  const int inf = info[ps];
   const double lp = -0.5 * ((double)n * 1.8378770664093454835606594728112 + ld + ss);
   const int o = map[p];          // un-sort: position in the caller's particle order
   out_logpdf[o] = (inf != 0) ? __builtin_nan("") : lp;
   out_info[o] = inf;
+}
+
+// Extension sweep: re-arm the rows the sweep recomputes (tile rows >= i0[p]) with the data, keep alpha of the rows
+// below; ready[slot] = i0 (those block columns are published), info cleared for particles factored from scratch.
+__global__ void k_init_extend(double* vec, int ldv, int n_pad, const double* xs, int n, const int* slot, const int* i0,
+                              int* info, int* ready) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  const int ps = slot[p], r0 = i0[p];
+  if (g == 0) { ready[ps] = r0; if (r0 == 0) info[ps] = 0; }
+  if (g >= n_pad || g < r0 * NB) return;
+  vec[(long long)ps * ldv + g] = g < n ? xs[g] : 0.0;
 }
 
 // x (minus the mean function on the training segment), zero elsewhere; clears info.

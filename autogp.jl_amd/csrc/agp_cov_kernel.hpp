@@ -37,6 +37,8 @@ struct CovArgs {
   int p_off;             // first particle (blockIdx.y is relative to it)
   const uint8_t* code;   // per joint point: 0 observable, i latent of component i (infer_gp_sum); null = all 0
   const double* logdt;   // packed lower tiles of log|t_i - t_j| over the resident data (programs with flags bit 0)
+  const int* slot;       // extension sweeps (see CholArgs): storage index per particle, first tile row to (re)build
+  const int* i0;
 };
 
 __device__ __forceinline__ int prm_count(int o) {
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
     while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
     tj = tix - ti * (ti + 1) / 2;
   }
+  if (a.i0 != nullptr && ti < a.i0[p]) return;        // extension sweep: this tile row keeps its factor
   const int tid = threadIdx.x;
   const ProgHdr h = a.hdr[p];
   const uint8_t* __restrict__ ops = a.ops + h.op_off;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
   const double tr0 = tpt[r0], tr1 = tpt[r0 + 1];
   const int gi0 = ti * NB + r0;
   const double noise = a.noise[p];
-  double* __restrict__ T = a.A + (long long)p * a.strideA + tile_off(ti, tj);
+  double* __restrict__ T = a.A + (long long)(a.slot != nullptr ? a.slot[p] : p) * a.strideA + tile_off(ti, tj);
 
   const bool use_tab = (h.flags & 1) != 0;
   const double* __restrict__ ltile = a.logdt + tile_off(ti, tj);      // only dereferenced when use_tab

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = [
     "agp_set_workspace_limit", "agp_set_coalesce_window", "agp_get_coalesce_stats", "agp_get_dedup_stats",
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi",
+    "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
 ]
 COMM_ID_BYTES = 128
 
@@ -118,6 +119,11 @@ def load_library(path=None):
     lib.agp_set_coalesce_window.argtypes = [vp, C.c_int32]; lib.agp_set_coalesce_window.restype = C.c_int
     lib.agp_get_coalesce_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.agp_get_coalesce_stats.restype = C.c_int
     lib.agp_get_dedup_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.agp_get_dedup_stats.restype = C.c_int
+    lib.agp_logpdf_batch_extend.argtypes = [vp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, ip]
+    lib.agp_logpdf_batch_extend.restype = C.c_int
+    lib.agp_extend_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_extend_stats.restype = C.c_int
+    lib.agp_extend_reset.argtypes = [vp, C.c_int]; lib.agp_extend_reset.restype = C.c_int
+    lib.agp_extend_reserve.argtypes = [vp, C.c_int64, C.c_int32]; lib.agp_extend_reserve.restype = C.c_int
     i32p = C.POINTER(C.c_int32)
     lib.agp_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32p, i32p]; lib.agp_shard_range.restype = None
     lib.agp_comm_get_unique_id.argtypes = [vp]; lib.agp_comm_get_unique_id.restype = C.c_int
@@ -269,6 +275,35 @@ class GPEngine:
             p = int(np.argmax(info > 0))
             raise PosDefException(int(info[p]), p)
         return out, info
+
+    def logpdf_batch_extend(self, nodes, noises, n=None, check=True, programs=None):
+        """agp_logpdf_batch_extend: like logpdf_batch, but the factors stay resident and a later call on a longer
+        prefix of the same data only computes the new tile rows (data annealing, add_data!)."""
+        n = self.n_max if n is None else int(n)
+        op_off, ops, prm_off, prm = programs if programs is not None else _gp.encode_batch(nodes)
+        P = op_off.shape[0] - 1
+        noises = _f64(noises)
+        if noises.shape != (P,):
+            raise ValueError("one noise per particle required")
+        out = np.empty(P, dtype=np.float64); info = np.empty(P, dtype=np.int32)
+        self._check(self._lib.agp_logpdf_batch_extend(self._ctx, n, P, _ip(op_off), _u8(ops), _ip(prm_off), _dp(prm),
+                                                      _dp(noises), _dp(out), _ip(info)))
+        if check and (info > 0).any():
+            p = int(np.argmax(info > 0))
+            raise PosDefException(int(info[p]), p)
+        return out, info
+
+    def extend_stats(self):
+        """dict(extended, from_scratch, tile_rows_reused, tile_rows_total)."""
+        out = (C.c_int64 * 4)()
+        self._check(self._lib.agp_extend_stats(self._ctx, out))
+        return dict(zip(("extended", "from_scratch", "tile_rows_reused", "tile_rows_total"), [int(v) for v in out]))
+
+    def extend_reset(self, release_memory=False):
+        self._check(self._lib.agp_extend_reset(self._ctx, 1 if release_memory else 0))
+
+    def extend_reserve(self, n_cap, n_slots):
+        self._check(self._lib.agp_extend_reserve(self._ctx, int(n_cap), int(n_slots)))
 
     def logpdf_grad_batch(self, nodes, noises, n=None, check=True, programs=None):
         """(logpdf[P], grads, grad_noise[P], info[P]); grads[p] is d logpdf / d theta in the order of

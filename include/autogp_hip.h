@@ -93,6 +93,33 @@ int agp_logpdf_batch(agp_ctx* ctx, int64_t n, int32_t P,
                      const double* noise,
                      double* out_logpdf /* P */, int32_t* out_info /* P */);
 
+/* agp_logpdf_batch with BLOCK-EXTENSION of resident factors.  The data-annealing loop re-scores
+ * every particle on a longer prefix of the same series with unchanged kernel parameters — the reweight step
+ * (src/inference_smc_anneal_data.jl:206-217), add_data! (src/api.jl:426-443), scripts/online.jl:200 — and the
+ * reference refactorises from scratch each time.  This entry keeps each particle's Cholesky factor (packed tiles,
+ * per-column inverse blocks, forward-solve vector, log-det / quadratic-form partials) in a context-owned store keyed by
+ * the exact bits of (program, parameters, noise).  Called again with a larger n for a particle it holds, it only
+ * computes the tile rows from floor(n_cached / 128) on: L_new = [L_old 0; B L_old^-T, chol(C - ..)], i.e.
+ * (n^3 - n_cached^3)/3 flops instead of n^3/3; called with the same n it only re-reads the result.  Results equal
+ * agp_logpdf_batch's (same kernels, same operation order per tile).  Any change of a parameter bit or of the tree is a
+ * different key and factors from scratch; agp_set_data keeps the store when the new series has the resident one as a
+ * prefix (add_data! appends) and empties it otherwise.  Duplicate particles (resampled populations) are evaluated
+ * once.  The store takes at most ~45 % of device memory, slots are recycled least-recently-used; a population that
+ * cannot fit runs through agp_logpdf_batch unchanged.  One extension sweep at a time per context. */
+int agp_logpdf_batch_extend(agp_ctx* ctx, int64_t n, int32_t P,
+                            const int32_t* op_off, const uint8_t* ops,
+                            const int32_t* prm_off, const double* prm,
+                            const double* noise,
+                            double* out_logpdf /* P */, int32_t* out_info /* P */);
+/* out4 = { particles extended from a resident factor, particles factored from scratch,
+ *          tile rows reused, tile rows a from-scratch sweep would have computed } since agp_init / the last reset */
+int agp_extend_stats(agp_ctx* ctx, int64_t* out4);
+/* forget every resident factor (release_memory != 0 also frees the store) */
+int agp_extend_reset(agp_ctx* ctx, int release_memory);
+/* pre-size the store for series of up to n_cap observations and n_slots particles (optional: it grows on demand,
+ * keeping its contents) */
+int agp_extend_reserve(agp_ctx* ctx, int64_t n_cap, int32_t n_slots);
+
 /* Value AND gradient: d logpdf / d theta for every (transformed) kernel parameter — out_grad has the
  * layout of `prm` (prm_off offsets; ChangePoint contributes d/dlocation, d/dscale) — and d logpdf / d noise.
  * This is what Gen.choice_gradients needs from the model body for Gen.hmc / Gen.map_optimize

@@ -9,8 +9,8 @@ particles) that the NumPy version — 2-4 n x n temporaries per leaf — only fi
     Gen.mvnormal -> Distributions.MvNormal -> PDMats -> LAPACK dpotrf, logdet = 2 sum log L_ii,
     sqmahal = |L^-1 x|^2 via dtrtrs) through SciPy's LAPACK (OpenBLAS, the family Julia links).
 
-One particle per thread with single-threaded BLAS — the reference's own decomposition
-(Threads.@threads over particles, src/api.jl:225-227); ctypes and SciPy release the GIL inside the C calls.
+One particle per worker with single-threaded BLAS — the reference's own decomposition
+(Threads.@threads over particles, src/api.jl:225-227) — in worker processes (OraclePool).
 Pinned against oracle/oracle.py in tests/test_oracle.py (which is itself pinned as its header states:
 PARITY UNPINNED BY THE REFERENCE).
 """
@@ -19,7 +19,6 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import numpy as np
@@ -27,6 +26,7 @@ from scipy.linalg import lapack
 
 _HERE = Path(__file__).resolve().parent
 _LIB = None
+_KBUF = {}
 
 
 def _lib():
@@ -56,7 +56,10 @@ def gp_logpdf_program(ops, prm, noise, ts, xs):
     n = ts.shape[0]
     if n == 0:
         return 0.0, 0
-    K = np.empty((n, n), dtype=np.float64, order="F")
+    K = _KBUF.get(n)
+    if K is None:
+        _KBUF.clear()
+        K = _KBUF[n] = np.empty((n, n), dtype=np.float64, order="F")     # reused: dpotrf overwrites the lower triangle only
     _lib().agp_oracle_cov_lower(ops.ctypes.data, int(ops.shape[0]), prm.ctypes.data, float(noise), ts.ctypes.data, n,
                                 K.ctypes.data)
     L, info = lapack.dpotrf(K, lower=1, clean=0, overwrite_a=1)
@@ -67,21 +70,135 @@ def gp_logpdf_program(ops, prm, noise, ts, xs):
     return -0.5 * (n * math.log(2.0 * math.pi) + logdet + float(a @ a)), 0
 
 
+# ---- many particles: one worker PROCESS per host core (SciPy's f2py LAPACK wrappers hold the GIL, and page faults of
+# many threads in one address space serialise on the mm lock), each with single-threaded BLAS and one reused n x n
+# buffer.  Workers are plain `python -c` subprocesses fed over pipes (no multiprocessing: nothing re-imports the
+# caller's __main__), the series / programs travel once through a temporary .npz file. ----
+_W = {}
+
+
+def _worker_load(programs, noises, ts, xs):
+    _W["programs"] = programs; _W["noises"] = noises; _W["ts"] = ts; _W["xs"] = xs
+
+
+def _worker_eval(i):
+    op_off, ops, prm_off, prm = _W["programs"]
+    return gp_logpdf_program(ops[op_off[i]:op_off[i + 1]], prm[prm_off[i]:prm_off[i + 1]], float(_W["noises"][i]),
+                             _W["ts"], _W["xs"])
+
+
+def _worker_main(npz_path):
+    """Entry of a worker subprocess: job indices in on stdin (one per line), 'index logpdf info' out on stdout."""
+    import sys
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    z = np.load(npz_path)
+    _worker_load((z["op_off"], z["ops"], z["prm_off"], z["prm"]), z["noises"], z["ts"], z["xs"])
+    _lib()
+    sys.stdout.write("ready\n"); sys.stdout.flush()
+    for line in sys.stdin:
+        line = line.strip()
+        if not line:
+            continue
+        i = int(line)
+        lp, info = _worker_eval(i)
+        sys.stdout.write(f"{i} {lp!r} {info}\n"); sys.stdout.flush()
+
+
+class OraclePool:
+    """Worker processes holding (programs, noises, ts, xs); evaluate(indices) -> (lp, info), work handed out
+    dynamically (one feeder thread per worker, blocked in pipe I/O)."""
+
+    def __init__(self, programs, noises, ts, xs, workers=None):
+        import subprocess
+        import sys
+        import tempfile
+        self.workers = int(workers or host_cores())
+        _lib()                                   # build the C oracle once, before the workers look for it
+        fd, self._npz = tempfile.mkstemp(suffix=".npz", prefix="agp_oracle_")
+        os.close(fd)
+        op_off, ops, prm_off, prm = programs
+        np.savez(self._npz, op_off=op_off, ops=ops, prm_off=prm_off, prm=prm if len(prm) else np.zeros(1),
+                 noises=np.asarray(noises, dtype=np.float64), ts=np.asarray(ts, dtype=np.float64), xs=np.asarray(xs, dtype=np.float64))
+        env = dict(os.environ, OPENBLAS_NUM_THREADS="1", OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        code = f"import sys; sys.path.insert(0, {str(_HERE.parent)!r}); from oracle import fast; fast._worker_main({self._npz!r})"
+        self.procs = [subprocess.Popen([sys.executable, "-c", code], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True,
+                                       env=env, bufsize=1) for _ in range(self.workers)]
+        for pr in self.procs:
+            if pr.stdout.readline().strip() != "ready":
+                self.close()
+                raise RuntimeError("oracle worker failed to start")
+
+    def evaluate(self, indices):
+        import queue
+        import threading
+        idx = list(indices)
+        q = queue.Queue()
+        for k, i in enumerate(idx):
+            q.put((k, i))
+        lp = np.full(len(idx), np.nan); info = np.zeros(len(idx), dtype=np.int32)
+        errs = []
+
+        def feed(pr):
+            try:
+                while True:
+                    try:
+                        k, i = q.get_nowait()
+                    except queue.Empty:
+                        return
+                    pr.stdin.write(f"{i}\n"); pr.stdin.flush()
+                    parts = pr.stdout.readline().split()
+                    if len(parts) != 3 or int(parts[0]) != i:
+                        raise RuntimeError(f"oracle worker protocol error: {parts}")
+                    lp[k] = float(parts[1]); info[k] = int(parts[2])
+            except Exception as e:      # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=feed, args=(pr,)) for pr in self.procs[:max(1, min(self.workers, len(idx)))]]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        return lp, info
+
+    def close(self):
+        for pr in getattr(self, "procs", []):
+            try:
+                pr.stdin.close()
+            except Exception:
+                pass
+        for pr in getattr(self, "procs", []):
+            try:
+                pr.wait(timeout=30)
+            except Exception:
+                pr.kill()
+        self.procs = []
+        try:
+            os.unlink(self._npz)
+        except OSError:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 def gp_logpdf_many(programs, noises, ts, xs, threads=None, indices=None):
     """logpdf (NaN where not PD) and info of many particles.  programs = (op_off, ops, prm_off, prm), the CSR
     form of the C ABI (autogp.jl_amd.gp.encode_batch).  Returns (lp[len(indices)], info[...])."""
-    from threadpoolctl import threadpool_limits
-    op_off, ops, prm_off, prm = programs
+    op_off = programs[0]
     idx = list(range(len(op_off) - 1)) if indices is None else list(indices)
-    threads = threads or host_cores()
-
-    def one(i):
-        return gp_logpdf_program(ops[op_off[i]:op_off[i + 1]], prm[prm_off[i]:prm_off[i + 1]], float(noises[i]), ts, xs)
-
-    with threadpool_limits(1):
-        if threads <= 1 or len(idx) <= 1:
-            res = [one(i) for i in idx]
-        else:
-            with ThreadPoolExecutor(min(threads, len(idx))) as ex:
-                res = list(ex.map(one, idx))
-    return np.array([r[0] for r in res]), np.array([r[1] for r in res], dtype=np.int32)
+    workers = min(threads or host_cores(), len(idx))
+    if workers <= 1 or len(idx) * len(ts) ** 2 < 4e7:         # small jobs: not worth the process start-up
+        _worker_load(programs, noises, ts, xs)
+        res = [_worker_eval(i) for i in idx]
+        return np.array([r[0] for r in res]), np.array([r[1] for r in res], dtype=np.int32)
+    with OraclePool(programs, noises, ts, xs, workers) as pool:
+        return pool.evaluate(idx)

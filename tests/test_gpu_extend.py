@@ -1,0 +1,199 @@
+"""GPU tests of the block-extension sweeps (agp_logpdf_batch_extend): factors stay resident between
+the steps of a data-annealing schedule and only the new tile rows are computed.  The reference refactorises from
+scratch at every prefix (src/inference_smc_anneal_data.jl:206-217, src/api.jl:426-443).  Run with `-m gpu`."""
+import numpy as np
+import pytest
+
+from oracle import fast as F
+
+pytestmark = pytest.mark.gpu
+LP_TOL = 1e-8
+
+
+def lp_err(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+def same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.fixture()
+def eng(pkg):
+    e = pkg.GPEngine(0)
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("P", [5, 70, 300])
+def test_extend_equals_scratch_along_a_schedule(pkg, eng, P):
+    """Prefix lengths that straddle tile boundaries (partial last tiles are redone in full), three population
+    regimes (the mixed kernel below 256 particles, the split diagonal / sub-diagonal launches above).  At every
+    step: extended == factored-from-scratch through the same entry BIT FOR BIT, == agp_logpdf_batch to rounding,
+    == oracle within the stated tolerance."""
+    n_max = 1100
+    ts, xs = pkg.prior.synthetic_series(n_max, seed=11, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(P), P, max_depth=4, max_size=31)
+    progs = pkg.encode_batch(nodes)
+    eng.set_data(ts, xs)
+    ref_eng = pkg.GPEngine(0)
+    ref_eng.set_data(ts, xs)
+    try:
+        prev_reused = 0
+        for n in (1, 127, 130, 256, 300, 301, 700, 1024, 1100):
+            lp, info = eng.logpdf_batch_extend(None, noises, n=n, check=False, programs=progs)
+            ref_eng.extend_reset()
+            lp0, info0 = ref_eng.logpdf_batch_extend(None, noises, n=n, check=False, programs=progs)     # from scratch
+            assert same(info, info0) and same(lp, lp0), (n, np.nanmax(np.abs(lp - lp0)))
+            lp1, info1 = ref_eng.logpdf_batch(None, noises, n=n, check=False, programs=progs)
+            ok = info == 0
+            assert same(info, info1) and lp_err(lp[ok], lp1[ok]).max() <= 1e-10
+            st = eng.extend_stats()
+            if n >= 256:
+                assert st["tile_rows_reused"] > prev_reused, "nothing was reused at a step that extends whole tiles"
+            prev_reused = st["tile_rows_reused"]
+        sub = np.arange(0, P, max(1, P // 24))
+        ref, rinfo = F.gp_logpdf_many(progs, noises, ts, xs, indices=sub)
+        both = (info[sub] == 0) & (rinfo == 0)
+        assert lp_err(lp[sub][both], ref[both]).max() <= LP_TOL
+        # the same n again: nothing to compute, same bits
+        lp2, info2 = eng.logpdf_batch_extend(None, noises, n=n_max, check=False, programs=progs)
+        assert same(lp2, lp) and same(info2, info)
+    finally:
+        ref_eng.close()
+
+
+def test_config3_schedule_with_extension(pkg, eng):
+    """Config 3: 512 particles along linear_schedule(2048, .10); every step's extended sweep equals the from-scratch
+    sweep of agp_logpdf_batch to rounding, 64 particles against the oracle at the final step, and the store reports
+    the reused tile rows (step k reuses floor(n_{k-1}/128) of ceil(n_k/128) rows per particle)."""
+    n, P = 2048, 512
+    ts, xs = pkg.prior.synthetic_series(n, seed=2048, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(2048), P, max_depth=-1, max_size=63)
+    progs = pkg.encode_batch(nodes)
+    eng.set_data(ts, xs)
+    steps = pkg.schedule.linear_schedule(n, 0.10)
+    expect_reused = 0; prev = 0
+    for step in steps:
+        lp, info = eng.logpdf_batch_extend(None, noises, n=step, check=False, programs=progs)
+        lp1, info1 = eng.logpdf_batch(None, noises, n=step, check=False, programs=progs)
+        ok = info == 0
+        assert same(info, info1) and ok.mean() > 0.97
+        assert lp_err(lp[ok], lp1[ok]).max() <= 1e-10, step
+        expect_reused += P * (prev // 128); prev = step
+    st = eng.extend_stats()
+    assert st["tile_rows_reused"] == expect_reused and st["from_scratch"] == P and st["extended"] == P * (len(steps) - 1)
+    sub = np.arange(3, P, 8)
+    ref, rinfo = F.gp_logpdf_many(progs, noises, ts, xs, indices=sub)
+    both = (info[sub] == 0) & (rinfo == 0)
+    assert lp_err(lp[sub][both], ref[both]).max() <= LP_TOL
+
+
+def test_config5_stream_resample_and_rejuvenate(pkg, eng):
+    """Config 5 shape (n = 128 k, k = 1..16, 256 particles) with what happens between the reweight steps of the
+    reference: resampling (copies of survivors -> evaluated once, and their factor is found under the same key) and
+    rejuvenation (some particles get new parameters -> different key, factored from scratch, the rest extend).
+    Every step is compared with the from-scratch sweep."""
+    n_max, P = 2048, 256
+    ts, xs = pkg.prior.synthetic_series(n_max, seed=128, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(128), P, max_depth=4, max_size=31)
+    eng.set_data(ts, xs)
+    rng = np.random.default_rng(5)
+    for k in range(1, 17):
+        n = 128 * k
+        lp, info = eng.logpdf_batch_extend(nodes, noises, n=n, check=False)
+        lp1, info1 = eng.logpdf_batch(nodes, noises, n=n, check=False)
+        ok = info == 0
+        assert same(info, info1) and lp_err(lp[ok], lp1[ok]).max() <= 1e-10, k
+        if k % 3 == 0:        # resample: multinomial parents
+            w = np.where(ok, lp - np.nanmax(lp[ok]), -np.inf); w = np.exp(w); w /= w.sum()
+            parents = rng.choice(P, size=P, p=w)
+            nodes = [nodes[i] for i in parents]; noises = noises[parents]
+        if k % 2 == 0:        # rejuvenate a tenth of the population: new noise (an MH / HMC move on :noise)
+            for i in rng.choice(P, size=P // 10, replace=False):
+                noises[i] = noises[i] * float(np.exp(0.05 * rng.standard_normal()))
+    st = eng.extend_stats()
+    assert st["extended"] > 0 and st["from_scratch"] > P          # misses beyond the first sweep: the moved particles
+    assert st["tile_rows_reused"] > 0.25 * st["tile_rows_total"]
+
+
+def test_invalidation(pkg, eng):
+    """A parameter that differs in its last bit, a different tree with the same parameters, a changed noise: all
+    factor from scratch and give the from-scratch value.  New data that does not extend the resident series empties
+    the store; appended data (add_data!) keeps it."""
+    G = pkg
+    n = 600
+    ts, xs = pkg.prior.synthetic_series(n + 300, seed=77, shuffle=True)
+    eng.set_data(ts[:n], xs[:n])
+    k = G.Linear(0.1, 0.3, 0.7) + G.Periodic(0.96, 0.21, 1.1) * G.SquaredExponential(0.47, 0.8)
+    lp300, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=300)
+    ell = np.nextafter(0.47, 1.0)
+    k2 = G.Linear(0.1, 0.3, 0.7) + G.Periodic(0.96, 0.21, 1.1) * G.SquaredExponential(ell, 0.8)
+    k3 = G.Linear(0.1, 0.3, 0.7) * G.Periodic(0.96, 0.21, 1.1) + G.SquaredExponential(0.47, 0.8)
+    for kk, nz in ((k2, 0.05), (k3, 0.05), (k, np.nextafter(0.05, 1.0))):
+        a, _ = eng.logpdf_batch_extend([kk], np.array([nz]), n=n)
+        b, _ = eng.logpdf_batch([kk], np.array([nz]), n=n)
+        assert lp_err(a, b).max() <= 1e-12
+    s0 = eng.extend_stats()
+    assert s0["extended"] == 0 and s0["from_scratch"] == 4
+    a, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=n)            # the original key: extended 300 -> 600
+    assert eng.extend_stats()["extended"] == 1
+    assert lp_err(a, eng.logpdf_batch([k], np.array([0.05]), n=n)[0]).max() <= 1e-12
+    # add_data!: the series grows, the prefix is unchanged -> the factor of n=600 is extended to 900
+    eng.set_data(ts, xs)
+    a, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=n + 300)
+    assert eng.extend_stats()["extended"] == 2
+    assert lp_err(a, eng.logpdf_batch([k], np.array([0.05]), n=n + 300)[0]).max() <= 1e-12
+    ref, _ = F.gp_logpdf_many(pkg.encode_batch([k]), np.array([0.05]), ts, xs)
+    assert lp_err(a, ref).max() <= LP_TOL
+    # different data (one observation changed inside the prefix): nothing may be reused
+    xs2 = xs.copy(); xs2[10] += 0.25
+    eng.set_data(ts, xs2)
+    a, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=n + 300)
+    st = eng.extend_stats()
+    assert st["extended"] == 2 and st["from_scratch"] == 5
+    ref2, _ = F.gp_logpdf_many(pkg.encode_batch([k]), np.array([0.05]), ts, xs2)
+    assert lp_err(a, ref2).max() <= LP_TOL and abs(a[0] - ref[0]) > 1e-6
+    # a shorter prefix than the resident factor's: redone, correct
+    b, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=250)
+    assert lp_err(b, eng.logpdf_batch([k], np.array([0.05]), n=250)[0]).max() <= 1e-12
+
+
+def test_not_positive_definite_survives_extension(pkg, eng):
+    """LAPACK's info (first failing leading minor) is a property of the prefix.  0.1 I - 0.01 t t' loses positive
+    definiteness at the 196th leading minor (inside the second tile): fine at n=150, and extended to n=500 it reports
+    the same info as the from-scratch sweep and as LAPACK; a particle that has failed keeps failing when extended."""
+    G = pkg
+    ts = np.linspace(0, 1, 500); xs = np.sin(7 * ts)
+    eng.set_data(ts, xs)
+    bad = G.Linear(0.0, 0.0, -0.01)
+    good = G.SquaredExponential(0.2, 1.0)
+    nz = np.array([0.1, 0.1])
+    lp, info = eng.logpdf_batch_extend([bad, good], nz, n=150, check=False)
+    assert (info == 0).all() and np.isfinite(lp).all()
+    lp2, info2 = eng.logpdf_batch_extend([bad, good], nz, n=300, check=False)
+    assert info2[0] == 196 and np.isnan(lp2[0]) and info2[1] == 0
+    lp3, info3 = eng.logpdf_batch_extend([bad, good], nz, n=500, check=False)          # extends a FAILED factor
+    assert info3[0] == 196 and np.isnan(lp3[0]) and info3[1] == 0
+    lp4, info4 = eng.logpdf_batch([bad, good], nz, n=500, check=False)
+    assert info4[0] == 196 and abs(lp4[1] - lp3[1]) <= 1e-10 * abs(lp4[1])
+    _, rinfo = F.gp_logpdf_many(pkg.encode_batch([bad]), nz[:1], ts, xs)
+    assert rinfo[0] == 196
+    with pytest.raises(pkg.PosDefException):
+        eng.logpdf_batch_extend([bad], nz[:1], n=500)
+
+
+def test_store_too_small_falls_back(pkg, monkeypatch):
+    """A population that cannot fit the store's share of memory runs through agp_logpdf_batch unchanged."""
+    monkeypatch.setenv("AGP_EXTEND_FRAC", "0.00001")
+    e = pkg.GPEngine(0)
+    try:
+        ts, xs = pkg.prior.synthetic_series(700, seed=3)
+        nodes, noises = pkg.prior.sample_particles(np.random.default_rng(3), 40, max_depth=3)
+        e.set_data(ts, xs)
+        a, ia = e.logpdf_batch_extend(nodes, noises, check=False)
+        b, ib = e.logpdf_batch(nodes, noises, check=False)
+        assert same(a, b) and same(ia, ib)
+        assert e.extend_stats()["from_scratch"] == 0
+    finally:
+        e.close()

@@ -196,3 +196,34 @@ def test_gradient_oracle_vs_finite_differences():
         h = mp.mpf("1e-15")
         fd = (f(mp.mpf(float(prm[k])) + h) - f(mp.mpf(float(prm[k])) - h)) / (2 * h)
         assert abs(g[k] - float(fd)) <= 1e-8 * max(1.0, abs(float(fd))), k
+
+
+def test_fast_oracle_matches_numpy_oracle(pkg, golden):
+    """oracle/fast.py (C assembly + LAPACK dpotrf/dtrtrs, the large-n checker and the bench's CPU baseline) against
+    the NumPy restatement on seeded prior trees (incl. duplicate time points, n = 1, non-PD detection) and against
+    every committed golden logpdf."""
+    from oracle import fast as F
+    for n, P, depth in ((1, 4, 2), (33, 8, 3), (257, 10, 4), (600, 6, 5)):
+        ts, xs = pkg.prior.synthetic_series(max(n, 2), seed=n, shuffle=True)
+        ts, xs = ts[:n].copy(), xs[:n].copy()
+        if n > 40:
+            ts[7] = ts[6]
+        nodes, noises = pkg.prior.sample_particles(np.random.default_rng(n), P, max_depth=depth)
+        lp, info = F.gp_logpdf_many(pkg.encode_batch(nodes), noises, ts, xs, threads=4)
+        ref = np.array([O.gp_logpdf(nd.to_tuple(), float(nz), ts, xs) for nd, nz in zip(nodes, noises)])
+        assert (info == 0).all()
+        assert (np.abs(lp - ref) <= 1e-11 * np.maximum(1.0, np.abs(ref))).all()
+    # not positive definite: Constant kernel with zero noise on 5 points -> dpotrf info = 2
+    lp, info = F.gp_logpdf_program(np.array([1], dtype=np.uint8), np.array([1.0]), 0.0, np.linspace(0, 1, 5), np.zeros(5))
+    assert np.isnan(lp) and info == 2
+    n_checked = 0
+    for c in golden["cases"]:
+        ops, prm = O.tree_to_program(to_tuple_(c["tree"]))
+        lp, info = F.gp_logpdf_program(ops, prm, c["noise"], np.array(c["ts"]), np.array(c["xs"]))
+        assert info == 0 and abs(lp - c["logpdf"]) <= 1e-10 * max(1.0, abs(c["logpdf"])), c["name"]
+        n_checked += 1
+    assert n_checked == golden["n_cases"]
+
+
+def to_tuple_(t):
+    return tuple(to_tuple_(x) for x in t) if isinstance(t, list) else t
