@@ -63,6 +63,13 @@ struct CholArgs {
   const int* slot;
   const int* i0;
   int ntp;              // row stride of `partial` per storage index (0: nt)
+  // Dataflow schedule (k_chol_flow): one int per tile and storage index (row-major lower triangle, ntri per
+  // particle), raised when the tile holds its final L(i,k); per-XCD ticket counters of the work queue.
+  int* tflag;
+  int ntri;
+  int* qnext;
+  long long* trace;     // optional (agp_debug_flow_trace): per item {start, end, wait} in 100 MHz ticks + {item info}
+  int flow_order;       // 0: sub-diagonal tiles of a block column tile-row-major (all particles' (k+1,k) first), 1: particle-major
 };
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -86,6 +93,7 @@ constexpr int U_EXTRA_DOUBLES = 128 + 128 + 64 + 256;
 constexpr int U_LDS_BYTES = (U_MAIN_DOUBLES + U_EXTRA_DOUBLES) * 8;
 
 __device__ __forceinline__ int blk_idx(int rb, int cb) { return rb * (rb + 1) / 2 + cb; }
+__device__ __forceinline__ int tri_idx(int i, int j) { return i * (i + 1) / 2 + j; }     // tile (i,j) in the packed lower triangle
 
 // Largest number of ChangePoint nodes whose sigma tables fit the (aliased) LDS of the fused path.
 // LDS map of the fused phase (aliases the slab buffers): tpt[256] | sig[n_cp][256] | prm[n_prm] | ops[n_ops] (int)
@@ -104,6 +112,11 @@ constexpr int U_MAX_CP = (U_MAIN_DOUBLES - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_O
 // the workgroup waits on the particle's `ready` word (published by the diagonal-tile workgroup, which
 // is dispatched first), stages +L(k,k) blocks and -W blocks in LDS and runs the blocked substitution
 // on its accumulators — one launch per block column, no panel round trip through HBM.
+// Measurement switch: scope of the release fence that publishes a finished tile ("agent" = L2 write-back + flag;
+// "workgroup" only orders the stores — physically sufficient when producer and consumer share an XCD's L2).
+#ifndef AGP_REL_SCOPE
+#define AGP_REL_SCOPE "agent"
+#endif
 #ifndef AGP_XCD_PIN
 #define AGP_XCD_PIN 1
 #endif
@@ -273,9 +286,10 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(a.ready + p, a.k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.tflag != nullptr) __hip_atomic_store(a.tflag + (long long)p * a.ntri + tri_idx(tk, tk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -292,69 +306,30 @@ __device__ __forceinline__ void st_pair(double* T, int col, int rowA, int rowB, 
   else { T[col * NB + rowA] = a0; T[col * NB + rowB] = a1; }
 }
 
-// DM (factor mode with INTRSM): 0 = diagonal and sub-diagonal tiles in one launch (medium populations, fallback
-// paths); 2 = sub-diagonal tiles only (the diagonal tiles of that block column then come from k_chol_diag).
-template <bool FACTOR, int DCOV, bool INTRSM, int DM = 0, bool TAB = false>
-__global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
-  static_assert(!TAB || DCOV > 0, "the log|dt| table only matters to instantiations that evaluate tiles");
-  static_assert(DM == 0 || (FACTOR && INTRSM), "split launches exist for the in-kernel-solve factorisation only");
-  static_assert(DM == 0 || DM == 2, "the diagonal-only launch is k_chol_diag");
+// one lane: wait until a tile flag is raised (bounded), then acquire at agent scope
+__device__ __forceinline__ bool flow_wait(const int* flag) {
+  int spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 24)) return false;
+  }
+  return true;
+}
+// One tile (ti, tk) of particle p (storage index ps) — the body shared by the per-column launches (k_chol_update)
+// and the single-launch dataflow schedule (k_chol_flow, FLOW = true).  With FLOW the tile's inputs are other tiles of
+// the SAME launch: before the K-loop touches block column j it waits for the flags of tiles (ti,j) and (tk,j), the
+// panel solve waits for the flag of tile (tk,tk), and the finished tile raises its own flag (a.tflag, one int per
+// tile and storage index, zeroed per sweep).
+template <bool FACTOR, int DCOV, bool INTRSM, int DM, bool TAB, bool FLOW>
+__device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const int ps, const int ti, const int tk,
+                                          const int jmax, const bool is_diag, double* sm, const int tid,
+                                          double* wait_acc = nullptr) {
   constexpr bool ADJ = ILV;       // strips are adjacent rows
-  __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;
   double* xv = avec + 128;     // [2][slab depth <= 32]
   double* Wl = xv + 64;        // [256]
-
-  // ---- XCD-aware block -> (particle, tile) map: block b runs on XCD b%8; all tiles of one
-  //      particle go to the same XCD so the shared L(k,j) panel stays in that XCD's L2. ----
-  int b = blockIdx.x;
-  int xcd, qq;
-  int T, ti, tk, jmax;
-  int pl, tl;
-  if (DM == 2) {
-    T = a.tiles;            // sub-diagonal tiles of block column k
-    xcd = b & 7; qq = b >> 3;
-    pl = qq / T; tl = a.t0 + (qq - pl * T);
-    tk = a.k; ti = a.k + tl; jmax = a.k;
-  } else if (FACTOR) {
-    // diagonal tiles occupy the first 8*ceil(P/8) blocks of the grid: their serial 128x128
-    // factorisation overlaps the bulk of the launch, and (INTRSM) they are resident before any
-    // workgroup that waits for them
-    T = a.tiles;
-    const int ndiag = 8 * ((a.P + 7) / 8);
-    if (b < ndiag) {
-      xcd = b & 7; pl = b >> 3; tl = 0;
-    } else if (XCD_PIN) {
-      b -= ndiag;
-      xcd = b & 7; qq = b >> 3;
-      pl = qq / (T - 1); tl = 1 + (qq - pl * (T - 1));
-    } else {
-      // particle-major over all XCDs: consecutive blocks are the tiles of one particle
-      b -= ndiag;
-      const int pp = b / (T - 1);
-      tl = 1 + (b - pp * (T - 1));
-      xcd = pp & 7; pl = pp >> 3;
-    }
-    tk = a.k; ti = a.k + tl; jmax = a.rl ? 0 : a.k;
-  } else {
-    xcd = b & 7; qq = b >> 3;
-    const int nt2 = a.nt - a.nt1;
-    T = nt2 * (nt2 + 1) / 2;
-    pl = qq / T; tl = qq - pl * T;
-    int ii = (int)((sqrt(8.0 * (double)tl + 1.0) - 1.0) * 0.5);
-    while (ii * (ii + 1) / 2 > tl) --ii;
-    while ((ii + 1) * (ii + 2) / 2 <= tl) ++ii;
-    const int kk = tl - ii * (ii + 1) / 2;
-    ti = a.nt1 + ii; tk = a.nt1 + kk; jmax = a.nt1;
-  }
-  const int p = pl * 8 + xcd;
-  if (p >= a.P) return;
-  if (FACTOR && a.i0 != nullptr && ti < a.i0[p]) return;    // extension sweep: this tile row is already factored
-  const int ps = (FACTOR && a.slot != nullptr) ? a.slot[p] : p;    // storage index
-  const bool is_diag = (DM == 2) ? false : (ti == tk);
-
-  const int tid = threadIdx.x;
+  (void)p;
   const int l = tid & 63;
   const int w = tid >> 6;
   const int l15 = l & 15, lq = l >> 4;
@@ -467,11 +442,27 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
       if (is_diag && tid < KS) xv[buf * KS + tid] = rx;
     };
 
+    // FLOW: the operands of block column j are tiles (ti,j) and (tk,j) of this launch; one lane waits for their
+    // flags one slab before the first load of that column is issued, the slab's barrier publishes the result
+    auto flow_ready = [&](int j) {
+      const long long tw0 = a.trace ? (long long)wall_clock64() : 0;
+      const int* tf = a.tflag + (long long)ps * a.ntri;
+      bool ok = flow_wait(tf + tri_idx(tk, j));
+      if (!is_diag) ok = flow_wait(tf + tri_idx(ti, j)) && ok;
+      if (!ok) a.info[ps] = -7;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (a.trace && wait_acc) *wait_acc += (double)((long long)wall_clock64() - tw0);
+    };
+    if (FLOW) {
+      if (tid == 0) flow_ready(jfirst);
+      __syncthreads();
+    }
     gload(0);
     lstore(0);
     d2 fr[NU];                                   // row fragments of the slab being multiplied
 #pragma unroll
     for (int u = 0; u < NU; ++u) fr[u] = ra[u];
+    if (FLOW && nslab > 1 && SLABS_PER_TILE == 1 && tid == 0) flow_ready(jfirst + 1);
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
       const int buf = s & 1;
@@ -510,6 +501,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
           for (int u = 0; u < NU; ++u) fr[u] = ra[u];
         }
       }
+      if (FLOW && tid == 0 && s + 2 < nslab && (s + 2) % SLABS_PER_TILE == 0) flow_ready(jfirst + (s + 2) / SLABS_PER_TILE);
       __syncthreads();
     }
   }
@@ -550,11 +542,15 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     // but the poll stays: its branch + acquire also keep the staging loads below from being hoisted into the GEMM
     // epilogue, which costs 30 VGPRs and spills)
     if (tid == 0) {
-      const int want = a.k + 1;
-      int spins = 0;
-      while (__hip_atomic_load(a.ready + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1 << 22)) { a.info[ps] = -7; break; }   // bounded (~1 s): never hang the device
+      if (FLOW) {
+        if (!flow_wait(a.tflag + (long long)ps * a.ntri + tri_idx(tk, tk))) a.info[ps] = -7;
+      } else {
+        const int want = a.k + 1;
+        int spins = 0;
+        while (__hip_atomic_load(a.ready + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1 << 22)) { a.info[ps] = -7; break; }   // bounded (~1 s): never hang the device
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -606,6 +602,16 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
         st_pair(Tt, jb * 16 + 4 * r + lq, row0, row1, x0[r], x1[r]);
       }
     }
+    if (FLOW) {
+      // L(i,k) is final: every wave drains its stores, one lane releases at agent scope and raises the tile's flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.tflag + (long long)ps * a.ntri + tri_idx(ti, tk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     return;
   }
 
@@ -626,31 +632,79 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   factor_diag_tile<INTRSM>(a, ps, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid);
 }
 
-// K2a — the diagonal tiles of block column k, one workgroup per particle.  Only the lower block triangle of
-// C(k,k) = A(k,k) - sum_j L(k,j) L(k,j)^T is formed: wave w owns the 16-row blocks w (strip 0) and 7-w (strip 1),
-// i.e. NINE 16x16 accumulator blocks per wave whatever w is — entry e of the wave's list is (strip 0, column block
-// e) for e <= w and (strip 1, column block e-w-1) after that.  The list index is static, so every accumulator
-// has a compile-time register and the MFMA loop is branch-free; which column block / which strip an entry stands
-// for only enters through wave-uniform LDS offsets and selects.  Both operands of the update are the same tile
-// (k,j): its 32-column slab is staged once in LDS and read as row fragments and as column fragments.
-template <int DCOV, bool TAB>
-__global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
+// DM (factor mode with INTRSM): 0 = diagonal and sub-diagonal tiles in one launch (medium populations, fallback
+// paths); 2 = sub-diagonal tiles only (the diagonal tiles of that block column then come from k_chol_diag).
+template <bool FACTOR, int DCOV, bool INTRSM, int DM = 0, bool TAB = false>
+__global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   static_assert(!TAB || DCOV > 0, "the log|dt| table only matters to instantiations that evaluate tiles");
+  static_assert(DM == 0 || (FACTOR && INTRSM), "split launches exist for the in-kernel-solve factorisation only");
+  static_assert(DM == 0 || DM == 2, "the diagonal-only launch is k_chol_diag");
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
+
+  // ---- XCD-aware block -> (particle, tile) map: block b runs on XCD b%8; all tiles of one
+  //      particle go to the same XCD so the shared L(k,j) panel stays in that XCD's L2. ----
+  int b = blockIdx.x;
+  int xcd, qq;
+  int T, ti, tk, jmax;
+  int pl, tl;
+  if (DM == 2) {
+    T = a.tiles;            // sub-diagonal tiles of block column k
+    xcd = b & 7; qq = b >> 3;
+    pl = qq / T; tl = a.t0 + (qq - pl * T);
+    tk = a.k; ti = a.k + tl; jmax = a.k;
+  } else if (FACTOR) {
+    // diagonal tiles occupy the first 8*ceil(P/8) blocks of the grid: their serial 128x128
+    // factorisation overlaps the bulk of the launch, and (INTRSM) they are resident before any
+    // workgroup that waits for them
+    T = a.tiles;
+    const int ndiag = 8 * ((a.P + 7) / 8);
+    if (b < ndiag) {
+      xcd = b & 7; pl = b >> 3; tl = 0;
+    } else if (XCD_PIN) {
+      b -= ndiag;
+      xcd = b & 7; qq = b >> 3;
+      pl = qq / (T - 1); tl = 1 + (qq - pl * (T - 1));
+    } else {
+      // particle-major over all XCDs: consecutive blocks are the tiles of one particle
+      b -= ndiag;
+      const int pp = b / (T - 1);
+      tl = 1 + (b - pp * (T - 1));
+      xcd = pp & 7; pl = pp >> 3;
+    }
+    tk = a.k; ti = a.k + tl; jmax = a.rl ? 0 : a.k;
+  } else {
+    xcd = b & 7; qq = b >> 3;
+    const int nt2 = a.nt - a.nt1;
+    T = nt2 * (nt2 + 1) / 2;
+    pl = qq / T; tl = qq - pl * T;
+    int ii = (int)((sqrt(8.0 * (double)tl + 1.0) - 1.0) * 0.5);
+    while (ii * (ii + 1) / 2 > tl) --ii;
+    while ((ii + 1) * (ii + 2) / 2 <= tl) ++ii;
+    const int kk = tl - ii * (ii + 1) / 2;
+    ti = a.nt1 + ii; tk = a.nt1 + kk; jmax = a.nt1;
+  }
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  if (FACTOR && a.i0 != nullptr && ti < a.i0[p]) return;    // extension sweep: this tile row is already factored
+  const int ps = (FACTOR && a.slot != nullptr) ? a.slot[p] : p;    // storage index
+  const bool is_diag = (DM == 2) ? false : (ti == tk);
+
+  chol_tile<FACTOR, DCOV, INTRSM, DM, TAB, false>(a, p, ps, ti, tk, jmax, is_diag, sm, threadIdx.x);
+}
+
+// Diagonal tile (tk, tk) of particle p (storage index ps): lower block triangle of the update, the 128x128
+// factorisation, forward-solve segment and partials — the body of k_chol_diag, also run by the dataflow schedule
+// (FLOW: waits for tile (tk, j) before the slabs of block column j are fetched; raises its own flag when done).
+template <int DCOV, bool TAB, bool FLOW>
+__device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, const int ps, const int tk, double* sm, const int tid,
+                                               double* wait_acc = nullptr) {
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;
   double* xv = avec + 128;     // [2][32]
   double* Wl = xv + 64;        // [256]
   constexpr int NE = NSB + 1;  // accumulator blocks per wave
-
-  const int b = blockIdx.x, xcd = b & 7, pl = b >> 3;
-  const int p = pl * 8 + xcd;
-  if (p >= a.P) return;
-  const int tk = a.k;
-  if (a.i0 != nullptr && tk < a.i0[p]) return;              // extension sweep: column already factored
-  const int ps = a.slot != nullptr ? a.slot[p] : p;         // storage index
   const int jmax = a.rl ? 0 : a.k;
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  const int l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   const int wu = __builtin_amdgcn_readfirstlane(w);
   const int row0 = 16 * w + l15, row1 = 16 * (NSB - 1 - w) + l15;
   // wave-uniform description of the nine entries
@@ -779,6 +833,18 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
         for (int kk = 0; kk < KS; ++kk) rv = fma(-Bs[kk * LDS_STRIDE + tid], xs_[kk], rv);
       }
     };
+    // FLOW: block column j's slabs are 4j .. 4j+3; slab 4j is the first of them to be fetched (by gload, two slabs
+    // ahead of its use), so one lane waits for tile (tk, j) at the end of the iteration before that fetch
+    auto flow_ready = [&](int j) {
+      const long long tw0 = a.trace ? (long long)wall_clock64() : 0;
+      if (!flow_wait(a.tflag + (long long)ps * a.ntri + tri_idx(tk, j))) a.info[ps] = -7;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (a.trace && wait_acc) *wait_acc += (double)((long long)wall_clock64() - tw0);
+    };
+    if (FLOW) {
+      if (tid == 0) flow_ready(0);
+      __syncthreads();
+    }
     // nslab is a multiple of 4: slabs 2i go through (rb, buffer 0), slabs 2i+1 through (rb2, buffer 1)
     gload(0);
     lstore(0);
@@ -792,6 +858,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
       if (s + 3 < nslab) gload2(s + 3);
       slab(1);
       if (s + 2 < nslab) lstore(0);
+      if (FLOW && tid == 0 && s + 4 < nslab && (s + 4) % SLABS_PER_TILE == 0) flow_ready((s + 4) / SLABS_PER_TILE);
       __syncthreads();
     }
   }
@@ -818,6 +885,87 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
   factor_diag_tile<true>(a, ps, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid);
 }
 
+template <int DCOV, bool TAB>
+__global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
+  static_assert(!TAB || DCOV > 0, "the log|dt| table only matters to instantiations that evaluate tiles");
+  __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
+
+  const int b = blockIdx.x, xcd = b & 7, pl = b >> 3;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const int tk = a.k;
+  if (a.i0 != nullptr && tk < a.i0[p]) return;              // extension sweep: column already factored
+  const int ps = a.slot != nullptr ? a.slot[p] : p;         // storage index
+  chol_diag_tile<DCOV, TAB, false>(a, p, ps, tk, sm, threadIdx.x);
+}
+
+// Dataflow schedule: the WHOLE factorisation of a batch in one launch of persistent workgroups.  Work items are
+// the tiles, queued per XCD (particle p lives on XCD p % 8, as in the per-column launches) in block-column order —
+// diagonal tiles of a column first — and handed out by ticket, so an item's producers always hold earlier tickets:
+// they are running or done, never waiting behind it.  A tile's K-loop starts as soon as a workgroup is free and only
+// stalls if the block column it reaches next is not final yet; the tail of one block column (few tiles left, the
+// serial 128x128 factorisations) is filled by the bulk of the next ones.  This is what medium populations
+// (one GPU's share of a sharded population) need: with fewer tiles per block column than the GPU has workgroup
+// slots, per-column launches leave most CUs idle around every column boundary.
+template <int DCOV, bool TAB>
+__global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
+  static_assert(!TAB || DCOV > 0, "the log|dt| table only matters to instantiations that evaluate tiles");
+  __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
+  __shared__ int s_item;
+  __shared__ double s_wait;
+  const int xcd = blockIdx.x & 7;
+  const int Pl = (a0.P - xcd + 7) / 8;          // particles pl*8 + xcd < P
+  const int nt = a0.nt;
+  const int total = Pl * (nt * (nt + 1) / 2);
+  for (;;) {
+    __syncthreads();                             // the previous item's LDS and s_item are no longer read
+    if (threadIdx.x == 0) s_item = atomicAdd(a0.qnext + xcd, 1);
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(s_item);      // wave-uniform: keeps the tile indices scalar
+    if (item >= total) return;
+    int k = 0, rem = item;
+    while (rem >= Pl * (nt - k)) { rem -= Pl * (nt - k); ++k; }
+    int pl, tl;
+    if (rem < Pl) { pl = rem; tl = 0; }
+    else {
+      rem -= Pl;
+      const int T1 = nt - k - 1;
+      if (a0.flow_order == 0) { tl = 1 + rem / Pl; pl = rem - (tl - 1) * Pl; }
+      else { pl = rem / T1; tl = 1 + rem - pl * T1; }
+    }
+    const int p = pl * 8 + xcd;
+    const int ps = a0.slot != nullptr ? a0.slot[p] : p;
+    CholArgs a = a0;
+    a.k = k;
+    const long long t_start = a0.trace ? (long long)wall_clock64() : 0;
+    if (a0.trace && threadIdx.x == 0) s_wait = 0.0;
+    // the lane index is made opaque per item: otherwise every lane-dependent offset of every phase of the tile body is
+    // hoisted out of this loop and stays live across the K-loop (hundreds of spilled registers)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    // diagonal tiles run the lower-triangle body of k_chol_diag, the others the sub-diagonal body (update + in-register
+    // solve) of the split per-column launches
+    if (tl == 0) chol_diag_tile<DCOV, TAB, true>(a, p, ps, k, sm, tid, &s_wait);
+    else chol_tile<true, DCOV, true, 2, TAB, true>(a, p, ps, k + tl, k, k, false, sm, tid, &s_wait);
+    if (a0.trace && threadIdx.x == 0) {
+      // record of this item: [start, end, K-loop wait ticks, (xcd, particle, tile row, block column)]
+      int gi = item;
+      for (int x = 0; x < xcd; ++x) gi += ((a0.P - x + 7) / 8) * (nt * (nt + 1) / 2);
+      long long* r = a0.trace + 4 * (long long)gi;
+      r[0] = t_start; r[1] = (long long)wall_clock64();
+      r[2] = (long long)s_wait;
+      r[3] = ((long long)blockIdx.x << 48) | ((long long)p << 24) | ((long long)(k + tl) << 12) | k;
+    }
+  }
+}
+
+// K2a — the diagonal tiles of block column k, one workgroup per particle.  Only the lower block triangle of
+// C(k,k) = A(k,k) - sum_j L(k,j) L(k,j)^T is formed: wave w owns the 16-row blocks w (strip 0) and 7-w (strip 1),
+// i.e. NINE 16x16 accumulator blocks per wave whatever w is — entry e of the wave's list is (strip 0, column block
+// e) for e <= w and (strip 1, column block e-w-1) after that.  The list index is static, so every accumulator
+// has a compile-time register and the MFMA loop is branch-free; which column block / which strip an entry stands
+// for only enters through wave-uniform LDS offsets and selects.  Both operands of the update are the same tile
+// (k,j): its 32-column slab is staged once in LDS and read as row fragments and as column fragments.
 // T — L(i,k) = C(i,k) L(k,k)^-T for the tiles below the diagonal of block column k.
 // One workgroup per tile; each wave solves two 16-row strips in MFMA registers.  The 28 strictly
 // lower 16x16 blocks of L(k,k) (negated) and the 8 diagonal-block inverses are staged once per

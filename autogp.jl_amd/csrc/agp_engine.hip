@@ -65,7 +65,7 @@ struct Slot {
   HostBuf h_stage, h_out;   // its pinned source, and the pinned landing zone of [logpdf | info]
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
-      Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist;
+      Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq;
   std::vector<hipEvent_t> events;
   std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
   std::vector<hipEvent_t> sub_ev;     // fork / join events
@@ -78,7 +78,7 @@ struct Slot {
     if (done) { (void)hipEventDestroy(done); done = nullptr; }
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
-                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist})
+                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq})
       b->release();
     stage.release(); h_stage.release(); h_out.release();
     for (auto e : events) (void)hipEventDestroy(e);
@@ -121,6 +121,7 @@ struct agp_ctx {
   // config
   int64_t ws_limit = 0;
   size_t total_mem = 0;
+  int n_cu = 256;
   bool profiling = false;
   int grad_split = 1;   // 1: K^-1 tiles to memory + lean contraction kernel; 0: fused tile kernel (env AGP_GRAD_SPLIT)
   int intrsm = 1;       // 1: triangular solve inside k_chol_update (one launch per block column); env AGP_INTRSM
@@ -139,6 +140,11 @@ struct agp_ctx {
   bool logdt_ok = false;
   int hybrid_blocks = 512;  // medium populations: switch to right-looking once a column has fewer workgroups; 0 = never; env AGP_HYBRID_BLOCKS
   int right_looking = -1;   // right-looking factorisation for small populations: -1 auto, 0, 1; env AGP_RIGHT_LOOKING
+  int flow = -1;        // dataflow schedule (whole factorisation in one launch of persistent workgroups): -1 auto, 0, 1; env AGP_FLOW
+  int flow_order = 1;   // queue order of a block column's sub-diagonal tiles: 0 tile-row-major, 1 particle-major; env AGP_FLOW_ORDER
+  long long* d_flow_trace = nullptr;   // agp_debug_flow_trace: 4 x int64 per work item of the next dataflow sweep
+  size_t flow_trace_items = 0;
+  int flow_fuse = 1;    // 1: dataflow sweeps evaluate tiles in-kernel like the large-population path; env AGP_FLOW_FUSE
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
@@ -416,7 +422,8 @@ int emit_grad(const std::vector<CNode>& nodes, int id, Batch& bt, int prm_base, 
 }
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
-                  const double* prm, Batch& bt, bool allow_sel = false, bool want_grad = false, bool ge_tab = false) {
+                  const double* prm, Batch& bt, bool allow_sel = false, bool want_grad = false, bool ge_tab = false,
+                  bool fuse_hint = false) {
   std::vector<Compiled> cps(P);
   std::vector<double> cost(P, 0.0);
   for (int p = 0; p < P; ++p) {
@@ -431,7 +438,8 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   }
   // Sort: fused particles first, most expensive evaluation first (their workgroups are dispatched
   // first inside every launch); particles whose tiles are prebuilt go last.
-  const bool fuse_on = c->fuse_mode == 1 || (c->fuse_mode < 0 && P >= 256);
+  // (fuse_hint: the caller will run the dataflow schedule, which evaluates tiles in-kernel whatever the batch size)
+  const bool fuse_on = c->fuse_mode == 1 || (c->fuse_mode < 0 && (P >= 256 || fuse_hint));
   auto fusable = [&](int p) { return fuse_on && cost[p] <= c->fuse_max_us && cps[p].n_cp <= U_MAX_CP; };
   bt.order.resize(P);
   for (int p = 0; p < P; ++p) bt.order[p] = p;
@@ -677,6 +685,31 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intr
   return hipGetLastError();
 }
 
+// Dataflow schedule (k_chol_flow): one launch of persistent workgroups, 2 per CU, tiles handed out by ticket.
+inline void launch_flow(int dcov, int n_wg, hipStream_t st, const CholArgs& ca) {
+  const bool tab = ca.logdt != nullptr && dcov > 0;
+  const dim3 grid(n_wg), block(256);
+  if (dcov == 0) hipLaunchKernelGGL((k_chol_flow<0, false>), grid, block, 0, st, ca);
+  else if (dcov <= 4) {
+    if (tab) hipLaunchKernelGGL((k_chol_flow<4, true>), grid, block, 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_flow<4, false>), grid, block, 0, st, ca);
+  } else {
+    if (tab) hipLaunchKernelGGL((k_chol_flow<8, true>), grid, block, 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_flow<8, false>), grid, block, 0, st, ca);
+  }
+}
+// Medium populations — more particles than the right-looking schedule serves, fewer than fill the GPU with the tiles
+// of one block column — take the dataflow schedule.
+// Measured on MI355X (tools/gpu_flow_perf.py, profiles/r02_flow_perf.txt): it beats the per-column launches (right-looking,
+// hybrid and mixed alike) from a handful of particles up to ~450 once the batch holds enough tile work to amortise
+// the persistent launch (P nt^2 >= 2000: n=2048 from 8 particles, n=1024 from 32, n=512 from 128); at 512 particles the
+// specialised per-column launches are ahead by 3 %.
+constexpr int FLOW_MAX_PARTICLES = 448;
+constexpr long long FLOW_MIN_WORK = 2000;
+inline bool use_flow(const agp_ctx* c, int P, int nt) {
+  return c->intrsm != 0 && (c->flow > 0 || (c->flow < 0 && P <= FLOW_MAX_PARTICLES && (long long)P * nt * nt >= FLOW_MIN_WORK));
+}
+
 // The specialised diagonal-tile launch pays off when the diagonal tiles alone fill the GPU (two workgroups per
 // CU); with fewer particles the mixed launch lets sub-diagonal tiles run beside the diagonal factorisations.
 constexpr int SPLIT_DIAG_MIN_PARTICLES = 256;
@@ -725,7 +758,9 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   pls.reserve(64);
   // (the log|dt|-table kernels exist for the in-kernel-solve factorisation launches, see launch_update)
   const bool ge_tab = c->logdt_ok && c->intrsm != 0;
-  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab);
+  // (the schedule is chosen per call from P and n; chunked / multi-stream sub-batches re-check with their own size)
+  const bool flow_hint = !go && n > 0 && c->flow_fuse && use_flow(c, P, (int)((n + NB - 1) / NB));
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint);
   if (rc) return rc;
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
   const int n_prm_total = prm_off[P];
@@ -762,7 +797,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     const long long strideA = (long long)ntiles * NB2;
     const int64_t bytes_pp = strideA * 8 * (go ? 2 : 1);      // + Z = L^-T for the gradient
     int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(P, ws_limit_bytes(c) / bytes_pp));
-    const int wsteps = go ? nt : 1;
+    // (the dataflow schedule has several block columns of a particle in flight: every column keeps its inverse blocks)
+    const int wsteps = (go || (c->intrsm && c->flow != 0)) ? nt : 1;
     const int gstride = go ? bt.g_max_prm + 1 : 0;
 
     HIPCHK(c, s->A.ensure((size_t)strideA * 8 * chunk));
@@ -785,6 +821,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
     HIPCHK(c, s->info.ensure(sizeof(int) * (size_t)chunk));
     HIPCHK(c, s->ready.ensure(sizeof(int) * (size_t)chunk));
+    if (!go && c->intrsm && c->flow != 0) {
+      HIPCHK(c, s->tflag.ensure(sizeof(int) * (size_t)chunk * ntiles));
+      HIPCHK(c, s->flowq.ensure(sizeof(int) * 8 * 8));
+    }
     // ---- one pinned-memory upload: [hdr | prm | noise (sorted) | map | ops], 16-byte aligned sections ----
     auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
     const size_t o_hdr = 0;
@@ -889,8 +929,28 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         set_cov(ca, cv);
         ca.n_fused = nf;
         ca.ready = s->ready.as<int>() + g0;
-        HIPCHK(c, run_factor(q, ca, nt, dcov, intrsm, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr, use_split_diag(c, ca.P),
-                             use_right_looking(c, ca.P), c->hybrid_blocks));
+        if (!go && use_flow(c, ca.P, nt)) {
+          // dataflow schedule: every tile of the batch in ONE launch of persistent workgroups (2 per CU)
+          const int ntri = nt * (nt + 1) / 2;
+          ca.tflag = s->tflag.as<int>() + (size_t)g0 * ntri; ca.ntri = ntri;
+          ca.qnext = s->flowq.as<int>() + 8 * g; ca.flow_order = c->flow_order;
+          {
+            size_t items = 0;
+            for (int x = 0; x < 8; ++x) items += (size_t)((Pg - x + 7) / 8) * ntri;
+            ca.trace = (c->d_flow_trace && items <= c->flow_trace_items && S == 1 && P <= chunk) ? c->d_flow_trace : nullptr;
+          }
+          HIPCHK(c, hipMemsetAsync(ca.tflag, 0, sizeof(int) * (size_t)Pg * ntri, q));
+          HIPCHK(c, hipMemsetAsync(ca.qnext, 0, sizeof(int) * 8, q));
+          size_t f0 = pf.mark(q);
+          launch_flow(dcov, 2 * c->n_cu, q, ca);
+          size_t f1 = pf.mark(q);
+          pf.span(2, f0, f1);
+          if (c->profiling) tacc[5] += 1;
+          HIPCHK(c, hipGetLastError());
+        } else {
+          HIPCHK(c, run_factor(q, ca, nt, dcov, intrsm, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr, use_split_diag(c, ca.P),
+                               use_right_looking(c, ca.P), c->hybrid_blocks));
+        }
 
         size_t e2 = pf.mark(q);
         hipLaunchKernelGGL(k_finish_logpdf, dim3((Pg + 63) / 64), dim3(64), 0, q, ca.partial, ca.info, nt, Pg, (int)n,
@@ -1050,6 +1110,7 @@ int agp_init(agp_ctx** out, int device_id) {
   size_t free_b = 0, tot_b = 0;
   (void)hipMemGetInfo(&free_b, &tot_b);
   c->total_mem = free_b ? free_b : tot_b;
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
   if (const char* e = getenv("AGP_TRTRI_CHAIN")) c->trtri_chain = atoi(e) != 0;
   if (const char* e = getenv("AGP_SPLIT_DIAG")) c->split_diag = atoi(e);
@@ -1062,6 +1123,9 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_INTRSM")) c->intrsm = atoi(e) != 0;
   if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_STREAMS")) c->n_streams = std::max(1, std::min(8, atoi(e)));
+  if (const char* e = getenv("AGP_FLOW")) c->flow = atoi(e);
+  if (const char* e = getenv("AGP_FLOW_ORDER")) c->flow_order = atoi(e) != 0;
+  if (const char* e = getenv("AGP_FLOW_FUSE")) c->flow_fuse = atoi(e) != 0;
   if (const char* e = getenv("AGP_EXTEND_FRAC")) c->store.max_frac = std::max(0.0, std::min(0.8, atof(e)));
   *out = c;
   return AGP_OK;
@@ -1079,6 +1143,7 @@ void agp_destroy(agp_ctx* c) {
   if (c->d_ts) (void)hipFree(c->d_ts);
   if (c->d_xs) (void)hipFree(c->d_xs);
   if (c->d_logdt) (void)hipFree(c->d_logdt);
+  if (c->d_flow_trace) (void)hipFree(c->d_flow_trace);
   delete c;
 }
 
@@ -1834,6 +1899,26 @@ int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t
 #endif
 }
 
+// Timeline of the next dataflow sweeps (k_chol_flow): out has 4 int64 per work item — start, end (100 MHz ticks),
+// ticks spent waiting for operand tiles inside the K-loop, and (workgroup << 48 | particle << 24 | tile row << 12 |
+// block column).  enable: allocate for max_items and start recording; otherwise copy out what was recorded.
+int agp_debug_flow_trace(agp_ctx* c, int32_t enable, int64_t max_items, int64_t* out) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  if (enable) {
+    if (c->d_flow_trace) { (void)hipFree(c->d_flow_trace); c->d_flow_trace = nullptr; }
+    if (max_items <= 0) { c->flow_trace_items = 0; return AGP_OK; }
+    HIPCHK(c, hipMalloc((void**)&c->d_flow_trace, sizeof(long long) * 4 * (size_t)max_items));
+    HIPCHK(c, hipMemset(c->d_flow_trace, 0, sizeof(long long) * 4 * (size_t)max_items));
+    c->flow_trace_items = (size_t)max_items;
+    return AGP_OK;
+  }
+  if (!out || !c->d_flow_trace || (size_t)max_items > c->flow_trace_items) return fail(c, AGP_ERR_ARG, "no trace recorded");
+  HIPCHK(c, hipMemcpy(out, c->d_flow_trace, sizeof(long long) * 4 * (size_t)max_items, hipMemcpyDeviceToHost));
+  return AGP_OK;
+}
+
 int agp_debug_math(agp_ctx* c, int32_t which, const double* x, const double* g, double* y, int32_t n) {
   if (!c || !x || !y || n <= 0 || (which == 3 && !g)) return fail(c, AGP_ERR_ARG, "bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
@@ -2006,7 +2091,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     // capacity: slots sized for the resident data, at least as many as this population (twice, so that a population
     // mid-rejuvenation keeps its previous states), within the store's share of device memory
     const int want_nt = std::max(fs.nt_cap, std::max(nt, round_up(c->n_max, NB) / NB));
-    int want_slots = std::max(fs.n_slots, 2 * U);
+    int want_slots = std::max(fs.n_slots, std::max(2 * U, 32));
     const size_t budget = (size_t)(fs.max_frac * (double)c->total_mem);
     const size_t per = store_bytes_per_slot(want_nt);
     if ((size_t)want_slots * per > budget) want_slots = (int)std::min<size_t>((size_t)want_slots, budget / per);

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "agp_set_workspace_limit", "agp_set_coalesce_window", "agp_get_coalesce_stats", "agp_get_dedup_stats",
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi",
-    "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
+    "agp_debug_flow_trace", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
 ]
 COMM_ID_BYTES = 128
 
@@ -121,6 +121,7 @@ def load_library(path=None):
     lib.agp_get_dedup_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.agp_get_dedup_stats.restype = C.c_int
     lib.agp_logpdf_batch_extend.argtypes = [vp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, ip]
     lib.agp_logpdf_batch_extend.restype = C.c_int
+    lib.agp_debug_flow_trace.argtypes = [vp, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]; lib.agp_debug_flow_trace.restype = C.c_int
     lib.agp_extend_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_extend_stats.restype = C.c_int
     lib.agp_extend_reset.argtypes = [vp, C.c_int]; lib.agp_extend_reset.restype = C.c_int
     lib.agp_extend_reserve.argtypes = [vp, C.c_int64, C.c_int32]; lib.agp_extend_reserve.restype = C.c_int
@@ -403,6 +404,15 @@ class GPEngine:
         ms = C.c_double()
         self._check(self._lib.agp_debug_gemm_variant(self._ctx, P, nt, k, variant, reps, C.byref(ms)))
         return ms.value
+
+    def flow_trace(self, enable, max_items):
+        """agp_debug_flow_trace: enable=True starts recording; enable=False returns an (items, 4) int64 array."""
+        if enable:
+            self._check(self._lib.agp_debug_flow_trace(self._ctx, 1, int(max_items), None))
+            return None
+        out = np.zeros((int(max_items), 4), dtype=np.int64)
+        self._check(self._lib.agp_debug_flow_trace(self._ctx, 0, int(max_items), out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
 
     def set_profiling(self, on: bool):
         self._check(self._lib.agp_set_profiling(self._ctx, 1 if on else 0))

@@ -241,6 +241,12 @@ int agp_debug_mfma_peak(agp_ctx* ctx, int32_t iters, int32_t wg_per_cu, double* 
  * builds (-DAGP_EXPERIMENTS, `python __graft_entry__.py --experiments`); the product library returns AGP_ERR_ARG. */
 int agp_debug_gemm_variant(agp_ctx* ctx, int32_t P, int32_t nt, int32_t k, int32_t variant, int32_t reps, double* out_ms);
 
+/* Timeline of the dataflow factorisation schedule (one launch of persistent workgroups, medium populations):
+ * enable != 0 allocates room for max_items work items (tiles) and records the following sweeps; enable == 0 copies
+ * the records out — 4 int64 per item: start, end (100 MHz ticks), ticks spent waiting for operand tiles, and
+ * (workgroup << 48 | particle << 24 | tile row << 12 | block column). */
+int agp_debug_flow_trace(agp_ctx* ctx, int32_t enable, int64_t max_items, int64_t* out);
+
 /* When enabled, batch calls bracket their phases with HIP events on the launch stream.
  * agp_get_timing fills out[0..7] = { total_ms, cov_build_ms, chol_update_ms, chol_trsm_ms,
  * finish_ms, n_update_launches, n_trsm_launches, h2d_d2h_ms } for the last batch call. */

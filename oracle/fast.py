@@ -117,6 +117,7 @@ class OraclePool:
         import sys
         import tempfile
         self.workers = int(workers or host_cores())
+        self.limit = None                        # evaluate() uses at most this many workers when set
         _lib()                                   # build the C oracle once, before the workers look for it
         fd, self._npz = tempfile.mkstemp(suffix=".npz", prefix="agp_oracle_")
         os.close(fd)
@@ -132,7 +133,7 @@ class OraclePool:
                 self.close()
                 raise RuntimeError("oracle worker failed to start")
 
-    def evaluate(self, indices):
+    def evaluate(self, indices, max_workers=None):
         import queue
         import threading
         idx = list(indices)
@@ -157,7 +158,8 @@ class OraclePool:
             except Exception as e:      # noqa: BLE001
                 errs.append(e)
 
-        th = [threading.Thread(target=feed, args=(pr,)) for pr in self.procs[:max(1, min(self.workers, len(idx)))]]
+        nw = max(1, min(max_workers or self.limit or self.workers, self.workers, len(idx)))
+        th = [threading.Thread(target=feed, args=(pr,)) for pr in self.procs[:nw]]
         for t in th:
             t.start()
         for t in th:

@@ -125,6 +125,7 @@ def test_invalidation(pkg, eng):
     n = 600
     ts, xs = pkg.prior.synthetic_series(n + 300, seed=77, shuffle=True)
     eng.set_data(ts[:n], xs[:n])
+    eng.extend_reserve(n + 300, 16)
     k = G.Linear(0.1, 0.3, 0.7) + G.Periodic(0.96, 0.21, 1.1) * G.SquaredExponential(0.47, 0.8)
     lp300, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=300)
     ell = np.nextafter(0.47, 1.0)

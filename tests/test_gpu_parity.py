@@ -225,7 +225,9 @@ def test_gamma_exponential_table_path(pkg, engine, monkeypatch):
                                  {"AGP_FUSE": "1", "AGP_FUSE_MAX_US": "1000"}, {"AGP_STREAMS": "2"},
                                  {"AGP_GRAD_SPLIT": "0"}, {"AGP_TRTRI_CHAIN": "0"}, {"AGP_DEDUP": "0", "AGP_GE_TABLE": "0"},
                                  {"AGP_RIGHT_LOOKING": "0"}, {"AGP_RIGHT_LOOKING": "1"}, {"AGP_HYBRID_BLOCKS": "0"},
-                                 {"AGP_SPLIT_DIAG": "0", "AGP_RIGHT_LOOKING": "0", "AGP_HYBRID_BLOCKS": "100000"}])
+                                 {"AGP_SPLIT_DIAG": "0", "AGP_RIGHT_LOOKING": "0", "AGP_HYBRID_BLOCKS": "100000"},
+                                 {"AGP_FLOW": "0"}, {"AGP_FLOW": "1"}, {"AGP_FLOW": "1", "AGP_FLOW_ORDER": "0"},
+                                 {"AGP_FLOW": "1", "AGP_FLOW_FUSE": "0"}, {"AGP_FLOW": "0", "AGP_RIGHT_LOOKING": "0"}])
 def test_runtime_switches_agree_with_default(pkg, engine, monkeypatch, env):
     """Every documented runtime switch selects a different kernel schedule for the same
     arithmetic: value, info and gradient agree with the default engine to rounding, on a 260-particle
@@ -253,6 +255,42 @@ def test_runtime_switches_agree_with_default(pkg, engine, monkeypatch, env):
                 assert np.abs(ga[1][i] - gb[1][i]).max() <= 1e-9 * sc and abs(ga[2][i] - gb[2][i]) <= 1e-9 * sc
     finally:
         other.close()
+
+
+@pytest.mark.parametrize("n,P", [(1500, 9), (1300, 70), (900, 300), (2048, 48)])
+def test_dataflow_schedule_vs_oracle(pkg, n, P, monkeypatch):
+    """The single-launch dataflow schedule (k_chol_flow: persistent workgroups, tiles handed out by ticket, per-tile
+    ready flags) — the default for medium populations — forced on (AGP_FLOW=1) and off (AGP_FLOW=0): both against the
+    oracle on every particle, against each other to rounding, bitwise reproducible run to run, in both queue orders
+    and with prebuilt tiles (AGP_FLOW_FUSE=0)."""
+    from oracle import fast as F
+    ts, xs = pkg.prior.synthetic_series(n, seed=n + P, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(n + P), P, max_depth=4, max_size=31)
+    progs = pkg.encode_batch(nodes)
+    ref, rinfo = F.gp_logpdf_many(progs, noises, ts, xs)
+    res = {}
+    for name, env in (("cols", {"AGP_FLOW": "0"}), ("flow", {"AGP_FLOW": "1"}), ("flow_tr", {"AGP_FLOW": "1", "AGP_FLOW_ORDER": "0"}),
+                      ("flow_prebuilt", {"AGP_FLOW": "1", "AGP_FLOW_FUSE": "0"}), ("auto", {})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = pkg.GPEngine(0)
+        for k in env:
+            monkeypatch.delenv(k)
+        try:
+            eng.set_data(ts, xs)
+            lp, info = eng.logpdf_batch(None, noises, check=False, programs=progs)
+            lp2, info2 = eng.logpdf_batch(None, noises, check=False, programs=progs)
+            assert np.array_equal(lp, lp2, equal_nan=True) and np.array_equal(info, info2), name
+            ok = (info == 0) & (rinfo == 0)
+            assert ok.sum() >= P - 2 and np.array_equal(info > 0, rinfo > 0)
+            assert lp_err(lp[ok], ref[ok]).max() <= LP_TOL, name
+            res[name] = lp
+        finally:
+            eng.close()
+    for name in res:
+        ok = np.isfinite(res[name]) & np.isfinite(res["cols"])
+        assert lp_err(res[name][ok], res["cols"][ok]).max() <= 1e-10, name
+    assert np.array_equal(res["flow"], res["flow_tr"], equal_nan=True)      # the queue order does not touch the arithmetic
 
 
 def test_config1_se_plus_linear(pkg, engine):
@@ -670,4 +708,8 @@ def test_full_size_properties(pkg, engine):
     assert lp_err(lp2[ok], lp[ok]).max() <= LP_TOL
     sub = [int(i) for i in np.flatnonzero(ok)[:5]]
     lp3, _ = engine.logpdf_batch([nodes[i] for i in sub[::-1]], noises[sub[::-1]])
-    assert np.array_equal(lp3[::-1], lp2[sub])
+    # (5 particles take the right-looking schedule, 24 the dataflow one: same value to rounding, not bit for bit)
+    assert lp_err(lp3[::-1], lp2[sub]).max() <= 1e-11
+    sub8 = [int(i) for i in np.flatnonzero(ok)[:12]]
+    lp4, _ = engine.logpdf_batch([nodes[i] for i in sub8[::-1]], noises[sub8[::-1]])
+    assert np.array_equal(lp4[::-1], lp2[sub8])          # same schedule, other batch composition: the same bits

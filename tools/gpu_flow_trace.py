@@ -1,0 +1,42 @@
+"""Timeline of one dataflow sweep (k_chol_flow): utilisation of the workgroup slots over time, time spent waiting on
+operand tiles, per block column.   python tools/gpu_flow_trace.py [n] [P]"""
+import os, sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+os.environ["AGP_FLOW"] = "1"
+import __graft_entry__ as g
+pkg = g.load_package()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+ts, xs = pkg.prior.synthetic_series(n, seed=n, shuffle=True)
+nodes, noises = pkg.prior.sample_particles(np.random.default_rng(n), P, max_size=63)
+progs = pkg.encode_batch(nodes)
+eng = pkg.GPEngine(0); eng.set_data(ts, xs)
+for _ in range(3):
+    eng.logpdf_batch(None, noises, check=False, programs=progs)
+nt = (n + 127) // 128; ntri = nt * (nt + 1) // 2
+items = sum(((P - x + 7) // 8) * ntri for x in range(8))
+eng.flow_trace(True, items)
+eng.logpdf_batch(None, noises, check=False, programs=progs)
+tr = eng.flow_trace(False, items)
+t0 = tr[:, 0].min(); us = 0.01
+st = (tr[:, 0] - t0) * us; en = (tr[:, 1] - t0) * us; wait = tr[:, 2] * us
+wg = tr[:, 3] >> 48; part = (tr[:, 3] >> 24) & 0xFFFFFF; ti = (tr[:, 3] >> 12) & 0xFFF; tk = tr[:, 3] & 0xFFF
+total = en.max()
+print(f"n={n} P={P}: {items} items, kernel span {total:.0f} us; busy (item time minus K-loop waits) summed over items {np.sum(en-st-wait)/1e3:.2f} ms, "
+      f"waits {wait.sum()/1e3:.2f} ms, slots {len(np.unique(wg))}")
+nb = 20
+edges = np.linspace(0, total, nb + 1)
+print("time window (us)    active items(avg)  waiting(avg)")
+for b in range(nb):
+    a, c = edges[b], edges[b + 1]
+    ov = np.clip(np.minimum(en, c) - np.maximum(st, a), 0, None)
+    act = ov.sum() / (c - a)
+    print(f"  {a:7.0f}-{c:7.0f}   {act:8.1f}")
+print("block column: first start, last end, mean item us (diag / sub), mean wait us")
+for k in range(nt):
+    m = tk == k
+    d = m & (ti == tk); sd = m & (ti != tk)
+    print(f"  k={k:2d} {st[m].min():8.0f} {en[m].max():8.0f}   diag {np.mean(en[d]-st[d]):7.1f}  sub {np.mean(en[sd]-st[sd]) if sd.any() else 0:7.1f}   wait diag {wait[d].mean():6.1f} sub {wait[sd].mean() if sd.any() else 0:6.1f}")
