@@ -7,6 +7,6 @@ from .gp import (Node, LeafNode, BinaryOpNode, WhiteNoise, Constant, Linear, Squ
                  GammaExponential, Periodic, Plus, Times, ChangePoint, unroll, encode, encode_batch, from_tuple)
 from .engine import (GPEngine, GPEngineMulti, shard_range, AGPError, PosDefException, load_library, LIB_PATH, EXPORTED_SYMBOLS,
                      compute_cov_matrix_vectorized, eval_cov, mvnormal_logpdf, MvNormal, quantile, infer_gp_sum)
-from . import prior, schedule, dist
+from . import prior, schedule, dist, stream
 
 __all__ = [n for n in dir() if not n.startswith("_")]

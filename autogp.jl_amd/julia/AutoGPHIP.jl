@@ -1,10 +1,14 @@
 # AutoGPHIP.jl — Julia-side binding of libautogp_hip.so (include/autogp_hip.h).
 #
-# STATUS: source only.  Julia is not installed in the build container nor on the GPU box, so this
-# file has never been executed; every executable test drives the same C ABI from Python/ctypes.
-# It is the `ccall` stub a maintainer of AutoGP.jl adds to switch the two hot call sites
+# STATUS: source only.  Julia is not installed in the build container nor on the GPU box, so this file has never been
+# executed; every executable test drives the same C ABI from Python/ctypes and from C++ (tools/native/).  Statements
+# about Gen's internals below (how the dynamic DSL calls logpdf / logpdf_grad, what choice_gradients passes) are
+# recalled from Gen 0.4's public source, which is not under /root/reference and could not be inspected here.
+#
+# It is the `ccall` layer a maintainer of AutoGP.jl adds to switch the hot call sites
 #   src/Model.jl:135-136   (compute_cov_matrix_vectorized + `xs ~ mvnormal(zeros(n), K)`)
 #   src/GP.jl:731-758      (Distributions.MvNormal(node, noise, ts, xs, ts_pred; ...))
+#   src/GP.jl:904-993      (GP.infer_gp_sum)
 # to the MI355X engine while `Inference.jl`, the SMC/MCMC moves and the public API stay untouched.
 module AutoGPHIP
 
@@ -15,10 +19,16 @@ import AutoGP
 const GP = AutoGP.GP
 
 const LIB = get(ENV, "AUTOGP_HIP_LIB", "libautogp_hip.so")
+const COMM_ID_BYTES = 128
 
+# ------------------------------------------------------------------------------------------------------------------
+# contexts
+# ------------------------------------------------------------------------------------------------------------------
 mutable struct Engine
     ptr::Ptr{Cvoid}
     n_max::Int
+    ts::Vector{Float64}     # host copies of the resident series: Gen hands (ts, xs) to logpdf on every call and
+    xs::Vector{Float64}     # the shim must know whether they ARE the resident prefix
 end
 
 function check(eng::Union{Engine,Nothing}, rc::Cint)
@@ -28,25 +38,65 @@ function check(eng::Union{Engine,Nothing}, rc::Cint)
     error("autogp_hip call failed ($rc): $msg")
 end
 
-"One engine per GPU (one process per GPU in the multi-GPU deployment)."
+destroy!(e::Engine) = (e.ptr != C_NULL && ccall((:agp_destroy, LIB), Cvoid, (Ptr{Cvoid},), e.ptr); e.ptr = C_NULL; nothing)
+
+"One engine per GPU."
 function Engine(device::Integer=0)
     ref = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:agp_init, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint), ref, device)
     check(nothing, rc)
-    eng = Engine(ref[], 0)
-    finalizer(e -> ccall((:agp_destroy, LIB), Cvoid, (Ptr{Cvoid},), e.ptr), eng)
+    eng = Engine(ref[], 0, Float64[], Float64[])
+    finalizer(destroy!, eng)
     return eng
 end
 
-"Upload the rescaled observations once; later calls use prefixes ts[1:n] (data annealing)."
+"""
+One Julia process driving several GPUs (agp_init_multi: n contexts + one RCCL communicator over them).
+`engine_for_thread(pool)` maps the calling Julia thread to a device, so that the reference's
+`Threads.@threads for i=1:num_particles` loops (src/inference_smc_anneal_data.jl:133,240; src/api.jl:293,386) spread
+their single-particle calls over the node: thread t always talks to device (t-1) % n_dev + 1, each device coalesces
+its own callers.
+"""
+struct EnginePool
+    engines::Vector{Engine}
+end
+
+function EnginePool(devices::AbstractVector{<:Integer})
+    n = length(devices)
+    ptrs = fill(C_NULL, n); ids = Int32.(collect(devices))
+    GC.@preserve ptrs ids check(nothing, ccall((:agp_init_multi, LIB), Cint, (Ptr{Ptr{Cvoid}}, Ptr{Int32}, Int32), ptrs, ids, n))
+    engines = [Engine(p, 0, Float64[], Float64[]) for p in ptrs]
+    foreach(e -> finalizer(destroy!, e), engines)
+    return EnginePool(engines)
+end
+
+engine_for_thread(pool::EnginePool) = pool.engines[(Threads.threadid() - 1) % length(pool.engines) + 1]
+engine_for_thread(eng::Engine) = eng
+
+"Upload the rescaled observations once; later calls use prefixes ts[1:n] (data annealing).  Appending observations
+(add_data!, src/api.jl:426-443) keeps the resident factors of `logpdf_batch_extend` valid."
 function set_data!(eng::Engine, ts::Vector{Float64}, xs::Vector{Float64})
     @assert length(ts) == length(xs)
     GC.@preserve ts xs check(eng, ccall((:agp_set_data, LIB), Cint,
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), eng.ptr, ts, xs, length(ts)))
-    eng.n_max = length(ts)
+    eng.n_max = length(ts); eng.ts = copy(ts); eng.xs = copy(xs)
+    return eng
+end
+set_data!(pool::EnginePool, ts::Vector{Float64}, xs::Vector{Float64}) = (foreach(e -> set_data!(e, ts, xs), pool.engines); pool)
+
+"Is (ts, xs) the prefix of the resident series?  O(n) comparisons next to an O(n^3) factorisation."
+function is_resident_prefix(eng::Engine, ts::AbstractVector{<:Real}, xs::AbstractVector{<:Real})
+    n = length(ts)
+    (n == length(xs) && n <= eng.n_max) || return false
+    @inbounds for i in 1:n
+        (ts[i] == eng.ts[i] && xs[i] == eng.xs[i]) || return false
+    end
+    return true
 end
 
-# ---- kernel tree -> postfix program (opcodes = GPConfig codes, src/GP.jl:1101-1108; 0 = WhiteNoise)
+# ------------------------------------------------------------------------------------------------------------------
+# kernel tree -> postfix program (opcodes = GPConfig codes, src/GP.jl:1101-1108; 0 = WhiteNoise)
+# ------------------------------------------------------------------------------------------------------------------
 opcode(::GP.WhiteNoise) = 0x00; opcode(::GP.Constant) = 0x01; opcode(::GP.Linear) = 0x02
 opcode(::GP.SquaredExponential) = 0x03; opcode(::GP.GammaExponential) = 0x04; opcode(::GP.Periodic) = 0x05
 opcode(::GP.Plus) = 0x06; opcode(::GP.Times) = 0x07; opcode(::GP.ChangePoint) = 0x08
@@ -60,29 +110,15 @@ params(n::GP.Periodic) = (n.lengthscale, n.period, n.amplitude)
 params(n::GP.ChangePoint) = (n.location, n.scale)
 params(::GP.BinaryOpNode) = ()
 
-"Program in `GP.unroll` order (left, right, node — src/GP.jl:112-113)."
-function encode(node::GP.Node)
-    seq = GP.unroll(node)
-    ops = UInt8[opcode(n) for n in seq]
-    prm = Float64[Float64(v) for n in seq for v in params(n)]
-    return ops, prm
-end
+"Opcodes of the tree in `GP.unroll` order (left, right, node — src/GP.jl:112-113)."
+structure(node::GP.Node) = UInt8[opcode(n) for n in GP.unroll(node)]
+"Parameters in the same order, struct-field order within a node; entries keep their type (Float64 or a tracked Real)."
+flat_params(node::GP.Node) = [v for n in GP.unroll(node) for v in params(n)]
 
-"log N(xs[1:n]; 0, eval_cov(node, ts[1:n]) + noise*I) — replaces src/Model.jl:135-136."
-function logpdf(eng::Engine, node::GP.Node, noise::Float64, n::Integer=eng.n_max)
-    ops, prm = encode(node)
-    isempty(prm) && push!(prm, 0.0)
-    out = Ref{Float64}(0.0); info = Ref{Int32}(0)
-    GC.@preserve ops prm check(eng, ccall((:agp_logpdf, LIB), Cint,
-        (Ptr{Cvoid}, Int64, Ptr{UInt8}, Int32, Ptr{Float64}, Int32, Float64, Ref{Float64}, Ref{Int32}),
-        eng.ptr, n, ops, length(ops), prm, length(prm), noise, out, info))
-    info[] > 0 && throw(LinearAlgebra.PosDefException(info[]))   # the reference aborts on non-PD too
-    return out[]
-end
+"(ops, prm) of the C ABI."
+encode(node::GP.Node) = (structure(node), Float64[Float64(v) for v in flat_params(node)])
 
-"All particles in one sweep — what a coalescing shim / the benchmark calls."
-function logpdf_batch(eng::Engine, nodes::Vector{<:GP.Node}, noises::Vector{Float64}, n::Integer=eng.n_max)
-    P = length(nodes)
+function encode_batch(nodes::Vector{<:GP.Node})
     op_off = Int32[0]; prm_off = Int32[0]; ops = UInt8[]; prm = Float64[]
     for nd in nodes
         o, q = encode(nd)
@@ -90,31 +126,82 @@ function logpdf_batch(eng::Engine, nodes::Vector{<:GP.Node}, noises::Vector{Floa
         push!(op_off, length(ops)); push!(prm_off, length(prm))
     end
     isempty(prm) && push!(prm, 0.0)
+    return op_off, ops, prm_off, prm
+end
+
+# ------------------------------------------------------------------------------------------------------------------
+# value path
+# ------------------------------------------------------------------------------------------------------------------
+function logpdf_program(eng::Engine, ops::Vector{UInt8}, prm::Vector{Float64}, noise::Float64, n::Integer)
+    np_ = length(prm)
+    q = isempty(prm) ? [0.0] : prm
+    out = Ref{Float64}(0.0); info = Ref{Int32}(0)
+    GC.@preserve ops q check(eng, ccall((:agp_logpdf, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{UInt8}, Int32, Ptr{Float64}, Int32, Float64, Ref{Float64}, Ref{Int32}),
+        eng.ptr, n, ops, length(ops), q, np_, noise, out, info))
+    info[] > 0 && throw(LinearAlgebra.PosDefException(info[]))   # the reference aborts on non-PD too
+    return out[]
+end
+
+"log N(xs[1:n]; 0, eval_cov(node, ts[1:n]) + noise*I) on the resident data — replaces src/Model.jl:135-136."
+logpdf(eng::Engine, node::GP.Node, noise::Float64, n::Integer=eng.n_max) = logpdf_program(eng, encode(node)..., noise, n)
+
+"All particles in one sweep."
+function logpdf_batch(eng::Engine, nodes::Vector{<:GP.Node}, noises::Vector{Float64}, n::Integer=eng.n_max; extend::Bool=false)
+    P = length(nodes)
+    op_off, ops, prm_off, prm = encode_batch(nodes)
     out = Vector{Float64}(undef, P); info = Vector{Int32}(undef, P)
-    GC.@preserve op_off ops prm_off prm noises out info check(eng, ccall((:agp_logpdf_batch, LIB), Cint,
-        (Ptr{Cvoid}, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
-        eng.ptr, n, P, op_off, ops, prm_off, prm, noises, out, info))
+    # extend = true: agp_logpdf_batch_extend — factors stay resident, a later call on a longer prefix only computes the
+    # new tile rows (the reweight step of data annealing, src/inference_smc_anneal_data.jl:206-217)
+    GC.@preserve op_off ops prm_off prm noises out info begin
+        rc = extend ?
+            ccall((:agp_logpdf_batch_extend, LIB), Cint,
+                (Ptr{Cvoid}, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                eng.ptr, n, P, op_off, ops, prm_off, prm, noises, out, info) :
+            ccall((:agp_logpdf_batch, LIB), Cint,
+                (Ptr{Cvoid}, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                eng.ptr, n, P, op_off, ops, prm_off, prm, noises, out, info)
+        check(eng, rc)
+    end
     return out, info
 end
 
+"The whole population over every GPU of the pool: shards by agp_shard_range, one sweep per device, log-weights
+all-gathered over RCCL inside the library (agp_logpdf_batch_multi)."
+function logpdf_batch(pool::EnginePool, nodes::Vector{<:GP.Node}, noises::Vector{Float64}, n::Integer=pool.engines[1].n_max)
+    P = length(nodes)
+    op_off, ops, prm_off, prm = encode_batch(nodes)
+    out = Vector{Float64}(undef, P); info = Vector{Int32}(undef, P)
+    ptrs = [e.ptr for e in pool.engines]
+    GC.@preserve ptrs op_off ops prm_off prm noises out info check(pool.engines[1], ccall((:agp_logpdf_batch_multi, LIB), Cint,
+        (Ptr{Ptr{Cvoid}}, Int32, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+        ptrs, length(ptrs), n, P, op_off, ops, prm_off, prm, noises, out, info))
+    return out, info
+end
+
+# ------------------------------------------------------------------------------------------------------------------
+# gradient path
+# ------------------------------------------------------------------------------------------------------------------
 """
-Value and gradient in one sweep: (logpdf, d/dθ in `encode(node)[2]` order — transformed parameters, ChangePoint
-contributes location and scale — and d/dnoise).  Chain through `Model.transform_param` on the Julia side:
-log-normal θ = exp(μ+σz) → ∂/∂z = σ θ ∂/∂θ;  gamma = s/(1+exp(-(μ+σz))) → ∂/∂z = σ γ (1 - γ/s) ∂/∂γ.
+Value and gradient in one call: (logpdf, d/dθ in `flat_params(node)` order — transformed parameters, ChangePoint
+contributes location and scale — and d/dnoise).  Single-particle entry: callers on different Julia threads are
+coalesced into batched gradient sweeps inside the library.
 """
-function logpdf_grad(eng::Engine, node::GP.Node, noise::Float64, n::Integer=eng.n_max)
-    ops, prm = encode(node)
+function logpdf_grad_program(eng::Engine, ops::Vector{UInt8}, prm::Vector{Float64}, noise::Float64, n::Integer)
     np_ = length(prm)
-    isempty(prm) && push!(prm, 0.0)
+    q = isempty(prm) ? [0.0] : prm
     lp = Ref{Float64}(0.0); gn = Ref{Float64}(0.0); info = Ref{Int32}(0); grad = zeros(max(np_, 1))
-    # single-particle entry: calls from Threads.@threads loops are coalesced into batched gradient sweeps by the library
-    GC.@preserve ops prm grad check(eng, ccall((:agp_logpdf_grad, LIB), Cint,
+    GC.@preserve ops q grad check(eng, ccall((:agp_logpdf_grad, LIB), Cint,
         (Ptr{Cvoid}, Int64, Ptr{UInt8}, Int32, Ptr{Float64}, Int32, Float64, Ref{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Int32}),
-        eng.ptr, n, ops, length(ops), prm, np_, noise, lp, grad, gn, info))
+        eng.ptr, n, ops, length(ops), q, np_, noise, lp, grad, gn, info))
     info[] > 0 && throw(LinearAlgebra.PosDefException(info[]))
     return lp[], grad[1:np_], gn[]
 end
+logpdf_grad(eng::Engine, node::GP.Node, noise::Float64, n::Integer=eng.n_max) = logpdf_grad_program(eng, encode(node)..., noise, n)
 
+# ------------------------------------------------------------------------------------------------------------------
+# predictive path
+# ------------------------------------------------------------------------------------------------------------------
 "Posterior predictive — replaces Distributions.MvNormal(node, noise, ts, xs, ts_pred; ...) (src/GP.jl:731-758)."
 function predict_mvn(eng::Engine, node::GP.Node, noise::Float64, ts_pred::Vector{Float64};
         n::Integer=eng.n_max, noise_pred::Union{Nothing,Float64}=nothing,
@@ -123,12 +210,18 @@ function predict_mvn(eng::Engine, node::GP.Node, noise::Float64, ts_pred::Vector
     m = length(ts_pred)
     op_off = Int32[0, length(ops)]; prm_off = Int32[0, length(prm)]
     mu = Vector{Float64}(undef, m); var = Vector{Float64}(undef, m); cov = Matrix{Float64}(undef, m, m)
-    info = Int32[0]; nz = [noise]; np = isnothing(noise_pred) ? C_NULL : pointer([noise_pred])
-    GC.@preserve ops prm ts_pred mu var cov nz mean_train mean_pred check(eng, ccall((:agp_predict_batch, LIB), Cint,
+    info = Int32[0]; nz = [noise]
+    # every optional array is bound to a local that is listed in GC.@preserve; C_NULL stands for "absent"
+    npv = isnothing(noise_pred) ? Float64[] : [noise_pred]
+    mt = isnothing(mean_train) ? Float64[] : mean_train
+    mp = isnothing(mean_pred) ? Float64[] : mean_pred
+    GC.@preserve ops prm op_off prm_off ts_pred mu var cov nz npv mt mp info check(eng, ccall((:agp_predict_batch, LIB), Cint,
         (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64},
          Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
-        eng.ptr, n, ts_pred, m, 1, op_off, ops, prm_off, prm, nz, np,
-        isnothing(mean_train) ? C_NULL : pointer(mean_train), isnothing(mean_pred) ? C_NULL : pointer(mean_pred),
+        eng.ptr, n, ts_pred, m, 1, op_off, ops, prm_off, prm, nz,
+        isempty(npv) ? Ptr{Float64}(C_NULL) : pointer(npv),
+        isempty(mt) ? Ptr{Float64}(C_NULL) : pointer(mt),
+        isempty(mp) ? Ptr{Float64}(C_NULL) : pointer(mp),
         mu, var, cov, info))
     info[1] > 0 && throw(LinearAlgebra.PosDefException(info[1]))
     return Distributions.MvNormal(mu, LinearAlgebra.Symmetric(cov))
@@ -138,39 +231,142 @@ end
 function infer_gp_sum(eng::Engine, nodes::Vector{<:GP.Node}, noise::Float64, ts_pred::Vector{Float64};
         n::Integer=eng.n_max, noise_pred::Union{Nothing,Float64}=nothing)
     M = length(nodes); p = length(ts_pred); ma = (M + 1) * p
-    op_off = Int32[0]; prm_off = Int32[0]; ops = UInt8[]; prm = Float64[]
-    for nd in nodes
-        o, q = encode(nd); append!(ops, o); append!(prm, q)
-        push!(op_off, length(ops)); push!(prm_off, length(prm))
-    end
-    isempty(prm) && push!(prm, 0.0)
+    op_off, ops, prm_off, prm = encode_batch(nodes)
     mu = Vector{Float64}(undef, ma); cov = Matrix{Float64}(undef, ma, ma); info = Ref{Int32}(0)
     GC.@preserve op_off ops prm_off prm ts_pred mu cov check(eng, ccall((:agp_infer_gp_sum, LIB), Cint,
         (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64},
          Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
         eng.ptr, n, ts_pred, p, M, op_off, ops, prm_off, prm, noise, isnothing(noise_pred) ? noise : noise_pred,
         mu, cov, info))
+    info[] > 0 && throw(LinearAlgebra.PosDefException(info[]))
     mvn = Distributions.MvNormal(mu, LinearAlgebra.Symmetric(cov))
     return (mvn=mvn, indexes=(F=[((i-1)*p+1):(i*p) for i in 1:M], X=(M*p+1):(M*p+p)))
 end
 
-# ---- Gen distribution: the trace-score term of src/Model.jl:136 evaluated on the GPU ------------
+# ------------------------------------------------------------------------------------------------------------------
+# multi-process deployment: one Julia process per GPU (Distributed / MPI), log-weights all-gathered through the engine
+# ------------------------------------------------------------------------------------------------------------------
+"rank 0: the 128-byte RCCL id to hand to the other ranks (any host channel)"
+function comm_unique_id()
+    id = Vector{UInt8}(undef, COMM_ID_BYTES)
+    GC.@preserve id check(nothing, ccall((:agp_comm_get_unique_id, LIB), Cint, (Ptr{UInt8},), id))
+    return id
+end
+function comm_init_rank!(eng::Engine, id::Vector{UInt8}, n_ranks::Integer, rank::Integer)
+    @assert length(id) == COMM_ID_BYTES
+    GC.@preserve id check(eng, ccall((:agp_comm_init_rank, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), eng.ptr, id, n_ranks, rank))
+end
+"block [lo, hi] (1-based, inclusive) of rank `rank` (0-based) — identical on every rank"
+function shard_range(P::Integer, rank::Integer, n_ranks::Integer)
+    lo = Ref{Int32}(0); hi = Ref{Int32}(0)
+    ccall((:agp_shard_range, LIB), Cvoid, (Int32, Int32, Int32, Ref{Int32}, Ref{Int32}), P, rank, n_ranks, lo, hi)
+    return (lo[] + 1):hi[]
+end
+"""
+`lw` has one entry per particle of the WHOLE population with this rank's block filled; on return every rank holds
+the complete vector — the input of compute_particle_weights / effective_sample_size / Gen.maybe_resample!
+(src/inference_smc_anneal_data.jl:22-31,232).
+"""
+function allgather_logweights!(eng::Engine, lw::Vector{Float64})
+    GC.@preserve lw check(eng, ccall((:agp_allgather_logweights, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int32), eng.ptr, lw, length(lw)))
+    return lw
+end
+
+# ------------------------------------------------------------------------------------------------------------------
+# Gen distributions: the trace-score term of src/Model.jl:136 evaluated on the GPU
+# ------------------------------------------------------------------------------------------------------------------
+# (1) Drop-in for the VALUE calls, tree-typed argument:
+#         xs ~ gp_marginal(engine, covariance_fn, noise, ts)
+#     Gen cannot differentiate through a GP.Node argument (has_argument_grads must be false for it), so this form is
+#     for traces whose parameters are moved by value-only kernels (MH, involutive MCMC, resample-move reweighting).
+#     It REFUSES to be used inside choice_gradients (tracked parameters), instead of silently dropping the
+#     likelihood gradient.
 struct GPMarginal <: Gen.Distribution{Vector{Float64}} end
 const gp_marginal = GPMarginal()
 
-# xs ~ gp_marginal(engine, node, noise, ts)    (ts must be a prefix of the resident data)
-function Gen.logpdf(::GPMarginal, xs::Vector{Float64}, eng::Engine, node::GP.Node, noise::Real, ts::Vector{Float64})
-    if noise isa Float64
-        return logpdf(eng, node, noise, length(ts))
-    end
-    # AD caveat (SURVEY.md §8b): ReverseDiff-tracked parameters stay on the reference's Julia path
-    K = GP.compute_cov_matrix_vectorized(node, noise, ts)
-    return Gen.logpdf(Gen.mvnormal, xs, zeros(length(ts)), K)
+reference_logpdf(xs, node, noise, ts) =
+    Gen.logpdf(Gen.mvnormal, xs, zeros(length(ts)), GP.compute_cov_matrix_vectorized(node, noise, ts))
+
+function Gen.logpdf(::GPMarginal, xs::Vector{Float64}, engs, node::GP.Node, noise::Real, ts::Vector{Float64})
+    any(v -> !(v isa AbstractFloat || v isa Integer), flat_params(node)) &&
+        error("gp_marginal received tracked kernel parameters (Gen.choice_gradients / hmc / map_optimize): use " *
+              "gp_marginal_flat, whose logpdf_grad returns the engine's gradient")
+    eng = engine_for_thread(engs)
+    # Gen.simulate / generate without a constraint on :xs sample xs themselves (Gen.random below): such a trace is
+    # scored on ITS xs, not on the resident series — through the reference's own arithmetic
+    is_resident_prefix(eng, ts, xs) || return reference_logpdf(xs, node, Float64(noise), ts)
+    return logpdf(eng, node, Float64(noise), length(ts))
 end
-Gen.random(::GPMarginal, eng, node, noise, ts) =
+Gen.random(::GPMarginal, engs, node, noise, ts) =
     Gen.random(Gen.mvnormal, zeros(length(ts)), GP.compute_cov_matrix_vectorized(node, noise, ts))
 Gen.has_output_grad(::GPMarginal) = false
 Gen.has_argument_grads(::GPMarginal) = (false, false, false, false)
 Gen.is_discrete(::GPMarginal) = false
+
+# (2) The differentiable form, flat arguments:
+#         xs ~ gp_marginal_flat(engine, structure(covariance_fn), flat_params(covariance_fn), noise, ts)
+#     `theta` is a Vector of Reals — exactly the values `covariance_prior` builds its nodes from
+#     (transform_param(field, z, config), src/Model.jl:94,116), so under Gen.choice_gradients its entries are tracked
+#     and Gen asks this distribution for argument gradients: has_argument_grads is true for theta and noise,
+#     logpdf_grad returns the engine's d logpdf / d theta and d logpdf / d noise, and ReverseDiff carries them on
+#     through transform_param to the latent N(0,1) choices that Gen.hmc / Gen.map_optimize move
+#     (src/inference_smc_anneal_data.jl:63-67, src/Greedy.jl:95,370).  ChangePoint's fixed scale (.001, src/Model.jl:121)
+#     is an untracked entry of theta: its gradient slot is computed and ignored.
+struct GPMarginalFlat <: Gen.Distribution{Vector{Float64}} end
+const gp_marginal_flat = GPMarginalFlat()
+
+function node_from_flat(ops::Vector{UInt8}, theta::AbstractVector)
+    stack = GP.Node[]; q = 0
+    take(k) = (v = theta[q+1:q+k]; q += k; v)
+    for o in ops
+        if o == 0x00 push!(stack, GP.WhiteNoise(take(1)...))
+        elseif o == 0x01 push!(stack, GP.Constant(take(1)...))
+        elseif o == 0x02 push!(stack, GP.Linear(take(3)...))
+        elseif o == 0x03 push!(stack, GP.SquaredExponential(take(2)...))
+        elseif o == 0x04 push!(stack, GP.GammaExponential(take(3)...))
+        elseif o == 0x05 push!(stack, GP.Periodic(take(3)...))
+        else
+            r = pop!(stack); l = pop!(stack)
+            push!(stack, o == 0x06 ? GP.Plus(l, r) : o == 0x07 ? GP.Times(l, r) : GP.ChangePoint(l, r, take(2)...))
+        end
+    end
+    return only(stack)
+end
+
+function Gen.logpdf(::GPMarginalFlat, xs::Vector{Float64}, engs, ops::Vector{UInt8}, theta::AbstractVector{<:Real},
+                    noise::Real, ts::Vector{Float64})
+    eng = engine_for_thread(engs)
+    th = Float64[Float64(v) for v in theta]       # Gen passes VALUES here (arguments are untracked in logpdf)
+    is_resident_prefix(eng, ts, xs) || return reference_logpdf(xs, node_from_flat(ops, th), Float64(noise), ts)
+    return logpdf_program(eng, ops, th, Float64(noise), length(ts))
+end
+
+function Gen.logpdf_grad(::GPMarginalFlat, xs::Vector{Float64}, engs, ops::Vector{UInt8}, theta::AbstractVector{<:Real},
+                         noise::Real, ts::Vector{Float64})
+    eng = engine_for_thread(engs)
+    th = Float64[Float64(v) for v in theta]
+    is_resident_prefix(eng, ts, xs) ||
+        error("gp_marginal_flat.logpdf_grad: (ts, xs) is not the prefix of the series uploaded with set_data!")
+    _, g, gn = logpdf_grad_program(eng, ops, th, Float64(noise), length(ts))
+    # (output grad, then one entry per argument: engine, ops, theta, noise, ts)
+    return (nothing, nothing, nothing, g, gn, nothing)
+end
+Gen.random(::GPMarginalFlat, engs, ops, theta, noise, ts) =
+    Gen.random(Gen.mvnormal, zeros(length(ts)),
+               GP.compute_cov_matrix_vectorized(node_from_flat(ops, Float64[Float64(v) for v in theta]), Float64(noise), ts))
+Gen.has_output_grad(::GPMarginalFlat) = false
+Gen.has_argument_grads(::GPMarginalFlat) = (false, false, true, true, false)
+Gen.is_discrete(::GPMarginalFlat) = false
+
+# The patched model body (replaces src/Model.jl:131-138; covariance_prior itself is unchanged):
+#
+#   @gen function model(ts::Vector{Float64}, config::GPConfig)
+#       covariance_fn = {:tree} ~ covariance_prior(1, config)
+#       noise ~ normal(0, 1)
+#       noise = transform_param(:noise, noise, config) + JITTER
+#       xs ~ AutoGPHIP.gp_marginal_flat(ENGINES[], AutoGPHIP.structure(covariance_fn),
+#                                       AutoGPHIP.flat_params(covariance_fn), noise, ts)
+#       return covariance_fn
+#   end
 
 end # module

@@ -238,3 +238,41 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["config"]["particles_total"] == 64 and out["config"]["particles_per_gpu"] == 32
     assert out["config"]["allgather_selfcheck"] is True
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
+
+
+def test_online_stream_driver_on_gpu(pkg):
+    """autogp.jl_amd/stream.py (the control flow of run_smc_anneal_data around the engine: reweight by block-extension
+    sweeps, ESS, resampling, per-step predictive callback) against the same driver fed by the CPU oracle: identical
+    resampling decisions, log-marginal-likelihood estimate and weights to 1e-8; the per-step predictions of the block
+    against the oracle's predictive at the last step."""
+    from oracle import oracle as O
+    n_max, P = 768, 40
+    ts, xs = pkg.prior.synthetic_series(n_max, seed=33, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(33), P, max_depth=3)
+    eng = pkg.GPEngine(0)
+    try:
+        eng.set_data(ts, xs)
+        gpu = pkg.stream.OnlineStream(nodes, noises, pkg.stream.EngineEvaluator(eng), seed=3)
+
+        def ev(nd, nz, n):
+            lp, info = F.gp_logpdf_many(pkg.encode_batch(nd), nz, ts[:n], xs[:n], threads=min(64, F.host_cores()))
+            return lp, info
+        cpu = pkg.stream.OnlineStream(nodes, noises, ev, seed=3)
+        steps = [96 * k for k in range(1, 9)]
+        tq = np.linspace(0.0, 1.1, 40)
+        for n in steps:
+            a = gpu.step(n, last=(n == steps[-1])); b = cpu.step(n, last=(n == steps[-1]))
+            assert a["resampled"] == b["resampled"] and abs(a["ess"] - b["ess"]) <= 1e-6 * max(1.0, b["ess"])
+            assert abs(a["log_ml_est"] - b["log_ml_est"]) <= 1e-8 * max(1.0, abs(b["log_ml_est"]))
+            mean, var = gpu.predict_block(eng, tq, n)            # the per-step callback
+            assert mean.shape == (P, 40) and np.isfinite(mean).all() and (var > 0).all()
+        assert any(h["resampled"] for h in gpu.history)
+        assert np.abs(gpu.particle_weights() - cpu.particle_weights()).max() <= 1e-7
+        st = eng.extend_stats()
+        assert st["extended"] > 0 and st["tile_rows_reused"] > 0
+        i = int(np.argmax(gpu.particle_weights()))
+        mu, cov = O.predict_mvn(gpu.nodes[i].to_tuple(), float(gpu.noises[i]), ts, xs, tq)
+        assert np.abs(mean[i] - mu).max() <= 1e-8 * max(1.0, np.abs(mu).max())
+        assert np.abs(var[i] - np.diag(cov)).max() <= 1e-8 * max(1.0, np.abs(cov).max())
+    finally:
+        eng.close()

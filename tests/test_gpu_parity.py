@@ -151,6 +151,37 @@ def test_golden_vectors_logpdf_and_predictive(pkg, engine, golden):
     assert n_checked == golden["n_cases"]
 
 
+_REF_GOLDEN = __import__("pathlib").Path(__file__).resolve().parent / "golden" / "golden_ref_v1.json"
+
+
+@pytest.mark.skipif(not _REF_GOLDEN.exists(), reason="tests/golden/golden_ref_v1.json absent: generate it with the real AutoGP.jl "
+                                                      "(julia tools/make_golden_reference.jl)")
+def test_reference_golden_vectors_on_gpu(pkg, engine):
+    """The HIP path against outputs of the REAL AutoGP.jl (file written by tools/make_golden_reference.jl under Julia;
+    same cases as golden_v1.json).  logpdf within 1e-8 relative, predictive mean / variance / quantiles within 1e-8."""
+    import json
+    from collections import defaultdict
+    ref = json.loads(_REF_GOLDEN.read_text())
+    groups = defaultdict(list)
+    for c in ref["cases"]:
+        groups[(tuple(c["ts"]), tuple(c["xs"]))].append(c)
+    for (ts, xs), cases in groups.items():
+        ts = np.array(ts); xs = np.array(xs)
+        engine.set_data(ts, xs)
+        nodes = [pkg.from_tuple(to_tuple(c["tree"])) for c in cases]
+        noises = np.array([c["noise"] for c in cases])
+        lp, info = engine.logpdf_batch(nodes, noises)
+        want = np.array([c["logpdf"] for c in cases])
+        assert (info == 0).all() and lp_err(lp, want).max() <= LP_TOL
+        for c, nd in zip(cases, nodes):
+            if "ts_pred" not in c:
+                continue
+            mean, var, _, _ = engine.predict_batch([nd], [c["noise"]], np.array(c["ts_pred"]))
+            pm = np.array(c["pred_mean"]); pv = np.array(c["pred_var"])
+            assert np.abs(mean[0] - pm).max() <= 1e-8 * max(1.0, np.abs(pm).max()), c["name"]
+            assert np.abs(var[0] - pv).max() <= 1e-8 * max(1.0, np.abs(pv).max()), c["name"]
+
+
 @pytest.mark.parametrize("n,P,max_depth", [(1, 4, 2), (2, 4, 2), (17, 6, 3), (127, 8, 3), (128, 8, 3), (129, 8, 3),
                                             (256, 8, 3), (700, 12, 4), (1024, 16, 3)])
 def test_logpdf_batch_vs_oracle(pkg, engine, n, P, max_depth):
