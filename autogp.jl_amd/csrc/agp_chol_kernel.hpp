@@ -453,16 +453,27 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       if (a.trace && wait_acc) *wait_acc += (double)((long long)wall_clock64() - tw0);
     };
+    // A tile of block column k-1 is final only after its own K-loop has consumed (acquired) every earlier column of
+    // its tile row — so when (tk,k-1) and (ti,k-1) are already raised, every operand of this K-loop is final and
+    // visible (release / acquire is cumulative): ONE probe replaces the per-column waits.  Otherwise column by column.
+    int all_ready = 0;
     if (FLOW) {
-      if (tid == 0) flow_ready(jfirst);
-      __syncthreads();
+      int probe = 0;
+      if (tid == 0) {
+        const int* tf = a.tflag + (long long)ps * a.ntri;
+        const int jl = jfirst + (nslab - 1) / SLABS_PER_TILE;         // last block column of the sum
+        probe = __hip_atomic_load(tf + tri_idx(tk, jl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+                (is_diag || __hip_atomic_load(tf + tri_idx(ti, jl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+        if (probe) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        else flow_ready(jfirst);
+      }
+      all_ready = __syncthreads_or(probe);
     }
     gload(0);
     lstore(0);
     d2 fr[NU];                                   // row fragments of the slab being multiplied
 #pragma unroll
     for (int u = 0; u < NU; ++u) fr[u] = ra[u];
-    if (FLOW && nslab > 1 && SLABS_PER_TILE == 1 && tid == 0) flow_ready(jfirst + 1);
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
       const int buf = s & 1;
@@ -501,7 +512,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
           for (int u = 0; u < NU; ++u) fr[u] = ra[u];
         }
       }
-      if (FLOW && tid == 0 && s + 2 < nslab && (s + 2) % SLABS_PER_TILE == 0) flow_ready(jfirst + (s + 2) / SLABS_PER_TILE);
+      if (FLOW && !all_ready && tid == 0 && s + 2 < nslab && (s + 2) % SLABS_PER_TILE == 0) flow_ready(jfirst + (s + 2) / SLABS_PER_TILE);
       __syncthreads();
     }
   }
@@ -841,9 +852,15 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       if (a.trace && wait_acc) *wait_acc += (double)((long long)wall_clock64() - tw0);
     };
+    int all_ready = 0;       // (see chol_tile: tile (tk, k-1) final => every earlier tile of the row is final and visible)
     if (FLOW) {
-      if (tid == 0) flow_ready(0);
-      __syncthreads();
+      int probe = 0;
+      if (tid == 0) {
+        probe = __hip_atomic_load(a.tflag + (long long)ps * a.ntri + tri_idx(tk, jmax - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (probe) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        else flow_ready(0);
+      }
+      all_ready = __syncthreads_or(probe);
     }
     // nslab is a multiple of 4: slabs 2i go through (rb, buffer 0), slabs 2i+1 through (rb2, buffer 1)
     gload(0);
@@ -858,7 +875,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
       if (s + 3 < nslab) gload2(s + 3);
       slab(1);
       if (s + 2 < nslab) lstore(0);
-      if (FLOW && tid == 0 && s + 4 < nslab && (s + 4) % SLABS_PER_TILE == 0) flow_ready((s + 4) / SLABS_PER_TILE);
+      if (FLOW && !all_ready && tid == 0 && s + 4 < nslab && (s + 4) % SLABS_PER_TILE == 0) flow_ready((s + 4) / SLABS_PER_TILE);
       __syncthreads();
     }
   }
@@ -934,6 +951,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
       else { pl = rem / T1; tl = 1 + rem - pl * T1; }
     }
     const int p = pl * 8 + xcd;
+    if (a0.i0 != nullptr && k + tl < a0.i0[p]) continue;        // extension sweep: this tile row keeps its factor (flag pre-raised)
     const int ps = a0.slot != nullptr ? a0.slot[p] : p;
     CholArgs a = a0;
     a.k = k;
@@ -1083,6 +1101,17 @@ __global__ void k_init_extend(double* vec, int ldv, int n_pad, const double* xs,
   if (g == 0) { ready[ps] = r0; if (r0 == 0) info[ps] = 0; }
   if (g >= n_pad || g < r0 * NB) return;
   vec[(long long)ps * ldv + g] = g < n ? xs[g] : 0.0;
+}
+
+// Dataflow extension sweep: flags of the tiles a particle already holds (rows < i0) are raised, the others cleared.
+__global__ void k_init_flow_flags(int* tflag, int ntri_stride, int ntri, const int* slot, const int* i0) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (t >= ntri) return;
+  int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+  while (ti * (ti + 1) / 2 > t) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+  tflag[(long long)slot[p] * ntri_stride + t] = ti < i0[p] ? 1 : 0;
 }
 
 // x (minus the mean function on the training segment), zero elsewhere; clears info.

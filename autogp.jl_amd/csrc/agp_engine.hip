@@ -169,7 +169,7 @@ struct agp_ctx {
     int nt_cap = 0;                     // tile rows a slot can hold
     int n_slots = 0;
     long long strideA = 0;              // doubles per slot
-    DevBuf A, W, vec, partial, info, ready;
+    DevBuf A, W, vec, partial, info, ready, tflag, flowq;
     std::vector<std::string> key;       // per slot; empty = free
     std::vector<int64_t> n_cached;      // observations the slot's factor covers
     std::vector<uint64_t> stamp;        // last use (LRU)
@@ -178,7 +178,7 @@ struct agp_ctx {
     int64_t hits = 0, misses = 0, tile_rows_reused = 0, tile_rows_total = 0;
     double max_frac = 0.45;             // share of the device memory the store may take
     void forget() { index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); }
-    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); n_slots = 0; nt_cap = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); }
+    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); n_slots = 0; nt_cap = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); }
   } store;
   // ---- RCCL communicator of the particle-sharded deployment (agp_comm_init_rank / agp_init_multi) ----
   ncclComm_t comm = nullptr;
@@ -2143,7 +2143,9 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
 
   Batch bt;
   const bool ge_tab = c->logdt_ok;
-  int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, ge_tab);
+  // (tiles are evaluated inside the factorisation kernels whatever the population size: the prebuilt-tile variants of
+  // the split launches carry the most register spills, and the store never needs K itself)
+  int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, ge_tab, /*fuse_hint=*/true);
   if (rc) { poison(); return rc; }
   int i0min = nt;
   for (int u = 0; u < U; ++u) i0min = std::min(i0min, (int)i0[u]);
@@ -2207,7 +2209,21 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     ca.info = fs.info.as<int>(); ca.ready = fs.ready.as<int>(); ca.P = U; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
     set_cov(ca, cv);
     ca.n_fused = nf; ca.slot = d_slot; ca.i0 = d_i0;
-    EXTCHK(run_factor_extend(st, ca, dcov, use_split_diag(c, U), i0min));
+    // an extension touches every block column (the new rows' tiles of the old columns, then the new columns): one
+    // dataflow launch instead of nt small per-column launches, whatever the amount of work
+    if (c->intrsm != 0 && (c->flow > 0 || (c->flow < 0 && U <= FLOW_MAX_PARTICLES && (nt >= 3 || use_flow(c, U, nt))))) {
+      // dataflow schedule over the rows to compute: flags of the resident rows are pre-raised
+      const int ntri_cap = fs.nt_cap * (fs.nt_cap + 1) / 2, ntri = nt * (nt + 1) / 2;
+      EXTCHK(fs.tflag.ensure(sizeof(int) * (size_t)fs.n_slots * ntri_cap));
+      EXTCHK(fs.flowq.ensure(sizeof(int) * 8));
+      hipLaunchKernelGGL(k_init_flow_flags, dim3((ntri + 255) / 256, U), dim3(256), 0, st, fs.tflag.as<int>(), ntri_cap, ntri, d_slot, d_i0);
+      EXTCHK(hipMemsetAsync(fs.flowq.p, 0, sizeof(int) * 8, st));
+      ca.tflag = fs.tflag.as<int>(); ca.ntri = ntri_cap; ca.qnext = fs.flowq.as<int>(); ca.flow_order = c->flow_order;
+      launch_flow(dcov, 2 * c->n_cu, st, ca);
+      EXTCHK(hipGetLastError());
+    } else {
+      EXTCHK(run_factor_extend(st, ca, dcov, use_split_diag(c, U), i0min));
+    }
   }
   hipLaunchKernelGGL(k_finish_logpdf, dim3((U + 63) / 64), dim3(64), 0, st, fs.partial.as<double>(), fs.info.as<int>(), nt, U,
                      (int)n, reinterpret_cast<const int*>(dstage + o_map), d_lp, d_info, d_slot, fs.nt_cap);
