@@ -55,7 +55,9 @@ import re
 upd = [k for k in res if re.search(r"k_chol_update<true, \d, true, 2\b", k)] or [k for k in res if "k_chol_update<true" in k]
 if upd and "fetch" in res[upd[0]] and "write" in res[upd[0]]:
     tot = res[upd[0]]["fetch"] + res[upd[0]]["write"]
+    import datetime
     (ROOT / "profiles/hbm_traffic.json").write_text(json.dumps({
+        "tag": tag, "date": datetime.date.today().isoformat(),
         "k_chol_update_bytes_per_launch": tot, "kernel": upd[0], "fetch_bytes_corrected_x2": res[upd[0]]["fetch"], "write_bytes": res[upd[0]]["write"],
         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1`, {tag}; "
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM"}))

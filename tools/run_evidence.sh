@@ -1,12 +1,27 @@
 #!/bin/bash
-# evidence pass: gpu tests, smoke, bench (with cpu baseline), rocprofv3 kernel stats, PMC passes
+# evidence pass: gpu tests, smoke, bench (with cpu baseline), rocprofv3 kernel stats, PMC passes, configs, schedules
+# usage (on the GPU box, from the repo root): bash tools/run_evidence.sh <tag>      -> gpurun_out/<tag>_*
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-cd $R
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/pytest_gpu.log; cat gpurun_out/pytest_gpu.log
+cd $R; mkdir -p gpurun_out
+(time python -m pytest tests -m gpu -q) > gpurun_out/${TAG}_pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/bench_n1.json; cut -c1-300 gpurun_out/bench_n1.json
+python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/${TAG}_bench_n1.json; cut -c1-300 gpurun_out/${TAG}_bench_n1.json
+python bench.py --particles 64 --no-cpu-baseline 2>>gpurun_out/bench.err | tail -1 > gpurun_out/${TAG}_bench_n1_P64_rank_share.json
+python tools/run_configs.py ${TAG} 2>&1 | grep -v amdgpu | tail -8
+FLOW_MODES=cols,flow_fused_pm python tools/gpu_flow_perf.py 2048x8 2048x16 2048x32 2048x64 2048x128 2048x256 2048x384 2048x512 1024x64 1024x128 512x256 4096x32 4096x128 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_flow_perf.txt; tail -3 gpurun_out/${TAG}_flow_perf.txt
+python tools/gpu_extend_perf.py ${TAG} 2>&1 | grep -v amdgpu | tail -4
+python tools/gpu_grad_perf.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_perf.txt; cat gpurun_out/${TAG}_grad_perf.txt
+(python tools/run_stream.py --rejuvenate; python tools/run_stream.py --rejuvenate --no-extend; python tools/run_stream.py --rejuvenate --predict) 2>&1 | grep -v amdgpu | grep "^{" > gpurun_out/${TAG}_stream.jsonl; cut -c1-200 gpurun_out/${TAG}_stream.jsonl
+(for T in 64 512; do tools/native/hmc_replay 2048 $T 2; done; tools/native/hmc_replay 512 256 4; tools/native/threads_bench 2048 512 8; tools/native/threads_bench 2048 64 8; tools/native/threads_bench 2048 512 4 grad) 2>&1 | grep "^{" > gpurun_out/${TAG}_native.jsonl; cut -c1-220 gpurun_out/${TAG}_native.jsonl
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof.log 2>&1
 cd $R
-python tools/rocprof_summary.py $(find gpurun_out/prof -name "*.db" | head -1) gpurun_out/bench_kernel_stats.txt --cmd "python bench.py --steps 5 --warmup 2 --no-cpu-baseline" | head -12
+python tools/rocprof_summary.py $(find gpurun_out/prof -name "*.db" | head -1) gpurun_out/${TAG}_bench_kernel_stats.txt --cmd "python bench.py --steps 5 --warmup 2 --no-cpu-baseline" | head -12
+cd /tmp
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof64 -o bench -- python $R/bench.py --particles 64 --steps 20 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof64.log 2>&1
+cd $R
+python tools/rocprof_summary.py $(find gpurun_out/prof64 -name "*.db" | head -1) gpurun_out/${TAG}_bench_P64_kernel_stats.txt --particles 64 --cmd "python bench.py --particles 64 --steps 20 --warmup 2 --no-cpu-baseline" | head -8
 bash tools/run_pmc.sh 2>&1 | tail -5
+python tools/pmc_summary.py ${TAG} > /dev/null 2>&1; cp profiles/${TAG}_pmc_summary.txt gpurun_out/ 2>/dev/null; cp profiles/hbm_traffic.json gpurun_out/${TAG}_hbm_traffic.json 2>/dev/null
+ls gpurun_out | grep ${TAG}
