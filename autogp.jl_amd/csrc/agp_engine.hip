@@ -140,6 +140,7 @@ struct agp_ctx {
   bool logdt_ok = false;
   int hybrid_blocks = 512;  // medium populations: switch to right-looking once a column has fewer workgroups; 0 = never; env AGP_HYBRID_BLOCKS
   int right_looking = -1;   // right-looking factorisation for small populations: -1 auto, 0, 1; env AGP_RIGHT_LOOKING
+  int stride_pad = 0;   // doubles added to a particle's matrix stride (multiple of 2: 16-byte tile accesses); env AGP_STRIDE_PAD
   int flow = -1;        // dataflow schedule (whole factorisation in one launch of persistent workgroups): -1 auto, 0, 1; env AGP_FLOW
   int flow_order = 1;   // queue order of a block column's sub-diagonal tiles: 0 tile-row-major, 1 particle-major; env AGP_FLOW_ORDER
   long long* d_flow_trace = nullptr;   // agp_debug_flow_trace: 4 x int64 per work item of the next dataflow sweep
@@ -794,7 +795,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     const int n_pad = round_up(n, NB);
     const int nt = n_pad / NB;
     const int ntiles = nt * (nt + 1) / 2;
-    const long long strideA = (long long)ntiles * NB2;
+    // Per-particle skew: with a stride of ntiles * 128 KiB every particle's tile (i,j) starts at the same address modulo
+    // 128 KiB, and the workgroups of a launch — one per particle, all reading the same tile offset at the same time —
+    // would queue on the same HBM channels.  stride_pad doubles shift each particle's matrix (env AGP_STRIDE_PAD).
+    const long long strideA = (long long)ntiles * NB2 + c->stride_pad;
     const int64_t bytes_pp = strideA * 8 * (go ? 2 : 1);      // + Z = L^-T for the gradient
     int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(P, ws_limit_bytes(c) / bytes_pp));
     // (the dataflow schedule has several block columns of a particle in flight: every column keeps its inverse blocks)
@@ -1123,8 +1127,9 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_INTRSM")) c->intrsm = atoi(e) != 0;
   if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_STREAMS")) c->n_streams = std::max(1, std::min(8, atoi(e)));
+  if (const char* e = getenv("AGP_STRIDE_PAD")) c->stride_pad = std::max(0, atoi(e)) & ~1;
   if (const char* e = getenv("AGP_FLOW")) c->flow = atoi(e);
-  if (const char* e = getenv("AGP_FLOW_ORDER")) c->flow_order = atoi(e) != 0;
+  if (const char* e = getenv("AGP_FLOW_ORDER")) c->flow_order = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("AGP_FLOW_FUSE")) c->flow_fuse = atoi(e) != 0;
   if (const char* e = getenv("AGP_EXTEND_FRAC")) c->store.max_frac = std::max(0.0, std::min(0.8, atof(e)));
   *out = c;

@@ -12,7 +12,8 @@ if len(sys.argv) > 1:
     cases = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
 modes = [("cols", {"AGP_FLOW": "0"}), ("flow", {"AGP_FLOW": "1"}), ("flow_pm", {"AGP_FLOW": "1", "AGP_FLOW_ORDER": "1"}),
          ("flow_fused", {"AGP_FLOW": "1", "AGP_FLOW_FUSE": "1", "AGP_FUSE": "1"}),
-         ("flow_fused_pm", {"AGP_FLOW": "1", "AGP_FLOW_FUSE": "1", "AGP_FUSE": "1", "AGP_FLOW_ORDER": "1"})]
+         ("flow_fused_pm", {"AGP_FLOW": "1", "AGP_FLOW_FUSE": "1", "AGP_FUSE": "1", "AGP_FLOW_ORDER": "1"}),
+         ("flow_la", {"AGP_FLOW": "1", "AGP_FLOW_ORDER": "2"})]
 if os.environ.get("FLOW_MODES"):
     modes = [m for m in modes if m[0] in os.environ["FLOW_MODES"].split(",")]
 out = {}

@@ -12,13 +12,19 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = {}
 
 
+import gc
+
+
 def sweep(nodes, noises, n, reps=5):
     progs = pkg.encode_batch(nodes)
+    gc.collect(); gc.disable()          # a generation-2 collection inside the timed calls showed up as a 15 ms outlier
     eng.logpdf_batch(None, noises, n=n, check=False, programs=progs)
     t0 = time.time()
     for _ in range(reps):
         lp, info = eng.logpdf_batch(None, noises, n=n, check=False, programs=progs)
-    return (time.time() - t0) / reps, lp, info
+    dt = (time.time() - t0) / reps
+    gc.enable()
+    return dt, lp, info
 
 
 def spot(nodes, noises, ts, xs, lp, info, k=2):
