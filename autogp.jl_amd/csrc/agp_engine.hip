@@ -760,7 +760,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   // (the log|dt|-table kernels exist for the in-kernel-solve factorisation launches, see launch_update)
   const bool ge_tab = c->logdt_ok && c->intrsm != 0;
   // (the schedule is chosen per call from P and n; chunked / multi-stream sub-batches re-check with their own size)
-  const bool flow_hint = !go && n > 0 && c->flow_fuse && use_flow(c, P, (int)((n + NB - 1) / NB));
+  const bool flow_hint = n > 0 && c->flow_fuse && use_flow(c, P, (int)((n + NB - 1) / NB));
   int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint);
   if (rc) return rc;
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
@@ -825,7 +825,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
     HIPCHK(c, s->info.ensure(sizeof(int) * (size_t)chunk));
     HIPCHK(c, s->ready.ensure(sizeof(int) * (size_t)chunk));
-    if (!go && c->intrsm && c->flow != 0) {
+    if (c->intrsm && c->flow != 0) {
       HIPCHK(c, s->tflag.ensure(sizeof(int) * (size_t)chunk * ntiles));
       HIPCHK(c, s->flowq.ensure(sizeof(int) * 8 * 8));
     }
@@ -933,7 +933,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         set_cov(ca, cv);
         ca.n_fused = nf;
         ca.ready = s->ready.as<int>() + g0;
-        if (!go && use_flow(c, ca.P, nt)) {
+        if (use_flow(c, ca.P, nt)) {      // (value and gradient sweeps alike: every block column keeps its inverse blocks)
           // dataflow schedule: every tile of the batch in ONE launch of persistent workgroups (2 per CU)
           const int ntri = nt * (nt + 1) / 2;
           ca.tflag = s->tflag.as<int>() + (size_t)g0 * ntri; ca.ntri = ntri;

@@ -596,6 +596,11 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
 }
 
 template <int MAXS>
+// Measured alternatives for this kernel (n=2048, 512 prior particles, 31 ms; PMC: VALU issue 31 % busy at 2 waves/SIMD,
+// SALU 0.42 per VALU instruction): 3 waves/SIMD (166 VGPRs) -2 %; 4 waves/SIMD (128 VGPRs, 48 spilled) +9 %; routing trees of
+// <= 16 nodes to the 16-slot-tape instantiation in a batch that also holds larger trees: no change; a register-resident
+// variant for trees of depth <= 3 (value stack + operand history + adjoint stack instead of the tape; 255 VGPRs + 98
+// AGPRs, one wave per SIMD) +6 %.  The cost is ~10 ms per tree node whatever the leaf kind (tools/gpu_grad_contract_probe.py).
 __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tix = blockIdx.x;

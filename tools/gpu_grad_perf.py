@@ -5,7 +5,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 import __graft_entry__ as g
 pkg = g.load_package(); eng = pkg.GPEngine(0)
-for n, P in ((256, 8), (1024, 64), (2048, 64), (2048, 512)):
+cases = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(256, 8), (1024, 64), (2048, 64), (2048, 512)]
+for n, P in cases:
     ts, xs = pkg.prior.synthetic_series(n, seed=n, shuffle=True)
     nodes, noises = pkg.prior.sample_particles(np.random.default_rng(n), P, max_depth=-1, max_size=63)
     progs = pkg.encode_batch(nodes); eng.set_data(ts, xs)
