@@ -2454,6 +2454,23 @@ int agp_allgather_logweights_device(agp_ctx* c, const double* d_local, int32_t P
   return AGP_OK;
 }
 
+// Test hook for the un-padding step of unequal shards (a one-GPU box can only form a one-rank communicator, where every
+// block is "equal"): `padded` holds n_ranks blocks of ceil(P / n_ranks) doubles as ncclAllGather would deliver them.
+int agp_debug_compact_shards(agp_ctx* c, const double* padded, int32_t P, int32_t n_ranks, double* out) {
+  if (!c || !padded || !out || P <= 0 || n_ranks <= 0) return fail(c, AGP_ERR_ARG, "bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int mx = (P + n_ranks - 1) / n_ranks;
+  double *d_in = nullptr, *d_out = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_in, sizeof(double) * (size_t)mx * n_ranks));
+  HIPCHK(c, hipMalloc((void**)&d_out, sizeof(double) * (size_t)P));
+  HIPCHK(c, hipMemcpy(d_in, padded, sizeof(double) * (size_t)mx * n_ranks, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_compact_shards, dim3((P + 255) / 256), dim3(256), 0, 0, d_in, mx, P, n_ranks, d_out);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpy(out, d_out, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost));
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return AGP_OK;
+}
+
 int agp_allgather_logweights(agp_ctx* c, double* inout_lw, int32_t P) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   if (P < 0 || (P > 0 && !inout_lw)) return fail(c, AGP_ERR_ARG, "bad arguments");

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "agp_set_workspace_limit", "agp_set_coalesce_window", "agp_get_coalesce_stats", "agp_get_dedup_stats",
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi",
-    "agp_debug_flow_trace", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
+    "agp_debug_flow_trace", "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
 ]
 COMM_ID_BYTES = 128
 
@@ -122,6 +122,7 @@ def load_library(path=None):
     lib.agp_logpdf_batch_extend.argtypes = [vp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, ip]
     lib.agp_logpdf_batch_extend.restype = C.c_int
     lib.agp_debug_flow_trace.argtypes = [vp, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]; lib.agp_debug_flow_trace.restype = C.c_int
+    lib.agp_debug_compact_shards.argtypes = [vp, dp, C.c_int32, C.c_int32, dp]; lib.agp_debug_compact_shards.restype = C.c_int
     lib.agp_extend_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_extend_stats.restype = C.c_int
     lib.agp_extend_reset.argtypes = [vp, C.c_int]; lib.agp_extend_reset.restype = C.c_int
     lib.agp_extend_reserve.argtypes = [vp, C.c_int64, C.c_int32]; lib.agp_extend_reserve.restype = C.c_int
@@ -412,6 +413,11 @@ class GPEngine:
             return None
         out = np.zeros((int(max_items), 4), dtype=np.int64)
         self._check(self._lib.agp_debug_flow_trace(self._ctx, 0, int(max_items), out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
+
+    def debug_compact_shards(self, padded, P, n_ranks):
+        padded = _f64(padded); out = np.empty(int(P))
+        self._check(self._lib.agp_debug_compact_shards(self._ctx, _dp(padded), int(P), int(n_ranks), _dp(out)))
         return out
 
     def set_profiling(self, on: bool):

@@ -241,6 +241,9 @@ int agp_debug_mfma_peak(agp_ctx* ctx, int32_t iters, int32_t wg_per_cu, double* 
  * builds (-DAGP_EXPERIMENTS, `python __graft_entry__.py --experiments`); the product library returns AGP_ERR_ARG. */
 int agp_debug_gemm_variant(agp_ctx* ctx, int32_t P, int32_t nt, int32_t k, int32_t variant, int32_t reps, double* out_ms);
 
+/* Test hook: the un-padding of unequal shards after the padded all-gather (`padded`: n_ranks blocks of ceil(P/n_ranks)). */
+int agp_debug_compact_shards(agp_ctx* ctx, const double* padded, int32_t P, int32_t n_ranks, double* out /* P */);
+
 /* Timeline of the dataflow factorisation schedule (one launch of persistent workgroups, medium populations):
  * enable != 0 allocates room for max_items work items (tiles) and records the following sweeps; enable == 0 copies
  * the records out — 4 int64 per item: start, end (100 MHz ticks), ticks spent waiting for operand tiles, and

@@ -197,6 +197,20 @@ def test_allgather_through_c_entry_single_rank(pkg):
         eng.close()
 
 
+def test_unequal_shards_are_unpadded_correctly(pkg, engine):
+    """Blocks of unequal length travel padded to the largest (ncclAllGather moves equal counts) and are compacted on
+    the device: the kernel against the host partition for every (P, R) shape class, incl. P < R."""
+    for P, R in ((11, 2), (13, 8), (512, 8), (257, 4), (5, 8), (1, 3), (1000, 7)):
+        mx = (P + R - 1) // R
+        padded = np.full(mx * R, np.nan)
+        want = np.arange(P, dtype=np.float64) + 0.5
+        for r in range(R):
+            lo, hi = pkg.shard_range(P, r, R)
+            assert (lo, hi) == pkg.dist.shard_range(P, r, R)
+            padded[r * mx: r * mx + (hi - lo)] = want[lo:hi]
+        assert np.array_equal(engine.debug_compact_shards(padded, P, R), want), (P, R)
+
+
 def test_multi_device_context_pool(pkg):
     """agp_init_multi + agp_logpdf_batch_multi with the devices this box has (one): the single-process deployment
     (one Julia process driving the node) returns the same values as the plain context."""
