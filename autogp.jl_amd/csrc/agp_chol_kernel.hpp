@@ -157,15 +157,16 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
 
   int bad = 0;           // first non-positive pivot (1-based global index), 0 = none
 
-  for (int jb = 0; jb < ((AGP_DBG_SKIP & 2) ? 0 : NSB); ++jb) {
-    // ---- (a) wave 0: 16x16 Cholesky of block (jb,jb) + its inverse, on lane broadcasts ----
-    if (w == 0 && !(AGP_DBG_SKIP & 16)) {
+  // 16x16 Cholesky of block (jb,jb) + its inverse on lane broadcasts, run by ONE wave.
+  // Lane r (= l15) holds row r of the block in s[] and column r of X in wv[] (X starts as I, ends as L^-1).
+  // Column c of L, once scaled, is broadcast lane by lane (v_readlane -> scalar pair); each scalar drives the
+  // trailing update of the block AND the forward substitution L X = I in the same step, so it is consumed at
+  // once (factoring first and inverting afterwards needs every broadcast twice, or parks 240 scalars in
+  // spill lanes).  This step is instruction-issue bound (one wave, 4 cycles per instruction).
+  auto factor16 = [&](int jb) {
+    if (AGP_DBG_SKIP & 16) return;
+
       double* blk = sm + blk_idx(jb, jb) * 256;
-      // Lane r (= l15) holds row r of the block in s[] and column r of X in wv[] (X starts as I, ends as L^-1).
-      // Column c of L, once scaled, is broadcast lane by lane (v_readlane -> scalar pair); each scalar drives the
-      // trailing update of the block AND the forward substitution L X = I in the same step, so it is consumed at
-      // once (factoring first and inverting afterwards needs every broadcast twice, or parks 240 scalars in
-      // spill lanes).  This step is instruction-issue bound (one wave, 4 cycles per instruction).
       double s[16], wv[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) { s[c] = blk[c * 16 + l15]; wv[c] = (c == l15) ? 1.0 : 0.0; }
@@ -198,9 +199,13 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
           Wg[l * 16 + r] = wv[r];
         }
       }
-    }
-    __syncthreads();
-
+      };
+  // Look-ahead inside the tile: while waves 1-3 apply block column jb to the trailing blocks, wave 0 applies it to the
+  // NEXT diagonal block only and factors that block at once — the wave-serial 16x16 step (the longest phase of an
+  // iteration) runs beside the MFMA updates instead of in front of them.
+  if (w == 0 && !(AGP_DBG_SKIP & 2)) factor16(0);
+  __syncthreads();
+  for (int jb = 0; jb < ((AGP_DBG_SKIP & 2) ? 0 : NSB); ++jb) {
     // ---- (b) panel: L(ib,jb) = S(ib,jb) W^T for ib > jb (MFMA); alpha_jb = W r_jb ----
     for (int ib = jb + 1 + w; ib < ((AGP_DBG_SKIP & 32) ? 0 : NSB); ib += 4) {
       double* blk = sm + blk_idx(ib, jb) * 256;
@@ -226,7 +231,8 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
     {
       const int nrem = NSB - 1 - jb;              // block rows below jb
       const int npair = nrem * (nrem + 1) / 2;
-      for (int e = w; e < ((AGP_DBG_SKIP & 64) ? 0 : npair); e += 4) {
+      // pair 0 is the next diagonal block (jb+1, jb+1): wave 0 takes it (and then factors it); waves 1-3 share the rest
+      for (int e = (w == 0 ? 0 : w); e < ((AGP_DBG_SKIP & 64) ? 0 : (w == 0 ? (npair > 0 ? 1 : 0) : npair)); e += 3) {
         int ii = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
         while (ii * (ii + 1) / 2 > e) --ii;
         while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
@@ -250,6 +256,7 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
         for (int q = 0; q < 16; ++q) t = fma(-lb[q * 16 + (tid & 15)], avec[jb * 16 + q], t);
         rvec[tid] = t;
       }
+      if (w == 0 && jb + 1 < NSB) factor16(jb + 1);      // (its block was brought up to date by this wave just above)
     }
     __syncthreads();
   }
