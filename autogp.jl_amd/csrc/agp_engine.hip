@@ -130,6 +130,7 @@ struct agp_ctx {
   // with two workgroups per CU) is not hidden by the co-resident workgroup's GEMM phase and would set the
   // duration of the short launches; such particles get their tiles from k_cov_tiles.  env AGP_FUSE_MAX_US
   double fuse_max_us = 35.0;
+  double flow_fuse_max_us = 70.0;   // the same limit under the dataflow schedule; env AGP_FLOW_FUSE_MAX_US
   int dedup = 1;        // evaluate identical particles of a host-output sweep once; env AGP_DEDUP
   int64_t n_particles_seen = 0, n_particles_run = 0;
   int trtri_chain = 1;  // Z = L^-T as independent per-row chains in one launch (0: one launch per block column); env AGP_TRTRI_CHAIN
@@ -441,7 +442,10 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   // first inside every launch); particles whose tiles are prebuilt go last.
   // (fuse_hint: the caller will run the dataflow schedule, which evaluates tiles in-kernel whatever the batch size)
   const bool fuse_on = c->fuse_mode == 1 || (c->fuse_mode < 0 && (P >= 256 || fuse_hint));
-  auto fusable = [&](int p) { return fuse_on && cost[p] <= c->fuse_max_us && cps[p].n_cp <= U_MAX_CP; };
+  // (the dataflow schedule has no launch tail for a long evaluation to hold up: its limit is higher — measured 35 / 70 /
+  // 150 / 1000 us: config 2 0.99 / 0.92 / 0.92 / 0.91 ms, 2048 x 64 4.47 / 4.45 / 4.61 / 4.62 ms, config 4 62.9 / 61.9 / 63.6 / 63.6 ms)
+  const double fuse_limit = fuse_hint ? std::max(c->fuse_max_us, c->flow_fuse_max_us) : c->fuse_max_us;
+  auto fusable = [&](int p) { return fuse_on && cost[p] <= fuse_limit && cps[p].n_cp <= U_MAX_CP; };
   bt.order.resize(P);
   for (int p = 0; p < P; ++p) bt.order[p] = p;
   std::stable_sort(bt.order.begin(), bt.order.end(), [&](int a, int b) {
@@ -1122,7 +1126,8 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_RIGHT_LOOKING")) c->right_looking = atoi(e);
   if (const char* e = getenv("AGP_HYBRID_BLOCKS")) c->hybrid_blocks = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
-  if (const char* e = getenv("AGP_FUSE_MAX_US")) c->fuse_max_us = atof(e);
+  if (const char* e = getenv("AGP_FUSE_MAX_US")) { c->fuse_max_us = atof(e); c->flow_fuse_max_us = std::min(c->flow_fuse_max_us, c->fuse_max_us); }
+  if (const char* e = getenv("AGP_FLOW_FUSE_MAX_US")) c->flow_fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
   if (const char* e = getenv("AGP_INTRSM")) c->intrsm = atoi(e) != 0;
   if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));

@@ -250,6 +250,11 @@ def main():
             diag_block = {"kernel": "k_chol_diag<DCOV,TAB>", "achieved": dg_ach, "frac": dg_ach / PEAK_FP64_MFMA_TFLOPS,
                           "avg_launch_ms": dg_ms, "launches_per_step": n_dg / args.steps, "ms_per_step": acc["chol_trsm_ms"] / args.steps,
                           "algorithmic_flops_per_launch": dg_flops}
+        elif round(n_upd / args.steps) == 1:
+            # dataflow schedule (default up to 448 particles per rank): the whole factorisation — diagonal factorisations,
+            # updates, panel solves, in-kernel tile evaluation — is ONE launch of persistent workgroups
+            kernel_name = "k_chol_flow<DCOV,TAB> (dataflow schedule: every tile of the sweep in one launch)"
+            upd_flops_launch = P * cholesky_flops(n)
         else:
             kernel_name = "k_chol_update (every update-kernel launch of the sweep: mixed left-looking columns, catch-up, right-looking)"
             upd_flops_launch = P * (cholesky_flops(n) - nt * NB ** 3 / 3.0) / (n_upd / args.steps)
