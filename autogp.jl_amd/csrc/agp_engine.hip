@@ -123,6 +123,7 @@ struct agp_ctx {
   size_t total_mem = 0;
   int n_cu = 256;
   bool profiling = false;
+  int grad_lds_tape = 1;   // 1: trees of <= 8 nodes keep the contraction's tape in LDS; env AGP_GRAD_LDS_TAPE
   int grad_split = 1;   // 1: K^-1 tiles to memory + lean contraction kernel; 0: fused tile kernel (env AGP_GRAD_SPLIT)
   int intrsm = 1;       // 1: triangular solve inside k_chol_update (one launch per block column); env AGP_INTRSM
   int n_streams = 1;    // sub-batches of one call run on this many streams (env AGP_STREAMS)
@@ -1002,8 +1003,25 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           if (c->grad_split) {
             hipLaunchKernelGGL(k_kinv_tiles, dim3(ntiles, Pg), dim3(256), 0, q, ga);
             const size_t lds2 = sizeof(double) * (256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes + 8);
-            if (max_nodes <= 16) HIPCHK(c, launch_grad_contract<16>(q, ga, ntiles, Pg, lds2));
-            else HIPCHK(c, launch_grad_contract<64>(q, ga, ntiles, Pg, lds2));
+            // three classes by tree size (the particle list is sorted by it): > 16 nodes and 9 .. 16 nodes keep their tape
+            // in private memory, trees of <= 8 nodes — the bulk of a prior-sampled population — keep it in LDS
+            int n_big = 0, n_mid = 0;
+            for (int r = 0; r < Pg; ++r) {
+              const int no = bt.ghdr[p0 + g0 + pl[r]].n_ops;
+              n_big += no > 16; n_mid += (no <= 16 && (no > LDS_TAPE_NODES || !c->grad_lds_tape));
+            }
+            const int n_small = Pg - n_big - n_mid;
+            GradArgs gs = ga;
+            if (n_big > 0) HIPCHK(c, launch_grad_contract<64>(q, gs, ntiles, n_big, lds2));
+            gs.plist = d_pl + n_big;
+            if (n_mid > 0) HIPCHK(c, launch_grad_contract<16>(q, gs, ntiles, n_mid, lds2));
+            if (n_small > 0) {
+              gs.plist = d_pl + n_big + n_mid;
+              gs.tape_off = (int)((lds2 + 15) / 16 * 2);                                  // doubles, 16-byte aligned
+              const size_t lds3 = (size_t)gs.tape_off * 8 + sizeof(double) * LDS_TAPE_NODES * 4 * 256;
+              HIPCHK(c, launch_grad_contract<0>(q, gs, ntiles, n_small, lds3));
+            }
+            (void)max_nodes;
           } else {
             if (max_nodes <= 16) HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, Pg, lds));
             else HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, Pg, lds));
@@ -1101,6 +1119,7 @@ int agp_init(agp_ctx** out, int device_id) {
     // raise the dynamic-LDS ceiling of the table-carrying kernels once (launches then never touch function attributes)
     const void* fns[] = {reinterpret_cast<const void*>(&k_cov_tiles<4>), reinterpret_cast<const void*>(&k_cov_tiles<8>),
                          reinterpret_cast<const void*>(&k_grad_contract<16>), reinterpret_cast<const void*>(&k_grad_contract<64>),
+                         reinterpret_cast<const void*>(&k_grad_contract<0>),
                          reinterpret_cast<const void*>(&k_grad_tiles<16>), reinterpret_cast<const void*>(&k_grad_tiles<64>)};
     for (const void* f : fns) {
       hipFuncAttributes fa;
@@ -1129,6 +1148,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_FUSE_MAX_US")) { c->fuse_max_us = atof(e); c->flow_fuse_max_us = std::min(c->flow_fuse_max_us, c->fuse_max_us); }
   if (const char* e = getenv("AGP_FLOW_FUSE_MAX_US")) c->flow_fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
+  if (const char* e = getenv("AGP_GRAD_LDS_TAPE")) c->grad_lds_tape = atoi(e) != 0;
   if (const char* e = getenv("AGP_INTRSM")) c->intrsm = atoi(e) != 0;
   if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_STREAMS")) c->n_streams = std::max(1, std::min(8, atoi(e)));

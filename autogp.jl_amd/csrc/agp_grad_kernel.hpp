@@ -18,6 +18,7 @@
 //                    element accumulates G_ab dK_ab/dtheta; per-tile partial sums go to a small buffer
 //   k_grad_finish    fixed-order sum over tiles (deterministic), scatter to the caller's parameter order
 #pragma once
+#include <type_traits>
 #include "agp_chol_kernel.hpp"
 
 namespace agp {
@@ -143,6 +144,7 @@ struct GradArgs {
   const int32_t* out_off;   // [P] offset of the particle's gradient block in out_grad (caller order, via map)
   const int32_t* pmap;   // sorted particle -> caller particle
   const int32_t* plist;  // k_grad_tiles: particles of this launch (indices into the sorted group)
+  int tape_off;          // k_grad_contract<0>: offset (doubles) of the LDS tape inside the dynamic shared memory
   double* out_grad;
   double* out_gnoise;
 };
@@ -284,43 +286,95 @@ __global__ __launch_bounds__(256) void k_alpha(GradArgs a) {
 // needs its children's values, never its own; a stationary leaf is handed adjoint x value so that it does not
 // evaluate its exponential again).  gacc: per parameter slot accumulator.
 // The E elements share one walk over the program, so their memory latencies overlap.
+// Node values / adjoints of the tape variant of the contraction.  RegTape: a private array (dynamic node indices put it in
+// scratch memory; any tree size).  LdsTape: one column of a [node][element][thread] array in LDS (trees of <= LDS_TAPE_NODES
+// nodes): the backward sweep is a chain of dependent tape round trips per node, ~60 cycles each in LDS instead of a
+// global-memory round trip (measured: ~6 ms per tree node and 512-particle sweep at n=2048 with the scratch tape).
+constexpr int LDS_TAPE_NODES = 8;
 template <int MAXS, int E>
+struct RegTape {
+  double v[MAXS][E];
+  __device__ __forceinline__ double get(int i, int e) const { return v[i][e]; }
+  __device__ __forceinline__ void set(int i, int e, double x) { v[i][e] = x; }
+};
+template <int E>
+struct LdsTape {
+  double* base;      // this thread's column: element (i, e) at base[(i * E + e) * 256]
+  __device__ __forceinline__ double get(int i, int e) const { return base[(i * E + e) * 256]; }
+  __device__ __forceinline__ void set(int i, int e, double x) { base[(i * E + e) * 256] = x; }
+};
+
+// Per-parameter gradient accumulators of one thread: an array indexed by parameter offset (private memory).  (Register
+// accumulators selected by the leaf's ordinal were measured for the LDS-tape variant: no gain — the accumulator updates are
+// not on the critical path, the tape round trips were.)
+template <int N>
+struct ScratchAcc {
+  double (&g)[N];
+  __device__ __forceinline__ void leaf(int po, int, double g0, double g1, double g2) { g[po] += g0; g[po + 1] += g1; g[po + 2] += g2; }
+  __device__ __forceinline__ void cp(int po, int, double g0, double g1) { g[po] += g0; g[po + 1] += g1; }
+};
+template <int MAXS, int E, class TapeT, class AccT>
 __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* ops, const uint8_t* lc, const uint8_t* rc,
                                               const uint8_t* mv, const int32_t* poff, const double* prm, const double* sig,
                                               const int (&ri)[E], const int (&ci)[E], const double (&ta)[E],
                                               const double (&tb)[E], const double (&wgt)[E],
                                               const double (&lt)[E], bool use_tab,
-                                              double (&tape)[MAXS][E], double (&gacc)[3 * MAXS + 2]) {
+                                              TapeT& tape, AccT& acc) {
   const double PI = 3.14159265358979323846;
   // ---------------- forward: node values ----------------
-  int cpi = 0;
+  int cpi = 0, nl = 0, nb = 0;      // ChangePoint tables / leaves / binary nodes seen so far (wave-uniform)
   for (int ip = 0; ip < h.n_ops; ++ip) {
     const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
     const double* q = prm + poff[ip];
     const double q0 = q[0], q1 = q[1], q2 = q[2];
     const int il = lc[ip], ir = rc[ip];
     const double lgl = (use_tab && o == OP_GE) ? fm::log_f(q0) : 0.0;      // once per node visit, not per element
+    if (o <= OP_PER) ++nl; else ++nb;
+    // (the opcode dispatch stays OUTSIDE the element loops: each branch is one basic block in which the E independent
+    // evaluation chains interleave)
+    double v[E];
+    if (o == OP_WN) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      double v;
-      if (o == OP_WN) v = (ta[e] == tb[e]) ? q0 : 0.0;
-      else if (o == OP_CONST) v = q0;
-      else if (o == OP_LIN) v = q1 + q2 * ((ta[e] - q0) * (tb[e] - q0));
-      else if (o == OP_SE) { const double d = ta[e] - tb[e]; v = q1 * fm::exp_f(-0.5 * d * d / (q0 * q0)); }
-      else if (o == OP_GE) {
-        // with the data set's log|dt| table (lt): (|dt|/l)^g = exp(g (log|dt| - log l)), no per-element log
-        const double ug = use_tab ? fm::exp_f(q1 * (lt[e] - lgl)) : fm::pow_f(fabs(ta[e] - tb[e]) / q0, q1);
-        v = q2 * fm::exp_f(-ug);
+      for (int e = 0; e < E; ++e) v[e] = (ta[e] == tb[e]) ? q0 : 0.0;
+    } else if (o == OP_CONST) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = q0;
+    } else if (o == OP_LIN) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = q1 + q2 * ((ta[e] - q0) * (tb[e] - q0));
+    } else if (o == OP_SE) {
+      const double c2 = -0.5 / (q0 * q0);
+#pragma unroll
+      for (int e = 0; e < E; ++e) { const double d = ta[e] - tb[e]; v[e] = q1 * fm::exp_f((d * d) * c2); }
+    } else if (o == OP_GE) {
+      // with the data set's log|dt| table (lt): (|dt|/l)^g = exp(g (log|dt| - log l)), no per-element log
+      if (use_tab) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = q2 * fm::exp_f(-fm::exp_f(q1 * (lt[e] - lgl)));
+      } else {
+        const double rl = 1.0 / q0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = q2 * fm::exp_f(-fm::pow_f(fabs(ta[e] - tb[e]) * rl, q1));
       }
-      else if (o == OP_PER) v = q2 * fm::exp_f(-2.0 * fm::sin2_f(PI / q1 * fabs(ta[e] - tb[e])) / (q0 * q0));
-      else if (o == OP_PLUS) v = tape[il][e] + tape[ir][e];
-      else if (o == OP_TIMES) v = tape[il][e] * tape[ir][e];
-      else {   // OP_CP (children by true left / right index)
+    } else if (o == OP_PER) {
+      const double wq = PI / q1, c2 = -2.0 / (q0 * q0);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = q2 * fm::exp_f(c2 * fm::sin2_f(wq * fabs(ta[e] - tb[e])));
+    } else if (o == OP_PLUS) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = tape.get(il, e) + tape.get(ir, e);
+    } else if (o == OP_TIMES) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = tape.get(il, e) * tape.get(ir, e);
+    } else {   // OP_CP (children by true left / right index)
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
         const double sa = sig[cpi * 256 + ri[e]], sb = sig[cpi * 256 + ci[e]];
-        v = (sa * sb) * tape[il][e] + ((1.0 - sa) * (1.0 - sb)) * tape[ir][e];
+        v[e] = (sa * sb) * tape.get(il, e) + ((1.0 - sa) * (1.0 - sb)) * tape.get(ir, e);
       }
-      tape[ip][e] = v;
     }
+#pragma unroll
+    for (int e = 0; e < E; ++e) tape.set(ip, e, v[e]);
     if (o == OP_CP) ++cpi;
   }
   // ---------------- backward: adjoints replace values top-down ----------------
@@ -331,7 +385,7 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
     const int root = h.n_ops - 1;
     const bool m = __builtin_amdgcn_readfirstlane((int)mv[root]) != 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) tape[root][e] = m ? wgt[e] * tape[root][e] : wgt[e];
+    for (int e = 0; e < E; ++e) tape.set(root, e, m ? wgt[e] * tape.get(root, e) : wgt[e]);
   }
   for (int ip = h.n_ops - 1; ip >= 0; --ip) {
     const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
@@ -342,17 +396,18 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
     const bool m = __builtin_amdgcn_readfirstlane((int)mv[ip]) != 0;
     if (o == OP_CP) --cpi;
     double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+    if (o <= OP_PER) --nl; else --nb;          // forward ordinal of this node among the leaves / binary nodes
     if (o <= OP_PER) {
       if (o == OP_WN) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) g0 += (ta[e] == tb[e]) ? tape[ip][e] : 0.0;
+        for (int e = 0; e < E; ++e) g0 += (ta[e] == tb[e]) ? tape.get(ip, e) : 0.0;
       } else if (o == OP_CONST) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) g0 += tape[ip][e];
+        for (int e = 0; e < E; ++e) g0 += tape.get(ip, e);
       } else if (o == OP_LIN) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          const double ad = tape[ip][e];
+          const double ad = tape.get(ip, e);
           g0 += ad * (-q2 * (ta[e] + tb[e] - 2.0 * q0));
           g1 += ad;
           g2 += ad * ((ta[e] - q0) * (tb[e] - q0));
@@ -361,7 +416,7 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
         if (m) {
 #pragma unroll
           for (int e = 0; e < E; ++e) {
-            const double sv = tape[ip][e], d = ta[e] - tb[e];
+            const double sv = tape.get(ip, e), d = ta[e] - tb[e];
             g0 += sv * (d * d);
             g1 += sv;
           }
@@ -370,7 +425,7 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
         } else {
 #pragma unroll
           for (int e = 0; e < E; ++e) {
-            const double ad = tape[ip][e], d = ta[e] - tb[e], d2 = d * d;
+            const double ad = tape.get(ip, e), d = ta[e] - tb[e], d2 = d * d;
             const double ex = fm::exp_f(-0.5 * d2 / (q0 * q0));
             g0 += ad * q1 * ex * d2 / (q0 * q0 * q0);
             g1 += ad * ex;
@@ -390,7 +445,7 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
             lu = fm::log_f(u > 0.0 ? u : 1.0);                       // u^g ln u -> 0 at u = 0
             ug = u > 0.0 ? fm::exp_f(q1 * lu) : 0.0;
           }
-          const double sv = m ? tape[ip][e] : tape[ip][e] * fm::exp_f(-ug);   // adjoint * amp * exp  |  adjoint * exp
+          const double sv = m ? tape.get(ip, e) : tape.get(ip, e) * fm::exp_f(-ug);   // adjoint * amp * exp  |  adjoint * exp
           g0 += sv * ug;
           g1 -= sv * (ug * lu);
           g2 += sv;
@@ -404,7 +459,7 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
           const double dd = fabs(ta[e] - tb[e]);
           double sn, cs;
           fm::sincos_pi_f(wq * dd, &sn, &cs);
-          const double sv = m ? tape[ip][e] : tape[ip][e] * fm::exp_f(-2.0 * sn * sn / l2);
+          const double sv = m ? tape.get(ip, e) : tape.get(ip, e) * fm::exp_f(-2.0 * sn * sn / l2);
           g0 += sv * (sn * sn);
           g1 += sv * (sn * cs * dd);
           g2 += sv;
@@ -413,40 +468,40 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
         if (m) { g0 *= f0; g1 *= f1; g2 *= 1.0 / q2; }
         else { g0 *= q2 * f0; g1 *= q2 * f1; }
       }
-      gacc[po] += g0; gacc[po + 1] += g1; gacc[po + 2] += g2;
+      acc.leaf(po, nl, g0, g1, g2);
     } else {
       const bool ml = __builtin_amdgcn_readfirstlane((int)mv[il]) != 0, mr = __builtin_amdgcn_readfirstlane((int)mv[ir]) != 0;
       if (o == OP_PLUS) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          const double ad = tape[ip][e];
-          tape[il][e] = ml ? ad * tape[il][e] : ad;
-          tape[ir][e] = mr ? ad * tape[ir][e] : ad;
+          const double ad = tape.get(ip, e);
+          tape.set(il, e, ml ? ad * tape.get(il, e) : ad);
+          tape.set(ir, e, mr ? ad * tape.get(ir, e) : ad);
         }
       } else if (o == OP_TIMES) {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          const double ad = tape[ip][e], kl = tape[il][e], kr = tape[ir][e];
+          const double ad = tape.get(ip, e), kl = tape.get(il, e), kr = tape.get(ir, e);
           const double al_ = ad * kr, ar_ = ad * kl;
-          tape[il][e] = ml ? al_ * kl : al_;
-          tape[ir][e] = mr ? ar_ * kr : ar_;
+          tape.set(il, e, ml ? al_ * kl : al_);
+          tape.set(ir, e, mr ? ar_ * kr : ar_);
         }
       } else {   // OP_CP: q = {location, scale}
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-          const double ad = tape[ip][e];
+          const double ad = tape.get(ip, e);
           const double x1 = sig[cpi * 256 + ri[e]], x2 = sig[cpi * 256 + ci[e]];
-          const double kl = tape[il][e], kr = tape[ir][e];
+          const double kl = tape.get(il, e), kr = tape.get(ir, e);
           const double al_ = ad * (x1 * x2), ar_ = ad * ((1.0 - x1) * (1.0 - x2));
-          tape[il][e] = ml ? al_ * kl : al_;
-          tape[ir][e] = mr ? ar_ * kr : ar_;
+          tape.set(il, e, ml ? al_ * kl : al_);
+          tape.set(ir, e, mr ? ar_ * kr : ar_);
           // d sigma / d loc = 2 sigma (1 - sigma) / scale;  d sigma / d scale = -(loc - t)/scale * that
           const double da = 2.0 * x1 * (1.0 - x1) / q1, db = 2.0 * x2 * (1.0 - x2) / q1;
           g0 += ad * ((da * x2 + x1 * db) * kl - (da * (1.0 - x2) + (1.0 - x1) * db) * kr);
           const double das = -da * (q0 - ta[e]) / q1, dbs = -db * (q0 - tb[e]) / q1;
           g1 += ad * ((das * x2 + x1 * dbs) * kl - (das * (1.0 - x2) + (1.0 - x1) * dbs) * kr);
         }
-        gacc[po] += g0; gacc[po + 1] += g1;
+        acc.cp(po, nb, g0, g1);
       }
     }
   }
@@ -514,7 +569,9 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
     __syncthreads();
   }
   constexpr int E = 4;     // elements walked in lockstep
-  double tape[MAXS][E], gacc[3 * MAXS + 2];
+  RegTape<MAXS, E> tape;
+  double gacc[3 * MAXS + 2];
+  ScratchAcc<3 * MAXS + 2> sacc{gacc};
   for (int q = 0; q <= h.n_prm + 2; ++q) gacc[q] = 0.0;     // (+2: leaves add three slots unconditionally)
   const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
   const double wfac = (ti == tj) ? 1.0 : 2.0;
@@ -549,7 +606,7 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
         if (ga == gb) gnoise += G;                       // d/d noise = tr G
         ri[e] = rslot; ci[e] = NB + cslot; ta[e] = tpt[rslot]; tb[e] = tpt[NB + cslot]; wg[e] = wfac * G;
       }
-      grad_elements<MAXS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, lt, use_tab, tape, gacc);
+      grad_elements<MAXS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, lt, use_tab, tape, sacc);
     }
   }
   gacc[h.n_prm] = gnoise;       // overwrites whatever the unconditional three-slot adds left there
@@ -596,11 +653,14 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
 }
 
 template <int MAXS>
-// Measured alternatives for this kernel (n=2048, 512 prior particles, 31 ms; PMC: VALU issue 31 % busy at 2 waves/SIMD,
-// SALU 0.42 per VALU instruction): 3 waves/SIMD (166 VGPRs) -2 %; 4 waves/SIMD (128 VGPRs, 48 spilled) +9 %; routing trees of
-// <= 16 nodes to the 16-slot-tape instantiation in a batch that also holds larger trees: no change; a register-resident
-// variant for trees of depth <= 3 (value stack + operand history + adjoint stack instead of the tape; 255 VGPRs + 98
-// AGPRs, one wave per SIMD) +6 %.  The cost is ~10 ms per tree node whatever the leaf kind (tools/gpu_grad_contract_probe.py).
+// History of this kernel (n=2048, 512 prior particles): 31 ms in round 1.  PMC then: VALU issue 31 % busy at 2 waves/SIMD — not
+// throughput.  What it waited on: (1) the K^-1 / alpha / log|dt| loads of every element group, exposed 16 times per tile
+// (now fetched one group ahead); (2) the tape: node values and adjoints in private memory, a dependent global-memory round
+// trip per tree node in the backward sweep — ~6 ms per node of the tree and sweep, whatever the leaf kind
+// (tools/gpu_grad_contract_probe.py); trees of <= 8 nodes (every tree of depth <= 3) now keep it in LDS (instantiation
+// MAXS = 0; AGP_GRAD_LDS_TAPE=0 restores the private tape).  Together 31 -> ~20 ms.  Measured and dropped: 3 / 4 waves per
+// SIMD by register cap (-2 % / +9 %), a fully register-resident variant (value stack + operand history + adjoint stack;
+// 353 registers, one wave per SIMD: +6 %), register accumulators instead of the private gacc[] (no change).
 __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tix = blockIdx.x;
@@ -645,7 +705,12 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
     __syncthreads();
   }
   constexpr int E = 4;
-  double tape[MAXS][E], gacc[3 * MAXS + 2];
+  // MAXS == 0: trees of <= LDS_TAPE_NODES nodes, tape in LDS behind the program tables (a.tape_off doubles into smem)
+  constexpr int GS = MAXS > 0 ? MAXS : LDS_TAPE_NODES;
+  typename std::conditional<(MAXS > 0), RegTape<(MAXS > 0 ? MAXS : 1), E>, LdsTape<E>>::type tape;
+  if constexpr (MAXS == 0) tape.base = smem + a.tape_off + tid;
+  double gacc[3 * GS + 2];
+  ScratchAcc<3 * GS + 2> sacc{gacc};
   for (int q = 0; q <= h.n_prm + 2; ++q) gacc[q] = 0.0;
   const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
   const double* __restrict__ Kt = a.A + (long long)p * a.strideA + tile_off(ti, tj);
@@ -657,6 +722,21 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
   const double ar = ga < a.n ? al[ga] : 0.0;
   const bool use_tab = a.logdt != nullptr && (h.flags & 1) != 0;
   const double* __restrict__ ltile = a.logdt + tile_off(ti, tj);       // only dereferenced when use_tab
+  // The K^-1 / alpha / log|dt| values of the NEXT group of E elements travel while the current group is differentiated:
+  // with two waves per SIMD an exposed global load per group was the floor of this kernel (a one-node program cost as
+  // much as its loads' latency, 16 times per tile).
+  double kin[E], alb[E], ltn[E];
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int cslot = chalf + c0 + e;
+      const int gb = tj * NB + cslot;
+      kin[e] = Kt[cslot * NB + rslot];
+      alb[e] = gb < a.n ? al[gb] : 0.0;
+      ltn[e] = use_tab ? ltile[cslot * NB + rslot] : 0.0;
+    }
+  };
+  fetch(0);
 #pragma unroll 1
   for (int c0 = 0; c0 < 64; c0 += E) {
     int ri[E], ci[E];
@@ -666,13 +746,13 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
       const int cslot = chalf + c0 + e;
       const int gb = tj * NB + cslot;
       const bool valid = ga < a.n && gb < a.n;
-      const double kinv = Kt[cslot * NB + rslot];
-      const double G = valid ? 0.5 * (ar * al[valid ? gb : 0] - kinv) : 0.0;
+      const double G = valid ? 0.5 * (ar * alb[e] - kin[e]) : 0.0;
       if (ga == gb) gnoise += G;
       ri[e] = rslot; ci[e] = NB + cslot; ta[e] = tpt[rslot]; tb[e] = tpt[NB + cslot]; wg[e] = wfac * G;
-      lt[e] = use_tab ? ltile[cslot * NB + rslot] : 0.0;
+      lt[e] = ltn[e];
     }
-    grad_elements<MAXS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, lt, use_tab, tape, gacc);
+    if (c0 + E < 64) fetch(c0 + E);
+    grad_elements<GS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, lt, use_tab, tape, sacc);
   }
   gacc[h.n_prm] = gnoise;
   __syncthreads();

@@ -254,7 +254,7 @@ def test_gamma_exponential_table_path(pkg, engine, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"AGP_INTRSM": "0"}, {"AGP_SPLIT_DIAG": "0"}, {"AGP_SPLIT_DIAG": "1"}, {"AGP_FUSE": "0"},
                                  {"AGP_FUSE": "1", "AGP_FUSE_MAX_US": "1000"}, {"AGP_STREAMS": "2"},
-                                 {"AGP_GRAD_SPLIT": "0"}, {"AGP_TRTRI_CHAIN": "0"}, {"AGP_DEDUP": "0", "AGP_GE_TABLE": "0"},
+                                 {"AGP_GRAD_SPLIT": "0"}, {"AGP_TRTRI_CHAIN": "0"}, {"AGP_GRAD_LDS_TAPE": "0"}, {"AGP_DEDUP": "0", "AGP_GE_TABLE": "0"},
                                  {"AGP_RIGHT_LOOKING": "0"}, {"AGP_RIGHT_LOOKING": "1"}, {"AGP_HYBRID_BLOCKS": "0"},
                                  {"AGP_SPLIT_DIAG": "0", "AGP_RIGHT_LOOKING": "0", "AGP_HYBRID_BLOCKS": "100000"},
                                  {"AGP_FLOW": "0"}, {"AGP_FLOW": "1"}, {"AGP_FLOW": "1", "AGP_FLOW_ORDER": "0"},
