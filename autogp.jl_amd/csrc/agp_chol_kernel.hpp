@@ -372,17 +372,25 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     // the same 128 KiB tile); the loads are issued at the top of the pass and consumed by the first such leaf
     const bool use_tab = TAB && (h.flags & 1) != 0;
     const double* __restrict__ ltile = a.logdt + tile_off(ti, tk);      // only dereferenced when use_tab
+    // (the table values of the NEXT pass travel while this one is evaluated: with two waves per SIMD an exposed load per
+    // pass made a table-reading GammaExp leaf half again as expensive as a Periodic one of the same instruction count)
+    double ltn[4] = {0.0, 0.0, 0.0, 0.0};
+    auto fetch_lt = [&](int t) {
+      const int cbn = t >> 1, rsn = (t & 1) ? row1 : row0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ltn[r] = ltile[(cbn * 16 + 4 * r + lq) * NB + rsn];
+    };
+    if (use_tab) fetch_lt(0);
 #pragma unroll 1
     for (int t = 0; t < 16; ++t) {
       const int cb = t >> 1, st = t & 1;
       const int rslot = st ? row1 : row0;
       double tr[4], tc[4], out[4];
-      double lt[4] = {0.0, 0.0, 0.0, 0.0};
+      double lt[4];
       int ri[4], ci[4];
-      if (use_tab) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lt[r] = ltile[(cb * 16 + 4 * r + lq) * NB + rslot];
-      }
+      for (int r = 0; r < 4; ++r) lt[r] = ltn[r];
+      if (use_tab && t + 1 < 16) fetch_lt(t + 1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int cslot = cb * 16 + 4 * r + lq;
@@ -751,18 +759,25 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
     const double noise = a.noise[p];
     const bool use_tab = TAB && (h.flags & 1) != 0;
     const double* __restrict__ ltile = a.logdt + tile_off(tk, tk);      // only dereferenced when use_tab
+    double ltn[4] = {0.0, 0.0, 0.0, 0.0};          // table values, fetched one pass ahead (see chol_tile)
+    auto fetch_lt = [&](int e) {
+      const bool s1n = e > wu;
+      const int cbn = s1n ? e - (wu + 1) : e, rsn = s1n ? row1 : row0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ltn[r] = ltile[(cbn * 16 + 4 * r + lq) * NB + rsn];
+    };
+    if (use_tab) fetch_lt(0);
 #pragma unroll 1
     for (int e = 0; e < NE; ++e) {
       const bool s1 = e > wu;
       const int cb = s1 ? e - (wu + 1) : e;
       const int rslot = s1 ? row1 : row0;
       double tr[4], tc[4], out[4];
-      double lt[4] = {0.0, 0.0, 0.0, 0.0};
+      double lt[4];
       int ri[4], ci[4];
-      if (use_tab) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) lt[r] = ltile[(cb * 16 + 4 * r + lq) * NB + rslot];
-      }
+      for (int r = 0; r < 4; ++r) lt[r] = ltn[r];
+      if (use_tab && e + 1 < NE) fetch_lt(e + 1);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int cslot = cb * 16 + 4 * r + lq;
