@@ -426,7 +426,7 @@ int emit_grad(const std::vector<CNode>& nodes, int id, Batch& bt, int prm_base, 
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                   const double* prm, Batch& bt, bool allow_sel = false, bool want_grad = false, bool ge_tab = false,
-                  bool fuse_hint = false) {
+                  bool fuse_hint = false, bool flow_limit = false) {
   std::vector<Compiled> cps(P);
   std::vector<double> cost(P, 0.0);
   for (int p = 0; p < P; ++p) {
@@ -445,7 +445,7 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   const bool fuse_on = c->fuse_mode == 1 || (c->fuse_mode < 0 && (P >= 256 || fuse_hint));
   // (the dataflow schedule has no launch tail for a long evaluation to hold up: its limit is higher — measured 35 / 70 /
   // 150 / 1000 us: config 2 0.99 / 0.92 / 0.92 / 0.91 ms, 2048 x 64 4.47 / 4.45 / 4.61 / 4.62 ms, config 4 62.9 / 61.9 / 63.6 / 63.6 ms)
-  const double fuse_limit = fuse_hint ? std::max(c->fuse_max_us, c->flow_fuse_max_us) : c->fuse_max_us;
+  const double fuse_limit = flow_limit ? std::max(c->fuse_max_us, c->flow_fuse_max_us) : c->fuse_max_us;
   auto fusable = [&](int p) { return fuse_on && cost[p] <= fuse_limit && cps[p].n_cp <= U_MAX_CP; };
   bt.order.resize(P);
   for (int p = 0; p < P; ++p) bt.order[p] = p;
@@ -766,7 +766,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   const bool ge_tab = c->logdt_ok && c->intrsm != 0;
   // (the schedule is chosen per call from P and n; chunked / multi-stream sub-batches re-check with their own size)
   const bool flow_hint = n > 0 && c->flow_fuse && use_flow(c, P, (int)((n + NB - 1) / NB));
-  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint);
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint);
   if (rc) return rc;
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
   const int n_prm_total = prm_off[P];
@@ -2175,7 +2175,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   const bool ge_tab = c->logdt_ok;
   // (tiles are evaluated inside the factorisation kernels whatever the population size: the prebuilt-tile variants of
   // the split launches carry the most register spills, and the store never needs K itself)
-  int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, ge_tab, /*fuse_hint=*/true);
+  int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, ge_tab, /*fuse_hint=*/true,
+                         /*flow_limit=*/c->intrsm != 0 && c->flow != 0 && U <= FLOW_MAX_PARTICLES);
   if (rc) { poison(); return rc; }
   int i0min = nt;
   for (int u = 0; u < U; ++u) i0min = std::min(i0min, (int)i0[u]);
