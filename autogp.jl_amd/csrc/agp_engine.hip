@@ -707,10 +707,10 @@ inline void launch_flow(int dcov, int n_wg, hipStream_t st, const CholArgs& ca) 
 // Medium populations — more particles than the right-looking schedule serves, fewer than fill the GPU with the tiles
 // of one block column — take the dataflow schedule.
 // Measured on MI355X (tools/gpu_flow_perf.py, profiles/r02_flow_perf.txt): it beats the per-column launches (right-looking,
-// hybrid and mixed alike) from a handful of particles up to ~450 once the batch holds enough tile work to amortise
+// hybrid and mixed alike) from a handful of particles up to ~400 once the batch holds enough tile work to amortise
 // the persistent launch (P nt^2 >= 2000: n=2048 from 8 particles, n=1024 from 32, n=512 from 128); at 512 particles the
 // specialised per-column launches are ahead by 3 %.
-constexpr int FLOW_MAX_PARTICLES = 448;
+constexpr int FLOW_MAX_PARTICLES = 400;      // (384: dataflow 23.4 vs 24.2 ms; 448: 28.1 vs 27.1 ms; 512: 30.4 .. 31.6 vs 29.4 ms)
 constexpr long long FLOW_MIN_WORK = 2000;
 inline bool use_flow(const agp_ctx* c, int P, int nt) {
   return c->intrsm != 0 && (c->flow > 0 || (c->flow < 0 && P <= FLOW_MAX_PARTICLES && (long long)P * nt * nt >= FLOW_MIN_WORK));

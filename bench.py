@@ -251,7 +251,7 @@ def main():
                           "avg_launch_ms": dg_ms, "launches_per_step": n_dg / args.steps, "ms_per_step": acc["chol_trsm_ms"] / args.steps,
                           "algorithmic_flops_per_launch": dg_flops}
         elif round(n_upd / args.steps) == 1:
-            # dataflow schedule (default up to 448 particles per rank): the whole factorisation — diagonal factorisations,
+            # dataflow schedule (default up to 400 particles per rank): the whole factorisation — diagonal factorisations,
             # updates, panel solves, in-kernel tile evaluation — is ONE launch of persistent workgroups
             kernel_name = "k_chol_flow<DCOV,TAB> (dataflow schedule: every tile of the sweep in one launch)"
             upd_flops_launch = P * cholesky_flops(n)
