@@ -1676,11 +1676,64 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
     return fail(c, AGP_ERR_ARG, "null pointer argument");
   if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
   HIPCHK(c, hipSetDevice(c->device));
+  // A resampled population holds copies of the survivors (src/inference_smc_anneal_data.jl:198-204) and the reference
+  // predicts particle by particle (src/api.jl:508-520): each distinct (program, parameters, noise, noise_pred) runs once.
+  std::vector<int> rep(P), uniq;
+  if (c->dedup && P > 1) {
+    bool sane = true;
+    for (int p = 0; p < P && sane; ++p)
+      sane = op_off[p + 1] >= op_off[p] && prm_off[p + 1] >= prm_off[p] && op_off[p] >= 0 && prm_off[p] >= 0;
+    if (sane) {
+      std::unordered_map<std::string, int> seen;
+      seen.reserve((size_t)P * 2);
+      for (int p = 0; p < P; ++p) {
+        const int no = op_off[p + 1] - op_off[p], np = prm_off[p + 1] - prm_off[p];
+        const int32_t lens[2] = {no, np};
+        std::string key(reinterpret_cast<const char*>(lens), sizeof lens);
+        key.append(reinterpret_cast<const char*>(ops + op_off[p]), (size_t)no);
+        key.append(reinterpret_cast<const char*>(prm + prm_off[p]), sizeof(double) * (size_t)np);
+        key.append(reinterpret_cast<const char*>(noise + p), sizeof(double));
+        if (noise_pred) key.append(reinterpret_cast<const char*>(noise_pred + p), sizeof(double));
+        auto it = seen.find(key);
+        if (it == seen.end()) { seen.emplace(std::move(key), (int)uniq.size()); rep[p] = (int)uniq.size(); uniq.push_back(p); }
+        else rep[p] = it->second;
+      }
+    }
+  }
+  const int U = (int)uniq.size();
+  if (U == 0 || U == P) {
+    Batch bt;
+    int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt);
+    if (rc) return rc;
+    return predict_core(c, n, ts_pred, m, P, bt, noise, noise_pred, nullptr, nullptr, mean_train, mean_pred, out_mean,
+                        out_var, out_cov, out_info);
+  }
+  std::vector<int32_t> uo(U + 1, 0), up(U + 1, 0), uinfo(U, 0);
+  std::vector<uint8_t> uops; std::vector<double> uprm, unoise(U), unp(noise_pred ? U : 0);
+  for (int u = 0; u < U; ++u) {
+    const int p = uniq[u];
+    uops.insert(uops.end(), ops + op_off[p], ops + op_off[p + 1]);
+    uprm.insert(uprm.end(), prm + prm_off[p], prm + prm_off[p + 1]);
+    uo[u + 1] = (int32_t)uops.size(); up[u + 1] = (int32_t)uprm.size();
+    unoise[u] = noise[p];
+    if (noise_pred) unp[u] = noise_pred[p];
+  }
+  if (uprm.empty()) uprm.push_back(0.0);
+  std::vector<double> umean((size_t)U * m), uvar((size_t)U * m), ucov(out_cov ? (size_t)U * m * m : 0);
   Batch bt;
-  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt);
+  int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt);
   if (rc) return rc;
-  return predict_core(c, n, ts_pred, m, P, bt, noise, noise_pred, nullptr, nullptr, mean_train, mean_pred, out_mean,
-                      out_var, out_cov, out_info);
+  rc = predict_core(c, n, ts_pred, m, U, bt, unoise.data(), noise_pred ? unp.data() : nullptr, nullptr, nullptr, mean_train,
+                    mean_pred, umean.data(), uvar.data(), out_cov ? ucov.data() : nullptr, uinfo.data());
+  if (rc) return rc;
+  for (int p = 0; p < P; ++p) {
+    const size_t u = (size_t)rep[p];
+    std::memcpy(out_mean + (size_t)p * m, umean.data() + u * m, sizeof(double) * (size_t)m);
+    std::memcpy(out_var + (size_t)p * m, uvar.data() + u * m, sizeof(double) * (size_t)m);
+    if (out_cov) std::memcpy(out_cov + (size_t)p * m * m, ucov.data() + u * m * m, sizeof(double) * (size_t)m * m);
+    if (out_info) out_info[p] = uinfo[u];
+  }
+  return AGP_OK;
 }
 
 // infer_gp_sum (src/GP.jl:904-993): posterior over Z = [F_1(T*); ...; F_M(T*); X(T*)] given X(T) = xs, for the

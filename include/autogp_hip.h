@@ -156,7 +156,8 @@ int agp_logpdf_batch_device(agp_ctx* ctx, int64_t n, int32_t P,
  * mean_train (n) / mean_pred (m) are the values of the `mean` function (NULL = 0).
  * noise_pred may be NULL (= noise, src/GP.jl:739).  out_mean, out_var: m x P column-major;
  * out_cov: m x m x P (each slice symmetric) or NULL.  out_var = diag(out_cov) — the only part
- * Distributions.quantile consumes (src/GP.jl:1006-1012). */
+ * Distributions.quantile consumes (src/GP.jl:1006-1012).  Identical particles (a resampled population) are evaluated
+ * once (AGP_DEDUP=0 disables). */
 int agp_predict_batch(agp_ctx* ctx, int64_t n, const double* ts_pred, int64_t m, int32_t P,
                       const int32_t* op_off, const uint8_t* ops,
                       const int32_t* prm_off, const double* prm,

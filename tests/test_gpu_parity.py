@@ -593,6 +593,23 @@ def test_resampled_population_is_evaluated_once(pkg, engine):
         assert np.array_equal(grads[j], rgrads[i]) and gn[j] == rgn[i]
 
 
+def test_predict_evaluates_duplicates_once(pkg, engine):
+    """agp_predict_batch on a resampled population (copies of a few survivors): same mean / variance / covariance / info
+    per copy as the particle evaluated on its own, whatever noise_pred the copies carry."""
+    ts, xs = pkg.prior.synthetic_series(260, seed=8)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(8), 5, max_depth=3)
+    engine.set_data(ts, xs)
+    tp = np.linspace(0.0, 1.2, 33)
+    parents = np.array([0, 3, 3, 1, 0, 0, 4, 3, 2, 2, 0])
+    pop = [nodes[i] for i in parents]; nz = noises[parents]
+    npred = np.where(np.arange(len(parents)) % 2 == 0, 0.05, 0.2)          # copies may differ in noise_pred
+    mean, var, cov, info = engine.predict_batch(pop, nz, tp, noise_pred=npred, want_cov=True)
+    for j, i in enumerate(parents):
+        m1, v1, c1, _ = engine.predict_batch([nodes[i]], noises[i:i + 1], tp, noise_pred=npred[j], want_cov=True)
+        assert np.array_equal(mean[j], m1[0]) and np.array_equal(var[j], v1[0]) and np.array_equal(cov[j], c1[0])
+    assert (info == 0).all()
+
+
 def test_workspace_chunking_is_invisible(pkg, engine):
     ts, xs = pkg.prior.synthetic_series(300, seed=8)
     nodes, noises = pkg.prior.sample_particles(np.random.default_rng(8), 13, max_depth=3)
