@@ -69,6 +69,7 @@ struct CholArgs {
   int ntri;
   int* qnext;
   long long* trace;     // optional (agp_debug_flow_trace): per item {start, end, wait} in 100 MHz ticks + {item info}
+  int schur_diag_only;  // Schur mode: only the diagonal tiles of the prediction block (marginal variances + mean; no covariance)
   int flow_order;       // 0: sub-diagonal tiles of a block column tile-row-major (all particles' (k+1,k) first), 1: particle-major
 };
 
@@ -703,13 +704,21 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   } else {
     xcd = b & 7; qq = b >> 3;
     const int nt2 = a.nt - a.nt1;
-    T = nt2 * (nt2 + 1) / 2;
-    pl = qq / T; tl = qq - pl * T;
-    int ii = (int)((sqrt(8.0 * (double)tl + 1.0) - 1.0) * 0.5);
-    while (ii * (ii + 1) / 2 > tl) --ii;
-    while ((ii + 1) * (ii + 2) / 2 <= tl) ++ii;
-    const int kk = tl - ii * (ii + 1) / 2;
-    ti = a.nt1 + ii; tk = a.nt1 + kk; jmax = a.nt1;
+    if (a.schur_diag_only) {
+      // marginal variances only (what Distributions.quantile consumes, src/GP.jl:1006-1012): the n m^2 update of the
+      // off-diagonal tiles of K22 - V^T V is never needed
+      T = nt2;
+      pl = qq / T; tl = qq - pl * T;
+      ti = tk = a.nt1 + tl; jmax = a.nt1;
+    } else {
+      T = nt2 * (nt2 + 1) / 2;
+      pl = qq / T; tl = qq - pl * T;
+      int ii = (int)((sqrt(8.0 * (double)tl + 1.0) - 1.0) * 0.5);
+      while (ii * (ii + 1) / 2 > tl) --ii;
+      while ((ii + 1) * (ii + 2) / 2 <= tl) ++ii;
+      const int kk = tl - ii * (ii + 1) / 2;
+      ti = a.nt1 + ii; tk = a.nt1 + kk; jmax = a.nt1;
+    }
   }
   const int p = pl * 8 + xcd;
   if (p >= a.P) return;
@@ -957,7 +966,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
   const int xcd = blockIdx.x & 7;
   const int Pl = (a0.P - xcd + 7) / 8;          // particles pl*8 + xcd < P
   const int nt = a0.nt;
-  const int total = Pl * (nt * (nt + 1) / 2);
+  const int nfac = a0.nt1;                       // block columns to factor: nt in a logpdf sweep, the training block in prediction
+  const int total = Pl * (nfac * nt - nfac * (nfac - 1) / 2);
   // (Drawing the NEXT ticket early, to hide the atomic's latency behind the current tile, was measured: a drawn-but-not-
   // started item delays its consumers by the rest of the current item — 4 % slower at 64 particles, neutral at 512.)
   for (;;) {
@@ -967,7 +977,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
     const int item = __builtin_amdgcn_readfirstlane(s_item);      // wave-uniform: keeps the tile indices scalar
     if (item >= total) return;
     int k = 0, rem = item, pl, tl;
-    if (a0.flow_order == 2) {
+    if (a0.flow_order == 2 && nfac == nt) {
       // Look-ahead order: after the diagonal tiles of column 0, "super-column" k = the (k+1,k) tiles of every particle,
       // then the diagonal tiles of column k+1 (their last operand is that tile), then the rest of column k.  The
       // factorisation of L(k+1,k+1) is thus issued a whole column of tiles before anything needs it: the panel solves
@@ -1012,7 +1022,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
     if (a0.trace && threadIdx.x == 0) {
       // record of this item: [start, end, K-loop wait ticks, (xcd, particle, tile row, block column)]
       int gi = item;
-      for (int x = 0; x < xcd; ++x) gi += ((a0.P - x + 7) / 8) * (nt * (nt + 1) / 2);
+      for (int x = 0; x < xcd; ++x) gi += ((a0.P - x + 7) / 8) * (nfac * nt - nfac * (nfac - 1) / 2);
       long long* r = a0.trace + 4 * (long long)gi;
       r[0] = t_start; r[1] = (long long)wall_clock64();
       r[2] = (long long)s_wait;

@@ -39,6 +39,7 @@ struct CovArgs {
   const double* logdt;   // packed lower tiles of log|t_i - t_j| over the resident data (programs with flags bit 0)
   const int* slot;       // extension sweeps (see CholArgs): storage index per particle, first tile row to (re)build
   const int* i0;
+  int skip_pred_offdiag; // prediction without a covariance request: off-diagonal tiles of the K22 block are never read
 };
 
 __device__ __forceinline__ int prm_count(int o) {
@@ -218,6 +219,7 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
     tj = tix - ti * (ti + 1) / 2;
   }
   if (a.i0 != nullptr && ti < a.i0[p]) return;        // extension sweep: this tile row keeps its factor
+  if (a.skip_pred_offdiag && ti != tj && tj * NB >= a.n1_pad) return;
   const int tid = threadIdx.x;
   const ProgHdr h = a.hdr[p];
   const uint8_t* __restrict__ ops = a.ops + h.op_off;

@@ -712,8 +712,14 @@ inline void launch_flow(int dcov, int n_wg, hipStream_t st, const CholArgs& ca) 
 // specialised per-column launches are ahead by 3 %.
 constexpr int FLOW_MAX_PARTICLES = 400;      // (384: dataflow 23.4 vs 24.2 ms; 448: 28.1 vs 27.1 ms; 512: 30.4 .. 31.6 vs 29.4 ms)
 constexpr long long FLOW_MIN_WORK = 2000;
-inline bool use_flow(const agp_ctx* c, int P, int nt) {
-  return c->intrsm != 0 && (c->flow > 0 || (c->flow < 0 && P <= FLOW_MAX_PARTICLES && (long long)P * nt * nt >= FLOW_MIN_WORK));
+// What decides is how many tiles a block column offers: above ~3400 workgroups per column (400 particles x 8.5 tiles on
+// average at n=2048; 256 particles x 28 in a prediction with 16 + 20 tile rows) the per-column launches fill the GPU by
+// themselves.  nfac: block columns that are factored (all of them, or the training block of a prediction).
+inline bool use_flow(const agp_ctx* c, int P, int nt, int nfac = 0) {
+  if (nfac <= 0) nfac = nt;
+  const double avg_tiles = nt - 0.5 * (nfac - 1);
+  return c->intrsm != 0 && (c->flow > 0 || (c->flow < 0 && P <= FLOW_MAX_PARTICLES && (double)P * avg_tiles <= 3400.0 &&
+                                            (long long)P * nt * nt >= FLOW_MIN_WORK));
 }
 
 // The specialised diagonal-tile launch pays off when the diagonal tiles alone fill the GPU (two workgroups per
@@ -1539,7 +1545,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
   }
 
   HIPCHK(c, s->A.ensure((size_t)bytes_pp * chunk));
-  HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256 * (size_t)chunk));
+  HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256 * (size_t)chunk * std::max(1, nt1)));     // (the dataflow schedule keeps every column's inverse blocks)
   HIPCHK(c, s->vec.ensure(sizeof(double) * (size_t)ntot * chunk));
   HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
   HIPCHK(c, s->info.ensure(sizeof(int) * (size_t)P));
@@ -1599,6 +1605,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       HIPCHK(c, launch_cov(st, cv, nt1 > 0 ? nt - 1 : 0, nf, bt.max_cp_fused, bt.max_depth_fused));
     }
     cv.col0_only = 0; cv.p_off = nf;
+    cv.skip_pred_offdiag = out_cov ? 0 : 1;
     HIPCHK(c, launch_cov(st, cv, ntiles, Pc - nf, bt.max_cp, bt.max_depth));
 
     CholArgs ca = {};
@@ -1608,11 +1615,27 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     set_cov(ca, cv);
     ca.n_fused = nf;
     ca.ready = s->ready.as<int>() + p0;
-    HIPCHK(c, run_factor(st, ca, nt1, dcov, intrsm, nullptr, nullptr, use_split_diag(c, ca.P)));
+    if (nt1 > 0 && use_flow(c, Pc, nt, nt1)) {
+      // dataflow schedule over the block columns of the training block (all rows: V = L^-1 K12 comes out of the same tiles)
+      const int ntri = nt * (nt + 1) / 2;
+      HIPCHK(c, s->tflag.ensure(sizeof(int) * (size_t)Pc * ntri));
+      HIPCHK(c, s->flowq.ensure(sizeof(int) * 8 * 8));
+      ca.tflag = s->tflag.as<int>(); ca.ntri = ntri; ca.qnext = s->flowq.as<int>(); ca.flow_order = c->flow_order;
+      ca.wsteps = nt1;
+      HIPCHK(c, hipMemsetAsync(ca.tflag, 0, sizeof(int) * (size_t)Pc * ntri, st));
+      HIPCHK(c, hipMemsetAsync(ca.qnext, 0, sizeof(int) * 8, st));
+      launch_flow(dcov, 2 * c->n_cu, st, ca);
+      HIPCHK(c, hipGetLastError());
+    } else {
+      HIPCHK(c, run_factor(st, ca, nt1, dcov, intrsm, nullptr, nullptr, use_split_diag(c, ca.P)));
+    }
     {
       // Schur complement of the prediction block + (-V^T alpha); with nt1 == 0 this just
       // passes K22 through.
-      const int T = nt2 * (nt2 + 1) / 2;
+      // without a covariance request only the diagonal tiles are updated: mean and marginal variances cost
+      // n^3/3 + n^2 m instead of n^3/3 + n^2 m + n m^2
+      ca.schur_diag_only = out_cov ? 0 : 1;
+      const int T = out_cov ? nt2 * (nt2 + 1) / 2 : nt2;
       const int Pg = (Pc + 7) / 8;
       launch_update<false, false>(dcov, 8 * Pg * T, st, ca);
     }
@@ -1703,7 +1726,8 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   const int U = (int)uniq.size();
   if (U == 0 || U == P) {
     Batch bt;
-    int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt);
+    const bool fh = c->flow_fuse && n > 0 && use_flow(c, P, (int)((n + NB - 1) / NB + (m + NB - 1) / NB), (int)((n + NB - 1) / NB));
+    int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, false, false, fh, fh);
     if (rc) return rc;
     return predict_core(c, n, ts_pred, m, P, bt, noise, noise_pred, nullptr, nullptr, mean_train, mean_pred, out_mean,
                         out_var, out_cov, out_info);
@@ -1721,7 +1745,8 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   if (uprm.empty()) uprm.push_back(0.0);
   std::vector<double> umean((size_t)U * m), uvar((size_t)U * m), ucov(out_cov ? (size_t)U * m * m : 0);
   Batch bt;
-  int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt);
+  const bool fh = c->flow_fuse && n > 0 && use_flow(c, U, (int)((n + NB - 1) / NB + (m + NB - 1) / NB), (int)((n + NB - 1) / NB));
+  int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, false, fh, fh);
   if (rc) return rc;
   rc = predict_core(c, n, ts_pred, m, U, bt, unoise.data(), noise_pred ? unp.data() : nullptr, nullptr, nullptr, mean_train,
                     mean_pred, umean.data(), uvar.data(), out_cov ? ucov.data() : nullptr, uinfo.data());

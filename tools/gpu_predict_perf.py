@@ -15,5 +15,5 @@ for n, m_extra, P in ((256, 64, 8), (1024, 256, 64), (2048, 512, 64), (2048, 512
     t0 = time.time(); reps = 3
     for _ in range(reps): mean, var, _, info = eng.predict_batch(nodes, noises, tp, check=False)
     dt = (time.time() - t0) / reps
-    fl = P * ((n + m) ** 3 / 3 - m ** 3 / 3)      # factor n columns of the joint matrix + Schur update of the m block
+    fl = P * (n ** 3 / 3 + n * n * m + n * m * 128)      # factor K11, V = L^-1 K12, diagonal tiles of K22 - V'V (no covariance requested)
     print(f"predict n={n} m={m} P={P}: {dt*1e3:8.2f} ms  {P/dt:8.0f} particles/s  ~{fl/dt/1e12:5.1f} TF/s  npd={(info>0).sum()}")
