@@ -227,6 +227,29 @@ function predict_mvn(eng::Engine, node::GP.Node, noise::Float64, ts_pred::Vector
     return Distributions.MvNormal(mu, LinearAlgebra.Symmetric(cov))
 end
 
+"""
+Marginal predictive mean and variance only — what `Inference.predict` (src/inference_utils.jl:186-196) consumes through
+`Distributions.quantile(dist, p)` = mu + sqrt(diag(cov)) * Phi^-1(p) (src/GP.jl:1006-1012).  Passing no covariance buffer
+lets the engine skip the n m^2 update of the prediction block's off-diagonal tiles.  Returns (mean, var).
+"""
+function predict_marginal(eng::Engine, node::GP.Node, noise::Float64, ts_pred::Vector{Float64};
+        n::Integer=eng.n_max, noise_pred::Union{Nothing,Float64}=nothing)
+    ops, prm = encode(node)
+    m = length(ts_pred)
+    op_off = Int32[0, length(ops)]; prm_off = Int32[0, length(prm)]
+    mu = Vector{Float64}(undef, m); var = Vector{Float64}(undef, m)
+    info = Int32[0]; nz = [noise]
+    npv = isnothing(noise_pred) ? Float64[] : [noise_pred]
+    GC.@preserve ops prm op_off prm_off ts_pred mu var nz npv info check(eng, ccall((:agp_predict_batch, LIB), Cint,
+        (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+        eng.ptr, n, ts_pred, m, 1, op_off, ops, prm_off, prm, nz,
+        isempty(npv) ? Ptr{Float64}(C_NULL) : pointer(npv), Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL),
+        mu, var, Ptr{Float64}(C_NULL), info))
+    info[1] > 0 && throw(LinearAlgebra.PosDefException(info[1]))
+    return mu, var
+end
+
 "Sum-of-GPs posterior — replaces GP.infer_gp_sum (src/GP.jl:904-993); returns the same named tuple."
 function infer_gp_sum(eng::Engine, nodes::Vector{<:GP.Node}, noise::Float64, ts_pred::Vector{Float64};
         n::Integer=eng.n_max, noise_pred::Union{Nothing,Float64}=nothing)
