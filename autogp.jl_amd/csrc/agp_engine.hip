@@ -280,7 +280,7 @@ struct Compiled {
 // k_cov_tiles / the gradient contraction keep one 256-entry table per ChangePoint node / selector leaf in LDS next to
 // the 256 time points (+ parameters and a tape in the gradient kernel): 160 KiB per workgroup on gfx950.
 constexpr int DYN_LDS_MAX_BYTES = 160 * 1024;
-constexpr int COV_MAX_TABLES = (DYN_LDS_MAX_BYTES / 8 - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_OPS_DEV - 16) / 256;   // 75
+constexpr int COV_MAX_TABLES = (DYN_LDS_MAX_BYTES / 8 - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_OPS_DEV - 16) / 256;   // 74
 
 int leaf_nprm(int op) {
   switch (op) {

@@ -560,6 +560,15 @@ def test_bad_programs_are_rejected(pkg, engine):
     assert call([1], [0.5, 0.7]) == -3               # parameter count mismatch
     assert call([42], [0.5]) == -3                   # unknown opcode
     assert b"particle 0" in lib.agp_last_error(ctx)
+    # a chain of 75 ChangePoints needs 75 per-point tables: more than 160 KiB of LDS can hold next to the program -> a
+    # clear program error, not an opaque launch failure (74 still run)
+    def chain(ncp):
+        ops, prm = [1], [0.5]
+        for _ in range(ncp):
+            ops += [1, 8]; prm += [0.5, 0.3, 0.05]
+        return ops, prm
+    assert call(*chain(74)) == 0 and np.isfinite(out.value), lib.agp_last_error(ctx)
+    assert call(*chain(75)) == -3 and b"LDS" in lib.agp_last_error(ctx)
 
 
 def test_resampled_population_is_evaluated_once(pkg, engine):
