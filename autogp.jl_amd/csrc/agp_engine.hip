@@ -1007,7 +1007,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           const size_t lds = sizeof(double) * std::max<size_t>(2 * U_SLAB, 256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes);
           const int Pall = ga.P;
           if (c->grad_split) {
-            hipLaunchKernelGGL(k_kinv_tiles, dim3(ntiles, Pg), dim3(256), 0, q, ga);
+            hipLaunchKernelGGL(k_kinv_tiles, dim3(8 * Pg8 * ntiles), dim3(256), 0, q, ga);
             const size_t lds2 = sizeof(double) * (256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes + 8);
             // three classes by tree size (the particle list is sorted by it): > 16 nodes and 9 .. 16 nodes keep their tape
             // in private memory, trees of <= 8 nodes — the bulk of a prior-sampled population — keep it in LDS

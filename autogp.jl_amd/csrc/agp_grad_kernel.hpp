@@ -627,7 +627,15 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
 // ---- split variant: K^-1 tiles to memory (over the L buffer, dead by now), then a lean contraction ----
 __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
   __shared__ __attribute__((aligned(16))) double sm[2 * U_SLAB];
-  const int tix = blockIdx.x, p = blockIdx.y;
+  // XCD-aware map (as in the factorisation kernels): block b runs on XCD b % 8; all tiles of a particle go to one XCD, in
+  // tile order, so the row panel Z(i,.) shared by tiles (i,0..i) and the column panels stay in that XCD's L2 — with the
+  // (tile, particle) grid every XCD streamed every particle's panels from HBM (~107 GB per 512-particle sweep at n=2048;
+  // 28.3 -> 26.5 ms)
+  const int ntl = a.nt * (a.nt + 1) / 2;
+  const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+  const int pl = qq / ntl, tix = qq - pl * ntl;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
   int ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
   while (ti * (ti + 1) / 2 > tix) --ti;
   while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
@@ -652,7 +660,6 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
     }
 }
 
-template <int MAXS>
 // History of this kernel (n=2048, 512 prior particles): 31 ms in round 1.  PMC then: VALU issue 31 % busy at 2 waves/SIMD — not
 // throughput.  What it waited on: (1) the K^-1 / alpha / log|dt| loads of every element group, exposed 16 times per tile
 // (now fetched one group ahead); (2) the tape: node values and adjoints in private memory, a dependent global-memory round
@@ -661,6 +668,9 @@ template <int MAXS>
 // MAXS = 0; AGP_GRAD_LDS_TAPE=0 restores the private tape).  Together 31 -> ~20 ms.  Measured and dropped: 3 / 4 waves per
 // SIMD by register cap (-2 % / +9 %), a fully register-resident variant (value stack + operand history + adjoint stack;
 // 353 registers, one wave per SIMD: +6 %), register accumulators instead of the private gacc[] (no change).
+// (An LDS tape with 2 / 1 elements in lockstep for trees of <= 16 / <= 32 nodes was measured too: no gain over the private
+// tape with 4 — those classes are a few particles of a prior-sampled population.)
+template <int MAXS>
 __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tix = blockIdx.x;
