@@ -198,3 +198,25 @@ def test_store_too_small_falls_back(pkg, monkeypatch):
         assert e.extend_stats()["from_scratch"] == 0
     finally:
         e.close()
+
+
+def test_store_grows_in_place(pkg, eng):
+    """A larger population than the store was sized for: the store is re-allocated with more slots and the factors it
+    held are carried over (one strided copy per buffer) — the particles seen before are still extended, the new ones
+    factored from scratch, every value equal to the from-scratch sweep."""
+    ts, xs = pkg.prior.synthetic_series(900, seed=19, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(19), 90, max_depth=3)
+    eng.set_data(ts, xs)
+    a, _ = eng.logpdf_batch_extend(nodes[:5], noises[:5], n=300, check=False)             # store: 32 slots
+    assert eng.extend_stats()["from_scratch"] == 5
+    b, ib = eng.logpdf_batch_extend(nodes, noises, n=650, check=False)                      # 90 particles: the store grows
+    st = eng.extend_stats()
+    assert st["extended"] == 5 and st["from_scratch"] == 5 + 85
+    ref, ir = eng.logpdf_batch(nodes, noises, n=650, check=False)
+    ok = ib == 0
+    assert same(ib, ir) and lp_err(b[ok], ref[ok]).max() <= 1e-10
+    c, ic = eng.logpdf_batch_extend(nodes, noises, n=900, check=False)                      # everyone extends now
+    assert eng.extend_stats()["extended"] == 5 + 90
+    ref, ir = eng.logpdf_batch(nodes, noises, n=900, check=False)
+    ok = ic == 0
+    assert same(ic, ir) and lp_err(c[ok], ref[ok]).max() <= 1e-10
