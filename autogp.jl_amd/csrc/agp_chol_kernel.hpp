@@ -1165,7 +1165,41 @@ __global__ void k_init_flow_flags(int* tflag, int ntri_stride, int ntri, const i
   int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
   while (ti * (ti + 1) / 2 > t) --ti;
   while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-  tflag[(long long)slot[p] * ntri_stride + t] = ti < i0[p] ? 1 : 0;
+  tflag[(long long)(slot != nullptr ? slot[p] : p) * ntri_stride + t] = ti < i0[p] ? 1 : 0;
+}
+
+// Predictive pass on a factor the store already holds (agp_predict_batch after agp_logpdf_batch_extend on the same
+// prefix): particle p takes tile rows < nt1 of L, the per-column inverse blocks and alpha = L^-1 y from store slot
+// src_slot[p] (< 0: no resident factor, nothing copied).  The first nt1 tile rows of the packed layout are a contiguous
+// prefix, so this is three straight copies per particle; ready[p] = nt1 publishes the columns to the panel solves.
+struct GatherArgs {
+  double* dstA; long long dst_strideA; const double* srcA; long long src_strideA; long long nA;      // doubles
+  double* dstW; long long dst_strideW; const double* srcW; long long src_strideW; long long nW;
+  double* dstV; long long dst_strideV; const double* srcV; long long src_strideV; long long nV;
+  const int* src_slot; int* ready; int nt1;
+};
+__global__ __launch_bounds__(256) void k_gather_factor(GatherArgs g) {
+  const int p = blockIdx.y;
+  const int sl = g.src_slot[p];
+  if (sl < 0) return;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  {
+    const d2* __restrict__ src = reinterpret_cast<const d2*>(g.srcA + sl * g.src_strideA);
+    d2* __restrict__ dst = reinterpret_cast<d2*>(g.dstA + p * g.dst_strideA);
+    for (long long i = t; i < g.nA / 2; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+  }
+  {
+    const d2* __restrict__ src = reinterpret_cast<const d2*>(g.srcW + sl * g.src_strideW);
+    d2* __restrict__ dst = reinterpret_cast<d2*>(g.dstW + p * g.dst_strideW);
+    for (long long i = t; i < g.nW / 2; i += stride) dst[i] = src[i];
+  }
+  {
+    const double* __restrict__ src = g.srcV + sl * g.src_strideV;
+    double* __restrict__ dst = g.dstV + p * g.dst_strideV;
+    for (long long i = t; i < g.nV; i += stride) dst[i] = src[i];
+  }
+  if (t == 0) g.ready[p] = g.nt1;
 }
 
 // x (minus the mean function on the training segment), zero elsewhere; clears info.

@@ -124,6 +124,7 @@ struct agp_ctx {
   int n_cu = 256;
   bool profiling = false;
   int grad_lds_tape = 1;   // 1: trees of <= 8 nodes keep the contraction's tape in LDS; env AGP_GRAD_LDS_TAPE
+  int predict_reuse = 1;   // 1: predictive passes take L11 / alpha of a particle from the factor store when it holds them; env AGP_PREDICT_REUSE
   int grad_split = 1;   // 1: K^-1 tiles to memory + lean contraction kernel; 0: fused tile kernel (env AGP_GRAD_SPLIT)
   int intrsm = 1;       // 1: triangular solve inside k_chol_update (one launch per block column); env AGP_INTRSM
   int n_streams = 1;    // sub-batches of one call run on this many streams (env AGP_STREAMS)
@@ -176,12 +177,14 @@ struct agp_ctx {
     std::vector<std::string> key;       // per slot; empty = free
     std::vector<int64_t> n_cached;      // observations the slot's factor covers
     std::vector<uint64_t> stamp;        // last use (LRU)
+    std::vector<int32_t> info_h;        // host copy of the slot's LAPACK info (a predictive pass only reuses info == 0)
     std::unordered_map<std::string, int> index;
     uint64_t clock = 0;
     int64_t hits = 0, misses = 0, tile_rows_reused = 0, tile_rows_total = 0;
+    int64_t pred_reused = 0, pred_factored = 0;   // predictive passes: particles served from a resident factor / factored
     double max_frac = 0.45;             // share of the device memory the store may take
     void forget() { index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); }
-    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); n_slots = 0; nt_cap = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); }
+    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); n_slots = 0; nt_cap = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); }
   } store;
   // ---- RCCL communicator of the particle-sharded deployment (agp_comm_init_rank / agp_init_multi) ----
   ncclComm_t comm = nullptr;
@@ -1155,6 +1158,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_FLOW_FUSE_MAX_US")) c->flow_fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LDS_TAPE")) c->grad_lds_tape = atoi(e) != 0;
+  if (const char* e = getenv("AGP_PREDICT_REUSE")) c->predict_reuse = atoi(e) != 0;
   if (const char* e = getenv("AGP_INTRSM")) c->intrsm = atoi(e) != 0;
   if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_STREAMS")) c->n_streams = std::max(1, std::min(8, atoi(e)));
@@ -1512,13 +1516,18 @@ int agp_set_coalesce_window(agp_ctx* c, int32_t microseconds) {
 }  // extern "C"
 
 namespace {
+std::string particle_key(const uint8_t* ops, int no, const double* prm, int np, double noise);
+hipError_t run_factor_extend(hipStream_t st, CholArgs ca, int dcov, bool split_diag, int i0min, int nfac = -1);
+
 // Core of the predictive path (src/GP.jl:739-757) for a compiled batch.  `pred_code` / `diag_add`
 // (both per prediction point, nullable) are what infer_gp_sum adds: component codes of the query
-// points and an extra diagonal term.
+// points and an extra diagonal term.  `keys` (nullable; per particle, caller order) are the factor-store keys of the
+// particles: one whose factor of exactly this prefix is resident (an extension sweep scored it: the per-step callback of
+// the streaming workload, scripts/online.jl:43, predicts right after the reweight) skips K11 and its factorisation.
 int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P, Batch& bt,
                  const double* noise, const double* noise_pred, const uint8_t* pred_code, const double* diag_add,
                  const double* mean_train, const double* mean_pred, double* out_mean, double* out_var,
-                 double* out_cov, int32_t* out_info) {
+                 double* out_cov, int32_t* out_info, const std::vector<std::string>* keys = nullptr) {
   SlotGuard sg(c);
   Slot* s = sg.s;
   if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -1586,12 +1595,59 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     HIPCHK(c, hipMemcpyAsync(s->diag_add.p, diag_add, sizeof(double) * m, hipMemcpyHostToDevice, st));
   }
 
+  // resident factors (sorted order): store slot per particle, first tile row to compute
+  agp_ctx::FactorStore& fs = c->store;
+  std::vector<int32_t> src_slot((size_t)P, -1), i0v((size_t)P, 0);
+  int n_hit = 0;
+  std::unique_lock<std::mutex> store_lk;
+  if (keys && c->predict_reuse && c->intrsm && nt1 > 0 && !mean_train && !pred_code) {
+    store_lk = std::unique_lock<std::mutex>(fs.mu);
+    if (fs.n_slots > 0 && fs.nt_cap >= nt1) {
+      const uint64_t call = ++fs.clock;
+      for (int q = 0; q < P; ++q) {
+        auto it = fs.index.find((*keys)[(size_t)bt.order[q]]);
+        if (it == fs.index.end()) continue;
+        const int sl = it->second;
+        if (fs.n_cached[sl] != n || fs.info_h[sl] != 0) continue;
+        src_slot[q] = sl; i0v[q] = nt1; fs.stamp[sl] = call; ++n_hit;
+      }
+    }
+    fs.pred_reused += n_hit; fs.pred_factored += P - n_hit;
+    if (n_hit == 0) store_lk.unlock();
+  }
+  const int32_t* d_src = nullptr; const int32_t* d_i0 = nullptr;
+  if (n_hit > 0) {
+    HIPCHK(c, s->stage.ensure(sizeof(int32_t) * 2 * (size_t)P));
+    int32_t* d = s->stage.as<int32_t>();
+    HIPCHK(c, hipMemcpyAsync(d, src_slot.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d + P, i0v.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+    d_src = d; d_i0 = d + P;
+  }
+
   std::vector<double> h_mean, h_var;
   for (int p0 = 0; p0 < P; p0 += chunk) {
     const int Pc = std::min(chunk, P - p0);
     hipLaunchKernelGGL(k_init_vec, dim3((ntot + 255) / 256, Pc), dim3(256), 0, st, s->vec.as<double>(), ntot,
                        Pc, c->d_xs, (mean_train && n > 0) ? s->mu1.as<double>() : (const double*)nullptr, (int)n,
                        s->info.as<int>() + p0, s->ready.as<int>() + p0);
+    if (n_hit > 0) {
+      GatherArgs ga = {};
+      ga.dstA = s->A.as<double>(); ga.dst_strideA = strideA; ga.srcA = fs.A.as<double>(); ga.src_strideA = fs.strideA;
+      ga.nA = (long long)nt1 * (nt1 + 1) / 2 * NB2;
+      ga.dstW = s->W.as<double>(); ga.dst_strideW = (long long)nt1 * NSB * 256; ga.srcW = fs.W.as<double>();
+      ga.src_strideW = (long long)fs.nt_cap * NSB * 256; ga.nW = (long long)nt1 * NSB * 256;
+      ga.dstV = s->vec.as<double>(); ga.dst_strideV = ntot; ga.srcV = fs.vec.as<double>();
+      ga.src_strideV = (long long)fs.nt_cap * NB; ga.nV = n1_pad;
+      ga.src_slot = d_src + p0; ga.ready = s->ready.as<int>() + p0; ga.nt1 = nt1;
+      const int gx = (int)std::min<long long>(128, (ga.nA / 2 + 255) / 256);
+      hipLaunchKernelGGL(k_gather_factor, dim3(gx, Pc), dim3(256), 0, st, ga);
+      HIPCHK(c, hipGetLastError());
+      if (p0 + chunk >= P) {
+        // the store may change again once the last copy has been made
+        HIPCHK(c, hipStreamSynchronize(st));
+        store_lk.unlock();
+      }
+    }
     CovArgs cv = {};
     cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n1_pad; cv.m2 = (int)m; cv.nt = nt;
     cv.hdr = s->hdr.as<ProgHdr>() + p0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
@@ -1606,6 +1662,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     }
     cv.col0_only = 0; cv.p_off = nf;
     cv.skip_pred_offdiag = out_cov ? 0 : 1;
+    cv.i0 = n_hit > 0 ? d_i0 + p0 : nullptr;
     HIPCHK(c, launch_cov(st, cv, ntiles, Pc - nf, bt.max_cp, bt.max_depth));
 
     CholArgs ca = {};
@@ -1615,6 +1672,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     set_cov(ca, cv);
     ca.n_fused = nf;
     ca.ready = s->ready.as<int>() + p0;
+    if (n_hit > 0) { ca.i0 = d_i0 + p0; ca.wsteps = nt1; }      // panel solves of the prediction rows read every column's inverse blocks
     if (nt1 > 0 && use_flow(c, Pc, nt, nt1)) {
       // dataflow schedule over the block columns of the training block (all rows: V = L^-1 K12 comes out of the same tiles)
       const int ntri = nt * (nt + 1) / 2;
@@ -1622,10 +1680,18 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       HIPCHK(c, s->flowq.ensure(sizeof(int) * 8 * 8));
       ca.tflag = s->tflag.as<int>(); ca.ntri = ntri; ca.qnext = s->flowq.as<int>(); ca.flow_order = c->flow_order;
       ca.wsteps = nt1;
-      HIPCHK(c, hipMemsetAsync(ca.tflag, 0, sizeof(int) * (size_t)Pc * ntri, st));
+      if (n_hit > 0)
+        hipLaunchKernelGGL(k_init_flow_flags, dim3((ntri + 255) / 256, Pc), dim3(256), 0, st, ca.tflag, ntri, ntri, (const int*)nullptr, ca.i0);
+      else
+        HIPCHK(c, hipMemsetAsync(ca.tflag, 0, sizeof(int) * (size_t)Pc * ntri, st));
       HIPCHK(c, hipMemsetAsync(ca.qnext, 0, sizeof(int) * 8, st));
       launch_flow(dcov, 2 * c->n_cu, st, ca);
       HIPCHK(c, hipGetLastError());
+    } else if (n_hit > 0) {
+      // per-column launches restricted to the rows some particle still has to compute
+      int i0min = nt1;
+      for (int q = 0; q < Pc; ++q) i0min = std::min(i0min, (int)i0v[(size_t)p0 + q]);
+      HIPCHK(c, run_factor_extend(st, ca, dcov, use_split_diag(c, ca.P), i0min, nt1));
     } else {
       HIPCHK(c, run_factor(st, ca, nt1, dcov, intrsm, nullptr, nullptr, use_split_diag(c, ca.P)));
     }
@@ -1724,13 +1790,19 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
     }
   }
   const int U = (int)uniq.size();
+  // (a store that holds nothing is not consulted: no key strings are built)
+  const bool want_keys = c->predict_reuse && c->intrsm && n > 0 && !mean_train && c->store.n_slots > 0;
   if (U == 0 || U == P) {
     Batch bt;
     const bool fh = c->flow_fuse && n > 0 && use_flow(c, P, (int)((n + NB - 1) / NB + (m + NB - 1) / NB), (int)((n + NB - 1) / NB));
     int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, false, false, fh, fh);
     if (rc) return rc;
+    std::vector<std::string> keys;
+    if (want_keys)
+      for (int p = 0; p < P; ++p)
+        keys.push_back(particle_key(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p], prm_off[p + 1] - prm_off[p], noise[p]));
     return predict_core(c, n, ts_pred, m, P, bt, noise, noise_pred, nullptr, nullptr, mean_train, mean_pred, out_mean,
-                        out_var, out_cov, out_info);
+                        out_var, out_cov, out_info, want_keys ? &keys : nullptr);
   }
   std::vector<int32_t> uo(U + 1, 0), up(U + 1, 0), uinfo(U, 0);
   std::vector<uint8_t> uops; std::vector<double> uprm, unoise(U), unp(noise_pred ? U : 0);
@@ -1748,8 +1820,12 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   const bool fh = c->flow_fuse && n > 0 && use_flow(c, U, (int)((n + NB - 1) / NB + (m + NB - 1) / NB), (int)((n + NB - 1) / NB));
   int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, false, fh, fh);
   if (rc) return rc;
+  std::vector<std::string> keys;
+  if (want_keys)
+    for (int u = 0; u < U; ++u)
+      keys.push_back(particle_key(uops.data() + uo[u], uo[u + 1] - uo[u], uprm.data() + up[u], up[u + 1] - up[u], unoise[u]));
   rc = predict_core(c, n, ts_pred, m, U, bt, unoise.data(), noise_pred ? unp.data() : nullptr, nullptr, nullptr, mean_train,
-                    mean_pred, umean.data(), uvar.data(), out_cov ? ucov.data() : nullptr, uinfo.data());
+                    mean_pred, umean.data(), uvar.data(), out_cov ? ucov.data() : nullptr, uinfo.data(), want_keys ? &keys : nullptr);
   if (rc) return rc;
   for (int p = 0; p < P; ++p) {
     const size_t u = (size_t)rep[p];
@@ -2123,13 +2199,15 @@ int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
   for (int sl = n_slots; sl < fs.n_slots; ++sl)
     if (!fs.key[sl].empty()) fs.index.erase(fs.key[sl]);
   fs.key.resize((size_t)n_slots); fs.n_cached.resize((size_t)n_slots, 0); fs.stamp.resize((size_t)n_slots, 0);
+  fs.info_h.resize((size_t)n_slots, 0);
   fs.nt_cap = nt_cap; fs.n_slots = n_slots; fs.strideA = strideA;
   return AGP_OK;
 }
 
-hipError_t run_factor_extend(hipStream_t st, CholArgs ca, int dcov, bool split_diag, int i0min) {
+hipError_t run_factor_extend(hipStream_t st, CholArgs ca, int dcov, bool split_diag, int i0min, int nfac) {
   const int Pg = (ca.P + 7) / 8;
-  for (int k = 0; k < ca.nt; ++k) {
+  if (nfac < 0) nfac = ca.nt;
+  for (int k = 0; k < nfac; ++k) {
     ca.k = k;
     if (k < i0min) {
       // every particle already holds block column k down to tile row i0min - 1: only the new rows' tiles, whose
@@ -2346,7 +2424,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     if (hinfo[u] < 0) { poison(); return fail(c, AGP_ERR_HIP, "in-kernel panel solve timed out waiting for its diagonal factor"); }
   for (int u = 0; u < U; ++u) {
     const int sl = slot[u];
-    fs.key[sl] = keys[u]; fs.index[keys[u]] = sl; fs.n_cached[sl] = n;
+    fs.key[sl] = keys[u]; fs.index[keys[u]] = sl; fs.n_cached[sl] = n; fs.info_h[sl] = hinfo[u];
     if (i0[u] > 0) ++fs.hits; else ++fs.misses;
   }
   fs.tile_rows_reused += rows_reused; fs.tile_rows_total += (int64_t)U * nt;
@@ -2368,6 +2446,13 @@ int agp_extend_stats(agp_ctx* c, int64_t* out4) {
   if (!c || !out4) return fail(c, AGP_ERR_ARG, "null pointer");
   std::lock_guard<std::mutex> g(c->store.mu);
   out4[0] = c->store.hits; out4[1] = c->store.misses; out4[2] = c->store.tile_rows_reused; out4[3] = c->store.tile_rows_total;
+  return AGP_OK;
+}
+
+int agp_predict_reuse_stats(agp_ctx* c, int64_t* out2) {
+  if (!c || !out2) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->store.mu);
+  out2[0] = c->store.pred_reused; out2[1] = c->store.pred_factored;
   return AGP_OK;
 }
 

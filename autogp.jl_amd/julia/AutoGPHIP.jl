@@ -166,6 +166,14 @@ function logpdf_batch(eng::Engine, nodes::Vector{<:GP.Node}, noises::Vector{Floa
     return out, info
 end
 
+"(particles a predictive call served from a resident factor, particles whose K11 it factored itself): after
+`logpdf_batch(...; extend=true)` on a prefix, `predict_marginal` / `predict_mvn` on the same prefix reuse L11 and alpha."
+function predict_reuse_stats(eng::Engine)
+    out = Vector{Int64}(undef, 2)
+    GC.@preserve out check(eng, ccall((:agp_predict_reuse_stats, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), eng.ptr, out))
+    return (reused = out[1], factored = out[2])
+end
+
 "The whole population over every GPU of the pool: shards by agp_shard_range, one sweep per device, log-weights
 all-gathered over RCCL inside the library (agp_logpdf_batch_multi)."
 function logpdf_batch(pool::EnginePool, nodes::Vector{<:GP.Node}, noises::Vector{Float64}, n::Integer=pool.engines[1].n_max)

@@ -119,6 +119,13 @@ int agp_extend_reset(agp_ctx* ctx, int release_memory);
 /* pre-size the store for series of up to n_cap observations and n_slots particles (optional: it grows on demand,
  * keeping its contents) */
 int agp_extend_reserve(agp_ctx* ctx, int64_t n_cap, int32_t n_slots);
+/* The predictive entries consult the same store: a particle whose factor of exactly the prefix n is resident (the
+ * per-step callback of the streaming workload predicts right after the reweight: scripts/online.jl:43,59 ->
+ * src/inference_utils.jl:174-196) takes L11, its inverse blocks and alpha = L11^-1 x from the store and only computes
+ * the prediction rows — n^2 m (+ n m^2 with a covariance request) instead of n^3/3 + n^2 m (+ n m^2).  Not used with
+ * a training mean function (alpha would differ).  AGP_PREDICT_REUSE=0 disables.
+ * out2 = { particles predicted from a resident factor, particles whose K11 was factored by the predictive pass } */
+int agp_predict_reuse_stats(agp_ctx* ctx, int64_t* out2);
 
 /* Value AND gradient: d logpdf / d theta for every (transformed) kernel parameter — out_grad has the
  * layout of `prm` (prm_off offsets; ChangePoint contributes d/dlocation, d/dscale) — and d logpdf / d noise.

@@ -220,3 +220,100 @@ def test_store_grows_in_place(pkg, eng):
     ref, ir = eng.logpdf_batch(nodes, noises, n=900, check=False)
     ok = ic == 0
     assert same(ic, ir) and lp_err(c[ok], ref[ok]).max() <= 1e-10
+
+
+def pred_err(a, b):
+    return np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))
+
+
+@pytest.mark.parametrize("env", [{}, {"AGP_FLOW": "0"}, {"AGP_FLOW": "1"}])
+@pytest.mark.parametrize("n", [700, 1024])
+def test_predict_from_resident_factor(pkg, monkeypatch, env, n):
+    """The per-step callback of the streaming workload (scripts/online.jl:43,59 -> Inference.predict,
+    src/inference_utils.jl:174-196) predicts right after the reweight: agp_predict_batch takes L11, its inverse blocks
+    and alpha from the factor store for every particle whose factor of exactly this prefix is resident and computes only
+    the prediction rows.  Same mean / variance / covariance as the pass that factors K11 itself (to rounding: the
+    resident factor came from a chain of extension sweeps) and as the oracle; particles that are not resident, resident
+    for another prefix, or not positive definite are factored by the predictive pass as before."""
+    import oracle.oracle as O
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = pkg.GPEngine(0)
+    try:
+        ts, xs = pkg.prior.synthetic_series(1100, seed=23, shuffle=True)
+        nodes, noises = pkg.prior.sample_particles(np.random.default_rng(23), 40, max_depth=3)
+        bad = pkg.Linear(0.0, 0.0, -0.01)                    # loses positive definiteness inside the second tile
+        e.set_data(ts, xs)
+        tp = np.concatenate([ts[:n:7], np.linspace(1.0, 1.3, 150)])      # observed points and a forecast grid (m = 2 tiles)
+        npred = np.linspace(0.0, 0.2, 40)
+
+        def run(pop, nz, npd, **kw):
+            return e.predict_batch(pop, nz, tp, n=n, noise_pred=npd, check=False, **kw)
+
+        base = run(nodes, noises, npred, want_cov=True)                      # empty store: K11 factored here
+        assert e.predict_reuse_stats()["reused"] == 0
+        # factors of the first 30 particles become resident along a schedule; 5 more are resident for ANOTHER prefix
+        for step in (300, 650, n):
+            e.logpdf_batch_extend(nodes[:30], noises[:30], n=step, check=False)
+        e.logpdf_batch_extend(nodes[30:35], noises[30:35], n=n - 100, check=False)
+        e.logpdf_batch_extend([bad], np.array([0.1]), n=n, check=False)
+        r0 = e.predict_reuse_stats()["reused"]
+        got = run(nodes, noises, npred, want_cov=True)
+        assert e.predict_reuse_stats()["reused"] - r0 == 30
+        ok = base[3] == 0
+        assert same(base[3], got[3]) and ok.sum() >= 30
+        for a, b in zip(base[:3], got[:3]):
+            assert pred_err(a[ok], b[ok]) <= 1e-10
+        # marginal-variance-only pass, duplicates (a resampled population), a non-PD particle with a resident (failed) factor
+        pop = [nodes[i] for i in (3, 3, 31, 7, 3, 39)] + [bad]
+        nz = np.concatenate([noises[[3, 3, 31, 7, 3, 39]], [0.1]])
+        npd = np.concatenate([npred[[3, 3, 31, 7, 3, 39]], [0.1]])
+        r0 = e.predict_reuse_stats()["reused"]
+        mean, var, _, info = run(pop, nz, npd)
+        assert e.predict_reuse_stats()["reused"] - r0 == 2              # distinct resident particles: 3 and 7
+        assert info[-1] > 0 and np.isnan(mean[-1]).all() and (info[:-1] == 0).all()
+        for j, i in enumerate((3, 3, 31, 7, 3, 39)):
+            assert pred_err(mean[j], base[0][i]) <= 1e-10 and pred_err(var[j], base[1][i]) <= 1e-10
+        for i in (3, 7):
+            mu, cov = O.predict_mvn(nodes[i].to_tuple(), float(noises[i]), ts[:n], xs[:n], tp, noise_pred=float(npred[i]))
+            assert pred_err(got[0][i], mu) <= 1e-8 and pred_err(got[2][i], cov) <= 1e-8
+        # a training mean function changes alpha: the store is not consulted
+        r0 = e.predict_reuse_stats()["reused"]
+        mt = 0.1 * np.ones(n)
+        m1 = e.predict_batch(nodes[:4], noises[:4], tp, n=n, mean_train=mt, mean_pred=0.1 * np.ones(len(tp)), check=False)
+        assert e.predict_reuse_stats()["reused"] == r0
+        mu, cov = O.predict_mvn(nodes[0].to_tuple(), float(noises[0]), ts[:n], xs[:n], tp, mean=lambda t: 0.1)
+        assert pred_err(m1[0][0], mu) <= 1e-8
+        # after a reset nothing is resident
+        e.extend_reset()
+        r0 = e.predict_reuse_stats()["reused"]
+        again = run(nodes, noises, npred)
+        assert e.predict_reuse_stats()["reused"] == r0
+        assert same(again[0][ok], base[0][ok])
+    finally:
+        e.close()
+
+
+def test_predict_reuse_large_population_and_switch(pkg, monkeypatch):
+    """Per-column launches (more than 400 particles) restricted to the prediction rows; AGP_PREDICT_REUSE=0 restores the
+    pass that always factors K11 — identical results to rounding."""
+    ts, xs = pkg.prior.synthetic_series(640, seed=29, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(29), 420, max_depth=3)
+    tp = np.linspace(0.0, 1.2, 100)
+    e = pkg.GPEngine(0)
+    monkeypatch.setenv("AGP_PREDICT_REUSE", "0")
+    e0 = pkg.GPEngine(0)
+    try:
+        for x in (e, e0):
+            x.set_data(ts, xs)
+            x.logpdf_batch_extend(nodes, noises, n=400, check=False)
+            x.logpdf_batch_extend(nodes, noises, n=640, check=False)
+        a = e.predict_batch(nodes, noises, tp, check=False)
+        b = e0.predict_batch(nodes, noises, tp, check=False)
+        assert e.predict_reuse_stats()["reused"] == len({(pkg.encode(nd)[0].tobytes(), pkg.encode(nd)[1].tobytes(), float(z)) for nd, z in zip(nodes, noises)})
+        assert e0.predict_reuse_stats()["reused"] == 0
+        ok = b[3] == 0
+        assert same(a[3], b[3])
+        assert pred_err(a[0][ok], b[0][ok]) <= 1e-10 and pred_err(a[1][ok], b[1][ok]) <= 1e-10
+    finally:
+        e.close(); e0.close()
