@@ -1176,6 +1176,7 @@ struct GatherArgs {
   double* dstA; long long dst_strideA; const double* srcA; long long src_strideA; long long nA;      // doubles
   double* dstW; long long dst_strideW; const double* srcW; long long src_strideW; long long nW;
   double* dstV; long long dst_strideV; const double* srcV; long long src_strideV; long long nV;
+  double* dstP; long long dst_strideP; const double* srcP; long long src_strideP; long long nP;      // log-det / quadratic-form partials (nP = 0: not wanted)
   const int* src_slot; int* ready; int nt1;
 };
 __global__ __launch_bounds__(256) void k_gather_factor(GatherArgs g) {
@@ -1199,6 +1200,7 @@ __global__ __launch_bounds__(256) void k_gather_factor(GatherArgs g) {
     double* __restrict__ dst = g.dstV + p * g.dst_strideV;
     for (long long i = t; i < g.nV; i += stride) dst[i] = src[i];
   }
+  for (long long i = t; i < g.nP; i += stride) g.dstP[p * g.dst_strideP + i] = g.srcP[sl * g.src_strideP + i];
   if (t == 0) g.ready[p] = g.nt1;
 }
 

@@ -124,6 +124,10 @@ struct agp_ctx {
   int n_cu = 256;
   bool profiling = false;
   int grad_lds_tape = 1;   // 1: trees of <= 8 nodes keep the contraction's tape in LDS; env AGP_GRAD_LDS_TAPE
+  int64_t pred_reused = 0, pred_factored = 0;   // predictive passes: particles served from a resident factor / factored (under mu)
+  int64_t grad_reused = 0, grad_factored = 0;   // gradient sweeps likewise
+  int factor_cache = 1;    // 1: coalesced agp_logpdf batches leave their factors in the store (a later call on a longer prefix extends
+                           // them, a gradient call at the same parameters skips the factorisation); env AGP_FACTOR_CACHE, agp_set_factor_cache
   int predict_reuse = 1;   // 1: predictive passes take L11 / alpha of a particle from the factor store when it holds them; env AGP_PREDICT_REUSE
   int grad_split = 1;   // 1: K^-1 tiles to memory + lean contraction kernel; 0: fused tile kernel (env AGP_GRAD_SPLIT)
   int intrsm = 1;       // 1: triangular solve inside k_chol_update (one launch per block column); env AGP_INTRSM
@@ -181,7 +185,6 @@ struct agp_ctx {
     std::unordered_map<std::string, int> index;
     uint64_t clock = 0;
     int64_t hits = 0, misses = 0, tile_rows_reused = 0, tile_rows_total = 0;
-    int64_t pred_reused = 0, pred_factored = 0;   // predictive passes: particles served from a resident factor / factored
     double max_frac = 0.45;             // share of the device memory the store may take
     void forget() { index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); }
     void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); n_slots = 0; nt_cap = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); }
@@ -757,6 +760,63 @@ hipError_t launch_grad_tiles(hipStream_t st, const GradArgs& ga, int ntiles, int
 
 // Core of agp_logpdf_batch{,_device} and agp_logpdf_grad_batch.  d_out_* may be caller device
 // buffers (user_stream path) or null (results copied to host h_out_*).
+std::string particle_key(const uint8_t* ops, int no, const double* prm, int np, double noise) {
+  std::string key;
+  const int32_t lens[2] = {no, np};
+  key.assign(reinterpret_cast<const char*>(lens), sizeof lens);
+  key.append(reinterpret_cast<const char*>(ops), (size_t)no);
+  key.append(reinterpret_cast<const char*>(prm), sizeof(double) * (size_t)np);
+  key.append(reinterpret_cast<const char*>(&noise), sizeof(double));
+  return key;
+}
+
+hipError_t run_factor_extend(hipStream_t st, CholArgs ca, int dcov, bool split_diag, int i0min, int nfac = -1);
+int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
+                const double* prm, const double* noise, double* out_lp, int32_t* out_info);
+
+// Factor-store lookup for a compiled batch (sorted order q -> caller index bt.order[q]): src_slot[q] = the slot that holds
+// the POSITIVE DEFINITE factor of particle q for exactly the prefix n (else -1), i0v[q] = nt for those (no tile row left to
+// compute).  Returns the number found; `lk` is held on return iff it is > 0 (the caller copies the factors out, then
+// unlocks).  Lock order everywhere: store mutex first, workspace slot second.
+int store_lookup(agp_ctx* c, const std::vector<std::string>& keys, const std::vector<int32_t>& order, int P, int64_t n, int nt,
+                 std::vector<int32_t>& src_slot, std::vector<int32_t>& i0v, std::unique_lock<std::mutex>& lk) {
+  agp_ctx::FactorStore& fs = c->store;
+  src_slot.assign((size_t)P, -1); i0v.assign((size_t)P, 0);
+  lk = std::unique_lock<std::mutex>(fs.mu);
+  int n_hit = 0;
+  if (fs.n_slots > 0 && fs.nt_cap >= nt) {
+    const uint64_t call = ++fs.clock;
+    for (int q = 0; q < P; ++q) {
+      auto it = fs.index.find(keys[(size_t)order[q]]);
+      if (it == fs.index.end()) continue;
+      const int sl = it->second;
+      if (fs.n_cached[sl] != n || fs.info_h[sl] != 0) continue;
+      src_slot[q] = sl; i0v[q] = nt; fs.stamp[sl] = call; ++n_hit;
+    }
+  }
+  if (n_hit == 0) lk.unlock();
+  return n_hit;
+}
+
+// Copies the resident factors (tile rows < nt1, inverse blocks, forward-solve vector, partials) of the particles with
+// src_slot >= 0 into a workspace laid out for Pc particles; ready[p] = nt1.
+void launch_gather(agp_ctx* c, hipStream_t st, int Pc, int nt1, double* dstA, long long dst_strideA, double* dstW, int dst_wsteps,
+                   double* dstV, long long dst_ldv, double* dstPart, int dst_ntp, const int32_t* d_src, int* ready) {
+  agp_ctx::FactorStore& fs = c->store;
+  GatherArgs ga = {};
+  ga.dstA = dstA; ga.dst_strideA = dst_strideA; ga.srcA = fs.A.as<double>(); ga.src_strideA = fs.strideA;
+  ga.nA = (long long)nt1 * (nt1 + 1) / 2 * NB2;
+  ga.dstW = dstW; ga.dst_strideW = (long long)dst_wsteps * NSB * 256; ga.srcW = fs.W.as<double>();
+  ga.src_strideW = (long long)fs.nt_cap * NSB * 256; ga.nW = (long long)nt1 * NSB * 256;
+  ga.dstV = dstV; ga.dst_strideV = dst_ldv; ga.srcV = fs.vec.as<double>();
+  ga.src_strideV = (long long)fs.nt_cap * NB; ga.nV = (long long)nt1 * NB;
+  ga.dstP = dstPart; ga.dst_strideP = 2LL * dst_ntp; ga.srcP = fs.partial.as<double>(); ga.src_strideP = 2LL * fs.nt_cap;
+  ga.nP = dstPart ? 2LL * nt1 : 0;
+  ga.src_slot = d_src; ga.ready = ready; ga.nt1 = nt1;
+  const int gx = (int)std::max<long long>(1, std::min<long long>(128, (ga.nA / 2 + 255) / 256));
+  hipLaunchKernelGGL(k_gather_factor, dim3(gx, Pc), dim3(256), 0, st, ga);
+}
+
 int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
                       const int32_t* prm_off, const double* prm, const double* noise,
                       double* h_out_lp, int32_t* h_out_info, double* d_user_lp, int32_t* d_user_info,
@@ -782,6 +842,21 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   if (go && n == 0) {
     for (int i = 0; i < n_prm_total; ++i) go->grad[i] = 0.0;
     for (int p = 0; p < P; ++p) go->gnoise[p] = 0.0;
+  }
+
+  // A gradient sweep right after a value call at the same parameters — every leapfrog step of Gen.hmc is `update`, then
+  // `choice_gradients` (src/inference_smc_anneal_data.jl:63-67) — finds the factor in the store (the coalesced value calls
+  // leave it there): covariance build and factorisation are skipped, the sweep starts at L^-T.
+  std::vector<int32_t> src_slot, i0v;
+  int n_hit = 0;
+  std::unique_lock<std::mutex> store_lk;       // held to the end of the sweep when anything is resident
+  if (go && n > 0 && c->factor_cache && c->intrsm && c->store.n_slots > 0) {
+    std::vector<std::string> keys((size_t)P);
+    for (int p = 0; p < P; ++p)
+      keys[p] = particle_key(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p], prm_off[p + 1] - prm_off[p], noise[p]);
+    n_hit = store_lookup(c, keys, bt.order, P, n, (int)((n + NB - 1) / NB), src_slot, i0v, store_lk);
+    std::lock_guard<std::mutex> g(c->mu);
+    c->grad_reused += n_hit; c->grad_factored += P - n_hit;
   }
 
   SlotGuard sg(c);
@@ -850,7 +925,9 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     const size_t o_noise = al16(o_prm + sizeof(double) * std::max<size_t>(1, bt.prm.size()));
     const size_t o_map = al16(o_noise + sizeof(double) * (size_t)P);
     const size_t o_ops = al16(o_map + sizeof(int32_t) * (size_t)P);
-    const size_t stage_bytes = al16(o_ops + bt.ops.size() + 4);
+    const size_t o_src = al16(o_ops + bt.ops.size() + 4);                       // resident-factor slots / first rows (n_hit > 0)
+    const size_t o_i0 = al16(o_src + (n_hit > 0 ? sizeof(int32_t) * (size_t)P : 0));
+    const size_t stage_bytes = al16(o_i0 + (n_hit > 0 ? sizeof(int32_t) * (size_t)P : 0));
     HIPCHK(c, s->stage.ensure(stage_bytes));
     HIPCHK(c, s->h_stage.ensure(stage_bytes));
     {
@@ -861,6 +938,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       for (int q = 0; q < P; ++q) hn[q] = noise[bt.order[q]];
       std::memcpy(h + o_map, bt.order.data(), sizeof(int32_t) * (size_t)P);
       std::memcpy(h + o_ops, bt.ops.data(), bt.ops.size());
+      if (n_hit > 0) {
+        std::memcpy(h + o_src, src_slot.data(), sizeof(int32_t) * (size_t)P);
+        std::memcpy(h + o_i0, i0v.data(), sizeof(int32_t) * (size_t)P);
+      }
     }
     char* dstage = static_cast<char*>(s->stage.p);
     ProgHdr* d_hdr = reinterpret_cast<ProgHdr*>(dstage + o_hdr);
@@ -868,6 +949,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     double* d_noise = reinterpret_cast<double*>(dstage + o_noise);
     int32_t* d_map = reinterpret_cast<int32_t*>(dstage + o_map);
     uint8_t* d_ops = reinterpret_cast<uint8_t*>(dstage + o_ops);
+    const int32_t* d_src = n_hit > 0 ? reinterpret_cast<const int32_t*>(dstage + o_src) : nullptr;
+    const int32_t* d_i0 = n_hit > 0 ? reinterpret_cast<const int32_t*>(dstage + o_i0) : nullptr;
 
     Prof pf{c, s, st, c->profiling};
     double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -921,6 +1004,16 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         cv.hdr = d_hdr + p0 + g0; cv.ops = d_ops; cv.prm = d_prm;
         cv.noise = d_noise + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
         cv.strideA = strideA; cv.P = Pg; cv.logdt = ge_tab ? c->d_logdt : nullptr;
+        int i0min = 0;
+        if (n_hit > 0) {
+          // resident factors: tiles, inverse blocks, forward-solve vector and partials come from the store
+          launch_gather(c, q, Pg, nt, cv.A, strideA, s->W.as<double>() + (size_t)g0 * NSB * 256 * wsteps, wsteps,
+                        s->vec.as<double>() + (size_t)g0 * n_pad, n_pad, s->partial.as<double>() + (size_t)g0 * 2 * nt, nt,
+                        d_src + p0 + g0, s->ready.as<int>() + g0);
+          cv.i0 = d_i0 + p0 + g0;
+          i0min = nt;
+          for (int r = 0; r < Pg; ++r) i0min = std::min(i0min, (int)i0v[(size_t)p0 + g0 + r]);
+        }
         // Hybrid build.  Sorted particles [0, n_fused) evaluate their own tiles inside k_chol_update
         // (only the sub-diagonal tiles of block column 0, which k_chol_trsm(0) reads, are
         // materialised); the few expensive particles behind them get every tile from k_cov_tiles,
@@ -947,7 +1040,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         set_cov(ca, cv);
         ca.n_fused = nf;
         ca.ready = s->ready.as<int>() + g0;
-        if (use_flow(c, ca.P, nt)) {      // (value and gradient sweeps alike: every block column keeps its inverse blocks)
+        ca.i0 = cv.i0;
+        if (n_hit > 0 && i0min == nt) {
+          // every particle of this group is resident: nothing to factor
+        } else if (use_flow(c, ca.P, nt)) {      // (value and gradient sweeps alike: every block column keeps its inverse blocks)
           // dataflow schedule: every tile of the batch in ONE launch of persistent workgroups (2 per CU)
           const int ntri = nt * (nt + 1) / 2;
           ca.tflag = s->tflag.as<int>() + (size_t)g0 * ntri; ca.ntri = ntri;
@@ -957,7 +1053,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             for (int x = 0; x < 8; ++x) items += (size_t)((Pg - x + 7) / 8) * ntri;
             ca.trace = (c->d_flow_trace && items <= c->flow_trace_items && S == 1 && P <= chunk) ? c->d_flow_trace : nullptr;
           }
-          HIPCHK(c, hipMemsetAsync(ca.tflag, 0, sizeof(int) * (size_t)Pg * ntri, q));
+          if (n_hit > 0)
+            hipLaunchKernelGGL(k_init_flow_flags, dim3((ntri + 255) / 256, Pg), dim3(256), 0, q, ca.tflag, ntri, ntri, (const int*)nullptr, ca.i0);
+          else
+            HIPCHK(c, hipMemsetAsync(ca.tflag, 0, sizeof(int) * (size_t)Pg * ntri, q));
           HIPCHK(c, hipMemsetAsync(ca.qnext, 0, sizeof(int) * 8, q));
           size_t f0 = pf.mark(q);
           launch_flow(dcov, 2 * c->n_cu, q, ca);
@@ -965,6 +1064,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           pf.span(2, f0, f1);
           if (c->profiling) tacc[5] += 1;
           HIPCHK(c, hipGetLastError());
+        } else if (n_hit > 0) {
+          HIPCHK(c, run_factor_extend(q, ca, dcov, use_split_diag(c, ca.P), i0min));
         } else {
           HIPCHK(c, run_factor(q, ca, nt, dcov, intrsm, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr, use_split_diag(c, ca.P),
                                use_right_looking(c, ca.P), c->hybrid_blocks));
@@ -1159,6 +1260,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LDS_TAPE")) c->grad_lds_tape = atoi(e) != 0;
   if (const char* e = getenv("AGP_PREDICT_REUSE")) c->predict_reuse = atoi(e) != 0;
+  if (const char* e = getenv("AGP_FACTOR_CACHE")) c->factor_cache = atoi(e) != 0;
   if (const char* e = getenv("AGP_INTRSM")) c->intrsm = atoi(e) != 0;
   if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_STREAMS")) c->n_streams = std::max(1, std::min(8, atoi(e)));
@@ -1379,8 +1481,11 @@ static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
   if (prm.empty()) prm.push_back(0.0);
   auto sweep = [&](int64_t n, int32_t Pn, const int32_t* oo, const uint8_t* o, const int32_t* po, const double* q,
                    const double* nz, double* out_lp, double* out_g, double* out_gn, int32_t* out_info) {
-    return want_grad ? agp_logpdf_grad_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_g, out_gn, out_info)
-                     : agp_logpdf_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_info);
+    if (want_grad) return agp_logpdf_grad_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_g, out_gn, out_info);
+    // value calls go through the factor store: the reweight on a longer prefix becomes an extension sweep, the gradient
+    // call that follows at the same parameters (HMC leapfrog) and a predictive call find the factor resident
+    return (c->factor_cache && c->intrsm) ? extend_impl(c, n, Pn, oo, o, po, q, nz, out_lp, out_info)
+                                          : agp_logpdf_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_info);
   };
   int rc = sweep(batch[0]->n, P, op_off.data(), ops.data(), prm_off.data(), prm.data(), noise.data(), lp.data(),
                  grad.data(), gn.data(), info.data());
@@ -1516,8 +1621,6 @@ int agp_set_coalesce_window(agp_ctx* c, int32_t microseconds) {
 }  // extern "C"
 
 namespace {
-std::string particle_key(const uint8_t* ops, int no, const double* prm, int np, double noise);
-hipError_t run_factor_extend(hipStream_t st, CholArgs ca, int dcov, bool split_diag, int i0min, int nfac = -1);
 
 // Core of the predictive path (src/GP.jl:739-757) for a compiled batch.  `pred_code` / `diag_add`
 // (both per prediction point, nullable) are what infer_gp_sum adds: component codes of the query
@@ -1528,14 +1631,24 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
                  const double* noise, const double* noise_pred, const uint8_t* pred_code, const double* diag_add,
                  const double* mean_train, const double* mean_pred, double* out_mean, double* out_var,
                  double* out_cov, int32_t* out_info, const std::vector<std::string>* keys = nullptr) {
+  const int n1_pad = round_up(n, NB);           // 0 when n == 0
+  const int m_pad = round_up(m, NB);
+  const int nt1 = n1_pad / NB, nt2 = m_pad / NB, nt = nt1 + nt2;
+  // resident factors (sorted order): store slot per particle, first tile row to compute
+  std::vector<int32_t> src_slot, i0v;
+  int n_hit = 0;
+  std::unique_lock<std::mutex> store_lk;
+  if (keys && c->predict_reuse && c->intrsm && nt1 > 0 && !mean_train && !pred_code) {
+    n_hit = store_lookup(c, *keys, bt.order, P, n, nt1, src_slot, i0v, store_lk);
+    std::lock_guard<std::mutex> g(c->mu);
+    c->pred_reused += n_hit; c->pred_factored += P - n_hit;
+  }
+
   SlotGuard sg(c);
   Slot* s = sg.s;
   if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   hipStream_t st = s->stream;
 
-  const int n1_pad = round_up(n, NB);           // 0 when n == 0
-  const int m_pad = round_up(m, NB);
-  const int nt1 = n1_pad / NB, nt2 = m_pad / NB, nt = nt1 + nt2;
   const int ntot = n1_pad + m_pad;
   const int ntiles = nt * (nt + 1) / 2;
   const long long strideA = (long long)ntiles * NB2;
@@ -1595,26 +1708,6 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     HIPCHK(c, hipMemcpyAsync(s->diag_add.p, diag_add, sizeof(double) * m, hipMemcpyHostToDevice, st));
   }
 
-  // resident factors (sorted order): store slot per particle, first tile row to compute
-  agp_ctx::FactorStore& fs = c->store;
-  std::vector<int32_t> src_slot((size_t)P, -1), i0v((size_t)P, 0);
-  int n_hit = 0;
-  std::unique_lock<std::mutex> store_lk;
-  if (keys && c->predict_reuse && c->intrsm && nt1 > 0 && !mean_train && !pred_code) {
-    store_lk = std::unique_lock<std::mutex>(fs.mu);
-    if (fs.n_slots > 0 && fs.nt_cap >= nt1) {
-      const uint64_t call = ++fs.clock;
-      for (int q = 0; q < P; ++q) {
-        auto it = fs.index.find((*keys)[(size_t)bt.order[q]]);
-        if (it == fs.index.end()) continue;
-        const int sl = it->second;
-        if (fs.n_cached[sl] != n || fs.info_h[sl] != 0) continue;
-        src_slot[q] = sl; i0v[q] = nt1; fs.stamp[sl] = call; ++n_hit;
-      }
-    }
-    fs.pred_reused += n_hit; fs.pred_factored += P - n_hit;
-    if (n_hit == 0) store_lk.unlock();
-  }
   const int32_t* d_src = nullptr; const int32_t* d_i0 = nullptr;
   if (n_hit > 0) {
     HIPCHK(c, s->stage.ensure(sizeof(int32_t) * 2 * (size_t)P));
@@ -1631,16 +1724,8 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
                        Pc, c->d_xs, (mean_train && n > 0) ? s->mu1.as<double>() : (const double*)nullptr, (int)n,
                        s->info.as<int>() + p0, s->ready.as<int>() + p0);
     if (n_hit > 0) {
-      GatherArgs ga = {};
-      ga.dstA = s->A.as<double>(); ga.dst_strideA = strideA; ga.srcA = fs.A.as<double>(); ga.src_strideA = fs.strideA;
-      ga.nA = (long long)nt1 * (nt1 + 1) / 2 * NB2;
-      ga.dstW = s->W.as<double>(); ga.dst_strideW = (long long)nt1 * NSB * 256; ga.srcW = fs.W.as<double>();
-      ga.src_strideW = (long long)fs.nt_cap * NSB * 256; ga.nW = (long long)nt1 * NSB * 256;
-      ga.dstV = s->vec.as<double>(); ga.dst_strideV = ntot; ga.srcV = fs.vec.as<double>();
-      ga.src_strideV = (long long)fs.nt_cap * NB; ga.nV = n1_pad;
-      ga.src_slot = d_src + p0; ga.ready = s->ready.as<int>() + p0; ga.nt1 = nt1;
-      const int gx = (int)std::min<long long>(128, (ga.nA / 2 + 255) / 256);
-      hipLaunchKernelGGL(k_gather_factor, dim3(gx, Pc), dim3(256), 0, st, ga);
+      launch_gather(c, st, Pc, nt1, s->A.as<double>(), strideA, s->W.as<double>(), nt1, s->vec.as<double>(), ntot, nullptr, 0,
+                    d_src + p0, s->ready.as<int>() + p0);
       HIPCHK(c, hipGetLastError());
       if (p0 + chunk >= P) {
         // the store may change again once the last copy has been made
@@ -2151,16 +2236,6 @@ int agp_debug_mfma_probe(agp_ctx* c, const double* A, const double* B, double* D
 // ==========================================================================================
 namespace {
 
-std::string particle_key(const uint8_t* ops, int no, const double* prm, int np, double noise) {
-  std::string key;
-  const int32_t lens[2] = {no, np};
-  key.assign(reinterpret_cast<const char*>(lens), sizeof lens);
-  key.append(reinterpret_cast<const char*>(ops), (size_t)no);
-  key.append(reinterpret_cast<const char*>(prm), sizeof(double) * (size_t)np);
-  key.append(reinterpret_cast<const char*>(&noise), sizeof(double));
-  return key;
-}
-
 inline size_t store_bytes_per_slot(int nt_cap) {
   const size_t tiles = (size_t)nt_cap * (nt_cap + 1) / 2;
   return tiles * NB2 * 8 + (size_t)nt_cap * NSB * 256 * 8 + (size_t)nt_cap * NB * 8 + (size_t)nt_cap * 2 * 8 + 8;
@@ -2278,6 +2353,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     // mid-rejuvenation keeps its previous states), within the store's share of device memory
     const int want_nt = std::max(fs.nt_cap, std::max(nt, round_up(c->n_max, NB) / NB));
     int want_slots = std::max(fs.n_slots, std::max(2 * U, 32));
+    if (want_slots > fs.n_slots && fs.n_slots > 0) want_slots = std::max(want_slots, fs.n_slots + fs.n_slots / 2);   // (growth copies the store: few, larger steps)
     const size_t budget = (size_t)(fs.max_frac * (double)c->total_mem);
     const size_t per = store_bytes_per_slot(want_nt);
     if ((size_t)want_slots * per > budget) want_slots = (int)std::min<size_t>((size_t)want_slots, budget / per);
@@ -2451,8 +2527,21 @@ int agp_extend_stats(agp_ctx* c, int64_t* out4) {
 
 int agp_predict_reuse_stats(agp_ctx* c, int64_t* out2) {
   if (!c || !out2) return fail(c, AGP_ERR_ARG, "null pointer");
-  std::lock_guard<std::mutex> g(c->store.mu);
-  out2[0] = c->store.pred_reused; out2[1] = c->store.pred_factored;
+  std::lock_guard<std::mutex> g(c->mu);
+  out2[0] = c->pred_reused; out2[1] = c->pred_factored;
+  return AGP_OK;
+}
+
+int agp_grad_reuse_stats(agp_ctx* c, int64_t* out2) {
+  if (!c || !out2) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  out2[0] = c->grad_reused; out2[1] = c->grad_factored;
+  return AGP_OK;
+}
+
+int agp_set_factor_cache(agp_ctx* c, int32_t on) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  c->factor_cache = on != 0;
   return AGP_OK;
 }
 

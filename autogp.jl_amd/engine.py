@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi",
     "agp_debug_flow_trace", "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
-    "agp_predict_reuse_stats",
+    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache",
 ]
 COMM_ID_BYTES = 128
 
@@ -127,6 +127,8 @@ def load_library(path=None):
     lib.agp_extend_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_extend_stats.restype = C.c_int
     lib.agp_extend_reset.argtypes = [vp, C.c_int]; lib.agp_extend_reset.restype = C.c_int
     lib.agp_predict_reuse_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_predict_reuse_stats.restype = C.c_int
+    lib.agp_grad_reuse_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_grad_reuse_stats.restype = C.c_int
+    lib.agp_set_factor_cache.argtypes = [vp, C.c_int32]; lib.agp_set_factor_cache.restype = C.c_int
     lib.agp_extend_reserve.argtypes = [vp, C.c_int64, C.c_int32]; lib.agp_extend_reserve.restype = C.c_int
     i32p = C.POINTER(C.c_int32)
     lib.agp_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32p, i32p]; lib.agp_shard_range.restype = None
@@ -308,6 +310,16 @@ class GPEngine:
         out = (C.c_int64 * 2)()
         self._check(self._lib.agp_predict_reuse_stats(self._ctx, out))
         return {"reused": int(out[0]), "factored": int(out[1])}
+
+    def grad_reuse_stats(self):
+        """dict(reused, factored): particles a gradient sweep served from a resident factor / factored itself."""
+        out = (C.c_int64 * 2)()
+        self._check(self._lib.agp_grad_reuse_stats(self._ctx, out))
+        return {"reused": int(out[0]), "factored": int(out[1])}
+
+    def set_factor_cache(self, on):
+        """Whether coalesced agp_logpdf batches leave their factors in the store (default on)."""
+        self._check(self._lib.agp_set_factor_cache(self._ctx, 1 if on else 0))
 
     def extend_reset(self, release_memory=False):
         self._check(self._lib.agp_extend_reset(self._ctx, 1 if release_memory else 0))

@@ -174,6 +174,19 @@ function predict_reuse_stats(eng::Engine)
     return (reused = out[1], factored = out[2])
 end
 
+"(particles of gradient sweeps served from a resident factor, particles the gradient sweep factored itself): every
+leapfrog step of `Gen.hmc` is `update` (-> agp_logpdf) followed by `choice_gradients` (-> agp_logpdf_grad) at the same
+parameters; the value call leaves its factor in the engine's store and the gradient call starts from it."
+function grad_reuse_stats(eng::Engine)
+    out = Vector{Int64}(undef, 2)
+    GC.@preserve out check(eng, ccall((:agp_grad_reuse_stats, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), eng.ptr, out))
+    return (reused = out[1], factored = out[2])
+end
+
+"Whether the single-particle value calls keep their factors resident (default: on)."
+set_factor_cache!(eng::Engine, on::Bool) =
+    check(eng, ccall((:agp_set_factor_cache, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
+
 "The whole population over every GPU of the pool: shards by agp_shard_range, one sweep per device, log-weights
 all-gathered over RCCL inside the library (agp_logpdf_batch_multi)."
 function logpdf_batch(pool::EnginePool, nodes::Vector{<:GP.Node}, noises::Vector{Float64}, n::Integer=pool.engines[1].n_max)

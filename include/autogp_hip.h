@@ -126,6 +126,20 @@ int agp_extend_reserve(agp_ctx* ctx, int64_t n_cap, int32_t n_slots);
  * a training mean function (alpha would differ).  AGP_PREDICT_REUSE=0 disables.
  * out2 = { particles predicted from a resident factor, particles whose K11 was factored by the predictive pass } */
 int agp_predict_reuse_stats(agp_ctx* ctx, int64_t* out2);
+/* The single-particle entry agp_logpdf (coalesced inside the library) leaves its factors in the same store by default
+ * (AGP_FACTOR_CACHE=0 / agp_set_factor_cache(ctx, 0) restore plain sweeps), which gives Gen's own call sequences the
+ * reuse without any change on the Julia side:
+ *   - the reweight step scores every particle again on a longer prefix with unchanged parameters
+ *     (src/inference_smc_anneal_data.jl:127-141,206-217): an extension sweep;
+ *   - each leapfrog step of Gen.hmc is `update` (a value call) followed by `choice_gradients` at the SAME parameters
+ *     (src/inference_smc_anneal_data.jl:63-67): agp_logpdf_grad / agp_logpdf_grad_batch find the factor resident and
+ *     start at L^-T — the covariance build and the n^3/3 factorisation are not repeated;
+ *   - a value call repeated at unchanged parameters costs a lookup.
+ * Results are those of the from-scratch sweeps to rounding (the resident factor may come from a chain of extension
+ * sweeps, whose tiles are bit-identical to a from-scratch sweep of the same entry).
+ * out2 = { particles of gradient sweeps served from a resident factor, particles factored by the gradient sweep } */
+int agp_grad_reuse_stats(agp_ctx* ctx, int64_t* out2);
+int agp_set_factor_cache(agp_ctx* ctx, int32_t on);
 
 /* Value AND gradient: d logpdf / d theta for every (transformed) kernel parameter — out_grad has the
  * layout of `prm` (prm_off offsets; ChangePoint contributes d/dlocation, d/dscale) — and d logpdf / d noise.

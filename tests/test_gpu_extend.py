@@ -317,3 +317,88 @@ def test_predict_reuse_large_population_and_switch(pkg, monkeypatch):
         assert pred_err(a[0][ok], b[0][ok]) <= 1e-10 and pred_err(a[1][ok], b[1][ok]) <= 1e-10
     finally:
         e.close(); e0.close()
+
+
+def grad_err(a, b):
+    return np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))
+
+
+@pytest.mark.parametrize("env", [{}, {"AGP_FLOW": "0"}])
+@pytest.mark.parametrize("n", [300, 1024])
+def test_gradient_from_resident_factor(pkg, monkeypatch, env, n):
+    """Every leapfrog step of Gen.hmc is `update` (value) then `choice_gradients` (gradient) at the same parameters
+    (src/inference_smc_anneal_data.jl:63-67).  A gradient sweep finds the factors the value sweep left in the store and
+    starts at L^-T: same logpdf, gradient and info as the sweep that factors itself (to rounding) and as the analytic
+    oracle; particles that are not resident (or resident for another prefix, or not PD) are factored as before."""
+    import oracle.oracle as O
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = pkg.GPEngine(0)
+    try:
+        ts, xs = pkg.prior.synthetic_series(n, seed=31, shuffle=True)
+        nodes, noises = pkg.prior.sample_particles(np.random.default_rng(31), 24, max_depth=3)
+        bad = pkg.Linear(0.0, 0.0, -0.01)
+        e.set_data(ts, xs)
+        base = e.logpdf_grad_batch(nodes, noises, check=False)                # (lp, grads, gnoise, info): nothing resident
+        assert e.grad_reuse_stats()["reused"] == 0
+        e.logpdf_batch_extend(nodes[:16], noises[:16], check=False)           # resident for this prefix
+        e.logpdf_batch_extend(nodes[16:20], noises[16:20], n=n - 40, check=False)   # resident for another prefix
+        e.logpdf_batch_extend([bad], np.array([0.1]), check=False)            # resident, failed
+        pop = list(nodes) + [bad, nodes[2]]
+        nz = np.concatenate([noises, [0.1, noises[2]]])
+        got = e.logpdf_grad_batch(pop, nz, check=False)
+        st = e.grad_reuse_stats()
+        assert st["reused"] == int((base[3][:16] == 0).sum()) >= 12, st
+        assert got[3][24] > 0 and np.isnan(got[0][24])
+        assert same(got[3][:24], base[3])
+        ok = base[3] == 0
+        assert lp_err(got[0][:24][ok], base[0][ok]).max() <= 1e-12
+        for i in np.flatnonzero(ok):
+            assert grad_err(got[1][i], base[1][i]) <= 1e-9 and abs(got[2][i] - base[2][i]) <= 1e-9 * max(1.0, abs(base[2][i]))
+        assert got[0][25] == got[0][2] and np.array_equal(got[1][25], got[1][2])          # the duplicate
+        for i in (0, 5, 17):
+            if not ok[i]:
+                continue
+            lp, g, gn = O.gp_logpdf_grad(nodes[i].to_tuple(), float(noises[i]), ts, xs)
+            assert abs(got[0][i] - lp) <= LP_TOL * max(1.0, abs(lp))
+            assert grad_err(got[1][i], np.asarray(g)) <= 1e-7 and abs(got[2][i] - gn) <= 1e-7 * max(1.0, abs(gn))
+    finally:
+        e.close()
+
+
+def test_single_particle_calls_use_the_store(pkg, monkeypatch):
+    """agp_logpdf (Gen's per-particle call, coalesced in the library) leaves its factor in the store: the same particle on
+    a longer prefix is an extension, agp_logpdf_grad at the same parameters reuses the factor, a predictive call too.
+    AGP_FACTOR_CACHE=0 / set_factor_cache(False) restore plain sweeps; values agree to rounding either way."""
+    ts, xs = pkg.prior.synthetic_series(700, seed=37, shuffle=True)
+    k = pkg.Linear(0.1, 0.3, 0.7) + pkg.Periodic(0.96, 0.21, 1.1) * pkg.SquaredExponential(0.47, 0.8)
+    e = pkg.GPEngine(0)
+    monkeypatch.setenv("AGP_FACTOR_CACHE", "0")
+    e0 = pkg.GPEngine(0)
+    try:
+        e.set_data(ts, xs); e0.set_data(ts, xs)
+        a1 = e.logpdf(k, 0.06, n=400); b1 = e0.logpdf(k, 0.06, n=400)
+        a2 = e.logpdf(k, 0.06, n=700); b2 = e0.logpdf(k, 0.06, n=700)
+        assert abs(a1 - b1) <= 1e-11 * abs(b1) and abs(a2 - b2) <= 1e-11 * abs(b2)
+        st = e.extend_stats()
+        assert st["extended"] == 1 and st["from_scratch"] == 1 and st["tile_rows_reused"] == 3
+        assert e0.extend_stats()["from_scratch"] == 0
+        ga = e.logpdf_grad(k, 0.06, n=700); gb = e0.logpdf_grad(k, 0.06, n=700)
+        assert e.grad_reuse_stats() == {"reused": 1, "factored": 0} and e0.grad_reuse_stats()["reused"] == 0
+        assert abs(ga[0] - gb[0]) <= 1e-11 * abs(gb[0]) and grad_err(np.asarray(ga[1]), np.asarray(gb[1])) <= 1e-9
+        assert abs(ga[2] - gb[2]) <= 1e-9 * max(1.0, abs(gb[2]))
+        tp = np.linspace(0, 1.2, 50)
+        pa = e.predict_batch([k], [0.06], tp); pb = e0.predict_batch([k], [0.06], tp)
+        assert e.predict_reuse_stats()["reused"] == 1
+        assert pred_err(pa[0], pb[0]) <= 1e-10 and pred_err(pa[1], pb[1]) <= 1e-10
+        # different parameters: nothing resident
+        gc = e.logpdf_grad(k, 0.07, n=700)
+        assert e.grad_reuse_stats() == {"reused": 1, "factored": 1}
+        assert np.isfinite(gc[0])
+        # switched off at run time: plain sweeps, the store is left alone
+        e.set_factor_cache(False)
+        before = e.extend_stats()
+        a3 = e.logpdf(k, 0.08, n=700)
+        assert e.extend_stats() == before and abs(a3 - e0.logpdf(k, 0.08, n=700)) <= 1e-11 * abs(a3)
+    finally:
+        e.close(); e0.close()

@@ -194,9 +194,15 @@ def test_logpdf_batch_vs_oracle(pkg, engine, n, P, max_depth):
     ref = np.array([O.gp_logpdf(nd.to_tuple(), float(nz), ts, xs) for nd, nz in zip(nodes, noises)])
     assert (info == 0).all()
     assert lp_err(lp, ref).max() <= LP_TOL
-    # single-particle entry (what Gen calls) agrees with the batch entry bit for bit
+    # single-particle entry (what Gen calls): bit for bit the batch entry's value when it runs the plain sweep, to rounding
+    # when it goes through the factor store (the default: its sweep evaluates every tile inside the factorisation kernels)
     one = engine.logpdf(nodes[0], float(noises[0]))
-    assert one == lp[0]
+    assert abs(one - lp[0]) <= 1e-12 * max(1.0, abs(lp[0]))
+    engine.set_factor_cache(False)
+    try:
+        assert engine.logpdf(nodes[0], float(noises[0])) == lp[0]
+    finally:
+        engine.set_factor_cache(True)
 
 
 @pytest.mark.parametrize("n,P", [(300, 300), (521, 263), (1000, 257)])
@@ -642,14 +648,19 @@ def test_concurrent_callers(pkg, engine):
     nodes, noises = pkg.prior.sample_particles(np.random.default_rng(12), 24, max_depth=3)
     engine.set_data(ts, xs)
     ref, _ = engine.logpdf_batch(nodes, noises)
-    out = np.zeros(24)
+    for cache in (True, False):          # through the factor store (default): to rounding; plain sweeps: bit for bit
+        engine.set_factor_cache(cache)
+        try:
+            out = np.zeros(24)
 
-    def work(i):
-        for _ in range(3):
-            out[i] = engine.logpdf(nodes[i], float(noises[i]))
-    th = [threading.Thread(target=work, args=(i,)) for i in range(24)]
-    [t.start() for t in th]; [t.join() for t in th]
-    assert np.array_equal(out, ref)
+            def work(i):
+                for _ in range(3):
+                    out[i] = engine.logpdf(nodes[i], float(noises[i]))
+            th = [threading.Thread(target=work, args=(i,)) for i in range(24)]
+            [t.start() for t in th]; [t.join() for t in th]
+            assert np.array_equal(out, ref) if not cache else lp_err(out, ref).max() <= 1e-12
+        finally:
+            engine.set_factor_cache(True)
 
 
 def test_coalescing_of_single_particle_callers(pkg, engine):
@@ -662,6 +673,7 @@ def test_coalescing_of_single_particle_callers(pkg, engine):
     ref_a, _ = engine.logpdf_batch(nodes, noises, n=300)
     ref_b, _ = engine.logpdf_batch(nodes, noises, n=170)
     engine.set_coalesce_window(20000)
+    engine.set_factor_cache(False)         # plain sweeps: the callers get the batch entry's values bit for bit
     c0, b0 = engine.coalesce_stats()
     out = np.zeros(32); errs = []
     barrier = threading.Barrier(33)
@@ -684,6 +696,7 @@ def test_coalescing_of_single_particle_callers(pkg, engine):
     th = [threading.Thread(target=work, args=(i,)) for i in range(32)] + [threading.Thread(target=bad)]
     [t.start() for t in th]; [t.join() for t in th]
     engine.set_coalesce_window(300)
+    engine.set_factor_cache(True)
     assert not errs, errs
     exp = np.where(np.arange(32) % 2 == 0, ref_a, ref_b)
     assert np.array_equal(out, exp)
@@ -699,22 +712,34 @@ def test_coalescing_of_single_particle_gradient_callers(pkg, engine):
     nodes, noises = pkg.prior.sample_particles(np.random.default_rng(21), 24, max_depth=3, max_size=15)
     engine.set_data(ts, xs)
     ref = engine.logpdf_grad_batch(nodes, noises, check=False)
-    out = [None] * 48
-    def work(i):
-        j = i % 24
-        if i < 24:
-            out[i] = engine.logpdf_grad(nodes[j], float(noises[j]), check=False)
-        else:
-            out[i] = engine.logpdf(nodes[j], float(noises[j]), check=False)
-    th = [threading.Thread(target=work, args=(i,)) for i in range(48)]
-    for t in th: t.start()
-    for t in th: t.join()
-    for i in range(24):
-        if ref[3][i] != 0:
-            continue
-        lp, g, gn = out[i]
-        assert lp == ref[0][i] and gn == ref[2][i] and np.array_equal(g, ref[1][i])
-        assert out[24 + i] == ref[0][i]
+    for cache in (False, True):
+        # plain sweeps: bit for bit.  Through the factor store (default) a gradient caller may find the factor its
+        # value-calling twin has just left there: to rounding.
+        engine.set_factor_cache(cache)
+        try:
+            out = [None] * 48
+            def work(i):
+                j = i % 24
+                if i < 24:
+                    out[i] = engine.logpdf_grad(nodes[j], float(noises[j]), check=False)
+                else:
+                    out[i] = engine.logpdf(nodes[j], float(noises[j]), check=False)
+            th = [threading.Thread(target=work, args=(i,)) for i in range(48)]
+            for t in th: t.start()
+            for t in th: t.join()
+        finally:
+            engine.set_factor_cache(True)
+        for i in range(24):
+            if ref[3][i] != 0:
+                continue
+            lp, g, gn = out[i]
+            if not cache:
+                assert lp == ref[0][i] and gn == ref[2][i] and np.array_equal(g, ref[1][i])
+                assert out[24 + i] == ref[0][i]
+            else:
+                assert abs(lp - ref[0][i]) <= 1e-12 * max(1.0, abs(ref[0][i])) and abs(gn - ref[2][i]) <= 1e-9 * max(1.0, abs(ref[2][i]))
+                assert np.all(np.abs(g - ref[1][i]) <= 1e-9 * np.maximum(1.0, np.abs(ref[1][i])))
+                assert abs(out[24 + i] - ref[0][i]) <= 1e-12 * max(1.0, abs(ref[0][i]))
 
 
 def test_randomised_soak(pkg, engine):

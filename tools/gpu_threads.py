@@ -15,8 +15,8 @@ for T in (8, 64, 256):
         eng.set_coalesce_window(win)
         reps = 4
         def work(i):
-            for _ in range(reps):
-                eng.logpdf(nodes[i], float(noises[i]), check=False)
+            for r in range(reps):      # fresh parameters per call (resident factors would make a repeated call a lookup)
+                eng.logpdf(nodes[i], float(noises[i]) * (1.0 + 1e-7 * (r + 1 + 10 * win)), check=False)
         th = [threading.Thread(target=work, args=(i,)) for i in range(T)]
         c0, b0 = eng.coalesce_stats()
         t0 = time.time(); [t.start() for t in th]; [t.join() for t in th]; dt = time.time() - t0

@@ -56,7 +56,10 @@ int main(int argc, char** argv) {
       th.emplace_back([&, t] {
         for (int r = 0; r < reps; ++r) {
           int32_t info = 0;
-          const Particle& p = ps[t];
+          Particle& p = ps[t];
+          // FRESH parameters at every call (an MCMC move proposes new values): the library keeps the factors of value
+          // calls resident, a repeated call at unchanged parameters would only measure the lookup
+          p.noise *= 1.0 + 1e-7;
           double g[64], gn = 0.0;       // trees of depth <= 2: at most 4 leaves x 3 parameters
           const int rc = grad ? agp_logpdf_grad(ctx, n, p.ops.data(), (int32_t)p.ops.size(), p.prm.data(), (int32_t)p.prm.size(),
                                                 p.noise, &lp[t], g, &gn, &info)
