@@ -801,7 +801,7 @@ int store_lookup(agp_ctx* c, const std::vector<std::string>& keys, const std::ve
 // Copies the resident factors (tile rows < nt1, inverse blocks, forward-solve vector, partials) of the particles with
 // src_slot >= 0 into a workspace laid out for Pc particles; ready[p] = nt1.
 void launch_gather(agp_ctx* c, hipStream_t st, int Pc, int nt1, double* dstA, long long dst_strideA, double* dstW, int dst_wsteps,
-                   double* dstV, long long dst_ldv, double* dstPart, int dst_ntp, const int32_t* d_src, int* ready) {
+                   double* dstV, long long dst_ldv, double* dstPart, int dst_ntp, const int32_t* d_src, int* ready, bool tiles = true) {
   agp_ctx::FactorStore& fs = c->store;
   GatherArgs ga = {};
   ga.dstA = dstA; ga.dst_strideA = dst_strideA; ga.srcA = fs.A.as<double>(); ga.src_strideA = fs.strideA;
@@ -812,6 +812,7 @@ void launch_gather(agp_ctx* c, hipStream_t st, int Pc, int nt1, double* dstA, lo
   ga.src_strideV = (long long)fs.nt_cap * NB; ga.nV = (long long)nt1 * NB;
   ga.dstP = dstPart; ga.dst_strideP = 2LL * dst_ntp; ga.srcP = fs.partial.as<double>(); ga.src_strideP = 2LL * fs.nt_cap;
   ga.nP = dstPart ? 2LL * nt1 : 0;
+  if (!tiles) { ga.nA = 0; ga.nW = 0; }      // the consumer reads L and the inverse blocks in place
   ga.src_slot = d_src; ga.ready = ready; ga.nt1 = nt1;
   const int gx = (int)std::max<long long>(1, std::min<long long>(128, (ga.nA / 2 + 255) / 256));
   hipLaunchKernelGGL(k_gather_factor, dim3(gx, Pc), dim3(256), 0, st, ga);
@@ -1006,10 +1007,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         cv.strideA = strideA; cv.P = Pg; cv.logdt = ge_tab ? c->d_logdt : nullptr;
         int i0min = 0;
         if (n_hit > 0) {
-          // resident factors: tiles, inverse blocks, forward-solve vector and partials come from the store
+          // resident factors: forward-solve vector and partials are copied out of the store; L and the inverse blocks
+          // are read in place by the L^-T kernels (the store mutex is held to the end of the sweep)
           launch_gather(c, q, Pg, nt, cv.A, strideA, s->W.as<double>() + (size_t)g0 * NSB * 256 * wsteps, wsteps,
                         s->vec.as<double>() + (size_t)g0 * n_pad, n_pad, s->partial.as<double>() + (size_t)g0 * 2 * nt, nt,
-                        d_src + p0 + g0, s->ready.as<int>() + g0);
+                        d_src + p0 + g0, s->ready.as<int>() + g0, /*tiles=*/false);
           cv.i0 = d_i0 + p0 + g0;
           i0min = nt;
           for (int r = 0; r < Pg; ++r) i0min = std::min(i0min, (int)i0v[(size_t)p0 + g0 + r]);
@@ -1088,6 +1090,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           ga.tt = c->d_ts; ga.logdt = c->logdt_ok ? c->d_logdt : nullptr; ga.gpart = s->gpart.as<double>() + (size_t)g0 * ntiles * gstride; ga.gstride = gstride;
           ga.gmap = s->gmap.as<int32_t>(); ga.out_off = s->goff.as<int32_t>() + p0 + g0;
           ga.pmap = d_map + p0 + g0; ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
+          if (n_hit > 0) {
+            ga.lslot = d_src + p0 + g0; ga.Lsrc = c->store.A.as<double>(); ga.Lstride = c->store.strideA;
+            ga.Wsrc = c->store.W.as<double>(); ga.Wnt = c->store.nt_cap;
+          }
           const int Pg8 = (Pg + 7) / 8;
           if (c->trtri_chain) {
             hipLaunchKernelGGL(k_trtri_chain, dim3(8 * Pg8 * nt), dim3(256), 0, q, ga);

@@ -145,6 +145,9 @@ struct GradArgs {
   const int32_t* pmap;   // sorted particle -> caller particle
   const int32_t* plist;  // k_grad_tiles: particles of this launch (indices into the sorted group)
   int tape_off;          // k_grad_contract<0>: offset (doubles) of the LDS tape inside the dynamic shared memory
+  // resident factors (nullable): particle p with lslot[p] >= 0 reads L and the inverse blocks from the factor store
+  // (slot lslot[p]; Lstride doubles per slot, Wnt block columns per slot) instead of A / W — nothing is copied
+  const int32_t* lslot; const double* Lsrc; long long Lstride; const double* Wsrc; int Wnt;
   double* out_grad;
   double* out_gnoise;
 };
@@ -191,7 +194,9 @@ __global__ __launch_bounds__(256, 2) void k_trtri_step(GradArgs a) {
   if (p >= a.P) return;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   const int row0 = 32 * w + 2 * l15;
-  const double* __restrict__ Lp = a.A + (long long)p * a.strideA;
+  const int lsl = a.lslot != nullptr ? a.lslot[p] : -1;
+  const double* __restrict__ Lp = lsl >= 0 ? a.Lsrc + (long long)lsl * a.Lstride : a.A + (long long)p * a.strideA;
+  const double* __restrict__ Wp = lsl >= 0 ? a.Wsrc + (long long)lsl * a.Wnt * NSB * 256 : a.W + (long long)p * a.nt * NSB * 256;
   double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
 
   // acc = -C,  C = d_ji I - sum_k Z(j,k) L(i,k)^T
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_step(GradArgs a) {
              [&](int s) { return Zp + zoff(j, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
              [&](int s) { return Lp + tile_off(i, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
              sm, tid, l15, lq, row0);
-  solve_in_regs(acc, Lp + tile_off(i, i), a.W + ((long long)p * a.nt + i) * NSB * 256, sm, tid, l);
+  solve_in_regs(acc, Lp + tile_off(i, i), Wp + (long long)i * NSB * 256, sm, tid, l);
   double* __restrict__ Tt = Zp + zoff(j, i);
 #pragma unroll
   for (int cb = 0; cb < NSB; ++cb)
@@ -232,7 +237,9 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
   if (p >= a.P) return;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   const int row0 = 32 * w + 2 * l15;
-  const double* __restrict__ Lp = a.A + (long long)p * a.strideA;
+  const int lsl = a.lslot != nullptr ? a.lslot[p] : -1;
+  const double* __restrict__ Lp = lsl >= 0 ? a.Lsrc + (long long)lsl * a.Lstride : a.A + (long long)p * a.strideA;
+  const double* __restrict__ Wp = lsl >= 0 ? a.Wsrc + (long long)lsl * a.Wnt * NSB * 256 : a.W + (long long)p * a.nt * NSB * 256;
   double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
 #pragma unroll 1
   for (int i = j; i < a.nt; ++i) {
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
                [&](int s) { return Zp + zoff(j, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
                [&](int s) { return Lp + tile_off(i, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
                sm, tid, l15, lq, row0);
-    solve_in_regs(acc, Lp + tile_off(i, i), a.W + ((long long)p * a.nt + i) * NSB * 256, sm, tid, l);
+    solve_in_regs(acc, Lp + tile_off(i, i), Wp + (long long)i * NSB * 256, sm, tid, l);
     double* __restrict__ Tt = Zp + zoff(j, i);
 #pragma unroll
     for (int cb = 0; cb < NSB; ++cb)
