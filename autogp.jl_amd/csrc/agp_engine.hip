@@ -1733,6 +1733,8 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       launch_gather(c, st, Pc, nt1, s->A.as<double>(), strideA, s->W.as<double>(), nt1, s->vec.as<double>(), ntot, nullptr, 0,
                     d_src + p0, s->ready.as<int>() + p0);
       HIPCHK(c, hipGetLastError());
+      // (Reading L11 and the inverse blocks in place — a second base pointer for the training rows in chol_tile — was
+      // measured: the streamed config 5 went 412 -> 406 ms, the dataflow kernel gained 4 spilled VGPRs; the copy stays.)
       if (p0 + chunk >= P) {
         // the store may change again once the last copy has been made
         HIPCHK(c, hipStreamSynchronize(st));
@@ -2255,25 +2257,33 @@ int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
   if (nt_cap == fs.nt_cap && n_slots == fs.n_slots) return AGP_OK;
   const long long strideA = (long long)nt_cap * (nt_cap + 1) / 2 * NB2;
   DevBuf A, W, vec, partial, info, ready;
-  HIPCHK(c, A.ensure((size_t)strideA * 8 * n_slots));
-  HIPCHK(c, W.ensure(sizeof(double) * NSB * 256 * (size_t)nt_cap * n_slots));
-  HIPCHK(c, vec.ensure(sizeof(double) * (size_t)nt_cap * NB * n_slots));
-  HIPCHK(c, partial.ensure(sizeof(double) * 2 * (size_t)nt_cap * n_slots));
-  HIPCHK(c, info.ensure(sizeof(int) * (size_t)n_slots));
-  HIPCHK(c, ready.ensure(sizeof(int) * (size_t)n_slots));
-  HIPCHK(c, hipMemset(info.p, 0, sizeof(int) * (size_t)n_slots));
+  // (a failed (re)allocation leaves the store as it was: the caller then runs without caching)
+  auto bail = [&](hipError_t e, const char* what) {
+    A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release();
+    (void)hipGetLastError();
+    return fail(c, AGP_ERR_HIP, std::string("factor store: ") + what + ": " + hipGetErrorString(e));
+  };
+#define STORECHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(e_, #expr); } while (0)
+  STORECHK(A.ensure((size_t)strideA * 8 * n_slots));
+  STORECHK(W.ensure(sizeof(double) * NSB * 256 * (size_t)nt_cap * n_slots));
+  STORECHK(vec.ensure(sizeof(double) * (size_t)nt_cap * NB * n_slots));
+  STORECHK(partial.ensure(sizeof(double) * 2 * (size_t)nt_cap * n_slots));
+  STORECHK(info.ensure(sizeof(int) * (size_t)n_slots));
+  STORECHK(ready.ensure(sizeof(int) * (size_t)n_slots));
+  STORECHK(hipMemset(info.p, 0, sizeof(int) * (size_t)n_slots));
   const int keep = std::min(n_slots, fs.n_slots), nto = std::min(nt_cap, fs.nt_cap);
   if (keep > 0 && nto > 0) {
     auto cp = [&](DevBuf& dst, size_t dpitch, DevBuf& src, size_t spitch, size_t width) {
       return hipMemcpy2D(dst.p, dpitch, src.p, spitch, width, (size_t)keep, hipMemcpyDeviceToDevice);
     };
     const size_t tiles_o = (size_t)nto * (nto + 1) / 2;
-    HIPCHK(c, cp(A, (size_t)strideA * 8, fs.A, (size_t)fs.strideA * 8, tiles_o * NB2 * 8));
-    HIPCHK(c, cp(W, (size_t)nt_cap * NSB * 256 * 8, fs.W, (size_t)fs.nt_cap * NSB * 256 * 8, (size_t)nto * NSB * 256 * 8));
-    HIPCHK(c, cp(vec, (size_t)nt_cap * NB * 8, fs.vec, (size_t)fs.nt_cap * NB * 8, (size_t)nto * NB * 8));
-    HIPCHK(c, cp(partial, (size_t)nt_cap * 16, fs.partial, (size_t)fs.nt_cap * 16, (size_t)nto * 16));
-    HIPCHK(c, hipMemcpy(info.p, fs.info.p, sizeof(int) * (size_t)keep, hipMemcpyDeviceToDevice));
+    STORECHK(cp(A, (size_t)strideA * 8, fs.A, (size_t)fs.strideA * 8, tiles_o * NB2 * 8));
+    STORECHK(cp(W, (size_t)nt_cap * NSB * 256 * 8, fs.W, (size_t)fs.nt_cap * NSB * 256 * 8, (size_t)nto * NSB * 256 * 8));
+    STORECHK(cp(vec, (size_t)nt_cap * NB * 8, fs.vec, (size_t)fs.nt_cap * NB * 8, (size_t)nto * NB * 8));
+    STORECHK(cp(partial, (size_t)nt_cap * 16, fs.partial, (size_t)fs.nt_cap * 16, (size_t)nto * 16));
+    STORECHK(hipMemcpy(info.p, fs.info.p, sizeof(int) * (size_t)keep, hipMemcpyDeviceToDevice));
   }
+#undef STORECHK
   fs.A.release(); fs.W.release(); fs.vec.release(); fs.partial.release(); fs.info.release(); fs.ready.release();
   fs.A = A; fs.W = W; fs.vec = vec; fs.partial = partial; fs.info = info; fs.ready = ready;
   // slots beyond the kept range disappear; factors longer than the new capacity cannot exist (nt_cap only grows)
@@ -2365,7 +2375,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     if ((size_t)want_slots * per > budget) want_slots = (int)std::min<size_t>((size_t)want_slots, budget / per);
     if (want_slots < U) { lk.unlock(); return plain(); }      // population larger than the store may hold: no caching
     const int rc = store_resize(c, want_nt, want_slots);
-    if (rc) { lk.unlock(); return rc; }
+    if (rc) { lk.unlock(); return plain(); }                  // no memory for the store right now: no caching
   }
   const uint64_t call = ++fs.clock;
   std::vector<int32_t> slot(U, -1), i0(U, 0);

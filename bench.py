@@ -240,6 +240,9 @@ def main():
         intrsm = os.environ.get("AGP_INTRSM", "1") != "0"
         sd_env = os.environ.get("AGP_SPLIT_DIAG", "-1")
         split_diag = intrsm and (sd_env == "1" or (sd_env not in ("0", "1") and P >= 256))
+        # (what actually ran decides: non-default schedule switches — AGP_STREAMS, AGP_FLOW — move a large shard onto the
+        # dataflow kernel, which has no separate diagonal launches)
+        split_diag = split_diag and acc.get("n_trsm_launches", 0.0) > 0 and acc.get("chol_trsm_ms", 0.0) > 0
         diag_block = None
         if split_diag:
             kernel_name = "k_chol_update<true,DCOV,true,2,TAB>"
