@@ -2791,9 +2791,9 @@ int agp_allgather_logweights(agp_ctx* c, double* inout_lw, int32_t P) {
 // particles over the contexts of agp_init_multi, run each shard's sweep from its own host thread with the results
 // left on its device, all-gather the log-weights over RCCL (one group call over the node's communicators), and
 // hand the complete vector back from device 0.  Every device ends up holding the full vector.
-int agp_logpdf_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off,
-                           const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
-                           double* out_logpdf, int32_t* out_info) {
+static int logpdf_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off,
+                                   const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
+                                   double* out_logpdf, int32_t* out_info, bool extend) {
   if (!ctxs || n_dev < 1 || !ctxs[0]) return fail(nullptr, AGP_ERR_ARG, "bad context list");
   agp_ctx* c0 = ctxs[0];
   if (P < 0 || n < 0) return fail(c0, AGP_ERR_ARG, "negative size");
@@ -2820,8 +2820,17 @@ int agp_logpdf_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32
       std::vector<int32_t> oo((size_t)Pl + 1), po((size_t)Pl + 1);
       for (int i = 0; i <= Pl; ++i) { oo[i] = op_off[lo + i] - op_off[lo]; po[i] = prm_off[lo + i] - prm_off[lo]; }
       double* d_loc = c->comm_all.as<double>() + P;
-      rcs[d] = logpdf_batch_impl(c, n, Pl, oo.data(), ops + op_off[lo], po.data(), prm + prm_off[lo], noise + lo, nullptr,
-                                 out_info + lo, d_loc, nullptr, nullptr, false);
+      if (extend) {
+        // every device keeps the factors of ITS shard resident (block sharding is stable while the population order is;
+        // a particle that lands on another device after resampling is simply factored from scratch there)
+        std::vector<double> hl((size_t)Pl);
+        rcs[d] = extend_impl(c, n, Pl, oo.data(), ops + op_off[lo], po.data(), prm + prm_off[lo], noise + lo, hl.data(), out_info + lo);
+        if (rcs[d] == AGP_OK && hipMemcpy(d_loc, hl.data(), sizeof(double) * (size_t)Pl, hipMemcpyHostToDevice) != hipSuccess)
+          rcs[d] = fail(c, AGP_ERR_HIP, "copy of the shard's log-weights failed");
+      } else {
+        rcs[d] = logpdf_batch_impl(c, n, Pl, oo.data(), ops + op_off[lo], po.data(), prm + prm_off[lo], noise + lo, nullptr,
+                                   out_info + lo, d_loc, nullptr, nullptr, false);
+      }
     });
   }
   for (auto& t : th) t.join();
@@ -2852,6 +2861,20 @@ int agp_logpdf_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32
     HIPCHK(c0, hipStreamSynchronize(ctxs[d]->comm_stream));
   }
   return AGP_OK;
+}
+
+int agp_logpdf_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off,
+                           const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
+                           double* out_logpdf, int32_t* out_info) {
+  return logpdf_batch_multi_impl(ctxs, n_dev, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, false);
+}
+
+// The same with resident factors: every device runs its shard as an extension sweep (agp_logpdf_batch_extend) — the
+// reweight step of data annealing for ONE process driving the node.
+int agp_logpdf_batch_extend_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off,
+                                  const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
+                                  double* out_logpdf, int32_t* out_info) {
+  return logpdf_batch_multi_impl(ctxs, n_dev, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, true);
 }
 
 }  // extern "C"

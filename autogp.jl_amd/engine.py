@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_debug_mfma_peak", "agp_debug_math", "agp_debug_gemm_variant", "agp_set_profiling", "agp_get_timing", "agp_get_launch_times",
     "agp_set_workspace_limit", "agp_set_coalesce_window", "agp_get_coalesce_stats", "agp_get_dedup_stats",
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
-    "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi",
+    "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi", "agp_logpdf_batch_extend_multi",
     "agp_debug_flow_trace", "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
     "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache",
 ]
@@ -141,6 +141,8 @@ def load_library(path=None):
     lib.agp_allgather_logweights_device.argtypes = [vp, vp, C.c_int32, vp, vp]; lib.agp_allgather_logweights_device.restype = C.c_int
     lib.agp_logpdf_batch_multi.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, ip]
     lib.agp_logpdf_batch_multi.restype = C.c_int
+    lib.agp_logpdf_batch_extend_multi.argtypes = lib.agp_logpdf_batch_multi.argtypes
+    lib.agp_logpdf_batch_extend_multi.restype = C.c_int
     if path is None:
         _lib = lib
     return lib
@@ -513,14 +515,16 @@ class GPEngineMulti:
         for e in self.engines:
             e.n_max = self.n_max
 
-    def logpdf_batch(self, nodes, noises, n=None, check=True, programs=None):
+    def logpdf_batch(self, nodes, noises, n=None, check=True, programs=None, extend=False):
+        """extend=True: every device runs its shard as an extension sweep (agp_logpdf_batch_extend_multi)."""
         n = self.n_max if n is None else int(n)
         op_off, ops, prm_off, prm = programs if programs is not None else _gp.encode_batch(nodes)
         P = op_off.shape[0] - 1
         noises = _f64(noises)
         out = np.empty(P); info = np.empty(P, dtype=np.int32)
-        self._check(self._lib.agp_logpdf_batch_multi(self._arr, self._n, n, P, _ip(op_off), _u8(ops), _ip(prm_off), _dp(prm),
-                                                     _dp(noises), _dp(out), _ip(info)))
+        fn = self._lib.agp_logpdf_batch_extend_multi if extend else self._lib.agp_logpdf_batch_multi
+        self._check(fn(self._arr, self._n, n, P, _ip(op_off), _u8(ops), _ip(prm_off), _dp(prm),
+                       _dp(noises), _dp(out), _ip(info)))
         if check and (info > 0).any():
             p = int(np.argmax(info > 0))
             raise PosDefException(int(info[p]), p)

@@ -189,14 +189,22 @@ set_factor_cache!(eng::Engine, on::Bool) =
 
 "The whole population over every GPU of the pool: shards by agp_shard_range, one sweep per device, log-weights
 all-gathered over RCCL inside the library (agp_logpdf_batch_multi)."
-function logpdf_batch(pool::EnginePool, nodes::Vector{<:GP.Node}, noises::Vector{Float64}, n::Integer=pool.engines[1].n_max)
+function logpdf_batch(pool::EnginePool, nodes::Vector{<:GP.Node}, noises::Vector{Float64}, n::Integer=pool.engines[1].n_max; extend::Bool=false)
     P = length(nodes)
     op_off, ops, prm_off, prm = encode_batch(nodes)
     out = Vector{Float64}(undef, P); info = Vector{Int32}(undef, P)
     ptrs = [e.ptr for e in pool.engines]
-    GC.@preserve ptrs op_off ops prm_off prm noises out info check(pool.engines[1], ccall((:agp_logpdf_batch_multi, LIB), Cint,
-        (Ptr{Ptr{Cvoid}}, Int32, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
-        ptrs, length(ptrs), n, P, op_off, ops, prm_off, prm, noises, out, info))
+    # extend = true: every device keeps the factors of its shard resident (agp_logpdf_batch_extend_multi)
+    GC.@preserve ptrs op_off ops prm_off prm noises out info begin
+        rc = extend ?
+            ccall((:agp_logpdf_batch_extend_multi, LIB), Cint,
+                (Ptr{Ptr{Cvoid}}, Int32, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                ptrs, length(ptrs), n, P, op_off, ops, prm_off, prm, noises, out, info) :
+            ccall((:agp_logpdf_batch_multi, LIB), Cint,
+                (Ptr{Ptr{Cvoid}}, Int32, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                ptrs, length(ptrs), n, P, op_off, ops, prm_off, prm, noises, out, info)
+        check(pool.engines[1], rc)
+    end
     return out, info
 end
 

@@ -240,6 +240,13 @@ int agp_logpdf_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32
                            const int32_t* op_off, const uint8_t* ops,
                            const int32_t* prm_off, const double* prm,
                            const double* noise, double* out_logpdf /* P */, int32_t* out_info /* P */);
+/* The same with resident factors (agp_logpdf_batch_extend per shard): the reweight step of data annealing / add_data!
+ * (src/inference_smc_anneal_data.jl:206-217, src/api.jl:426-443) for one process driving the node.  Every device keeps
+ * the factors of its own shard; a particle that lands on another device after resampling is factored from scratch there. */
+int agp_logpdf_batch_extend_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P,
+                                  const int32_t* op_off, const uint8_t* ops,
+                                  const int32_t* prm_off, const double* prm,
+                                  const double* noise, double* out_logpdf /* P */, int32_t* out_info /* P */);
 
 /* ---- measurement / debugging hooks (not part of the reference surface) ---- */
 

@@ -229,6 +229,15 @@ def test_multi_device_context_pool(pkg):
         assert np.array_equal(info, rinfo)
         ok = info == 0
         assert lp_err(lp[ok], ref[ok]).max() <= 1e-10
+        # the same with resident factors per device (agp_logpdf_batch_extend_multi) along a short schedule
+        for step in (300, 520, 700):
+            lpe, infoe = multi.logpdf_batch(nodes, noises, n=step, check=False, extend=True)
+            refe, rinfoe = eng.logpdf_batch(nodes, noises, n=step, check=False)
+            oke = infoe == 0
+            assert np.array_equal(infoe, rinfoe) and lp_err(lpe[oke], refe[oke]).max() <= 1e-10
+        st = eng.extend_stats()
+        U = len({(pkg.encode(nd)[0].tobytes(), pkg.encode(nd)[1].tobytes(), float(z)) for nd, z in zip(nodes, noises)})
+        assert st["extended"] == 2 * U and st["from_scratch"] == U
         with pytest.raises(pkg.AGPError):
             pkg.GPEngineMulti([0, 0])
     finally:
