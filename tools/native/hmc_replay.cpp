@@ -140,10 +140,15 @@ int main(int argc, char** argv) {
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   agp_get_coalesce_stats(ctx, &c1, &b1);
   const double it_total = (double)T * iters;
-  printf("{\"tool\": \"hmc_replay\", \"n\": %d, \"threads\": %d, \"hmc_iterations_per_particle\": %d, \"L\": %d, \"eps\": %g, "
+  int64_t gr[2] = {0, 0};
+  agp_grad_reuse_stats(ctx, gr);      // gradient calls that started from the factor of the value call before them
+  const char* fc = getenv("AGP_FACTOR_CACHE");
+  printf("{\"tool\": \"hmc_replay\", \"factor_cache\": %s, \"gradient_particles_from_resident_factor\": %lld, \"gradient_particles_factored\": %lld, "
+         "\"n\": %d, \"threads\": %d, \"hmc_iterations_per_particle\": %d, \"L\": %d, \"eps\": %g, "
          "\"seconds\": %.4f, \"hmc_iterations_per_s\": %.2f, \"seconds_per_iteration_of_the_population\": %.4f, "
          "\"gradient_calls\": %lld, \"value_calls\": %lld, \"calls_per_s\": %.1f, \"coalesced_batches\": %lld, \"mean_batch\": %.1f, "
          "\"accepted_param_moves\": %lld, \"failed_calls\": %lld}\n",
+         (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
          n, T, iters, L, eps, dt, it_total / dt, dt / iters, cnt.grad.load(), cnt.value.load(),
          (double)(cnt.grad.load() + cnt.value.load()) / dt, (long long)(b1 - b0),
          (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), cnt.accepted.load(), cnt.failed.load());

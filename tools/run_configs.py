@@ -19,12 +19,15 @@ def sweep(nodes, noises, n, reps=5):
     progs = pkg.encode_batch(nodes)
     gc.collect(); gc.disable()          # a generation-2 collection inside the timed calls showed up as a 15 ms outlier
     eng.logpdf_batch(None, noises, n=n, check=False, programs=progs)
-    t0 = time.time()
-    for _ in range(reps):
+    times = []
+    for _ in range(max(3, reps)):
+        t0 = time.perf_counter()
         lp, info = eng.logpdf_batch(None, noises, n=n, check=False, programs=progs)
-    dt = (time.time() - t0) / reps
+        times.append(time.perf_counter() - t0)
     gc.enable()
-    return dt, lp, info
+    # median of the per-call times: a single stalled call (r02d: one 50 ms call among 2.4 ms ones on an otherwise idle
+    # box) would otherwise decide a whole step of a schedule; bench.py's headline is the plain total over 200 steps
+    return float(np.median(times)), lp, info
 
 
 def spot(nodes, noises, ts, xs, lp, info, k=2):
