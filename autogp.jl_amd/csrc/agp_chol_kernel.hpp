@@ -485,6 +485,9 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
       }
       all_ready = __syncthreads_or(probe);
     }
+    // (Fetching the direct row operand TWO slabs ahead — 16 more VGPRs, still no spills — was measured: the 512-particle
+    // sub-diagonal launch went 1.560 -> 1.664 ms.  The loop is not waiting for its loads; more of them in flight only
+    // crowd the co-resident workgroup's.)
     gload(0);
     lstore(0);
     d2 fr[NU];                                   // row fragments of the slab being multiplied
