@@ -18,7 +18,10 @@ import Distributions
 import AutoGP
 const GP = AutoGP.GP
 
-const LIB = get(ENV, "AUTOGP_HIP_LIB", "libautogp_hip.so")
+# library: AUTOGP_HIP_LIB, else the path deps/build.jl recorded, else the loader's search path
+const _DEPS = joinpath(@__DIR__, "..", "deps", "deps.jl")
+isfile(_DEPS) && include(_DEPS)
+const LIB = get(ENV, "AUTOGP_HIP_LIB", @isdefined(libautogp_hip) ? libautogp_hip : "libautogp_hip.so")
 const COMM_ID_BYTES = 128
 
 # ------------------------------------------------------------------------------------------------------------------
