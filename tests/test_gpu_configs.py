@@ -299,3 +299,63 @@ def test_online_stream_driver_on_gpu(pkg):
         assert np.abs(var[i] - np.diag(cov)).max() <= 1e-8 * max(1.0, np.abs(cov).max())
     finally:
         eng.close()
+
+
+def test_large_n_8192(pkg, engine):
+    """Beyond BASELINE's sizes: n=8192 (64 tile rows, 2 080 tiles = 273 MB per particle), 6 particles — the small-population
+    schedules at the largest matrix the suite factors, n not a multiple of the tile size alongside (8100).  logpdf against the
+    C + LAPACK oracle, value+gradient sweep's value against the value sweep, predictive variance positive and the predictive
+    likelihood identity logpdf(joint) - logpdf(obs) = logpdf(xs_test | obs) with every term from the GPU."""
+    n = 8192
+    ts, xs = pkg.prior.synthetic_series(n, seed=8192, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(8192), 6, max_depth=3)
+    progs = pkg.encode_batch(nodes)
+    engine.set_data(ts, xs)
+    for m in (8192, 8100):
+        lp, info = engine.logpdf_batch(None, noises, n=m, check=False, programs=progs)
+        ref, rinfo = F.gp_logpdf_many(progs, noises, ts[:m], xs[:m], indices=np.arange(3))
+        ok = (info[:3] == 0) & (rinfo == 0)
+        assert ok.any() and np.array_equal(info[:3] == 0, rinfo == 0)
+        assert lp_err(lp[:3][ok], ref[ok]).max() <= LP_TOL
+    lpg, grads, gn, ig = engine.logpdf_grad_batch(nodes[:2], noises[:2], n=8100, check=False)
+    for i in range(2):
+        if info[i] == 0:
+            assert ig[i] == 0 and abs(lpg[i] - lp[i]) <= 1e-10 * max(1.0, abs(lp[i])) and np.isfinite(grads[i]).all() and np.isfinite(gn[i])
+    # predictive identity on the last 92 points given the first 8100
+    k = next(nd for nd, i in zip(nodes, info) if i == 0)
+    nz = float(noises[[i for i, v in enumerate(info) if v == 0][0]])
+    lj = engine.logpdf_batch([k], [nz], n=8192)[0][0]
+    lo = engine.logpdf_batch([k], [nz], n=8100)[0][0]
+    mean, var, cov, _ = engine.predict_batch([k], [nz], ts[8100:], n=8100, want_cov=True)
+    assert (var > 0).all()
+    d = xs[8100:] - mean[0]
+    L = np.linalg.cholesky(cov[0])
+    z = np.linalg.solve(L, d)
+    lpred = -0.5 * (len(d) * np.log(2 * np.pi) + 2 * np.log(np.diag(L)).sum() + z @ z)
+    assert abs((lj - lo) - lpred) <= 1e-7 * max(1.0, abs(lpred))
+
+
+def test_large_n_16384(pkg, engine):
+    """n=16384: 128 tile rows, 8 256 tiles = 1.08 GB per particle (the tile-row indices of the kernels, the packed offsets and
+    the per-column inverse-block store at their largest in this suite).  One particle against the C + LAPACK oracle, two
+    through the size-independent identity logpdf(n) = logpdf(n - r) + logpdf(last r | first n - r)."""
+    n = 16384
+    ts, xs = pkg.prior.synthetic_series(n, seed=16384, shuffle=True)
+    ks = [pkg.Linear(0.1, 0.3, 0.7) + pkg.Periodic(0.96, 0.21, 1.1) * pkg.SquaredExponential(0.47, 0.8),
+          pkg.GammaExponential(0.2, 1.3, 0.9) + pkg.ChangePoint(pkg.Constant(0.2), pkg.SquaredExponential(0.05, 0.6), 0.5, 0.001)]
+    nz = np.array([0.08, 0.05])
+    engine.set_data(ts, xs)
+    lp, info = engine.logpdf_batch(ks, nz, check=False)
+    assert (info == 0).all()
+    ref, rinfo = F.gp_logpdf_many(pkg.encode_batch(ks), nz, ts, xs, indices=np.arange(1))
+    assert rinfo[0] == 0 and lp_err(lp[:1], ref).max() <= LP_TOL
+    r = 70
+    lo, _ = engine.logpdf_batch(ks, nz, n=n - r, check=False)
+    mean, var, cov, pinfo = engine.predict_batch(ks, nz, ts[n - r:], n=n - r, want_cov=True, check=False)
+    assert (pinfo == 0).all() and (var > 0).all()
+    for i in range(2):
+        d = xs[n - r:] - mean[i]
+        L = np.linalg.cholesky(cov[i])
+        z = np.linalg.solve(L, d)
+        lpred = -0.5 * (r * np.log(2 * np.pi) + 2 * np.log(np.diag(L)).sum() + z @ z)
+        assert abs((lp[i] - lo[i]) - lpred) <= 1e-7 * max(1.0, abs(lpred))
