@@ -12,7 +12,7 @@ from oracle import oracle as O
 
 def run(pkg, eng, cases=60, seed=1):
     rng = np.random.default_rng(seed)
-    worst = 0.0; worst_g = 0.0; t0 = time.time(); nbad = 0
+    worst = 0.0; worst_g = 0.0; t0 = time.time(); nbad = 0; nstore = 0
     for c in range(cases):
         n = int(rng.choice([1, 2, 63, 127, 128, 129, 255, 256, 257, 383, 385, 500, 640, 777, 900]))
         P = int(rng.choice([1, 2, 7, 8, 9, 47, 48, 49, 63, 100, 129, 255, 256, 257, 300, 513]))
@@ -47,7 +47,39 @@ def run(pkg, eng, cases=60, seed=1):
                 sc = max(1.0, np.abs(go).max(), abs(gno))
                 eg = max(np.abs(gr[0] - go).max() if go.size else 0.0, abs(gn[0] - gno)) / sc; worst_g = max(worst_g, eg)
                 assert eg <= 1e-6, ("gradient", n, P, eg)
-    msg = f"fuzz ok: {cases} cases, worst logpdf rel err {worst:.2e}, worst gradient rel err {worst_g:.2e}, not-PD particles skipped {nbad}, {time.time()-t0:.0f}s"
+        if n >= 2 and c % 2 == 1:
+            # factor store: extension at a random split point, then gradient and predictive sweeps from the resident
+            # factors — against the sweeps that factor themselves (computed with an empty store)
+            m = min(P, 24)
+            tp = np.concatenate([ts[: max(1, n // 3)], np.linspace(1.0, 1.2, 5)])
+            eng.extend_reset()
+            pm0, pv0, _, pi0 = eng.predict_batch(nodes[:m], noises[:m], tp, check=False)
+            sel = [j for j in range(m) if nodes[j].size() <= 63]
+            g0 = eng.logpdf_grad_batch([nodes[j] for j in sel], noises[sel], check=False) if sel else None
+            n0 = int(rng.integers(1, n))
+            eng.logpdf_batch_extend(nodes[:m], noises[:m], n=n0, check=False)
+            le, ie = eng.logpdf_batch_extend(nodes[:m], noises[:m], check=False)
+            assert np.array_equal(ie, info[:m]), ("extension info", n, n0, P)
+            okm = ie == 0
+            assert np.all(np.abs(le[okm] - lp[:m][okm]) <= 1e-10 * np.maximum(1.0, np.abs(lp[:m][okm]))), ("extension value", n, n0, P)
+            r0 = eng.predict_reuse_stats()["reused"]
+            pm1, pv1, _, pi1 = eng.predict_batch(nodes[:m], noises[:m], tp, check=False)
+            assert np.array_equal(pi0, pi1) and (eng.predict_reuse_stats()["reused"] > r0 or not okm.any())
+            okp = pi0 == 0
+            if okp.any():
+                sc = max(1.0, np.abs(pm0[okp]).max(), np.abs(pv0[okp]).max())
+                assert np.abs(pm1[okp] - pm0[okp]).max() <= 1e-9 * sc and np.abs(pv1[okp] - pv0[okp]).max() <= 1e-9 * sc, ("predict reuse", n, P)
+            if sel:
+                g1 = eng.logpdf_grad_batch([nodes[j] for j in sel], noises[sel], check=False)
+                assert np.array_equal(g0[3], g1[3])
+                for q in range(len(sel)):
+                    if g0[3][q] != 0:
+                        continue
+                    scg = max(1.0, np.abs(g0[1][q]).max() if g0[1][q].size else 0.0, abs(g0[2][q]))
+                    assert abs(g1[0][q] - g0[0][q]) <= 1e-10 * max(1.0, abs(g0[0][q])), ("gradient reuse value", n, P, q)
+                    assert (np.abs(g1[1][q] - g0[1][q]).max() if g0[1][q].size else 0.0) <= 1e-8 * scg and abs(g1[2][q] - g0[2][q]) <= 1e-8 * scg, ("gradient reuse", n, P, q)
+            nstore += 1
+    msg = f"fuzz ok: {cases} cases ({nstore} with factor-store sweeps), worst logpdf rel err {worst:.2e}, worst gradient rel err {worst_g:.2e}, not-PD particles skipped {nbad}, {time.time()-t0:.0f}s"
     return msg
 
 
