@@ -875,6 +875,8 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
       __builtin_amdgcn_s_setprio(0);
       if (tid < NB && !(AGP_DBG_SKIP & 128)) {
         // r -= L(k,j)[:, slab] * alpha_j[slab]
+        // (Spreading this over all four waves — each half of the workgroup taking half of the slab's columns — was tried:
+        // the kernel sits at exactly 256 VGPRs and the extra live values turned 1 spilled register into 97.)
         const double* xs_ = xv + buf * KS;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) rv = fma(-Bs[kk * LDS_STRIDE + tid], xs_[kk], rv);
