@@ -24,5 +24,7 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof64 -o bench -- python $R/b
 cd $R
 python tools/rocprof_summary.py $(find gpurun_out/prof64 -name "*.db" | head -1) gpurun_out/${TAG}_bench_P64_kernel_stats.txt --particles 64 --cmd "python bench.py --particles 64 --steps 20 --warmup 2 --no-cpu-baseline" | head -8
 bash tools/run_pmc.sh 2>&1 | tail -5
+# the 64-particle share (dataflow kernel): MFMA busy, HBM bytes
+(bash tools/run_pmc_cmd.sh sq64 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline; bash tools/run_pmc_cmd.sh fetch64 "FETCH_SIZE" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline; bash tools/run_pmc_cmd.sh write64 "WRITE_SIZE" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline) 2>&1 | grep -v "at::native\|rocclr" > gpurun_out/${TAG}_pmc_P64.txt; cd $R; head -12 gpurun_out/${TAG}_pmc_P64.txt | cut -c1-250
 python tools/pmc_summary.py ${TAG} > /dev/null 2>&1; cp profiles/${TAG}_pmc_summary.txt gpurun_out/ 2>/dev/null; cp profiles/hbm_traffic.json gpurun_out/${TAG}_hbm_traffic.json 2>/dev/null
 ls gpurun_out | grep ${TAG}
