@@ -2138,6 +2138,28 @@ int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t
         hipLaunchKernelGGL((k_gemm_nolds<true>), dim3(blocks), dim3(256), 0, st, ca);
         break;
       }
+      case 3000: {   // every block column in one launch, EIGHT waves per workgroup (column halves)
+        int blocks = 0;
+        for (int kk = 1; kk < nt - 1; ++kk) blocks += Pg8 * (nt - kk - 1);
+        hipLaunchKernelGGL((k_gemm_strip8<16, true>), dim3(blocks), dim3(512), 0, st, ca);
+        break;
+      }
+      case 3001: {   // one launch per block column, eight waves per workgroup
+        CholArgs cb = ca;
+        for (int kk = 1; kk < nt - 1; ++kk) {
+          cb.k = kk; cb.tiles = nt - kk - 1;
+          hipLaunchKernelGGL((k_gemm_strip8<16, false>), dim3(Pg8 * cb.tiles), dim3(512), 0, st, cb);
+        }
+        break;
+      }
+      case 3032: {   // as 3001 with 32-column slabs
+        CholArgs cb = ca;
+        for (int kk = 1; kk < nt - 1; ++kk) {
+          cb.k = kk; cb.tiles = nt - kk - 1;
+          hipLaunchKernelGGL((k_gemm_strip8<32, false>), dim3(Pg8 * cb.tiles), dim3(512), 0, st, cb);
+        }
+        break;
+      }
       case 2001: {   // the same tiles, one launch per block column
         CholArgs cb = ca;
         for (int kk = 1; kk < nt - 1; ++kk) {

@@ -339,6 +339,94 @@ __global__ __launch_bounds__(256, 2) void k_gemm_strip(CholArgs a) {
     }
 }
 
+// Variant: EIGHT waves per workgroup (512 threads, two workgroups per CU = four waves per SIMD at <= 128 registers).
+// Wave w takes the 32-row strip pair (w & 3) and the column half (w >> 2) of the 128x128 tile: 8 accumulator blocks per wave
+// instead of 16, the same LDS traffic per MFMA (the column operand is split between the two halves), the row operand
+// fetched by both halves (second fetch from L1).  Timing only, same tile walk as k_gemm_strip.
+template <int KBX, bool ALL = false>
+__global__ __launch_bounds__(512, 4) void k_gemm_strip8(CholArgs a) {
+  __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
+  constexpr int SLAB = KBX * LDS_STRIDE;
+  int b = blockIdx.x;
+  int kcol = a.k, T = a.tiles;
+  if (ALL) {
+    const int npl8 = 8 * ((a.P + 7) / 8);
+    kcol = 1;
+    while (kcol < a.nt - 1 && b >= npl8 * (a.nt - kcol - 1)) { b -= npl8 * (a.nt - kcol - 1); ++kcol; }
+    T = a.nt - kcol - 1;
+  }
+  const int xcd = b & 7, qq = b >> 3;
+  const int pl = qq / T, tl = qq - pl * T;
+  const int tk = kcol, ti = kcol + 1 + tl, jmax = kcol;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  const int wr = w & 3, ch = w >> 2;
+  const int row0 = 32 * wr + 2 * l15;
+  double* __restrict__ Ap = a.A + (long long)p * a.strideA;
+  constexpr int NC = NSB / 2;
+  d4 acc[NC][2];
+#pragma unroll
+  for (int cb = 0; cb < NC; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
+  constexpr int NU = KBX / 4;                 // row-operand loads per thread and slab
+  constexpr int NUB = KBX / 8;                // column-operand loads per thread and slab (512 threads)
+  const int nslab = jmax * (NB / KBX);
+  const int scol0 = tid >> 6, srow = 2 * (tid & 63);       // staging: column scol0 + 8u
+  d2 ra[NU], rb[NUB], fr[NU];
+  auto gload = [&](int s) {
+    const int per = NB / KBX;
+    const int j = s / per, cs = (s % per) * KBX;
+    const double* __restrict__ srcA = Ap + tile_off(ti, j) + (long long)cs * NB;
+    const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) ra[u] = *reinterpret_cast<const d2*>(srcA + (4 * u + lq) * NB + row0);
+#pragma unroll
+    for (int u = 0; u < NUB; ++u) rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 8 * u) * NB + srow);
+  };
+  auto lstore = [&](int buf) {
+    double* Bs = sm + buf * SLAB;
+#pragma unroll
+    for (int u = 0; u < NUB; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 8 * u) * LDS_STRIDE + srow) = rb[u];
+  };
+  gload(0); lstore(0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) fr[u] = ra[u];
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) gload(s + 1);
+    const double* Bs = sm + buf * SLAB + ch * (NC * 16);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < KBX / 4; ++kk) {
+      const int krow = (kk * 4 + lq) * LDS_STRIDE;
+      double fa[NC];
+#pragma unroll
+      for (int cb = 0; cb < NC; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];
+#pragma unroll
+      for (int cb = 0; cb < NC; ++cb) {
+        acc[cb][0] = mfma(fa[cb], fr[kk].x, acc[cb][0]);
+        acc[cb][1] = mfma(fa[cb], fr[kk].y, acc[cb][1]);
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (s + 1 < nslab) {
+      lstore(buf ^ 1);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) fr[u] = ra[u];
+    }
+    __syncthreads();
+  }
+  double* __restrict__ Tt = Ap + tile_off(ti, tk);
+#pragma unroll
+  for (int cb = 0; cb < NC; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d2 o2; o2.x = -acc[cb][0][r]; o2.y = -acc[cb][1][r];
+      *reinterpret_cast<d2*>(Tt + ((ch * NC + cb) * 16 + 4 * r + lq) * NB + row0) = o2;
+    }
+}
+
 // Variant without LDS and without barriers: every wave fetches BOTH operands' MFMA fragments straight from global
 // memory (the column operand is the same for the four waves: L1 / L2 hits), one 4-column k-step at a time into a
 // register ring of four k-steps that is refilled right behind the MFMAs that consumed it.  ALL as in k_gemm_strip.
