@@ -14,7 +14,10 @@ properties.  This restatement is therefore pinned by
       (src/GP.jl:666-684),
   (3) closed-form known answers (Constant+noise rank-1, WhiteNoise diagonal, n=1),
   (4) an independent >=50-digit mpmath restatement (oracle/oracle_mp.py),
-  (5) the reference's relational tests restated (tests/test_oracle.py).
+  (5) the reference's relational tests restated (tests/test_oracle.py),
+  (6) a third party's implementation of the same mathematics: scikit-learn's
+      GaussianProcessRegressor (log marginal likelihood, posterior mean and covariance)
+      on every kernel both define (tests/test_oracle.py::test_oracle_against_scikit_learn).
 
 Tree representation used by the oracle (independent of the product package):
 nested tuples

@@ -254,3 +254,70 @@ def test_reference_golden_vectors():
             assert np.abs(np.diag(cov) - np.array(c["pred_var"])).max() <= 1e-8 * max(1.0, np.abs(np.array(c["pred_var"])).max()), c["name"]
             q = O.quantile(mu, cov, [0.025, 0.5, 0.975])
             assert np.abs(q - np.array(c["pred_q"])).max() <= 1e-8 * max(1.0, np.abs(q).max()), c["name"]
+
+
+def _sk_kernel(tree):
+    """The same covariance function in scikit-learn's kernel algebra (an implementation written by other people: it shares
+    no code with the oracle).  Leaves sklearn lacks (GammaExponential with gamma != 1, ChangePoint) raise KeyError."""
+    from sklearn.gaussian_process import kernels as K
+    tag = tree[0]
+    if tag == "WN":
+        return K.WhiteKernel(noise_level=tree[1], noise_level_bounds="fixed")
+    if tag == "C":
+        return K.ConstantKernel(tree[1], "fixed")
+    if tag == "SE":
+        return K.ConstantKernel(tree[2], "fixed") * K.RBF(length_scale=tree[1], length_scale_bounds="fixed")
+    if tag == "PER":
+        return K.ConstantKernel(tree[3], "fixed") * K.ExpSineSquared(length_scale=tree[1], periodicity=tree[2],
+                                                                      length_scale_bounds="fixed", periodicity_bounds="fixed")
+    if tag == "GE" and tree[2] == 1.0:
+        return K.ConstantKernel(tree[3], "fixed") * K.Matern(length_scale=tree[1], nu=0.5, length_scale_bounds="fixed")
+    if tag == "+":
+        return _sk_kernel(tree[1]) + _sk_kernel(tree[2])
+    if tag == "*":
+        return _sk_kernel(tree[1]) * _sk_kernel(tree[2])
+    raise KeyError(tag)
+
+
+def test_oracle_against_scikit_learn():
+    """An INDEPENDENT implementation of the same mathematics: scikit-learn's GaussianProcessRegressor (log marginal likelihood,
+    posterior mean and covariance) on every kernel both libraries define — SE = C*RBF, Periodic = C*ExpSineSquared (the
+    same exp(-2 sin^2(pi d / p) / l^2) form), GammaExponential at gamma = 1 = C*Matern(1/2), Constant, WhiteNoise, sums and
+    products; Linear enters through DotProduct on shifted inputs in a separate case.  This does not pin the oracle to
+    AutoGP.jl (only Julia can), it removes the possibility that the oracle and the engine share one author's mistake."""
+    pytest.importorskip("sklearn")
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process import kernels as K
+    rng = np.random.default_rng(5)
+    ts = np.sort(rng.random(90)); xs = np.sin(9 * ts) + 0.1 * rng.standard_normal(90)
+    tp = np.concatenate([ts[::7], np.linspace(1.0, 1.3, 9)])
+    trees = [
+        ("SE", 0.21, 0.9),
+        ("PER", 0.96, 0.21, 1.1),
+        ("GE", 0.33, 1.0, 0.8),
+        ("+", ("C", 0.4), ("WN", 0.2)),
+        ("+", ("SE", 0.3, 0.5), ("*", ("PER", 0.7, 0.15, 0.9), ("SE", 0.47, 0.8))),
+        ("*", ("+", ("GE", 0.5, 1.0, 1.2), ("C", 0.1)), ("+", ("PER", 1.3, 0.4, 0.6), ("SE", 0.1, 0.3))),
+    ]
+    noise = 0.07
+    for tree in trees:
+        kern = _sk_kernel(tree) + K.WhiteKernel(noise_level=noise, noise_level_bounds="fixed")
+        gpr = GaussianProcessRegressor(kernel=kern, alpha=0.0, optimizer=None, normalize_y=False).fit(ts[:, None], xs)
+        lml = gpr.log_marginal_likelihood()
+        ref = O.gp_logpdf(tree, noise, ts, xs)
+        assert abs(lml - ref) <= 1e-9 * max(1.0, abs(ref)), (tree, lml, ref)
+        # (a WhiteNoise LEAF is (t == t') * value on the joint point list in the reference — it correlates a query point
+        # with the training point at the same time; sklearn's WhiteKernel never does: such trees get fresh query times)
+        tq = tp[len(ts[::7]):] if "WN" in repr(tree) else tp
+        mu_sk, cov_sk = gpr.predict(tq[:, None], return_cov=True)
+        mu, cov = O.predict_mvn(tree, noise, ts, xs, tq)          # noise_pred = noise: what WhiteKernel adds to K(X*, X*)
+        assert np.abs(mu_sk - mu).max() <= 1e-8 * max(1.0, np.abs(mu).max()), tree
+        assert np.abs(cov_sk - cov).max() <= 1e-8 * max(1.0, np.abs(cov).max()), tree
+    # Linear(intercept c, bias b, amplitude a) = b + a (t - c)(t' - c) = ConstantKernel(b) + a * DotProduct(sigma_0 = 0) on t - c
+    c, b, a = 0.1, 0.3, 0.7
+    tree = ("+", ("LIN", c, b, a), ("SE", 0.2, 0.5))
+    kern = (K.ConstantKernel(b, "fixed") + K.ConstantKernel(a, "fixed") * K.DotProduct(sigma_0=0.0, sigma_0_bounds="fixed")
+            + K.ConstantKernel(0.5, "fixed") * K.RBF(0.2, "fixed") + K.WhiteKernel(noise, "fixed"))
+    gpr = GaussianProcessRegressor(kernel=kern, alpha=0.0, optimizer=None).fit((ts - c)[:, None], xs)
+    ref = O.gp_logpdf(tree, noise, ts, xs)
+    assert abs(gpr.log_marginal_likelihood() - ref) <= 1e-9 * max(1.0, abs(ref))
