@@ -795,3 +795,34 @@ def test_full_size_properties(pkg, engine):
     sub8 = [int(i) for i in np.flatnonzero(ok)[:12]]
     lp4, _ = engine.logpdf_batch([nodes[i] for i in sub8[::-1]], noises[sub8[::-1]])
     assert np.array_equal(lp4[::-1], lp2[sub8])          # same schedule, other batch composition: the same bits
+
+
+def test_engine_against_scikit_learn(pkg, engine):
+    """The engine against a THIRD PARTY's implementation, no oracle in between: scikit-learn's GaussianProcessRegressor
+    (log marginal likelihood, posterior mean / covariance) on kernels both define, n = 700 (six tile rows, partial last tile),
+    through agp_logpdf_batch / agp_predict_batch.  Tolerances as for the oracle: 1e-8."""
+    pytest.importorskip("sklearn")
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process import kernels as K
+    from test_oracle import _sk_kernel
+    G = pkg
+    ts, xs = pkg.prior.synthetic_series(700, seed=41, shuffle=True)
+    engine.set_data(ts, xs)
+    ks = [G.SquaredExponential(0.21, 0.9),
+          G.Periodic(0.96, 0.21, 1.1),
+          G.GammaExponential(0.33, 1.0, 0.8),
+          G.SquaredExponential(0.3, 0.5) + G.Periodic(0.7, 0.15, 0.9) * G.SquaredExponential(0.47, 0.8),
+          (G.GammaExponential(0.5, 1.0, 1.2) + G.Constant(0.1)) * (G.Periodic(1.3, 0.4, 0.6) + G.SquaredExponential(0.1, 0.3))]
+    nz = np.array([0.07, 0.05, 0.1, 0.08, 0.06])
+    tp = np.concatenate([ts[::9], np.linspace(1.0, 1.3, 20)])
+    lp, info = engine.logpdf_batch(ks, nz)
+    mean, var, cov, _ = engine.predict_batch(ks, nz, tp, want_cov=True)
+    assert (info == 0).all()
+    for i, k in enumerate(ks):
+        kern = _sk_kernel(k.to_tuple()) + K.WhiteKernel(noise_level=float(nz[i]), noise_level_bounds="fixed")
+        gpr = GaussianProcessRegressor(kernel=kern, alpha=0.0, optimizer=None).fit(ts[:, None], xs)
+        ref = gpr.log_marginal_likelihood()
+        assert abs(lp[i] - ref) <= LP_TOL * max(1.0, abs(ref)), (i, lp[i], ref)
+        mu_sk, cov_sk = gpr.predict(tp[:, None], return_cov=True)
+        assert np.abs(mean[i] - mu_sk).max() <= 1e-8 * max(1.0, np.abs(mu_sk).max())
+        assert np.abs(cov[i] - cov_sk).max() <= 1e-8 * max(1.0, np.abs(cov_sk).max())
