@@ -826,3 +826,22 @@ def test_engine_against_scikit_learn(pkg, engine):
         mu_sk, cov_sk = gpr.predict(tp[:, None], return_cov=True)
         assert np.abs(mean[i] - mu_sk).max() <= 1e-8 * max(1.0, np.abs(mu_sk).max())
         assert np.abs(cov[i] - cov_sk).max() <= 1e-8 * max(1.0, np.abs(cov_sk).max())
+    # gradients: sklearn differentiates w.r.t. log-parameters (d/dlog p = p d/dp), order = hyperparameter order of the kernel
+    cases = [(G.SquaredExponential(0.21, 0.9), 0.07,
+              lambda: K.ConstantKernel(0.9) * K.RBF(0.21) + K.WhiteKernel(0.07), ("amp", "len", "noise")),
+             (G.Periodic(0.96, 0.21, 1.1), 0.05,
+              lambda: K.ConstantKernel(1.1) * K.ExpSineSquared(length_scale=0.96, periodicity=0.21) + K.WhiteKernel(0.05),
+              ("amp", "len", "per", "noise"))]
+    for k, z, mk, names in cases:
+        gpr = GaussianProcessRegressor(kernel=mk(), alpha=0.0, optimizer=None).fit(ts[:, None], xs)
+        ref, gsk = gpr.log_marginal_likelihood(gpr.kernel_.theta, eval_gradient=True)
+        lpg, g, gn = engine.logpdf_grad(k, z)
+        prm = pkg.encode(k)[1]
+        mine = {"noise": gn * z}
+        if len(names) == 3:
+            mine.update(len=g[0] * prm[0], amp=g[1] * prm[1])
+        else:
+            mine.update(len=g[0] * prm[0], per=g[1] * prm[1], amp=g[2] * prm[2])
+        assert abs(lpg - ref) <= LP_TOL * max(1.0, abs(ref))
+        for nm, want in zip(names, gsk):
+            assert abs(mine[nm] - want) <= 1e-7 * max(1.0, abs(want)), (nm, mine[nm], want)
