@@ -24,6 +24,7 @@
 // (columns of C), MFMA "B" = the slab of tile (i,j) (rows of C), so that the accumulator's
 // lane%16 index runs along the ROWS of C, which are contiguous in the column-major tile.
 #pragma once
+#include <type_traits>
 #include "agp_common.hpp"
 #include "agp_cov_kernel.hpp"
 
@@ -128,6 +129,9 @@ constexpr bool XCD_PIN = AGP_XCD_PIN != 0;     // 1: all tiles of a particle on 
 // diagonal kernel's forward-solve accumulation / its MFMAs.
 #ifndef AGP_DBG_SKIP
 #define AGP_DBG_SKIP 0
+#endif
+#ifndef AGP_POST_EVAL
+#define AGP_POST_EVAL 0
 #endif
 #ifndef AGP_A_DIRECT
 #define AGP_A_DIRECT 1
@@ -356,7 +360,13 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
   double* __restrict__ Tt = Ap + tile_off(ti, tk);
   d4 acc[NSB][2];
   const bool prebuilt = (DCOV == 0) || (p >= a.n_fused);
-  if (!prebuilt) {
+  // Every tile of a per-column launch has the same K-loop length, so the two workgroups of a CU run in step: both evaluate
+  // (fp64 VALU, MFMA pipe idle), then both multiply.  Workgroups of the second half of each 512-block wave therefore evaluate
+  // their tile AFTER the K-loop (accumulators start at zero, -A(i,k) is added at the end): one workgroup's VALU phase falls
+  // into the other's MFMA phase.  The choice depends on the block index only: results are reproducible run to run.
+  const bool post_eval = AGP_POST_EVAL && !prebuilt && DM == 2 && !FLOW && ((blockIdx.x >> 8) & 1);
+  auto run_eval = [&](auto ADDC) {
+    constexpr bool ADD = decltype(ADDC)::value;
     const ProgHdr h = a.hdr[p];
     double* tpt = sm;
     double* sig = sm + 256;
@@ -366,6 +376,8 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     int* ops = reinterpret_cast<int*>(prm + h.n_prm + 2);
     for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
     for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
+    double* etab = sm + U_MAIN_DOUBLES;      // exp table in the (still unused) forward-solve scratch: rvec[128]
+    if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
     __syncthreads();
     cov_prologue(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid);
     const double noise = a.noise[p];
@@ -398,19 +410,23 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
         tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
         ri[r] = rslot; ci[r] = NB + cslot;
       }
-      eval_program<(DCOV > 0 ? DCOV : 4), 4, (TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out);
+      eval_program<(DCOV > 0 ? DCOV : 4), 4, (TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab);
       d4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         v[r] = -cov_finalize(out[r], ti * NB + rslot, tk * NB + cb * 16 + 4 * r + lq, a.n1, a.n1_pad, a.m2, noise);
+      auto put = [&](d4& dst) { if (ADD) dst += v; else dst = v; };
       switch (t) {   // wave-uniform scalar dispatch keeps every accumulator index static
-        case 0: acc[0][0] = v; break;  case 1: acc[0][1] = v; break;  case 2: acc[1][0] = v; break;  case 3: acc[1][1] = v; break;
-        case 4: acc[2][0] = v; break;  case 5: acc[2][1] = v; break;  case 6: acc[3][0] = v; break;  case 7: acc[3][1] = v; break;
-        case 8: acc[4][0] = v; break;  case 9: acc[4][1] = v; break;  case 10: acc[5][0] = v; break; case 11: acc[5][1] = v; break;
-        case 12: acc[6][0] = v; break; case 13: acc[6][1] = v; break; case 14: acc[7][0] = v; break; default: acc[7][1] = v; break;
+        case 0: put(acc[0][0]); break;  case 1: put(acc[0][1]); break;  case 2: put(acc[1][0]); break;  case 3: put(acc[1][1]); break;
+        case 4: put(acc[2][0]); break;  case 5: put(acc[2][1]); break;  case 6: put(acc[3][0]); break;  case 7: put(acc[3][1]); break;
+        case 8: put(acc[4][0]); break;  case 9: put(acc[4][1]); break;  case 10: put(acc[5][0]); break; case 11: put(acc[5][1]); break;
+        case 12: put(acc[6][0]); break; case 13: put(acc[6][1]); break; case 14: put(acc[7][0]); break; default: put(acc[7][1]); break;
       }
     }
     __syncthreads();   // the sigma tables alias the GEMM slab buffers
+  };
+  if (!prebuilt && !post_eval) {
+    run_eval(std::false_type{});
   } else {
 #pragma unroll
     for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
@@ -536,6 +552,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     }
   }
 
+  if (post_eval) run_eval(std::true_type{});      // (its leading barrier comes after the K-loop's last one: the slab buffers are free)
   if (prebuilt) {
     // resident tile: bring the accumulators to the same -C representation (one column block at a
     // time — the scheduling fence stops the compiler from hoisting all 64 loads, which would spill)
@@ -766,6 +783,8 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
     int* ops = reinterpret_cast<int*>(prm + h.n_prm + 2);
     for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
     for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
+    double* etab = rvec;                     // exp table in the (still unused) forward-solve scratch
+    if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
     __syncthreads();
     cov_prologue(a.tt, a.code, tk, tk, h, ops, prm, tpt, sig, tid);
     const double noise = a.noise[p];
@@ -796,7 +815,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
         tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
         ri[r] = rslot; ci[r] = NB + cslot;
       }
-      eval_program<(DCOV > 0 ? DCOV : 4), 4, (TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out);
+      eval_program<(DCOV > 0 ? DCOV : 4), 4, (TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab);
       d4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -1313,20 +1332,40 @@ __global__ void k_math_probe(int which, const double* x, const double* g, double
 }
 
 // fp64 MFMA issue-rate microbenchmark: every wave keeps 16 independent accumulators busy.
-__global__ __launch_bounds__(256, 2) void k_mfma_peak(double* out, long long* cycles, int iters) {
+// mode 0: MFMAs only; 1: fp64 VALU FMAs only (128 per iteration on 16 independent chains); 2: both in the same wave,
+// independent of each other (does the vector fp64 work hide under the matrix work, or do they add up?); 3: waves 0,1 of a
+// workgroup run the MFMAs, waves 2,3 the FMAs; 4, 5: see `role` below.
+__global__ __launch_bounds__(256, 2) void k_mfma_peak(double* out, long long* cycles, int iters, int mode) {
   d4 acc[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  double v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = 1.0 + 1e-3 * i;
   double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  const int w = threadIdx.x >> 6;
+  // 4 / 5: whole workgroups take one role each, by block-index parity / by halves of 256 blocks (two workgroups per CU: a
+  // matrix wave and a vector wave then share every SIMD)
+  const int role = mode == 4 ? (blockIdx.x & 1) : mode == 5 ? ((blockIdx.x >> 8) & 1) : -1;
+  const bool do_m = mode == 0 || mode == 2 || (mode == 3 && w < 2) || role == 0;
+  const bool do_v = mode == 1 || mode == 2 || (mode == 3 && w >= 2) || role == 1;
   const long long t0 = clock64();
   for (int it = 0; it < iters; ++it) {
+    if (do_m) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = mfma(a, b, acc[i]);
+      for (int i = 0; i < 16; ++i) acc[i] = mfma(a, b, acc[i]);
+    }
+    if (do_v) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = __builtin_fma(v[i], b, a);
+    }
   }
   const long long t1 = clock64();
   double s = 0.0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + v[i];
   out[(long long)blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }

@@ -15,6 +15,9 @@
 //                     pass in the accumulator layout), so K never round-trips through HBM and the
 //                     fp64 transcendental work overlaps the co-resident workgroup's MFMA phase.
 #pragma once
+#ifndef AGP_EXP_TABLE
+#define AGP_EXP_TABLE 1
+#endif
 #include "agp_common.hpp"
 #include "agp_math.hpp"
 
@@ -88,8 +91,10 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
                                              const double* __restrict__ prm, const double* sig,
                                              const double (&tr)[E], const double (&tc)[E],
                                              const int (&ri)[E], const int (&ci)[E], const double (&lt)[E],
-                                             double (&out)[E]) {
+                                             double (&out)[E], const double* etab = nullptr) {
   // lt: log|t_row - t_col| of the E elements from the data set's table (only read by OP_GE_TAB leaves)
+  // etab: LDS copy of fm::c_exp_tab (fm::exp_t, 11 fp64 operations instead of exp_f's 21)
+  auto ex = [&](double x) { return (AGP_EXP_TABLE != 0) ? fm::exp_t(x, etab) : fm::exp_f(x); };
   double st[D][E];
 #pragma unroll
   for (int d = 0; d < D; ++d)
@@ -136,13 +141,13 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
           for (int e = 0; e < E; ++e) arg[e] = -fm::pow_f(fabs(tr[e] - tc[e]) * p0, p1);
         } else if (GEMODE != 1 && (o == OP_GE_TAB || (GEMODE == 2 && o == OP_GE))) {   // p0 = log l, p1 = gamma
 #pragma unroll
-          for (int e = 0; e < E; ++e) arg[e] = -fm::exp_f(p1 * (lt[e] - p0));
+          for (int e = 0; e < E; ++e) arg[e] = -ex(p1 * (lt[e] - p0));
         } else {                   // OP_PER: p0 = -2/l^2, p1 = pi/p
 #pragma unroll
           for (int e = 0; e < E; ++e) arg[e] = p0 * fm::sin2_f(p1 * fabs(tr[e] - tc[e]));
         }
 #pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = amp * fm::exp_f(arg[e]);
+        for (int e = 0; e < E; ++e) v[e] = amp * ex(arg[e]);
       }
 #pragma unroll
       for (int d = D - 1; d > 0; --d)
@@ -224,6 +229,8 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
   const ProgHdr h = a.hdr[p];
   const uint8_t* __restrict__ ops = a.ops + h.op_off;
   const double* __restrict__ prm = a.prm + h.prm_off;
+  double* etab = sig + h.n_cp * 256;      // [128] exp table (launch_cov sizes the dynamic LDS for it)
+  if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
   cov_prologue(a.tt, a.code, ti, tj, h, ops, prm, tpt, sig, tid);
 
   const int rp = tid & 63;        // row pair: rows 2rp, 2rp+1
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
       ri[e] = r0 + (e & 1);
       ci[e] = NB + c0 + (e >> 1);
     }
-    eval_program<D, E, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out);
+    eval_program<D, E, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab);
 #pragma unroll
     for (int cc = 0; cc < CPP; ++cc) {
       const int gj = tj * NB + c0 + cc;

@@ -515,7 +515,7 @@ int64_t ws_limit_bytes(agp_ctx* c) {
 
 hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int max_cp, int depth) {
   if (ntiles <= 0 || P <= 0) return hipSuccess;
-  const size_t lds = (256 + (size_t)max_cp * 256) * sizeof(double);
+  const size_t lds = (256 + (size_t)max_cp * 256 + AGP_EXP_TAB_N) * sizeof(double);      // tpt, sigma tables, exp table
   dim3 grid(ntiles, P), block(256);
   // (the dynamic-LDS ceiling of these kernels is raised once, in agp_init; compile_program bounds max_cp)
   if (depth <= 4) hipLaunchKernelGGL(k_cov_tiles<4>, grid, block, lds, st, ca);
@@ -2071,15 +2071,17 @@ int agp_debug_mfma_peak(agp_ctx* c, int32_t iters, int32_t wg_per_cu, double* ou
   HIPCHK(c, hipSetDevice(c->device));
   hipDeviceProp_t prop;
   HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+  const int mode = wg_per_cu >> 8;          // (high bits: what the waves execute, see k_mfma_peak)
+  wg_per_cu &= 255;
   const int nblk = prop.multiProcessorCount * (wg_per_cu > 0 ? wg_per_cu : 2);
   double* d_out = nullptr; long long* d_cyc = nullptr;
   HIPCHK(c, hipMalloc((void**)&d_out, sizeof(double) * 256 * (size_t)nblk));
   HIPCHK(c, hipMalloc((void**)&d_cyc, sizeof(long long) * (size_t)nblk));
   hipEvent_t e0, e1;
   HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
-  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, d_out, d_cyc, 64);   // warm-up
+  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, d_out, d_cyc, 64, mode);   // warm-up
   HIPCHK(c, hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, d_out, d_cyc, iters);
+  hipLaunchKernelGGL(k_mfma_peak, dim3(nblk), dim3(256), 0, 0, d_out, d_cyc, iters, mode);
   HIPCHK(c, hipEventRecord(e1, 0));
   HIPCHK(c, hipEventSynchronize(e1));
   float ms = 0.f;

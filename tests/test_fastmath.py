@@ -13,6 +13,7 @@ SRC = r'''
 #include "agp_math.hpp"
 extern "C" {
 void v_exp(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = agp::fm::exp_f(x[i]); }
+void v_exp_t(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = agp::fm::exp_t(x[i], agp::fm::EXP_TAB); }
 void v_sin2(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = agp::fm::sin2_f(x[i]); }
 void v_sincos(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) agp::fm::sincos_pi_f(x[i], y + 2 * i, y + 2 * i + 1); }
 void v_log(const double* x, double* y, int n) { for (int i = 0; i < n; ++i) y[i] = agp::fm::log_f(x[i]); }
@@ -54,6 +55,25 @@ def test_exp(lib):
     assert call1(lib.v_exp, np.array([-746.0, -1000.0, -1e9]))[0:3].tolist() == [0.0, 0.0, 0.0]
     sub = call1(lib.v_exp, np.array([-720.0]))[0]          # subnormal result
     assert abs(sub - float(mp.exp(-720))) <= 5e-324 * 2
+
+
+def test_exp_table(lib):
+    """exp_t (128-entry table of 2^(j/128) + degree-5 polynomial: the version the covariance evaluation uses on the device):
+    same accuracy class as exp_f on the same domain, same underflow behaviour; the table itself is correctly rounded."""
+    mp.mp.dps = 40
+    rng = np.random.default_rng(1)
+    x = np.concatenate([-rng.random(3000) * 50, -np.exp(rng.uniform(-40, 6.5, 3000)), rng.random(800) * 12,
+                        np.arange(-1280, 1281) * (np.log(2) / 256),          # ties of the table index
+                        [0.0, -1e-300, -700.0, -1e-17, 11.5, 700.0]])
+    u = ulps(call1(lib.v_exp_t, x), [mp.exp(mp.mpf(float(v))) for v in x])
+    assert u.max() < 1.6, u.max()
+    assert call1(lib.v_exp_t, np.array([-746.0, -1000.0, -1e9]))[0:3].tolist() == [0.0, 0.0, 0.0]
+    sub = call1(lib.v_exp_t, np.array([-720.0]))[0]
+    assert abs(sub - float(mp.exp(-720))) <= 5e-324 * 2
+    assert call1(lib.v_exp_t, np.array([0.0]))[0] == 1.0
+    # agreement of the two implementations where the kernels use them (arg <= 0)
+    a = call1(lib.v_exp, x[x <= 0]); b = call1(lib.v_exp_t, x[x <= 0])
+    assert np.max(np.abs(a - b) / np.maximum(a, 1e-300)) < 5e-16
 
 
 def test_sin2(lib):
