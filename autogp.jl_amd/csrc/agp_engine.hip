@@ -135,7 +135,7 @@ struct agp_ctx {
   // A tile evaluation longer than this (cost model op_cost_us, measured per-leaf cost of one 128x128 tile
   // with two workgroups per CU) is not hidden by the co-resident workgroup's GEMM phase and would set the
   // duration of the short launches; such particles get their tiles from k_cov_tiles.  env AGP_FUSE_MAX_US
-  double fuse_max_us = 35.0;
+  double fuse_max_us = 25.0;     // (priced with the per-leaf costs of compile_batch, which predate exp_t: 25 vs 35: 29.28 vs 29.6 ms at 512 particles)
   double flow_fuse_max_us = 70.0;   // the same limit under the dataflow schedule; env AGP_FLOW_FUSE_MAX_US
   int dedup = 1;        // evaluate identical particles of a host-output sweep once; env AGP_DEDUP
   int64_t n_particles_seen = 0, n_particles_run = 0;
