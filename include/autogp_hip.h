@@ -262,7 +262,10 @@ int agp_debug_mfma_probe(agp_ctx* ctx, const double* A, const double* B, double*
 int agp_debug_math(agp_ctx* ctx, int32_t which, const double* x, const double* g, double* y, int32_t n);
 
 /* fp64 MFMA issue-rate microbenchmark (16 independent accumulators per wave, wg_per_cu
- * workgroups of 4 waves per CU): sustained TFLOP/s and the shader clock while it ran. */
+ * workgroups of 4 waves per CU): sustained TFLOP/s and the shader clock while it ran.
+ * Bits 8.. of wg_per_cu select what the waves execute (tools/gpu_dp_share.py): 0 MFMAs only, 1 fp64 VALU FMAs only
+ * (128 per iteration), 2 both in every wave, 3 waves 0-1 MFMAs / waves 2-3 FMAs, 4 / 5 whole workgroups take one role
+ * each (by block-index parity / by halves of 256 blocks); the TFLOP/s figure always assumes 16 MFMAs per wave and iteration. */
 int agp_debug_mfma_peak(agp_ctx* ctx, int32_t iters, int32_t wg_per_cu, double* out_tflops, double* out_ghz);
 
 /* Ablation harness for the update GEMM (off-diagonal tiles of block column k on pseudo-random data):
