@@ -1169,6 +1169,24 @@ __global__ void k_finish_logpdf(const double* partial, const int* info, int nt, 
   out_info[o] = inf;
 }
 
+// row r (blockIdx.y) of a pitched buffer -> row r of another (pitches and width in doubles; width even or odd):
+// the factor store's growth copy (a slot's resident prefix is contiguous, slots are ~GiB apart).
+__global__ __launch_bounds__(256) void k_copy_rows(double* __restrict__ dst, long long dpitch, const double* __restrict__ src,
+                                                   long long spitch, long long width) {
+  const long long r = blockIdx.y;
+  const double* s = src + r * spitch;
+  double* d = dst + r * dpitch;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < width; i += stride) d[i] = s[i];
+}
+
+// out[p] = lp[rep[p]]: the distinct particles' results expanded to the caller's population order (device-resident
+// output of the extension sweeps: the shard handed to the log-weight all-gather).
+__global__ void k_expand_rep(const double* __restrict__ lp, const int32_t* __restrict__ rep, int P, double* __restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < P) out[p] = lp[rep[p]];
+}
+
 // Extension sweep: re-arm the rows the sweep recomputes (tile rows >= i0[p]) with the data, keep alpha of the rows
 // below; ready[slot] = i0 (those block columns are published), info cleared for particles factored from scratch.
 __global__ void k_init_extend(double* vec, int ldv, int n_pad, const double* xs, int n, const int* slot, const int* i0,

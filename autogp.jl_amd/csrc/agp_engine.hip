@@ -6,18 +6,20 @@
 #include "agp_cov_kernel.hpp"
 #include "agp_chol_kernel.hpp"
 #ifdef AGP_EXPERIMENTS
-#include "agp_experiments.hpp"   // ablation kernels of the update GEMM (measurement builds only)
+#include "experiments/agp_experiments.hpp"   // ablation kernels of the update GEMM (measurement builds only: libautogp_hip_exp.so)
 #endif
 #include "agp_grad_kernel.hpp"
 #include "agp_comm.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -74,13 +76,15 @@ struct Slot {
   // recorded behind the call's last launch, has completed
   hipEvent_t done = nullptr;
   bool pending = false;
+  HostBuf h_async_info;     // pinned copy of the call's info words, read when the slot is next claimed
+  int async_P = 0;
   void release() {
     if (done) { (void)hipEventDestroy(done); done = nullptr; }
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
                       &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq})
       b->release();
-    stage.release(); h_stage.release(); h_out.release();
+    stage.release(); h_stage.release(); h_out.release(); h_async_info.release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
     for (auto e : sub_ev) (void)hipEventDestroy(e);
@@ -154,7 +158,7 @@ struct agp_ctx {
   size_t flow_trace_items = 0;
   int flow_fuse = 1;    // 1: dataflow sweeps evaluate tiles in-kernel like the large-population path; env AGP_FLOW_FUSE
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
-  double timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double timing[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // [8..11]: gradient sweep: L^-T chain, K^-1 tiles, contraction, alpha + reduction
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
   // ---- coalescing of concurrent single-particle callers (agp_logpdf) ----
   std::mutex qmu;
@@ -186,8 +190,10 @@ struct agp_ctx {
     uint64_t clock = 0;
     int64_t hits = 0, misses = 0, tile_rows_reused = 0, tile_rows_total = 0;
     double max_frac = 0.45;             // share of the device memory the store may take
-    void forget() { index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); }
-    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); n_slots = 0; nt_cap = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); }
+    std::atomic<size_t> footprint{0};   // bytes the store holds right now (read by ws_limit_bytes without the lock)
+    size_t failed_bytes = 0;            // size of the last (re)allocation that failed: not retried at that size or above
+    void forget() { failed_bytes = 0; index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); }
+    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); n_slots = 0; nt_cap = 0; footprint = 0; failed_bytes = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); }
   } store;
   // ---- RCCL communicator of the particle-sharded deployment (agp_comm_init_rank / agp_init_multi) ----
   ncclComm_t comm = nullptr;
@@ -195,6 +201,19 @@ struct agp_ctx {
   hipStream_t comm_stream = nullptr;
   std::mutex comm_mu;                   // one collective at a time per context
   DevBuf comm_in, comm_out, comm_all;   // padded shard, padded gather, compact vector
+  // ---- asynchronous device-output calls (agp_logpdf_batch_device on a caller stream) return before their kernels ran: a
+  //      negative info word (the bounded in-kernel wait gave up) is latched here when the slot is next claimed and
+  //      reported by the next device-output call / agp_wait ----
+  bool async_fault = false;
+  // ---- persistent host thread of this device for the one-process-drives-the-node entries (agp_logpdf_batch_multi) ----
+  struct Worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = true, stop = false;
+  };
+  Worker* worker = nullptr;
 };
 
 namespace {
@@ -218,6 +237,14 @@ int fail(agp_ctx* c, int code, const std::string& msg) {
     }                                                                                       \
   } while (0)
 
+// (c->mu held) an asynchronously handed-back slot whose event has completed: look at the info words it left behind
+void latch_async_info(agp_ctx* c, Slot* s) {
+  const int32_t* hi = static_cast<const int32_t*>(s->h_async_info.p);
+  for (int p = 0; hi && p < s->async_P; ++p)
+    if (hi[p] < 0) { c->async_fault = true; break; }
+  s->async_P = 0;
+}
+
 Slot* acquire_slot(agp_ctx* c) {
   std::unique_lock<std::mutex> g(c->mu);
   for (;;) {
@@ -225,7 +252,7 @@ Slot* acquire_slot(agp_ctx* c) {
     for (Slot* s : c->slots) {
       if (!s->busy) { s->busy = true; return s; }
       if (s->pending) {                    // handed back asynchronously: free once its event has completed
-        if (hipEventQuery(s->done) == hipSuccess) { s->pending = false; return s; }
+        if (hipEventQuery(s->done) == hipSuccess) { s->pending = false; latch_async_info(c, s); return s; }
         waiting = s;
       }
     }
@@ -241,6 +268,8 @@ Slot* acquire_slot(agp_ctx* c) {
       waiting->pending = false;
       g.unlock();
       (void)hipEventSynchronize(waiting->done);
+      g.lock();
+      latch_async_info(c, waiting);
       return waiting;
     }
     c->cv.wait(g);
@@ -506,11 +535,17 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
 
 inline int round_up(int64_t n, int m) { return (int)(((n + m - 1) / m) * m); }
 
+// Matrix workspace one call may take: 55 % of the memory that was free at agp_init (at most 96 GiB), less what the
+// resident factor store has taken since (the store is allocated on demand, up to 45 %: together they must still fit
+// beside the gradient's second matrix set and the small buffers).
 int64_t ws_limit_bytes(agp_ctx* c) {
   if (c->ws_limit > 0) return c->ws_limit;
   int64_t lim = (int64_t)(c->total_mem * 0.55);
   const int64_t cap = 96LL << 30;
-  return std::min(lim, cap);
+  lim = std::min(lim, cap);
+  const int64_t store = (int64_t)c->store.footprint.load(std::memory_order_relaxed);
+  if (store > 0) lim = std::max<int64_t>(std::min<int64_t>(lim, (int64_t)(c->total_mem * 0.92) - store), 1LL << 30);
+  return lim;
 }
 
 hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int max_cp, int depth) {
@@ -772,7 +807,8 @@ std::string particle_key(const uint8_t* ops, int no, const double* prm, int np, 
 
 hipError_t run_factor_extend(hipStream_t st, CholArgs ca, int dcov, bool split_diag, int i0min, int nfac = -1);
 int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
-                const double* prm, const double* noise, double* out_lp, int32_t* out_info);
+                const double* prm, const double* noise, double* out_lp, int32_t* out_info,
+                double* d_out_caller = nullptr, bool* wrote_device = nullptr);
 
 // Factor-store lookup for a compiled batch (sorted order q -> caller index bt.order[q]): src_slot[q] = the slot that holds
 // the POSITIVE DEFINITE factor of particle q for exactly the prefix n (else -1), i0v[q] = nt for those (no tile row left to
@@ -954,7 +990,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     const int32_t* d_i0 = n_hit > 0 ? reinterpret_cast<const int32_t*>(dstage + o_i0) : nullptr;
 
     Prof pf{c, s, st, c->profiling};
-    double tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     size_t ev_begin = pf.mark();
     HIPCHK(c, hipMemcpyAsync(dstage, s->h_stage.p, stage_bytes, hipMemcpyHostToDevice, st));
     std::vector<int32_t> goff_sorted;
@@ -1095,6 +1131,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             ga.Wsrc = c->store.W.as<double>(); ga.Wnt = c->store.nt_cap;
           }
           const int Pg8 = (Pg + 7) / 8;
+          const size_t gm0 = pf.mark(q);
           if (c->trtri_chain) {
             hipLaunchKernelGGL(k_trtri_chain, dim3(8 * Pg8 * nt), dim3(256), 0, q, ga);
           } else {
@@ -1103,7 +1140,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
               hipLaunchKernelGGL(k_trtri_step, dim3(8 * Pg8 * (i + 1)), dim3(256), 0, q, ga);
             }
           }
+          const size_t gm1 = pf.mark(q);
+          pf.span(8, gm0, gm1);
           hipLaunchKernelGGL(k_alpha, dim3(nt, Pg), dim3(256), 0, q, ga);
+          size_t gm2 = pf.mark(q);
+          pf.span(11, gm1, gm2);
           // One contraction launch per group, largest trees first (their workgroups run longest); the 16-node
           // (800 B private memory) variant serves groups without a larger tree.
           pls.emplace_back(Pg);
@@ -1118,6 +1159,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           const int Pall = ga.P;
           if (c->grad_split) {
             hipLaunchKernelGGL(k_kinv_tiles, dim3(8 * Pg8 * ntiles), dim3(256), 0, q, ga);
+            { const size_t gk = pf.mark(q); pf.span(9, gm2, gk); gm2 = gk; }
             const size_t lds2 = sizeof(double) * (256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes + 8);
             // three classes by tree size (the particle list is sorted by it): > 16 nodes and 9 .. 16 nodes keep their tape
             // in private memory, trees of <= 8 nodes — the bulk of a prior-sampled population — keep it in LDS
@@ -1143,7 +1185,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             else HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, Pg, lds));
           }
           ga.P = Pall;
+          const size_t gm3 = pf.mark(q);
+          pf.span(10, gm2, gm3);
           hipLaunchKernelGGL(k_grad_finish, dim3(Pg), dim3(64), 0, q, ga);
+          pf.span(11, gm3, pf.mark(q));
           HIPCHK(c, hipGetLastError());
         }
         if (g > 0) {
@@ -1158,15 +1203,20 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       HIPCHK(c, hipStreamSynchronize(st));
       pf.collect(tacc);
       std::lock_guard<std::mutex> g(c->mu);
-      for (int i = 0; i < 8; ++i) c->timing[i] = tacc[i];
+      for (int i = 0; i < 16; ++i) c->timing[i] = tacc[i];
     }
   }
 
   if (use_user_stream && !go && !c->profiling && !h_out_lp && !h_out_info) {
     // Device-output entry on the caller's stream: everything is enqueued, nothing is waited for — the caller chains
     // its consumer (the log-weight all-gather) on the same stream.  The slot stays reserved until the event fires.
-    // (The -7 in-kernel-timeout marker then only reaches the caller through d_out_info.)
+    // The info words also travel to pinned memory behind the work: a negative one (the bounded in-kernel wait for a
+    // diagonal factor gave up: -7) is latched when the slot is next claimed and fails the next device-output call or
+    // agp_wait with AGP_ERR_HIP — the caller never has to scan d_out_info for it.
     if (!s->done) HIPCHK(c, hipEventCreateWithFlags(&s->done, hipEventDisableTiming));
+    HIPCHK(c, s->h_async_info.ensure(sizeof(int32_t) * (size_t)P));
+    HIPCHK(c, hipMemcpyAsync(s->h_async_info.p, d_info_out, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToHost, st));
+    s->async_P = P;
     HIPCHK(c, hipEventRecord(s->done, st));
     sg.async_done = true;
     return AGP_OK;
@@ -1281,6 +1331,13 @@ int agp_init(agp_ctx** out, int device_id) {
 
 void agp_destroy(agp_ctx* c) {
   if (!c) return;
+  if (c->worker) {
+    { std::lock_guard<std::mutex> g(c->worker->mu); c->worker->stop = true; }
+    c->worker->cv.notify_all();
+    if (c->worker->th.joinable()) c->worker->th.join();
+    delete c->worker;
+    c->worker = nullptr;
+  }
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (Slot* s : c->slots) { s->release(); delete s; }
@@ -1318,7 +1375,7 @@ int agp_set_profiling(agp_ctx* c, int enabled) {
 int agp_get_timing(agp_ctx* c, double* out, int32_t n_out) {
   if (!c || !out) return fail(c, AGP_ERR_ARG, "null pointer");
   std::lock_guard<std::mutex> g(c->mu);
-  for (int i = 0; i < n_out && i < 8; ++i) out[i] = c->timing[i];
+  for (int i = 0; i < n_out && i < 16; ++i) out[i] = c->timing[i];
   return AGP_OK;
 }
 
@@ -1465,8 +1522,34 @@ int agp_logpdf_batch_device(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_
                             const int32_t* prm_off, const double* prm, const double* noise,
                             double* d_out_logpdf, int32_t* d_out_info, void* hip_stream) {
   if (c && P > 0 && (!d_out_logpdf || !d_out_info)) return fail(c, AGP_ERR_ARG, "null output pointer");
+  if (c) {
+    bool fault;
+    { std::lock_guard<std::mutex> g(c->mu); fault = c->async_fault; c->async_fault = false; }
+    if (fault) return fail(c, AGP_ERR_HIP, "an earlier asynchronous sweep timed out inside a kernel waiting for a diagonal factor (its info words are < 0)");
+  }
   return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, nullptr, nullptr, d_out_logpdf,
                            d_out_info, (hipStream_t)hip_stream, hip_stream != nullptr);
+}
+
+int agp_wait(agp_ctx* c) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  HIPCHK(c, hipSetDevice(c->device));
+  for (;;) {
+    Slot* w = nullptr;
+    {
+      std::lock_guard<std::mutex> g(c->mu);
+      for (Slot* s : c->slots) if (s->pending) { w = s; break; }
+    }
+    if (!w) break;
+    HIPCHK(c, hipEventSynchronize(w->done));
+    std::lock_guard<std::mutex> g(c->mu);
+    if (w->pending && hipEventQuery(w->done) == hipSuccess) { w->pending = false; w->busy = false; latch_async_info(c, w); }
+  }
+  c->cv.notify_all();
+  bool fault;
+  { std::lock_guard<std::mutex> g(c->mu); fault = c->async_fault; c->async_fault = false; }
+  if (fault) return fail(c, AGP_ERR_HIP, "an asynchronous sweep timed out inside a kernel waiting for a diagonal factor (its info words are < 0)");
+  return AGP_OK;
 }
 
 // Run one coalesced batch (all requests share n and the kind: value only / value + gradient) through the batched sweep.
@@ -2280,11 +2363,16 @@ int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
   agp_ctx::FactorStore& fs = c->store;
   if (nt_cap == fs.nt_cap && n_slots == fs.n_slots) return AGP_OK;
   const long long strideA = (long long)nt_cap * (nt_cap + 1) / 2 * NB2;
+  const size_t want_bytes = (size_t)n_slots * store_bytes_per_slot(nt_cap);
+  // (an allocation of this size already failed: do not retry the multi-GB allocations and copies on every call —
+  // agp_extend_reset / agp_set_data on another series clear the memo)
+  if (fs.failed_bytes && want_bytes >= fs.failed_bytes) return fail(c, AGP_ERR_HIP, "factor store: an allocation of this size failed before");
   DevBuf A, W, vec, partial, info, ready;
   // (a failed (re)allocation leaves the store as it was: the caller then runs without caching)
   auto bail = [&](hipError_t e, const char* what) {
     A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release();
     (void)hipGetLastError();
+    fs.failed_bytes = want_bytes;
     return fail(c, AGP_ERR_HIP, std::string("factor store: ") + what + ": " + hipGetErrorString(e));
   };
 #define STORECHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(e_, #expr); } while (0)
@@ -2297,8 +2385,14 @@ int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
   STORECHK(hipMemset(info.p, 0, sizeof(int) * (size_t)n_slots));
   const int keep = std::min(n_slots, fs.n_slots), nto = std::min(nt_cap, fs.nt_cap);
   if (keep > 0 && nto > 0) {
+    // strided copy by a small kernel (row = slot): the per-slot stride is ~1 GiB at n = 16k and passes 2 GiB from n ~ 23k —
+    // pitches hipMemcpy2D may refuse
     auto cp = [&](DevBuf& dst, size_t dpitch, DevBuf& src, size_t spitch, size_t width) {
-      return hipMemcpy2D(dst.p, dpitch, src.p, spitch, width, (size_t)keep, hipMemcpyDeviceToDevice);
+      const long long words = (long long)(width / 8);
+      const int gx = (int)std::max<long long>(1, std::min<long long>(2048, (words / 2 + 255) / 256));
+      hipLaunchKernelGGL(k_copy_rows, dim3(gx, keep), dim3(256), 0, 0, dst.as<double>(), (long long)(dpitch / 8), src.as<double>(),
+                         (long long)(spitch / 8), words);
+      return hipGetLastError();
     };
     const size_t tiles_o = (size_t)nto * (nto + 1) / 2;
     STORECHK(cp(A, (size_t)strideA * 8, fs.A, (size_t)fs.strideA * 8, tiles_o * NB2 * 8));
@@ -2306,6 +2400,7 @@ int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
     STORECHK(cp(vec, (size_t)nt_cap * NB * 8, fs.vec, (size_t)fs.nt_cap * NB * 8, (size_t)nto * NB * 8));
     STORECHK(cp(partial, (size_t)nt_cap * 16, fs.partial, (size_t)fs.nt_cap * 16, (size_t)nto * 16));
     STORECHK(hipMemcpy(info.p, fs.info.p, sizeof(int) * (size_t)keep, hipMemcpyDeviceToDevice));
+    STORECHK(hipDeviceSynchronize());
   }
 #undef STORECHK
   fs.A.release(); fs.W.release(); fs.vec.release(); fs.partial.release(); fs.info.release(); fs.ready.release();
@@ -2316,6 +2411,7 @@ int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
   fs.key.resize((size_t)n_slots); fs.n_cached.resize((size_t)n_slots, 0); fs.stamp.resize((size_t)n_slots, 0);
   fs.info_h.resize((size_t)n_slots, 0);
   fs.nt_cap = nt_cap; fs.n_slots = n_slots; fs.strideA = strideA;
+  fs.footprint = A.cap + W.cap + vec.cap + partial.cap + info.cap + ready.cap + fs.tflag.cap + fs.flowq.cap;
   return AGP_OK;
 }
 
@@ -2344,8 +2440,13 @@ hipError_t run_factor_extend(hipStream_t st, CholArgs ca, int dcov, bool split_d
   return hipGetLastError();
 }
 
+// d_out_caller (optional, device, P doubles): the log-pdfs in the CALLER's particle order (duplicates expanded) are also left
+// there, ordered behind the sweep on the slot's stream and complete on return; *wrote_device says whether that happened
+// (not for n = 0 or when the sweep fell back to the plain entry).
 int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
-                const double* prm, const double* noise, double* out_lp, int32_t* out_info) {
+                const double* prm, const double* noise, double* out_lp, int32_t* out_info,
+                double* d_out_caller, bool* wrote_device) {
+  if (wrote_device) *wrote_device = false;
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   if (P < 0 || n < 0) return fail(c, AGP_ERR_ARG, "negative size");
   if (P == 0) return AGP_OK;
@@ -2465,7 +2566,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   const size_t o_slot = al16(o_map + sizeof(int32_t) * (size_t)U);
   const size_t o_i0 = al16(o_slot + sizeof(int32_t) * (size_t)U);
   const size_t o_ops = al16(o_i0 + sizeof(int32_t) * (size_t)U);
-  const size_t stage_bytes = al16(o_ops + bt.ops.size() + 4);
+  const size_t o_rep = al16(o_ops + bt.ops.size() + 4);                  // caller particle -> distinct particle (d_out_caller)
+  const size_t stage_bytes = al16(o_rep + (d_out_caller ? sizeof(int32_t) * (size_t)P : 0));
   auto hipfail = [&](hipError_t e, const char* what) {
     poison();
     return fail(c, AGP_ERR_HIP, std::string("HIP error in the extension sweep (") + what + "): " + hipGetErrorString(e));
@@ -2485,6 +2587,10 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     for (int q = 0; q < U; ++q) { const int u = bt.order[q]; hn[q] = unoise[u]; hs[q] = slot[u]; hi[q] = i0[u]; }
     std::memcpy(h + o_map, bt.order.data(), sizeof(int32_t) * (size_t)U);
     std::memcpy(h + o_ops, bt.ops.data(), bt.ops.size());
+    if (d_out_caller) {
+      int32_t* hr = reinterpret_cast<int32_t*>(h + o_rep);
+      for (int p = 0; p < P; ++p) hr[p] = rep[p];
+    }
   }
   char* dstage = static_cast<char*>(s->stage.p);
   EXTCHK(hipMemcpyAsync(dstage, s->h_stage.p, stage_bytes, hipMemcpyHostToDevice, st));
@@ -2531,8 +2637,13 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   hipLaunchKernelGGL(k_finish_logpdf, dim3((U + 63) / 64), dim3(64), 0, st, fs.partial.as<double>(), fs.info.as<int>(), nt, U,
                      (int)n, reinterpret_cast<const int*>(dstage + o_map), d_lp, d_info, d_slot, fs.nt_cap);
   EXTCHK(hipGetLastError());
+  if (d_out_caller) {
+    hipLaunchKernelGGL(k_expand_rep, dim3((P + 255) / 256), dim3(256), 0, st, d_lp, reinterpret_cast<const int32_t*>(dstage + o_rep), P, d_out_caller);
+    EXTCHK(hipGetLastError());
+  }
   EXTCHK(hipMemcpyAsync(s->h_out.p, d_lp, sizeof(double) * U + sizeof(int32_t) * U, hipMemcpyDeviceToHost, st));
   EXTCHK(hipStreamSynchronize(st));
+  if (d_out_caller && wrote_device) *wrote_device = true;
 #undef EXTCHK
   const double* hl = static_cast<const double*>(s->h_out.p);
   const int32_t* hinfo = reinterpret_cast<const int32_t*>(hl + U);
@@ -2708,6 +2819,18 @@ int agp_comm_info(agp_ctx* c, int32_t* rank, int32_t* n_ranks) {
   return c->comm ? 1 : 0;
 }
 
+int agp_comm_count(agp_ctx* c, int32_t* out_n_ranks) {
+  if (!c || !out_n_ranks) return fail(c, AGP_ERR_ARG, "null pointer");
+  *out_n_ranks = 0;
+  if (!c->comm) return AGP_OK;
+  int rc = need_rccl(c);
+  if (rc) return rc;
+  int cnt = 0;
+  NCCLCHK(c, rccl().CommCount(c->comm, &cnt));
+  *out_n_ranks = cnt;
+  return AGP_OK;
+}
+
 int agp_init_multi(agp_ctx** out, const int32_t* device_ids, int32_t n_dev) {
   if (!out || !device_ids || n_dev < 1) return fail(nullptr, AGP_ERR_ARG, "bad arguments");
   for (int i = 0; i < n_dev; ++i) out[i] = nullptr;
@@ -2744,15 +2867,8 @@ int agp_set_data_multi(agp_ctx* const* ctxs, int32_t n_dev, const double* ts, co
   return AGP_OK;
 }
 
-int agp_allgather_logweights_device(agp_ctx* c, const double* d_local, int32_t P, double* d_all, void* hip_stream) {
-  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
-  if (P < 0 || (P > 0 && !d_all)) return fail(c, AGP_ERR_ARG, "bad arguments");
-  if (P == 0) return AGP_OK;
-  int lo, hi;
-  shard_range(P, c->comm_rank, c->comm_size, &lo, &hi);
-  if (hi > lo && !d_local) return fail(c, AGP_ERR_ARG, "null shard pointer");
-  HIPCHK(c, hipSetDevice(c->device));
-  std::lock_guard<std::mutex> g(c->comm_mu);
+// (c->comm_mu held by the caller)
+static int allgather_device_locked(agp_ctx* c, const double* d_local, int32_t P, double* d_all, void* hip_stream) {
   if (!c->comm) {
     // no communicator: a population that lives on this GPU alone
     if (c->comm_size != 1) return fail(c, AGP_ERR_COMM, "no communicator");
@@ -2770,6 +2886,18 @@ int agp_allgather_logweights_device(agp_ctx* c, const double* d_local, int32_t P
   if (rc) return rc;
   if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
   return AGP_OK;
+}
+
+int agp_allgather_logweights_device(agp_ctx* c, const double* d_local, int32_t P, double* d_all, void* hip_stream) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (P < 0 || (P > 0 && !d_all)) return fail(c, AGP_ERR_ARG, "bad arguments");
+  if (P == 0) return AGP_OK;
+  int lo, hi;
+  shard_range(P, c->comm_rank, c->comm_size, &lo, &hi);
+  if (hi > lo && !d_local) return fail(c, AGP_ERR_ARG, "null shard pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::lock_guard<std::mutex> g(c->comm_mu);
+  return allgather_device_locked(c, d_local, P, d_all, hip_stream);
 }
 
 // Test hook for the un-padding step of unequal shards (a one-GPU box can only form a one-rank communicator, where every
@@ -2797,14 +2925,13 @@ int agp_allgather_logweights(agp_ctx* c, double* inout_lw, int32_t P) {
   HIPCHK(c, hipSetDevice(c->device));
   int lo, hi;
   shard_range(P, c->comm_rank, c->comm_size, &lo, &hi);
-  {
-    std::lock_guard<std::mutex> g(c->comm_mu);
-    HIPCHK(c, c->comm_all.ensure(sizeof(double) * (size_t)P * 2));
-  }
+  // the staging buffer belongs to the context: the lock covers its (re)allocation AND its use
+  std::lock_guard<std::mutex> g(c->comm_mu);
+  HIPCHK(c, c->comm_all.ensure(sizeof(double) * (size_t)P * 2));
   double* d_all = c->comm_all.as<double>();
   double* d_loc = d_all + P;
   if (hi > lo) HIPCHK(c, hipMemcpyAsync(d_loc, inout_lw + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyHostToDevice, c->comm_stream));
-  int rc = agp_allgather_logweights_device(c, d_loc, P, d_all, c->comm_stream);
+  int rc = allgather_device_locked(c, d_loc, P, d_all, c->comm_stream);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(inout_lw, d_all, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, c->comm_stream));
   HIPCHK(c, hipStreamSynchronize(c->comm_stream));
@@ -2815,6 +2942,30 @@ int agp_allgather_logweights(agp_ctx* c, double* inout_lw, int32_t P) {
 // particles over the contexts of agp_init_multi, run each shard's sweep from its own host thread with the results
 // left on its device, all-gather the log-weights over RCCL (one group call over the node's communicators), and
 // hand the complete vector back from device 0.  Every device ends up holding the full vector.
+static agp_ctx::Worker* ensure_worker(agp_ctx* c) {
+  if (c->worker) return c->worker;
+  agp_ctx::Worker* w = new agp_ctx::Worker();
+  c->worker = w;
+  const int dev = c->device;
+  w->th = std::thread([w, dev]() {
+    (void)hipSetDevice(dev);
+    std::unique_lock<std::mutex> g(w->mu);
+    for (;;) {
+      w->cv.wait(g, [&] { return w->has_job || w->stop; });
+      if (w->stop) return;
+      std::function<void()> job;
+      job.swap(w->job);
+      w->has_job = false;
+      g.unlock();
+      job();
+      g.lock();
+      w->done = true;
+      w->cv.notify_all();
+    }
+  });
+  return w;
+}
+
 static int logpdf_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off,
                                    const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
                                    double* out_logpdf, int32_t* out_info, bool extend) {
@@ -2828,36 +2979,49 @@ static int logpdf_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t 
       return fail(c0, AGP_ERR_ARG, "contexts must come from agp_init_multi, in order");
   const int mx = (P + n_dev - 1) / n_dev;
   std::vector<int> rcs((size_t)n_dev, AGP_OK);
-  std::vector<std::thread> th;
-  for (int d = 0; d < n_dev; ++d) {
-    th.emplace_back([&, d]() {
-      agp_ctx* c = ctxs[d];
-      int lo, hi;
-      shard_range(P, d, n_dev, &lo, &hi);
-      if (hipSetDevice(c->device) != hipSuccess) { rcs[d] = fail(c, AGP_ERR_HIP, "hipSetDevice failed"); return; }
-      {
-        std::lock_guard<std::mutex> g(c->comm_mu);
-        if (c->comm_all.ensure(sizeof(double) * ((size_t)P + mx)) != hipSuccess) { rcs[d] = fail(c, AGP_ERR_HIP, "allocation failed"); return; }
-      }
-      if (hi == lo) return;
-      const int Pl = hi - lo;
-      std::vector<int32_t> oo((size_t)Pl + 1), po((size_t)Pl + 1);
-      for (int i = 0; i <= Pl; ++i) { oo[i] = op_off[lo + i] - op_off[lo]; po[i] = prm_off[lo + i] - prm_off[lo]; }
-      double* d_loc = c->comm_all.as<double>() + P;
-      if (extend) {
-        // every device keeps the factors of ITS shard resident (block sharding is stable while the population order is;
-        // a particle that lands on another device after resampling is simply factored from scratch there)
-        std::vector<double> hl((size_t)Pl);
-        rcs[d] = extend_impl(c, n, Pl, oo.data(), ops + op_off[lo], po.data(), prm + prm_off[lo], noise + lo, hl.data(), out_info + lo);
-        if (rcs[d] == AGP_OK && hipMemcpy(d_loc, hl.data(), sizeof(double) * (size_t)Pl, hipMemcpyHostToDevice) != hipSuccess)
-          rcs[d] = fail(c, AGP_ERR_HIP, "copy of the shard's log-weights failed");
-      } else {
-        rcs[d] = logpdf_batch_impl(c, n, Pl, oo.data(), ops + op_off[lo], po.data(), prm + prm_off[lo], noise + lo, nullptr,
-                                   out_info + lo, d_loc, nullptr, nullptr, false);
-      }
-    });
+  auto shard = [&](int d) {
+    agp_ctx* c = ctxs[d];
+    int lo, hi;
+    shard_range(P, d, n_dev, &lo, &hi);
+    if (hipSetDevice(c->device) != hipSuccess) { rcs[d] = fail(c, AGP_ERR_HIP, "hipSetDevice failed"); return; }
+    {
+      std::lock_guard<std::mutex> g(c->comm_mu);
+      if (c->comm_all.ensure(sizeof(double) * ((size_t)P + mx)) != hipSuccess) { rcs[d] = fail(c, AGP_ERR_HIP, "allocation failed"); return; }
+    }
+    if (hi == lo) return;
+    const int Pl = hi - lo;
+    std::vector<int32_t> oo((size_t)Pl + 1), po((size_t)Pl + 1);
+    for (int i = 0; i <= Pl; ++i) { oo[i] = op_off[lo + i] - op_off[lo]; po[i] = prm_off[lo + i] - prm_off[lo]; }
+    double* d_loc = c->comm_all.as<double>() + P;
+    if (extend) {
+      // every device keeps the factors of ITS shard resident (block sharding is stable while the population order is;
+      // a particle that lands on another device after resampling is simply factored from scratch there).  The shard's
+      // log-weights are also left on the device, in caller order, for the gather (no host round trip).
+      std::vector<double> hl((size_t)Pl);
+      bool on_device = false;
+      rcs[d] = extend_impl(c, n, Pl, oo.data(), ops + op_off[lo], po.data(), prm + prm_off[lo], noise + lo, hl.data(), out_info + lo,
+                           d_loc, &on_device);
+      if (rcs[d] == AGP_OK && !on_device &&      // (n = 0, or the sweep fell back to the plain entry: host results only)
+          hipMemcpy(d_loc, hl.data(), sizeof(double) * (size_t)Pl, hipMemcpyHostToDevice) != hipSuccess)
+        rcs[d] = fail(c, AGP_ERR_HIP, "copy of the shard's log-weights failed");
+    } else {
+      rcs[d] = logpdf_batch_impl(c, n, Pl, oo.data(), ops + op_off[lo], po.data(), prm + prm_off[lo], noise + lo, nullptr,
+                                 out_info + lo, d_loc, nullptr, nullptr, false);
+    }
+  };
+  // devices 1 .. n_dev-1 run on their contexts' persistent host threads (created at the first call, joined by
+  // agp_destroy), device 0's shard on the calling thread
+  for (int d = 1; d < n_dev; ++d) {
+    agp_ctx::Worker* w = ensure_worker(ctxs[d]);
+    { std::lock_guard<std::mutex> g(w->mu); w->job = [&shard, d]() { shard(d); }; w->has_job = true; w->done = false; }
+    w->cv.notify_all();
   }
-  for (auto& t : th) t.join();
+  shard(0);
+  for (int d = 1; d < n_dev; ++d) {
+    agp_ctx::Worker* w = ctxs[d]->worker;
+    std::unique_lock<std::mutex> g(w->mu);
+    w->cv.wait(g, [&] { return w->done; });
+  }
   for (int d = 0; d < n_dev; ++d)
     if (rcs[d]) { if (d) fail(c0, rcs[d], agp_last_error(ctxs[d])); return rcs[d]; }
   if (n_dev == 1) {

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi", "agp_logpdf_batch_extend_multi",
     "agp_debug_flow_trace", "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
-    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache",
+    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count",
 ]
 COMM_ID_BYTES = 128
 
@@ -135,6 +135,8 @@ def load_library(path=None):
     lib.agp_comm_get_unique_id.argtypes = [vp]; lib.agp_comm_get_unique_id.restype = C.c_int
     lib.agp_comm_init_rank.argtypes = [vp, vp, C.c_int32, C.c_int32]; lib.agp_comm_init_rank.restype = C.c_int
     lib.agp_comm_info.argtypes = [vp, i32p, i32p]; lib.agp_comm_info.restype = C.c_int
+    lib.agp_comm_count.argtypes = [vp, i32p]; lib.agp_comm_count.restype = C.c_int
+    lib.agp_wait.argtypes = [vp]; lib.agp_wait.restype = C.c_int
     lib.agp_init_multi.argtypes = [C.POINTER(vp), i32p, C.c_int32]; lib.agp_init_multi.restype = C.c_int
     lib.agp_set_data_multi.argtypes = [C.POINTER(vp), C.c_int32, dp, dp, C.c_int64]; lib.agp_set_data_multi.restype = C.c_int
     lib.agp_allgather_logweights.argtypes = [vp, dp, C.c_int32]; lib.agp_allgather_logweights.restype = C.c_int
@@ -202,6 +204,16 @@ class GPEngine:
         r = C.c_int32(); n = C.c_int32()
         has = self._lib.agp_comm_info(self._ctx, C.byref(r), C.byref(n))
         return bool(has), r.value, n.value
+
+    def comm_count(self):
+        """Ranks RCCL reports for this context's communicator (ncclCommCount); 0 without one."""
+        n = C.c_int32()
+        self._check(self._lib.agp_comm_count(self._ctx, C.byref(n)))
+        return n.value
+
+    def wait(self):
+        """agp_wait: block until every asynchronously enqueued sweep has completed; raises on a latched kernel timeout."""
+        self._check(self._lib.agp_wait(self._ctx))
 
     def allgather_logweights(self, lw):
         """Host form: `lw` (P float64) with this rank's block filled; returns the complete vector."""
@@ -446,10 +458,10 @@ class GPEngine:
         self._check(self._lib.agp_set_profiling(self._ctx, 1 if on else 0))
 
     def timing(self):
-        out = np.zeros(8)
-        self._check(self._lib.agp_get_timing(self._ctx, _dp(out), 8))
+        out = np.zeros(12)
+        self._check(self._lib.agp_get_timing(self._ctx, _dp(out), 12))
         keys = ["total_ms", "cov_build_ms", "chol_update_ms", "chol_trsm_ms", "finish_ms", "n_update_launches",
-                "n_trsm_launches", "h2d_ms"]
+                "n_trsm_launches", "h2d_ms", "grad_trtri_ms", "grad_kinv_ms", "grad_contract_ms", "grad_alpha_finish_ms"]
         return dict(zip(keys, out.tolist()))
 
     def launch_times(self, which=0, n=64):

@@ -311,6 +311,14 @@ function comm_init_rank!(eng::Engine, id::Vector{UInt8}, n_ranks::Integer, rank:
     @assert length(id) == COMM_ID_BYTES
     GC.@preserve id check(eng, ccall((:agp_comm_init_rank, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), eng.ptr, id, n_ranks, rank))
 end
+"ranks RCCL itself reports for the engine's communicator (ncclCommCount); 0 without one"
+function comm_count(eng::Engine)
+    n = Ref{Int32}(0)
+    check(eng, ccall((:agp_comm_count, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}), eng.ptr, n))
+    return Int(n[])
+end
+"block until every asynchronously enqueued sweep of the engine has completed (reports a latched in-kernel timeout)"
+wait!(eng::Engine) = check(eng, ccall((:agp_wait, LIB), Cint, (Ptr{Cvoid},), eng.ptr))
 "block [lo, hi] (1-based, inclusive) of rank `rank` (0-based) — identical on every rank"
 function shard_range(P::Integer, rank::Integer, n_ranks::Integer)
     lo = Ref{Int32}(0); hi = Ref{Int32}(0)

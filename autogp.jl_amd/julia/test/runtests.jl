@@ -174,5 +174,13 @@ kernels() = GP.Node[
                      ref_logpdf(H.node_from_flat(ops, th4), nz4, ts, tr4[:xs])) <= 1e-12
     end
 
+    @testset "communicator bookkeeping, explicit wait" begin
+        @test H.comm_count(eng) == 0                     # no communicator on a plain single-GPU engine
+        @test H.shard_range(11, 1, 2) == 7:11 && H.shard_range(11, 0, 2) == 1:6
+        H.wait!(eng)                                     # nothing pending: returns at once, no latched fault
+        lw = collect(1.0:5.0)
+        @test H.allgather_logweights!(eng, copy(lw)) == lw      # one rank: already complete
+    end
+
     H.destroy!(eng)
 end

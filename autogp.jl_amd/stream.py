@@ -45,13 +45,17 @@ class EngineEvaluator:
 class OnlineStream:
     """State of one rank: the WHOLE population's programs (host side, a few KB) and this rank's block of it."""
 
-    def __init__(self, nodes, noises, evaluate, rank=0, world=1, allgather=None, adaptive_resampling=True, seed=0):
+    def __init__(self, nodes, noises, evaluate, rank=0, world=1, allgather=None, adaptive_resampling=True, seed=0,
+                 allgather_objects=None):
         self.nodes = list(nodes)
         self.noises = np.asarray(noises, dtype=np.float64).copy()
         self.P = len(self.nodes)
         self.rank, self.world = int(rank), int(world)
         self.evaluate = evaluate
         self.allgather = allgather                   # callable(full_vector_with_local_block_filled) -> full vector
+        # callable(obj) -> [obj of rank 0, obj of rank 1, ...]: the HOST channel the rejuvenated blocks' programs travel
+        # over (a few hundred bytes per particle; torch.distributed.all_gather_object, MPI, Julia's Distributed ...)
+        self.allgather_objects = allgather_objects
         self.adaptive_resampling = adaptive_resampling
         self.seed = int(seed)
         self.log_weights = np.zeros(self.P)
@@ -102,7 +106,41 @@ class OnlineStream:
         if rejuvenate is not None:
             # hook(nodes, noises, lo, hi) -> (nodes_block, noises_block, logpdf_block) for this rank's block, or None
             out = rejuvenate(self.nodes[lo:hi], self.noises[lo:hi], int(n))
-            if out is not None:
+            if self.world > 1:
+                # Every rank keeps the WHOLE population's programs (the next resampling step copies particles across
+                # blocks), so the moved blocks of all ranks are exchanged: encoded programs + noises through the host
+                # channel, log-pdfs through the log-weight all-gather.  All ranks take part, moved or not.
+                if self.allgather_objects is None:
+                    if out is not None:
+                        raise RuntimeError("world > 1: a rejuvenation hook that changes particles needs allgather_objects "
+                                           "(every rank must learn the other blocks' new programs and noises)")
+                    blocks = None
+                else:
+                    mine = None
+                    if out is not None:
+                        nb, zb, lb = out
+                        if len(nb) != hi - lo:
+                            raise ValueError("the rejuvenation hook must return its whole block")
+                        mine = ([nd.to_tuple() for nd in nb], np.asarray(zb, dtype=np.float64).tolist())
+                    blocks = self.allgather_objects(mine)
+                    if len(blocks) != self.world:
+                        raise RuntimeError("allgather_objects must return one entry per rank")
+                moved = blocks is not None and any(b is not None for b in blocks)
+                if moved:
+                    for r, b in enumerate(blocks):
+                        if b is None:
+                            continue
+                        rlo, rhi = _dist.shard_range(self.P, r, self.world)
+                        if r == self.rank:
+                            self.nodes[rlo:rhi] = list(out[0])
+                        else:
+                            self.nodes[rlo:rhi] = [_gp.from_tuple(t) for t in b[0]]
+                        self.noises[rlo:rhi] = np.asarray(b[1], dtype=np.float64)
+                    # ranks that did not move keep their block's log-pdfs
+                    lb_local = np.asarray(out[2], dtype=np.float64) if out is not None else self.prev_logpdf[lo:hi]
+                    self.prev_logpdf = self._gather(lb_local)
+                    rejuvenated = True
+            elif out is not None:
                 nb, zb, lb = out
                 self.nodes[lo:hi] = list(nb); self.noises[lo:hi] = np.asarray(zb, dtype=np.float64)
                 full = self._gather(np.asarray(lb, dtype=np.float64))

@@ -2,7 +2,13 @@
 """Benchmark of the GP marginal-likelihood hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 needs no launcher: started plainly, this script re-executes itself as N ranks (one per GPU) under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` and relays
+rank 0's JSON line; started BY such a launcher (RANK / WORLD_SIZE in the environment) it is one of the ranks.
+`--single-process` instead drives all N GPUs from ONE host process through agp_init_multi + agp_logpdf_batch_multi
+(the deployment of a single Julia process: one persistent host thread per device inside the library, RCCL group all-gather)
+and prints the same line.
 
 One "step" = one pass of the hot path over the particle population: for every particle of the rank's
 shard, covariance build from its kernel program at n observations -> + (noise+jitter) I -> fp64
@@ -17,6 +23,11 @@ scaling: 512/N particles per GPU — BASELINE's metric and config are quoted on 
 `--weak` keeps 512 particles PER GPU instead (population 512 N).  ts/xs are resident in HBM before the
 timed region; kernel programs (a few KB) are handed over per call, as the reference's call site would.
 
+After the timed region (N = 1 only, never inside it) three short legs put the paths beside the value sweep into the same
+record: the stand-alone covariance builder (GB/s written, leaf evaluations/s: SURVEY.md §8(d) K1), the value+gradient sweep
+(src/inference_smc_anneal_data.jl:63-67: where fit_smc! spends its time) and the marginal predictive pass at m = 2n
+(src/GP.jl:731-758).  `--no-extra-legs` skips them.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -24,6 +35,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -40,6 +53,7 @@ NB = 128
 # fp64 matrix peak of MI355X: 256 CU x 4 SIMD x 2.4 GHz x 32 flop/clk/SIMD (v_mfma_f64_16x16x4 =
 # 2048 flop / 64 cycles) = 78.6 TFLOP/s (AMD spec figure; MI355X_MICROARCH.md lists clocks/CUs).
 PEAK_FP64_MFMA_TFLOPS = 78.6
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def cholesky_flops(n):          # LAPACK convention, SURVEY.md §8(d)
@@ -61,6 +75,12 @@ def diag_kernel_flops(n):
     return float(sum(NB * (NB + 1.0) * (k * NB) + NB ** 3 / 3.0 for k in range(nt)))
 
 
+def algorithmic_bytes_per_eval(n):
+    """8 n^2 bytes per evaluation when the covariance build is fused into the factorisation (K is never
+    written and re-read: the factor is written once), 16 n^2 unfused."""
+    return 8.0 * n * n
+
+
 # ------------------------------------------------------------------------------------------------
 # CPU baseline leg: oracle/fast.py — the C restatement of eval_cov assembles the lower triangle, SciPy's
 # LAPACK (OpenBLAS, the family Julia's LinearAlgebra links) does dpotrf + dtrtrs; one particle per host
@@ -72,6 +92,8 @@ def cpu_baseline(programs, noises, ts, xs, gpu_lp, budget_s=20.0):
     cores = F.host_cores()
     P = len(noises)
     with F.OraclePool(programs, noises, ts, xs, workers=min(cores, P)) as pool:     # start-up is not timed
+        # ONE worker alone first (two particles): the uncontended per-core rate, to read the saturated-socket figure against
+        t0 = time.time(); pool.evaluate(range(min(2, P)), max_workers=1); t_one = (time.time() - t0) / min(2, P)
         # calibrate on one particle per worker, then size the sample to ~budget_s (at most the population)
         ncal = min(P, pool.workers)
         t0 = time.time(); pool.evaluate(range(ncal)); t_cal = time.time() - t0
@@ -92,7 +114,255 @@ def cpu_baseline(programs, noises, ts, xs, gpu_lp, budget_s=20.0):
                       f"(oracle/agp_oracle.c) + LAPACK dpotrf/dtrtrs via SciPy-OpenBLAS (Julia reference not installed), "
                       f"one particle per worker process ({used} workers on {cores} host cores), 1 BLAS thread each, {dt:.1f} s",
             "gflops": gf, "gflops_per_core": gf / max(1, min(used, ns)),
+            "one_worker_evals_per_s": 1.0 / t_one, "one_worker_gflops": cholesky_flops(len(ts)) / t_one / 1e9,
+            "one_worker_note": "the same code with ONE worker process on an otherwise idle host: the uncontended per-core rate "
+                               "(the all-core figure is a saturated socket: memory bandwidth and shared caches, not the port, limit it)",
             "parity_max_rel_err_vs_gpu": err}
+
+
+# ------------------------------------------------------------------------------------------------
+# Legs beside the value sweep (world == 1, after the timed region)
+# ------------------------------------------------------------------------------------------------
+def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
+    import torch
+    op_off, ops, prm_off, prm = programs
+    P = len(noises)
+    nt = (n + NB - 1) // NB
+    ntiles = nt * (nt + 1) // 2
+    out = {}
+    stream = torch.cuda.current_stream().cuda_stream
+    # ---- K1: the stand-alone covariance builder k_cov_tiles on EVERY tile of EVERY particle (a second context with the
+    #      in-kernel evaluation switched off: AGP_FUSE=0 is read by agp_init) ----
+    try:
+        old = os.environ.get("AGP_FUSE"); old_flow = os.environ.get("AGP_FLOW")
+        os.environ["AGP_FUSE"] = "0"; os.environ["AGP_FLOW"] = "0"
+        try:
+            e2 = pkg.GPEngine(device)
+        finally:
+            for k, v in (("AGP_FUSE", old), ("AGP_FLOW", old_flow)):
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        e2.set_data(ts, xs)
+        d_lp = torch.zeros(P, dtype=torch.float64, device=f"cuda:{device}"); d_info = torch.zeros(P, dtype=torch.int32, device=f"cuda:{device}")
+        e2.logpdf_batch_device(programs, noises, n, d_lp.data_ptr(), d_info.data_ptr(), stream); torch.cuda.synchronize()
+        e2.set_profiling(True)
+        reps, ms = 3, 0.0
+        for _ in range(reps):
+            e2.logpdf_batch_device(programs, noises, n, d_lp.data_ptr(), d_info.data_ptr(), stream); torch.cuda.synchronize()
+            ms += e2.timing()["cov_build_ms"]
+        e2.set_profiling(False); e2.close()
+        ms /= reps
+        leaves = int((ops[: op_off[P]] <= 5).sum())
+        bytes_w = float(P) * ntiles * NB * NB * 8
+        gbs = bytes_w / (ms * 1e-3) / 1e9
+        out["roofline_cov_kernel"] = {
+            "kernel": "k_cov_tiles<D> (stand-alone tile builder: every tile of every particle, AGP_FUSE=0 context)", "bound": "hbm",
+            "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "ms": ms,
+            "algorithmic_bytes": bytes_w + 8.0 * n, "leaf_evals_per_s": leaves / P * (P * ntiles * NB * NB) / (ms * 1e-3),
+            "leaves_per_particle": leaves / P,
+            "note": "HBM-write bound only for trivial kernels; with transcendental leaves it is fp64-VALU bound (SURVEY.md §8(d)): both figures reported"}
+    except Exception as e:      # noqa: BLE001
+        out["roofline_cov_kernel"] = {"error": str(e)[:300]}
+    # ---- value + gradient sweep (agp_logpdf_grad_batch): Cholesky, L^-T, K^-1 tiles, per-element reverse sweep of the programs ----
+    try:
+        eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
+        eng.set_profiling(True)
+        reps = 3; acc = {}
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
+            for k, v in eng.timing().items():
+                acc[k] = acc.get(k, 0.0) + v
+        dt = (time.perf_counter() - t0) / reps
+        eng.set_profiling(False)
+        tf = P * float(n) ** 3 / dt / 1e12
+        out["grad"] = {"what": "value + gradient sweep of the same population (agp_logpdf_grad_batch, host outputs; HIP-event marks on)",
+                       "evals_per_s": P / dt, "ms_per_sweep": dt * 1e3, "tflops_on_n3": tf, "frac_of_fp64_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
+                       "flop_count": "n^3 per particle: factorisation n^3/3 + L^-T n^3/3 + K^-1 = Z Z^T n^3/3",
+                       "kernel_ms": {"factorisation": (acc["chol_update_ms"] + acc["chol_trsm_ms"] + acc["cov_build_ms"]) / reps,
+                                     "k_trtri_chain": acc["grad_trtri_ms"] / reps, "k_kinv_tiles": acc["grad_kinv_ms"] / reps,
+                                     "k_grad_contract": acc["grad_contract_ms"] / reps, "k_alpha+k_grad_finish": acc["grad_alpha_finish_ms"] / reps}}
+    except Exception as e:      # noqa: BLE001
+        out["grad"] = {"error": str(e)[:300]}
+    # ---- marginal predictive pass at m = 2n (means + variances: what Inference.predict / quantile consume) ----
+    try:
+        Pp = min(P, 128)
+        m = 2 * n
+        tq = np.linspace(0.0, 1.25, m)
+        eng.predict_batch(nodes[:Pp], noises[:Pp], tq, n=n, check=False)
+        reps = 2
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng.predict_batch(nodes[:Pp], noises[:Pp], tq, n=n, check=False)
+        dt = (time.perf_counter() - t0) / reps
+        fl = Pp * (cholesky_flops(n) + float(n) * n * m)
+        out["predict"] = {"what": f"agp_predict_batch, first {Pp} particles, n={n}, m={m} query points, marginal variances (out_cov = NULL), "
+                                  f"host outputs, K11 factored by the pass", "ms": dt * 1e3, "particles": Pp, "m": m,
+                          "tflops": fl / dt / 1e12, "frac_of_fp64_mfma_peak": fl / dt / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                          "flop_count": "n^3/3 + n^2 m per particle"}
+    except Exception as e:      # noqa: BLE001
+        out["predict"] = {"error": str(e)[:300]}
+    return out
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started plainly: become the launcher of N ranks and relay their output."""
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["AGP_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve())] + sys.argv[1:]
+    print("[bench] self-launch:", " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def build_roofline(pkg, acc, n_prof, args, n, P, world, prof_every):
+    """roofline blocks from the engine's HIP-event timings of rank 0's shard (P particles)."""
+    n_upd = max(1.0, acc.get("n_update_launches", 0.0))
+    n_dg = max(1.0, acc.get("n_trsm_launches", 0.0))
+    upd_ms = acc["chol_update_ms"] / n_upd                      # average launch duration of k_chol_update
+    nt = (n + NB - 1) // NB
+    # large-population schedule (>= 256 particles on the rank): diagonal tiles in their own launch (reported
+    # under the engine's "trsm" timing keys), sub-diagonal tiles (update + in-register solve) in the dominant
+    # kernel, nt-1 launches per sweep.  Smaller shards take the dataflow schedule: one launch per sweep.
+    intrsm = os.environ.get("AGP_INTRSM", "1") != "0"
+    sd_env = os.environ.get("AGP_SPLIT_DIAG", "-1")
+    split_diag = intrsm and (sd_env == "1" or (sd_env not in ("0", "1") and P >= 256))
+    # (what actually ran decides: non-default schedule switches — AGP_STREAMS, AGP_FLOW — move a large shard onto the
+    # dataflow kernel, which has no separate diagonal launches)
+    split_diag = split_diag and acc.get("n_trsm_launches", 0.0) > 0 and acc.get("chol_trsm_ms", 0.0) > 0
+    diag_block = None
+    if split_diag:
+        kernel_name = "k_chol_update<true,DCOV,true,2,TAB>"
+        upd_flops_launch = P * subdiag_kernel_flops(n) / max(1, nt - 1)
+        dg_ms = acc["chol_trsm_ms"] / n_dg
+        dg_flops = P * diag_kernel_flops(n) / nt
+        dg_ach = dg_flops / (dg_ms * 1e-3) / 1e12
+        diag_block = {"kernel": "k_chol_diag<DCOV,TAB>", "achieved": dg_ach, "frac": dg_ach / PEAK_FP64_MFMA_TFLOPS,
+                      "avg_launch_ms": dg_ms, "launches_per_step": n_dg / n_prof, "ms_per_step": acc["chol_trsm_ms"] / n_prof,
+                      "algorithmic_flops_per_launch": dg_flops}
+    elif round(n_upd / n_prof) == 1:
+        # dataflow schedule (default up to 400 particles per rank): the whole factorisation — diagonal factorisations,
+        # updates, panel solves, in-kernel tile evaluation — is ONE launch of persistent workgroups
+        kernel_name = "k_chol_flow<DCOV,TAB> (dataflow schedule: every tile of the sweep in one launch)"
+        upd_flops_launch = P * cholesky_flops(n)
+    else:
+        kernel_name = "k_chol_update (every update-kernel launch of the sweep: mixed left-looking columns, catch-up, right-looking)"
+        upd_flops_launch = P * (cholesky_flops(n) - nt * NB ** 3 / 3.0) / (n_upd / n_prof)
+    achieved = upd_flops_launch / (upd_ms * 1e-3) / 1e12
+    traffic = None; traffic_src = None; traffic_step = None
+    tf = ROOT / "profiles" / "hbm_traffic.json"
+    if tf.exists() and split_diag and world == 1 and n == N_OBS and P == P_POPULATION:
+        try:
+            tj = json.loads(tf.read_text())
+            traffic = tj.get("k_chol_update_bytes_per_launch")
+            traffic_step = tj.get("bytes_per_step")
+            traffic_src = {"file": "profiles/hbm_traffic.json", "tag": tj.get("tag"), "date": tj.get("date"),
+                           "note": "rocprofv3 --pmc pass of this command on an earlier box (FETCH_SIZE, WRITE_SIZE corrected per MI355X_MICROARCH.md); not re-measured in this run"}
+        except Exception:
+            traffic = None
+    alg_step = P * algorithmic_bytes_per_eval(n)
+    roof = {"kernel": kernel_name, "bound": "mfma", "achieved": achieved,
+            "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
+            "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": upd_ms,
+            "launches_per_step": n_upd / n_prof, "algorithmic_flops_per_launch": upd_flops_launch,
+            "algorithmic_bytes_per_step": alg_step,
+            "algorithmic_bytes_note": "SURVEY.md §8(d): 8 n^2 bytes per evaluation with the covariance build fused into the factorisation (the factor written once), x particles of the step",
+            "traffic_bytes_per_step": traffic_step,
+            "traffic_ratio": (traffic_step / alg_step) if traffic_step else None,
+            "timing": f"HIP events recorded by the engine on the launch stream around every launch of {n_prof} of the {args.steps} timed steps "
+                      f"(every {prof_every}th: the marks and their readout cost ~1 % of a step; rank 0)"}
+    return roof, diag_block, split_diag
+
+
+def run_single_process(args):
+    """ONE host process drives all N GPUs: agp_init_multi (contexts + ncclCommInitAll), agp_logpdf_batch_multi per step
+    (shards on persistent per-device host threads inside the library, one RCCL group all-gather, complete vector back on
+    the host).  What a single Julia process would run."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    ndev = args.gpus
+    if ndev > torch.cuda.device_count():
+        raise SystemExit(f"--single-process --gpus {ndev} but only {torch.cuda.device_count()} device(s) are visible")
+    pkg = g.load_package()
+    multi = pkg.GPEngineMulti(list(range(ndev)))
+    n = args.n
+    ts, xs = pkg.prior.synthetic_series(n, seed=2048, shuffle=True)
+    P_total = args.particles * ndev if args.weak else args.particles
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(2048), P_total, max_depth=-1, max_size=63)
+    programs = pkg.encode_batch(nodes)
+    multi.set_data(ts, xs)
+    eng0 = multi.engines[0]
+    P0 = pkg.shard_range(P_total, 0, ndev)[1]
+    ranks_seen = [e.comm_count() for e in multi.engines]
+
+    def step():
+        return multi.logpdf_batch(None, noises, n=n, check=False, programs=programs)
+
+    prewarm_s = float(os.environ.get("AGP_BENCH_PREWARM_S", "1.5"))
+    n_prewarm = 0
+    if prewarm_s > 0:
+        step(); step()
+        t_pw = time.perf_counter(); step(); one = max(time.perf_counter() - t_pw, 1e-4)
+        n_prewarm = int(min(4000, max(0, round(prewarm_s / one))))
+        for _ in range(n_prewarm):
+            step()
+        n_prewarm += 3
+    for _ in range(args.warmup):
+        step()
+    prof_every = 1 if args.steps < 8 else max(1, int(os.environ.get("AGP_BENCH_PROF_EVERY", "4")))
+    acc = {}; n_prof = 0
+    for d in range(ndev):
+        torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        prof = i % prof_every == 0
+        eng0.set_profiling(prof)
+        lp, info = step()
+        if prof:
+            n_prof += 1
+            for k, v in eng0.timing().items():
+                acc[k] = acc.get(k, 0.0) + v
+    for d in range(ndev):
+        torch.cuda.synchronize(d)
+    dt = time.perf_counter() - t0
+    eng0.set_profiling(False)
+    # self-check: the gathered vector equals every device's own sweep of its shard
+    ok = True
+    for d, e in enumerate(multi.engines):
+        lo, hi = pkg.shard_range(P_total, d, ndev)
+        if hi > lo:
+            ref, _ = e.logpdf_batch(nodes[lo:hi], noises[lo:hi], n=n, check=False)
+            ok = ok and bool(np.array_equal(ref, lp[lo:hi], equal_nan=True))
+    roof, diag_block, split_diag = build_roofline(pkg, acc, n_prof, args, n, P0, ndev, prof_every)
+    evals_s = P_total * args.steps / dt
+    chol_gf = evals_s * cholesky_flops(n) / 1e9
+    out = {"metric": "particle_logpdf_evals_per_sec", "value": evals_s, "unit": "evals/s", "n_gpus": ndev, "steps": args.steps,
+           "warmup": args.warmup, "prewarm_steps": n_prewarm, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"AutoGP config-3 final annealing step: n={n} observations, population of {P_total} particles, kernel trees "
+                                  f"sampled from the restated AutoGP prior; ONE host process drives {ndev} GPU(s): agp_logpdf_batch_multi "
+                                  f"(per-device host threads inside the library + one RCCL group all-gather), complete vector returned to the host",
+                      "n": n, "particles_total": P_total, "particles_per_gpu": P0, "tile": NB, "not_positive_definite": int((info != 0).sum()),
+                      "parallelism": f"particle-shard x{ndev} (single process)", "launch": "single-process (agp_init_multi)",
+                      "collective": "rccl via C ABI (ncclCommInitAll + one ncclGroup of all-gathers inside agp_logpdf_batch_multi)" if ndev > 1 else None,
+                      "rccl_ranks_seen": ranks_seen, "allgather_selfcheck": ok},
+           "cholesky_gflops": chol_gf, "sweep_frac_of_fp64_mfma_peak": chol_gf / 1e3 / (PEAK_FP64_MFMA_TFLOPS * ndev),
+           "roofline": roof}
+    if diag_block:
+        out["roofline_diag_kernel"] = diag_block
+    print(json.dumps(out), flush=True)
+    multi.close()
 
 
 def main():
@@ -104,14 +374,22 @@ def main():
     ap.add_argument("--particles", type=int, default=P_POPULATION, help="population size (total; per GPU with --weak)")
     ap.add_argument("--weak", action="store_true", help="--particles per GPU instead of in total")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the covariance-builder / gradient / predictive legs (N = 1)")
+    ap.add_argument("--single-process", action="store_true", help="one host process drives all --gpus devices (agp_init_multi)")
     args = ap.parse_args()
+
+    if args.single_process:
+        return run_single_process(args)
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(self_launch(args))
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
     # AGP_BENCH_SHARE_GPU=1 (tests only): all ranks use cuda:0 and the collective runs over gloo (RCCL refuses two
@@ -119,6 +397,9 @@ def main():
     share = os.environ.get("AGP_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} device(s) are visible "
+                         f"(AGP_BENCH_SHARE_GPU=1 runs every rank on cuda:0 for tests)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -130,6 +411,7 @@ def main():
     eng = pkg.GPEngine(local_rank)
     collective = None
     nccl_group = None
+    ranks_seen = None
     if world > 1 and share:
         collective = "gloo (shared-GPU test mode)"
     elif world > 1:
@@ -143,6 +425,7 @@ def main():
         if ids[0] is not None:
             try:
                 eng.comm_init_rank(ids[0], world, rank)
+                ranks_seen = eng.comm_count()
             except Exception as e:      # noqa: BLE001
                 err = str(e)
         else:
@@ -155,6 +438,7 @@ def main():
                   f"falling back to torch.distributed nccl", file=sys.stderr, flush=True)
             nccl_group = dist.new_group(backend="nccl")
             collective = "torch.distributed nccl (fallback; engine communicator failed to initialise)"
+            ranks_seen = None
     n = args.n
     ts, xs = pkg.prior.synthetic_series(n, seed=2048, shuffle=True)
     P_total = args.particles * world if args.weak else args.particles
@@ -230,12 +514,18 @@ def main():
             for k, v in eng.timing().items():
                 acc[k] = acc.get(k, 0.0) + v
     sync()
-    dt = time.perf_counter() - t0
+    dt_rank = time.perf_counter() - t0
+    dt = dt_rank
     eng.set_profiling(False)
+    eng.wait()                     # (reports a latched in-kernel timeout of the asynchronous sweeps, if there ever was one)
+    per_rank_ms = [dt_rank / args.steps * 1e3]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        allt = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(allt, torch.tensor([dt_rank / args.steps * 1e3], dtype=torch.float64))
+        per_rank_ms = [float(x.item()) for x in allt]
 
     lp = d_lp[:P].cpu().numpy(); info = d_info[:P].cpu().numpy()
     n_bad = int((info != 0).sum())
@@ -253,52 +543,14 @@ def main():
         okt = torch.tensor([1 if (mine and same) else 0], dtype=torch.int64)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         gather_ok = bool(okt.item())
+        if ranks_seen is not None:
+            rs = torch.tensor([ranks_seen], dtype=torch.int64)
+            dist.all_reduce(rs, op=dist.ReduceOp.MIN)
+            ranks_seen = int(rs.item())
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         evals_s = P_total * args.steps / dt
-        n_upd = max(1.0, acc.get("n_update_launches", 0.0))
-        n_dg = max(1.0, acc.get("n_trsm_launches", 0.0))
-        upd_ms = acc["chol_update_ms"] / n_upd                      # average launch duration of k_chol_update
-        nt = (n + NB - 1) // NB
-        # large-population schedule (>= 256 particles on the rank): diagonal tiles in their own launch (reported
-        # under the engine's "trsm" timing keys), sub-diagonal tiles (update + in-register solve) in the dominant
-        # kernel, nt-1 launches per sweep.  Smaller shards take the mixed / hybrid schedule: one update-kernel
-        # family, all of its launches pooled.
-        intrsm = os.environ.get("AGP_INTRSM", "1") != "0"
-        sd_env = os.environ.get("AGP_SPLIT_DIAG", "-1")
-        split_diag = intrsm and (sd_env == "1" or (sd_env not in ("0", "1") and P >= 256))
-        # (what actually ran decides: non-default schedule switches — AGP_STREAMS, AGP_FLOW — move a large shard onto the
-        # dataflow kernel, which has no separate diagonal launches)
-        split_diag = split_diag and acc.get("n_trsm_launches", 0.0) > 0 and acc.get("chol_trsm_ms", 0.0) > 0
-        diag_block = None
-        if split_diag:
-            kernel_name = "k_chol_update<true,DCOV,true,2,TAB>"
-            upd_flops_launch = P * subdiag_kernel_flops(n) / max(1, nt - 1)
-            dg_ms = acc["chol_trsm_ms"] / n_dg
-            dg_flops = P * diag_kernel_flops(n) / nt
-            dg_ach = dg_flops / (dg_ms * 1e-3) / 1e12
-            diag_block = {"kernel": "k_chol_diag<DCOV,TAB>", "achieved": dg_ach, "frac": dg_ach / PEAK_FP64_MFMA_TFLOPS,
-                          "avg_launch_ms": dg_ms, "launches_per_step": n_dg / n_prof, "ms_per_step": acc["chol_trsm_ms"] / n_prof,
-                          "algorithmic_flops_per_launch": dg_flops}
-        elif round(n_upd / n_prof) == 1:
-            # dataflow schedule (default up to 400 particles per rank): the whole factorisation — diagonal factorisations,
-            # updates, panel solves, in-kernel tile evaluation — is ONE launch of persistent workgroups
-            kernel_name = "k_chol_flow<DCOV,TAB> (dataflow schedule: every tile of the sweep in one launch)"
-            upd_flops_launch = P * cholesky_flops(n)
-        else:
-            kernel_name = "k_chol_update (every update-kernel launch of the sweep: mixed left-looking columns, catch-up, right-looking)"
-            upd_flops_launch = P * (cholesky_flops(n) - nt * NB ** 3 / 3.0) / (n_upd / n_prof)
-        achieved = upd_flops_launch / (upd_ms * 1e-3) / 1e12
-        traffic = None; traffic_src = None
-        tf = ROOT / "profiles" / "hbm_traffic.json"
-        if tf.exists() and split_diag and world == 1:
-            try:
-                tj = json.loads(tf.read_text())
-                traffic = tj.get("k_chol_update_bytes_per_launch")
-                traffic_src = {"file": "profiles/hbm_traffic.json", "tag": tj.get("tag"), "date": tj.get("date"),
-                               "note": "rocprofv3 --pmc pass of this command on an earlier box (FETCH_SIZE, WRITE_SIZE corrected per MI355X_MICROARCH.md); not re-measured in this run"}
-            except Exception:
-                traffic = None
+        roof, diag_block, split_diag = build_roofline(pkg, acc, n_prof, args, n, P, world, prof_every)
         chol_gf = evals_s * cholesky_flops(n) / 1e9
         out = {
             "metric": "particle_logpdf_evals_per_sec", "value": evals_s, "unit": "evals/s",
@@ -310,22 +562,21 @@ def main():
                                    f"(+ RCCL all-gather of the log-weights through agp_allgather_logweights_device when n_gpus>1)",
                        "n": n, "particles_total": P_total, "particles_per_gpu": P, "tile": NB,
                        "not_positive_definite": n_bad, "parallelism": f"particle-shard x{world}",
-                       "collective": collective,
+                       "launch": ("self-launched torch.distributed.run" if os.environ.get("AGP_BENCH_SELF_LAUNCHED") == "1" else
+                                  "external torch.distributed.run") if world > 1 else "single rank",
+                       "collective": collective, "rccl_ranks_seen": ranks_seen, "per_rank_ms_per_step": per_rank_ms,
                        "allgather_selfcheck": gather_ok},
             "cholesky_gflops": chol_gf,
             "sweep_frac_of_fp64_mfma_peak": chol_gf / 1e3 / (PEAK_FP64_MFMA_TFLOPS * world),
             "phase_ms_per_step": {("chol_diag_tiles_ms" if (split_diag and k == "chol_trsm_ms") else
                                    "chol_subdiag_tiles_ms" if (split_diag and k == "chol_update_ms") else k): acc[k] / n_prof
                                   for k in ("total_ms", "cov_build_ms", "chol_update_ms", "chol_trsm_ms", "finish_ms", "h2d_ms")},
-            "roofline": {"kernel": kernel_name, "bound": "mfma", "achieved": achieved,
-                         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP64_MFMA_TFLOPS,
-                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": upd_ms,
-                         "launches_per_step": n_upd / n_prof, "algorithmic_flops_per_launch": upd_flops_launch,
-                         "timing": f"HIP events recorded by the engine on the launch stream around every launch of {n_prof} of the {args.steps} timed steps "
-                                   f"(every {prof_every}th: the marks and their readout cost ~1 % of a step; rank 0)"},
+            "roofline": roof,
         }
         if diag_block:
             out["roofline_diag_kernel"] = diag_block
+        if world == 1 and not args.no_extra_legs:
+            out.update(extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, local_rank))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(programs, noises, ts, xs, lp)
         print(json.dumps(out), flush=True)

@@ -172,6 +172,15 @@ int agp_logpdf_batch_device(agp_ctx* ctx, int64_t n, int32_t P,
                             const int32_t* prm_off, const double* prm,
                             const double* noise,
                             double* d_out_logpdf, int32_t* d_out_info, void* hip_stream);
+/* CONTRACT of the caller-stream form (changed in round 2, stated here once more because it is easy to miss): the
+ * outputs are NOT complete when the call returns — read them only after synchronising hip_stream (or after work
+ * ordered behind it on that stream).  Numerical failures are in d_out_info as usual.  The one failure that is not
+ * numerical — a kernel's bounded wait for a diagonal factor giving up (info word -7; never observed, it exists so a
+ * fault cannot hang the device) — cannot be returned by a call that does not wait: it is latched in the context when
+ * the call's workspace is next claimed and fails the NEXT agp_logpdf_batch_device call, or agp_wait, with AGP_ERR_HIP.
+ * agp_wait blocks until every asynchronously enqueued sweep of the context has completed and reports (and clears) that
+ * latch; call it before trusting a run that never synchronises through another entry. */
+int agp_wait(agp_ctx* ctx);
 
 /* Posterior predictive of src/GP.jl:731-758 for P particles on the resident (ts, xs)[1:n].
  * mean_train (n) / mean_pred (m) are the values of the `mean` function (NULL = 0).
@@ -220,6 +229,9 @@ int agp_comm_get_unique_id(void* out_id /* AGP_COMM_ID_BYTES */);
 int agp_comm_init_rank(agp_ctx* ctx, const void* id, int32_t n_ranks, int32_t rank);
 /* returns 1 when the context has a communicator, 0 otherwise; rank / n_ranks may be NULL */
 int agp_comm_info(agp_ctx* ctx, int32_t* rank, int32_t* n_ranks);
+/* the number of ranks RCCL itself reports for the context's communicator (ncclCommCount); 0 without a communicator.
+ * What a launcher prints to show that the ranks really met (bench.py: config.rccl_ranks_seen). */
+int agp_comm_count(agp_ctx* ctx, int32_t* out_n_ranks);
 
 /* One host process driving n_dev GPUs (a single Julia process): n_dev contexts + one communicator over them
  * (ncclCommInitAll).  out[i] is the context of device_ids[i] and rank i; destroy each with agp_destroy. */
@@ -234,7 +246,8 @@ int agp_allgather_logweights(agp_ctx* ctx, double* inout_lw, int32_t P);
 int agp_allgather_logweights_device(agp_ctx* ctx, const double* d_local, int32_t P, double* d_all, void* hip_stream);
 
 /* agp_logpdf_batch over the contexts of agp_init_multi: shards the P particles by agp_shard_range, runs every
- * shard's sweep concurrently (one host thread per device), all-gathers the log-weights over RCCL in one group call
+ * shard's sweep concurrently (device 0's on the calling thread, the others on one persistent host thread per context,
+ * created at the first call and joined by agp_destroy), all-gathers the log-weights over RCCL in one group call
  * and returns the complete vector (every device also keeps it).  out_logpdf / out_info: P entries, caller order. */
 int agp_logpdf_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P,
                            const int32_t* op_off, const uint8_t* ops,
@@ -269,8 +282,9 @@ int agp_debug_math(agp_ctx* ctx, int32_t which, const double* x, const double* g
 int agp_debug_mfma_peak(agp_ctx* ctx, int32_t iters, int32_t wg_per_cu, double* out_tflops, double* out_ghz);
 
 /* Ablation harness for the update GEMM (off-diagonal tiles of block column k on pseudo-random data):
- * average milliseconds per launch for `variant` (see csrc/agp_experiments.hpp).  Compiled only into measurement
- * builds (-DAGP_EXPERIMENTS, `python __graft_entry__.py --experiments`); the product library returns AGP_ERR_ARG. */
+ * average milliseconds per launch for `variant` (see csrc/experiments/agp_experiments.hpp).  Compiled only into the
+ * measurement library (libautogp_hip_exp.so: -DAGP_EXPERIMENTS, `python __graft_entry__.py --experiments`); the product library
+ * returns AGP_ERR_ARG. */
 int agp_debug_gemm_variant(agp_ctx* ctx, int32_t P, int32_t nt, int32_t k, int32_t variant, int32_t reps, double* out_ms);
 
 /* Test hook: the un-padding of unequal shards after the padded all-gather (`padded`: n_ranks blocks of ceil(P/n_ranks)). */
@@ -284,7 +298,8 @@ int agp_debug_flow_trace(agp_ctx* ctx, int32_t enable, int64_t max_items, int64_
 
 /* When enabled, batch calls bracket their phases with HIP events on the launch stream.
  * agp_get_timing fills out[0..7] = { total_ms, cov_build_ms, chol_update_ms, chol_trsm_ms,
- * finish_ms, n_update_launches, n_trsm_launches, h2d_d2h_ms } for the last batch call. */
+ * finish_ms, n_update_launches, n_trsm_launches, h2d_d2h_ms } for the last batch call; a value+gradient sweep also
+ * fills out[8..11] = { L^-T chain ms, K^-1 tiles ms, contraction ms, alpha + reductions ms } (n_out up to 16). */
 int agp_set_profiling(agp_ctx* ctx, int enabled);
 int agp_get_timing(agp_ctx* ctx, double* out, int32_t n_out);
 /* per-launch durations (ms) of the last profiled batch call: which = 0 update kernel, 1 trsm kernel;

@@ -70,6 +70,23 @@ def gp_logpdf_program(ops, prm, noise, ts, xs):
     return -0.5 * (n * math.log(2.0 * math.pi) + logdet + float(a @ a)), 0
 
 
+def gp_pivot_ratio(ops, prm, noise, ts):
+    """(info, min_i L_ii^2 / max_i K_ii) of one particle's covariance matrix: how close LAPACK's factorisation came to a
+    non-positive pivot.  The tests use it to judge a particle the GPU rejects although dpotrf accepts it: only a numerically
+    borderline matrix (ratio < 1e-12) may differ."""
+    ops = np.ascontiguousarray(ops, dtype=np.uint8)
+    prm = np.ascontiguousarray(prm if len(prm) else [0.0], dtype=np.float64)
+    ts = np.ascontiguousarray(ts, dtype=np.float64)
+    n = ts.shape[0]
+    K = np.empty((n, n), dtype=np.float64, order="F")
+    _lib().agp_oracle_cov_lower(ops.ctypes.data, int(ops.shape[0]), prm.ctypes.data, float(noise), ts.ctypes.data, n, K.ctypes.data)
+    dmax = float(np.max(np.diagonal(K)))
+    L, info = lapack.dpotrf(K, lower=1, clean=0, overwrite_a=1)
+    if info != 0:
+        return int(info), 0.0
+    return 0, float(np.min(np.diagonal(L)) ** 2 / dmax)
+
+
 # ---- many particles: one worker PROCESS per host core (SciPy's f2py LAPACK wrappers hold the GIL, and page faults of
 # many threads in one address space serialise on the mm lock), each with single-threaded BLAS and one reused n x n
 # buffer.  Workers are plain `python -c` subprocesses fed over pipes (no multiprocessing: nothing re-imports the

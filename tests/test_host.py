@@ -4,6 +4,7 @@ calls without a GPU)."""
 import ctypes
 import math
 import re
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -64,6 +65,41 @@ def test_header_symbols_exported(pkg):
         assert getattr(lib, sym) is not None
     lib.agp_version.restype = ctypes.c_char_p
     assert b"gfx950" in lib.agp_version()
+
+
+def test_julia_ccall_signatures(tmp_path):
+    """The Julia shim has never been executed (no Julia here or on the GPU box): every ccall's type tuple, argument count
+    and return type is checked statically against the prototypes of include/autogp_hip.h (tools/check_ccall_signatures.py)
+    — and the checker itself is checked on deliberately broken copies of the shim."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import check_ccall_signatures as CK
+    problems, n_calls, seen, protos = CK.check()
+    assert n_calls >= 20 and len(protos) >= 40
+    assert problems == [], "\n".join(problems)
+    # every entry of the reference's path has a binding
+    for sym in ("agp_init", "agp_set_data", "agp_logpdf", "agp_logpdf_grad", "agp_logpdf_batch", "agp_logpdf_batch_extend",
+                "agp_predict_batch", "agp_infer_gp_sum", "agp_init_multi", "agp_logpdf_batch_multi", "agp_allgather_logweights",
+                "agp_comm_init_rank", "agp_comm_get_unique_id", "agp_shard_range", "agp_destroy", "agp_last_error"):
+        assert sym in seen, sym
+    shim = (ROOT / "autogp.jl_amd" / "julia" / "src" / "AutoGPHIP.jl").read_text()
+    breakages = [
+        ("(Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64), eng.ptr, ts, xs, length(ts))", "(Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32), eng.ptr, ts, xs, length(ts))"),   # width
+        ("(Ptr{Cvoid}, Ptr{Float64}, Int32), eng.ptr, lw, length(lw))", "(Ptr{Cvoid}, Float64, Int32), eng.ptr, lw, length(lw))"),                                          # pointer-ness
+        ("(Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32), eng.ptr, id, n_ranks, rank)", "(Ptr{Cvoid}, Ptr{UInt8}, Int32), eng.ptr, id, n_ranks)"),                                  # arity
+        ("(Ref{Ptr{Cvoid}}, Cint), ref, device)", "(Ref{Ptr{Cvoid}}, Cint), ref)"),                                                                                          # argument count
+        ("ccall((:agp_destroy, LIB), Cvoid,", "ccall((:agp_destroy, LIB), Cint,"),                                                                                          # return type
+    ]
+    for good, bad in breakages:
+        assert good in shim, good
+        f = tmp_path / "broken.jl"
+        f.write_text(shim.replace(good, bad))
+        orig_root = CK.ROOT
+        try:
+            CK.ROOT = tmp_path
+            pr, _, _, _ = CK.check(shims=[f])
+        finally:
+            CK.ROOT = orig_root
+        assert len(pr) >= 1, f"checker missed: {bad}"
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")

@@ -2,7 +2,10 @@ import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+import os
 import __graft_entry__ as g
+g.build(experiments=True)                                  # measurement build: its own library file
+os.environ["AUTOGP_HIP_LIB"] = str(g.LIB_EXP)
 pkg = g.load_package()
 eng = pkg.GPEngine(0)
 P, nt = 512, 16

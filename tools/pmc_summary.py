@@ -25,6 +25,7 @@ for name in ("sq", "lds", "fetch", "write"):
     out.append(f"## pass '{name}': mean per dispatch\n{agg.to_string(float_format=lambda v: f'{v:,.1f}')}\n")
 
 res = {}
+step_bytes = {}
 if "sq" in tabs:
     t = tabs["sq"]; t = t[t.kernel.str.contains("agp::")]
     g = t.groupby("kernel").sum(numeric_only=True)
@@ -47,6 +48,10 @@ for name, col in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
                    "\n".join(f"{k:40s} {v:14.1f} KB  -> {v * 1024 * fac / 1e6:10.1f} MB" for k, v in m.items()) + "\n")
         for k, v in m.items():
             res.setdefault(k, {})[name] = v * 1024 * fac
+        # whole-sweep traffic: every agp:: dispatch of the pass, per step (one k_finish_logpdf dispatch per step)
+        n_steps = int(t.kernel.str.contains("k_finish_logpdf").sum())
+        if n_steps > 0:
+            step_bytes[name] = float(t[col].sum()) * 1024 * fac / n_steps
 txt = "\n".join(out)
 (ROOT / f"profiles/{tag}_pmc_summary.txt").write_text(txt)
 print(txt)
@@ -58,7 +63,8 @@ if upd and "fetch" in res[upd[0]] and "write" in res[upd[0]]:
     import datetime
     (ROOT / "profiles/hbm_traffic.json").write_text(json.dumps({
         "tag": tag, "date": datetime.date.today().isoformat(),
-        "k_chol_update_bytes_per_launch": tot, "kernel": upd[0], "fetch_bytes_corrected_x2": res[upd[0]]["fetch"], "write_bytes": res[upd[0]]["write"],
+        "k_chol_update_bytes_per_launch": tot, "bytes_per_step": (step_bytes["fetch"] + step_bytes["write"]) if len(step_bytes) == 2 else None,
+        "kernel": upd[0], "fetch_bytes_corrected_x2": res[upd[0]]["fetch"], "write_bytes": res[upd[0]]["write"],
         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1`, {tag}; "
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM"}))
     print("hbm bytes/launch", tot / 1e6, "MB")

@@ -7,7 +7,7 @@ cd $R; mkdir -p gpurun_out
 (time python -m pytest tests -m gpu -q) > gpurun_out/${TAG}_pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/${TAG}_bench_n1.json; cut -c1-300 gpurun_out/${TAG}_bench_n1.json
-python bench.py --particles 64 --no-cpu-baseline 2>>gpurun_out/bench.err | tail -1 > gpurun_out/${TAG}_bench_n1_P64_rank_share.json
+python bench.py --particles 64 --no-cpu-baseline --no-extra-legs 2>>gpurun_out/bench.err | tail -1 > gpurun_out/${TAG}_bench_n1_P64_rank_share.json
 python tools/run_configs.py ${TAG} 2>&1 | grep -v amdgpu | tail -8
 FLOW_MODES=cols,flow_fused_pm python tools/gpu_flow_perf.py 2048x8 2048x16 2048x32 2048x64 2048x128 2048x256 2048x384 2048x512 1024x64 1024x128 512x256 4096x32 4096x128 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_flow_perf.txt; tail -3 gpurun_out/${TAG}_flow_perf.txt
 python tools/gpu_extend_perf.py ${TAG} 2>&1 | grep -v amdgpu | tail -4
@@ -16,15 +16,15 @@ python tools/gpu_grad_perf.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_per
 python tools/gpu_scratch_via_store.py 2>&1 | grep "^n=" > gpurun_out/${TAG}_store_scratch.txt; cat gpurun_out/${TAG}_store_scratch.txt
 (for T in 64 512; do tools/native/hmc_replay 2048 $T 2; AGP_FACTOR_CACHE=0 tools/native/hmc_replay 2048 $T 2; done; tools/native/hmc_replay 512 256 4; tools/native/threads_bench 2048 512 8; tools/native/threads_bench 2048 64 8; tools/native/threads_bench 2048 512 4 grad) 2>&1 | grep "^{" > gpurun_out/${TAG}_native.jsonl; cut -c1-220 gpurun_out/${TAG}_native.jsonl
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $R/gpurun_out/prof.log 2>&1
 cd $R
-python tools/rocprof_summary.py $(find gpurun_out/prof -name "*.db" | head -1) gpurun_out/${TAG}_bench_kernel_stats.txt --cmd "python bench.py --steps 5 --warmup 2 --no-cpu-baseline" | head -12
+python tools/rocprof_summary.py $(find gpurun_out/prof -name "*.db" | head -1) gpurun_out/${TAG}_bench_kernel_stats.txt --cmd "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs" | head -12
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof64 -o bench -- python $R/bench.py --particles 64 --steps 20 --warmup 2 --no-cpu-baseline > $R/gpurun_out/prof64.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof64 -o bench -- python $R/bench.py --particles 64 --steps 20 --warmup 2 --no-cpu-baseline --no-extra-legs > $R/gpurun_out/prof64.log 2>&1
 cd $R
-python tools/rocprof_summary.py $(find gpurun_out/prof64 -name "*.db" | head -1) gpurun_out/${TAG}_bench_P64_kernel_stats.txt --particles 64 --cmd "python bench.py --particles 64 --steps 20 --warmup 2 --no-cpu-baseline" | head -8
+python tools/rocprof_summary.py $(find gpurun_out/prof64 -name "*.db" | head -1) gpurun_out/${TAG}_bench_P64_kernel_stats.txt --particles 64 --cmd "python bench.py --particles 64 --steps 20 --warmup 2 --no-cpu-baseline --no-extra-legs" | head -8
 bash tools/run_pmc.sh 2>&1 | tail -5
 # the 64-particle share (dataflow kernel): MFMA busy, HBM bytes
-(bash tools/run_pmc_cmd.sh sq64 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline; bash tools/run_pmc_cmd.sh fetch64 "FETCH_SIZE" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline; bash tools/run_pmc_cmd.sh write64 "WRITE_SIZE" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline) 2>&1 | grep -v "at::native\|rocclr" > gpurun_out/${TAG}_pmc_P64.txt; cd $R; head -12 gpurun_out/${TAG}_pmc_P64.txt | cut -c1-250
+(bash tools/run_pmc_cmd.sh sq64 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs; bash tools/run_pmc_cmd.sh fetch64 "FETCH_SIZE" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs; bash tools/run_pmc_cmd.sh write64 "WRITE_SIZE" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs) 2>&1 | grep -v "at::native\|rocclr" > gpurun_out/${TAG}_pmc_P64.txt; cd $R; head -12 gpurun_out/${TAG}_pmc_P64.txt | cut -c1-250
 python tools/pmc_summary.py ${TAG} > /dev/null 2>&1; cp profiles/${TAG}_pmc_summary.txt gpurun_out/ 2>/dev/null; cp profiles/hbm_traffic.json gpurun_out/${TAG}_hbm_traffic.json 2>/dev/null
 ls gpurun_out | grep ${TAG}

@@ -17,7 +17,7 @@ P = 256; n_max = 2048
 ts, xs = pkg.prior.synthetic_series(n_max, seed=128, shuffle=True)
 nodes, noises = pkg.prior.sample_particles(np.random.default_rng(128), P, max_depth=-1, max_size=63)
 eng = pkg.GPEngine(lrank)
-gather = None
+gather = None; gather_obj = None
 if world > 1:
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -26,13 +26,18 @@ if world > 1:
     dist.broadcast_object_list(ids, src=0)
     eng.comm_init_rank(ids[0], world, rank)
     gather = eng.allgather_logweights
+
+    def gather_obj(obj):          # host channel for the rejuvenated blocks' programs (a few hundred bytes per particle)
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
 eng.set_data(ts, xs)
 future = np.linspace(1.0, 1.05, 100)
 res = []
 for rep in range(2):          # first pass warms the allocations up
     eng.extend_reset()
     st = pkg.stream.OnlineStream(nodes, noises, pkg.stream.EngineEvaluator(eng, extend=extend), rank=rank, world=world,
-                                 allgather=gather, seed=9)
+                                 allgather=gather, seed=9, allgather_objects=gather_obj)
     t_steps = []; t_pred = []
     rng = np.random.default_rng(77 + rank)
     ev = st.evaluate
