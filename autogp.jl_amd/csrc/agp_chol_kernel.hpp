@@ -72,6 +72,7 @@ struct CholArgs {
   long long* trace;     // optional (agp_debug_flow_trace): per item {start, end, wait} in 100 MHz ticks + {item info}
   int schur_diag_only;  // Schur mode: only the diagonal tiles of the prediction block (marginal variances + mean; no covariance)
   int flow_order;       // 0: sub-diagonal tiles of a block column tile-row-major (all particles' (k+1,k) first), 1: particle-major
+  int lag;              // 1: sorted regular grid, the fused programs' stationary leaves are OP_LAG_* (GM = 2 instantiations)
 };
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -332,10 +333,13 @@ __device__ __forceinline__ bool flow_wait(const int* flag) {
 // the SAME launch: before the K-loop touches block column j it waits for the flags of tiles (ti,j) and (tk,j), the
 // panel solve waits for the flag of tile (tk,tk), and the finished tile raises its own flag (a.tflag, one int per
 // tile and storage index, zeroed per sweep).
-template <bool FACTOR, int DCOV, bool INTRSM, int DM, bool TAB, bool FLOW>
+// GM: how the fused programs' stationary leaves are evaluated — 0 directly, 1 GammaExp from the data set's log|dt| table,
+// 2 every stationary leaf from the tile's lag tables (sorted regular grid; see cov_prologue)
+template <bool FACTOR, int DCOV, bool INTRSM, int DM, int GM, bool FLOW>
 __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const int ps, const int ti, const int tk,
                                           const int jmax, const bool is_diag, double* sm, const int tid,
                                           double* wait_acc = nullptr) {
+  constexpr bool TAB = GM == 1, LAGM = GM == 2;
   constexpr bool ADJ = ILV;       // strips are adjacent rows
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;
@@ -372,14 +376,15 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     double* sig = sm + 256;
     // Stage the program in LDS: this kernel also stores to global memory, so the compiler cannot
     // keep the opcode / parameter fetches on the scalar cache; from LDS they are broadcast reads.
-    double* prm = sig + h.n_cp * 256;
+    const double* lagt = sig + h.n_cp * 256;
+    double* prm = sig + (h.n_cp + (LAGM ? h.n_lag : 0)) * 256;
     int* ops = reinterpret_cast<int*>(prm + h.n_prm + 2);
     for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
     for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
     double* etab = sm + U_MAIN_DOUBLES;      // exp table in the (still unused) forward-solve scratch: rvec[128]
     if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
     __syncthreads();
-    cov_prologue(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid);
+    cov_prologue<LAGM>(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid);
     const double noise = a.noise[p];
     // GammaExp leaves read log|dt| from the data set's table (L2 / Infinity-Cache resident: every particle reads
     // the same 128 KiB tile); the loads are issued at the top of the pass and consumed by the first such leaf
@@ -410,7 +415,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
         tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
         ri[r] = rslot; ci[r] = NB + cslot;
       }
-      eval_program<(DCOV > 0 ? DCOV : 4), 4, (TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab);
+      eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt);
       d4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -683,9 +688,9 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
 
 // DM (factor mode with INTRSM): 0 = diagonal and sub-diagonal tiles in one launch (medium populations, fallback
 // paths); 2 = sub-diagonal tiles only (the diagonal tiles of that block column then come from k_chol_diag).
-template <bool FACTOR, int DCOV, bool INTRSM, int DM = 0, bool TAB = false>
+template <bool FACTOR, int DCOV, bool INTRSM, int DM = 0, int GM = 0>
 __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
-  static_assert(!TAB || DCOV > 0, "the log|dt| table only matters to instantiations that evaluate tiles");
+  static_assert(GM == 0 || DCOV > 0, "the log|dt| table / the lag tables only matter to instantiations that evaluate tiles");
   static_assert(DM == 0 || (FACTOR && INTRSM), "split launches exist for the in-kernel-solve factorisation only");
   static_assert(DM == 0 || DM == 2, "the diagonal-only launch is k_chol_diag");
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
@@ -746,15 +751,16 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
   const int ps = (FACTOR && a.slot != nullptr) ? a.slot[p] : p;    // storage index
   const bool is_diag = (DM == 2) ? false : (ti == tk);
 
-  chol_tile<FACTOR, DCOV, INTRSM, DM, TAB, false>(a, p, ps, ti, tk, jmax, is_diag, sm, threadIdx.x);
+  chol_tile<FACTOR, DCOV, INTRSM, DM, GM, false>(a, p, ps, ti, tk, jmax, is_diag, sm, threadIdx.x);
 }
 
 // Diagonal tile (tk, tk) of particle p (storage index ps): lower block triangle of the update, the 128x128
 // factorisation, forward-solve segment and partials — the body of k_chol_diag, also run by the dataflow schedule
 // (FLOW: waits for tile (tk, j) before the slabs of block column j are fetched; raises its own flag when done).
-template <int DCOV, bool TAB, bool FLOW>
+template <int DCOV, int GM, bool FLOW>
 __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, const int ps, const int tk, double* sm, const int tid,
                                                double* wait_acc = nullptr) {
+  constexpr bool TAB = GM == 1, LAGM = GM == 2;
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;
   double* xv = avec + 128;     // [2][32]
@@ -779,14 +785,15 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
     const ProgHdr h = a.hdr[p];
     double* tpt = sm;
     double* sig = sm + 256;
-    double* prm = sig + h.n_cp * 256;
+    const double* lagt = sig + h.n_cp * 256;
+    double* prm = sig + (h.n_cp + (LAGM ? h.n_lag : 0)) * 256;
     int* ops = reinterpret_cast<int*>(prm + h.n_prm + 2);
     for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
     for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
     double* etab = rvec;                     // exp table in the (still unused) forward-solve scratch
     if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
     __syncthreads();
-    cov_prologue(a.tt, a.code, tk, tk, h, ops, prm, tpt, sig, tid);
+    cov_prologue<LAGM>(a.tt, a.code, tk, tk, h, ops, prm, tpt, sig, tid);
     const double noise = a.noise[p];
     const bool use_tab = TAB && (h.flags & 1) != 0;
     const double* __restrict__ ltile = a.logdt + tile_off(tk, tk);      // only dereferenced when use_tab
@@ -815,7 +822,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
         tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
         ri[r] = rslot; ci[r] = NB + cslot;
       }
-      eval_program<(DCOV > 0 ? DCOV : 4), 4, (TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab);
+      eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt);
       d4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -959,9 +966,9 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
   factor_diag_tile<true>(a, ps, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid);
 }
 
-template <int DCOV, bool TAB>
+template <int DCOV, int GM>
 __global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
-  static_assert(!TAB || DCOV > 0, "the log|dt| table only matters to instantiations that evaluate tiles");
+  static_assert(GM == 0 || DCOV > 0, "the log|dt| table / the lag tables only matter to instantiations that evaluate tiles");
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
 
   const int b = blockIdx.x, xcd = b & 7, pl = b >> 3;
@@ -970,7 +977,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
   const int tk = a.k;
   if (a.i0 != nullptr && tk < a.i0[p]) return;              // extension sweep: column already factored
   const int ps = a.slot != nullptr ? a.slot[p] : p;         // storage index
-  chol_diag_tile<DCOV, TAB, false>(a, p, ps, tk, sm, threadIdx.x);
+  chol_diag_tile<DCOV, GM, false>(a, p, ps, tk, sm, threadIdx.x);
 }
 
 // Dataflow schedule: the WHOLE factorisation of a batch in one launch of persistent workgroups.  Work items are
@@ -981,9 +988,9 @@ __global__ __launch_bounds__(256, 2) void k_chol_diag(CholArgs a) {
 // serial 128x128 factorisations) is filled by the bulk of the next ones.  This is what medium populations
 // (one GPU's share of a sharded population) need: with fewer tiles per block column than the GPU has workgroup
 // slots, per-column launches leave most CUs idle around every column boundary.
-template <int DCOV, bool TAB>
+template <int DCOV, int GM>
 __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
-  static_assert(!TAB || DCOV > 0, "the log|dt| table only matters to instantiations that evaluate tiles");
+  static_assert(GM == 0 || DCOV > 0, "the log|dt| table / the lag tables only matter to instantiations that evaluate tiles");
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
   __shared__ int s_item;
   __shared__ double s_wait;
@@ -1041,8 +1048,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
     asm volatile("" : "+v"(tid));
     // diagonal tiles run the lower-triangle body of k_chol_diag, the others the sub-diagonal body (update + in-register
     // solve) of the split per-column launches
-    if (tl == 0) chol_diag_tile<DCOV, TAB, true>(a, p, ps, k, sm, tid, &s_wait);
-    else chol_tile<true, DCOV, true, 2, TAB, true>(a, p, ps, k + tl, k, k, false, sm, tid, &s_wait);
+    if (tl == 0) chol_diag_tile<DCOV, GM, true>(a, p, ps, k, sm, tid, &s_wait);
+    else chol_tile<true, DCOV, true, 2, GM, true>(a, p, ps, k + tl, k, k, false, sm, tid, &s_wait);
     if (a0.trace && threadIdx.x == 0) {
       // record of this item: [start, end, K-loop wait ticks, (xcd, particle, tile row, block column)]
       int gi = item;

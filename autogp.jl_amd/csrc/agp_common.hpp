@@ -26,8 +26,13 @@ constexpr int LDS_STRIDE = 144;  // 128 + 16 doubles: k-rows 32 banks apart -> c
 // an observable (code 0) or the latent of that component (code == id), else 0.
 // 11 is GammaExponential evaluated from the data set's log|t_i - t_j| table (agp_set_data builds it once; every
 // particle's GammaExp leaves share it): (|dt|/l)^gamma = exp(gamma (log|dt| - log l)), one exp instead of log + exp.
+// 12..14 are the stationary leaves (SE / GammaExp / Periodic, same parameters as 3..5) of a sweep over data whose time
+// points are a REGULAR GRID held in sorted order (agp_set_data detects it; see "lag tables" in agp_cov_kernel.hpp): inside a
+// tile the value then depends on (row - column) only, so the leaf is evaluated 255 times per tile into an LDS table and
+// looked up per element.
 enum : int { OP_WN = 0, OP_CONST = 1, OP_LIN = 2, OP_SE = 3, OP_GE = 4, OP_PER = 5,
-             OP_PLUS = 6, OP_TIMES = 7, OP_CP = 8, OP_CP_SWAP = 9, OP_SEL = 10, OP_GE_TAB = 11 };
+             OP_PLUS = 6, OP_TIMES = 7, OP_CP = 8, OP_CP_SWAP = 9, OP_SEL = 10, OP_GE_TAB = 11,
+             OP_LAG_SE = 12, OP_LAG_GE = 13, OP_LAG_PER = 14 };
 constexpr double LOGDT_ZERO = -1.0e8;    // table entry for dt = 0: exp(gamma (LOGDT_ZERO - log l)) == 0 exactly
 
 struct ProgHdr {
@@ -37,6 +42,8 @@ struct ProgHdr {
   int32_t n_cp;     // number of per-point LDS tables: ChangePoint nodes + selector leaves
   int32_t n_prm;    // device parameters of this program
   int32_t flags;    // bit 0: the program has OP_GE_TAB leaves (reads the log|dt| table)
+  int32_t n_lag;    // number of per-tile lag tables (OP_LAG_* leaves); they follow the n_cp per-point tables in LDS
+  int32_t pad_;
 };
 
 __host__ __device__ inline long long tile_off(int i, int j) {

@@ -47,12 +47,46 @@ struct CovArgs {
 
 __device__ __forceinline__ int prm_count(int o) {
   // WN, CONST, LIN, SE, GE, PER, PLUS, TIMES, CP, CP_SWAP
-  return (o == OP_WN || o == OP_CONST || o == OP_SEL) ? 1 : (o == OP_SE || o == OP_CP || o == OP_CP_SWAP) ? 2
-         : (o == OP_PLUS || o == OP_TIMES) ? 0 : 3;     // (LIN, GE, GE_TAB, PER: 3)
+  return (o == OP_WN || o == OP_CONST || o == OP_SEL) ? 1 : (o == OP_SE || o == OP_LAG_SE || o == OP_CP || o == OP_CP_SWAP) ? 2
+         : (o == OP_PLUS || o == OP_TIMES) ? 0 : 3;     // (LIN, GE, GE_TAB, PER, LAG_GE, LAG_PER: 3)
 }
 
-// LDS scratch of the evaluator: tpt[256] (row times 0..127, column times 128..255) then sig[n_cp][256].
+// LDS scratch of the evaluator: tpt[256] (row times 0..127, column times 128..255), sig[n_cp][256], then lag[n_lag][256].
+//
+// Lag tables (LAG = true instantiations; programs compiled for a sweep over SORTED, REGULARLY SPACED time points — the host
+// only emits OP_LAG_* leaves then): with t_g = t_0 + g h the difference t_(I0+a) - t_(J0+b) of a tile's element (a, b) is
+// (I0 - J0 + a - b) h: a function of a - b alone, 255 distinct values per tile.  Thread d + 127 evaluates every stationary
+// leaf ONCE at the tile's lag d — on the actual stored time points of the representative element (a, b) = (d, 0) for d >= 0,
+// (0, -d) for d < 0, with exactly the arithmetic of the general path (src/GP.jl:241-245, 285-289, 331-336) — and the 16 384
+// elements read the leaf from the table: one LDS access instead of 40-90 fp64 instructions.  The other elements of a
+// diagonal differ from the representative only by the rounding of their own t_i - t_j (a few ulp of t: agp_set_data admits
+// a grid only when every point sits within 16 ulp of t_0 + g h).  A padding row / column is never a representative of a
+// lag that a valid element uses (lag d >= 0 is represented by row d <= the valid element's row, d < 0 by a column of the
+// valid element's tile column or an earlier one).
+// (its own function, not inlined: the power / sin^2 / exp code would otherwise be allocated inside the factorisation
+// kernels' register budget — the dataflow kernel went from 21 to 74 spilled registers with it inlined)
 template <typename OpT>
+__device__ __attribute__((noinline)) void lag_tables(int n_ops, const OpT* __restrict__ ops, const double* __restrict__ prm,
+                                                     const double* tpt, double* lag, int tid) {
+  const int d = tid - (NB - 1);
+  const double dx = (tid >= 2 * NB - 1) ? 0.0 : (d >= 0 ? tpt[d] - tpt[NB] : tpt[0] - tpt[NB - d]);
+  int q = 0, li = 0;
+  for (int ip = 0; ip < n_ops; ++ip) {
+    const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
+    if (o >= OP_LAG_SE) {
+      const double p0 = prm[q], p1 = prm[q + 1], p2 = prm[q + 2];
+      double arg, amp;
+      if (o == OP_LAG_SE) { arg = ((-0.5 * dx) * dx) * p0; amp = p1; }                       // p0 = 1/l^2
+      else if (o == OP_LAG_GE) { arg = -fm::pow_f(fabs(dx) * p0, p1); amp = p2; }            // p0 = 1/l, p1 = gamma
+      else { arg = p0 * fm::sin2_f(p1 * fabs(dx)); amp = p2; }                              // p0 = -2/l^2, p1 = pi/p
+      lag[li * 256 + tid] = amp * fm::exp_f(arg);
+      ++li;
+    }
+    q += prm_count(o);
+  }
+}
+
+template <bool LAG = false, typename OpT>
 __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, const uint8_t* __restrict__ code,
                                              int ti, int tj, const ProgHdr& h,
                                              const OpT* __restrict__ ops, const double* __restrict__ prm,
@@ -79,19 +113,25 @@ __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, cons
     }
     __syncthreads();
   }
+  if (LAG && h.n_lag > 0) {
+    lag_tables(h.n_ops, ops, prm, tpt, sig + h.n_cp * 256, tid);
+    __syncthreads();
+  }
 }
 
 // Evaluate the program at E (row, column) pairs.  tr/tc: time values; ri/ci: indices into the sigma
 // tables (row slot 0..127, column slot 128..255).  All arrays are statically indexed registers.
-// GEMODE: 0 = GammaExp leaves of both kinds (OP_GE computes the power, OP_GE_TAB reads the log|dt| table),
-// 1 = OP_GE only, 2 = OP_GE_TAB only (the instantiations inside the factorisation kernel carry one kind, which
-// keeps the unused power / table code out of their register budget).
+// GEMODE: 0 = every leaf kind (OP_GE computes the power, OP_GE_TAB reads the log|dt| table, OP_LAG_* read the tile's lag
+// tables), 1 = OP_GE only, 2 = OP_GE_TAB only, 3 = lag tables only: no per-element transcendental code at all (the
+// instantiations inside the factorisation kernel carry one kind, which keeps the unused code out of their register budget).
+// lag: the tile's lag tables (after the per-point tables), element (row slot ri, column slot ci - 128) reads entry
+// ri - (ci - 128) + 127.
 template <int D, int E, int GEMODE = 0, typename OpT>
 __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __restrict__ ops,
                                              const double* __restrict__ prm, const double* sig,
                                              const double (&tr)[E], const double (&tc)[E],
                                              const int (&ri)[E], const int (&ci)[E], const double (&lt)[E],
-                                             double (&out)[E], const double* etab = nullptr) {
+                                             double (&out)[E], const double* etab = nullptr, const double* lag = nullptr) {
   // lt: log|t_row - t_col| of the E elements from the data set's table (only read by OP_GE_TAB leaves)
   // etab: LDS copy of fm::c_exp_tab (fm::exp_t, 11 fp64 operations instead of exp_f's 21)
   auto ex = [&](double x) { return (AGP_EXP_TABLE != 0) ? fm::exp_t(x, etab) : fm::exp_f(x); };
@@ -101,11 +141,12 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
 #pragma unroll
     for (int e = 0; e < E; ++e) st[d][e] = 0.0;
 
-  int q = 0, cpi = 0;
+  int q = 0, cpi = 0, li = 0;
+  (void)li;
   for (int ip = 0; ip < h.n_ops; ++ip) {
     // the opcode is wave-uniform: keep it (and the dispatch on it) on the scalar unit
     const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
-    if (o <= OP_PER || o == OP_SEL || o == OP_GE_TAB) {
+    if (o <= OP_PER || o >= OP_SEL) {
       // ---------------- leaf: push ----------------
       // every leaf's (up to three) parameters are fetched unconditionally — the parameter buffers
       // carry two doubles of tail padding — and picked by opcode afterwards
@@ -126,7 +167,13 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
         // bias + amp * (ti - c)(tj - c)
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = p1 + p2 * ((tr[e] - p0) * (tc[e] - p0));
-      } else {
+      } else if ((GEMODE == 0 || GEMODE == 3) && (GEMODE == 3 || o >= OP_LAG_SE)) {
+        // stationary leaf of a sorted regular grid: the tile's lag table
+        const double* lg = lag + li * 256 + (2 * NB - 1);
+#pragma unroll
+        for (int e = 0; e < E; ++e) v[e] = lg[ri[e] - ci[e]];
+        ++li;
+      } else if (GEMODE != 3) {
         // stationary leaves: amp * exp(arg)
         double arg[E];
         const double amp = (o == OP_SE) ? p1 : p2;
@@ -229,9 +276,10 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
   const ProgHdr h = a.hdr[p];
   const uint8_t* __restrict__ ops = a.ops + h.op_off;
   const double* __restrict__ prm = a.prm + h.prm_off;
-  double* etab = sig + h.n_cp * 256;      // [128] exp table (launch_cov sizes the dynamic LDS for it)
+  double* etab = sig + (h.n_cp + h.n_lag) * 256;      // [128] exp table (launch_cov sizes the dynamic LDS for it)
   if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
-  cov_prologue(a.tt, a.code, ti, tj, h, ops, prm, tpt, sig, tid);
+  cov_prologue<true>(a.tt, a.code, ti, tj, h, ops, prm, tpt, sig, tid);
+  const double* lag = sig + h.n_cp * 256;
 
   const int rp = tid & 63;        // row pair: rows 2rp, 2rp+1
   const int cq = tid >> 6;        // column group: 32 columns
@@ -267,7 +315,7 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
       ri[e] = r0 + (e & 1);
       ci[e] = NB + c0 + (e >> 1);
     }
-    eval_program<D, E, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab);
+    eval_program<D, E, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lag);
 #pragma unroll
     for (int cc = 0; cc < CPP; ++cc) {
       const int gj = tj * NB + c0 + cc;

@@ -146,6 +146,14 @@ struct agp_ctx {
   int trtri_chain = 1;  // Z = L^-T as independent per-row chains in one launch (0: one launch per block column); env AGP_TRTRI_CHAIN
   int split_diag = -1;  // diagonal tiles in their own specialised launch: -1 auto (when they fill the GPU), 0, 1; env AGP_SPLIT_DIAG
   int ge_table = 1;     // GammaExp leaves read log|dt| from a table built by agp_set_data (env AGP_GE_TABLE)
+  // Sorted regular grid (agp_set_data): when the resident time points, put in ascending order, are equally spaced, value
+  // sweeps over the WHOLE series run on the sorted copy (the log-pdf is invariant under a symmetric permutation of K and
+  // x) and evaluate stationary leaves from per-tile lag tables (OP_LAG_*, agp_cov_kernel.hpp).  env AGP_LAG=0 disables.
+  double* d_ts_s = nullptr;
+  double* d_xs_s = nullptr;
+  bool lag_ok = false;
+  int lag_enable = 1;
+  int64_t n_lag_sweeps = 0;       // sweeps that took the lag path (agp_get_lag_stats)
   double* d_logdt = nullptr;      // packed lower tiles, covers the resident data
   size_t logdt_cap = 0;
   bool logdt_ok = false;
@@ -310,6 +318,7 @@ struct Compiled {
   int root = -1;
   int n_prm_caller = 0;
   bool uses_tab = false;      // has OP_GE_TAB leaves
+  int n_lag = 0;              // OP_LAG_* leaves (one per-tile lag table each)
 };
 
 // k_cov_tiles / the gradient contraction keep one 256-entry table per ChangePoint node / selector leaf in LDS next to
@@ -326,7 +335,8 @@ int leaf_nprm(int op) {
   }
 }
 
-void emit(const std::vector<CNode>& nodes, int id, Compiled& out, bool ge_tab) {
+// lag: the sweep runs on a sorted regular grid — stationary leaves become OP_LAG_* (same parameters as the direct forms)
+void emit(const std::vector<CNode>& nodes, int id, Compiled& out, bool ge_tab, bool lag = false) {
   const CNode& nd = nodes[id];
   if (nd.left < 0) {
     out.ops.push_back((uint8_t)nd.op);
@@ -334,9 +344,15 @@ void emit(const std::vector<CNode>& nodes, int id, Compiled& out, bool ge_tab) {
       case OP_WN: case OP_CONST: out.prm.push_back(nd.prm[0]); break;
       case OP_SEL: out.prm.push_back(nd.prm[0]); out.n_cp++; break;     // uses one per-point LDS table
       case OP_LIN: out.prm.insert(out.prm.end(), {nd.prm[0], nd.prm[1], nd.prm[2]}); break;
-      case OP_SE: out.prm.insert(out.prm.end(), {1.0 / (nd.prm[0] * nd.prm[0]), nd.prm[1]}); break;
+      case OP_SE:
+        out.prm.insert(out.prm.end(), {1.0 / (nd.prm[0] * nd.prm[0]), nd.prm[1]});
+        if (lag) { out.ops.back() = (uint8_t)OP_LAG_SE; out.n_lag++; }
+        break;
       case OP_GE:
-        if (ge_tab) {       // (|dt|/l)^gamma from the data set's log|dt| table (l <= 0 gives NaN, as a negative base would)
+        if (lag) {
+          out.ops.back() = (uint8_t)OP_LAG_GE; out.n_lag++;
+          out.prm.insert(out.prm.end(), {1.0 / nd.prm[0], nd.prm[1], nd.prm[2]});
+        } else if (ge_tab) {       // (|dt|/l)^gamma from the data set's log|dt| table (l <= 0 gives NaN, as a negative base would)
           out.ops.back() = (uint8_t)OP_GE_TAB;
           out.uses_tab = true;
           out.prm.insert(out.prm.end(), {std::log(nd.prm[0]), nd.prm[1], nd.prm[2]});
@@ -346,13 +362,14 @@ void emit(const std::vector<CNode>& nodes, int id, Compiled& out, bool ge_tab) {
         break;
       case OP_PER:
         out.prm.insert(out.prm.end(), {-2.0 / (nd.prm[0] * nd.prm[0]), M_PI / nd.prm[1], nd.prm[2]});
+        if (lag) { out.ops.back() = (uint8_t)OP_LAG_PER; out.n_lag++; }
         break;
     }
     return;
   }
   const bool swap = nodes[nd.right].need > nodes[nd.left].need;
-  emit(nodes, swap ? nd.right : nd.left, out, ge_tab);
-  emit(nodes, swap ? nd.left : nd.right, out, ge_tab);
+  emit(nodes, swap ? nd.right : nd.left, out, ge_tab, lag);
+  emit(nodes, swap ? nd.left : nd.right, out, ge_tab, lag);
   if (nd.op == OP_CP) {
     out.ops.push_back((uint8_t)(swap ? OP_CP_SWAP : OP_CP));
     out.prm.push_back(nd.prm[0]);
@@ -365,7 +382,7 @@ void emit(const std::vector<CNode>& nodes, int id, Compiled& out, bool ge_tab) {
 
 // returns 0 or an error string
 const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, int n_prm, Compiled& out,
-                            bool allow_sel = false, bool ge_tab = false) {
+                            bool allow_sel = false, bool ge_tab = false, bool lag = false) {
   if (n_ops <= 0 || n_ops > AGP_MAX_OPS) return "program length out of range";
   std::vector<CNode> nodes;
   nodes.reserve(n_ops);
@@ -401,7 +418,13 @@ const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, in
   if (ip != n_prm) return "parameter count mismatch";
   out.depth_need = nodes[stack[0]].need;
   if (out.depth_need > 8) return "kernel tree needs an evaluation stack deeper than 8";
-  emit(nodes, stack[0], out, ge_tab);
+  emit(nodes, stack[0], out, ge_tab, lag);
+  if (lag && out.n_cp + out.n_lag > COV_MAX_TABLES) {      // (a 63-node tree has at most 32 leaves + 31 ChangePoints: does not happen below 75 nodes)
+    Compiled plain;
+    emit(nodes, stack[0], plain, false, false);
+    plain.depth_need = out.depth_need;
+    out = plain;
+  }
   if (out.n_cp > COV_MAX_TABLES) return "kernel tree needs more per-point LDS tables (ChangePoint nodes + component selectors) than fit 160 KiB";
   out.root = stack[0];
   out.n_prm_caller = n_prm;
@@ -435,6 +458,7 @@ double op_cost_us(int op) {
     case OP_SE: return 7.0;
     case OP_LIN: return 2.0;
     case OP_CP: case OP_CP_SWAP: return 2.0;
+    case OP_LAG_SE: case OP_LAG_GE: case OP_LAG_PER: return 1.0;      // one LDS read per element (+ 255 leaf evaluations per tile)
     default: return 0.6;
   }
 }
@@ -461,12 +485,12 @@ int emit_grad(const std::vector<CNode>& nodes, int id, Batch& bt, int prm_base, 
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                   const double* prm, Batch& bt, bool allow_sel = false, bool want_grad = false, bool ge_tab = false,
-                  bool fuse_hint = false, bool flow_limit = false) {
+                  bool fuse_hint = false, bool flow_limit = false, bool lag = false) {
   std::vector<Compiled> cps(P);
   std::vector<double> cost(P, 0.0);
   for (int p = 0; p < P; ++p) {
     const char* e = compile_program(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p],
-                                    prm_off[p + 1] - prm_off[p], cps[p], allow_sel, ge_tab);
+                                    prm_off[p + 1] - prm_off[p], cps[p], allow_sel, ge_tab && !lag, lag);
     if (e) {
       char buf[256];
       snprintf(buf, sizeof buf, "particle %d: %s", p, e);
@@ -481,7 +505,14 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   // (the dataflow schedule has no launch tail for a long evaluation to hold up: its limit is higher — measured 35 / 70 /
   // 150 / 1000 us: config 2 0.99 / 0.92 / 0.92 / 0.91 ms, 2048 x 64 4.47 / 4.45 / 4.61 / 4.62 ms, config 4 62.9 / 61.9 / 63.6 / 63.6 ms)
   const double fuse_limit = flow_limit ? std::max(c->fuse_max_us, c->flow_fuse_max_us) : c->fuse_max_us;
-  auto fusable = [&](int p) { return fuse_on && cost[p] <= fuse_limit && cps[p].n_cp <= U_MAX_CP; };
+  // (a lag sweep fuses every program whose tables fit the aliased LDS of the factorisation kernels: its evaluation costs next
+  // to nothing; one that carries direct stationary leaves there — see compile_program — must be prebuilt: the GM = 2
+  // instantiations have no transcendental code)
+  auto lag_ok = [&](int p) { bool direct = false; for (uint8_t o : cps[p].ops) direct |= (o == OP_SE || o == OP_GE || o == OP_PER || o == OP_GE_TAB); return !direct; };
+  auto fusable = [&](int p) {
+    if (lag) return fuse_on && lag_ok(p) && cps[p].n_cp + cps[p].n_lag <= U_MAX_CP;
+    return fuse_on && cost[p] <= fuse_limit && cps[p].n_cp <= U_MAX_CP;
+  };
   bt.order.resize(P);
   for (int p = 0; p < P; ++p) bt.order[p] = p;
   std::stable_sort(bt.order.begin(), bt.order.end(), [&](int a, int b) {
@@ -499,14 +530,15 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
     h.n_cp = cp.n_cp;
     h.n_prm = (int32_t)cp.prm.size();
     h.flags = cp.uses_tab ? 1 : 0;
+    h.n_lag = cp.n_lag; h.pad_ = 0;
     bt.hdr[q] = h;
     bt.ops.insert(bt.ops.end(), cp.ops.begin(), cp.ops.end());
     bt.prm.insert(bt.prm.end(), cp.prm.begin(), cp.prm.end());
-    bt.max_cp = std::max(bt.max_cp, cp.n_cp);
+    bt.max_cp = std::max(bt.max_cp, cp.n_cp + cp.n_lag);        // LDS tables of any kind (per-point + lag)
     bt.max_depth = std::max(bt.max_depth, cp.depth_need);
     if (fusable(bt.order[q])) {
       bt.n_fused = q + 1;
-      bt.max_cp_fused = std::max(bt.max_cp_fused, cp.n_cp);
+      bt.max_cp_fused = std::max(bt.max_cp_fused, cp.n_cp + cp.n_lag);
       bt.max_depth_fused = std::max(bt.max_depth_fused, cp.depth_need);
     }
   }
@@ -564,29 +596,37 @@ hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int 
 // compiled with OP_GE_TAB leaves only); it exists for the in-kernel-solve factorisation launches.
 template <bool FACTOR, bool INTRSM, int DM = 0>
 void launch_update(int dcov, int grid, hipStream_t st, const CholArgs& ca) {
-  constexpr bool CAN_TAB = FACTOR && INTRSM;
-  const bool tab = CAN_TAB && ca.logdt != nullptr && dcov > 0;
-  if (dcov == 0) hipLaunchKernelGGL((k_chol_update<FACTOR, 0, INTRSM, DM>), dim3(grid), dim3(256), 0, st, ca);
+  // GM (see chol_tile): 1 / 2 exist for the in-kernel-solve factorisation launches only
+  constexpr bool CAN_GM = FACTOR && INTRSM;
+  const int gm = (CAN_GM && dcov > 0) ? (ca.lag ? 2 : (ca.logdt != nullptr ? 1 : 0)) : 0;
+  const dim3 g(grid), b(256);
+  if (dcov == 0) hipLaunchKernelGGL((k_chol_update<FACTOR, 0, INTRSM, DM>), g, b, 0, st, ca);
   else if (dcov <= 4) {
-    if (tab) hipLaunchKernelGGL((k_chol_update<FACTOR, 4, INTRSM, DM, CAN_TAB>), dim3(grid), dim3(256), 0, st, ca);
-    else hipLaunchKernelGGL((k_chol_update<FACTOR, 4, INTRSM, DM>), dim3(grid), dim3(256), 0, st, ca);
+    if (gm == 2) hipLaunchKernelGGL((k_chol_update<FACTOR, 4, INTRSM, DM, CAN_GM ? 2 : 0>), g, b, 0, st, ca);
+    else if (gm == 1) hipLaunchKernelGGL((k_chol_update<FACTOR, 4, INTRSM, DM, CAN_GM ? 1 : 0>), g, b, 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_update<FACTOR, 4, INTRSM, DM>), g, b, 0, st, ca);
   } else {
-    if (tab) hipLaunchKernelGGL((k_chol_update<FACTOR, 8, INTRSM, DM, CAN_TAB>), dim3(grid), dim3(256), 0, st, ca);
-    else hipLaunchKernelGGL((k_chol_update<FACTOR, 8, INTRSM, DM>), dim3(grid), dim3(256), 0, st, ca);
+    if (gm == 2) hipLaunchKernelGGL((k_chol_update<FACTOR, 8, INTRSM, DM, CAN_GM ? 2 : 0>), g, b, 0, st, ca);
+    else if (gm == 1) hipLaunchKernelGGL((k_chol_update<FACTOR, 8, INTRSM, DM, CAN_GM ? 1 : 0>), g, b, 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_update<FACTOR, 8, INTRSM, DM>), g, b, 0, st, ca);
   }
 }
 
+inline int chol_gm(int dcov, const CholArgs& ca) { return dcov > 0 ? (ca.lag ? 2 : (ca.logdt != nullptr ? 1 : 0)) : 0; }
+
 // diagonal tiles of block column ca.k (k_chol_diag), one workgroup per particle
 inline void launch_diag(int dcov, int Pg8, hipStream_t st, const CholArgs& ca) {
-  const bool tab = ca.logdt != nullptr && dcov > 0;
+  const int gm = chol_gm(dcov, ca);
   const dim3 grid(Pg8), block(256);
-  if (dcov == 0) hipLaunchKernelGGL((k_chol_diag<0, false>), grid, block, 0, st, ca);
+  if (dcov == 0) hipLaunchKernelGGL((k_chol_diag<0, 0>), grid, block, 0, st, ca);
   else if (dcov <= 4) {
-    if (tab) hipLaunchKernelGGL((k_chol_diag<4, true>), grid, block, 0, st, ca);
-    else hipLaunchKernelGGL((k_chol_diag<4, false>), grid, block, 0, st, ca);
+    if (gm == 2) hipLaunchKernelGGL((k_chol_diag<4, 2>), grid, block, 0, st, ca);
+    else if (gm == 1) hipLaunchKernelGGL((k_chol_diag<4, 1>), grid, block, 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_diag<4, 0>), grid, block, 0, st, ca);
   } else {
-    if (tab) hipLaunchKernelGGL((k_chol_diag<8, true>), grid, block, 0, st, ca);
-    else hipLaunchKernelGGL((k_chol_diag<8, false>), grid, block, 0, st, ca);
+    if (gm == 2) hipLaunchKernelGGL((k_chol_diag<8, 2>), grid, block, 0, st, ca);
+    else if (gm == 1) hipLaunchKernelGGL((k_chol_diag<8, 1>), grid, block, 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_diag<8, 0>), grid, block, 0, st, ca);
   }
 }
 
@@ -734,15 +774,17 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intr
 
 // Dataflow schedule (k_chol_flow): one launch of persistent workgroups, 2 per CU, tiles handed out by ticket.
 inline void launch_flow(int dcov, int n_wg, hipStream_t st, const CholArgs& ca) {
-  const bool tab = ca.logdt != nullptr && dcov > 0;
+  const int gm = chol_gm(dcov, ca);
   const dim3 grid(n_wg), block(256);
-  if (dcov == 0) hipLaunchKernelGGL((k_chol_flow<0, false>), grid, block, 0, st, ca);
+  if (dcov == 0) hipLaunchKernelGGL((k_chol_flow<0, 0>), grid, block, 0, st, ca);
   else if (dcov <= 4) {
-    if (tab) hipLaunchKernelGGL((k_chol_flow<4, true>), grid, block, 0, st, ca);
-    else hipLaunchKernelGGL((k_chol_flow<4, false>), grid, block, 0, st, ca);
+    if (gm == 2) hipLaunchKernelGGL((k_chol_flow<4, 2>), grid, block, 0, st, ca);
+    else if (gm == 1) hipLaunchKernelGGL((k_chol_flow<4, 1>), grid, block, 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_flow<4, 0>), grid, block, 0, st, ca);
   } else {
-    if (tab) hipLaunchKernelGGL((k_chol_flow<8, true>), grid, block, 0, st, ca);
-    else hipLaunchKernelGGL((k_chol_flow<8, false>), grid, block, 0, st, ca);
+    if (gm == 2) hipLaunchKernelGGL((k_chol_flow<8, 2>), grid, block, 0, st, ca);
+    else if (gm == 1) hipLaunchKernelGGL((k_chol_flow<8, 1>), grid, block, 0, st, ca);
+    else hipLaunchKernelGGL((k_chol_flow<8, 0>), grid, block, 0, st, ca);
   }
 }
 // Medium populations — more particles than the right-looking schedule serves, fewer than fill the GPU with the tiles
@@ -857,7 +899,7 @@ void launch_gather(agp_ctx* c, hipStream_t st, int Pc, int nt1, double* dstA, lo
 int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
                       const int32_t* prm_off, const double* prm, const double* noise,
                       double* h_out_lp, int32_t* h_out_info, double* d_user_lp, int32_t* d_user_info,
-                      hipStream_t user_stream, bool use_user_stream, GradOut* go = nullptr) {
+                      hipStream_t user_stream, bool use_user_stream, GradOut* go = nullptr, bool allow_lag = true) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   if (P < 0 || n < 0) return fail(c, AGP_ERR_ARG, "negative size");
   if (P == 0) return AGP_OK;
@@ -872,9 +914,12 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   const bool ge_tab = c->logdt_ok && c->intrsm != 0;
   // (the schedule is chosen per call from P and n; chunked / multi-stream sub-batches re-check with their own size)
   const bool flow_hint = n > 0 && c->flow_fuse && use_flow(c, P, (int)((n + NB - 1) / NB));
-  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint);
+  // value sweeps over the whole of a regular grid run on the sorted copy with lag tables (see agp_ctx::d_ts_s)
+  const bool lag = allow_lag && c->lag_enable && c->lag_ok && !go && n > 0 && n == c->n_max && c->intrsm != 0;
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint, lag);
   if (rc) return rc;
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
+  if (lag) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_sweeps; }
   const int n_prm_total = prm_off[P];
   if (go && n == 0) {
     for (int i = 0; i < n_prm_total; ++i) go->grad[i] = 0.0;
@@ -1034,13 +1079,13 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         if (Pg <= 0) continue;
         hipStream_t q = (g == 0) ? st : s->sub[g - 1];
         hipLaunchKernelGGL(k_init_vec, dim3((n_pad + 255) / 256, Pg), dim3(256), 0, q,
-                           s->vec.as<double>() + (size_t)g0 * n_pad, n_pad, Pg, c->d_xs, (const double*)nullptr, (int)n,
+                           s->vec.as<double>() + (size_t)g0 * n_pad, n_pad, Pg, lag ? c->d_xs_s : c->d_xs, (const double*)nullptr, (int)n,
                            s->info.as<int>() + g0, s->ready.as<int>() + g0);
         CovArgs cv = {};
-        cv.tt = c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
+        cv.tt = lag ? c->d_ts_s : c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
         cv.hdr = d_hdr + p0 + g0; cv.ops = d_ops; cv.prm = d_prm;
         cv.noise = d_noise + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
-        cv.strideA = strideA; cv.P = Pg; cv.logdt = ge_tab ? c->d_logdt : nullptr;
+        cv.strideA = strideA; cv.P = Pg; cv.logdt = (ge_tab && !lag) ? c->d_logdt : nullptr;
         int i0min = 0;
         if (n_hit > 0) {
           // resident factors: forward-solve vector and partials are copied out of the store; L and the inverse blocks
@@ -1076,6 +1121,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         ca.partial = s->partial.as<double>() + (size_t)g0 * 2 * nt;
         ca.info = s->info.as<int>() + g0; ca.P = Pg; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
         set_cov(ca, cv);
+        ca.lag = lag ? 1 : 0;
         ca.n_fused = nf;
         ca.ready = s->ready.as<int>() + g0;
         ca.i0 = cv.i0;
@@ -1247,6 +1293,34 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   }
   for (int p = 0; p < P; ++p)
     if (h_info[p] < 0) return fail(c, AGP_ERR_HIP, "in-kernel panel solve timed out waiting for its diagonal factor");
+  if (lag && h_out_info) {
+    // LAPACK's info names the first non-positive leading minor IN THE CALLER'S ORDER of the observations
+    // (LinearAlgebra.PosDefException(info) in the reference); the sorted sweep found the matrix not positive definite
+    // at some minor of the sorted order.  The (rare) rejected particles are factored once more in the caller's order.
+    std::vector<int> bad;
+    for (int p = 0; p < P; ++p) if (h_info[p] > 0) bad.push_back(p);
+    if (!bad.empty()) {
+      const int B = (int)bad.size();
+      std::vector<int32_t> bo(B + 1, 0), bp(B + 1, 0), binfo(B);
+      std::vector<uint8_t> bops; std::vector<double> bprm, bnoise(B), blp(B);
+      for (int b = 0; b < B; ++b) {
+        const int p = bad[b];
+        bops.insert(bops.end(), ops + op_off[p], ops + op_off[p + 1]);
+        bprm.insert(bprm.end(), prm + prm_off[p], prm + prm_off[p + 1]);
+        bo[b + 1] = (int32_t)bops.size(); bp[b + 1] = (int32_t)bprm.size();
+        bnoise[b] = noise[p];
+      }
+      if (bprm.empty()) bprm.push_back(0.0);
+      const int rc2 = logpdf_batch_impl(c, n, B, bo.data(), bops.data(), bp.data(), bprm.data(), bnoise.data(), blp.data(), binfo.data(),
+                                        nullptr, nullptr, nullptr, false, nullptr, /*allow_lag=*/false);
+      if (rc2) return rc2;
+      for (int b = 0; b < B; ++b) {
+        // (a matrix that is indefinite to rounding may factor in one order and not in the other: the caller's order decides)
+        h_out_info[bad[b]] = binfo[b];
+        if (h_out_lp) h_out_lp[bad[b]] = blp[b];
+      }
+    }
+  }
   return AGP_OK;
 }
 
@@ -1308,6 +1382,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_TRTRI_CHAIN")) c->trtri_chain = atoi(e) != 0;
   if (const char* e = getenv("AGP_SPLIT_DIAG")) c->split_diag = atoi(e);
   if (const char* e = getenv("AGP_GE_TABLE")) c->ge_table = atoi(e) != 0;
+  if (const char* e = getenv("AGP_LAG")) c->lag_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_RIGHT_LOOKING")) c->right_looking = atoi(e);
   if (const char* e = getenv("AGP_HYBRID_BLOCKS")) c->hybrid_blocks = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
@@ -1348,6 +1423,8 @@ void agp_destroy(agp_ctx* c) {
   if (c->d_ts) (void)hipFree(c->d_ts);
   if (c->d_xs) (void)hipFree(c->d_xs);
   if (c->d_logdt) (void)hipFree(c->d_logdt);
+  if (c->d_ts_s) (void)hipFree(c->d_ts_s);
+  if (c->d_xs_s) (void)hipFree(c->d_xs_s);
   if (c->d_flow_trace) (void)hipFree(c->d_flow_trace);
   delete c;
 }
@@ -1416,6 +1493,33 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
   c->h_ts.assign(ts, ts + n_max);
   c->h_xs.assign(xs, xs + n_max);
   c->n_max = n_max;
+  // Is the series a regular grid (in any order)?  Sort, compare every point with t_0 + g h: admitted only when each sits
+  // within 16 ulp of its grid position (np.linspace / a min-max rescaled integer grid are within 1-2), so that the lag
+  // tables' representative differences equal every element's own t_i - t_j to rounding.
+  c->lag_ok = false;
+  if (c->d_ts_s) { HIPCHK(c, hipFree(c->d_ts_s)); c->d_ts_s = nullptr; }
+  if (c->d_xs_s) { HIPCHK(c, hipFree(c->d_xs_s)); c->d_xs_s = nullptr; }
+  if (c->lag_enable && n_max >= 2) {
+    std::vector<int64_t> perm((size_t)n_max);
+    for (int64_t i = 0; i < n_max; ++i) perm[(size_t)i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return ts[a] < ts[b]; });
+    std::vector<double> tss((size_t)n_max), xss((size_t)n_max);
+    for (int64_t i = 0; i < n_max; ++i) { tss[(size_t)i] = ts[perm[(size_t)i]]; xss[(size_t)i] = xs[perm[(size_t)i]]; }
+    const double t0 = tss.front(), t1 = tss.back();
+    const double h = (t1 - t0) / (double)(n_max - 1);
+    const double tol = 16.0 * 2.220446049250313e-16 * std::max(std::fabs(t0), std::fabs(t1));
+    bool regular = std::isfinite(h) && h > 0.0 && tol < 1e-6 * h;
+    for (int64_t i = 0; regular && i < n_max; ++i) regular = std::fabs(tss[(size_t)i] - (t0 + (double)i * h)) <= tol;
+    if (regular) {
+      HIPCHK(c, hipMalloc((void**)&c->d_ts_s, sizeof(double) * npad));
+      HIPCHK(c, hipMalloc((void**)&c->d_xs_s, sizeof(double) * npad));
+      HIPCHK(c, hipMemset(c->d_ts_s, 0, sizeof(double) * npad));
+      HIPCHK(c, hipMemset(c->d_xs_s, 0, sizeof(double) * npad));
+      HIPCHK(c, hipMemcpy(c->d_ts_s, tss.data(), sizeof(double) * n_max, hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemcpy(c->d_xs_s, xss.data(), sizeof(double) * n_max, hipMemcpyHostToDevice));
+      c->lag_ok = true;
+    }
+  }
   // log|t_i - t_j| over the resident points, shared by the GammaExp leaves of every particle (OP_GE_TAB)
   c->logdt_ok = false;
   if (c->ge_table && n_max > 0) {
@@ -2687,6 +2791,20 @@ int agp_grad_reuse_stats(agp_ctx* c, int64_t* out2) {
   if (!c || !out2) return fail(c, AGP_ERR_ARG, "null pointer");
   std::lock_guard<std::mutex> g(c->mu);
   out2[0] = c->grad_reused; out2[1] = c->grad_factored;
+  return AGP_OK;
+}
+
+int agp_get_lag_stats(agp_ctx* c, int32_t* regular_grid, int64_t* n_lag_sweeps) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  std::lock_guard<std::mutex> g(c->mu);
+  if (regular_grid) *regular_grid = (c->lag_enable && c->lag_ok) ? 1 : 0;
+  if (n_lag_sweeps) *n_lag_sweeps = c->n_lag_sweeps;
+  return AGP_OK;
+}
+
+int agp_set_lag_tables(agp_ctx* c, int32_t on) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  c->lag_enable = on != 0;
   return AGP_OK;
 }
 

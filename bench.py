@@ -23,7 +23,12 @@ scaling: 512/N particles per GPU — BASELINE's metric and config are quoted on 
 `--weak` keeps 512 particles PER GPU instead (population 512 N).  ts/xs are resident in HBM before the
 timed region; kernel programs (a few KB) are handed over per call, as the reference's call site would.
 
-After the timed region (N = 1 only, never inside it) three short legs put the paths beside the value sweep into the same
+The synthetic series is a regular time grid in shuffled order; the engine detects that and evaluates
+stationary kernels from per-tile lag tables on a sorted copy (include/autogp_hip.h "Regular time grids";
+config.regular_grid_lag_tables says whether the timed sweeps took that path, and the `general_path` block gives the same
+sweep with it switched off).
+
+After the timed region (N = 1 only, never inside it) short legs put the paths beside the value sweep into the same
 record: the stand-alone covariance builder (GB/s written, leaf evaluations/s: SURVEY.md §8(d) K1), the value+gradient sweep
 (src/inference_smc_anneal_data.jl:63-67: where fit_smc! spends its time) and the marginal predictive pass at m = 2n
 (src/GP.jl:731-758).  `--no-extra-legs` skips them.
@@ -165,6 +170,34 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
             "note": "HBM-write bound only for trivial kernels; with transcendental leaves it is fp64-VALU bound (SURVEY.md §8(d)): both figures reported"}
     except Exception as e:      # noqa: BLE001
         out["roofline_cov_kernel"] = {"error": str(e)[:300]}
+    # ---- the same value sweep WITHOUT the regular-grid lag tables (what an irregularly sampled series of the same size costs) ----
+    try:
+        old = os.environ.get("AGP_LAG")
+        os.environ["AGP_LAG"] = "0"
+        try:
+            e3 = pkg.GPEngine(device)
+        finally:
+            if old is None:
+                os.environ.pop("AGP_LAG", None)
+            else:
+                os.environ["AGP_LAG"] = old
+        e3.set_data(ts, xs)
+        d_lp = torch.zeros(P, dtype=torch.float64, device=f"cuda:{device}"); d_info = torch.zeros(P, dtype=torch.int32, device=f"cuda:{device}")
+        for _ in range(3):
+            e3.logpdf_batch_device(programs, noises, n, d_lp.data_ptr(), d_info.data_ptr(), stream); torch.cuda.synchronize()
+        reps = 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            e3.logpdf_batch_device(programs, noises, n, d_lp.data_ptr(), d_info.data_ptr(), stream)
+            torch.cuda.current_stream().synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        lp_gen = d_lp.cpu().numpy()
+        e3.close()
+        out["general_path"] = {"what": "the same sweep with AGP_LAG=0: every covariance element evaluated from its own t_i - t_j in the caller's order "
+                                       "(irregular series, prefixes of a shuffled grid)", "evals_per_s": P / dt, "ms_per_step": dt * 1e3,
+                               "steps": reps, "logpdf": lp_gen}
+    except Exception as e:      # noqa: BLE001
+        out["general_path"] = {"error": str(e)[:300]}
     # ---- value + gradient sweep (agp_logpdf_grad_batch): Cholesky, L^-T, K^-1 tiles, per-element reverse sweep of the programs ----
     try:
         eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
@@ -356,7 +389,8 @@ def run_single_process(args):
                       "n": n, "particles_total": P_total, "particles_per_gpu": P0, "tile": NB, "not_positive_definite": int((info != 0).sum()),
                       "parallelism": f"particle-shard x{ndev} (single process)", "launch": "single-process (agp_init_multi)",
                       "collective": "rccl via C ABI (ncclCommInitAll + one ncclGroup of all-gathers inside agp_logpdf_batch_multi)" if ndev > 1 else None,
-                      "rccl_ranks_seen": ranks_seen, "allgather_selfcheck": ok},
+                      "rccl_ranks_seen": ranks_seen, "allgather_selfcheck": ok,
+                      "regular_grid_lag_tables": eng0.lag_stats()[0] and eng0.lag_stats()[1] > 0},
            "cholesky_gflops": chol_gf, "sweep_frac_of_fp64_mfma_peak": chol_gf / 1e3 / (PEAK_FP64_MFMA_TFLOPS * ndev),
            "roofline": roof}
     if diag_block:
@@ -575,8 +609,14 @@ def main():
         }
         if diag_block:
             out["roofline_diag_kernel"] = diag_block
+        out["config"]["regular_grid_lag_tables"] = eng.lag_stats()[0] and eng.lag_stats()[1] > 0
         if world == 1 and not args.no_extra_legs:
             out.update(extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, local_rank))
+            gp_ = out.get("general_path", {})
+            if "logpdf" in gp_:
+                lg = gp_.pop("logpdf")
+                okb = np.isfinite(lg) & np.isfinite(lp)
+                gp_["max_rel_diff_vs_lag_path"] = float(np.max(np.abs(lg[okb] - lp[okb]) / np.maximum(1.0, np.abs(lp[okb])))) if okb.any() else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(programs, noises, ts, xs, lp)
         print(json.dumps(out), flush=True)

@@ -141,6 +141,20 @@ int agp_predict_reuse_stats(agp_ctx* ctx, int64_t* out2);
 int agp_grad_reuse_stats(agp_ctx* ctx, int64_t* out2);
 int agp_set_factor_cache(agp_ctx* ctx, int32_t on);
 
+/* Regular time grids.  agp_set_data checks whether the series' time points, put in ascending order, are equally spaced
+ * (every point within 16 ulp of t_0 + g h: np.linspace, range(...), a min-max rescaled daily / hourly / yearly index).  If
+ * so, value sweeps over the WHOLE series (n == n_max; agp_logpdf_batch{,_device,_multi}) run on a sorted copy of the data
+ * — log N(x; 0, K) is invariant under a symmetric permutation of K and x — where an element of a tile depends on
+ * (row - column) only: every stationary leaf (SquaredExponential, GammaExponential, Periodic; src/GP.jl:236-245,
+ * 279-289, 324-336) is evaluated 255 times per 128 x 128 tile into an LDS table instead of 16 384 times, and tiles are
+ * evaluated inside the factorisation kernels whatever the kernel tree's size.  Results agree with the general path to
+ * rounding (the table's representative t_i - t_j differs from an element's own by a few ulp of t).  Prefix sweeps
+ * (n < n_max: a subset of a shuffled grid is not a grid), irregular series, the extension / factor-store entries, gradient
+ * and predictive entries take the general path.  AGP_LAG=0 / agp_set_lag_tables(ctx, 0) disable it (the switch is read at
+ * the next agp_set_data).  agp_get_lag_stats: whether the resident series qualifies, and how many sweeps took the path. */
+int agp_get_lag_stats(agp_ctx* ctx, int32_t* regular_grid, int64_t* n_lag_sweeps);
+int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
+
 /* Value AND gradient: d logpdf / d theta for every (transformed) kernel parameter — out_grad has the
  * layout of `prm` (prm_off offsets; ChangePoint contributes d/dlocation, d/dscale) — and d logpdf / d noise.
  * This is what Gen.choice_gradients needs from the model body for Gen.hmc / Gen.map_optimize

@@ -314,14 +314,14 @@ def test_bench_single_process_mode():
 
 def test_bench_default_line_has_every_block():
     """The default single-GPU line (short run, small shapes): roofline + the legs beside the value sweep + cpu_baseline."""
-    out = _bench_line(["--steps", "8", "--warmup", "1", "--n-obs", "640", "--particles", "256"])
+    out = _bench_line(["--steps", "8", "--warmup", "1", "--n-obs", "384", "--particles", "512"])
     assert out["config"]["not_positive_definite"] == 0
     for key in ("roofline", "roofline_diag_kernel", "roofline_cov_kernel", "grad", "predict", "cpu_baseline"):
         assert key in out and "error" not in out[key], (key, out.get(key))
     assert out["roofline_cov_kernel"]["unit"] == "GB/s" and out["roofline_cov_kernel"]["leaf_evals_per_s"] > 0
     assert out["grad"]["kernel_ms"]["k_trtri_chain"] > 0 and out["grad"]["kernel_ms"]["k_grad_contract"] > 0
     assert out["cpu_baseline"]["one_worker_evals_per_s"] > 0 and out["cpu_baseline"]["parity_max_rel_err_vs_gpu"] < 1e-8
-    assert out["roofline"]["algorithmic_bytes_per_step"] == 8.0 * 640 * 640 * 256
+    assert out["roofline"]["algorithmic_bytes_per_step"] == 8.0 * 384 * 384 * 512
 
 
 def test_two_rank_stream_on_one_gpu(tmp_path, pkg):

@@ -1,0 +1,131 @@
+"""GPU tests of the regular-grid path (include/autogp_hip.h "Regular time grids"; csrc/agp_cov_kernel.hpp lag tables): value
+sweeps over the whole of a regularly spaced series run on a sorted copy and read stationary leaves from per-tile lag tables.
+Checked against the oracle (1e-8, BASELINE.json's tolerance), against the general path of the same engine (1e-10: the two differ
+by the rounding of t_i - t_j and by the pivot order) in every schedule regime, and that everything which must NOT take the path —
+prefixes, irregular series, jittered grids — does not."""
+import numpy as np
+import pytest
+
+from oracle import fast as F
+
+pytestmark = pytest.mark.gpu
+LP_TOL = 1e-8
+
+
+def lp_err(a, b):
+    return np.abs(a - b) / np.maximum(1.0, np.abs(b))
+
+
+def both_paths(pkg, nodes, noises, ts, xs, n=None):
+    """(lag-path values, general-path values, lag sweeps counted) from two contexts over the same data."""
+    a = pkg.GPEngine(0); b = pkg.GPEngine(0)
+    try:
+        b.set_lag_tables(False)
+        a.set_data(ts, xs); b.set_data(ts, xs)
+        before = a.lag_stats()[1]
+        la, ia = a.logpdf_batch(nodes, noises, n=n, check=False)
+        took = a.lag_stats()[1] - before
+        lb, ib = b.logpdf_batch(nodes, noises, n=n, check=False)
+        assert b.lag_stats() == (False, 0)
+        return la, ia, lb, ib, took, a.lag_stats()[0]
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("n,P,depth", [(640, 300, 3),      # >= 256 particles: per-column launches, tiles evaluated in-kernel
+                                        (768, 40, 3),       # dataflow schedule
+                                        (700, 3, 3),        # right-looking schedule, tiles prebuilt by k_cov_tiles (n not a tile multiple)
+                                        (128, 9, 2), (129, 9, 2), (2, 4, 2),
+                                        (1024, 24, 6)])     # deep trees: depth-8 evaluation stack, many tables
+def test_lag_path_vs_oracle_and_general_path(pkg, n, P, depth):
+    ts, xs = pkg.prior.synthetic_series(n, seed=900 + n, shuffle=True)
+    kw = dict(max_depth=depth) if depth < 6 else dict(max_depth=6, min_depth=5, max_size=63)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(n + P), P, **kw)
+    la, ia, lb, ib, took, regular = both_paths(pkg, nodes, noises, ts, xs)
+    assert regular and took >= 1, "the sweep did not take the lag-table path"
+    assert np.array_equal(ia == 0, ib == 0) or (np.sum((ia == 0) != (ib == 0)) <= 1)
+    ok = (ia == 0) & (ib == 0)
+    assert ok.mean() >= 0.9
+    assert lp_err(la[ok], lb[ok]).max() <= 1e-10
+    ref, rinfo = F.gp_logpdf_many(pkg.encode_batch(nodes), noises, ts, xs)
+    both = ok & (rinfo == 0)
+    assert lp_err(la[both], ref[both]).max() <= LP_TOL
+    # rejected particles carry LAPACK's info of the CALLER's order (repaired by a second factorisation in that order)
+    bad = (ia > 0) & (ib > 0)
+    assert np.array_equal(ia[bad], ib[bad])
+
+
+def test_lag_path_fixture_kernels_and_changepoints(pkg):
+    """Every leaf kind and combinator (test/test_GP.jl:24-33 kernels and their composites), incl. WhiteNoise (the identity
+    survives the sort), ChangePoint with its per-point tables next to the lag tables, and an unsorted regular grid with an offset
+    and a negative range."""
+    G = pkg
+    base = [G.WhiteNoise(0.3), G.Constant(0.5), G.Linear(0.1, 1.3, 0.7), G.SquaredExponential(0.47, 0.13),
+            G.GammaExponential(0.42, 0.58, 3.2), G.Periodic(0.96, 0.21, 1.1)]
+    ks = list(base[2:])
+    for x in base:
+        for y in base[3:]:
+            ks += [x + y, x * y, G.ChangePoint(x, y, 0.5, 0.05), G.ChangePoint(y, x * y, 0.3, 0.001)]
+    nz = np.full(len(ks), 0.07)
+    for t0, t1, n in ((0.0, 1.0, 300), (-3.0, 2.0, 257), (5.0, 5.5, 128)):
+        ts = np.linspace(t0, t1, n)
+        rng = np.random.default_rng(n)
+        perm = rng.permutation(n)
+        ts = ts[perm]; xs = np.sin(5 * ts) + 0.1 * rng.standard_normal(n)
+        la, ia, lb, ib, took, regular = both_paths(pkg, ks, nz, ts, xs)
+        assert regular and took >= 1
+        assert (ia == 0).all() and (ib == 0).all()
+        assert lp_err(la, lb).max() <= 1e-10
+        ref, rinfo = F.gp_logpdf_many(pkg.encode_batch(ks), nz, ts, xs)
+        assert (rinfo == 0).all() and lp_err(la, ref).max() <= LP_TOL
+
+
+def test_what_must_not_take_the_lag_path(pkg):
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(5), 12, max_depth=3)
+    eng = pkg.GPEngine(0)
+    try:
+        # prefixes of a shuffled grid are not grids
+        ts, xs = pkg.prior.synthetic_series(512, seed=4, shuffle=True)
+        eng.set_data(ts, xs)
+        assert eng.lag_stats() == (True, 0)
+        lp, info = eng.logpdf_batch(nodes, noises, n=300, check=False)
+        assert eng.lag_stats() == (True, 0)
+        ref, _ = F.gp_logpdf_many(pkg.encode_batch(nodes), noises, ts[:300], xs[:300])
+        ok = info == 0
+        assert lp_err(lp[ok], ref[ok]).max() <= LP_TOL
+        eng.logpdf_batch(nodes, noises, check=False)
+        assert eng.lag_stats() == (True, 1)
+        # gradient, extension and predictive entries keep the caller's order
+        eng.logpdf_grad_batch(nodes, noises, check=False)
+        eng.logpdf_batch_extend(nodes, noises, check=False)
+        eng.predict_batch(nodes[:2], noises[:2], np.linspace(0, 1.1, 20), check=False)
+        assert eng.lag_stats() == (True, 1)
+        # a grid jittered by 1e-9 (relative), a random series, a grid with one point missing and with a duplicate
+        rng = np.random.default_rng(0)
+        grid = np.linspace(0.0, 1.0, 400)
+        for bad in (grid * (1 + 1e-9 * rng.standard_normal(400)), np.sort(rng.random(400)), np.delete(grid, 17),
+                    np.concatenate([grid[:200], grid[199:]])):
+            eng.set_data(bad, np.cos(3 * bad))
+            assert eng.lag_stats()[0] is False
+            lp, info = eng.logpdf_batch(nodes[:4], noises[:4], check=False)
+            ref, rinfo = F.gp_logpdf_many(pkg.encode_batch(nodes[:4]), noises[:4], bad, np.cos(3 * bad))
+            ok = (info == 0) & (rinfo == 0)
+            assert lp_err(lp[ok], ref[ok]).max() <= LP_TOL
+        assert eng.lag_stats()[1] == 1
+    finally:
+        eng.close()
+
+
+def test_lag_path_non_positive_definite_info(pkg):
+    """A matrix that is not positive definite: the lag sweep flags it, and the info it hands back is LAPACK's for the caller's
+    order of the observations (the reference raises PosDefException(info) with that index)."""
+    n = 256
+    ts, xs = pkg.prior.synthetic_series(n, seed=11, shuffle=True)
+    ks = [pkg.SquaredExponential(5.0, 1.0), pkg.SquaredExponential(0.1, 1.0) + pkg.Linear(0.2, 0.1, 1.0)]   # smooth kernel, noise 0: singular to rounding
+    nz = np.array([0.0, 0.05])
+    la, ia, lb, ib, took, regular = both_paths(pkg, ks, nz, ts, xs)
+    assert regular and took >= 1
+    assert ia[0] > 0 and ib[0] > 0 and ia[0] == ib[0] and np.isnan(la[0])
+    assert ia[1] == 0 and ib[1] == 0 and lp_err(la[1:], lb[1:]).max() <= 1e-10
+    _, rinfo = F.gp_logpdf_many(pkg.encode_batch(ks), nz, ts, xs)
+    assert rinfo[0] > 0
