@@ -73,6 +73,7 @@ struct CholArgs {
   int schur_diag_only;  // Schur mode: only the diagonal tiles of the prediction block (marginal variances + mean; no covariance)
   int flow_order;       // 0: sub-diagonal tiles of a block column tile-row-major (all particles' (k+1,k) first), 1: particle-major
   int lag;              // 1: sorted regular grid, the fused programs' stationary leaves are OP_LAG_* (GM = 2 instantiations)
+  const double* lagtab; // ... and their tables (k_lag_tables)
 };
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -140,6 +141,29 @@ constexpr bool XCD_PIN = AGP_XCD_PIN != 0;     // 1: all tiles of a particle on 
 #ifndef AGP_INTERLEAVE
 #define AGP_INTERLEAVE 1
 #endif
+// Measurement switches for wave priorities.
+// AGP_PRIO_ASYM: MFMA-block priority by hardware wave slot (odd slot 2, even slot 1), so that the two workgroups of a CU stop
+// running the same phases at the same time.  Measured (r03e): no effect, 23.38 vs 23.27 ms of sub-diagonal launches per sweep.
+// AGP_CHAIN_PRIO: in the dataflow kernel the items of the per-column dependency chain — diagonal tiles and the (k+1, k) tiles —
+// run at a higher priority than the bulk tiles throughout (2, 3 inside their MFMA blocks; the bulk 0 / 1).
+#ifndef AGP_PRIO_ASYM
+#define AGP_PRIO_ASYM 0
+#endif
+#ifndef AGP_CHAIN_PRIO
+#define AGP_CHAIN_PRIO 0
+#endif
+__device__ __forceinline__ void mfma_prio_on(bool hi) {
+  if ((AGP_PRIO_ASYM || AGP_CHAIN_PRIO) && hi) __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO ? 3 : 2);
+  else __builtin_amdgcn_s_setprio(1);
+}
+__device__ __forceinline__ void mfma_prio_off(bool hi) {
+  if (AGP_CHAIN_PRIO && hi) __builtin_amdgcn_s_setprio(2);
+  else __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ bool wave_slot_odd() {
+  // HW_REG_HW_ID (id 4), WAVE_ID = bits [3:0]
+  return AGP_PRIO_ASYM ? ((__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1) != 0) : false;
+}
 constexpr bool ILV = AGP_INTERLEAVE != 0;      // strips = even/odd rows (1) or rows [0,16) / [16,32) of the wave (0)
 constexpr bool A_DIRECT = AGP_A_DIRECT != 0;   // row operand: 1 = global -> registers, 0 = through LDS
 constexpr int T_NBLK = NSB * (NSB - 1) / 2;              // 28 strictly-lower 16x16 blocks
@@ -384,7 +408,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     double* etab = sm + U_MAIN_DOUBLES;      // exp table in the (still unused) forward-solve scratch: rvec[128]
     if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
     __syncthreads();
-    cov_prologue<LAGM>(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid);
+    cov_prologue<LAGM>(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt);
     const double noise = a.noise[p];
     // GammaExp leaves read log|dt| from the data set's table (L2 / Infinity-Cache resident: every particle reads
     // the same 128 KiB tile); the loads are issued at the top of the pass and consumed by the first such leaf
@@ -509,6 +533,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     // (Fetching the direct row operand TWO slabs ahead — 16 more VGPRs, still no spills — was measured: the 512-particle
     // sub-diagonal launch went 1.560 -> 1.664 ms.  The loop is not waiting for its loads; more of them in flight only
     // crowd the co-resident workgroup's.)
+    const bool prio_hi = (AGP_CHAIN_PRIO && FLOW) ? (ti == tk + 1) : wave_slot_odd();
     gload(0);
     lstore(0);
     d2 fr[NU];                                   // row fragments of the slab being multiplied
@@ -521,7 +546,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
       const double* Bs = sm + buf * SLAB_DOUBLES;
       const double* As = sm + (2 + buf) * SLAB_DOUBLES;
       // waves inside their MFMA block outrank the co-resident workgroup's load/store/barrier phase
-      __builtin_amdgcn_s_setprio(1);
+      mfma_prio_on(prio_hi);
 #pragma unroll
       for (int kk = 0; kk < KS / 4; ++kk) {
         const int krow = (kk * 4 + lq) * LDS_STRIDE;
@@ -538,7 +563,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
           acc[cb][1] = mfma(fa[cb], fb.y, acc[cb][1]);
         }
       }
-      __builtin_amdgcn_s_setprio(0);
+      mfma_prio_off(prio_hi);
       if (is_diag && tid < NB) {
         // r -= L(k,j)[:, slab] * alpha_j[slab]
         const double* xs_ = xv + buf * KS;
@@ -793,7 +818,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
     double* etab = rvec;                     // exp table in the (still unused) forward-solve scratch
     if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
     __syncthreads();
-    cov_prologue<LAGM>(a.tt, a.code, tk, tk, h, ops, prm, tpt, sig, tid);
+    cov_prologue<LAGM>(a.tt, a.code, tk, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt);
     const double noise = a.noise[p];
     const bool use_tab = TAB && (h.flags & 1) != 0;
     const double* __restrict__ ltile = a.logdt + tile_off(tk, tk);      // only dereferenced when use_tab
@@ -888,9 +913,10 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
       for (int u = 0; u < NU; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb2[u];
       if (tid < KS) xv[buf * KS + tid] = rx2;
     };
+    const bool prio_hi = (AGP_CHAIN_PRIO && FLOW) ? true : wave_slot_odd();
     auto slab = [&](int buf) {
       const double* Bs = sm + buf * SLAB_DOUBLES;
-      __builtin_amdgcn_s_setprio(1);
+      mfma_prio_on(prio_hi);
 #pragma unroll
       for (int kk = 0; kk < KS / 4; ++kk) {
         const double* Bk = Bs + kk * 4 * LDS_STRIDE;
@@ -898,7 +924,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
 #pragma unroll
         for (int e = 0; e < ((AGP_DBG_SKIP & 256) ? 0 : NE); ++e) acc[e] = mfma(Bk[fao[e]], st1[e] ? f1 : f0, acc[e]);
       }
-      __builtin_amdgcn_s_setprio(0);
+      mfma_prio_off(prio_hi);
       if (tid < NB && !(AGP_DBG_SKIP & 128)) {
         // r -= L(k,j)[:, slab] * alpha_j[slab]
         // (Spreading this over all four waves — each half of the workgroup taking half of the slab's columns — was tried:
@@ -1048,8 +1074,10 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
     asm volatile("" : "+v"(tid));
     // diagonal tiles run the lower-triangle body of k_chol_diag, the others the sub-diagonal body (update + in-register
     // solve) of the split per-column launches
+    if (AGP_CHAIN_PRIO) { if (tl <= 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
     if (tl == 0) chol_diag_tile<DCOV, GM, true>(a, p, ps, k, sm, tid, &s_wait);
     else chol_tile<true, DCOV, true, 2, GM, true>(a, p, ps, k + tl, k, k, false, sm, tid, &s_wait);
+    if (AGP_CHAIN_PRIO) __builtin_amdgcn_s_setprio(0);
     if (a0.trace && threadIdx.x == 0) {
       // record of this item: [start, end, K-loop wait ticks, (xcd, particle, tile row, block column)]
       int gi = item;

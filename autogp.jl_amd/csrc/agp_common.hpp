@@ -43,7 +43,7 @@ struct ProgHdr {
   int32_t n_prm;    // device parameters of this program
   int32_t flags;    // bit 0: the program has OP_GE_TAB leaves (reads the log|dt| table)
   int32_t n_lag;    // number of per-tile lag tables (OP_LAG_* leaves); they follow the n_cp per-point tables in LDS
-  int32_t pad_;
+  int32_t lag_off;  // index of the program's first lag table in the sweep's table buffer (k_lag_tables)
 };
 
 __host__ __device__ inline long long tile_off(int i, int j) {

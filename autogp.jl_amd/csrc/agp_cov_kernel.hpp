@@ -43,6 +43,7 @@ struct CovArgs {
   const int* slot;       // extension sweeps (see CholArgs): storage index per particle, first tile row to (re)build
   const int* i0;
   int skip_pred_offdiag; // prediction without a covariance request: off-diagonal tiles of the K22 block are never read
+  const double* lagtab;  // lag tables of the sweep's OP_LAG_* leaves (k_lag_tables): [table][block lag 0..nt-1][256]
 };
 
 __device__ __forceinline__ int prm_count(int o) {
@@ -54,43 +55,21 @@ __device__ __forceinline__ int prm_count(int o) {
 // LDS scratch of the evaluator: tpt[256] (row times 0..127, column times 128..255), sig[n_cp][256], then lag[n_lag][256].
 //
 // Lag tables (LAG = true instantiations; programs compiled for a sweep over SORTED, REGULARLY SPACED time points — the host
-// only emits OP_LAG_* leaves then): with t_g = t_0 + g h the difference t_(I0+a) - t_(J0+b) of a tile's element (a, b) is
-// (I0 - J0 + a - b) h: a function of a - b alone, 255 distinct values per tile.  Thread d + 127 evaluates every stationary
-// leaf ONCE at the tile's lag d — on the actual stored time points of the representative element (a, b) = (d, 0) for d >= 0,
-// (0, -d) for d < 0, with exactly the arithmetic of the general path (src/GP.jl:241-245, 285-289, 331-336) — and the 16 384
-// elements read the leaf from the table: one LDS access instead of 40-90 fp64 instructions.  The other elements of a
-// diagonal differ from the representative only by the rounding of their own t_i - t_j (a few ulp of t: agp_set_data admits
-// a grid only when every point sits within 16 ulp of t_0 + g h).  A padding row / column is never a representative of a
-// lag that a valid element uses (lag d >= 0 is represented by row d <= the valid element's row, d < 0 by a column of the
-// valid element's tile column or an earlier one).
-// (its own function, not inlined: the power / sin^2 / exp code would otherwise be allocated inside the factorisation
-// kernels' register budget — the dataflow kernel went from 21 to 74 spilled registers with it inlined)
-template <typename OpT>
-__device__ __attribute__((noinline)) void lag_tables(int n_ops, const OpT* __restrict__ ops, const double* __restrict__ prm,
-                                                     const double* tpt, double* lag, int tid) {
-  const int d = tid - (NB - 1);
-  const double dx = (tid >= 2 * NB - 1) ? 0.0 : (d >= 0 ? tpt[d] - tpt[NB] : tpt[0] - tpt[NB - d]);
-  int q = 0, li = 0;
-  for (int ip = 0; ip < n_ops; ++ip) {
-    const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
-    if (o >= OP_LAG_SE) {
-      const double p0 = prm[q], p1 = prm[q + 1], p2 = prm[q + 2];
-      double arg, amp;
-      if (o == OP_LAG_SE) { arg = ((-0.5 * dx) * dx) * p0; amp = p1; }                       // p0 = 1/l^2
-      else if (o == OP_LAG_GE) { arg = -fm::pow_f(fabs(dx) * p0, p1); amp = p2; }            // p0 = 1/l, p1 = gamma
-      else { arg = p0 * fm::sin2_f(p1 * fabs(dx)); amp = p2; }                              // p0 = -2/l^2, p1 = pi/p
-      lag[li * 256 + tid] = amp * fm::exp_f(arg);
-      ++li;
-    }
-    q += prm_count(o);
-  }
-}
-
+// only emits OP_LAG_* leaves then): with t_g = t_0 + g h the difference t_(I0+a) - t_(J0+b) of element (a, b) of tile (I, J)
+// is (128 (I - J) + a - b) h: a function of the block lag I - J and of a - b alone — 255 distinct values per tile, the same
+// for every tile of a block diagonal.  k_lag_tables evaluates every stationary leaf of every particle ONCE per sweep at
+// the lags g = 128 bl + d (bl = 0..nt-1, d = -127..127) — on the stored time points, dt = t_|g| - t_0, with exactly the
+// arithmetic of the general path (src/GP.jl:241-245, 285-289, 331-336) — and a tile copies the 2 KiB table of its block lag
+// into LDS; its 16 384 elements read the leaf from there: one LDS access instead of 40-90 fp64 instructions, and no
+// transcendental code in the factorisation kernels at all.  An element's own t_i - t_j differs from the table's
+// representative only by rounding (agp_set_data admits a grid only when every point sits within 16 ulp of t_0 + g h).
+// Lags beyond the data (g >= n) only occur in padding rows, which cov_finalize overwrites.
 template <bool LAG = false, typename OpT>
 __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, const uint8_t* __restrict__ code,
                                              int ti, int tj, const ProgHdr& h,
                                              const OpT* __restrict__ ops, const double* __restrict__ prm,
-                                             double* tpt, double* sig, int tid) {
+                                             double* tpt, double* sig, int tid,
+                                             const double* __restrict__ lagtab = nullptr, int nt = 0) {
   const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
   tpt[tid] = tt[g];
   __syncthreads();
@@ -114,7 +93,10 @@ __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, cons
     __syncthreads();
   }
   if (LAG && h.n_lag > 0) {
-    lag_tables(h.n_ops, ops, prm, tpt, sig + h.n_cp * 256, tid);
+    // this tile's lag tables: block lag ti - tj of every OP_LAG_* leaf, 2 KiB each, built once per sweep by k_lag_tables
+    double* lag = sig + h.n_cp * 256;
+    const double* __restrict__ src = lagtab + ((long long)h.lag_off * nt + (ti - tj)) * 256 + tid;
+    for (int li = 0; li < h.n_lag; ++li) lag[li * 256 + tid] = src[(long long)li * nt * 256];
     __syncthreads();
   }
 }
@@ -278,7 +260,7 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
   const double* __restrict__ prm = a.prm + h.prm_off;
   double* etab = sig + (h.n_cp + h.n_lag) * 256;      // [128] exp table (launch_cov sizes the dynamic LDS for it)
   if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
-  cov_prologue<true>(a.tt, a.code, ti, tj, h, ops, prm, tpt, sig, tid);
+  cov_prologue<true>(a.tt, a.code, ti, tj, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt);
   const double* lag = sig + h.n_cp * 256;
 
   const int rp = tid & 63;        // row pair: rows 2rp, 2rp+1
@@ -324,6 +306,41 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
       o2.y = cov_finalize(out[2 * cc + 1], gi0 + 1, gj, a.n1, a.n1_pad, a.m2, noise);
       *reinterpret_cast<d2*>(T + (long long)(c0 + cc) * NB + r0) = o2;
     }
+  }
+}
+
+// The lag tables of a sweep on a sorted regular grid (see cov_prologue): block (bl, p) evaluates the stationary leaves of
+// particle p at the 255 lags 128 bl + d, d = -127 .. 127 (entry d + 127; entry 255 unused).
+struct LagArgs {
+  const double* tt;      // sorted time points
+  const ProgHdr* hdr;
+  const uint8_t* ops;
+  const double* prm;
+  double* tab;           // [table][nt][256]
+  int nt, P;
+};
+__global__ __launch_bounds__(256) void k_lag_tables(LagArgs a) {
+  const int p = blockIdx.y, bl = blockIdx.x, tid = threadIdx.x;
+  const ProgHdr h = a.hdr[p];
+  if (h.n_lag == 0) return;
+  const uint8_t* __restrict__ ops = a.ops + h.op_off;
+  const double* __restrict__ prm = a.prm + h.prm_off;
+  int g = bl * NB + tid - (NB - 1);
+  if (g < 0) g = -g;                                  // stationary leaves are even in dt
+  const double dx = (tid >= 2 * NB - 1 || g >= a.nt * NB) ? 0.0 : a.tt[g] - a.tt[0];
+  int q = 0, li = 0;
+  for (int ip = 0; ip < h.n_ops; ++ip) {
+    const int o = (int)ops[ip];
+    if (o >= OP_LAG_SE) {
+      const double p0 = prm[q], p1 = prm[q + 1], p2 = prm[q + 2];
+      double arg, amp;
+      if (o == OP_LAG_SE) { arg = ((-0.5 * dx) * dx) * p0; amp = p1; }                       // p0 = 1/l^2
+      else if (o == OP_LAG_GE) { arg = -fm::pow_f(fabs(dx) * p0, p1); amp = p2; }            // p0 = 1/l, p1 = gamma
+      else { arg = p0 * fm::sin2_f(p1 * fabs(dx)); amp = p2; }                              // p0 = -2/l^2, p1 = pi/p
+      a.tab[((long long)(h.lag_off + li) * a.nt + bl) * 256 + tid] = amp * fm::exp_f(arg);
+      ++li;
+    }
+    q += prm_count(o);
   }
 }
 

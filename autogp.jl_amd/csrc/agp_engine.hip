@@ -67,7 +67,7 @@ struct Slot {
   HostBuf h_stage, h_out;   // its pinned source, and the pinned landing zone of [logpdf | info]
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
-      Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq;
+      Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq, lagtab;
   std::vector<hipEvent_t> events;
   std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
   std::vector<hipEvent_t> sub_ev;     // fork / join events
@@ -82,7 +82,7 @@ struct Slot {
     if (done) { (void)hipEventDestroy(done); done = nullptr; }
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
-                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq})
+                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab})
       b->release();
     stage.release(); h_stage.release(); h_out.release(); h_async_info.release();
     for (auto e : events) (void)hipEventDestroy(e);
@@ -141,6 +141,9 @@ struct agp_ctx {
   // duration of the short launches; such particles get their tiles from k_cov_tiles.  env AGP_FUSE_MAX_US
   double fuse_max_us = 25.0;     // (priced with the per-leaf costs of compile_batch, which predate exp_t: 25 vs 35: 29.28 vs 29.6 ms at 512 particles)
   double flow_fuse_max_us = 70.0;   // the same limit under the dataflow schedule; env AGP_FLOW_FUSE_MAX_US
+  double lag_fuse_max_us = 8.0;     // ... and for the per-column launches of a lag-table sweep (programs are priced at ~2 us per leaf there:
+                                    // up to three leaves are evaluated in-kernel; measured 4 / 6 / 8 / 10 / 15 / 25 / 40 us: 27.78 / 27.77 / 27.78 /
+                                    // 27.81 / 27.91 / 28.26 / 29.26 ms per 512-particle sweep); env AGP_LAG_FUSE_MAX_US
   int dedup = 1;        // evaluate identical particles of a host-output sweep once; env AGP_DEDUP
   int64_t n_particles_seen = 0, n_particles_run = 0;
   int trtri_chain = 1;  // Z = L^-T as independent per-row chains in one launch (0: one launch per block column); env AGP_TRTRI_CHAIN
@@ -441,6 +444,7 @@ struct Batch {
   int max_cp = 0;
   int max_depth = 1;
   int max_cp_fused = 0, max_depth_fused = 1;
+  int n_lag_tables = 0;           // OP_LAG_* leaves of the whole batch (one table set each, k_lag_tables)
   // gradient programs (sorted order), built on request
   std::vector<GProgHdr> ghdr;
   std::vector<uint8_t> gops, glc, grc;
@@ -458,7 +462,7 @@ double op_cost_us(int op) {
     case OP_SE: return 7.0;
     case OP_LIN: return 2.0;
     case OP_CP: case OP_CP_SWAP: return 2.0;
-    case OP_LAG_SE: case OP_LAG_GE: case OP_LAG_PER: return 1.0;      // one LDS read per element (+ 255 leaf evaluations per tile)
+    case OP_LAG_SE: case OP_LAG_GE: case OP_LAG_PER: return 2.0;      // one LDS read per element: what is left is the interpreter's per-node latency (as for Linear)
     default: return 0.6;
   }
 }
@@ -504,13 +508,14 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   const bool fuse_on = c->fuse_mode == 1 || (c->fuse_mode < 0 && (P >= 256 || fuse_hint));
   // (the dataflow schedule has no launch tail for a long evaluation to hold up: its limit is higher — measured 35 / 70 /
   // 150 / 1000 us: config 2 0.99 / 0.92 / 0.92 / 0.91 ms, 2048 x 64 4.47 / 4.45 / 4.61 / 4.62 ms, config 4 62.9 / 61.9 / 63.6 / 63.6 ms)
-  const double fuse_limit = flow_limit ? std::max(c->fuse_max_us, c->flow_fuse_max_us) : c->fuse_max_us;
-  // (a lag sweep fuses every program whose tables fit the aliased LDS of the factorisation kernels: its evaluation costs next
-  // to nothing; one that carries direct stationary leaves there — see compile_program — must be prebuilt: the GM = 2
-  // instantiations have no transcendental code)
+  const double fuse_limit = flow_limit ? std::max(c->fuse_max_us, c->flow_fuse_max_us) : (lag ? std::min(c->fuse_max_us, c->lag_fuse_max_us) : c->fuse_max_us);
+  // (lag sweeps: the same price limit with the lag leaves' price — a 30-leaf tree still costs ~80 us per tile in interpreter
+  // latency, measured: fusing everything made every diagonal-tile launch wait 110 us for the largest tree and forced the
+  // depth-8 instantiation on the whole batch, 29.4 -> 31.0 ms per 512-particle sweep; a program that carries direct
+  // stationary leaves there — see compile_program — must be prebuilt: the GM = 2 instantiations have no transcendental code)
   auto lag_ok = [&](int p) { bool direct = false; for (uint8_t o : cps[p].ops) direct |= (o == OP_SE || o == OP_GE || o == OP_PER || o == OP_GE_TAB); return !direct; };
   auto fusable = [&](int p) {
-    if (lag) return fuse_on && lag_ok(p) && cps[p].n_cp + cps[p].n_lag <= U_MAX_CP;
+    if (lag) return fuse_on && cost[p] <= fuse_limit && lag_ok(p) && cps[p].n_cp + cps[p].n_lag <= U_MAX_CP;
     return fuse_on && cost[p] <= fuse_limit && cps[p].n_cp <= U_MAX_CP;
   };
   bt.order.resize(P);
@@ -530,7 +535,8 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
     h.n_cp = cp.n_cp;
     h.n_prm = (int32_t)cp.prm.size();
     h.flags = cp.uses_tab ? 1 : 0;
-    h.n_lag = cp.n_lag; h.pad_ = 0;
+    h.n_lag = cp.n_lag; h.lag_off = bt.n_lag_tables;
+    bt.n_lag_tables += cp.n_lag;
     bt.hdr[q] = h;
     bt.ops.insert(bt.ops.end(), cp.ops.begin(), cp.ops.end());
     bt.prm.insert(bt.prm.end(), cp.prm.begin(), cp.prm.end());
@@ -633,6 +639,7 @@ inline void launch_diag(int dcov, int Pg8, hipStream_t st, const CholArgs& ca) {
 inline void set_cov(CholArgs& ca, const CovArgs& cv) {
   ca.tt = cv.tt; ca.n1 = cv.n1; ca.n1_pad = cv.n1_pad; ca.m2 = cv.m2;
   ca.hdr = cv.hdr; ca.ops = cv.ops; ca.prm = cv.prm; ca.noise = cv.noise; ca.code = cv.code; ca.logdt = cv.logdt;
+  ca.lagtab = cv.lagtab;
 }
 
 struct Prof {
@@ -1053,6 +1060,14 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       HIPCHK(c, hipMemcpyAsync(s->goff.p, goff_sorted.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
       HIPCHK(c, hipStreamSynchronize(st));     // goff_sorted is a local
     }
+    if (lag && bt.n_lag_tables > 0) {
+      // the sweep's lag tables: every stationary leaf of every particle at the 255 lags of each of the nt block diagonals
+      HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * nt * 256));
+      LagArgs la = {};
+      la.tt = c->d_ts_s; la.hdr = d_hdr; la.ops = d_ops; la.prm = d_prm; la.tab = s->lagtab.as<double>(); la.nt = nt; la.P = P;
+      hipLaunchKernelGGL(k_lag_tables, dim3(nt, P), dim3(256), 0, st, la);
+      HIPCHK(c, hipGetLastError());
+    }
     size_t ev_h2d = pf.mark();
     pf.span(7, ev_begin, ev_h2d);
 
@@ -1086,6 +1101,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         cv.hdr = d_hdr + p0 + g0; cv.ops = d_ops; cv.prm = d_prm;
         cv.noise = d_noise + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
         cv.strideA = strideA; cv.P = Pg; cv.logdt = (ge_tab && !lag) ? c->d_logdt : nullptr;
+        cv.lagtab = lag ? s->lagtab.as<double>() : nullptr;
         int i0min = 0;
         if (n_hit > 0) {
           // resident factors: forward-solve vector and partials are copied out of the store; L and the inverse blocks
@@ -1388,6 +1404,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
   if (const char* e = getenv("AGP_FUSE_MAX_US")) { c->fuse_max_us = atof(e); c->flow_fuse_max_us = std::min(c->flow_fuse_max_us, c->fuse_max_us); }
   if (const char* e = getenv("AGP_FLOW_FUSE_MAX_US")) c->flow_fuse_max_us = atof(e);
+  if (const char* e = getenv("AGP_LAG_FUSE_MAX_US")) c->lag_fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LDS_TAPE")) c->grad_lds_tape = atoi(e) != 0;
   if (const char* e = getenv("AGP_PREDICT_REUSE")) c->predict_reuse = atoi(e) != 0;

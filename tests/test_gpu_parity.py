@@ -603,7 +603,10 @@ def test_resampled_population_is_evaluated_once(pkg, engine):
             assert abs(lp[i] - lpo) <= LP_TOL * max(1.0, abs(lpo))
     lpg, grads, gn, ginfo = engine.logpdf_grad_batch(pop, pnz, check=False)
     rlp, rgrads, rgn, _ = engine.logpdf_grad_batch(nodes, noises, check=False)
-    assert np.array_equal(lpg, lp)
+    # (the value sweep of this regularly spaced series runs on the sorted copy with lag tables, the gradient sweep in the
+    # caller's order: equal to rounding, not bit for bit)
+    okg = (ginfo == 0) & (info == 0)
+    assert np.array_equal(ginfo == 0, info == 0) and lp_err(lpg[okg], lp[okg]).max() <= 1e-11
     for j, i in enumerate(idx):
         assert np.array_equal(grads[j], rgrads[i]) and gn[j] == rgn[i]
 
@@ -735,7 +738,8 @@ def test_coalescing_of_single_particle_gradient_callers(pkg, engine):
             lp, g, gn = out[i]
             if not cache:
                 assert lp == ref[0][i] and gn == ref[2][i] and np.array_equal(g, ref[1][i])
-                assert out[24 + i] == ref[0][i]
+                # (value-only callers of a regular grid take the sorted lag-table sweep: equal to rounding)
+                assert abs(out[24 + i] - ref[0][i]) <= 1e-11 * max(1.0, abs(ref[0][i]))
             else:
                 assert abs(lp - ref[0][i]) <= 1e-12 * max(1.0, abs(ref[0][i])) and abs(gn - ref[2][i]) <= 1e-9 * max(1.0, abs(ref[2][i]))
                 assert np.all(np.abs(g - ref[1][i]) <= 1e-9 * np.maximum(1.0, np.abs(ref[1][i])))

@@ -40,3 +40,18 @@ for k in range(nt):
     m = tk == k
     d = m & (ti == tk); sd = m & (ti != tk)
     print(f"  k={k:2d} {st[m].min():8.0f} {en[m].max():8.0f}   diag {np.mean(en[d]-st[d]):7.1f}  sub {np.mean(en[sd]-st[sd]) if sd.any() else 0:7.1f}   wait diag {wait[d].mean():6.1f} sub {wait[sd].mean() if sd.any() else 0:6.1f}")
+# gaps between consecutive items of one workgroup (ticket + loop overhead), and the fixed part of an item by linear fit
+gaps = []
+for w in np.unique(wg):
+    m = np.flatnonzero(wg == w)
+    o = m[np.argsort(st[m])]
+    gaps += list(st[o[1:]] - en[o[:-1]])
+gaps = np.array(gaps)
+print(f"gap between consecutive items of a workgroup: mean {gaps.mean():.2f} us, median {np.median(gaps):.2f}, p90 {np.percentile(gaps, 90):.2f}")
+ks = np.arange(1, nt)
+for name, sel in (("diag", ti == tk), ("sub", ti != tk)):
+    dur = np.array([np.mean((en - st - wait)[sel & (tk == k)]) for k in ks if (sel & (tk == k)).any()])
+    kk = np.array([k for k in ks if (sel & (tk == k)).any()])
+    if len(kk) > 2:
+        a, b = np.polyfit(kk, dur, 1)
+        print(f"{name} items (waits excluded): {b:.1f} us + {a:.2f} us per 128-deep K-block")
