@@ -74,7 +74,25 @@ struct CholArgs {
   int flow_order;       // 0: sub-diagonal tiles of a block column tile-row-major (all particles' (k+1,k) first), 1: particle-major
   int lag;              // 1: sorted regular grid, the fused programs' stationary leaves are OP_LAG_* (GM = 2 instantiations)
   const double* lagtab; // ... and their tables (k_lag_tables)
+  // Dataflow schedule with a host-built work list and EARLY PARTIAL SUMS (plain sweeps; see k_chol_flow): the K-loops of
+  // the tiles of the last part_tb tile rows x columns are cut into chunks of part_ch block columns that are queued in the
+  // middle of the kernel — as soon as their operands exist — and leave their sums in `part`; the tile's own item then only
+  // multiplies the block columns behind the last chunk and adds the partial sums in chunk order (deterministic).
+  const int4* items;    // work list: per XCD items_stride entries {kind | chunk << 8, local particle, tile row, block column}
+  int items_stride;
+  const int* n_items;   // [8] entries per XCD
+  double* part;         // [storage idx][part_slots][PART_DOUBLES]
+  int* pflag;           // [storage idx][part_slots], zeroed per sweep
+  int part_slots, part_tb, part_ch, part_nch;
+  // per item (set by k_chol_flow): first block column of the item's own K-loop, partial sums to add, producer mode + chunk
+  int jstart, npart, part_mode, part_chunk;
 };
+constexpr int PART_DOUBLES = NB2 + NB;       // a partial tile + the partial forward-solve vector of a diagonal tile
+// slot of the partial sum of trailing tile (ti, tk), chunk c
+__device__ __forceinline__ int part_slot(const CholArgs& a, int ti, int tk, int c) {
+  const int r0 = a.nt - a.part_tb;
+  return ((ti - r0) * (ti - r0 + 1) / 2 + (tk - r0)) * a.part_nch + c;
+}
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -381,13 +399,14 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
 
   // Accumulators hold -C(i,k) throughout: they start at -A(i,k), the K-loop adds L(i,j) L(k,j)^T.
   // Fused particles evaluate A(i,k) from their kernel program straight into the accumulator layout
-  // (4 elements per interpreter pass: one row, four columns) — the tile is never read from HBM and
-  // this fp64-VALU phase shares the CU with the co-resident workgroup's MFMA phase.  Particles with
+  // (4 elements per interpreter pass: one row, four columns) — the tile is never read from HBM (the
+  // fp64-VALU work is paid in full, it does not hide under the co-resident workgroup's MFMAs).  Particles with
   // prebuilt tiles (DCOV == 0, or the expensive tail of a hybrid batch) start from zero and subtract
   // the stored tile after the loop.
   double* __restrict__ Tt = Ap + tile_off(ti, tk);
   d4 acc[NSB][2];
-  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused);
+  const bool producer = FLOW && a.part_mode != 0;        // early partial sum of a trailing tile: no evaluation, no solve
+  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused) || producer;
   // Every tile of a per-column launch has the same K-loop length, so the two workgroups of a CU run in step: both evaluate
   // (fp64 VALU, MFMA pipe idle), then both multiply.  Workgroups of the second half of each 512-block wave therefore evaluate
   // their tile AFTER the K-loop (accumulators start at zero, -A(i,k) is added at the end): one workgroup's VALU phase falls
@@ -471,7 +490,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
   constexpr int SLABS_PER_TILE = NB / KS;
   constexpr int SLAB_DOUBLES = KS * LDS_STRIDE;
   static_assert(4 * SLAB_DOUBLES <= U_MAIN_DOUBLES, "slab buffers");
-  const int jfirst = FACTOR ? 0 : a.j0;          // first block column of the sum
+  const int jfirst = FACTOR ? (FLOW ? a.jstart : 0) : a.j0;          // first block column of the sum
   const int nslab = (AGP_DBG_SKIP & 4) ? 0 : (jmax - jfirst) * SLABS_PER_TILE;
   if (nslab > 0) {
     // column operand: 256 threads stage the slab of tile (k,j), NU x 16 B each (element 2*(tid+256u));
@@ -583,6 +602,48 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
   }
 
   if (post_eval) run_eval(std::true_type{});      // (its leading barrier comes after the K-loop's last one: the slab buffers are free)
+  if (FLOW && producer) {
+    // partial sum + sum_{j in chunk} L(i,j) L(k,j)^T -> its slot; release; raise the slot's flag
+    double* __restrict__ Pt = a.part + ((long long)ps * a.part_slots + part_slot(a, ti, tk, a.part_chunk)) * PART_DOUBLES;
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st_pair<ADJ>(Pt, cb * 16 + 4 * r + lq, row0, row1, acc[cb][0][r], acc[cb][1][r]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a.pflag + (long long)ps * a.part_slots + part_slot(a, ti, tk, a.part_chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  if (FLOW && a.npart > 0) {
+    // the early partial sums of this tile, in chunk order
+    if (tid == 0) {
+      const int* pf = a.pflag + (long long)ps * a.part_slots + part_slot(a, ti, tk, 0);
+      bool ok = true;
+      for (int c = 0; c < a.npart; ++c) ok = flow_wait(pf + c) && ok;
+      if (!ok) a.info[ps] = -7;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    for (int c = 0; c < a.npart; ++c) {
+      const double* __restrict__ Pt = a.part + ((long long)ps * a.part_slots + part_slot(a, ti, tk, c)) * PART_DOUBLES;
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const d2 t2 = ld_pair<ADJ>(Pt, cb * 16 + 4 * r + lq, row0, row1);
+          acc[cb][0][r] += t2.x;
+          acc[cb][1][r] += t2.y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
   if (prebuilt) {
     // resident tile: bring the accumulators to the same -C representation (one column block at a
     // time — the scheduling fence stops the compiler from hoisting all 64 loads, which would spill)
@@ -791,7 +852,9 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
   double* xv = avec + 128;     // [2][32]
   double* Wl = xv + 64;        // [256]
   constexpr int NE = NSB + 1;  // accumulator blocks per wave
-  const int jmax = a.rl ? 0 : a.k;
+  const bool producer = FLOW && a.part_mode != 0;        // early partial sum (see CholArgs::items): no evaluation, no factorisation
+  const int jfirst = producer ? a.part_chunk * a.part_ch : (FLOW ? a.jstart : 0);
+  const int jmax = producer ? jfirst + a.part_ch : (a.rl ? 0 : a.k);
   const int l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   const int wu = __builtin_amdgcn_readfirstlane(w);
   const int row0 = 16 * w + l15, row1 = 16 * (NSB - 1 - w) + l15;
@@ -805,7 +868,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
   double* vecp = a.vec + (long long)ps * a.ldv;
   double* __restrict__ Tt = Ap + tile_off(tk, tk);
   d4 acc[NE];
-  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused);
+  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused) || producer;
   if (!prebuilt) {
     const ProgHdr h = a.hdr[p];
     double* tpt = sm;
@@ -865,20 +928,20 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
   }
 
   double rv = 0.0;
-  if (tid < NB) rv = vecp[tk * NB + tid];
+  if (tid < NB && !producer) rv = vecp[tk * NB + tid];
 
   constexpr int KS = 2 * KB;                      // 32-column slabs
   constexpr int NU = KS / 4;
   constexpr int SLABS_PER_TILE = NB / KS;
   constexpr int SLAB_DOUBLES = KS * LDS_STRIDE;
   static_assert(2 * SLAB_DOUBLES <= U_MAIN_DOUBLES, "slab buffers");
-  const int nslab = jmax * SLABS_PER_TILE;
+  const int nslab = (jmax - jfirst) * SLABS_PER_TILE;
   if (nslab > 0) {
     const int scol0 = tid >> 6, srow = 2 * (tid & 63);
     d2 rb[NU];
     double rx = 0.0;
     auto gload = [&](int s) {
-      const int j = s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
+      const int j = jfirst + s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
       const double* __restrict__ src = Ap + tile_off(tk, j) + (long long)cs * NB;
 #pragma unroll
       for (int u = 0; u < NU; ++u) rb[u] = *reinterpret_cast<const d2*>(src + (scol0 + 4 * u) * NB + srow);
@@ -901,7 +964,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
     d2 rb2[NU];
     double rx2 = 0.0;
     auto gload2 = [&](int s) {
-      const int j = s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
+      const int j = jfirst + s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
       const double* __restrict__ src = Ap + tile_off(tk, j) + (long long)cs * NB;
 #pragma unroll
       for (int u = 0; u < NU; ++u) rb2[u] = *reinterpret_cast<const d2*>(src + (scol0 + 4 * u) * NB + srow);
@@ -948,7 +1011,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
       if (tid == 0) {
         probe = __hip_atomic_load(a.tflag + (long long)ps * a.ntri + tri_idx(tk, jmax - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
         if (probe) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        else flow_ready(0);
+        else flow_ready(jfirst);
       }
       all_ready = __syncthreads_or(probe);
     }
@@ -965,11 +1028,52 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
       if (s + 3 < nslab) gload2(s + 3);
       slab(1);
       if (s + 2 < nslab) lstore(0);
-      if (FLOW && !all_ready && tid == 0 && s + 4 < nslab && (s + 4) % SLABS_PER_TILE == 0) flow_ready((s + 4) / SLABS_PER_TILE);
+      if (FLOW && !all_ready && tid == 0 && s + 4 < nslab && (s + 4) % SLABS_PER_TILE == 0) flow_ready(jfirst + (s + 4) / SLABS_PER_TILE);
       __syncthreads();
     }
   }
 
+  if (FLOW && producer) {
+    // partial sums (lower block triangle in tile layout, then the forward-solve vector's share) -> slot; release; flag
+    double* __restrict__ Pt = a.part + ((long long)ps * a.part_slots + part_slot(a, tk, tk, a.part_chunk)) * PART_DOUBLES;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int rw = st1[e] ? row1 : row0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pt[(cbe[e] * 16 + 4 * r + lq) * NB + rw] = acc[e][r];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tid < NB) Pt[NB2 + tid] = rv;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a.pflag + (long long)ps * a.part_slots + part_slot(a, tk, tk, a.part_chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  if (FLOW && a.npart > 0) {
+    if (tid == 0) {
+      const int* pf = a.pflag + (long long)ps * a.part_slots + part_slot(a, tk, tk, 0);
+      bool ok = true;
+      for (int c = 0; c < a.npart; ++c) ok = flow_wait(pf + c) && ok;
+      if (!ok) a.info[ps] = -7;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    for (int c = 0; c < a.npart; ++c) {
+      const double* __restrict__ Pt = a.part + ((long long)ps * a.part_slots + part_slot(a, tk, tk, c)) * PART_DOUBLES;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int rw = st1[e] ? row1 : row0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[e][r] += Pt[(cbe[e] * 16 + 4 * r + lq) * NB + rw];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tid < NB) rv += Pt[NB2 + tid];
+    }
+  }
   if (prebuilt) {
     // resident tile: bring the accumulators to the -C representation
 #pragma unroll
@@ -1024,7 +1128,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
   const int Pl = (a0.P - xcd + 7) / 8;          // particles pl*8 + xcd < P
   const int nt = a0.nt;
   const int nfac = a0.nt1;                       // block columns to factor: nt in a logpdf sweep, the training block in prediction
-  const int total = Pl * (nfac * nt - nfac * (nfac - 1) / 2);
+  const bool listed = a0.items != nullptr;       // host-built work list (plain sweeps with early partial sums)
+  const int total = listed ? a0.n_items[xcd] : Pl * (nfac * nt - nfac * (nfac - 1) / 2);
   // (Drawing the NEXT ticket early, to hide the atomic's latency behind the current tile, was measured: a drawn-but-not-
   // started item delays its consumers by the rest of the current item — 4 % slower at 64 particles, neutral at 512.)
   for (;;) {
@@ -1034,7 +1139,13 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
     const int item = __builtin_amdgcn_readfirstlane(s_item);      // wave-uniform: keeps the tile indices scalar
     if (item >= total) return;
     int k = 0, rem = item, pl, tl;
-    if (a0.flow_order == 2 && nfac == nt) {
+    int kind = 0, chunk = 0;
+    if (listed) {
+      const int4 it = a0.items[(long long)xcd * a0.items_stride + item];
+      kind = __builtin_amdgcn_readfirstlane(it.x & 255); chunk = __builtin_amdgcn_readfirstlane(it.x >> 8);
+      pl = __builtin_amdgcn_readfirstlane(it.y);
+      k = __builtin_amdgcn_readfirstlane(it.w); tl = __builtin_amdgcn_readfirstlane(it.z) - k;
+    } else if (a0.flow_order == 2 && nfac == nt) {
       // Look-ahead order: after the diagonal tiles of column 0, "super-column" k = the (k+1,k) tiles of every particle,
       // then the diagonal tiles of column k+1 (their last operand is that tile), then the rest of column k.  The
       // factorisation of L(k+1,k+1) is thus issued a whole column of tiles before anything needs it: the panel solves
@@ -1066,6 +1177,13 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
     const int ps = a0.slot != nullptr ? a0.slot[p] : p;
     CholArgs a = a0;
     a.k = k;
+    if (listed) {
+      // kinds: 0 diagonal tile, 1 sub-diagonal tile, 2 / 3 early partial sum of a trailing diagonal / sub-diagonal tile
+      const bool trailing = k >= nt - a0.part_tb;
+      a.part_mode = kind >= 2 ? 1 : 0; a.part_chunk = chunk;
+      a.npart = (kind < 2 && trailing) ? a0.part_nch : 0;
+      a.jstart = (kind < 2 && trailing) ? a0.part_nch * a0.part_ch : (kind >= 2 ? chunk * a0.part_ch : 0);
+    }
     const long long t_start = a0.trace ? (long long)wall_clock64() : 0;
     if (a0.trace && threadIdx.x == 0) s_wait = 0.0;
     // the lane index is made opaque per item: otherwise every lane-dependent offset of every phase of the tile body is
@@ -1076,16 +1194,17 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
     // solve) of the split per-column launches
     if (AGP_CHAIN_PRIO) { if (tl <= 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
     if (tl == 0) chol_diag_tile<DCOV, GM, true>(a, p, ps, k, sm, tid, &s_wait);
-    else chol_tile<true, DCOV, true, 2, GM, true>(a, p, ps, k + tl, k, k, false, sm, tid, &s_wait);
+    else chol_tile<true, DCOV, true, 2, GM, true>(a, p, ps, k + tl, k, (listed && kind >= 2) ? (chunk + 1) * a0.part_ch : k, false, sm, tid, &s_wait);
     if (AGP_CHAIN_PRIO) __builtin_amdgcn_s_setprio(0);
     if (a0.trace && threadIdx.x == 0) {
       // record of this item: [start, end, K-loop wait ticks, (xcd, particle, tile row, block column)]
-      int gi = item;
-      for (int x = 0; x < xcd; ++x) gi += ((a0.P - x + 7) / 8) * (nfac * nt - nfac * (nfac - 1) / 2);
-      long long* r = a0.trace + 4 * (long long)gi;
+      long long gi = item;
+      if (listed) gi += (long long)xcd * a0.items_stride;
+      else for (int x = 0; x < xcd; ++x) gi += ((a0.P - x + 7) / 8) * (nfac * nt - nfac * (nfac - 1) / 2);
+      long long* r = a0.trace + 4 * gi;
       r[0] = t_start; r[1] = (long long)wall_clock64();
       r[2] = (long long)s_wait;
-      r[3] = ((long long)blockIdx.x << 48) | ((long long)p << 24) | ((long long)(k + tl) << 12) | k;
+      r[3] = ((long long)blockIdx.x << 48) | ((long long)kind << 44) | ((long long)p << 24) | ((long long)(k + tl) << 12) | k;
     }
   }
 }

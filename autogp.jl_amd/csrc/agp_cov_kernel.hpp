@@ -11,9 +11,11 @@
 // Two users:
 //   * k_cov_tiles   — stand-alone tile builder (block column 0 of a factorisation, agp_cov_matrix);
 //                     4 elements per lane and pass at 4 waves/SIMD, 16 B stores, 1 KiB contiguous per wave instruction.
-//   * k_chol_update — evaluates its own tile straight into the MFMA accumulators (4 elements per
-//                     pass in the accumulator layout), so K never round-trips through HBM and the
-//                     fp64 transcendental work overlaps the co-resident workgroup's MFMA phase.
+//   * k_chol_update / k_chol_diag / k_chol_flow — evaluate their own tile straight into the MFMA accumulators (4
+//                     elements per pass in the accumulator layout), so K never round-trips through HBM.  The fp64 VALU
+//                     work is NOT hidden under the co-resident workgroup's MFMA phase (vector and matrix fp64 share the
+//                     issue rate on gfx950: measured, NOTES_dead_ends.md), so only cheap programs are evaluated there
+//                     (host price list, compile_batch) — and on regular time grids the leaves come from lag tables.
 #pragma once
 #ifndef AGP_EXP_TABLE
 #define AGP_EXP_TABLE 1

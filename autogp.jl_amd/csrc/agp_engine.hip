@@ -67,7 +67,10 @@ struct Slot {
   HostBuf h_stage, h_out;   // its pinned source, and the pinned landing zone of [logpdf | info]
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
-      Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq, lagtab;
+      Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq, lagtab,
+      flowlist, flowpart, flowpflag;
+  long long flowlist_key = -1;        // (P, nt, order, tb, ch) the device-resident work list was built for
+  int flowlist_stride = 0;
   std::vector<hipEvent_t> events;
   std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
   std::vector<hipEvent_t> sub_ev;     // fork / join events
@@ -82,7 +85,7 @@ struct Slot {
     if (done) { (void)hipEventDestroy(done); done = nullptr; }
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
-                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab})
+                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab, &flowlist, &flowpart, &flowpflag})
       b->release();
     stage.release(); h_stage.release(); h_out.release(); h_async_info.release();
     for (auto e : events) (void)hipEventDestroy(e);
@@ -168,6 +171,9 @@ struct agp_ctx {
   long long* d_flow_trace = nullptr;   // agp_debug_flow_trace: 4 x int64 per work item of the next dataflow sweep
   size_t flow_trace_items = 0;
   int flow_fuse = 1;    // 1: dataflow sweeps evaluate tiles in-kernel like the large-population path; env AGP_FLOW_FUSE
+  // Early partial sums in the dataflow schedule (plain sweeps): the K-loops of the tiles of the last flow_part_tb tile rows
+  // are cut into chunks of flow_part_ch block columns queued mid-kernel (CholArgs::items); 0 disables.  env AGP_FLOW_PART_TB / _CH
+  int flow_part_tb = 4, flow_part_ch = 4;
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // [8..11]: gradient sweep: L^-T chain, K^-1 tiles, contraction, alpha + reduction
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
@@ -794,6 +800,37 @@ inline void launch_flow(int dcov, int n_wg, hipStream_t st, const CholArgs& ca) 
     else hipLaunchKernelGGL((k_chol_flow<8, 0>), grid, block, 0, st, ca);
   }
 }
+// Work list of a plain dataflow sweep with early partial sums (CholArgs::items): per XCD, block column by block column —
+// diagonal tiles, then the sub-diagonal tiles particle-major (order 1) or tile-row-major (order 0) — and behind the last
+// column of every chunk the partial-sum items of the trailing tiles for that chunk.  Every item's producers precede it.
+struct FlowItem { int32_t x, y, z, w; };
+static int build_flow_list(int P, int nt, int order, int tb, int ch, std::vector<FlowItem>& out, int counts[8]) {
+  const int r0 = nt - tb, nch = r0 / ch;
+  size_t stride = 0;
+  std::vector<std::vector<FlowItem>> per(8);
+  for (int x = 0; x < 8; ++x) {
+    const int Pl = (P - x + 7) / 8;
+    auto& v = per[x];
+    for (int k = 0; k < nt; ++k) {
+      for (int pl = 0; pl < Pl; ++pl) v.push_back({0, pl, k, k});
+      if (order == 0) { for (int i = k + 1; i < nt; ++i) for (int pl = 0; pl < Pl; ++pl) v.push_back({1, pl, i, k}); }
+      else { for (int pl = 0; pl < Pl; ++pl) for (int i = k + 1; i < nt; ++i) v.push_back({1, pl, i, k}); }
+      if ((k + 1) % ch == 0 && (k + 1) / ch <= nch) {
+        const int c = (k + 1) / ch - 1;
+        // longest remaining K-loops first: the tiles of the last rows
+        for (int pl = 0; pl < Pl; ++pl)
+          for (int i = nt - 1; i >= r0; --i)
+            for (int kk = r0; kk <= i; ++kk) v.push_back({(i == kk ? 2 : 3) | (c << 8), pl, i, kk});
+      }
+    }
+    counts[x] = (int)v.size();
+    stride = std::max(stride, v.size());
+  }
+  out.assign(stride * 8, FlowItem{0, 0, 0, 0});
+  for (int x = 0; x < 8; ++x) std::copy(per[x].begin(), per[x].end(), out.begin() + (size_t)x * stride);
+  return (int)stride;
+}
+
 // Medium populations — more particles than the right-looking schedule serves, fewer than fill the GPU with the tiles
 // of one block column — take the dataflow schedule.
 // Measured on MI355X (tools/gpu_flow_perf.py, profiles/r02_flow_perf.txt): it beats the per-column launches (right-looking,
@@ -1158,6 +1195,30 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           else
             HIPCHK(c, hipMemsetAsync(ca.tflag, 0, sizeof(int) * (size_t)Pg * ntri, q));
           HIPCHK(c, hipMemsetAsync(ca.qnext, 0, sizeof(int) * 8, q));
+          // early partial sums for the trailing tile rows (plain sweeps, one stream, one chunk)
+          const int tb = c->flow_part_tb, chw = c->flow_part_ch;
+          if (n_hit == 0 && S == 1 && P <= chunk && tb > 0 && nt - tb >= chw) {
+            const int nch = (nt - tb) / chw, pslots = tb * (tb + 1) / 2 * nch;
+            const long long key = (((((long long)Pg * 4096 + nt) * 4 + c->flow_order) * 64 + tb) * 64 + chw);
+            if (s->flowlist_key != key) {
+              std::vector<FlowItem> list; int counts[8];
+              const int stride = build_flow_list(Pg, nt, c->flow_order == 0 ? 0 : 1, tb, chw, list, counts);
+              HIPCHK(c, s->flowlist.ensure(sizeof(FlowItem) * list.size() + 64));
+              HIPCHK(c, hipStreamSynchronize(q));            // (an earlier sweep may still read the old list)
+              HIPCHK(c, hipMemcpy(static_cast<char*>(s->flowlist.p) + 64, list.data(), sizeof(FlowItem) * list.size(), hipMemcpyHostToDevice));
+              HIPCHK(c, hipMemcpy(s->flowlist.p, counts, sizeof(int) * 8, hipMemcpyHostToDevice));
+              s->flowlist_key = key; s->flowlist_stride = stride;
+            }
+            HIPCHK(c, s->flowpart.ensure(sizeof(double) * (size_t)Pg * pslots * PART_DOUBLES));
+            HIPCHK(c, s->flowpflag.ensure(sizeof(int) * (size_t)Pg * pslots));
+            HIPCHK(c, hipMemsetAsync(s->flowpflag.p, 0, sizeof(int) * (size_t)Pg * pslots, q));
+            ca.n_items = s->flowlist.as<int>();
+            ca.items = reinterpret_cast<const int4*>(static_cast<char*>(s->flowlist.p) + 64);
+            ca.items_stride = s->flowlist_stride;
+            ca.part = s->flowpart.as<double>(); ca.pflag = s->flowpflag.as<int>();
+            ca.part_slots = pslots; ca.part_tb = tb; ca.part_ch = chw; ca.part_nch = nch;
+            if (ca.trace && (size_t)8 * s->flowlist_stride > c->flow_trace_items) ca.trace = nullptr;
+          }
           size_t f0 = pf.mark(q);
           launch_flow(dcov, 2 * c->n_cu, q, ca);
           size_t f1 = pf.mark(q);
@@ -1416,6 +1477,8 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_FLOW")) c->flow = atoi(e);
   if (const char* e = getenv("AGP_FLOW_ORDER")) c->flow_order = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("AGP_FLOW_FUSE")) c->flow_fuse = atoi(e) != 0;
+  if (const char* e = getenv("AGP_FLOW_PART_TB")) c->flow_part_tb = std::max(0, std::min(16, atoi(e)));
+  if (const char* e = getenv("AGP_FLOW_PART_CH")) c->flow_part_ch = std::max(1, std::min(64, atoi(e)));
   if (const char* e = getenv("AGP_EXTEND_FRAC")) c->store.max_frac = std::max(0.0, std::min(0.8, atof(e)));
   *out = c;
   return AGP_OK;

@@ -17,13 +17,15 @@ eng = pkg.GPEngine(0); eng.set_data(ts, xs)
 for _ in range(3):
     eng.logpdf_batch(None, noises, check=False, programs=progs)
 nt = (n + 127) // 128; ntri = nt * (nt + 1) // 2
-items = sum(((P - x + 7) // 8) * ntri for x in range(8))
+items = 2 * sum(((P - x + 7) // 8) * ntri for x in range(8))      # (room for the early partial-sum items of the work list)
 eng.flow_trace(True, items)
 eng.logpdf_batch(None, noises, check=False, programs=progs)
 tr = eng.flow_trace(False, items)
+tr = tr[tr[:, 1] > 0]                 # (unused records of the padded work list)
+items = len(tr)
 t0 = tr[:, 0].min(); us = 0.01
 st = (tr[:, 0] - t0) * us; en = (tr[:, 1] - t0) * us; wait = tr[:, 2] * us
-wg = tr[:, 3] >> 48; part = (tr[:, 3] >> 24) & 0xFFFFFF; ti = (tr[:, 3] >> 12) & 0xFFF; tk = tr[:, 3] & 0xFFF
+wg = tr[:, 3] >> 48; kind = (tr[:, 3] >> 44) & 0xF; part = (tr[:, 3] >> 24) & 0xFFFFF; ti = (tr[:, 3] >> 12) & 0xFFF; tk = tr[:, 3] & 0xFFF
 total = en.max()
 print(f"n={n} P={P}: {items} items, kernel span {total:.0f} us; busy (item time minus K-loop waits) summed over items {np.sum(en-st-wait)/1e3:.2f} ms, "
       f"waits {wait.sum()/1e3:.2f} ms, slots {len(np.unique(wg))}")
@@ -38,7 +40,7 @@ for b in range(nb):
 print("block column: first start, last end, mean item us (diag / sub), mean wait us")
 for k in range(nt):
     m = tk == k
-    d = m & (ti == tk); sd = m & (ti != tk)
+    d = m & (ti == tk) & (kind < 2); sd = m & (ti != tk) & (kind < 2)
     print(f"  k={k:2d} {st[m].min():8.0f} {en[m].max():8.0f}   diag {np.mean(en[d]-st[d]):7.1f}  sub {np.mean(en[sd]-st[sd]) if sd.any() else 0:7.1f}   wait diag {wait[d].mean():6.1f} sub {wait[sd].mean() if sd.any() else 0:6.1f}")
 # gaps between consecutive items of one workgroup (ticket + loop overhead), and the fixed part of an item by linear fit
 gaps = []
@@ -49,7 +51,10 @@ for w in np.unique(wg):
 gaps = np.array(gaps)
 print(f"gap between consecutive items of a workgroup: mean {gaps.mean():.2f} us, median {np.median(gaps):.2f}, p90 {np.percentile(gaps, 90):.2f}")
 ks = np.arange(1, nt)
-for name, sel in (("diag", ti == tk), ("sub", ti != tk)):
+if (kind >= 2).any():
+    pm = kind >= 2
+    print(f"early partial-sum items: {pm.sum()}, mean {np.mean((en - st)[pm]):.1f} us (waits {wait[pm].mean():.1f}), first start {st[pm].min():.0f}, last end {en[pm].max():.0f} us")
+for name, sel in (("diag", (ti == tk) & (kind < 2)), ("sub", (ti != tk) & (kind < 2))):
     dur = np.array([np.mean((en - st - wait)[sel & (tk == k)]) for k in ks if (sel & (tk == k)).any()])
     kk = np.array([k for k in ks if (sel & (tk == k)).any()])
     if len(kk) > 2:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # evidence pass: gpu tests, smoke, bench (with cpu baseline), rocprofv3 kernel stats, PMC passes, configs, schedules
 # usage (on the GPU box, from the repo root): bash tools/run_evidence.sh <tag>      -> gpurun_out/<tag>_*
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out
 (time python -m pytest tests -m gpu -q) > gpurun_out/${TAG}_pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_pytest_gpu.log
