@@ -74,24 +74,37 @@ struct CholArgs {
   int flow_order;       // 0: sub-diagonal tiles of a block column tile-row-major (all particles' (k+1,k) first), 1: particle-major
   int lag;              // 1: sorted regular grid, the fused programs' stationary leaves are OP_LAG_* (GM = 2 instantiations)
   const double* lagtab; // ... and their tables (k_lag_tables)
-  // Dataflow schedule with a host-built work list and EARLY PARTIAL SUMS (plain sweeps; see k_chol_flow): the K-loops of
-  // the tiles of the last part_tb tile rows x columns are cut into chunks of part_ch block columns that are queued in the
-  // middle of the kernel — as soon as their operands exist — and leave their sums in `part`; the tile's own item then only
-  // multiplies the block columns behind the last chunk and adds the partial sums in chunk order (deterministic).
+  // Dataflow schedule with a host-built work list and EARLY SUMS (plain sweeps; see k_chol_flow): the K-loops of the tiles
+  // in the last part_tb tile rows x columns are cut into part_nch chunks of part_ch block columns.  The chunks are queued in
+  // the middle of the kernel — right behind the last block column they read — and work IN PLACE on the tile's own storage:
+  // chunk 0 leaves A(i,k) - sum_{j in chunk 0} L(i,j) L(k,j)^T there (A evaluated in-kernel or read, as the particle has
+  // it), chunk c subtracts its sum from what chunk c-1 left, and the tile's own item treats the tile as resident and only
+  // multiplies the block columns behind the last chunk.  A diagonal tile's share of the forward-solve vector is carried in
+  // `vec` the same way.  pflag[storage idx][trailing tile] counts the chunks done (release / acquire like tflag).
+  // The sums are formed in a fixed order: results are reproducible run to run (but differ in rounding from a sweep
+  // without the chunks).
   const int4* items;    // work list: per XCD items_stride entries {kind | chunk << 8, local particle, tile row, block column}
   int items_stride;
   const int* n_items;   // [8] entries per XCD
-  double* part;         // [storage idx][part_slots][PART_DOUBLES]
-  int* pflag;           // [storage idx][part_slots], zeroed per sweep
-  int part_slots, part_tb, part_ch, part_nch;
-  // per item (set by k_chol_flow): first block column of the item's own K-loop, partial sums to add, producer mode + chunk
-  int jstart, npart, part_mode, part_chunk;
+  int* pflag;           // [storage idx][part_tiles], zeroed per sweep
+  int part_tiles, part_tb, part_ch, part_nch;
+  // per item (set by k_chol_flow): first block column of the item's own K-loop; chunk + 1 for an early-sum item (0: the
+  // tile's own item); early sums to wait for before the tile / vector is read (0: none)
+  int jstart, early, need;
 };
-constexpr int PART_DOUBLES = NB2 + NB;       // a partial tile + the partial forward-solve vector of a diagonal tile
-// slot of the partial sum of trailing tile (ti, tk), chunk c
-__device__ __forceinline__ int part_slot(const CholArgs& a, int ti, int tk, int c) {
+// index of trailing tile (ti, tk) in pflag
+__device__ __forceinline__ int part_tile(const CholArgs& a, int ti, int tk) {
   const int r0 = a.nt - a.part_tb;
-  return ((ti - r0) * (ti - r0 + 1) / 2 + (tk - r0)) * a.part_nch + c;
+  return (ti - r0) * (ti - r0 + 1) / 2 + (tk - r0);
+}
+// one lane: wait until a counter has reached `want` (bounded)
+__device__ __forceinline__ bool flow_wait_ge(const int* flag, int want) {
+  int spins = 0;
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1 << 24)) return false;
+  }
+  return true;
 }
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
@@ -170,6 +183,15 @@ constexpr bool XCD_PIN = AGP_XCD_PIN != 0;     // 1: all tiles of a particle on 
 #ifndef AGP_CHAIN_PRIO
 #define AGP_CHAIN_PRIO 0
 #endif
+// AGP_PHASE_PRIO: priority of a wave OUTSIDE its K-loop (tile evaluation, staging, panel solve, 128 x 128 factorisation, stores).
+// Those phases are latency-bound chains of LDS / global round trips with little arithmetic; at priority 0 beside a co-resident
+// workgroup whose MFMA blocks run at priority 1 they are starved of issue slots (flow trace r03j: 40-65 us from item start to
+// "accumulators ready" for a tile whose evaluation costs ~3 us, 10-50 us for staging 72 KB).  Raised above the MFMA blocks they
+// finish quickly and the workgroup returns to feeding the MFMA pipe.
+#ifndef AGP_PHASE_PRIO
+#define AGP_PHASE_PRIO 0
+#endif
+__device__ __forceinline__ void phase_prio() { if (AGP_PHASE_PRIO) __builtin_amdgcn_s_setprio(AGP_PHASE_PRIO); }
 __device__ __forceinline__ void mfma_prio_on(bool hi) {
   if ((AGP_PRIO_ASYM || AGP_CHAIN_PRIO) && hi) __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO ? 3 : 2);
   else __builtin_amdgcn_s_setprio(1);
@@ -197,7 +219,7 @@ __device__ __forceinline__ int sblk_idx(int jb, int lb) { return jb * (jb - 1) /
 template <bool INTRSM>
 __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int tk, double* __restrict__ Tt,
                                                  double* vecp, double* sm, double* rvec, double* avec, double* Wl,
-                                                 double rv, int tid) {
+                                                 double rv, int tid, long long* mark = nullptr) {
   const int l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   (void)lq;
   if (tid < NB) rvec[tid] = rv;
@@ -309,6 +331,7 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
     __syncthreads();
   }
 
+  if (mark && tid == 0) *mark = (long long)wall_clock64();
   // ---- write L(k,k) (upper part zero), alpha_k, partials, info ----
   for (int bi = 0; bi < NSB * NSB; ++bi) {
     const int rb = bi >> 3, cb = bi & 7;
@@ -361,6 +384,10 @@ __device__ __forceinline__ void st_pair(double* T, int col, int rowA, int rowB, 
   else { T[col * NB + rowA] = a0; T[col * NB + rowB] = a1; }
 }
 
+// agp_debug_flow_trace: per-item probe in LDS — ticks spent waiting on operand tiles and the times (lane 0) at which the item's
+// phases ended: [0] tile evaluated / accumulators ready, [1] K-loop done, [2] solve / factorisation inputs staged, [3] arithmetic done
+struct FlowProbe { double wait; long long ph[4]; };
+#define AGP_PROBE(i) do { if (a.trace && wait_acc && tid == 0) wait_acc->ph[i] = (long long)wall_clock64(); } while (0)
 // one lane: wait until a tile flag is raised (bounded), then acquire at agent scope
 __device__ __forceinline__ bool flow_wait(const int* flag) {
   int spins = 0;
@@ -380,9 +407,10 @@ __device__ __forceinline__ bool flow_wait(const int* flag) {
 template <bool FACTOR, int DCOV, bool INTRSM, int DM, int GM, bool FLOW>
 __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const int ps, const int ti, const int tk,
                                           const int jmax, const bool is_diag, double* sm, const int tid,
-                                          double* wait_acc = nullptr) {
+                                          FlowProbe* wait_acc = nullptr) {
   constexpr bool TAB = GM == 1, LAGM = GM == 2;
   constexpr bool ADJ = ILV;       // strips are adjacent rows
+  phase_prio();
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;
   double* xv = avec + 128;     // [2][slab depth <= 32]
@@ -405,8 +433,10 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
   // the stored tile after the loop.
   double* __restrict__ Tt = Ap + tile_off(ti, tk);
   d4 acc[NSB][2];
-  const bool producer = FLOW && a.part_mode != 0;        // early partial sum of a trailing tile: no evaluation, no solve
-  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused) || producer;
+  // early sums (CholArgs::items): an early-sum item stops after its chunk of the K-loop and leaves A - sums in the tile; chunks
+  // behind the first and the tile's own item find the tile resident
+  const bool producer = FLOW && a.early != 0;
+  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused) || (FLOW && a.need > 0);
   // Every tile of a per-column launch has the same K-loop length, so the two workgroups of a CU run in step: both evaluate
   // (fp64 VALU, MFMA pipe idle), then both multiply.  Workgroups of the second half of each 512-block wave therefore evaluate
   // their tile AFTER the K-loop (accumulators start at zero, -A(i,k) is added at the end): one workgroup's VALU phase falls
@@ -482,6 +512,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
 
   double rv = 0.0;
   if (is_diag && tid < NB) rv = vecp[tk * NB + tid];
+  if (FLOW) AGP_PROBE(0);
 
   // slab depth: 16 columns of the operand tiles per barrier; the diagonal-only kernel (fewer MFMAs per slab, no
   // row-operand registers) takes 32, which doubles the work and the prefetch distance per barrier
@@ -531,7 +562,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
       if (!is_diag) ok = flow_wait(tf + tri_idx(ti, j)) && ok;
       if (!ok) a.info[ps] = -7;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (a.trace && wait_acc) *wait_acc += (double)((long long)wall_clock64() - tw0);
+      if (a.trace && wait_acc) wait_acc->wait += (double)((long long)wall_clock64() - tw0);
     };
     // A tile of block column k-1 is final only after its own K-loop has consumed (acquired) every earlier column of
     // its tile row — so when (tk,k-1) and (ti,k-1) are already raised, every operand of this K-loop is final and
@@ -601,48 +632,16 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     }
   }
 
+  phase_prio();
+  if (FLOW) AGP_PROBE(1);
   if (post_eval) run_eval(std::true_type{});      // (its leading barrier comes after the K-loop's last one: the slab buffers are free)
-  if (FLOW && producer) {
-    // partial sum + sum_{j in chunk} L(i,j) L(k,j)^T -> its slot; release; raise the slot's flag
-    double* __restrict__ Pt = a.part + ((long long)ps * a.part_slots + part_slot(a, ti, tk, a.part_chunk)) * PART_DOUBLES;
-#pragma unroll
-    for (int cb = 0; cb < NSB; ++cb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) st_pair<ADJ>(Pt, cb * 16 + 4 * r + lq, row0, row1, acc[cb][0][r], acc[cb][1][r]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  if (FLOW && a.need > 0) {
+    // the tile holds what the early-sum items left: wait for the last of them
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a.pflag + (long long)ps * a.part_slots + part_slot(a, ti, tk, a.part_chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-  }
-  if (FLOW && a.npart > 0) {
-    // the early partial sums of this tile, in chunk order
-    if (tid == 0) {
-      const int* pf = a.pflag + (long long)ps * a.part_slots + part_slot(a, ti, tk, 0);
-      bool ok = true;
-      for (int c = 0; c < a.npart; ++c) ok = flow_wait(pf + c) && ok;
-      if (!ok) a.info[ps] = -7;
+      if (!flow_wait_ge(a.pflag + (long long)ps * a.part_tiles + part_tile(a, ti, tk), a.need)) a.info[ps] = -7;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    for (int c = 0; c < a.npart; ++c) {
-      const double* __restrict__ Pt = a.part + ((long long)ps * a.part_slots + part_slot(a, ti, tk, c)) * PART_DOUBLES;
-#pragma unroll
-      for (int cb = 0; cb < NSB; ++cb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const d2 t2 = ld_pair<ADJ>(Pt, cb * 16 + 4 * r + lq, row0, row1);
-          acc[cb][0][r] += t2.x;
-          acc[cb][1][r] += t2.y;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
   }
   if (prebuilt) {
     // resident tile: bring the accumulators to the same -C representation (one column block at a
@@ -659,7 +658,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     }
   }
 
-  if (!FACTOR || (!is_diag && !INTRSM)) {
+  if (!FACTOR || (!is_diag && !INTRSM) || (FLOW && producer)) {
     // ---- plain epilogue: C = -acc ----
 #pragma unroll
     for (int cb = 0; cb < NSB; ++cb) {
@@ -670,6 +669,16 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
       __builtin_amdgcn_sched_barrier(0);
     }
     if (is_diag && tid < NB) vecp[tk * NB + tid] = rv;   // Schur mode: -(V^T alpha) (+x = 0)
+    if (FLOW && producer) {
+      // early-sum item: the tile holds A - (sums so far); release; count the chunk
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(a.pflag + (long long)ps * a.part_tiles + part_tile(a, ti, tk), a.early, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     return;
   }
 
@@ -683,7 +692,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
       if (FLOW) {
         const long long tw0 = a.trace ? (long long)wall_clock64() : 0;
         if (!flow_wait(a.tflag + (long long)ps * a.ntri + tri_idx(tk, tk))) a.info[ps] = -7;
-        if (a.trace && wait_acc) *wait_acc += (double)((long long)wall_clock64() - tw0);
+        if (a.trace && wait_acc) wait_acc->wait += (double)((long long)wall_clock64() - tw0);
       } else {
         const int want = a.k + 1;
         int spins = 0;
@@ -710,6 +719,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     }
     __syncthreads();
     }
+    if (FLOW) AGP_PROBE(2);
     // With acc = -C:  t = acc_jb + sum_lb L(jb,lb) X_lb = -(C_jb - sum L X),  X_jb = (-W_jb) t.
 #pragma unroll
     for (int jb = 0; jb < NSB; ++jb) {
@@ -743,6 +753,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
       }
     }
     if (FLOW) {
+      AGP_PROBE(3);
       // L(i,k) is final: every wave drains its stores, one lane releases at agent scope and raises the tile's flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -845,15 +856,16 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 // (FLOW: waits for tile (tk, j) before the slabs of block column j are fetched; raises its own flag when done).
 template <int DCOV, int GM, bool FLOW>
 __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, const int ps, const int tk, double* sm, const int tid,
-                                               double* wait_acc = nullptr) {
+                                               FlowProbe* wait_acc = nullptr) {
   constexpr bool TAB = GM == 1, LAGM = GM == 2;
+  phase_prio();
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;
   double* xv = avec + 128;     // [2][32]
   double* Wl = xv + 64;        // [256]
   constexpr int NE = NSB + 1;  // accumulator blocks per wave
-  const bool producer = FLOW && a.part_mode != 0;        // early partial sum (see CholArgs::items): no evaluation, no factorisation
-  const int jfirst = producer ? a.part_chunk * a.part_ch : (FLOW ? a.jstart : 0);
+  const bool producer = FLOW && a.early != 0;            // early-sum item (see CholArgs::items): its chunk of the K-loop, no factorisation
+  const int jfirst = FLOW ? a.jstart : 0;
   const int jmax = producer ? jfirst + a.part_ch : (a.rl ? 0 : a.k);
   const int l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   const int wu = __builtin_amdgcn_readfirstlane(w);
@@ -868,7 +880,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
   double* vecp = a.vec + (long long)ps * a.ldv;
   double* __restrict__ Tt = Ap + tile_off(tk, tk);
   d4 acc[NE];
-  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused) || producer;
+  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused) || (FLOW && a.need > 0);
   if (!prebuilt) {
     const ProgHdr h = a.hdr[p];
     double* tpt = sm;
@@ -928,7 +940,9 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
   }
 
   double rv = 0.0;
-  if (tid < NB && !producer) rv = vecp[tk * NB + tid];
+  const bool late = FLOW && a.need > 0;       // the vector segment is what the previous early-sum item left: read behind the wait
+  if (tid < NB && !late) rv = vecp[tk * NB + tid];
+  if (FLOW) AGP_PROBE(0);
 
   constexpr int KS = 2 * KB;                      // 32-column slabs
   constexpr int NU = KS / 4;
@@ -1003,7 +1017,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
       const long long tw0 = a.trace ? (long long)wall_clock64() : 0;
       if (!flow_wait(a.tflag + (long long)ps * a.ntri + tri_idx(tk, j))) a.info[ps] = -7;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (a.trace && wait_acc) *wait_acc += (double)((long long)wall_clock64() - tw0);
+      if (a.trace && wait_acc) wait_acc->wait += (double)((long long)wall_clock64() - tw0);
     };
     int all_ready = 0;       // (see chol_tile: tile (tk, k-1) final => every earlier tile of the row is final and visible)
     if (FLOW) {
@@ -1033,46 +1047,15 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
     }
   }
 
-  if (FLOW && producer) {
-    // partial sums (lower block triangle in tile layout, then the forward-solve vector's share) -> slot; release; flag
-    double* __restrict__ Pt = a.part + ((long long)ps * a.part_slots + part_slot(a, tk, tk, a.part_chunk)) * PART_DOUBLES;
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int rw = st1[e] ? row1 : row0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Pt[(cbe[e] * 16 + 4 * r + lq) * NB + rw] = acc[e][r];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (tid < NB) Pt[NB2 + tid] = rv;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  phase_prio();
+  if (FLOW) AGP_PROBE(1);
+  if (FLOW && a.need > 0) {
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a.pflag + (long long)ps * a.part_slots + part_slot(a, tk, tk, a.part_chunk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
-  }
-  if (FLOW && a.npart > 0) {
-    if (tid == 0) {
-      const int* pf = a.pflag + (long long)ps * a.part_slots + part_slot(a, tk, tk, 0);
-      bool ok = true;
-      for (int c = 0; c < a.npart; ++c) ok = flow_wait(pf + c) && ok;
-      if (!ok) a.info[ps] = -7;
+      if (!flow_wait_ge(a.pflag + (long long)ps * a.part_tiles + part_tile(a, tk, tk), a.need)) a.info[ps] = -7;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    for (int c = 0; c < a.npart; ++c) {
-      const double* __restrict__ Pt = a.part + ((long long)ps * a.part_slots + part_slot(a, tk, tk, c)) * PART_DOUBLES;
-#pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        const int rw = st1[e] ? row1 : row0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[e][r] += Pt[(cbe[e] * 16 + 4 * r + lq) * NB + rw];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (tid < NB) rv += Pt[NB2 + tid];
-    }
+    if (tid < NB) rv += vecp[tk * NB + tid];
   }
   if (prebuilt) {
     // resident tile: bring the accumulators to the -C representation
@@ -1084,6 +1067,25 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  if (FLOW && producer) {
+    // early-sum item: A - (sums so far) back into the tile's lower block triangle, the vector's share into vec; release; count
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int rw = st1[e] ? row1 : row0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Tt[(cbe[e] * 16 + 4 * r + lq) * NB + rw] = -acc[e][r];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tid < NB) vecp[tk * NB + tid] = rv;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a.pflag + (long long)ps * a.part_tiles + part_tile(a, tk, tk), a.early, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
 
   // S = -acc into the 16x16 blocks of the lower block triangle (column-major blocks)
 #pragma unroll
@@ -1093,7 +1095,8 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
 #pragma unroll
     for (int r = 0; r < 4; ++r) blk[(4 * r + lq) * 16 + l15] = -acc[e][r];
   }
-  factor_diag_tile<true>(a, ps, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid);
+  if (FLOW) AGP_PROBE(2);
+  factor_diag_tile<true>(a, ps, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid, (FLOW && a.trace && wait_acc) ? &wait_acc->ph[3] : nullptr);
 }
 
 template <int DCOV, int GM>
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
   static_assert(GM == 0 || DCOV > 0, "the log|dt| table / the lag tables only matter to instantiations that evaluate tiles");
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES + U_EXTRA_DOUBLES];
   __shared__ int s_item;
-  __shared__ double s_wait;
+  __shared__ FlowProbe s_probe;
   const int xcd = blockIdx.x & 7;
   const int Pl = (a0.P - xcd + 7) / 8;          // particles pl*8 + xcd < P
   const int nt = a0.nt;
@@ -1180,12 +1183,12 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
     if (listed) {
       // kinds: 0 diagonal tile, 1 sub-diagonal tile, 2 / 3 early partial sum of a trailing diagonal / sub-diagonal tile
       const bool trailing = k >= nt - a0.part_tb;
-      a.part_mode = kind >= 2 ? 1 : 0; a.part_chunk = chunk;
-      a.npart = (kind < 2 && trailing) ? a0.part_nch : 0;
-      a.jstart = (kind < 2 && trailing) ? a0.part_nch * a0.part_ch : (kind >= 2 ? chunk * a0.part_ch : 0);
+      a.early = kind >= 2 ? chunk + 1 : 0;
+      a.need = kind >= 2 ? chunk : (trailing ? a0.part_nch : 0);
+      a.jstart = kind >= 2 ? chunk * a0.part_ch : (trailing ? a0.part_nch * a0.part_ch : 0);
     }
     const long long t_start = a0.trace ? (long long)wall_clock64() : 0;
-    if (a0.trace && threadIdx.x == 0) s_wait = 0.0;
+    if (a0.trace && threadIdx.x == 0) { s_probe.wait = 0.0; s_probe.ph[0] = s_probe.ph[1] = s_probe.ph[2] = s_probe.ph[3] = 0; }
     // the lane index is made opaque per item: otherwise every lane-dependent offset of every phase of the tile body is
     // hoisted out of this loop and stays live across the K-loop (hundreds of spilled registers)
     int tid = threadIdx.x;
@@ -1193,17 +1196,18 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
     // diagonal tiles run the lower-triangle body of k_chol_diag, the others the sub-diagonal body (update + in-register
     // solve) of the split per-column launches
     if (AGP_CHAIN_PRIO) { if (tl <= 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
-    if (tl == 0) chol_diag_tile<DCOV, GM, true>(a, p, ps, k, sm, tid, &s_wait);
-    else chol_tile<true, DCOV, true, 2, GM, true>(a, p, ps, k + tl, k, (listed && kind >= 2) ? (chunk + 1) * a0.part_ch : k, false, sm, tid, &s_wait);
+    if (tl == 0) chol_diag_tile<DCOV, GM, true>(a, p, ps, k, sm, tid, &s_probe);
+    else chol_tile<true, DCOV, true, 2, GM, true>(a, p, ps, k + tl, k, (listed && kind >= 2) ? (chunk + 1) * a0.part_ch : k, false, sm, tid, &s_probe);
     if (AGP_CHAIN_PRIO) __builtin_amdgcn_s_setprio(0);
     if (a0.trace && threadIdx.x == 0) {
       // record of this item: [start, end, K-loop wait ticks, (xcd, particle, tile row, block column)]
       long long gi = item;
       if (listed) gi += (long long)xcd * a0.items_stride;
       else for (int x = 0; x < xcd; ++x) gi += ((a0.P - x + 7) / 8) * (nfac * nt - nfac * (nfac - 1) / 2);
-      long long* r = a0.trace + 4 * gi;
+      long long* r = a0.trace + 8 * gi;
       r[0] = t_start; r[1] = (long long)wall_clock64();
-      r[2] = (long long)s_wait;
+      r[2] = (long long)s_probe.wait;
+      r[4] = s_probe.ph[0]; r[5] = s_probe.ph[1]; r[6] = s_probe.ph[2]; r[7] = s_probe.ph[3];
       r[3] = ((long long)blockIdx.x << 48) | ((long long)kind << 44) | ((long long)p << 24) | ((long long)(k + tl) << 12) | k;
     }
   }

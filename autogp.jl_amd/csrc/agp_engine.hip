@@ -68,7 +68,7 @@ struct Slot {
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
       Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq, lagtab,
-      flowlist, flowpart, flowpflag;
+      flowlist, flowpflag;
   long long flowlist_key = -1;        // (P, nt, order, tb, ch) the device-resident work list was built for
   int flowlist_stride = 0;
   std::vector<hipEvent_t> events;
@@ -85,7 +85,7 @@ struct Slot {
     if (done) { (void)hipEventDestroy(done); done = nullptr; }
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
-                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab, &flowlist, &flowpart, &flowpflag})
+                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab, &flowlist, &flowpflag})
       b->release();
     stage.release(); h_stage.release(); h_out.release(); h_async_info.release();
     for (auto e : events) (void)hipEventDestroy(e);
@@ -168,12 +168,12 @@ struct agp_ctx {
   int stride_pad = 0;   // doubles added to a particle's matrix stride (multiple of 2: 16-byte tile accesses); env AGP_STRIDE_PAD
   int flow = -1;        // dataflow schedule (whole factorisation in one launch of persistent workgroups): -1 auto, 0, 1; env AGP_FLOW
   int flow_order = 1;   // queue order of a block column's sub-diagonal tiles: 0 tile-row-major, 1 particle-major; env AGP_FLOW_ORDER
-  long long* d_flow_trace = nullptr;   // agp_debug_flow_trace: 4 x int64 per work item of the next dataflow sweep
+  long long* d_flow_trace = nullptr;   // agp_debug_flow_trace: 8 x int64 per work item of the next dataflow sweep
   size_t flow_trace_items = 0;
   int flow_fuse = 1;    // 1: dataflow sweeps evaluate tiles in-kernel like the large-population path; env AGP_FLOW_FUSE
   // Early partial sums in the dataflow schedule (plain sweeps): the K-loops of the tiles of the last flow_part_tb tile rows
   // are cut into chunks of flow_part_ch block columns queued mid-kernel (CholArgs::items); 0 disables.  env AGP_FLOW_PART_TB / _CH
-  int flow_part_tb = 4, flow_part_ch = 4;
+  int flow_part_tb = 0, flow_part_ch = 4;      // (measured r03i: 4.28 vs 4.20 ms at 64 particles with tb = 4 — the extra items cost what the shorter tail saves: off)
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // [8..11]: gradient sweep: L^-T chain, K^-1 tiles, contraction, alpha + reduction
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
@@ -1198,7 +1198,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           // early partial sums for the trailing tile rows (plain sweeps, one stream, one chunk)
           const int tb = c->flow_part_tb, chw = c->flow_part_ch;
           if (n_hit == 0 && S == 1 && P <= chunk && tb > 0 && nt - tb >= chw) {
-            const int nch = (nt - tb) / chw, pslots = tb * (tb + 1) / 2 * nch;
+            const int nch = (nt - tb) / chw, ptiles = tb * (tb + 1) / 2;
             const long long key = (((((long long)Pg * 4096 + nt) * 4 + c->flow_order) * 64 + tb) * 64 + chw);
             if (s->flowlist_key != key) {
               std::vector<FlowItem> list; int counts[8];
@@ -1209,14 +1209,13 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
               HIPCHK(c, hipMemcpy(s->flowlist.p, counts, sizeof(int) * 8, hipMemcpyHostToDevice));
               s->flowlist_key = key; s->flowlist_stride = stride;
             }
-            HIPCHK(c, s->flowpart.ensure(sizeof(double) * (size_t)Pg * pslots * PART_DOUBLES));
-            HIPCHK(c, s->flowpflag.ensure(sizeof(int) * (size_t)Pg * pslots));
-            HIPCHK(c, hipMemsetAsync(s->flowpflag.p, 0, sizeof(int) * (size_t)Pg * pslots, q));
+            HIPCHK(c, s->flowpflag.ensure(sizeof(int) * (size_t)Pg * ptiles));
+            HIPCHK(c, hipMemsetAsync(s->flowpflag.p, 0, sizeof(int) * (size_t)Pg * ptiles, q));
             ca.n_items = s->flowlist.as<int>();
             ca.items = reinterpret_cast<const int4*>(static_cast<char*>(s->flowlist.p) + 64);
             ca.items_stride = s->flowlist_stride;
-            ca.part = s->flowpart.as<double>(); ca.pflag = s->flowpflag.as<int>();
-            ca.part_slots = pslots; ca.part_tb = tb; ca.part_ch = chw; ca.part_nch = nch;
+            ca.pflag = s->flowpflag.as<int>();
+            ca.part_tiles = ptiles; ca.part_tb = tb; ca.part_ch = chw; ca.part_nch = nch;
             if (ca.trace && (size_t)8 * s->flowlist_stride > c->flow_trace_items) ca.trace = nullptr;
           }
           size_t f0 = pf.mark(q);
@@ -2477,13 +2476,13 @@ int agp_debug_flow_trace(agp_ctx* c, int32_t enable, int64_t max_items, int64_t*
   if (enable) {
     if (c->d_flow_trace) { (void)hipFree(c->d_flow_trace); c->d_flow_trace = nullptr; }
     if (max_items <= 0) { c->flow_trace_items = 0; return AGP_OK; }
-    HIPCHK(c, hipMalloc((void**)&c->d_flow_trace, sizeof(long long) * 4 * (size_t)max_items));
-    HIPCHK(c, hipMemset(c->d_flow_trace, 0, sizeof(long long) * 4 * (size_t)max_items));
+    HIPCHK(c, hipMalloc((void**)&c->d_flow_trace, sizeof(long long) * 8 * (size_t)max_items));
+    HIPCHK(c, hipMemset(c->d_flow_trace, 0, sizeof(long long) * 8 * (size_t)max_items));
     c->flow_trace_items = (size_t)max_items;
     return AGP_OK;
   }
   if (!out || !c->d_flow_trace || (size_t)max_items > c->flow_trace_items) return fail(c, AGP_ERR_ARG, "no trace recorded");
-  HIPCHK(c, hipMemcpy(out, c->d_flow_trace, sizeof(long long) * 4 * (size_t)max_items, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(out, c->d_flow_trace, sizeof(long long) * 8 * (size_t)max_items, hipMemcpyDeviceToHost));
   return AGP_OK;
 }
 

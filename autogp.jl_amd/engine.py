@@ -453,11 +453,11 @@ class GPEngine:
         return ms.value
 
     def flow_trace(self, enable, max_items):
-        """agp_debug_flow_trace: enable=True starts recording; enable=False returns an (items, 4) int64 array."""
+        """agp_debug_flow_trace: enable=True starts recording; enable=False returns an (items, 8) int64 array."""
         if enable:
             self._check(self._lib.agp_debug_flow_trace(self._ctx, 1, int(max_items), None))
             return None
-        out = np.zeros((int(max_items), 4), dtype=np.int64)
+        out = np.zeros((int(max_items), 8), dtype=np.int64)
         self._check(self._lib.agp_debug_flow_trace(self._ctx, 0, int(max_items), out.ctypes.data_as(C.POINTER(C.c_int64))))
         return out
 

@@ -306,8 +306,9 @@ int agp_debug_compact_shards(agp_ctx* ctx, const double* padded, int32_t P, int3
 
 /* Timeline of the dataflow factorisation schedule (one launch of persistent workgroups, medium populations):
  * enable != 0 allocates room for max_items work items (tiles) and records the following sweeps; enable == 0 copies
- * the records out — 4 int64 per item: start, end (100 MHz ticks), ticks spent waiting for operand tiles, and
- * (workgroup << 48 | particle << 24 | tile row << 12 | block column). */
+ * the records out — 8 int64 per item: start, end (100 MHz ticks), ticks spent waiting for operand tiles,
+ * (workgroup << 48 | item kind << 44 | particle << 24 | tile row << 12 | block column), then the times at which the item's
+ * phases ended: tile evaluated, K-loop done, solve / factorisation inputs staged, arithmetic done (0: phase not run). */
 int agp_debug_flow_trace(agp_ctx* ctx, int32_t enable, int64_t max_items, int64_t* out);
 
 /* When enabled, batch calls bracket their phases with HIP events on the launch stream.

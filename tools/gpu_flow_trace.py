@@ -60,3 +60,13 @@ for name, sel in (("diag", (ti == tk) & (kind < 2)), ("sub", (ti != tk) & (kind 
     if len(kk) > 2:
         a, b = np.polyfit(kk, dur, 1)
         print(f"{name} items (waits excluded): {b:.1f} us + {a:.2f} us per 128-deep K-block")
+# phase breakdown of the items (lane 0's clock): evaluation | K-loop | wait + staging | solve / factorisation | stores + release
+ph = tr[:, 4:8].astype(np.float64)
+for name, sel in (("diag", (ti == tk) & (kind < 2)), ("sub", (ti != tk) & (kind < 2))):
+    for kq in sorted(set([1, nt // 2, nt - 2])):
+        m = sel & (tk == kq) & (ph > 0).all(axis=1)
+        if not m.any():
+            continue
+        s0 = tr[m, 0]; e0 = tr[m, 1]
+        seg = np.stack([ph[m, 0] - s0, ph[m, 1] - ph[m, 0], ph[m, 2] - ph[m, 1], ph[m, 3] - ph[m, 2], e0 - ph[m, 3]], axis=1) * us
+        print(f"{name} k={kq:2d}: eval {seg[:,0].mean():6.1f} | K-loop {seg[:,1].mean():7.1f} (waits {wait[m].mean():5.1f}) | stage {seg[:,2].mean():6.1f} | arithmetic {seg[:,3].mean():6.1f} | store+release {seg[:,4].mean():6.1f} us   ({m.sum()} items)")
