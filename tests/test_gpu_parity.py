@@ -299,7 +299,7 @@ def test_dataflow_schedule_vs_oracle(pkg, n, P, monkeypatch):
     """The single-launch dataflow schedule (k_chol_flow: persistent workgroups, tiles handed out by ticket, per-tile
     ready flags) — the default for medium populations — forced on (AGP_FLOW=1) and off (AGP_FLOW=0): both against the
     oracle on every particle, against each other to rounding, bitwise reproducible run to run, in both queue orders
-    and with prebuilt tiles (AGP_FLOW_FUSE=0)."""
+    and with prebuilt tiles (AGP_FLOW_FUSE=0); also with the work-list / early-sum variant of the schedule."""
     from oracle import fast as F
     ts, xs = pkg.prior.synthetic_series(n, seed=n + P, shuffle=True)
     nodes, noises = pkg.prior.sample_particles(np.random.default_rng(n + P), P, max_depth=4, max_size=31)
@@ -307,7 +307,11 @@ def test_dataflow_schedule_vs_oracle(pkg, n, P, monkeypatch):
     ref, rinfo = F.gp_logpdf_many(progs, noises, ts, xs)
     res = {}
     for name, env in (("cols", {"AGP_FLOW": "0"}), ("flow", {"AGP_FLOW": "1"}), ("flow_tr", {"AGP_FLOW": "1", "AGP_FLOW_ORDER": "0"}),
-                      ("flow_prebuilt", {"AGP_FLOW": "1", "AGP_FLOW_FUSE": "0"}), ("auto", {})):
+                      ("flow_prebuilt", {"AGP_FLOW": "1", "AGP_FLOW_FUSE": "0"}),
+                      # host-built work list with in-place early sums for the trailing tile rows (off by default; CholArgs::items)
+                      ("flow_early", {"AGP_FLOW": "1", "AGP_FLOW_PART_TB": "3", "AGP_FLOW_PART_CH": "2"}),
+                      ("flow_early_prebuilt_general", {"AGP_FLOW": "1", "AGP_FLOW_PART_TB": "2", "AGP_FLOW_PART_CH": "1", "AGP_FLOW_FUSE": "0", "AGP_LAG": "0"}),
+                      ("auto", {})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         eng = pkg.GPEngine(0)
