@@ -191,6 +191,10 @@ constexpr bool XCD_PIN = AGP_XCD_PIN != 0;     // 1: all tiles of a particle on 
 #ifndef AGP_PHASE_PRIO
 #define AGP_PHASE_PRIO 0
 #endif
+#ifndef AGP_DIAG_SELECT
+#define AGP_DIAG_SELECT 0        // 1: entries 1..3 of the diagonal kernel's K-loop select their row fragment in registers
+#endif
+
 __device__ __forceinline__ void phase_prio() { if (AGP_PHASE_PRIO) __builtin_amdgcn_s_setprio(AGP_PHASE_PRIO); }
 __device__ __forceinline__ void mfma_prio_on(bool hi) {
   if ((AGP_PRIO_ASYM || AGP_CHAIN_PRIO) && hi) __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO ? 3 : 2);
@@ -388,6 +392,17 @@ __device__ __forceinline__ void st_pair(double* T, int col, int rowA, int rowB, 
 // phases ended: [0] tile evaluated / accumulators ready, [1] K-loop done, [2] solve / factorisation inputs staged, [3] arithmetic done
 struct FlowProbe { double wait; long long ph[4]; };
 #define AGP_PROBE(i) do { if (a.trace && wait_acc && tid == 0) wait_acc->ph[i] = (long long)wall_clock64(); } while (0)
+// Operand streams of the K-loops go through raw BUFFER loads: descriptor (tile row's base, in SGPRs) + per-lane byte offset
+// (one VGPR, constant for the whole loop) + wave-uniform byte offset of the slab (an SGPR advanced on the scalar unit).
+// Formed as per-lane 64-bit pointers the same loads cost ~20 vector instructions per 16-column slab — on the issue port the
+// MFMAs need (plus 8 register copies at the slab boundary, gone since the slab loop is unrolled by two).
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_row_rsrc(const double* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ d2 buf_load_d2(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, int soff_bytes) {
+  return __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
+}
 // one lane: wait until a tile flag is raised (bounded), then acquire at agent scope
 __device__ __forceinline__ bool flow_wait(const int* flag) {
   int spins = 0;
@@ -525,30 +540,34 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
   const int nslab = (AGP_DBG_SKIP & 4) ? 0 : (jmax - jfirst) * SLABS_PER_TILE;
   if (nslab > 0) {
     // column operand: 256 threads stage the slab of tile (k,j), NU x 16 B each (element 2*(tid+256u));
-    // row operand: each lane fetches its own two rows of tile (i,j) for k-step kk at column 4kk + lq
+    // row operand: each lane fetches its own two rows of tile (i,j) for k-step kk at column 4kk + lq.
+    // Addresses are (wave-uniform tile / slab base) + (32-bit lane offset): the base lives in SGPRs and moves on the scalar
+    // unit, the loads take it as their scalar base — formed per lane in 64 bits (as the compiler does with signed offsets)
+    // they cost ~20 vector instructions per slab on the issue port the MFMAs need (r03: 80 % -> see NOTES).
     const int scol0 = tid >> 6;        // + 4u
     const int srow = 2 * (tid & 63);
-    d2 ra[NU], rb[NU];
+    const unsigned offB = (unsigned)(scol0 * NB + srow);
+    const unsigned offA = A_DIRECT ? (unsigned)(lq * NB + row0) : offB;
     double rx = 0.0;
-    auto gload = [&](int s) {
-      const int j = jfirst + s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
-      const double* __restrict__ srcA = Ap + tile_off(ti, j) + (long long)cs * NB;
-      const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
+    // (the tiles (i,0..i) of a tile row are contiguous: slab s of the sum sits (jfirst * SLABS_PER_TILE + s) slabs into the row)
+    const __amdgpu_buffer_rsrc_t rsA = tile_row_rsrc(Ap + tile_off(ti, 0)), rsB = tile_row_rsrc(Ap + tile_off(tk, 0));
+    static_assert(ADJ || !A_DIRECT, "the direct row operand is fetched as adjacent row pairs");
+    auto gload = [&](int s, d2 (&ra_)[NU], d2 (&rb_)[NU]) {
+      const int sb = (jfirst * SLABS_PER_TILE + s) * (KS * NB * 8);       // byte offset of the slab in both tile rows
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        ra[u] = A_DIRECT ? ld_pair<ADJ>(srcA, 4 * u + lq, row0, row1)
-                         : *reinterpret_cast<const d2*>(srcA + (scol0 + 4 * u) * NB + srow);
-        rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 4 * u) * NB + srow);
+        ra_[u] = buf_load_d2(rsA, offA * 8, sb + u * (4 * NB * 8));
+        rb_[u] = buf_load_d2(rsB, offB * 8, sb + u * (4 * NB * 8));
       }
-      if (is_diag && tid < KS) rx = vecp[j * NB + cs + tid];
+      if (is_diag && tid < KS) rx = vecp[(jfirst * SLABS_PER_TILE + s) * KS + tid];
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, const d2 (&ra_)[NU], const d2 (&rb_)[NU]) {
       double* Bs = sm + buf * SLAB_DOUBLES;
       double* As = sm + (2 + buf) * SLAB_DOUBLES;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb[u];
-        if (!A_DIRECT) *reinterpret_cast<d2*>(As + (scol0 + 4 * u) * LDS_STRIDE + srow) = ra[u];
+        *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb_[u];
+        if (!A_DIRECT) *reinterpret_cast<d2*>(As + (scol0 + 4 * u) * LDS_STRIDE + srow) = ra_[u];
       }
       if (is_diag && tid < KS) xv[buf * KS + tid] = rx;
     };
@@ -584,15 +603,14 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     // sub-diagonal launch went 1.560 -> 1.664 ms.  The loop is not waiting for its loads; more of them in flight only
     // crowd the co-resident workgroup's.)
     const bool prio_hi = (AGP_CHAIN_PRIO && FLOW) ? (ti == tk + 1) : wave_slot_odd();
-    gload(0);
-    lstore(0);
-    d2 fr[NU];                                   // row fragments of the slab being multiplied
-#pragma unroll
-    for (int u = 0; u < NU; ++u) fr[u] = ra[u];
+    // Two register sets X / Y take turns as "row fragments of the slab being multiplied" and "row fragments in flight" (the
+    // slab loop is unrolled by two; nslab is a multiple of 8): no register copies at the slab boundary.
+    d2 fx[NU], fy[NU], rb[NU];
+    gload(0, fx, rb);
+    lstore(0, fx, rb);
     __syncthreads();
-    for (int s = 0; s < nslab; ++s) {
-      const int buf = s & 1;
-      if (s + 1 < nslab) gload(s + 1);
+    auto slab = [&](const int s, const int buf, const d2 (&fr)[NU], d2 (&rn)[NU]) {
+      if (s + 1 < nslab) gload(s + 1, rn, rb);
       const double* Bs = sm + buf * SLAB_DOUBLES;
       const double* As = sm + (2 + buf) * SLAB_DOUBLES;
       // waves inside their MFMA block outrank the co-resident workgroup's load/store/barrier phase
@@ -620,15 +638,13 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) rv = fma(-Bs[kk * LDS_STRIDE + tid], xs_[kk], rv);
       }
-      if (s + 1 < nslab) {
-        lstore(buf ^ 1);
-        if (A_DIRECT) {
-#pragma unroll
-          for (int u = 0; u < NU; ++u) fr[u] = ra[u];
-        }
-      }
+      if (s + 1 < nslab) lstore(buf ^ 1, rn, rb);
       if (FLOW && !all_ready && tid == 0 && s + 2 < nslab && (s + 2) % SLABS_PER_TILE == 0) flow_ready(jfirst + (s + 2) / SLABS_PER_TILE);
       __syncthreads();
+    };
+    for (int s = 0; s < nslab; s += 2) {
+      slab(s, 0, fx, fy);
+      slab(s + 1, 1, fy, fx);
     }
   }
 
@@ -952,14 +968,15 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
   const int nslab = (jmax - jfirst) * SLABS_PER_TILE;
   if (nslab > 0) {
     const int scol0 = tid >> 6, srow = 2 * (tid & 63);
+    const unsigned offB = (unsigned)(scol0 * NB + srow);      // (32-bit lane offset on a wave-uniform base: see chol_tile)
     d2 rb[NU];
     double rx = 0.0;
+    const __amdgpu_buffer_rsrc_t rsB = tile_row_rsrc(Ap + tile_off(tk, 0));       // (buffer loads: see chol_tile)
     auto gload = [&](int s) {
-      const int j = jfirst + s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
-      const double* __restrict__ src = Ap + tile_off(tk, j) + (long long)cs * NB;
+      const int sb = (jfirst * SLABS_PER_TILE + s) * (KS * NB * 8);
 #pragma unroll
-      for (int u = 0; u < NU; ++u) rb[u] = *reinterpret_cast<const d2*>(src + (scol0 + 4 * u) * NB + srow);
-      if (tid < KS) rx = vecp[j * NB + cs + tid];
+      for (int u = 0; u < NU; ++u) rb[u] = buf_load_d2(rsB, offB * 8, sb + u * (4 * NB * 8));
+      if (tid < KS) rx = vecp[(jfirst * SLABS_PER_TILE + s) * KS + tid];
     };
     auto lstore = [&](int buf) {
       double* Bs = sm + buf * SLAB_DOUBLES;
@@ -972,17 +989,19 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
 #pragma unroll
     for (int e = 0; e < NE; ++e) fao[e] = lq * LDS_STRIDE + cbe[e] * 16 + l15;
     const int fb0 = lq * LDS_STRIDE + row0, fb1 = lq * LDS_STRIDE + row1;
+    int fbo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) fbo[e] = st1[e] ? fb1 : fb0;
 
     // Two slabs are in flight beyond the one being multiplied (two register sets): this kernel streams its row
     // panel once at 18 flop/B, so what bounds it is how many bytes it keeps outstanding, not the MFMA rate.
     d2 rb2[NU];
     double rx2 = 0.0;
     auto gload2 = [&](int s) {
-      const int j = jfirst + s / SLABS_PER_TILE, cs = (s % SLABS_PER_TILE) * KS;
-      const double* __restrict__ src = Ap + tile_off(tk, j) + (long long)cs * NB;
+      const int sb = (jfirst * SLABS_PER_TILE + s) * (KS * NB * 8);
 #pragma unroll
-      for (int u = 0; u < NU; ++u) rb2[u] = *reinterpret_cast<const d2*>(src + (scol0 + 4 * u) * NB + srow);
-      if (tid < KS) rx2 = vecp[j * NB + cs + tid];
+      for (int u = 0; u < NU; ++u) rb2[u] = buf_load_d2(rsB, offB * 8, sb + u * (4 * NB * 8));
+      if (tid < KS) rx2 = vecp[(jfirst * SLABS_PER_TILE + s) * KS + tid];
     };
     auto lstore2 = [&](int buf) {
       double* Bs = sm + buf * SLAB_DOUBLES;
@@ -998,8 +1017,18 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
       for (int kk = 0; kk < KS / 4; ++kk) {
         const double* Bk = Bs + kk * 4 * LDS_STRIDE;
         const double f0 = Bk[fb0], f1 = Bk[fb1];
+        // entry e multiplies the rows of block w (f0) for e <= w and of block 7-w (f1) after that; w <= 3, so only entries
+        // 1..3 depend on the wave: a register select in front of EVERY MFMA (what `st1[e] ? f1 : f0` compiles to for all
+        // nine) costs 18 vector instructions per 9 MFMAs on the port that issues them
+        if (!(AGP_DBG_SKIP & 256)) {
+          acc[0] = mfma(Bk[fao[0]], f0, acc[0]);
+          // (entries 1..3 read their row fragment through a per-entry LDS offset fixed before the loop: three more LDS reads
+          // per k-step instead of six selects)
 #pragma unroll
-        for (int e = 0; e < ((AGP_DBG_SKIP & 256) ? 0 : NE); ++e) acc[e] = mfma(Bk[fao[e]], st1[e] ? f1 : f0, acc[e]);
+          for (int e = 1; e < 4; ++e) acc[e] = mfma(Bk[fao[e]], AGP_DIAG_SELECT ? (st1[e] ? f1 : f0) : Bk[fbo[e]], acc[e]);
+#pragma unroll
+          for (int e = 4; e < NE; ++e) acc[e] = mfma(Bk[fao[e]], f1, acc[e]);
+        }
       }
       mfma_prio_off(prio_hi);
       if (tid < NB && !(AGP_DBG_SKIP & 128)) {
