@@ -26,21 +26,26 @@ namespace agp {
 // ---- shared building blocks (same wave tiling as k_chol_update: wave w owns rows [32w, 32w+32),
 //      strips = even / odd rows, 8 column blocks) ------------------------------------------------------
 
-// acc += sum_s rowop(s) colop(s)^T over `nslab` 16-column slabs.  colop slabs are staged through LDS
-// (double buffered, shared by the 4 waves), rowop fragments go global -> registers.
+// acc += sum_s rowop(s) colop(s)^T over `nslab` 16-column slabs (nslab even).  colop slabs are staged through LDS
+// (double buffered, shared by the 4 waves), rowop fragments go global -> registers.  Both streams are raw buffer loads
+// (see agp_chol_kernel.hpp): base = the particle's packed buffer, rowoff(s) / coloff(s) = the slab's wave-uniform BYTE offset
+// in it (scalar arithmetic), one constant per-lane offset register per stream; the two row-fragment register sets take
+// turns across a slab loop unrolled by two (no copies).  Offsets are 32-bit: packed buffers of up to 2 GiB (n <= 23 040).
 template <typename FR, typename FC>
-__device__ __forceinline__ void gemm_slabs(d4 (&acc)[NSB][2], int nslab, FR rowslab, FC colslab, double* sm,
+__device__ __forceinline__ void gemm_slabs(d4 (&acc)[NSB][2], int nslab, const double* rowbase, FR rowoff,
+                                           const double* colbase, FC coloff, double* sm,
                                            int tid, int l15, int lq, int row0) {
   if (nslab <= 0) return;
   const int scol0 = tid >> 6, srow = 2 * (tid & 63);
-  d2 ra[4], rb[4];
-  auto gload = [&](int s) {
-    const double* __restrict__ srcA = rowslab(s);
-    const double* __restrict__ srcB = colslab(s);
+  const __amdgpu_buffer_rsrc_t rsA = tile_row_rsrc(rowbase), rsB = tile_row_rsrc(colbase);
+  const unsigned voA = (unsigned)(lq * NB + row0) * 8u, voB = (unsigned)(scol0 * NB + srow) * 8u;
+  d2 fx[4], fy[4], rb[4];
+  auto gload = [&](int s, d2 (&ra_)[4]) {
+    const int oa = rowoff(s), ob = coloff(s);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      ra[u] = *reinterpret_cast<const d2*>(srcA + (4 * u + lq) * NB + row0);
-      rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 4 * u) * NB + srow);
+      ra_[u] = buf_load_d2(rsA, voA, oa + u * (4 * NB * 8));
+      rb[u] = buf_load_d2(rsB, voB, ob + u * (4 * NB * 8));
     }
   };
   auto lstore = [&](int buf) {
@@ -48,13 +53,11 @@ __device__ __forceinline__ void gemm_slabs(d4 (&acc)[NSB][2], int nslab, FR rows
 #pragma unroll
     for (int u = 0; u < 4; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb[u];
   };
-  gload(0);
+  gload(0, fx);
   lstore(0);
-  d2 fr[4] = {ra[0], ra[1], ra[2], ra[3]};
   __syncthreads();
-  for (int s = 0; s < nslab; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nslab) gload(s + 1);
+  auto slab = [&](const int s, const int buf, const d2 (&fr)[4], d2 (&rn)[4]) {
+    if (s + 1 < nslab) gload(s + 1, rn);
     const double* Bs = sm + buf * U_SLAB;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -70,12 +73,12 @@ __device__ __forceinline__ void gemm_slabs(d4 (&acc)[NSB][2], int nslab, FR rows
       }
     }
     __builtin_amdgcn_s_setprio(0);
-    if (s + 1 < nslab) {
-      lstore(buf ^ 1);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) fr[u] = ra[u];
-    }
+    if (s + 1 < nslab) lstore(buf ^ 1);
     __syncthreads();
+  };
+  for (int s = 0; s < nslab; s += 2) {
+    slab(s, 0, fx, fy);
+    slab(s + 1, 1, fy, fx);
   }
 }
 
@@ -209,8 +212,8 @@ __global__ __launch_bounds__(256, 2) void k_trtri_step(GradArgs a) {
       for (int r = 0; r < 4; ++r) acc[cb][st][r] = (j == i && (cb * 16 + 4 * r + lq) == row0 + st) ? -1.0 : 0.0;
   const int nslab = (i - j) * (NB / KB);
   gemm_slabs(acc, nslab,
-             [&](int s) { return Zp + zoff(j, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
-             [&](int s) { return Lp + tile_off(i, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+             Zp, [&](int s) { return (int)((zoff(j, j + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
+             Lp, [&](int s) { return (int)((tile_off(i, j + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
              sm, tid, l15, lq, row0);
   solve_in_regs(acc, Lp + tile_off(i, i), Wp + (long long)i * NSB * 256, sm, tid, l);
   double* __restrict__ Tt = Zp + zoff(j, i);
@@ -252,8 +255,8 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[cb][st][r] = (j == i && (cb * 16 + 4 * r + lq) == row0 + st) ? -1.0 : 0.0;
     gemm_slabs(acc, (i - j) * (NB / KB),
-               [&](int s) { return Zp + zoff(j, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
-               [&](int s) { return Lp + tile_off(i, j + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+               Zp, [&](int s) { return (int)((zoff(j, j + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
+               Lp, [&](int s) { return (int)((tile_off(i, j + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
                sm, tid, l15, lq, row0);
     solve_in_regs(acc, Lp + tile_off(i, i), Wp + (long long)i * NSB * 256, sm, tid, l);
     double* __restrict__ Tt = Zp + zoff(j, i);
@@ -535,8 +538,8 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
 #pragma unroll
   for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
   gemm_slabs(acc, (a.nt - ti) * (NB / KB),
-             [&](int s) { return Zp + zoff(ti, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
-             [&](int s) { return Zp + zoff(tj, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+             Zp, [&](int s) { return (int)((zoff(ti, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
+             Zp, [&](int s) { return (int)((zoff(tj, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
              smem, tid, l15, lq, row0);
 
   // ---- per-element reverse-mode contraction ----
@@ -654,8 +657,8 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
 #pragma unroll
   for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
   gemm_slabs(acc, (a.nt - ti) * (NB / KB),
-             [&](int s) { return Zp + zoff(ti, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
-             [&](int s) { return Zp + zoff(tj, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB; },
+             Zp, [&](int s) { return (int)((zoff(ti, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
+             Zp, [&](int s) { return (int)((zoff(tj, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
              sm, tid, l15, lq, row0);
   double* __restrict__ Kt = const_cast<double*>(a.A) + (long long)p * a.strideA + tile_off(ti, tj);
 #pragma unroll
