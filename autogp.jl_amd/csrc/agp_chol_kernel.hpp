@@ -470,8 +470,8 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
     for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
     double* etab = sm + U_MAIN_DOUBLES;      // exp table in the (still unused) forward-solve scratch: rvec[128]
-    if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
-    __syncthreads();
+    if (AGP_EXP_TABLE && !LAGM && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];      // (lag sweeps evaluate no exponential)
+    // (program, parameters, time points and lag tables travel in ONE round trip; the prologue's barrier publishes all of it)
     cov_prologue<LAGM>(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt);
     const double noise = a.noise[p];
     // GammaExp leaves read log|dt| from the data set's table (L2 / Infinity-Cache resident: every particle reads
@@ -907,8 +907,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
     for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
     for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
     double* etab = rvec;                     // exp table in the (still unused) forward-solve scratch
-    if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
-    __syncthreads();
+    if (AGP_EXP_TABLE && !LAGM && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
     cov_prologue<LAGM>(a.tt, a.code, tk, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt);
     const double noise = a.noise[p];
     const bool use_tab = TAB && (h.flags & 1) != 0;

@@ -66,6 +66,9 @@ __device__ __forceinline__ int prm_count(int o) {
 // transcendental code in the factorisation kernels at all.  An element's own t_i - t_j differs from the table's
 // representative only by rounding (agp_set_data admits a grid only when every point sits within 16 ulp of t_0 + g h).
 // Lags beyond the data (g >= n) only occur in padding rows, which cov_finalize overwrites.
+// The time points and the lag tables are loaded in ONE round trip and the first barrier below also publishes whatever the caller
+// has just stored to LDS without synchronising (the factorisation kernels stage program and parameters there: three dependent
+// global round trips + barriers per tile became one).
 template <bool LAG = false, typename OpT>
 __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, const uint8_t* __restrict__ code,
                                              int ti, int tj, const ProgHdr& h,
@@ -73,10 +76,17 @@ __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, cons
                                              double* tpt, double* sig, int tid,
                                              const double* __restrict__ lagtab = nullptr, int nt = 0) {
   const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
-  tpt[tid] = tt[g];
+  const double tg = tt[g];
+  if (LAG && h.n_lag > 0) {
+    // this tile's lag tables: block lag ti - tj of every OP_LAG_* leaf, 2 KiB each, built once per sweep by k_lag_tables
+    double* lag = sig + h.n_cp * 256;
+    const double* __restrict__ src = lagtab + ((long long)h.lag_off * nt + (ti - tj)) * 256 + tid;
+    for (int li = 0; li < h.n_lag; ++li) lag[li * 256 + tid] = src[(long long)li * nt * 256];
+  }
+  tpt[tid] = tg;
   __syncthreads();
   if (h.n_cp > 0) {
-    const double t = tpt[tid];
+    const double t = tg;
     const int cd = code ? (int)code[g] : 0;
     int q = 0, c = 0;
     for (int ip = 0; ip < h.n_ops; ++ip) {
@@ -92,13 +102,6 @@ __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, cons
       }
       q += prm_count(o);
     }
-    __syncthreads();
-  }
-  if (LAG && h.n_lag > 0) {
-    // this tile's lag tables: block lag ti - tj of every OP_LAG_* leaf, 2 KiB each, built once per sweep by k_lag_tables
-    double* lag = sig + h.n_cp * 256;
-    const double* __restrict__ src = lagtab + ((long long)h.lag_off * nt + (ti - tj)) * 256 + tid;
-    for (int li = 0; li < h.n_lag; ++li) lag[li * 256 + tid] = src[(long long)li * nt * 256];
     __syncthreads();
   }
 }
