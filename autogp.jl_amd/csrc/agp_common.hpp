@@ -26,13 +26,14 @@ constexpr int LDS_STRIDE = 144;  // 128 + 16 doubles: k-rows 32 banks apart -> c
 // an observable (code 0) or the latent of that component (code == id), else 0.
 // 11 is GammaExponential evaluated from the data set's log|t_i - t_j| table (agp_set_data builds it once; every
 // particle's GammaExp leaves share it): (|dt|/l)^gamma = exp(gamma (log|dt| - log l)), one exp instead of log + exp.
-// 12..14 are the stationary leaves (SE / GammaExp / Periodic, same parameters as 3..5) of a sweep over data whose time
-// points are a REGULAR GRID held in sorted order (agp_set_data detects it; see "lag tables" in agp_cov_kernel.hpp): inside a
-// tile the value then depends on (row - column) only, so the leaf is evaluated 255 times per tile into an LDS table and
-// looked up per element.
+// 12 is a STATIONARY SUBTREE of a sweep over data whose time points are a REGULAR GRID held in sorted order (agp_set_data
+// detects it; see "lag tables" in agp_cov_kernel.hpp): any subtree built from SE / GammaExp / Periodic / Constant /
+// WhiteNoise leaves with + and x depends on t_i - t_j only, i.e. inside a tile on (row - column) only — the host replaces
+// every maximal such subtree by ONE OP_LAG leaf, k_lag_tables evaluates the subtree's own (direct-form) program once per sweep
+// at the 255 lags of every block diagonal, and the tile's elements read the value from an LDS table.
 enum : int { OP_WN = 0, OP_CONST = 1, OP_LIN = 2, OP_SE = 3, OP_GE = 4, OP_PER = 5,
              OP_PLUS = 6, OP_TIMES = 7, OP_CP = 8, OP_CP_SWAP = 9, OP_SEL = 10, OP_GE_TAB = 11,
-             OP_LAG_SE = 12, OP_LAG_GE = 13, OP_LAG_PER = 14 };
+             OP_LAG = 12 };
 constexpr double LOGDT_ZERO = -1.0e8;    // table entry for dt = 0: exp(gamma (LOGDT_ZERO - log l)) == 0 exactly
 
 struct ProgHdr {
@@ -42,8 +43,13 @@ struct ProgHdr {
   int32_t n_cp;     // number of per-point LDS tables: ChangePoint nodes + selector leaves
   int32_t n_prm;    // device parameters of this program
   int32_t flags;    // bit 0: the program has OP_GE_TAB leaves (reads the log|dt| table)
-  int32_t n_lag;    // number of per-tile lag tables (OP_LAG_* leaves); they follow the n_cp per-point tables in LDS
+  int32_t n_lag;    // number of per-tile lag tables (OP_LAG leaves); they follow the n_cp per-point tables in LDS
   int32_t lag_off;  // index of the program's first lag table in the sweep's table buffer (k_lag_tables)
+};
+
+// program of one lag table: the stationary subtree in the direct device form (OP_SE with 1/l^2, OP_GE with 1/l, ...)
+struct LagTabHdr {
+  int32_t op_off, n_ops, prm_off, pad_;
 };
 
 __host__ __device__ inline long long tile_off(int i, int j) {

@@ -50,22 +50,24 @@ struct CovArgs {
 
 __device__ __forceinline__ int prm_count(int o) {
   // WN, CONST, LIN, SE, GE, PER, PLUS, TIMES, CP, CP_SWAP
-  return (o == OP_WN || o == OP_CONST || o == OP_SEL) ? 1 : (o == OP_SE || o == OP_LAG_SE || o == OP_CP || o == OP_CP_SWAP) ? 2
-         : (o == OP_PLUS || o == OP_TIMES) ? 0 : 3;     // (LIN, GE, GE_TAB, PER, LAG_GE, LAG_PER: 3)
+  return (o == OP_WN || o == OP_CONST || o == OP_SEL) ? 1 : (o == OP_SE || o == OP_CP || o == OP_CP_SWAP) ? 2
+         : (o == OP_PLUS || o == OP_TIMES || o == OP_LAG) ? 0 : 3;     // (LIN, GE, GE_TAB, PER: 3)
 }
 
 // LDS scratch of the evaluator: tpt[256] (row times 0..127, column times 128..255), sig[n_cp][256], then lag[n_lag][256].
 //
-// Lag tables (LAG = true instantiations; programs compiled for a sweep over SORTED, REGULARLY SPACED time points — the host
-// only emits OP_LAG_* leaves then): with t_g = t_0 + g h the difference t_(I0+a) - t_(J0+b) of element (a, b) of tile (I, J)
-// is (128 (I - J) + a - b) h: a function of the block lag I - J and of a - b alone — 255 distinct values per tile, the same
-// for every tile of a block diagonal.  k_lag_tables evaluates every stationary leaf of every particle ONCE per sweep at
-// the lags g = 128 bl + d (bl = 0..nt-1, d = -127..127) — on the stored time points, dt = t_|g| - t_0, with exactly the
-// arithmetic of the general path (src/GP.jl:241-245, 285-289, 331-336) — and a tile copies the 2 KiB table of its block lag
-// into LDS; its 16 384 elements read the leaf from there: one LDS access instead of 40-90 fp64 instructions, and no
-// transcendental code in the factorisation kernels at all.  An element's own t_i - t_j differs from the table's
-// representative only by rounding (agp_set_data admits a grid only when every point sits within 16 ulp of t_0 + g h).
-// Lags beyond the data (g >= n) only occur in padding rows, which cov_finalize overwrites.
+// Lag tables (LAG = true instantiations; programs compiled for a sweep over SORTED, REGULARLY SPACED time points): with
+// t_g = t_0 + g h the difference t_(I0+a) - t_(J0+b) of element (a, b) of tile (I, J) is (128 (I - J) + a - b) h: a function of
+// the block lag I - J and of a - b alone — 255 distinct values per tile, the same for every tile of a block diagonal.  Every
+// MAXIMAL STATIONARY SUBTREE of a kernel expression (SE / GammaExp / Periodic / Constant / WhiteNoise leaves under + and x:
+// src/GP.jl:236-245, 279-289, 324-336, 371-377, 417-423) is a function of t_i - t_j, so the host emits ONE OP_LAG leaf for it and
+// k_lag_tables evaluates the subtree's own program ONCE per sweep at the lags g = 128 bl + d (bl = 0..nt-1, d = -127..127) — on
+// the stored time points, dt = t_|g| - t_0, with exactly the arithmetic of the general path — and a tile copies the 2 KiB
+// table of its block lag into LDS; its 16 384 elements read the subtree's value from there: one LDS access instead of
+// 40-90 fp64 instructions per leaf, one interpreter step instead of one per node, and no transcendental code in the
+// factorisation kernels at all.  An element's own t_i - t_j differs from the table's representative only by rounding
+// (agp_set_data admits a grid only when every point sits within 16 ulp of t_0 + g h).  Lags beyond the data (g >= n) only
+// occur in padding rows, which cov_finalize overwrites.
 // The time points and the lag tables are loaded in ONE round trip and the first barrier below also publishes whatever the caller
 // has just stored to LDS without synchronising (the factorisation kernels stage program and parameters there: three dependent
 // global round trips + barriers per tile became one).
@@ -108,7 +110,7 @@ __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, cons
 
 // Evaluate the program at E (row, column) pairs.  tr/tc: time values; ri/ci: indices into the sigma
 // tables (row slot 0..127, column slot 128..255).  All arrays are statically indexed registers.
-// GEMODE: 0 = every leaf kind (OP_GE computes the power, OP_GE_TAB reads the log|dt| table, OP_LAG_* read the tile's lag
+// GEMODE: 0 = every leaf kind (OP_GE computes the power, OP_GE_TAB reads the log|dt| table, OP_LAG reads the tile's lag
 // tables), 1 = OP_GE only, 2 = OP_GE_TAB only, 3 = lag tables only: no per-element transcendental code at all (the
 // instantiations inside the factorisation kernel carry one kind, which keeps the unused code out of their register budget).
 // lag: the tile's lag tables (after the per-point tables), element (row slot ri, column slot ci - 128) reads entry
@@ -154,8 +156,8 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
         // bias + amp * (ti - c)(tj - c)
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = p1 + p2 * ((tr[e] - p0) * (tc[e] - p0));
-      } else if ((GEMODE == 0 || GEMODE == 3) && (GEMODE == 3 || o >= OP_LAG_SE)) {
-        // stationary leaf of a sorted regular grid: the tile's lag table
+      } else if ((GEMODE == 0 || GEMODE == 3) && (GEMODE == 3 || o == OP_LAG)) {
+        // stationary subtree of a sorted regular grid: the tile's lag table
         const double* lg = lag + li * 256 + (2 * NB - 1);
 #pragma unroll
         for (int e = 0; e < E; ++e) v[e] = lg[ri[e] - ci[e]];
@@ -314,39 +316,33 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
   }
 }
 
-// The lag tables of a sweep on a sorted regular grid (see cov_prologue): block (bl, p) evaluates the stationary leaves of
-// particle p at the 255 lags 128 bl + d, d = -127 .. 127 (entry d + 127; entry 255 unused).
+// The lag tables of a sweep on a sorted regular grid (see cov_prologue): block (bl, t) evaluates table t's program — a
+// stationary subtree in the direct device form — at the 255 lags 128 bl + d, d = -127 .. 127 (entry d + 127; entry 255 unused),
+// with the evaluator of the general path on the "element" (t_|g|, t_0).
 struct LagArgs {
-  const double* tt;      // sorted time points
-  const ProgHdr* hdr;
-  const uint8_t* ops;
-  const double* prm;
-  double* tab;           // [table][nt][256]
-  int nt, P;
+  const double* tt;        // sorted time points
+  const LagTabHdr* thdr;   // [n_tables]
+  const uint8_t* tops;
+  const double* tprm;
+  double* tab;             // [table][nt][256]
+  int nt, n_tables;
 };
 __global__ __launch_bounds__(256) void k_lag_tables(LagArgs a) {
-  const int p = blockIdx.y, bl = blockIdx.x, tid = threadIdx.x;
-  const ProgHdr h = a.hdr[p];
-  if (h.n_lag == 0) return;
-  const uint8_t* __restrict__ ops = a.ops + h.op_off;
-  const double* __restrict__ prm = a.prm + h.prm_off;
+  const int t = blockIdx.y, bl = blockIdx.x, tid = threadIdx.x;
+  __shared__ double etab[AGP_EXP_TAB_N];
+  if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
+  __syncthreads();
+  const LagTabHdr th = a.thdr[t];
+  ProgHdr h = {};
+  h.n_ops = th.n_ops;
   int g = bl * NB + tid - (NB - 1);
-  if (g < 0) g = -g;                                  // stationary leaves are even in dt
-  const double dx = (tid >= 2 * NB - 1 || g >= a.nt * NB) ? 0.0 : a.tt[g] - a.tt[0];
-  int q = 0, li = 0;
-  for (int ip = 0; ip < h.n_ops; ++ip) {
-    const int o = (int)ops[ip];
-    if (o >= OP_LAG_SE) {
-      const double p0 = prm[q], p1 = prm[q + 1], p2 = prm[q + 2];
-      double arg, amp;
-      if (o == OP_LAG_SE) { arg = ((-0.5 * dx) * dx) * p0; amp = p1; }                       // p0 = 1/l^2
-      else if (o == OP_LAG_GE) { arg = -fm::pow_f(fabs(dx) * p0, p1); amp = p2; }            // p0 = 1/l, p1 = gamma
-      else { arg = p0 * fm::sin2_f(p1 * fabs(dx)); amp = p2; }                              // p0 = -2/l^2, p1 = pi/p
-      a.tab[((long long)(h.lag_off + li) * a.nt + bl) * 256 + tid] = amp * fm::exp_f(arg);
-      ++li;
-    }
-    q += prm_count(o);
-  }
+  if (g < 0) g = -g;                                  // stationary kernels are even in dt
+  const bool live = tid < 2 * NB - 1 && g < a.nt * NB;
+  const double tr[1] = {live ? a.tt[g] : 0.0}, tc[1] = {live ? a.tt[0] : 0.0}, lt[1] = {0.0};
+  const int ri[1] = {0}, ci[1] = {NB};
+  double out[1];
+  eval_program<8, 1, 1>(h, a.tops + th.op_off, a.tprm + th.prm_off, nullptr, tr, tc, ri, ci, lt, out, etab);
+  a.tab[((long long)t * a.nt + bl) * 256 + tid] = out[0];
 }
 
 // log|t_i - t_j| for every element of the lower tiles of the resident data (diagonal tiles in full), same packed

@@ -327,7 +327,11 @@ struct Compiled {
   int root = -1;
   int n_prm_caller = 0;
   bool uses_tab = false;      // has OP_GE_TAB leaves
-  int n_lag = 0;              // OP_LAG_* leaves (one per-tile lag table each)
+  int n_lag = 0;              // OP_LAG leaves (one per-tile lag table each)
+  // programs of the lag tables (direct device form), one LagTabHdr per OP_LAG leaf in program order
+  std::vector<LagTabHdr> thdr;
+  std::vector<uint8_t> tops;
+  std::vector<double> tprm;
 };
 
 // k_cov_tiles / the gradient contraction keep one 256-entry table per ChangePoint node / selector leaf in LDS next to
@@ -344,24 +348,46 @@ int leaf_nprm(int op) {
   }
 }
 
-// lag: the sweep runs on a sorted regular grid — stationary leaves become OP_LAG_* (same parameters as the direct forms)
-void emit(const std::vector<CNode>& nodes, int id, Compiled& out, bool ge_tab, bool lag = false) {
+// A subtree is stationary when every leaf is SE / GammaExp / Periodic / Constant / WhiteNoise and every inner node + or x:
+// its value depends on t_i - t_j only.  `heavy`: it contains a transcendental leaf (worth a table).
+void classify(const std::vector<CNode>& nodes, int id, std::vector<char>& stat, std::vector<char>& heavy) {
   const CNode& nd = nodes[id];
+  if (nd.left < 0) {
+    stat[id] = nd.op == OP_WN || nd.op == OP_CONST || nd.op == OP_SE || nd.op == OP_GE || nd.op == OP_PER;
+    heavy[id] = nd.op == OP_SE || nd.op == OP_GE || nd.op == OP_PER;
+    return;
+  }
+  classify(nodes, nd.left, stat, heavy); classify(nodes, nd.right, stat, heavy);
+  stat[id] = (nd.op == OP_PLUS || nd.op == OP_TIMES) && stat[nd.left] && stat[nd.right];
+  heavy[id] = heavy[nd.left] || heavy[nd.right];
+}
+
+// lag: the sweep runs on a sorted regular grid — every maximal stationary subtree with a transcendental leaf becomes ONE OP_LAG
+// leaf, its own program (direct forms, same child order) goes to the table-program arrays (k_lag_tables evaluates it)
+void emit(const std::vector<CNode>& nodes, int id, Compiled& out, bool ge_tab, bool lag = false,
+          const std::vector<char>* stat = nullptr, const std::vector<char>* heavy = nullptr) {
+  const CNode& nd = nodes[id];
+  if (lag && stat && (*stat)[id] && (*heavy)[id]) {
+    Compiled sub;
+    emit(nodes, id, sub, false, false);
+    LagTabHdr th;
+    th.op_off = (int32_t)out.tops.size(); th.n_ops = (int32_t)sub.ops.size(); th.prm_off = (int32_t)out.tprm.size(); th.pad_ = 0;
+    out.thdr.push_back(th);
+    out.tops.insert(out.tops.end(), sub.ops.begin(), sub.ops.end());
+    out.tprm.insert(out.tprm.end(), sub.prm.begin(), sub.prm.end());
+    out.ops.push_back((uint8_t)OP_LAG);
+    out.n_lag++;
+    return;
+  }
   if (nd.left < 0) {
     out.ops.push_back((uint8_t)nd.op);
     switch (nd.op) {
       case OP_WN: case OP_CONST: out.prm.push_back(nd.prm[0]); break;
       case OP_SEL: out.prm.push_back(nd.prm[0]); out.n_cp++; break;     // uses one per-point LDS table
       case OP_LIN: out.prm.insert(out.prm.end(), {nd.prm[0], nd.prm[1], nd.prm[2]}); break;
-      case OP_SE:
-        out.prm.insert(out.prm.end(), {1.0 / (nd.prm[0] * nd.prm[0]), nd.prm[1]});
-        if (lag) { out.ops.back() = (uint8_t)OP_LAG_SE; out.n_lag++; }
-        break;
+      case OP_SE: out.prm.insert(out.prm.end(), {1.0 / (nd.prm[0] * nd.prm[0]), nd.prm[1]}); break;
       case OP_GE:
-        if (lag) {
-          out.ops.back() = (uint8_t)OP_LAG_GE; out.n_lag++;
-          out.prm.insert(out.prm.end(), {1.0 / nd.prm[0], nd.prm[1], nd.prm[2]});
-        } else if (ge_tab) {       // (|dt|/l)^gamma from the data set's log|dt| table (l <= 0 gives NaN, as a negative base would)
+        if (ge_tab) {       // (|dt|/l)^gamma from the data set's log|dt| table (l <= 0 gives NaN, as a negative base would)
           out.ops.back() = (uint8_t)OP_GE_TAB;
           out.uses_tab = true;
           out.prm.insert(out.prm.end(), {std::log(nd.prm[0]), nd.prm[1], nd.prm[2]});
@@ -371,14 +397,13 @@ void emit(const std::vector<CNode>& nodes, int id, Compiled& out, bool ge_tab, b
         break;
       case OP_PER:
         out.prm.insert(out.prm.end(), {-2.0 / (nd.prm[0] * nd.prm[0]), M_PI / nd.prm[1], nd.prm[2]});
-        if (lag) { out.ops.back() = (uint8_t)OP_LAG_PER; out.n_lag++; }
         break;
     }
     return;
   }
   const bool swap = nodes[nd.right].need > nodes[nd.left].need;
-  emit(nodes, swap ? nd.right : nd.left, out, ge_tab, lag);
-  emit(nodes, swap ? nd.left : nd.right, out, ge_tab, lag);
+  emit(nodes, swap ? nd.right : nd.left, out, ge_tab, lag, stat, heavy);
+  emit(nodes, swap ? nd.left : nd.right, out, ge_tab, lag, stat, heavy);
   if (nd.op == OP_CP) {
     out.ops.push_back((uint8_t)(swap ? OP_CP_SWAP : OP_CP));
     out.prm.push_back(nd.prm[0]);
@@ -427,12 +452,18 @@ const char* compile_program(const uint8_t* ops, int n_ops, const double* prm, in
   if (ip != n_prm) return "parameter count mismatch";
   out.depth_need = nodes[stack[0]].need;
   if (out.depth_need > 8) return "kernel tree needs an evaluation stack deeper than 8";
-  emit(nodes, stack[0], out, ge_tab, lag);
-  if (lag && out.n_cp + out.n_lag > COV_MAX_TABLES) {      // (a 63-node tree has at most 32 leaves + 31 ChangePoints: does not happen below 75 nodes)
-    Compiled plain;
-    emit(nodes, stack[0], plain, false, false);
-    plain.depth_need = out.depth_need;
-    out = plain;
+  if (lag) {
+    std::vector<char> stat(nodes.size(), 0), heavy(nodes.size(), 0);
+    classify(nodes, stack[0], stat, heavy);
+    emit(nodes, stack[0], out, false, true, &stat, &heavy);
+    if (out.n_cp + out.n_lag > COV_MAX_TABLES) {      // (a 63-node tree has at most 32 leaves + 31 ChangePoints: does not happen below 75 nodes)
+      Compiled plain;
+      emit(nodes, stack[0], plain, false, false);
+      plain.depth_need = out.depth_need;
+      out = plain;
+    }
+  } else {
+    emit(nodes, stack[0], out, ge_tab, false);
   }
   if (out.n_cp > COV_MAX_TABLES) return "kernel tree needs more per-point LDS tables (ChangePoint nodes + component selectors) than fit 160 KiB";
   out.root = stack[0];
@@ -450,7 +481,10 @@ struct Batch {
   int max_cp = 0;
   int max_depth = 1;
   int max_cp_fused = 0, max_depth_fused = 1;
-  int n_lag_tables = 0;           // OP_LAG_* leaves of the whole batch (one table set each, k_lag_tables)
+  int n_lag_tables = 0;           // OP_LAG leaves of the whole batch (one table set each, k_lag_tables)
+  std::vector<LagTabHdr> thdr;    // their programs, offsets into tops / tprm
+  std::vector<uint8_t> tops;
+  std::vector<double> tprm;
   // gradient programs (sorted order), built on request
   std::vector<GProgHdr> ghdr;
   std::vector<uint8_t> gops, glc, grc;
@@ -468,7 +502,7 @@ double op_cost_us(int op) {
     case OP_SE: return 7.0;
     case OP_LIN: return 2.0;
     case OP_CP: case OP_CP_SWAP: return 2.0;
-    case OP_LAG_SE: case OP_LAG_GE: case OP_LAG_PER: return 2.0;      // one LDS read per element: what is left is the interpreter's per-node latency (as for Linear)
+    case OP_LAG: return 2.0;      // one LDS read per element: what is left is the interpreter's per-node latency (as for Linear)
     default: return 0.6;
   }
 }
@@ -543,6 +577,12 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
     h.flags = cp.uses_tab ? 1 : 0;
     h.n_lag = cp.n_lag; h.lag_off = bt.n_lag_tables;
     bt.n_lag_tables += cp.n_lag;
+    for (LagTabHdr th : cp.thdr) {
+      th.op_off += (int32_t)bt.tops.size(); th.prm_off += (int32_t)bt.tprm.size();
+      bt.thdr.push_back(th);
+    }
+    bt.tops.insert(bt.tops.end(), cp.tops.begin(), cp.tops.end());
+    bt.tprm.insert(bt.tprm.end(), cp.tprm.begin(), cp.tprm.end());
     bt.hdr[q] = h;
     bt.ops.insert(bt.ops.end(), cp.ops.begin(), cp.ops.end());
     bt.prm.insert(bt.prm.end(), cp.prm.begin(), cp.prm.end());
@@ -574,6 +614,8 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   // keep ops 4-byte padded; the evaluator reads three parameters per leaf unconditionally
   while (bt.ops.size() % 4) bt.ops.push_back(0);
   bt.prm.push_back(0.0); bt.prm.push_back(0.0);
+  while (bt.tops.size() % 4) bt.tops.push_back(0);
+  bt.tprm.push_back(0.0); bt.tprm.push_back(0.0); bt.tprm.push_back(0.0);
   return AGP_OK;
 }
 
@@ -1054,7 +1096,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     const size_t o_ops = al16(o_map + sizeof(int32_t) * (size_t)P);
     const size_t o_src = al16(o_ops + bt.ops.size() + 4);                       // resident-factor slots / first rows (n_hit > 0)
     const size_t o_i0 = al16(o_src + (n_hit > 0 ? sizeof(int32_t) * (size_t)P : 0));
-    const size_t stage_bytes = al16(o_i0 + (n_hit > 0 ? sizeof(int32_t) * (size_t)P : 0));
+    const size_t o_thdr = al16(o_i0 + (n_hit > 0 ? sizeof(int32_t) * (size_t)P : 0));      // lag-table programs (lag sweeps)
+    const size_t o_tprm = al16(o_thdr + sizeof(LagTabHdr) * bt.thdr.size());
+    const size_t o_tops = al16(o_tprm + sizeof(double) * bt.tprm.size());
+    const size_t stage_bytes = al16(o_tops + bt.tops.size() + 4);
     HIPCHK(c, s->stage.ensure(stage_bytes));
     HIPCHK(c, s->h_stage.ensure(stage_bytes));
     {
@@ -1068,6 +1113,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       if (n_hit > 0) {
         std::memcpy(h + o_src, src_slot.data(), sizeof(int32_t) * (size_t)P);
         std::memcpy(h + o_i0, i0v.data(), sizeof(int32_t) * (size_t)P);
+      }
+      if (!bt.thdr.empty()) {
+        std::memcpy(h + o_thdr, bt.thdr.data(), sizeof(LagTabHdr) * bt.thdr.size());
+        std::memcpy(h + o_tprm, bt.tprm.data(), sizeof(double) * bt.tprm.size());
+        std::memcpy(h + o_tops, bt.tops.data(), bt.tops.size());
       }
     }
     char* dstage = static_cast<char*>(s->stage.p);
@@ -1102,8 +1152,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       // the sweep's lag tables: every stationary leaf of every particle at the 255 lags of each of the nt block diagonals
       HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * nt * 256));
       LagArgs la = {};
-      la.tt = c->d_ts_s; la.hdr = d_hdr; la.ops = d_ops; la.prm = d_prm; la.tab = s->lagtab.as<double>(); la.nt = nt; la.P = P;
-      hipLaunchKernelGGL(k_lag_tables, dim3(nt, P), dim3(256), 0, st, la);
+      la.tt = c->d_ts_s; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
+      la.tops = reinterpret_cast<const uint8_t*>(dstage + o_tops); la.tprm = reinterpret_cast<const double*>(dstage + o_tprm);
+      la.tab = s->lagtab.as<double>(); la.nt = nt; la.n_tables = bt.n_lag_tables;
+      hipLaunchKernelGGL(k_lag_tables, dim3(nt, bt.n_lag_tables), dim3(256), 0, st, la);
       HIPCHK(c, hipGetLastError());
     }
     size_t ev_h2d = pf.mark();
