@@ -457,22 +457,54 @@ def main():
             ids = [None]; err = str(e)
         dist.broadcast_object_list(ids, src=0)
         if ids[0] is not None:
-            try:
-                eng.comm_init_rank(ids[0], world, rank)
-                ranks_seen = eng.comm_count()
-            except Exception as e:      # noqa: BLE001
-                err = str(e)
+            # (a communicator bootstrap that can neither succeed nor fail — e.g. no usable network interface — must not hang
+            # the benchmark: it runs in a thread and is abandoned after AGP_BENCH_COMM_TIMEOUT_S seconds)
+            import threading
+            res = {}
+
+            def _init():
+                try:
+                    eng.comm_init_rank(ids[0], world, rank)
+                    res["n"] = eng.comm_count()
+                except Exception as e:      # noqa: BLE001
+                    res["err"] = str(e)
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("AGP_BENCH_COMM_TIMEOUT_S", "180")))
+            if th.is_alive():
+                err = "agp_comm_init_rank did not return (timeout)"
+            elif "err" in res:
+                err = res["err"]
+            else:
+                ranks_seen = res.get("n")
         else:
             err = err or "rank 0 could not create the RCCL id"
         flag = torch.tensor([0 if err else 1], dtype=torch.int64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            # safety net for the scaling run only: the same all-gather through torch.distributed's RCCL group
+            # safety nets for the scaling run only: the same all-gather through torch.distributed's RCCL group, and if that
+            # cannot be formed either, through the host over gloo — the line says which one ran
             print(f"[bench rank {rank}] engine communicator unavailable ({err or 'another rank failed'}); "
                   f"falling back to torch.distributed nccl", file=sys.stderr, flush=True)
-            nccl_group = dist.new_group(backend="nccl")
-            collective = "torch.distributed nccl (fallback; engine communicator failed to initialise)"
             ranks_seen = None
+            ok_nccl = 1
+            try:
+                nccl_group = dist.new_group(backend="nccl")
+                probe = torch.zeros(world, dtype=torch.float64, device=f"cuda:{local_rank}")
+                dist.all_gather_into_tensor(probe, torch.ones(1, dtype=torch.float64, device=f"cuda:{local_rank}"), group=nccl_group)
+                torch.cuda.synchronize()
+            except Exception as e:          # noqa: BLE001
+                ok_nccl = 0
+                print(f"[bench rank {rank}] torch.distributed nccl unavailable too ({e}); log-weights travel through the host (gloo)",
+                      file=sys.stderr, flush=True)
+            okf = torch.tensor([ok_nccl], dtype=torch.int64)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 1:
+                collective = "torch.distributed nccl (fallback; engine communicator failed to initialise: " + (err or "another rank failed")[:120] + ")"
+            else:
+                nccl_group = None
+                share = True             # (same data path as the shared-GPU test mode: device -> host -> gloo all-gather -> device)
+                collective = "gloo through the host (fallback; neither the engine's nor torch's RCCL communicator could be formed)"
     n = args.n
     ts, xs = pkg.prior.synthetic_series(n, seed=2048, shuffle=True)
     P_total = args.particles * world if args.weak else args.particles
