@@ -473,6 +473,9 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     if (AGP_EXP_TABLE && !LAGM && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];      // (lag sweeps evaluate no exponential)
     // (program, parameters, time points and lag tables travel in ONE round trip; the prologue's barrier publishes all of it)
     cov_prologue<LAGM>(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt);
+#ifdef AGP_PROBE_PROLOGUE
+    if (FLOW) AGP_PROBE(2);          // (measurement build: "stage" column of the flow trace = end of the tile prologue)
+#endif
     const double noise = a.noise[p];
     // GammaExp leaves read log|dt| from the data set's table (L2 / Infinity-Cache resident: every particle reads
     // the same 128 KiB tile); the loads are issued at the top of the pass and consumed by the first such leaf
@@ -487,6 +490,9 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
       for (int r = 0; r < 4; ++r) ltn[r] = ltile[(cbn * 16 + 4 * r + lq) * NB + rsn];
     };
     if (use_tab) fetch_lt(0);
+    const bool one_node = LAGM && h.n_ops == 1;
+    const int op1 = one_node ? __builtin_amdgcn_readfirstlane(ops[0]) : -1;
+    const double q0 = one_node ? prm[0] : 0.0, q1 = one_node ? prm[1] : 0.0, q2 = one_node ? prm[2] : 0.0;
 #pragma unroll 1
     for (int t = 0; t < 16; ++t) {
       const int cb = t >> 1, st = t & 1;
@@ -503,7 +509,26 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
         tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
         ri[r] = rslot; ci[r] = NB + cslot;
       }
-      eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt);
+      if (LAGM && one_node) {
+        // one-node program of a lag sweep (three quarters of a prior-sampled population once stationary subtrees are tables):
+        // no interpreter — the pass costs four LDS reads (or four Linear products) instead of ~2 us of opcode / parameter /
+        // stack latency
+        if (op1 == OP_LAG) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[r] = lagt[ri[r] - ci[r] + (2 * NB - 1)];
+        } else if (op1 == OP_LIN) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[r] = q1 + q2 * ((tr[r] - q0) * (tc[r] - q0));
+        } else if (op1 == OP_CONST) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[r] = q0;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[r] = (tr[r] == tc[r]) ? q0 : 0.0;        // OP_WN
+        }
+      } else {
+        eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt);
+      }
       d4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -735,7 +760,9 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     }
     __syncthreads();
     }
+#ifndef AGP_PROBE_PROLOGUE
     if (FLOW) AGP_PROBE(2);
+#endif
     // With acc = -C:  t = acc_jb + sum_lb L(jb,lb) X_lb = -(C_jb - sum L X),  X_jb = (-W_jb) t.
 #pragma unroll
     for (int jb = 0; jb < NSB; ++jb) {
@@ -920,6 +947,9 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
       for (int r = 0; r < 4; ++r) ltn[r] = ltile[(cbn * 16 + 4 * r + lq) * NB + rsn];
     };
     if (use_tab) fetch_lt(0);
+    const bool one_node = LAGM && h.n_ops == 1;
+    const int op1 = one_node ? __builtin_amdgcn_readfirstlane(ops[0]) : -1;
+    const double q0 = one_node ? prm[0] : 0.0, q1 = one_node ? prm[1] : 0.0, q2 = one_node ? prm[2] : 0.0;
 #pragma unroll 1
     for (int e = 0; e < NE; ++e) {
       const bool s1 = e > wu;
@@ -937,7 +967,23 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
         tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
         ri[r] = rslot; ci[r] = NB + cslot;
       }
-      eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt);
+      if (LAGM && one_node) {       // (one-node program of a lag sweep: no interpreter, see chol_tile)
+        if (op1 == OP_LAG) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[r] = lagt[ri[r] - ci[r] + (2 * NB - 1)];
+        } else if (op1 == OP_LIN) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[r] = q1 + q2 * ((tr[r] - q0) * (tc[r] - q0));
+        } else if (op1 == OP_CONST) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[r] = q0;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[r] = (tr[r] == tc[r]) ? q0 : 0.0;
+        }
+      } else {
+        eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt);
+      }
       d4 v;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
