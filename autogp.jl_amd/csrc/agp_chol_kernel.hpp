@@ -490,7 +490,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
       for (int r = 0; r < 4; ++r) ltn[r] = ltile[(cbn * 16 + 4 * r + lq) * NB + rsn];
     };
     if (use_tab) fetch_lt(0);
-    const bool one_node = LAGM && h.n_ops == 1;
+    const bool one_node = h.n_ops == 1;
     const int op1 = one_node ? __builtin_amdgcn_readfirstlane(ops[0]) : -1;
     const double q0 = one_node ? prm[0] : 0.0, q1 = one_node ? prm[1] : 0.0, q2 = one_node ? prm[2] : 0.0;
 #pragma unroll 1
@@ -509,23 +509,11 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
         tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
         ri[r] = rslot; ci[r] = NB + cslot;
       }
-      if (LAGM && one_node) {
-        // one-node program of a lag sweep (three quarters of a prior-sampled population once stationary subtrees are tables):
-        // no interpreter — the pass costs four LDS reads (or four Linear products) instead of ~2 us of opcode / parameter /
-        // stack latency
-        if (op1 == OP_LAG) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) out[r] = lagt[ri[r] - ci[r] + (2 * NB - 1)];
-        } else if (op1 == OP_LIN) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) out[r] = q1 + q2 * ((tr[r] - q0) * (tc[r] - q0));
-        } else if (op1 == OP_CONST) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) out[r] = q0;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) out[r] = (tr[r] == tc[r]) ? q0 : 0.0;        // OP_WN
-        }
+      if (one_node) {
+        // one-node program (three quarters of a prior-sampled population in a lag sweep — stationary subtrees are tables —,
+        // two thirds otherwise): no interpreter, the pass is the leaf's arithmetic alone instead of ~2 us of opcode /
+        // parameter / stack latency around it
+        eval_leaf<4, (LAGM ? 3 : TAB ? 2 : 1)>(op1, q0, q1, q2, sig, lagt, tr, tc, ri, ci, lt, etab, out);
       } else {
         eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt);
       }
@@ -947,7 +935,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
       for (int r = 0; r < 4; ++r) ltn[r] = ltile[(cbn * 16 + 4 * r + lq) * NB + rsn];
     };
     if (use_tab) fetch_lt(0);
-    const bool one_node = LAGM && h.n_ops == 1;
+    const bool one_node = h.n_ops == 1;
     const int op1 = one_node ? __builtin_amdgcn_readfirstlane(ops[0]) : -1;
     const double q0 = one_node ? prm[0] : 0.0, q1 = one_node ? prm[1] : 0.0, q2 = one_node ? prm[2] : 0.0;
 #pragma unroll 1
@@ -967,20 +955,8 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
         tr[r] = tpt[rslot]; tc[r] = tpt[NB + cslot];
         ri[r] = rslot; ci[r] = NB + cslot;
       }
-      if (LAGM && one_node) {       // (one-node program of a lag sweep: no interpreter, see chol_tile)
-        if (op1 == OP_LAG) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) out[r] = lagt[ri[r] - ci[r] + (2 * NB - 1)];
-        } else if (op1 == OP_LIN) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) out[r] = q1 + q2 * ((tr[r] - q0) * (tc[r] - q0));
-        } else if (op1 == OP_CONST) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) out[r] = q0;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) out[r] = (tr[r] == tc[r]) ? q0 : 0.0;
-        }
+      if (one_node) {       // (one-node program: no interpreter, see chol_tile)
+        eval_leaf<4, (LAGM ? 3 : TAB ? 2 : 1)>(op1, q0, q1, q2, sig, lagt, tr, tc, ri, ci, lt, etab, out);
       } else {
         eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt);
       }

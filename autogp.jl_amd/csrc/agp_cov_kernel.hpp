@@ -108,22 +108,70 @@ __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, cons
   }
 }
 
-// Evaluate the program at E (row, column) pairs.  tr/tc: time values; ri/ci: indices into the sigma
-// tables (row slot 0..127, column slot 128..255).  All arrays are statically indexed registers.
+// One leaf of the program at E (row, column) pairs: v[e] = leaf(o; p0, p1, p2).  tr / tc: time values; ri / ci: indices into the
+// per-point tables (row slot 0..127, column slot 128..255); lt: log|t_row - t_col| from the data set's table (OP_GE_TAB);
+// sg: this leaf's per-point table (OP_SEL); lg: this leaf's lag table (OP_LAG), element (ri, ci) reads lg[ri - ci + 255].
 // GEMODE: 0 = every leaf kind (OP_GE computes the power, OP_GE_TAB reads the log|dt| table, OP_LAG reads the tile's lag
 // tables), 1 = OP_GE only, 2 = OP_GE_TAB only, 3 = lag tables only: no per-element transcendental code at all (the
 // instantiations inside the factorisation kernel carry one kind, which keeps the unused code out of their register budget).
-// lag: the tile's lag tables (after the per-point tables), element (row slot ri, column slot ci - 128) reads entry
-// ri - (ci - 128) + 127.
+template <int E, int GEMODE>
+__device__ __forceinline__ void eval_leaf(const int o, const double p0, const double p1, const double p2,
+                                          const double* sg, const double* lg,
+                                          const double (&tr)[E], const double (&tc)[E],
+                                          const int (&ri)[E], const int (&ci)[E], const double (&lt)[E],
+                                          const double* etab, double (&v)[E]) {
+  auto ex = [&](double x) { return (AGP_EXP_TABLE != 0) ? fm::exp_t(x, etab) : fm::exp_f(x); };
+  if (o == OP_SEL) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = sg[ri[e]] * sg[ci[e]];
+  } else if (o == OP_WN) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = (tr[e] == tc[e]) ? p0 : 0.0;
+  } else if (o == OP_CONST) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = p0;
+  } else if (o == OP_LIN) {
+    // bias + amp * (ti - c)(tj - c)
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = p1 + p2 * ((tr[e] - p0) * (tc[e] - p0));
+  } else if ((GEMODE == 0 || GEMODE == 3) && (GEMODE == 3 || o == OP_LAG)) {
+    // stationary subtree of a sorted regular grid: the tile's lag table
+    const double* lq_ = lg + (2 * NB - 1);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = lq_[ri[e] - ci[e]];
+  } else if (GEMODE != 3) {
+    // stationary leaves: amp * exp(arg)
+    double arg[E];
+    const double amp = (o == OP_SE) ? p1 : p2;
+    if (o == OP_SE) {          // p0 = 1/l^2
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const double dx = tr[e] - tc[e];
+        arg[e] = ((-0.5 * dx) * dx) * p0;
+      }
+    } else if (GEMODE != 2 && o == OP_GE) {   // p0 = 1/l, p1 = gamma
+#pragma unroll
+      for (int e = 0; e < E; ++e) arg[e] = -fm::pow_f(fabs(tr[e] - tc[e]) * p0, p1);
+    } else if (GEMODE != 1 && (o == OP_GE_TAB || (GEMODE == 2 && o == OP_GE))) {   // p0 = log l, p1 = gamma
+#pragma unroll
+      for (int e = 0; e < E; ++e) arg[e] = -ex(p1 * (lt[e] - p0));
+    } else {                   // OP_PER: p0 = -2/l^2, p1 = pi/p
+#pragma unroll
+      for (int e = 0; e < E; ++e) arg[e] = p0 * fm::sin2_f(p1 * fabs(tr[e] - tc[e]));
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = amp * ex(arg[e]);
+  }
+}
+
+// Evaluate the program at E (row, column) pairs.  All arrays are statically indexed registers.  lag: the tile's lag tables
+// (after the per-point tables); etab: LDS copy of fm::c_exp_tab (fm::exp_t, 11 fp64 operations instead of exp_f's 21).
 template <int D, int E, int GEMODE = 0, typename OpT>
 __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __restrict__ ops,
                                              const double* __restrict__ prm, const double* sig,
                                              const double (&tr)[E], const double (&tc)[E],
                                              const int (&ri)[E], const int (&ci)[E], const double (&lt)[E],
                                              double (&out)[E], const double* etab = nullptr, const double* lag = nullptr) {
-  // lt: log|t_row - t_col| of the E elements from the data set's table (only read by OP_GE_TAB leaves)
-  // etab: LDS copy of fm::c_exp_tab (fm::exp_t, 11 fp64 operations instead of exp_f's 21)
-  auto ex = [&](double x) { return (AGP_EXP_TABLE != 0) ? fm::exp_t(x, etab) : fm::exp_f(x); };
   double st[D][E];
 #pragma unroll
   for (int d = 0; d < D; ++d)
@@ -131,7 +179,6 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
     for (int e = 0; e < E; ++e) st[d][e] = 0.0;
 
   int q = 0, cpi = 0, li = 0;
-  (void)li;
   for (int ip = 0; ip < h.n_ops; ++ip) {
     // the opcode is wave-uniform: keep it (and the dispatch on it) on the scalar unit
     const int o = __builtin_amdgcn_readfirstlane((int)ops[ip]);
@@ -141,50 +188,9 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
       // carry two doubles of tail padding — and picked by opcode afterwards
       const double p0 = prm[q], p1 = prm[q + 1], p2 = prm[q + 2];
       double v[E];
-      if (o == OP_SEL) {
-        const double* sg = sig + cpi * 256;
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = sg[ri[e]] * sg[ci[e]];
-        ++cpi;
-      } else if (o == OP_WN) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = (tr[e] == tc[e]) ? p0 : 0.0;
-      } else if (o == OP_CONST) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = p0;
-      } else if (o == OP_LIN) {
-        // bias + amp * (ti - c)(tj - c)
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = p1 + p2 * ((tr[e] - p0) * (tc[e] - p0));
-      } else if ((GEMODE == 0 || GEMODE == 3) && (GEMODE == 3 || o == OP_LAG)) {
-        // stationary subtree of a sorted regular grid: the tile's lag table
-        const double* lg = lag + li * 256 + (2 * NB - 1);
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = lg[ri[e] - ci[e]];
-        ++li;
-      } else if (GEMODE != 3) {
-        // stationary leaves: amp * exp(arg)
-        double arg[E];
-        const double amp = (o == OP_SE) ? p1 : p2;
-        if (o == OP_SE) {          // p0 = 1/l^2
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const double dx = tr[e] - tc[e];
-            arg[e] = ((-0.5 * dx) * dx) * p0;
-          }
-        } else if (GEMODE != 2 && o == OP_GE) {   // p0 = 1/l, p1 = gamma
-#pragma unroll
-          for (int e = 0; e < E; ++e) arg[e] = -fm::pow_f(fabs(tr[e] - tc[e]) * p0, p1);
-        } else if (GEMODE != 1 && (o == OP_GE_TAB || (GEMODE == 2 && o == OP_GE))) {   // p0 = log l, p1 = gamma
-#pragma unroll
-          for (int e = 0; e < E; ++e) arg[e] = -ex(p1 * (lt[e] - p0));
-        } else {                   // OP_PER: p0 = -2/l^2, p1 = pi/p
-#pragma unroll
-          for (int e = 0; e < E; ++e) arg[e] = p0 * fm::sin2_f(p1 * fabs(tr[e] - tc[e]));
-        }
-#pragma unroll
-        for (int e = 0; e < E; ++e) v[e] = amp * ex(arg[e]);
-      }
+      eval_leaf<E, GEMODE>(o, p0, p1, p2, sig + cpi * 256, lag + li * 256, tr, tc, ri, ci, lt, etab, v);
+      if (o == OP_SEL) ++cpi;
+      if (o == OP_LAG) ++li;
 #pragma unroll
       for (int d = D - 1; d > 0; --d)
 #pragma unroll
