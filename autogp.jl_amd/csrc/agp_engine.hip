@@ -74,6 +74,8 @@ struct Slot {
   std::vector<hipEvent_t> events;
   std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
   std::vector<hipEvent_t> sub_ev;     // fork / join events
+  hipStream_t gq[3] = {nullptr, nullptr, nullptr};     // gradient sweeps: the contraction's launch classes run side by side
+  hipEvent_t gq_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   bool busy = false;
   // asynchronous hand-back (agp_logpdf_batch_device on a caller stream): the slot stays reserved until `done`,
   // recorded behind the call's last launch, has completed
@@ -94,6 +96,8 @@ struct Slot {
     sub_ev.clear();
     for (auto q : sub) (void)hipStreamDestroy(q);
     sub.clear();
+    for (auto& q : gq) { if (q) (void)hipStreamDestroy(q); q = nullptr; }
+    for (auto& e : gq_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
   }
@@ -157,6 +161,11 @@ struct agp_ctx {
   // x) and evaluate stationary leaves from per-tile lag tables (OP_LAG_*, agp_cov_kernel.hpp).  env AGP_LAG=0 disables.
   double* d_ts_s = nullptr;
   double* d_xs_s = nullptr;
+  int32_t* d_rank = nullptr;     // rank of resident point i in the sorted series (lag-domain gradient contraction, k_kinv_tiles)
+  double t_ref = 0.0;            // middle of the series: reference time of the Linear moments there
+  int grad_fork = 1;             // the gradient contraction's launch classes on separate streams; env AGP_GRAD_FORK
+  int grad_lagdom = 1;           // gradient sweeps on a regular grid: lag-domain contraction where the kernel allows; env AGP_GRAD_LAGDOM
+  int64_t n_lagdom_particles = 0;   // particles contracted in the lag domain so far (agp_get_lag_stats)
   bool lag_ok = false;
   int lag_enable = 1;
   int64_t n_lag_sweeps = 0;       // sweeps that took the lag path (agp_get_lag_stats)
@@ -1007,6 +1016,29 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
   if (go && n > 23040) return fail(c, AGP_ERR_ARG, "gradient sweeps address a particle's packed matrix with 32-bit byte offsets: n <= 23040");
   if (lag) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_sweeps; }
+  // Gradient sweeps on a regular grid (any order of the points): particles whose kernel is a sum of stationary subtrees and
+  // Linear leaves are contracted in the lag domain (k_kinv_tiles / k_lag_grad, agp_grad_kernel.hpp)
+  if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->grad_split && c->n_max <= LAGDOM_MAX_BINS) {
+    int64_t n_cov = 0;
+    for (int q = 0; q < P; ++q) {
+      GProgHdr& g = bt.ghdr[q];
+      if (g.n_cp > 0 || g.n_ops > 64) continue;
+      uint8_t stat[64], cov[64];
+      for (int i = 0; i < g.n_ops; ++i) {
+        const int o = bt.gops[g.node_off + i], li = bt.glc[g.node_off + i], ri = bt.grc[g.node_off + i];
+        if (o == OP_PLUS || o == OP_TIMES) {
+          stat[i] = stat[li] && stat[ri];
+          cov[i] = stat[i] || (o == OP_PLUS && cov[li] && cov[ri]);
+        } else {
+          stat[i] = (o == OP_SE || o == OP_GE || o == OP_PER || o == OP_CONST || o == OP_WN);
+          cov[i] = stat[i] || o == OP_LIN;
+        }
+      }
+      if (g.n_ops > 0 && cov[g.n_ops - 1]) { g.flags |= GFLAG_LAGDOM; ++n_cov; }
+    }
+    std::lock_guard<std::mutex> g(c->mu);
+    c->n_lagdom_particles += n_cov;
+  }
   const int n_prm_total = prm_off[P];
   if (go && n == 0) {
     for (int i = 0; i < n_prm_total; ++i) go->grad[i] = 0.0;
@@ -1301,6 +1333,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           ga.tt = c->d_ts; ga.logdt = c->logdt_ok ? c->d_logdt : nullptr; ga.gpart = s->gpart.as<double>() + (size_t)g0 * ntiles * gstride; ga.gstride = gstride;
           ga.gmap = s->gmap.as<int32_t>(); ga.out_off = s->goff.as<int32_t>() + p0 + g0;
           ga.pmap = d_map + p0 + g0; ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
+          ga.rank = c->d_rank; ga.tts = c->d_ts_s; ga.nbins = (int)c->n_max; ga.tref = c->t_ref;
           if (n_hit > 0) {
             ga.lslot = d_src + p0 + g0; ga.Lsrc = c->store.A.as<double>(); ga.Lstride = c->store.strideA;
             ga.Wsrc = c->store.W.as<double>(); ga.Wnt = c->store.nt_cap;
@@ -1317,7 +1350,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           }
           const size_t gm1 = pf.mark(q);
           pf.span(8, gm0, gm1);
-          hipLaunchKernelGGL(k_alpha, dim3(nt, Pg), dim3(256), 0, q, ga);
+          if (!c->trtri_chain) hipLaunchKernelGGL(k_alpha, dim3(nt, Pg), dim3(256), 0, q, ga);      // (the chain kernel forms alpha itself)
           size_t gm2 = pf.mark(q);
           pf.span(11, gm1, gm2);
           // One contraction launch per group, largest trees first (their workgroups run longest); the 16-node
@@ -1326,7 +1359,14 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           std::vector<int32_t>& pl = pls.back();          // outlives the async upload (synchronised at the end of the call)
           int max_nodes = 0;
           for (int r = 0; r < Pg; ++r) { pl[r] = r; max_nodes = std::max(max_nodes, (int)bt.ghdr[p0 + g0 + r].n_ops); }
-          std::stable_sort(pl.begin(), pl.end(), [&](int a_, int b_) { return bt.ghdr[p0 + g0 + a_].n_ops > bt.ghdr[p0 + g0 + b_].n_ops; });
+          // (lag-domain particles behind the others: the contraction launches below take the first Pn entries, k_lag_grad the rest)
+          auto lagdom = [&](int r) { return (bt.ghdr[p0 + g0 + r].flags & GFLAG_LAGDOM) != 0; };
+          std::stable_sort(pl.begin(), pl.end(), [&](int a_, int b_) {
+            if (lagdom(a_) != lagdom(b_)) return lagdom(b_);
+            return bt.ghdr[p0 + g0 + a_].n_ops > bt.ghdr[p0 + g0 + b_].n_ops;
+          });
+          int Pn = 0;
+          for (int r = 0; r < Pg; ++r) Pn += !lagdom(r);
           int32_t* d_pl = s->plist.as<int32_t>() + p0 + g0;
           HIPCHK(c, hipMemcpyAsync(d_pl, pl.data(), sizeof(int32_t) * Pg, hipMemcpyHostToDevice, q));
           ga.plist = d_pl;
@@ -1339,21 +1379,40 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             // three classes by tree size (the particle list is sorted by it): > 16 nodes and 9 .. 16 nodes keep their tape
             // in private memory, trees of <= 8 nodes — the bulk of a prior-sampled population — keep it in LDS
             int n_big = 0, n_mid = 0;
-            for (int r = 0; r < Pg; ++r) {
+            for (int r = 0; r < Pn; ++r) {
               const int no = bt.ghdr[p0 + g0 + pl[r]].n_ops;
               n_big += no > 16; n_mid += (no <= 16 && (no > LDS_TAPE_NODES || !c->grad_lds_tape));
             }
-            const int n_small = Pg - n_big - n_mid;
+            const int n_small = Pn - n_big - n_mid;
+            // The launch classes are independent and each ends on a few long-running workgroups (the largest trees; the
+            // 64-node class alone: ~2 000 workgroups of ~1 ms at n=2048): they run side by side on three more streams,
+            // forked behind the K^-1 tiles and joined in front of the reduction.
+            const bool fork = c->grad_fork != 0;
+            hipStream_t qs[4] = {q, q, q, q};
+            if (fork) {
+              for (int i2 = 0; i2 < 3; ++i2) if (!s->gq[i2]) HIPCHK(c, hipStreamCreateWithFlags(&s->gq[i2], hipStreamNonBlocking));
+              for (int i2 = 0; i2 < 4; ++i2) if (!s->gq_ev[i2]) HIPCHK(c, hipEventCreateWithFlags(&s->gq_ev[i2], hipEventDisableTiming));
+              HIPCHK(c, hipEventRecord(s->gq_ev[3], q));
+              for (int i2 = 0; i2 < 3; ++i2) { HIPCHK(c, hipStreamWaitEvent(s->gq[i2], s->gq_ev[3], 0)); qs[i2 + 1] = s->gq[i2]; }
+            }
             GradArgs gs = ga;
-            if (n_big > 0) HIPCHK(c, launch_grad_contract<64>(q, gs, ntiles, n_big, lds2));
+            if (n_big > 0) HIPCHK(c, launch_grad_contract<64>(qs[0], gs, ntiles, n_big, lds2));
             gs.plist = d_pl + n_big;
-            if (n_mid > 0) HIPCHK(c, launch_grad_contract<16>(q, gs, ntiles, n_mid, lds2));
+            if (n_mid > 0) HIPCHK(c, launch_grad_contract<16>(qs[1], gs, ntiles, n_mid, lds2));
             if (n_small > 0) {
               gs.plist = d_pl + n_big + n_mid;
               gs.tape_off = (int)((lds2 + 15) / 16 * 2);                                  // doubles, 16-byte aligned
               const size_t lds3 = (size_t)gs.tape_off * 8 + sizeof(double) * LDS_TAPE_NODES * 4 * 256;
-              HIPCHK(c, launch_grad_contract<0>(q, gs, ntiles, n_small, lds3));
+              HIPCHK(c, launch_grad_contract<0>(qs[2], gs, ntiles, n_small, lds3));
             }
+            if (Pn < Pg) {
+              gs.plist = d_pl + Pn;
+              const size_t lds4 = sizeof(double) * ((size_t)c->n_max + bt.g_max_prm + 3 + bt.g_max_nodes + 16 + bt.g_max_prm);
+              hipLaunchKernelGGL(k_lag_grad, dim3(Pg - Pn), dim3(256), lds4, qs[3], gs);
+              HIPCHK(c, hipGetLastError());
+            }
+            if (fork)
+              for (int i2 = 0; i2 < 3; ++i2) { HIPCHK(c, hipEventRecord(s->gq_ev[i2], s->gq[i2])); HIPCHK(c, hipStreamWaitEvent(q, s->gq_ev[i2], 0)); }
             (void)max_nodes;
           } else {
             if (max_nodes <= 16) HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, Pg, lds));
@@ -1512,6 +1571,8 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_SPLIT_DIAG")) c->split_diag = atoi(e);
   if (const char* e = getenv("AGP_GE_TABLE")) c->ge_table = atoi(e) != 0;
   if (const char* e = getenv("AGP_LAG")) c->lag_enable = atoi(e) != 0;
+  if (const char* e = getenv("AGP_GRAD_LAGDOM")) c->grad_lagdom = atoi(e) != 0;
+  if (const char* e = getenv("AGP_GRAD_FORK")) c->grad_fork = atoi(e) != 0;
   if (const char* e = getenv("AGP_RIGHT_LOOKING")) c->right_looking = atoi(e);
   if (const char* e = getenv("AGP_HYBRID_BLOCKS")) c->hybrid_blocks = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
@@ -1557,6 +1618,7 @@ void agp_destroy(agp_ctx* c) {
   if (c->d_logdt) (void)hipFree(c->d_logdt);
   if (c->d_ts_s) (void)hipFree(c->d_ts_s);
   if (c->d_xs_s) (void)hipFree(c->d_xs_s);
+  if (c->d_rank) (void)hipFree(c->d_rank);
   if (c->d_flow_trace) (void)hipFree(c->d_flow_trace);
   delete c;
 }
@@ -1631,6 +1693,7 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
   c->lag_ok = false;
   if (c->d_ts_s) { HIPCHK(c, hipFree(c->d_ts_s)); c->d_ts_s = nullptr; }
   if (c->d_xs_s) { HIPCHK(c, hipFree(c->d_xs_s)); c->d_xs_s = nullptr; }
+  if (c->d_rank) { HIPCHK(c, hipFree(c->d_rank)); c->d_rank = nullptr; }
   if (c->lag_enable && n_max >= 2) {
     std::vector<int64_t> perm((size_t)n_max);
     for (int64_t i = 0; i < n_max; ++i) perm[(size_t)i] = i;
@@ -1649,6 +1712,11 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
       HIPCHK(c, hipMemset(c->d_xs_s, 0, sizeof(double) * npad));
       HIPCHK(c, hipMemcpy(c->d_ts_s, tss.data(), sizeof(double) * n_max, hipMemcpyHostToDevice));
       HIPCHK(c, hipMemcpy(c->d_xs_s, xss.data(), sizeof(double) * n_max, hipMemcpyHostToDevice));
+      std::vector<int32_t> rank((size_t)npad, 0);
+      for (int64_t i = 0; i < n_max; ++i) rank[(size_t)perm[(size_t)i]] = (int32_t)i;
+      HIPCHK(c, hipMalloc((void**)&c->d_rank, sizeof(int32_t) * npad));
+      HIPCHK(c, hipMemcpy(c->d_rank, rank.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice));
+      c->t_ref = 0.5 * (t0 + t1);
       c->lag_ok = true;
     }
   }
@@ -2937,6 +3005,19 @@ int agp_get_lag_stats(agp_ctx* c, int32_t* regular_grid, int64_t* n_lag_sweeps) 
 int agp_set_lag_tables(agp_ctx* c, int32_t on) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   c->lag_enable = on != 0;
+  return AGP_OK;
+}
+
+int agp_set_grad_lag_domain(agp_ctx* c, int32_t on) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  c->grad_lagdom = on != 0;
+  return AGP_OK;
+}
+
+int agp_get_grad_lag_domain_stats(agp_ctx* c, int64_t* n_particles) {
+  if (!c || !n_particles) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  *n_particles = c->n_lagdom_particles;
   return AGP_OK;
 }
 

@@ -153,6 +153,9 @@ struct GradArgs {
   const int32_t* lslot; const double* Lsrc; long long Lstride; const double* Wsrc; int Wnt;
   double* out_grad;
   double* out_gnoise;
+  // lag-domain contraction (regular time grids; see k_lag_grad): rank of every resident point in the sorted series, the sorted
+  // series itself, number of lag bins (= resident points), reference time of the Linear moments
+  const int32_t* rank; const double* tts; int nbins; double tref;
 };
 
 struct GProgHdr {
@@ -162,7 +165,10 @@ struct GProgHdr {
   int32_t n_prm;
   int32_t n_cp;
   int32_t flags;      // bit 0: the tree has GammaExp leaves (reads the log|dt| table when there is one)
+                      // bit 1: lag-domain contraction (k_kinv_tiles bins G by lag, k_lag_grad differentiates n lags instead of n^2 elements)
 };
+constexpr int GFLAG_LAGDOM = 2;
+constexpr int LAGDOM_MAX_BINS = 4096;      // LDS histogram of k_kinv_tiles (32 KiB)
 
 __device__ __forceinline__ long long zoff(int r, int k) { return tile_off(k, r); }   // r <= k
 
@@ -244,6 +250,10 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
   const double* __restrict__ Lp = lsl >= 0 ? a.Lsrc + (long long)lsl * a.Lstride : a.A + (long long)p * a.strideA;
   const double* __restrict__ Wp = lsl >= 0 ? a.Wsrc + (long long)lsl * a.Wnt * NSB * 256 : a.W + (long long)p * a.nt * NSB * 256;
   double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
+  // alpha_j = sum_{i >= j} Z(j,i) beta_i is formed here, from the tiles while they are in registers (a separate pass over Z
+  // — k_alpha, what the per-column variant runs — read all 9 GB of it again: 2.3 ms per 512-particle sweep at n=2048)
+  const double* __restrict__ bp = a.beta + (long long)p * a.ldv;
+  double al0 = 0.0, al1 = 0.0;
 #pragma unroll 1
   for (int i = j; i < a.nt; ++i) {
     // acc = -C,  C = d_ji I - sum_{k=j}^{i-1} Z(j,k) L(i,k)^T
@@ -266,8 +276,17 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
       for (int r = 0; r < 4; ++r) {
         d2 o2; o2.x = acc[cb][0][r]; o2.y = acc[cb][1][r];
         *reinterpret_cast<d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
+        const double bk = bp[i * NB + cb * 16 + 4 * r + lq];
+        al0 = fma(acc[cb][0][r], bk, al0); al1 = fma(acc[cb][1][r], bk, al1);
       }
     __syncthreads();      // the solve's LDS blocks are overwritten by the next contraction's first slab
+  }
+  // the four column groups of a row (lanes l15 + 16 lq) in a fixed order
+  al0 += __shfl_xor(al0, 16); al1 += __shfl_xor(al1, 16);
+  al0 += __shfl_xor(al0, 32); al1 += __shfl_xor(al1, 32);
+  if (lq == 0) {
+    d2 o2; o2.x = al0; o2.y = al1;
+    *reinterpret_cast<d2*>(a.alpha + (long long)p * a.ldv + j * NB + row0) = o2;
   }
 }
 
@@ -635,8 +654,18 @@ __global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
 }
 
 // ---- split variant: K^-1 tiles to memory (over the L buffer, dead by now), then a lean contraction ----
+//
+// Lag-domain particles (GFLAG_LAGDOM; regular time grid, kernel = sum of stationary subtrees and Linear leaves): on a regular
+// grid a stationary kernel's dK_ab/dtheta depends on the lag |rank_a - rank_b| alone, so
+//     sum_ab G_ab dK_ab/dtheta = sum_g D_g dk(g h)/dtheta,   D_g = sum over the pairs (a, b) at lag g of G_ab:
+// the contraction over n^2 elements (40-90 fp64 instructions per leaf and element) becomes one over n lags once G has been
+// summed along the (permuted) diagonals.  The tile's G = 1/2 (alpha alpha' - K^-1) goes from the accumulators into an LDS
+// histogram over the lags (fixed point: reproducible whatever the order of the atomics) and the histogram — not
+// the tile — is written to the tile's slot, together with the three moments sum G, sum G (t_a + t_b - 2 t_ref),
+// sum G (t_a - t_ref)(t_b - t_ref) that the Linear leaves' derivatives are polynomials of.  k_lag_grad finishes the job.
 __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
   __shared__ __attribute__((aligned(16))) double sm[2 * U_SLAB];
+  __shared__ __attribute__((aligned(16))) double bins[LAGDOM_MAX_BINS];
   // XCD-aware map (as in the factorisation kernels): block b runs on XCD b % 8; all tiles of a particle go to one XCD, in
   // tile order, so the row panel Z(i,.) shared by tiles (i,0..i) and the column panels stay in that XCD's L2 — with the
   // (tile, particle) grid every XCD streamed every particle's panels from HBM (~107 GB per 512-particle sweep at n=2048;
@@ -652,6 +681,9 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
   const int tj = tix - ti * (ti + 1) / 2;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   const int row0 = 32 * w + 2 * l15;
+  const bool lagdom = (a.ghdr[p].flags & GFLAG_LAGDOM) != 0;
+  if (lagdom)
+    for (int i = tid; i < a.nbins; i += 256) bins[i] = 0.0;       // (published by the barriers of the slab loop)
   const double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
   d4 acc[NSB][2];
 #pragma unroll
@@ -661,6 +693,88 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
              Zp, [&](int s) { return (int)((zoff(tj, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
              sm, tid, l15, lq, row0);
   double* __restrict__ Kt = const_cast<double*>(a.A) + (long long)p * a.strideA + tile_off(ti, tj);
+  if (lagdom) {
+    // column side of the tile in LDS (the slab buffers are free): alpha_b, rank_b, t_b - t_ref
+    double* cal = sm;
+    double* ctm = sm + NB;
+    int* crk = reinterpret_cast<int*>(sm + 2 * NB);
+    const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
+    __syncthreads();
+    if (tid < NB) {
+      const int gb = tj * NB + tid;
+      cal[tid] = gb < a.n ? al[gb] : 0.0;
+      ctm[tid] = a.tt[gb] - a.tref;
+      crk[tid] = gb < a.n ? a.rank[gb] : -1;
+    }
+    __syncthreads();
+    const double wfac = (ti == tj) ? 0.5 : 1.0;          // G = 1/2 (...), off-diagonal tiles stand for their mirror image too
+    double ar[2], tr[2]; int rr[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int ga = ti * NB + row0 + s2;
+      ar[s2] = ga < a.n ? al[ga] : 0.0;
+      tr[s2] = a.tt[ga] - a.tref;
+      rr[s2] = ga < a.n ? a.rank[ga] : -1;
+    }
+    // G in place of the accumulators, the moments and max |G| of the tile
+    double m0 = 0.0, m1 = 0.0, m2 = 0.0, gmax = 0.0;
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = cb * 16 + 4 * r + lq;
+        const double ab = cal[c], tb = ctm[c];
+        const bool cv = crk[c] >= 0;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const double G = (cv && rr[s2] >= 0) ? wfac * (ar[s2] * ab - acc[cb][s2][r]) : 0.0;
+          acc[cb][s2][r] = G;
+          gmax = fmax(gmax, fabs(G));
+          m0 += G; m1 += G * (tr[s2] + tb); m2 += G * (tr[s2] * tb);
+        }
+      }
+    // (a NaN anywhere — a particle that was not positive definite — must reach the output: NaN-propagating maximum)
+    auto nmax = [](double x, double y) { return (y > x || y != y) ? y : x; };
+    if (m0 != m0) gmax = m0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmax = nmax(gmax, __shfl_xor(gmax, off));
+    if (l == 0) sm[4 * NB + w] = gmax;
+    __syncthreads();
+    gmax = nmax(nmax(sm[4 * NB], sm[4 * NB + 1]), nmax(sm[4 * NB + 2], sm[4 * NB + 3]));
+    // The histogram in 64-bit FIXED POINT: integer atomics commute, so all four waves add at once and the sums are still
+    // reproducible (fp64 LDS atomics would have to go wave after wave for that, and run at half the rate: 6.5 vs 3.8 us per tile,
+    // tools/native/lds_atomic_bench.hip — time the co-resident workgroup's slab loop cannot use the LDS either).  Scale 2^s with
+    // |G| 2^s < 2^51: a bin collects at most 256 elements of a tile (two per row), so the sums stay below 2^59; an element is
+    // rounded to 2^-52 of the tile's largest one, the resolution an fp64 running sum of that size has.  x + 1.5 * 2^52 leaves
+    // round(x) in the low mantissa bits (two's complement), so the conversion is one add and one 64-bit subtraction.
+    const bool finite = gmax < 1e300;
+    const int ex = (gmax > 0.0 && finite) ? ilogb(gmax) : 0;
+    const double scale = ldexp(1.0, 50 - ex), rscale = finite ? ldexp(1.0, ex - 50) : __builtin_nan("");
+    const double magic = 6755399441055744.0;
+    unsigned long long* ibins = reinterpret_cast<unsigned long long*>(bins);
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rk = crk[cb * 16 + 4 * r + lq];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int d = rr[s2] - rk;                 // (padding rows / columns carry G = 0: any bin will do)
+          const double y = fma(acc[cb][s2][r], scale, magic);
+          const unsigned long long q = (unsigned long long)(__double_as_longlong(y) - __double_as_longlong(magic));
+          __hip_atomic_fetch_add(&ibins[(d < 0 ? -d : d) & (LAGDOM_MAX_BINS - 1)], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+    __syncthreads();
+    for (int i = tid; i < a.nbins; i += 256) Kt[i] = (double)(long long)ibins[i] * rscale;
+    // moments: lanes, then waves, in a fixed order
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { m0 += __shfl_xor(m0, off); m1 += __shfl_xor(m1, off); m2 += __shfl_xor(m2, off); }
+    if (l == 0) { sm[3 * NB + 3 * w] = m0; sm[3 * NB + 3 * w + 1] = m1; sm[3 * NB + 3 * w + 2] = m2; }
+    __syncthreads();
+    if (tid < 3) Kt[a.nbins + tid] = (sm[3 * NB + tid] + sm[3 * NB + 3 + tid]) + (sm[3 * NB + 6 + tid] + sm[3 * NB + 9 + tid]);
+    return;
+  }
 #pragma unroll
   for (int cb = 0; cb < NSB; ++cb)
 #pragma unroll
@@ -668,6 +782,91 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
       d2 o2; o2.x = acc[cb][0][r]; o2.y = acc[cb][1][r];
       *reinterpret_cast<d2*>(Kt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
     }
+}
+
+// ---- lag-domain contraction: one workgroup per GFLAG_LAGDOM particle.  D_g = fixed-order sum over the particle's tiles of
+// the histograms k_kinv_tiles left in the tile slots; then the reverse-mode pass of the contraction kernel over the n "virtual
+// elements" (t_g, t_0) of the SORTED series with weight D_g — every stationary subtree's parameters; the Linear leaves (children
+// of the top-level sum: their adjoint is G itself) from the three moments:
+//   K = bias + amp (t_a - c)(t_b - c):  d/dbias = M0,  d/damp = M2 - c' M1 + c'^2 M0,  d/dc = -amp (M1 - 2 c' M0),  c' = c - t_ref.
+// d logpdf / d noise = tr G = D_0.
+__global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int p = a.plist[blockIdx.x];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const GProgHdr h = a.ghdr[p];
+  const int ntiles = a.nt * (a.nt + 1) / 2;
+  double* D = smem;                                    // [nbins]
+  double* prm = D + a.nbins;
+  int32_t* poff = reinterpret_cast<int32_t*>(prm + h.n_prm + 3);
+  uint8_t* ops = reinterpret_cast<uint8_t*>(poff + h.n_ops);
+  uint8_t* lc = ops + h.n_ops;
+  uint8_t* rc = lc + h.n_ops;
+  uint8_t* mv = rc + h.n_ops;
+  for (int i = tid; i < h.n_prm + 3; i += 256) prm[i] = a.gprm[h.prm_off + i];
+  for (int i = tid; i < h.n_ops; i += 256) {
+    const int po = a.gpoff[h.node_off + i];
+    const int o = a.gops[h.node_off + i];
+    poff[i] = po;
+    ops[i] = (uint8_t)o; lc[i] = a.glc[h.node_off + i]; rc[i] = a.grc[h.node_off + i];
+    const bool stat = (o == OP_SE || o == OP_GE || o == OP_PER);
+    mv[i] = (stat && a.gprm[h.prm_off + po + (o == OP_SE ? 1 : 2)] != 0.0) ? 1 : 0;
+  }
+  const double* __restrict__ Ap = a.A + (long long)p * a.strideA;
+  for (int g = tid; g < a.nbins; g += 256) {
+    double s = 0.0;
+    for (int t = 0; t < ntiles; ++t) s += Ap[(long long)t * NB2 + g];
+    D[g] = s;
+  }
+  double mom[3] = {0.0, 0.0, 0.0};
+  if (tid < 3)
+    for (int t = 0; t < ntiles; ++t) mom[0] += Ap[(long long)t * NB2 + a.nbins + tid];
+  __syncthreads();
+  constexpr int E = 4, GS = 64;
+  RegTape<GS, E> tape;
+  double gacc[3 * GS + 2];
+  ScratchAcc<3 * GS + 2> sacc{gacc};
+  for (int q = 0; q <= h.n_prm + 2; ++q) gacc[q] = 0.0;
+  const double t0 = a.tts[0];
+  for (int g0 = 0; g0 < a.nbins; g0 += 256 * E) {
+    int ri[E], ci[E];
+    double ta[E], tb[E], wg[E], lt[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int g = g0 + e * 256 + tid;
+      const bool in = g < a.nbins;
+      ri[e] = 0; ci[e] = 0; lt[e] = 0.0;
+      ta[e] = in ? a.tts[g] : t0; tb[e] = t0; wg[e] = in ? D[g] : 0.0;
+    }
+    grad_elements<GS, E>(h, ops, lc, rc, mv, poff, prm, nullptr, ri, ci, ta, tb, wg, lt, false, tape, sacc);
+  }
+  // reduction scratch behind the program tables: [0..3] per-wave partials, [4..6] moments, [8 + q] parameter q
+  double* red = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(mv + h.n_ops) + 15) & ~(uintptr_t)15);
+  for (int q = 0; q < h.n_prm; ++q) {
+    double s = gacc[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (l == 0) red[w] = s;
+    __syncthreads();
+    if (tid == 0) red[8 + q] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+  if (tid < 3) red[4 + tid] = mom[0];
+  __syncthreads();
+  if (tid == 0) {
+    const double M0 = red[4], M1 = red[5], M2 = red[6];
+    for (int ip = 0; ip < h.n_ops; ++ip)
+      if (ops[ip] == OP_LIN) {
+        const double* q = prm + poff[ip];
+        const double cc = q[0] - a.tref;
+        red[8 + poff[ip]] = -q[2] * (M1 - 2.0 * cc * M0);
+        red[8 + poff[ip] + 1] = M0;
+        red[8 + poff[ip] + 2] = M2 - cc * M1 + cc * cc * M0;
+      }
+    a.out_gnoise[a.pmap[p]] = D[0];
+  }
+  __syncthreads();
+  for (int q = tid; q < h.n_prm; q += 256) a.out_grad[a.out_off[p] + a.gmap[h.prm_off + q]] = red[8 + q];
 }
 
 // History of this kernel (n=2048, 512 prior particles): 31 ms in round 1.  PMC then: VALU issue 31 % busy at 2 waves/SIMD — not
@@ -791,6 +990,7 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
 __global__ void k_grad_finish(GradArgs a) {
   const int p = blockIdx.x;
   const GProgHdr h = a.ghdr[p];
+  if (h.flags & GFLAG_LAGDOM) return;          // (k_lag_grad wrote this particle's outputs)
   const int ntiles = a.nt * (a.nt + 1) / 2;
   for (int q = threadIdx.x; q <= h.n_prm; q += blockDim.x) {
     double s = 0.0;

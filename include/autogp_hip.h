@@ -155,6 +155,17 @@ int agp_set_factor_cache(agp_ctx* ctx, int32_t on);
 int agp_get_lag_stats(agp_ctx* ctx, int32_t* regular_grid, int64_t* n_lag_sweeps);
 int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
 
+/* Gradient sweeps on a regular time grid (the points in any order, any prefix n <= n_max <= 4096): for a stationary kernel
+ * dK_ab/dtheta depends on the lag |rank_a - rank_b| alone, so sum_ab G_ab dK_ab/dtheta = sum_g D_g dk(g h)/dtheta with D_g the
+ * sum of G = 1/2 (alpha alpha' - K^-1) along the lag-g diagonals of the sorted series.  Particles whose kernel is a sum of
+ * stationary subtrees (SquaredExponential, GammaExponential, Periodic, Constant, WhiteNoise under + and x) and Linear leaves
+ * are contracted that way: the K^-1 tile kernel bins G by lag instead of writing the tile, and the reverse-mode pass of
+ * Gen.choice_gradients' replacement (src/inference_smc_anneal_data.jl:63-67) runs over n lags instead of n^2 elements
+ * (Linear leaves: three moments of G).  Same result as the element-wise contraction to rounding.  AGP_GRAD_LAGDOM=0 /
+ * agp_set_grad_lag_domain(ctx, 0) disable it; the stats call counts the particles contracted this way so far. */
+int agp_set_grad_lag_domain(agp_ctx* ctx, int32_t on);
+int agp_get_grad_lag_domain_stats(agp_ctx* ctx, int64_t* n_particles);
+
 /* Value AND gradient: d logpdf / d theta for every (transformed) kernel parameter — out_grad has the
  * layout of `prm` (prm_off offsets; ChangePoint contributes d/dlocation, d/dscale) — and d logpdf / d noise.
  * This is what Gen.choice_gradients needs from the model body for Gen.hmc / Gen.map_optimize

@@ -129,3 +129,82 @@ def test_lag_path_non_positive_definite_info(pkg):
     assert ia[1] == 0 and ib[1] == 0 and lp_err(la[1:], lb[1:]).max() <= 1e-10
     _, rinfo = F.gp_logpdf_many(pkg.encode_batch(ks), nz, ts, xs)
     assert rinfo[0] > 0
+
+
+# ---- gradient sweeps: lag-domain contraction (include/autogp_hip.h agp_set_grad_lag_domain; csrc/agp_grad_kernel.hpp) ----
+
+def _grad_shapes(G):
+    se, ge, per = G.SquaredExponential(0.3, 0.8), G.GammaExponential(0.4, 1.3, 0.6), G.Periodic(0.7, 0.21, 1.1)
+    lin, lin2, cst, wn = G.Linear(0.3, 0.2, 0.7), G.Linear(-0.4, 0.1, 0.5), G.Constant(0.4), G.WhiteNoise(0.05)
+    covered = [se, ge, per, cst + wn, per * se, per * se + ge, lin, lin + ge, ge + lin, lin + lin2, (lin + per * se) + (ge + lin2),
+               cst * per + wn]
+    elementwise = [lin * se, lin * lin2, G.ChangePoint(se, per, 0.5, 0.05), (lin + se) * per, se + lin * ge]
+    return covered, elementwise
+
+
+@pytest.mark.parametrize("n_max,n", [(300, 300), (300, 250), (128, 128), (640, 513), (17, 17)])
+def test_gradient_lag_domain_vs_elementwise_and_oracle(pkg, n_max, n):
+    """A sum of stationary subtrees and Linear leaves on a (shuffled) regular grid is contracted over n lags instead of n^2
+    elements: same gradient as the element-wise contraction (1e-10 of the gradient's scale) and as the oracle (1e-7), on the
+    whole series and on a prefix of it; kernels outside the class keep the element-wise contraction in the same batch."""
+    from oracle import oracle as O
+    G = pkg
+    covered, elementwise = _grad_shapes(G)
+    kernels = covered + elementwise
+    ts, xs = pkg.prior.synthetic_series(n_max, seed=77 + n_max, shuffle=True)
+    noises = np.linspace(0.05, 0.3, len(kernels))
+    eng = pkg.GPEngine(0)
+    try:
+        eng.set_data(ts, xs)
+        assert eng.lag_stats()[0]
+        k0 = eng.grad_lag_domain_particles()
+        lp, g, gn, info = eng.logpdf_grad_batch(kernels, noises, n=n)
+        assert eng.grad_lag_domain_particles() - k0 == len(covered)
+        lp_r, g_r, gn_r, _ = eng.logpdf_grad_batch(kernels, noises, n=n)          # reproducible sums
+        assert np.array_equal(gn, gn_r) and all(np.array_equal(a, b) for a, b in zip(g, g_r))
+        eng.set_grad_lag_domain(False)
+        lp2, g2, gn2, info2 = eng.logpdf_grad_batch(kernels, noises, n=n)
+        assert eng.grad_lag_domain_particles() - k0 == 2 * len(covered)
+        assert (info == 0).all() and (info2 == 0).all() and np.array_equal(lp, lp2)
+        for i, k in enumerate(kernels):
+            sc = max(1.0, np.abs(g2[i]).max(), abs(gn2[i]))
+            assert np.abs(g[i] - g2[i]).max() <= 1e-10 * sc and abs(gn[i] - gn2[i]) <= 1e-10 * sc, (i, k, g[i], g2[i])
+            lpo, go, gno = O.gp_logpdf_grad(k.to_tuple(), float(noises[i]), ts[:n], xs[:n])
+            sc = max(1.0, np.abs(go).max(), abs(gno))
+            assert np.abs(g[i] - go).max() <= 1e-7 * sc and abs(gn[i] - gno) <= 1e-7 * sc, (i, k, g[i], go)
+    finally:
+        eng.close()
+
+
+def test_gradient_lag_domain_population_and_switches(pkg, monkeypatch):
+    """Prior-sampled population at n=1024 (several launch classes of the element-wise contraction beside the lag-domain particles,
+    chunked workspace), the environment switch, and an irregular series (nothing contracted in the lag domain)."""
+    ts, xs = pkg.prior.synthetic_series(1024, seed=4, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(8), 96, max_depth=-1, max_size=31)
+    a = pkg.GPEngine(0)
+    monkeypatch.setenv("AGP_GRAD_LAGDOM", "0")
+    b = pkg.GPEngine(0)
+    monkeypatch.delenv("AGP_GRAD_LAGDOM")
+    try:
+        a.set_data(ts, xs); b.set_data(ts, xs)
+        lp, g, gn, info = a.logpdf_grad_batch(nodes, noises, check=False)
+        lp2, g2, gn2, info2 = b.logpdf_grad_batch(nodes, noises, check=False)
+        assert a.grad_lag_domain_particles() >= 40 and b.grad_lag_domain_particles() == 0
+        assert np.array_equal(info, info2)
+        for i in np.flatnonzero(info == 0):
+            sc = max(1.0, np.abs(g2[i]).max(), abs(gn2[i]))
+            assert np.abs(g[i] - g2[i]).max() <= 1e-9 * sc and abs(gn[i] - gn2[i]) <= 1e-9 * sc, (i, nodes[i])
+        a.set_workspace_limit(8 * 2 * 36 * 128 * 128 * 8)          # eight particles per chunk
+        try:
+            lp3, g3, gn3, _ = a.logpdf_grad_batch(nodes, noises, check=False)
+        finally:
+            a.set_workspace_limit(0)
+        ok = info == 0
+        assert np.array_equal(gn[ok], gn3[ok]) and all(np.array_equal(g[i], g3[i]) for i in np.flatnonzero(ok))
+        tj = ts.copy(); tj[5] += 3e-4
+        a.set_data(tj, xs)
+        k0 = a.grad_lag_domain_particles()
+        a.logpdf_grad_batch(nodes[:8], noises[:8], check=False)
+        assert a.grad_lag_domain_particles() == k0 and not a.lag_stats()[0]
+    finally:
+        a.close(); b.close()
