@@ -75,7 +75,7 @@ struct Slot {
   std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
   std::vector<hipEvent_t> sub_ev;     // fork / join events
   hipStream_t gq[3] = {nullptr, nullptr, nullptr};     // gradient sweeps: the contraction's launch classes run side by side
-  hipEvent_t gq_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t gq_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool busy = false;
   // asynchronous hand-back (agp_logpdf_batch_device on a caller stream): the slot stays reserved until `done`,
   // recorded behind the call's last launch, has completed
@@ -164,6 +164,9 @@ struct agp_ctx {
   int32_t* d_rank = nullptr;     // rank of resident point i in the sorted series (lag-domain gradient contraction, k_kinv_tiles)
   double t_ref = 0.0;            // middle of the series: reference time of the Linear moments there
   int grad_fork = 1;             // the gradient contraction's launch classes on separate streams; env AGP_GRAD_FORK
+  int grad_fft = 1;              // lag-domain particles of series of <= FFT_N / 2 points: lag sums from Z's power spectrum; env AGP_GRAD_FFT
+  int grad_fft_min_n = 1024;     // env AGP_GRAD_FFT_MIN_N
+  double* d_fft_tw = nullptr;    // twiddle factors of that transform
   int grad_lagdom = 1;           // gradient sweeps on a regular grid: lag-domain contraction where the kernel allows; env AGP_GRAD_LAGDOM
   int64_t n_lagdom_particles = 0;   // particles contracted in the lag domain so far (agp_get_lag_stats)
   bool lag_ok = false;
@@ -1020,6 +1023,17 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   // Linear leaves are contracted in the lag domain (k_kinv_tiles / k_lag_grad, agp_grad_kernel.hpp)
   if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->grad_split && c->n_max <= LAGDOM_MAX_BINS) {
     int64_t n_cov = 0;
+    // (the transform has one length, 4096: below ~1000 points the K^-1 tiles are cheaper than n/2 transforms of that length)
+    const bool use_fft = c->grad_fft && 2 * c->n_max <= FFT_N && c->n_max > c->grad_fft_min_n;
+    if (use_fft && !c->d_fft_tw) {
+      std::vector<double> tw(2 * (size_t)FFT_N);
+      for (int k = 0; k < FFT_N; ++k) {
+        const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)FFT_N;
+        tw[2 * (size_t)k] = (double)cosl(ang); tw[2 * (size_t)k + 1] = (double)sinl(ang);
+      }
+      HIPCHK(c, hipMalloc((void**)&c->d_fft_tw, sizeof(double) * tw.size()));
+      HIPCHK(c, hipMemcpy(c->d_fft_tw, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice));
+    }
     for (int q = 0; q < P; ++q) {
       GProgHdr& g = bt.ghdr[q];
       if (g.n_cp > 0 || g.n_ops > 64) continue;
@@ -1034,7 +1048,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           cov[i] = stat[i] || o == OP_LIN;
         }
       }
-      if (g.n_ops > 0 && cov[g.n_ops - 1]) { g.flags |= GFLAG_LAGDOM; ++n_cov; }
+      if (g.n_ops > 0 && cov[g.n_ops - 1]) { g.flags |= GFLAG_LAGDOM | (use_fft ? GFLAG_LAGFFT : 0); ++n_cov; }
     }
     std::lock_guard<std::mutex> g(c->mu);
     c->n_lagdom_particles += n_cov;
@@ -1333,7 +1347,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           ga.tt = c->d_ts; ga.logdt = c->logdt_ok ? c->d_logdt : nullptr; ga.gpart = s->gpart.as<double>() + (size_t)g0 * ntiles * gstride; ga.gstride = gstride;
           ga.gmap = s->gmap.as<int32_t>(); ga.out_off = s->goff.as<int32_t>() + p0 + g0;
           ga.pmap = d_map + p0 + g0; ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
-          ga.rank = c->d_rank; ga.tts = c->d_ts_s; ga.nbins = (int)c->n_max; ga.tref = c->t_ref;
+          ga.rank = c->d_rank; ga.tts = c->d_ts_s; ga.nbins = (int)c->n_max; ga.tref = c->t_ref; ga.tw = c->d_fft_tw;
           if (n_hit > 0) {
             ga.lslot = d_src + p0 + g0; ga.Lsrc = c->store.A.as<double>(); ga.Lstride = c->store.strideA;
             ga.Wsrc = c->store.W.as<double>(); ga.Wnt = c->store.nt_cap;
@@ -1373,6 +1387,23 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           const size_t lds = sizeof(double) * std::max<size_t>(2 * U_SLAB, 256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes);
           const int Pall = ga.P;
           if (c->grad_split) {
+            const bool any_fft = Pn < Pg && (bt.ghdr[p0 + g0 + pl[Pn]].flags & GFLAG_LAGFFT) != 0;      // (all lag-domain particles or none)
+            // Two independent branches behind the inverse chain: [power spectra of Z -> lag-domain gradients] of the lag-domain
+            // particles and [K^-1 tiles -> element-wise contraction] of the others.  On separate streams a CU holds one workgroup
+            // of each (256 registers x 4 waves each): LDS / vector transforms beside MFMA tile products.
+            const bool fork = c->grad_fork != 0;
+            hipStream_t qs[4] = {q, q, q, q};
+            if (fork) {
+              for (int i2 = 0; i2 < 3; ++i2) if (!s->gq[i2]) HIPCHK(c, hipStreamCreateWithFlags(&s->gq[i2], hipStreamNonBlocking));
+              for (int i2 = 0; i2 < 5; ++i2) if (!s->gq_ev[i2]) HIPCHK(c, hipEventCreateWithFlags(&s->gq_ev[i2], hipEventDisableTiming));
+              for (int i2 = 0; i2 < 3; ++i2) qs[i2 + 1] = s->gq[i2];
+              HIPCHK(c, hipEventRecord(s->gq_ev[4], q));
+              HIPCHK(c, hipStreamWaitEvent(qs[3], s->gq_ev[4], 0));
+            }
+            if (any_fft) {
+              GradArgs gz = ga; gz.plist = d_pl + Pn;
+              hipLaunchKernelGGL(k_zspec, dim3(nt, Pg - Pn), dim3(256), 0, qs[3], gz);
+            }
             hipLaunchKernelGGL(k_kinv_tiles, dim3(8 * Pg8 * ntiles), dim3(256), 0, q, ga);
             { const size_t gk = pf.mark(q); pf.span(9, gm2, gk); gm2 = gk; }
             const size_t lds2 = sizeof(double) * (256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes + 8);
@@ -1387,13 +1418,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             // The launch classes are independent and each ends on a few long-running workgroups (the largest trees; the
             // 64-node class alone: ~2 000 workgroups of ~1 ms at n=2048): they run side by side on three more streams,
             // forked behind the K^-1 tiles and joined in front of the reduction.
-            const bool fork = c->grad_fork != 0;
-            hipStream_t qs[4] = {q, q, q, q};
             if (fork) {
-              for (int i2 = 0; i2 < 3; ++i2) if (!s->gq[i2]) HIPCHK(c, hipStreamCreateWithFlags(&s->gq[i2], hipStreamNonBlocking));
-              for (int i2 = 0; i2 < 4; ++i2) if (!s->gq_ev[i2]) HIPCHK(c, hipEventCreateWithFlags(&s->gq_ev[i2], hipEventDisableTiming));
               HIPCHK(c, hipEventRecord(s->gq_ev[3], q));
-              for (int i2 = 0; i2 < 3; ++i2) { HIPCHK(c, hipStreamWaitEvent(s->gq[i2], s->gq_ev[3], 0)); qs[i2 + 1] = s->gq[i2]; }
+              for (int i2 = 0; i2 < 2; ++i2) HIPCHK(c, hipStreamWaitEvent(qs[i2 + 1], s->gq_ev[3], 0));
+              if (!any_fft) HIPCHK(c, hipStreamWaitEvent(qs[3], s->gq_ev[3], 0));      // (k_lag_grad then reads the tiles' histograms)
             }
             GradArgs gs = ga;
             if (n_big > 0) HIPCHK(c, launch_grad_contract<64>(qs[0], gs, ntiles, n_big, lds2));
@@ -1407,7 +1435,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             }
             if (Pn < Pg) {
               gs.plist = d_pl + Pn;
-              const size_t lds4 = sizeof(double) * ((size_t)c->n_max + bt.g_max_prm + 3 + bt.g_max_nodes + 16 + bt.g_max_prm);
+              const size_t lds4 = sizeof(double) * ((any_fft ? 2 * (size_t)FFT_BUF : 0) + (size_t)c->n_max + 8 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
               hipLaunchKernelGGL(k_lag_grad, dim3(Pg - Pn), dim3(256), lds4, qs[3], gs);
               HIPCHK(c, hipGetLastError());
             }
@@ -1547,7 +1575,7 @@ int agp_init(agp_ctx** out, int device_id) {
     // raise the dynamic-LDS ceiling of the table-carrying kernels once (launches then never touch function attributes)
     const void* fns[] = {reinterpret_cast<const void*>(&k_cov_tiles<4>), reinterpret_cast<const void*>(&k_cov_tiles<8>),
                          reinterpret_cast<const void*>(&k_grad_contract<16>), reinterpret_cast<const void*>(&k_grad_contract<64>),
-                         reinterpret_cast<const void*>(&k_grad_contract<0>),
+                         reinterpret_cast<const void*>(&k_grad_contract<0>), reinterpret_cast<const void*>(&k_lag_grad),
                          reinterpret_cast<const void*>(&k_grad_tiles<16>), reinterpret_cast<const void*>(&k_grad_tiles<64>)};
     for (const void* f : fns) {
       hipFuncAttributes fa;
@@ -1573,6 +1601,8 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_LAG")) c->lag_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LAGDOM")) c->grad_lagdom = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_FORK")) c->grad_fork = atoi(e) != 0;
+  if (const char* e = getenv("AGP_GRAD_FFT")) c->grad_fft = atoi(e) != 0;
+  if (const char* e = getenv("AGP_GRAD_FFT_MIN_N")) c->grad_fft_min_n = atoi(e);
   if (const char* e = getenv("AGP_RIGHT_LOOKING")) c->right_looking = atoi(e);
   if (const char* e = getenv("AGP_HYBRID_BLOCKS")) c->hybrid_blocks = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
@@ -1619,6 +1649,7 @@ void agp_destroy(agp_ctx* c) {
   if (c->d_ts_s) (void)hipFree(c->d_ts_s);
   if (c->d_xs_s) (void)hipFree(c->d_xs_s);
   if (c->d_rank) (void)hipFree(c->d_rank);
+  if (c->d_fft_tw) (void)hipFree(c->d_fft_tw);
   if (c->d_flow_trace) (void)hipFree(c->d_flow_trace);
   delete c;
 }

@@ -156,6 +156,7 @@ struct GradArgs {
   // lag-domain contraction (regular time grids; see k_lag_grad): rank of every resident point in the sorted series, the sorted
   // series itself, number of lag bins (= resident points), reference time of the Linear moments
   const int32_t* rank; const double* tts; int nbins; double tref;
+  const double* tw;      // exp(-2 pi i k / 4096), k = 0 .. 4095, (re, im) pairs (k_zspec / k_lag_grad)
 };
 
 struct GProgHdr {
@@ -167,8 +168,11 @@ struct GProgHdr {
   int32_t flags;      // bit 0: the tree has GammaExp leaves (reads the log|dt| table when there is one)
                       // bit 1: lag-domain contraction (k_kinv_tiles bins G by lag, k_lag_grad differentiates n lags instead of n^2 elements)
 };
+                      // bit 2 (with bit 1): the lag sums of K^-1 come from the power spectrum of Z's columns (k_zspec), no K^-1 tiles at all
 constexpr int GFLAG_LAGDOM = 2;
+constexpr int GFLAG_LAGFFT = 4;
 constexpr int LAGDOM_MAX_BINS = 4096;      // LDS histogram of k_kinv_tiles (32 KiB)
+constexpr int FFT_N = 4096;                // transform length of the spectral variant: series of up to FFT_N / 2 points
 
 __device__ __forceinline__ long long zoff(int r, int k) { return tile_off(k, r); }   // r <= k
 
@@ -681,7 +685,9 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
   const int tj = tix - ti * (ti + 1) / 2;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   const int row0 = 32 * w + 2 * l15;
-  const bool lagdom = (a.ghdr[p].flags & GFLAG_LAGDOM) != 0;
+  const int pflags = a.ghdr[p].flags;
+  if (pflags & GFLAG_LAGFFT) return;                  // (its lag sums come from k_zspec)
+  const bool lagdom = (pflags & GFLAG_LAGDOM) != 0;
   if (lagdom)
     for (int i = tid; i < a.nbins; i += 256) bins[i] = 0.0;       // (published by the barriers of the slab loop)
   const double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
@@ -784,6 +790,172 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
     }
 }
 
+// ---- spectral variant of the lag sums (GFLAG_LAGFFT; series of up to FFT_N / 2 points) -------------------------------------
+// K^-1 = Z Z^T, so the sum of K^-1 along the lag-g diagonals of the sorted series is sum_k r_k(g), r_k = the autocorrelation of
+// column k of Z with its rows put in sorted order — and sum_k r_k = IDFT( sum_k |DFT(z_k)|^2 ) (zero-padded to FFT_N >= 2n):
+// n transforms of 5 N log2 N flops instead of the n^3/3 of the K^-1 tiles, which these particles then never form.  Two real
+// columns ride one complex transform (z_k + i z_k+1: the cross terms cancel in the even part of the power spectrum, and the
+// real part of the final transform only sees the even part).  The Linear leaves' moments follow from the column sums
+// s_k = sum_a Z_ak (the DC bin) and u_k = sum_a (t_a - t_ref) Z_ak:  sum K^-1_ab = sum_k s_k^2, and so on.
+//
+// In-place radix-4 decimation-in-frequency transform of FFT_N complex numbers in LDS by 256 threads (six stages, output in
+// base-4 digit-reversed order: the power spectra are accumulated in that order and un-permuted once, before the final transform).
+__device__ __forceinline__ d2 cmul(d2 x, d2 w) { d2 r; r.x = x.x * w.x - x.y * w.y; r.y = x.x * w.y + x.y * w.x; return r; }
+__device__ __forceinline__ int rev4_12(int x) {                 // reverse the six base-4 digits of a 12-bit index
+  const int b = (int)(__brev((unsigned)x) >> 20);
+  return ((b & 0xAAA) >> 1) | ((b & 0x555) << 1);
+}
+// Three radix-16 passes (each = two radix-4 stages on 16 numbers a thread holds in registers: half the LDS traffic and barriers of
+// six radix-4 stages); element i lives at i + i/16 (one pad per 16: the last pass reads 16 consecutive numbers per lane).  The
+// twiddle factors a thread needs depend on its index alone.
+constexpr int FFT_BUF = FFT_N + FFT_N / 16;
+__device__ __forceinline__ int fft_pad(int i) { return i + (i >> 4); }
+// x * exp(-2 pi i k / 16), k a compile-time constant 0..9
+template <int K>
+__device__ __forceinline__ d2 cmul_w16(d2 x) {
+  constexpr double C = 0.92387953251128674, S = 0.38268343236508977, H = 0.70710678118654752;
+  constexpr double re = K == 0 ? 1.0 : K == 1 ? C : K == 2 ? H : K == 3 ? S : K == 4 ? 0.0 : K == 5 ? -S : K == 6 ? -H : K == 7 ? -C : K == 8 ? -1.0 : -C;
+  constexpr double im = K == 0 ? 0.0 : K == 1 ? -S : K == 2 ? -H : K == 3 ? -C : K == 4 ? -1.0 : K == 5 ? -C : K == 6 ? -H : K == 7 ? -S : K == 8 ? 0.0 : S;
+  d2 r;
+  if (K == 0) return x;
+  if (K == 4) { r.x = x.y; r.y = -x.x; return r; }
+  if (K == 8) { r.x = -x.x; r.y = -x.y; return r; }
+  r.x = x.x * re - x.y * im; r.y = x.x * im + x.y * re;
+  return r;
+}
+__device__ __forceinline__ void bfly4(d2 x0, d2 x1, d2 x2, d2 x3, d2& y0, d2& y1, d2& y2, d2& y3) {
+  d2 a0, a1, a2, a3;
+  a0.x = x0.x + x2.x; a0.y = x0.y + x2.y; a1.x = x0.x - x2.x; a1.y = x0.y - x2.y;
+  a2.x = x1.x + x3.x; a2.y = x1.y + x3.y;
+  a3.x = x1.y - x3.y; a3.y = -(x1.x - x3.x);               // -i (x1 - x3)
+  y0.x = a0.x + a2.x; y0.y = a0.y + a2.y; y2.x = a0.x - a2.x; y2.y = a0.y - a2.y;
+  y1.x = a1.x + a3.x; y1.y = a1.y + a3.y; y3.x = a1.x - a3.x; y3.y = a1.y - a3.y;
+}
+// (ZHI: the upper half of the input is zero — a series of <= FFT_N / 2 points — and is neither cleared nor read: the first
+// pass's A stage sees x2 = x3 = 0)
+template <int PASS, bool ZHI = false>
+__device__ __forceinline__ void fft_r16(d2* buf, const d2* __restrict__ tw, int tid) {
+  constexpr int R = PASS == 0 ? 256 : PASS == 1 ? 16 : 1, M = 16 * R;
+  const int i = tid & (R - 1), base = (tid / R) * M + i;
+  // this thread's twiddle factors: A stage W_M^(q i) (its other factor, W_16^(m q), is a literal), B stage W_(M/4)^(q i), q = 1..3 —
+  // fetched per pass (64 KiB table, cache-resident) rather than held across passes: 48 registers the transform needs itself
+  d2 ta[3], tb[3];
+  if (PASS < 2) {
+    constexpr int sc = PASS == 0 ? 1 : 16;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) { ta[q - 1] = tw[(q * i * sc) & (FFT_N - 1)]; tb[q - 1] = tw[(q * i * 4 * sc) & (FFT_N - 1)]; }
+  }
+  // (element base + m R sits at pad(base) + m (R + R/16): R is a multiple of 16, or — last pass — base is and m < 16)
+  constexpr int ST = R >= 16 ? R + R / 16 : 1;
+  d2* const pb = buf + fft_pad(base);
+  d2 e[16];
+#pragma unroll
+  for (int m = 0; m < (ZHI ? 8 : 16); ++m) e[m] = pb[m * ST];
+  auto stage_a = [&](auto mc) {
+    constexpr int m = decltype(mc)::value;
+    d2 y0, y1, y2, y3;
+    if (ZHI) {
+      const d2 x0 = e[m], x1 = e[m + 4];
+      y0.x = x0.x + x1.x; y0.y = x0.y + x1.y; y2.x = x0.x - x1.x; y2.y = x0.y - x1.y;
+      y1.x = x0.x + x1.y; y1.y = x0.y - x1.x; y3.x = x0.x - x1.y; y3.y = x0.y + x1.x;
+    } else {
+      bfly4(e[m], e[m + 4], e[m + 8], e[m + 12], y0, y1, y2, y3);
+    }
+    y1 = cmul_w16<m>(y1); y2 = cmul_w16<2 * m>(y2); y3 = cmul_w16<3 * m>(y3);
+    if (PASS < 2) { y1 = cmul(y1, ta[0]); y2 = cmul(y2, ta[1]); y3 = cmul(y3, ta[2]); }
+    e[m] = y0; e[m + 4] = y1; e[m + 8] = y2; e[m + 12] = y3;
+  };
+  stage_a(std::integral_constant<int, 0>{}); stage_a(std::integral_constant<int, 1>{});
+  stage_a(std::integral_constant<int, 2>{}); stage_a(std::integral_constant<int, 3>{});
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    d2 g0, g1, g2, g3;
+    bfly4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3], g0, g1, g2, g3);
+    if (PASS < 2) { g1 = cmul(g1, tb[0]); g2 = cmul(g2, tb[1]); g3 = cmul(g3, tb[2]); }
+    pb[(4 * q) * ST] = g0; pb[(4 * q + 1) * ST] = g1; pb[(4 * q + 2) * ST] = g2; pb[(4 * q + 3) * ST] = g3;
+  }
+}
+constexpr int FFT_ZHI_CLEAR = FFT_N / 2 + FFT_N / 32;      // padded extent of the lower half
+template <bool ZHI = false>
+__device__ __forceinline__ void fft4096_lds(d2* buf, const d2* __restrict__ tw, int tid) {
+  fft_r16<0, ZHI>(buf, tw, tid); __syncthreads();
+  fft_r16<1>(buf, tw, tid); __syncthreads();
+  fft_r16<2>(buf, tw, tid); __syncthreads();
+}
+
+// One workgroup per (block column kc of Z, GFLAG_LAGFFT particle): power spectrum of the block column's 128 columns (digit-reversed
+// order) and its share of the three moments, into tile slot kc of the particle's (dead) L buffer.
+__global__ __launch_bounds__(256, 2) void k_zspec(GradArgs a) {
+  __shared__ __attribute__((aligned(16))) d2 buf[FFT_BUF];
+  __shared__ double red[4];
+  const int kc = blockIdx.x, p = a.plist[blockIdx.y];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = tid >> 7, row = tid & 127;
+  const double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
+  const d2* __restrict__ tw = reinterpret_cast<const d2*>(a.tw);
+  const int ncol = (a.n - kc * NB) < NB ? (a.n - kc * NB) : NB;
+  // this thread's rows (one per tile row r <= kc): LDS slot of the row's rank, t - t_ref
+  // (two 16-bit slots per register; 0xffff = no such row)
+  unsigned slot2[8];
+#pragma unroll
+  for (int r = 0; r < 16; r += 2) {
+    unsigned v = 0;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int ga = (r + h2) * NB + row;
+      const bool in = r + h2 <= kc && ga < a.n;
+      v |= (in ? (unsigned)(2 * fft_pad(a.rank[ga]) + half) : 0xffffu) << (16 * h2);
+    }
+    slot2[r >> 1] = v;
+  }
+  double P[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) P[j] = 0.0;
+  double m0 = 0.0, m1 = 0.0, m2 = 0.0;
+  // the column's entries travel one column pair ahead of their transform (zv: this thread's rows of column c + half)
+  double zv[16];
+  const double* __restrict__ Zc = Zp + zoff(0, kc);      // tiles Z(0..kc, kc) are consecutive slots: wave-uniform base + r NB2
+  auto fetch = [&](int c) {
+    const unsigned off = (unsigned)((c + half) * NB + row);      // (32-bit lane offset on a wave-uniform base)
+    const bool cv = c + half < ncol;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned sl = (slot2[r >> 1] >> (16 * (r & 1))) & 0xffffu;
+      zv[r] = (cv && sl != 0xffffu) ? (Zc + (long long)r * NB2)[off] : 0.0;
+    }
+  };
+  fetch(0);
+  for (int c = 0; c < ncol; c += 2) {
+    for (int i = tid; i < FFT_ZHI_CLEAR; i += 256) buf[i] = d2{0.0, 0.0};
+    __syncthreads();
+    double ut = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned sl = (slot2[r >> 1] >> (16 * (r & 1))) & 0xffffu;
+      if (sl != 0xffffu) {
+        reinterpret_cast<double*>(buf)[sl] = zv[r];
+        ut = fma(zv[r], a.tt[r * NB + row] - a.tref, ut);
+      }
+    }
+    if (c + 2 < ncol) fetch(c + 2);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ut += __shfl_xor(ut, off);
+    if (l == 0) red[w] = ut;
+    __syncthreads();
+    fft4096_lds<true>(buf, tw, tid);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { const d2 f = (buf + fft_pad(tid))[j * 272]; P[j] = fma(f.x, f.x, fma(f.y, f.y, P[j])); }
+    if (tid == 0) {
+      const double s0 = buf[0].x, s1 = buf[0].y, u0 = red[0] + red[1], u1 = red[2] + red[3];
+      m0 += s0 * s0 + s1 * s1; m1 += 2.0 * (s0 * u0 + s1 * u1); m2 += u0 * u0 + u1 * u1;
+    }
+    __syncthreads();
+  }
+  double* __restrict__ out = const_cast<double*>(a.A) + (long long)p * a.strideA + (long long)kc * NB2;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) out[tid + 256 * j] = P[j];
+  if (tid == 0) { out[FFT_N] = m0; out[FFT_N + 1] = m1; out[FFT_N + 2] = m2; }
+}
+
 // ---- lag-domain contraction: one workgroup per GFLAG_LAGDOM particle.  D_g = fixed-order sum over the particle's tiles of
 // the histograms k_kinv_tiles left in the tile slots; then the reverse-mode pass of the contraction kernel over the n "virtual
 // elements" (t_g, t_0) of the SORTED series with weight D_g — every stationary subtree's parameters; the Linear leaves (children
@@ -796,8 +968,9 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const GProgHdr h = a.ghdr[p];
   const int ntiles = a.nt * (a.nt + 1) / 2;
-  double* D = smem;                                    // [nbins]
-  double* prm = D + a.nbins;
+  const bool fft = (h.flags & GFLAG_LAGFFT) != 0;
+  double* D = smem + (fft ? 2 * FFT_BUF : 0);          // [nbins] (behind the transform buffer of the spectral variant)
+  double* prm = D + a.nbins + 8;
   int32_t* poff = reinterpret_cast<int32_t*>(prm + h.n_prm + 3);
   uint8_t* ops = reinterpret_cast<uint8_t*>(poff + h.n_ops);
   uint8_t* lc = ops + h.n_ops;
@@ -813,14 +986,57 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
     mv[i] = (stat && a.gprm[h.prm_off + po + (o == OP_SE ? 1 : 2)] != 0.0) ? 1 : 0;
   }
   const double* __restrict__ Ap = a.A + (long long)p * a.strideA;
-  for (int g = tid; g < a.nbins; g += 256) {
-    double s = 0.0;
-    for (int t = 0; t < ntiles; ++t) s += Ap[(long long)t * NB2 + g];
-    D[g] = s;
-  }
   double mom[3] = {0.0, 0.0, 0.0};
-  if (tid < 3)
-    for (int t = 0; t < ntiles; ++t) mom[0] += Ap[(long long)t * NB2 + a.nbins + tid];
+  if (fft) {
+    // spectral variant: S = |DFT(alpha)|^2 - sum over Z's block columns of their power spectra (k_zspec), D = Re DFT(S) / N
+    d2* buf = reinterpret_cast<d2*>(smem);
+    double* fred = D + a.nbins;      // behind D: 8 doubles (host sizes the LDS for them)
+    const d2* __restrict__ tw = reinterpret_cast<const d2*>(a.tw);
+    const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
+    for (int i = tid; i < FFT_ZHI_CLEAR; i += 256) buf[i] = d2{0.0, 0.0};
+    __syncthreads();
+    double ut = 0.0;
+    for (int ga = tid; ga < a.n; ga += 256) {
+      const double v = al[ga];
+      buf[fft_pad(a.rank[ga])].x = v;
+      ut = fma(v, a.tt[ga] - a.tref, ut);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ut += __shfl_xor(ut, off);
+    if (l == 0) fred[w] = ut;
+    __syncthreads();
+    fft4096_lds<true>(buf, tw, tid);
+    double S[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int o = tid + 256 * j;
+      const d2 f = buf[fft_pad(o)];
+      double z = 0.0;
+      for (int kc = 0; kc < a.nt; ++kc) z += Ap[(long long)kc * NB2 + o];
+      S[j] = fma(f.x, f.x, f.y * f.y) - z;
+    }
+    if (tid < 3) {
+      double z = 0.0;
+      for (int kc = 0; kc < a.nt; ++kc) z += Ap[(long long)kc * NB2 + FFT_N + tid];
+      const double sa = buf[0].x, ua = (fred[0] + fred[1]) + (fred[2] + fred[3]);
+      const double am = tid == 0 ? sa * sa : tid == 1 ? 2.0 * sa * ua : ua * ua;
+      mom[0] = 0.5 * (am - z);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) buf[fft_pad(rev4_12(tid + 256 * j))] = d2{S[j], 0.0};
+    __syncthreads();
+    fft4096_lds(buf, tw, tid);
+    for (int g = tid; g < a.nbins; g += 256) D[g] = buf[fft_pad(rev4_12(g))].x * ((g == 0 ? 0.5 : 1.0) / (double)FFT_N);
+  } else {
+    for (int g = tid; g < a.nbins; g += 256) {
+      double s = 0.0;
+      for (int t = 0; t < ntiles; ++t) s += Ap[(long long)t * NB2 + g];
+      D[g] = s;
+    }
+    if (tid < 3)
+      for (int t = 0; t < ntiles; ++t) mom[0] += Ap[(long long)t * NB2 + a.nbins + tid];
+  }
   __syncthreads();
   constexpr int E = 4, GS = 64;
   RegTape<GS, E> tape;

@@ -142,17 +142,21 @@ def _grad_shapes(G):
     return covered, elementwise
 
 
-@pytest.mark.parametrize("n_max,n", [(300, 300), (300, 250), (128, 128), (640, 513), (17, 17)])
-def test_gradient_lag_domain_vs_elementwise_and_oracle(pkg, n_max, n):
+@pytest.mark.parametrize("n_max,n,fft", [(300, 300, 1), (300, 250, 1), (128, 128, 1), (640, 513, 1), (17, 17, 1), (2, 2, 1),
+                                          (300, 300, 0), (300, 250, 0), (129, 129, 0), (17, 17, 0)])
+def test_gradient_lag_domain_vs_elementwise_and_oracle(pkg, monkeypatch, n_max, n, fft):
     """A sum of stationary subtrees and Linear leaves on a (shuffled) regular grid is contracted over n lags instead of n^2
     elements: same gradient as the element-wise contraction (1e-10 of the gradient's scale) and as the oracle (1e-7), on the
-    whole series and on a prefix of it; kernels outside the class keep the element-wise contraction in the same batch."""
+    whole series and on a prefix of it; kernels outside the class keep the element-wise contraction in the same batch.  Both
+    sources of the lag sums: the power spectrum of Z's columns (fft = 1: series of up to 2048 points) and the histogram of the
+    K^-1 tiles (fft = 0: what longer series use)."""
     from oracle import oracle as O
     G = pkg
     covered, elementwise = _grad_shapes(G)
     kernels = covered + elementwise
     ts, xs = pkg.prior.synthetic_series(n_max, seed=77 + n_max, shuffle=True)
     noises = np.linspace(0.05, 0.3, len(kernels))
+    monkeypatch.setenv("AGP_GRAD_FFT", str(fft))
     eng = pkg.GPEngine(0)
     try:
         eng.set_data(ts, xs)
@@ -185,15 +189,20 @@ def test_gradient_lag_domain_population_and_switches(pkg, monkeypatch):
     monkeypatch.setenv("AGP_GRAD_LAGDOM", "0")
     b = pkg.GPEngine(0)
     monkeypatch.delenv("AGP_GRAD_LAGDOM")
+    monkeypatch.setenv("AGP_GRAD_FFT", "0")
+    h = pkg.GPEngine(0)
+    monkeypatch.delenv("AGP_GRAD_FFT")
     try:
-        a.set_data(ts, xs); b.set_data(ts, xs)
+        a.set_data(ts, xs); b.set_data(ts, xs); h.set_data(ts, xs)
         lp, g, gn, info = a.logpdf_grad_batch(nodes, noises, check=False)
         lp2, g2, gn2, info2 = b.logpdf_grad_batch(nodes, noises, check=False)
-        assert a.grad_lag_domain_particles() >= 40 and b.grad_lag_domain_particles() == 0
-        assert np.array_equal(info, info2)
+        lp3, g3, gn3, info3 = h.logpdf_grad_batch(nodes, noises, check=False)
+        assert a.grad_lag_domain_particles() >= 40 and b.grad_lag_domain_particles() == 0 and h.grad_lag_domain_particles() >= 40
+        assert np.array_equal(info, info2) and np.array_equal(info, info3)
         for i in np.flatnonzero(info == 0):
             sc = max(1.0, np.abs(g2[i]).max(), abs(gn2[i]))
             assert np.abs(g[i] - g2[i]).max() <= 1e-9 * sc and abs(gn[i] - gn2[i]) <= 1e-9 * sc, (i, nodes[i])
+            assert np.abs(g3[i] - g2[i]).max() <= 1e-9 * sc and abs(gn3[i] - gn2[i]) <= 1e-9 * sc, (i, nodes[i])
         a.set_workspace_limit(8 * 2 * 36 * 128 * 128 * 8)          # eight particles per chunk
         try:
             lp3, g3, gn3, _ = a.logpdf_grad_batch(nodes, noises, check=False)
@@ -207,4 +216,4 @@ def test_gradient_lag_domain_population_and_switches(pkg, monkeypatch):
         a.logpdf_grad_batch(nodes[:8], noises[:8], check=False)
         assert a.grad_lag_domain_particles() == k0 and not a.lag_stats()[0]
     finally:
-        a.close(); b.close()
+        a.close(); b.close(); h.close()

@@ -8,7 +8,7 @@ for n, P in [(2048, 512), (2048, 64), (1024, 64)]:
     ts, xs = pkg.prior.synthetic_series(n, seed=n, shuffle=True)
     nodes, noises = pkg.prior.sample_particles(np.random.default_rng(n), P, max_depth=-1, max_size=63)
     progs = pkg.encode_batch(nodes); eng.set_data(ts, xs)
-    for on in (1, 0, 1):
+    for on in (1, 0):
         eng.set_grad_lag_domain(on)
         eng.logpdf_grad_batch(None, noises, check=False, programs=progs)
         eng.set_profiling(True) if hasattr(eng, "set_profiling") else None
