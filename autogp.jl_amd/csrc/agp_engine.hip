@@ -1024,7 +1024,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->grad_split && c->n_max <= LAGDOM_MAX_BINS) {
     int64_t n_cov = 0;
     // (the transform has one length, 4096: below ~1000 points the K^-1 tiles are cheaper than n/2 transforms of that length)
-    const bool use_fft = c->grad_fft && 2 * c->n_max <= FFT_N && c->n_max > c->grad_fft_min_n;
+    const bool use_fft = c->grad_fft && 2 * c->n_max <= FFT_N && n > c->grad_fft_min_n;      // (n: this sweep's prefix — the number of transforms)
     if (use_fft && !c->d_fft_tw) {
       std::vector<double> tw(2 * (size_t)FFT_N);
       for (int k = 0; k < FFT_N; ++k) {
@@ -1404,7 +1404,13 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
               GradArgs gz = ga; gz.plist = d_pl + Pn;
               hipLaunchKernelGGL(k_zspec, dim3(nt, Pg - Pn), dim3(256), 0, qs[3], gz);
             }
-            hipLaunchKernelGGL(k_kinv_tiles, dim3(8 * Pg8 * ntiles), dim3(256), 0, q, ga);
+            {
+              // (spectral lag-domain particles have no K^-1 tiles: the launch covers the first Pn entries of the list only)
+              GradArgs gk = ga;
+              if (any_fft) { gk.klist = d_pl; gk.kn = Pn; }
+              const int nk = any_fft ? Pn : Pg;
+              if (nk > 0) hipLaunchKernelGGL(k_kinv_tiles, dim3(8 * ((nk + 7) / 8) * ntiles), dim3(256), 0, q, gk);
+            }
             { const size_t gk = pf.mark(q); pf.span(9, gm2, gk); gm2 = gk; }
             const size_t lds2 = sizeof(double) * (256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes + 8);
             // three classes by tree size (the particle list is sorted by it): > 16 nodes and 9 .. 16 nodes keep their tape

@@ -157,6 +157,7 @@ struct GradArgs {
   // series itself, number of lag bins (= resident points), reference time of the Linear moments
   const int32_t* rank; const double* tts; int nbins; double tref;
   const double* tw;      // exp(-2 pi i k / 4096), k = 0 .. 4095, (re, im) pairs (k_zspec / k_lag_grad)
+  const int32_t* klist; int kn;      // k_kinv_tiles: the particles whose K^-1 tiles are wanted (null: all P)
 };
 
 struct GProgHdr {
@@ -677,8 +678,9 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
   const int ntl = a.nt * (a.nt + 1) / 2;
   const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
   const int pl = qq / ntl, tix = qq - pl * ntl;
-  const int p = pl * 8 + xcd;
-  if (p >= a.P) return;
+  const int pi = pl * 8 + xcd;
+  if (pi >= (a.klist ? a.kn : a.P)) return;
+  const int p = a.klist ? a.klist[pi] : pi;
   int ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
   while (ti * (ti + 1) / 2 > tix) --ti;
   while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
@@ -686,7 +688,7 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   const int row0 = 32 * w + 2 * l15;
   const int pflags = a.ghdr[p].flags;
-  if (pflags & GFLAG_LAGFFT) return;                  // (its lag sums come from k_zspec)
+  if (pflags & GFLAG_LAGFFT) return;                  // (its lag sums come from k_zspec; the host's list leaves these out anyway)
   const bool lagdom = (pflags & GFLAG_LAGDOM) != 0;
   if (lagdom)
     for (int i = tid; i < a.nbins; i += 256) bins[i] = 0.0;       // (published by the barriers of the slab loop)
