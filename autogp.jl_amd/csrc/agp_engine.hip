@@ -163,6 +163,7 @@ struct agp_ctx {
   double* d_xs_s = nullptr;
   int32_t* d_rank = nullptr;     // rank of resident point i in the sorted series (lag-domain gradient contraction, k_kinv_tiles)
   double t_ref = 0.0;            // middle of the series: reference time of the Linear moments there
+  double grid_h = 0.0, grid_mid = 0.0;      // grid spacing; t_sorted[r] - t_ref = (r - grid_mid) h
   int grad_fork = 1;             // the gradient contraction's launch classes on separate streams; env AGP_GRAD_FORK
   int grad_fft = 1;              // lag-domain particles of series of <= FFT_N / 2 points: lag sums from Z's power spectrum; env AGP_GRAD_FFT
   int grad_fft_min_n = 1024;     // env AGP_GRAD_FFT_MIN_N
@@ -1347,7 +1348,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           ga.tt = c->d_ts; ga.logdt = c->logdt_ok ? c->d_logdt : nullptr; ga.gpart = s->gpart.as<double>() + (size_t)g0 * ntiles * gstride; ga.gstride = gstride;
           ga.gmap = s->gmap.as<int32_t>(); ga.out_off = s->goff.as<int32_t>() + p0 + g0;
           ga.pmap = d_map + p0 + g0; ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
-          ga.rank = c->d_rank; ga.tts = c->d_ts_s; ga.nbins = (int)c->n_max; ga.tref = c->t_ref; ga.tw = c->d_fft_tw;
+          ga.rank = c->d_rank; ga.tts = c->d_ts_s; ga.nbins = (int)c->n_max; ga.tref = c->t_ref; ga.tw = c->d_fft_tw; ga.grid_h = c->grid_h; ga.grid_mid = c->grid_mid;
           if (n_hit > 0) {
             ga.lslot = d_src + p0 + g0; ga.Lsrc = c->store.A.as<double>(); ga.Lstride = c->store.strideA;
             ga.Wsrc = c->store.W.as<double>(); ga.Wnt = c->store.nt_cap;
@@ -1753,7 +1754,7 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
       for (int64_t i = 0; i < n_max; ++i) rank[(size_t)perm[(size_t)i]] = (int32_t)i;
       HIPCHK(c, hipMalloc((void**)&c->d_rank, sizeof(int32_t) * npad));
       HIPCHK(c, hipMemcpy(c->d_rank, rank.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice));
-      c->t_ref = 0.5 * (t0 + t1);
+      c->t_ref = 0.5 * (t0 + t1); c->grid_h = h; c->grid_mid = 0.5 * (double)(n_max - 1);
       c->lag_ok = true;
     }
   }

@@ -158,6 +158,7 @@ struct GradArgs {
   const int32_t* rank; const double* tts; int nbins; double tref;
   const double* tw;      // exp(-2 pi i k / 4096), k = 0 .. 4095, (re, im) pairs (k_zspec / k_lag_grad)
   const int32_t* klist; int kn;      // k_kinv_tiles: the particles whose K^-1 tiles are wanted (null: all P)
+  double grid_h, grid_mid;           // regular grid: spacing, and the (fractional) rank of t_ref: t_sorted[r] - t_ref = (r - grid_mid) h
 };
 
 struct GProgHdr {
@@ -935,7 +936,8 @@ __global__ __launch_bounds__(256, 2) void k_zspec(GradArgs a) {
       const unsigned sl = (slot2[r >> 1] >> (16 * (r & 1))) & 0xffffu;
       if (sl != 0xffffu) {
         reinterpret_cast<double*>(buf)[sl] = zv[r];
-        ut = fma(zv[r], a.tt[r * NB + row] - a.tref, ut);
+        const int ps = (int)(sl >> 1);                           // padded slot -> rank: p = i + i/16  =>  i = p - p/17
+        ut = fma(zv[r], (double)(ps - ps / 17) - a.grid_mid, ut);      // (t - t_ref) / h of the row, from its rank
       }
     }
     if (c + 2 < ncol) fetch(c + 2);
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(256, 2) void k_zspec(GradArgs a) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) { const d2 f = (buf + fft_pad(tid))[j * 272]; P[j] = fma(f.x, f.x, fma(f.y, f.y, P[j])); }
     if (tid == 0) {
-      const double s0 = buf[0].x, s1 = buf[0].y, u0 = red[0] + red[1], u1 = red[2] + red[3];
+      const double s0 = buf[0].x, s1 = buf[0].y, u0 = (red[0] + red[1]) * a.grid_h, u1 = (red[2] + red[3]) * a.grid_h;
       m0 += s0 * s0 + s1 * s1; m1 += 2.0 * (s0 * u0 + s1 * u1); m2 += u0 * u0 + u1 * u1;
     }
     __syncthreads();
@@ -1000,8 +1002,9 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
     double ut = 0.0;
     for (int ga = tid; ga < a.n; ga += 256) {
       const double v = al[ga];
-      buf[fft_pad(a.rank[ga])].x = v;
-      ut = fma(v, a.tt[ga] - a.tref, ut);
+      const int rk = a.rank[ga];
+      buf[fft_pad(rk)].x = v;
+      ut = fma(v, ((double)rk - a.grid_mid) * a.grid_h, ut);      // t - t_ref from the rank, as in k_zspec
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ut += __shfl_xor(ut, off);

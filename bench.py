@@ -210,13 +210,30 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
                 acc[k] = acc.get(k, 0.0) + v
         dt = (time.perf_counter() - t0) / reps
         eng.set_profiling(False)
-        tf = P * float(n) ** 3 / dt / 1e12
+        k0 = eng.grad_lag_domain_particles()
+        eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
+        n_lagdom = eng.grad_lag_domain_particles() - k0
+        # the same sweep with every particle contracted element by element (what an irregular series costs)
+        eng.set_grad_lag_domain(False)
+        eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
+        dt_el = (time.perf_counter() - t0) / 2
+        eng.set_grad_lag_domain(True)
+        tf = P * float(n) ** 3 / dt_el / 1e12
         out["grad"] = {"what": "value + gradient sweep of the same population (agp_logpdf_grad_batch, host outputs; HIP-event marks on)",
-                       "evals_per_s": P / dt, "ms_per_sweep": dt * 1e3, "tflops_on_n3": tf, "frac_of_fp64_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
-                       "flop_count": "n^3 per particle: factorisation n^3/3 + L^-T n^3/3 + K^-1 = Z Z^T n^3/3",
+                       "evals_per_s": P / dt, "ms_per_sweep": dt * 1e3,
+                       "lag_domain_particles": n_lagdom,
+                       "lag_domain": "regular grid: particles whose kernel is a sum of stationary subtrees and Linear leaves are contracted over n lags; "
+                                     "their K^-1 lag sums come from the power spectrum of Z's columns (n <= 2048), so their n^3/3 of K^-1 tiles is not formed",
+                       "elementwise": {"what": "agp_set_grad_lag_domain(0): K^-1 tiles and the per-element reverse sweep for every particle (any series)",
+                                       "evals_per_s": P / dt_el, "ms_per_sweep": dt_el * 1e3, "tflops_on_n3": tf,
+                                       "frac_of_fp64_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
+                                       "flop_count": "n^3 per particle: factorisation n^3/3 + L^-T n^3/3 + K^-1 = Z Z^T n^3/3"},
                        "kernel_ms": {"factorisation": (acc["chol_update_ms"] + acc["chol_trsm_ms"] + acc["cov_build_ms"]) / reps,
-                                     "k_trtri_chain": acc["grad_trtri_ms"] / reps, "k_kinv_tiles": acc["grad_kinv_ms"] / reps,
-                                     "k_grad_contract": acc["grad_contract_ms"] / reps, "k_alpha+k_grad_finish": acc["grad_alpha_finish_ms"] / reps}}
+                                     "k_trtri_chain": acc["grad_trtri_ms"] / reps, "k_kinv_tiles (+ k_zspec beside it)": acc["grad_kinv_ms"] / reps,
+                                     "k_grad_contract + k_lag_grad": acc["grad_contract_ms"] / reps, "k_grad_finish": acc["grad_alpha_finish_ms"] / reps}}
     except Exception as e:      # noqa: BLE001
         out["grad"] = {"error": str(e)[:300]}
     # ---- marginal predictive pass at m = 2n (means + variances: what Inference.predict / quantile consume) ----

@@ -319,7 +319,8 @@ def test_bench_default_line_has_every_block():
     for key in ("roofline", "roofline_diag_kernel", "roofline_cov_kernel", "grad", "predict", "cpu_baseline"):
         assert key in out and "error" not in out[key], (key, out.get(key))
     assert out["roofline_cov_kernel"]["unit"] == "GB/s" and out["roofline_cov_kernel"]["leaf_evals_per_s"] > 0
-    assert out["grad"]["kernel_ms"]["k_trtri_chain"] > 0 and out["grad"]["kernel_ms"]["k_grad_contract"] > 0
+    assert out["grad"]["kernel_ms"]["k_trtri_chain"] > 0 and out["grad"]["kernel_ms"]["k_grad_contract + k_lag_grad"] > 0
+    assert out["grad"]["lag_domain_particles"] > 0 and out["grad"]["elementwise"]["ms_per_sweep"] > 0
     assert out["cpu_baseline"]["one_worker_evals_per_s"] > 0 and out["cpu_baseline"]["parity_max_rel_err_vs_gpu"] < 1e-8
     assert out["roofline"]["algorithmic_bytes_per_step"] == 8.0 * 384 * 384 * 512
 
