@@ -46,6 +46,8 @@ struct CovArgs {
   const int* i0;
   int skip_pred_offdiag; // prediction without a covariance request: off-diagonal tiles of the K22 block are never read
   const double* lagtab;  // lag tables of the sweep's OP_LAG_* leaves (k_lag_tables): [table][block lag 0..nt-1][256]
+  int csplit;            // 4: a tile is shared by four workgroups (grid.z; 32 columns each) — launches of a few large trees,
+                         // whose length is ONE workgroup's walk over its tile (launch_cov); otherwise one workgroup per tile
 };
 
 __device__ __forceinline__ int prm_count(int o) {
@@ -248,7 +250,9 @@ __device__ __forceinline__ double cov_finalize(double v, int gi, int gj, int n1,
 // Measured (all tiles prebuilt, n=2048, 512 particles): E=8 at 2 waves/SIMD 4.27 ms, E=4 at 4 waves/SIMD 4.05 ms.
 template <int D>
 __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
-  constexpr int E = AGP_COV_E, CPP = E / 2, NPASS = 32 / CPP;      // columns per pass, passes over this thread's 32 columns
+  constexpr int E = AGP_COV_E, CPP = E / 2;      // columns per pass
+  const int cpt = a.csplit == 4 ? 8 : 32;        // columns per thread
+  const int NPASS = cpt / CPP;                   // passes over them
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* tpt = smem;         // [256]
   double* sig = smem + 256;   // [n_cp][256]
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
   const double* lag = sig + h.n_cp * 256;
 
   const int rp = tid & 63;        // row pair: rows 2rp, 2rp+1
-  const int cq = tid >> 6;        // column group: 32 columns
+  const int cb0 = a.csplit == 4 ? (int)blockIdx.z * 32 + (tid >> 6) * 8 : (tid >> 6) * 32;      // this thread's first column
   const int r0 = 2 * rp;
   const double tr0 = tpt[r0], tr1 = tpt[r0 + 1];
   const int gi0 = ti * NB + r0;
@@ -291,10 +295,10 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
   for (int cc = 0; cc < CPP; ++cc) ltn[cc] = d2{0.0, 0.0};
   if (use_tab) {
 #pragma unroll
-    for (int cc = 0; cc < CPP; ++cc) ltn[cc] = *reinterpret_cast<const d2*>(ltile + (long long)(cq * 32 + cc) * NB + r0);
+    for (int cc = 0; cc < CPP; ++cc) ltn[cc] = *reinterpret_cast<const d2*>(ltile + (long long)(cb0 + cc) * NB + r0);
   }
   for (int pass = 0; pass < NPASS; ++pass) {
-    const int c0 = cq * 32 + pass * CPP;
+    const int c0 = cb0 + pass * CPP;
     double tr[E], tc[E], out[E], lt[E];
     int ri[E], ci[E];
 #pragma unroll

@@ -148,6 +148,7 @@ struct agp_ctx {
   // duration of the short launches; such particles get their tiles from k_cov_tiles.  env AGP_FUSE_MAX_US
   double fuse_max_us = 25.0;     // (priced with the per-leaf costs of compile_batch, which predate exp_t: 25 vs 35: 29.28 vs 29.6 ms at 512 particles)
   double flow_fuse_max_us = 70.0;   // the same limit under the dataflow schedule; env AGP_FLOW_FUSE_MAX_US
+  double flow_lag_fuse_max_us = 10.0;   // the dataflow schedule on a lag-table sweep (measured 2.5 / 5 / 9 / 16 / 70 us, n=2048 x 64: 3.87 / 3.83 / 3.83 / 3.86 / 4.01 ms; the tiles of larger programs come from k_cov_tiles, fast with lag tables); env AGP_FLOW_LAG_FUSE_MAX_US
   double lag_fuse_max_us = 8.0;     // ... and for the per-column launches of a lag-table sweep (programs are priced at ~2 us per leaf there:
                                     // up to three leaves are evaluated in-kernel; measured 4 / 6 / 8 / 10 / 15 / 25 / 40 us: 27.78 / 27.77 / 27.78 /
                                     // 27.81 / 27.91 / 28.26 / 29.26 ms per 512-particle sweep); env AGP_LAG_FUSE_MAX_US
@@ -561,7 +562,8 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   const bool fuse_on = c->fuse_mode == 1 || (c->fuse_mode < 0 && (P >= 256 || fuse_hint));
   // (the dataflow schedule has no launch tail for a long evaluation to hold up: its limit is higher — measured 35 / 70 /
   // 150 / 1000 us: config 2 0.99 / 0.92 / 0.92 / 0.91 ms, 2048 x 64 4.47 / 4.45 / 4.61 / 4.62 ms, config 4 62.9 / 61.9 / 63.6 / 63.6 ms)
-  const double fuse_limit = flow_limit ? std::max(c->fuse_max_us, c->flow_fuse_max_us) : (lag ? std::min(c->fuse_max_us, c->lag_fuse_max_us) : c->fuse_max_us);
+  const double fuse_limit = flow_limit ? (lag ? c->flow_lag_fuse_max_us : std::max(c->fuse_max_us, c->flow_fuse_max_us))
+                                       : (lag ? std::min(c->fuse_max_us, c->lag_fuse_max_us) : c->fuse_max_us);
   // (lag sweeps: the same price limit with the lag leaves' price — a 30-leaf tree still costs ~80 us per tile in interpreter
   // latency, measured: fusing everything made every diagonal-tile launch wait 110 us for the largest tree and forced the
   // depth-8 instantiation on the whole batch, 29.4 -> 31.0 ms per 512-particle sweep; a program that carries direct
@@ -650,10 +652,14 @@ int64_t ws_limit_bytes(agp_ctx* c) {
 hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int max_cp, int depth) {
   if (ntiles <= 0 || P <= 0) return hipSuccess;
   const size_t lds = (256 + (size_t)max_cp * 256 + AGP_EXP_TAB_N) * sizeof(double);      // tpt, sigma tables, exp table
-  dim3 grid(ntiles, P), block(256);
+  // A launch that does not fill the GPU (1024 workgroup slots) lasts as long as its largest tree's walk over one tile — ~150 us
+  // for a 63-node tree, whatever the batch: four workgroups per tile then
+  CovArgs cs = ca;
+  cs.csplit = ((long long)ntiles * P < 4096) ? 4 : 1;
+  dim3 grid(ntiles, P, cs.csplit), block(256);
   // (the dynamic-LDS ceiling of these kernels is raised once, in agp_init; compile_program bounds max_cp)
-  if (depth <= 4) hipLaunchKernelGGL(k_cov_tiles<4>, grid, block, lds, st, ca);
-  else hipLaunchKernelGGL(k_cov_tiles<8>, grid, block, lds, st, ca);
+  if (depth <= 4) hipLaunchKernelGGL(k_cov_tiles<4>, grid, block, lds, st, cs);
+  else hipLaunchKernelGGL(k_cov_tiles<8>, grid, block, lds, st, cs);
   return hipGetLastError();
 }
 
@@ -1616,6 +1622,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_FUSE_MAX_US")) { c->fuse_max_us = atof(e); c->flow_fuse_max_us = std::min(c->flow_fuse_max_us, c->fuse_max_us); }
   if (const char* e = getenv("AGP_FLOW_FUSE_MAX_US")) c->flow_fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_LAG_FUSE_MAX_US")) c->lag_fuse_max_us = atof(e);
+  if (const char* e = getenv("AGP_FLOW_LAG_FUSE_MAX_US")) c->flow_lag_fuse_max_us = atof(e);
   if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LDS_TAPE")) c->grad_lds_tape = atoi(e) != 0;
   if (const char* e = getenv("AGP_PREDICT_REUSE")) c->predict_reuse = atoi(e) != 0;
