@@ -16,7 +16,9 @@
 //   run:   hmc_replay <n> <threads> <hmc_iterations> [L=10] [eps=0.02]
 #include "autogp_hip.h"
 
+#include <algorithm>
 #include <atomic>
+#include <string>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -104,12 +106,21 @@ int main(int argc, char** argv) {
   const int iters = argc > 3 ? atoi(argv[3]) : 2;
   const int L = argc > 4 ? atoi(argv[4]) : 10;
   const double eps = argc > 5 ? atof(argv[5]) : 0.02;
+  // argv[6] = "grid": time points = a regular grid in shuffled order — what AutoGP hands over for a regularly sampled series
+  // (min-max rescaled index, shuffle = true: src/api.jl:98-102,232); default: irregular times
+  const bool grid = argc > 6 && std::string(argv[6]) == "grid";
   agp_ctx* ctx = nullptr;
   if (agp_init(&ctx, 0) != 0) { fprintf(stderr, "agp_init: %s\n", agp_last_error(nullptr)); return 1; }
   std::mt19937_64 g(11);
   std::vector<double> ts(n), xs(n);
   std::uniform_real_distribution<double> u(0.0, 1.0); std::normal_distribution<double> nrm(0.0, 1.0);
   for (int i = 0; i < n; ++i) { ts[i] = u(g); xs[i] = 0.5 * std::sin(12.0 * ts[i]) + 0.3 * nrm(g); }
+  if (grid) {
+    std::vector<int> perm(n);
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    std::shuffle(perm.begin(), perm.end(), g);
+    for (int i = 0; i < n; ++i) { ts[i] = (double)perm[i] / (double)(n - 1); xs[i] = 0.5 * std::sin(12.0 * ts[i]) + 0.3 * nrm(g); }
+  }
   if (agp_set_data(ctx, ts.data(), xs.data(), n) != 0) { fprintf(stderr, "set_data: %s\n", agp_last_error(ctx)); return 1; }
   std::vector<Particle> ps(T);
   for (auto& p : ps) { gen_tree(g, 2, p); p.noise = 0.05 + 0.3 * u(g); }
@@ -143,12 +154,14 @@ int main(int argc, char** argv) {
   int64_t gr[2] = {0, 0};
   agp_grad_reuse_stats(ctx, gr);      // gradient calls that started from the factor of the value call before them
   const char* fc = getenv("AGP_FACTOR_CACHE");
-  printf("{\"tool\": \"hmc_replay\", \"factor_cache\": %s, \"gradient_particles_from_resident_factor\": %lld, \"gradient_particles_factored\": %lld, "
+  int64_t n_lagdom = 0;
+  agp_get_grad_lag_domain_stats(ctx, &n_lagdom);
+  printf("{\"tool\": \"hmc_replay\", \"time_points\": \"%s\", \"gradient_particles_in_lag_domain\": %lld, \"factor_cache\": %s, \"gradient_particles_from_resident_factor\": %lld, \"gradient_particles_factored\": %lld, "
          "\"n\": %d, \"threads\": %d, \"hmc_iterations_per_particle\": %d, \"L\": %d, \"eps\": %g, "
          "\"seconds\": %.4f, \"hmc_iterations_per_s\": %.2f, \"seconds_per_iteration_of_the_population\": %.4f, "
          "\"gradient_calls\": %lld, \"value_calls\": %lld, \"calls_per_s\": %.1f, \"coalesced_batches\": %lld, \"mean_batch\": %.1f, "
          "\"accepted_param_moves\": %lld, \"failed_calls\": %lld}\n",
-         (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
+         grid ? "regular grid, shuffled" : "irregular", (long long)n_lagdom, (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
          n, T, iters, L, eps, dt, it_total / dt, dt / iters, cnt.grad.load(), cnt.value.load(),
          (double)(cnt.grad.load() + cnt.value.load()) / dt, (long long)(b1 - b0),
          (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), cnt.accepted.load(), cnt.failed.load());
