@@ -493,8 +493,24 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     const bool one_node = h.n_ops == 1;
     const int op1 = one_node ? __builtin_amdgcn_readfirstlane(ops[0]) : -1;
     const double q0 = one_node ? prm[0] : 0.0, q1 = one_node ? prm[1] : 0.0, q2 = one_node ? prm[2] : 0.0;
+    // A program that is ONE lag table (a purely stationary kernel: half of a prior-sampled population) on a tile without padding
+    // rows / columns and off the diagonal: element (row, column) = table[row - column + 127], nothing else — 64 LDS reads per lane
+    // instead of 16 passes through the leaf evaluator and cov_finalize
+    const bool pure_lag = LAGM && one_node && op1 == OP_LAG && ti != tk && (ti + 1) * NB <= a.n1 && (tk + 1) * NB <= a.n1;
+    if (pure_lag) {
+      const double* lq_ = lagt + (NB - 1);
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double v = -lq_[(st ? row1 : row0) - (cb * 16 + 4 * r + lq)];
+            if (ADD) acc[cb][st][r] += v; else acc[cb][st][r] = v;
+          }
+    }
 #pragma unroll 1
-    for (int t = 0; t < 16; ++t) {
+    for (int t = pure_lag ? 16 : 0; t < 16; ++t) {
       const int cb = t >> 1, st = t & 1;
       const int rslot = st ? row1 : row0;
       double tr[4], tc[4], out[4];
