@@ -509,8 +509,21 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
             if (ADD) acc[cb][st][r] += v; else acc[cb][st][r] = v;
           }
     }
+    // ... and ONE Linear leaf (src/GP.jl:194-203; a quarter of the population): bias + amp (t_i - c)(t_j - c), same tiles
+    const bool pure_lin = one_node && op1 == OP_LIN && ti != tk && (ti + 1) * NB <= a.n1 && (tk + 1) * NB <= a.n1;
+    if (pure_lin) {
+      const double u0 = tpt[row0] - q0, u1 = tpt[row1] - q0;
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double tcc = tpt[NB + cb * 16 + 4 * r + lq] - q0;
+          const double v0 = -(q1 + q2 * (u0 * tcc)), v1 = -(q1 + q2 * (u1 * tcc));      // (eval_leaf's expression)
+          if (ADD) { acc[cb][0][r] += v0; acc[cb][1][r] += v1; } else { acc[cb][0][r] = v0; acc[cb][1][r] = v1; }
+        }
+    }
 #pragma unroll 1
-    for (int t = pure_lag ? 16 : 0; t < 16; ++t) {
+    for (int t = (pure_lag || pure_lin) ? 16 : 0; t < 16; ++t) {
       const int cb = t >> 1, st = t & 1;
       const int rslot = st ? row1 : row0;
       double tr[4], tc[4], out[4];
@@ -954,8 +967,30 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
     const bool one_node = h.n_ops == 1;
     const int op1 = one_node ? __builtin_amdgcn_readfirstlane(ops[0]) : -1;
     const double q0 = one_node ? prm[0] : 0.0, q1 = one_node ? prm[1] : 0.0, q2 = one_node ? prm[2] : 0.0;
+    // One lag table / one Linear leaf on a diagonal tile without padding rows (see chol_tile): the table (the leaf's formula)
+    // straight into the accumulators, the noise on the diagonal
+    const bool full = (tk + 1) * NB <= a.n1;
+    const bool pure_lag = LAGM && one_node && op1 == OP_LAG && full;
+    const bool pure_lin = one_node && op1 == OP_LIN && full;
+    if (pure_lag || pure_lin) {
+      const double* lq_ = lagt + (NB - 1);
+      const double u0 = tpt[row0] - q0, u1 = tpt[row1] - q0;
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int rs = st1[e] ? row1 : row0;
+        const double ue = st1[e] ? u1 : u0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cs = cbe[e] * 16 + 4 * r + lq;
+          double v;
+          if (pure_lag) v = lq_[rs - cs];
+          else v = q1 + q2 * (ue * (tpt[NB + cs] - q0));
+          acc[e][r] = -(rs == cs ? v + noise : v);
+        }
+      }
+    }
 #pragma unroll 1
-    for (int e = 0; e < NE; ++e) {
+    for (int e = (pure_lag || pure_lin) ? NE : 0; e < NE; ++e) {
       const bool s1 = e > wu;
       const int cb = s1 ? e - (wu + 1) : e;
       const int rslot = s1 ? row1 : row0;
