@@ -74,6 +74,8 @@ struct CholArgs {
   int flow_order;       // 0: sub-diagonal tiles of a block column tile-row-major (all particles' (k+1,k) first), 1: particle-major
   int lag;              // 1: sorted regular grid, the fused programs' stationary leaves are OP_LAG_* (GM = 2 instantiations)
   const double* lagtab; // ... and their tables (k_lag_tables)
+  const int32_t* lagr;  // rank tables (sweeps in the caller's order; see cov_prologue): ranks of the resident points, null = sorted sweep
+  int lag_stride;       // ... doubles per table
   // Dataflow schedule with a host-built work list and EARLY SUMS (plain sweeps; see k_chol_flow): the K-loops of the tiles
   // in the last part_tb tile rows x columns are cut into part_nch chunks of part_ch block columns.  The chunks are queued in
   // the middle of the kernel — right behind the last block column they read — and work IN PLACE on the tile's own storage:
@@ -465,14 +467,18 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     // Stage the program in LDS: this kernel also stores to global memory, so the compiler cannot
     // keep the opcode / parameter fetches on the scalar cache; from LDS they are broadcast reads.
     const double* lagt = sig + h.n_cp * 256;
-    double* prm = sig + (h.n_cp + (LAGM ? h.n_lag : 0)) * 256;
+    const bool rankt = LAGM && a.lagr != nullptr;                  // rank tables (whole-series tables + the points' ranks)
+    const int lstride = rankt ? a.lag_stride : 256;
+    int* xrk = reinterpret_cast<int*>(sig + h.n_cp * 256 + (LAGM ? h.n_lag * lstride : 0));
+    const int* rk = rankt ? xrk : nullptr;
+    double* prm = reinterpret_cast<double*>(xrk) + (rankt ? 128 : 0);
     int* ops = reinterpret_cast<int*>(prm + h.n_prm + 2);
     for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
     for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
     double* etab = sm + U_MAIN_DOUBLES;      // exp table in the (still unused) forward-solve scratch: rvec[128]
     if (AGP_EXP_TABLE && !LAGM && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];      // (lag sweeps evaluate no exponential)
     // (program, parameters, time points and lag tables travel in ONE round trip; the prologue's barrier publishes all of it)
-    cov_prologue<LAGM>(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt);
+    cov_prologue<LAGM>(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt, LAGM ? a.lagr : nullptr, lstride, xrk);
 #ifdef AGP_PROBE_PROLOGUE
     if (FLOW) AGP_PROBE(2);          // (measurement build: "stage" column of the flow trace = end of the tile prologue)
 #endif
@@ -499,15 +505,21 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
     const bool pure_lag = LAGM && one_node && op1 == OP_LAG && ti != tk && (ti + 1) * NB <= a.n1 && (tk + 1) * NB <= a.n1;
     if (pure_lag) {
       const double* lq_ = lagt + (NB - 1);
+      const int rk0 = rk ? rk[row0] : 0, rk1 = rk ? rk[row1] : 0;
 #pragma unroll
       for (int cb = 0; cb < NSB; ++cb)
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double v = -lq_[(st ? row1 : row0) - (cb * 16 + 4 * r + lq)];
-            if (ADD) acc[cb][st][r] += v; else acc[cb][st][r] = v;
+        for (int r = 0; r < 4; ++r) {
+          const int cs = cb * 16 + 4 * r + lq;
+          double v0, v1;
+          if (rk) {
+            const int rc = rk[NB + cs], d0 = rk0 - rc, d1 = rk1 - rc;
+            v0 = -lagt[d0 < 0 ? -d0 : d0]; v1 = -lagt[d1 < 0 ? -d1 : d1];
+          } else {
+            v0 = -lq_[row0 - cs]; v1 = -lq_[row1 - cs];
           }
+          if (ADD) { acc[cb][0][r] += v0; acc[cb][1][r] += v1; } else { acc[cb][0][r] = v0; acc[cb][1][r] = v1; }
+        }
     }
     // ... and ONE Linear leaf (src/GP.jl:194-203; a quarter of the population): bias + amp (t_i - c)(t_j - c), same tiles
     const bool pure_lin = one_node && op1 == OP_LIN && ti != tk && (ti + 1) * NB <= a.n1 && (tk + 1) * NB <= a.n1;
@@ -542,9 +554,9 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const 
         // one-node program (three quarters of a prior-sampled population in a lag sweep — stationary subtrees are tables —,
         // two thirds otherwise): no interpreter, the pass is the leaf's arithmetic alone instead of ~2 us of opcode /
         // parameter / stack latency around it
-        eval_leaf<4, (LAGM ? 3 : TAB ? 2 : 1)>(op1, q0, q1, q2, sig, lagt, tr, tc, ri, ci, lt, etab, out);
+        eval_leaf<4, (LAGM ? 3 : TAB ? 2 : 1)>(op1, q0, q1, q2, sig, lagt, tr, tc, ri, ci, lt, etab, out, rk);
       } else {
-        eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt);
+        eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt, rk, lstride);
       }
       d4 v;
 #pragma unroll
@@ -946,13 +958,17 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
     double* tpt = sm;
     double* sig = sm + 256;
     const double* lagt = sig + h.n_cp * 256;
-    double* prm = sig + (h.n_cp + (LAGM ? h.n_lag : 0)) * 256;
+    const bool rankt = LAGM && a.lagr != nullptr;                  // rank tables (see chol_tile)
+    const int lstride = rankt ? a.lag_stride : 256;
+    int* xrk = reinterpret_cast<int*>(sig + h.n_cp * 256 + (LAGM ? h.n_lag * lstride : 0));
+    const int* rk = rankt ? xrk : nullptr;
+    double* prm = reinterpret_cast<double*>(xrk) + (rankt ? 128 : 0);
     int* ops = reinterpret_cast<int*>(prm + h.n_prm + 2);
     for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
     for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
     double* etab = rvec;                     // exp table in the (still unused) forward-solve scratch
     if (AGP_EXP_TABLE && !LAGM && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
-    cov_prologue<LAGM>(a.tt, a.code, tk, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt);
+    cov_prologue<LAGM>(a.tt, a.code, tk, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt, LAGM ? a.lagr : nullptr, lstride, xrk);
     const double noise = a.noise[p];
     const bool use_tab = TAB && (h.flags & 1) != 0;
     const double* __restrict__ ltile = a.logdt + tile_off(tk, tk);      // only dereferenced when use_tab
@@ -983,8 +999,12 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
         for (int r = 0; r < 4; ++r) {
           const int cs = cbe[e] * 16 + 4 * r + lq;
           double v;
-          if (pure_lag) v = lq_[rs - cs];
-          else v = q1 + q2 * (ue * (tpt[NB + cs] - q0));
+          if (pure_lag) {
+            if (rk) { const int d = rk[rs] - rk[NB + cs]; v = lagt[d < 0 ? -d : d]; }
+            else v = lq_[rs - cs];
+          } else {
+            v = q1 + q2 * (ue * (tpt[NB + cs] - q0));
+          }
           acc[e][r] = -(rs == cs ? v + noise : v);
         }
       }
@@ -1007,9 +1027,9 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, c
         ri[r] = rslot; ci[r] = NB + cslot;
       }
       if (one_node) {       // (one-node program: no interpreter, see chol_tile)
-        eval_leaf<4, (LAGM ? 3 : TAB ? 2 : 1)>(op1, q0, q1, q2, sig, lagt, tr, tc, ri, ci, lt, etab, out);
+        eval_leaf<4, (LAGM ? 3 : TAB ? 2 : 1)>(op1, q0, q1, q2, sig, lagt, tr, tc, ri, ci, lt, etab, out, rk);
       } else {
-        eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt);
+        eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt, rk, lstride);
       }
       d4 v;
 #pragma unroll

@@ -46,6 +46,8 @@ struct CovArgs {
   const int* i0;
   int skip_pred_offdiag; // prediction without a covariance request: off-diagonal tiles of the K22 block are never read
   const double* lagtab;  // lag tables of the sweep's OP_LAG_* leaves (k_lag_tables): [table][block lag 0..nt-1][256]
+  const int32_t* lagr;   // RANK lag tables (regular grid, points in the caller's order; null: sorted sweep): rank of every resident
+  int lag_stride;        //   point in the sorted series; a leaf's table then holds all lag_stride lags 0 .. n_max-1 (see cov_prologue)
   int csplit;            // 4: a tile is shared by four workgroups (grid.z; 32 columns each) — launches of a few large trees,
                          // whose length is ONE workgroup's walk over its tile (launch_cov); otherwise one workgroup per tile
 };
@@ -78,14 +80,28 @@ __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, cons
                                              int ti, int tj, const ProgHdr& h,
                                              const OpT* __restrict__ ops, const double* __restrict__ prm,
                                              double* tpt, double* sig, int tid,
-                                             const double* __restrict__ lagtab = nullptr, int nt = 0) {
+                                             const double* __restrict__ lagtab = nullptr, int nt = 0,
+                                             const int32_t* __restrict__ rank = nullptr, int lstride = 256, int* xrk = nullptr,
+                                             bool copy_rank_tables = true) {
   const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
   const double tg = tt[g];
   if (LAG && h.n_lag > 0) {
-    // this tile's lag tables: block lag ti - tj of every OP_LAG_* leaf, 2 KiB each, built once per sweep by k_lag_tables
     double* lag = sig + h.n_cp * 256;
-    const double* __restrict__ src = lagtab + ((long long)h.lag_off * nt + (ti - tj)) * 256 + tid;
-    for (int li = 0; li < h.n_lag; ++li) lag[li * 256 + tid] = src[(long long)li * nt * 256];
+    if (rank != nullptr) {
+      // RANK tables — the same leaves for sweeps in the CALLER's order (prefixes of a shuffled grid, store / gradient sweeps):
+      // |t_a - t_b| = |rank_a - rank_b| h whatever the order, so a leaf's table holds all n_max lags (k_lag_tables, `full`), the
+      // tile copies it whole (16 KiB at n_max = 2048) with the ranks of its 256 points, and an element reads
+      // table[|rank_row - rank_col|]
+      // (k_cov_tiles leaves the tables where they are — L2-resident, a tree there may carry dozens — and only stages the ranks)
+      const double* __restrict__ src = lagtab + (long long)h.lag_off * lstride;
+      if (copy_rank_tables)
+        for (int i = tid; i < h.n_lag * lstride; i += 256) lag[i] = src[i];
+      xrk[tid] = rank[g];
+    } else {
+      // this tile's lag tables: block lag ti - tj of every OP_LAG_* leaf, 2 KiB each, built once per sweep by k_lag_tables
+      const double* __restrict__ src = lagtab + ((long long)h.lag_off * nt + (ti - tj)) * 256 + tid;
+      for (int li = 0; li < h.n_lag; ++li) lag[li * 256 + tid] = src[(long long)li * nt * 256];
+    }
   }
   tpt[tid] = tg;
   __syncthreads();
@@ -121,7 +137,7 @@ __device__ __forceinline__ void eval_leaf(const int o, const double p0, const do
                                           const double* sg, const double* lg,
                                           const double (&tr)[E], const double (&tc)[E],
                                           const int (&ri)[E], const int (&ci)[E], const double (&lt)[E],
-                                          const double* etab, double (&v)[E]) {
+                                          const double* etab, double (&v)[E], const int* rk = nullptr) {
   auto ex = [&](double x) { return (AGP_EXP_TABLE != 0) ? fm::exp_t(x, etab) : fm::exp_f(x); };
   if (o == OP_SEL) {
 #pragma unroll
@@ -137,10 +153,15 @@ __device__ __forceinline__ void eval_leaf(const int o, const double p0, const do
 #pragma unroll
     for (int e = 0; e < E; ++e) v[e] = p1 + p2 * ((tr[e] - p0) * (tc[e] - p0));
   } else if ((GEMODE == 0 || GEMODE == 3) && (GEMODE == 3 || o == OP_LAG)) {
-    // stationary subtree of a sorted regular grid: the tile's lag table
-    const double* lq_ = lg + (2 * NB - 1);
+    // stationary subtree of a regular grid: the tile's lag table (sorted sweep: by position; rk: by the points' ranks)
+    if (rk != nullptr) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = lq_[ri[e] - ci[e]];
+      for (int e = 0; e < E; ++e) { const int d = rk[ri[e]] - rk[ci[e]]; v[e] = lg[d < 0 ? -d : d]; }
+    } else {
+      const double* lq_ = lg + (2 * NB - 1);
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = lq_[ri[e] - ci[e]];
+    }
   } else if (GEMODE != 3) {
     // stationary leaves: amp * exp(arg)
     double arg[E];
@@ -173,7 +194,8 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
                                              const double* __restrict__ prm, const double* sig,
                                              const double (&tr)[E], const double (&tc)[E],
                                              const int (&ri)[E], const int (&ci)[E], const double (&lt)[E],
-                                             double (&out)[E], const double* etab = nullptr, const double* lag = nullptr) {
+                                             double (&out)[E], const double* etab = nullptr, const double* lag = nullptr,
+                                             const int* rk = nullptr, int lstride = 256) {
   double st[D][E];
 #pragma unroll
   for (int d = 0; d < D; ++d)
@@ -190,7 +212,7 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
       // carry two doubles of tail padding — and picked by opcode afterwards
       const double p0 = prm[q], p1 = prm[q + 1], p2 = prm[q + 2];
       double v[E];
-      eval_leaf<E, GEMODE>(o, p0, p1, p2, sig + cpi * 256, lag + li * 256, tr, tc, ri, ci, lt, etab, v);
+      eval_leaf<E, GEMODE>(o, p0, p1, p2, sig + cpi * 256, lag + li * lstride, tr, tc, ri, ci, lt, etab, v, rk);
       if (o == OP_SEL) ++cpi;
       if (o == OP_LAG) ++li;
 #pragma unroll
@@ -275,10 +297,14 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
   const ProgHdr h = a.hdr[p];
   const uint8_t* __restrict__ ops = a.ops + h.op_off;
   const double* __restrict__ prm = a.prm + h.prm_off;
-  double* etab = sig + (h.n_cp + h.n_lag) * 256;      // [128] exp table (launch_cov sizes the dynamic LDS for it)
+  const bool rankt = a.lagr != nullptr;       // rank tables: read in place (global memory), only the tile's ranks go to LDS
+  const int lstride = rankt ? a.lag_stride : 256;
+  int* xrk = reinterpret_cast<int*>(sig + h.n_cp * 256 + (rankt ? 0 : h.n_lag * 256));      // [256] ranks (rank tables only)
+  double* etab = reinterpret_cast<double*>(xrk) + (rankt ? 128 : 0);      // [128] exp table (launch_cov sizes the dynamic LDS for all of it)
   if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
-  cov_prologue<true>(a.tt, a.code, ti, tj, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt);
-  const double* lag = sig + h.n_cp * 256;
+  cov_prologue<true>(a.tt, a.code, ti, tj, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt, a.lagr, lstride, xrk, false);
+  const double* lag = rankt ? a.lagtab + (long long)h.lag_off * lstride : sig + h.n_cp * 256;
+  const int* rk = rankt ? xrk : nullptr;
 
   const int rp = tid & 63;        // row pair: rows 2rp, 2rp+1
   const int cb0 = a.csplit == 4 ? (int)blockIdx.z * 32 + (tid >> 6) * 8 : (tid >> 6) * 32;      // this thread's first column
@@ -314,7 +340,7 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
       ri[e] = r0 + (e & 1);
       ci[e] = NB + c0 + (e >> 1);
     }
-    eval_program<D, E, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lag);
+    eval_program<D, E, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lag, rk, lstride);
 #pragma unroll
     for (int cc = 0; cc < CPP; ++cc) {
       const int gj = tj * NB + c0 + cc;
@@ -334,8 +360,9 @@ struct LagArgs {
   const LagTabHdr* thdr;   // [n_tables]
   const uint8_t* tops;
   const double* tprm;
-  double* tab;             // [table][nt][256]
+  double* tab;             // [table][nt][256]; full: [table][stride]
   int nt, n_tables;
+  int full, stride;        // full = 1: rank tables — grid.x = stride / 256 blocks of lags 256 bl + tid, 0 .. stride-1
 };
 __global__ __launch_bounds__(256) void k_lag_tables(LagArgs a) {
   const int t = blockIdx.y, bl = blockIdx.x, tid = threadIdx.x;
@@ -345,14 +372,15 @@ __global__ __launch_bounds__(256) void k_lag_tables(LagArgs a) {
   const LagTabHdr th = a.thdr[t];
   ProgHdr h = {};
   h.n_ops = th.n_ops;
-  int g = bl * NB + tid - (NB - 1);
+  int g = a.full ? bl * 256 + tid : bl * NB + tid - (NB - 1);
   if (g < 0) g = -g;                                  // stationary kernels are even in dt
-  const bool live = tid < 2 * NB - 1 && g < a.nt * NB;
+  const bool live = a.full ? g < a.nt * NB : (tid < 2 * NB - 1 && g < a.nt * NB);
   const double tr[1] = {live ? a.tt[g] : 0.0}, tc[1] = {live ? a.tt[0] : 0.0}, lt[1] = {0.0};
   const int ri[1] = {0}, ci[1] = {NB};
   double out[1];
   eval_program<8, 1, 1>(h, a.tops + th.op_off, a.tprm + th.prm_off, nullptr, tr, tc, ri, ci, lt, out, etab);
-  a.tab[((long long)t * a.nt + bl) * 256 + tid] = out[0];
+  if (a.full) a.tab[(long long)t * a.stride + g] = out[0];
+  else a.tab[((long long)t * a.nt + bl) * 256 + tid] = out[0];
 }
 
 // log|t_i - t_j| for every element of the lower tiles of the resident data (diagonal tiles in full), same packed

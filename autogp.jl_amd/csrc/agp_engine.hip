@@ -162,6 +162,8 @@ struct agp_ctx {
   // x) and evaluate stationary leaves from per-tile lag tables (OP_LAG_*, agp_cov_kernel.hpp).  env AGP_LAG=0 disables.
   double* d_ts_s = nullptr;
   double* d_xs_s = nullptr;
+  int lag_rank_enable = 1;       // regular grid, sweeps in the CALLER's order (prefixes, gradient sweeps): rank lag tables (cov_prologue); env AGP_LAG_RANK
+  int64_t n_lag_rank_sweeps = 0;
   int32_t* d_rank = nullptr;     // rank of resident point i in the sorted series (lag-domain gradient contraction, k_kinv_tiles)
   double t_ref = 0.0;            // middle of the series: reference time of the Linear moments there
   double grid_h = 0.0, grid_mid = 0.0;      // grid spacing; t_sorted[r] - t_ref = (r - grid_mid) h
@@ -543,7 +545,9 @@ int emit_grad(const std::vector<CNode>& nodes, int id, Batch& bt, int prm_base, 
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                   const double* prm, Batch& bt, bool allow_sel = false, bool want_grad = false, bool ge_tab = false,
-                  bool fuse_hint = false, bool flow_limit = false, bool lag = false) {
+                  bool fuse_hint = false, bool flow_limit = false, bool lag = false, int lag_units = 1) {
+  // (lag_units: LDS footprint of one lag table in 256-double units — 1 on a sorted sweep, n_max / 256 for rank tables, + 1 there
+  // for the tile's ranks)
   std::vector<Compiled> cps(P);
   std::vector<double> cost(P, 0.0);
   for (int p = 0; p < P; ++p) {
@@ -570,7 +574,7 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   // stationary leaves there — see compile_program — must be prebuilt: the GM = 2 instantiations have no transcendental code)
   auto lag_ok = [&](int p) { bool direct = false; for (uint8_t o : cps[p].ops) direct |= (o == OP_SE || o == OP_GE || o == OP_PER || o == OP_GE_TAB); return !direct; };
   auto fusable = [&](int p) {
-    if (lag) return fuse_on && cost[p] <= fuse_limit && lag_ok(p) && cps[p].n_cp + cps[p].n_lag <= U_MAX_CP;
+    if (lag) return fuse_on && cost[p] <= fuse_limit && lag_ok(p) && cps[p].n_cp + cps[p].n_lag * lag_units + (lag_units > 1 ? 1 : 0) <= U_MAX_CP;
     return fuse_on && cost[p] <= fuse_limit && cps[p].n_cp <= U_MAX_CP;
   };
   bt.order.resize(P);
@@ -601,11 +605,12 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
     bt.hdr[q] = h;
     bt.ops.insert(bt.ops.end(), cp.ops.begin(), cp.ops.end());
     bt.prm.insert(bt.prm.end(), cp.prm.begin(), cp.prm.end());
-    bt.max_cp = std::max(bt.max_cp, cp.n_cp + cp.n_lag);        // LDS tables of any kind (per-point + lag)
+    const int lds_units = cp.n_cp + cp.n_lag * lag_units + (lag_units > 1 ? 1 : 0);      // LDS tables of any kind (per-point + lag), 256 doubles each
+    bt.max_cp = std::max(bt.max_cp, lag_units > 1 ? cp.n_cp + 1 : lds_units);      // (k_cov_tiles reads rank tables in place)
     bt.max_depth = std::max(bt.max_depth, cp.depth_need);
     if (fusable(bt.order[q])) {
       bt.n_fused = q + 1;
-      bt.max_cp_fused = std::max(bt.max_cp_fused, cp.n_cp + cp.n_lag);
+      bt.max_cp_fused = std::max(bt.max_cp_fused, lds_units);
       bt.max_depth_fused = std::max(bt.max_depth_fused, cp.depth_need);
     }
   }
@@ -706,7 +711,7 @@ inline void launch_diag(int dcov, int Pg8, hipStream_t st, const CholArgs& ca) {
 inline void set_cov(CholArgs& ca, const CovArgs& cv) {
   ca.tt = cv.tt; ca.n1 = cv.n1; ca.n1_pad = cv.n1_pad; ca.m2 = cv.m2;
   ca.hdr = cv.hdr; ca.ops = cv.ops; ca.prm = cv.prm; ca.noise = cv.noise; ca.code = cv.code; ca.logdt = cv.logdt;
-  ca.lagtab = cv.lagtab;
+  ca.lagtab = cv.lagtab; ca.lagr = cv.lagr; ca.lag_stride = cv.lag_stride;
 }
 
 struct Prof {
@@ -1021,8 +1026,13 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   const bool flow_hint = n > 0 && c->flow_fuse && use_flow(c, P, (int)((n + NB - 1) / NB));
   // value sweeps over the whole of a regular grid run on the sorted copy with lag tables (see agp_ctx::d_ts_s)
   const bool lag = allow_lag && c->lag_enable && c->lag_ok && !go && n > 0 && n == c->n_max && c->intrsm != 0;
-  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint, lag);
+  // ... every other sweep over (a prefix of) a regular grid — annealing prefixes, gradient sweeps — keeps the caller's order and
+  // reads the same leaves from RANK tables: |t_a - t_b| = |rank_a - rank_b| h in any order (cov_prologue)
+  const int rank_units = (int)((c->n_max + 255) / 256);
+  bool lagr = !lag && allow_lag && c->lag_rank_enable && c->lag_enable && c->lag_ok && n > 0 && c->intrsm != 0 && c->n_max <= 4096;
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint, lag || lagr, lagr ? rank_units : 1);
   if (rc) return rc;
+  if (lagr) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_rank_sweeps; }
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
   if (go && n > 23040) return fail(c, AGP_ERR_ARG, "gradient sweeps address a particle's packed matrix with 32-bit byte offsets: n <= 23040");
   if (lag) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_sweeps; }
@@ -1201,14 +1211,22 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       HIPCHK(c, hipMemcpyAsync(s->goff.p, goff_sorted.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
       HIPCHK(c, hipStreamSynchronize(st));     // goff_sorted is a local
     }
-    if (lag && bt.n_lag_tables > 0) {
+    if ((lag || lagr) && bt.n_lag_tables > 0) {
       // the sweep's lag tables: every stationary leaf of every particle at the 255 lags of each of the nt block diagonals
-      HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * nt * 256));
+      // (sorted sweep) / at every lag 0 .. n_max-1 of the series (rank tables)
       LagArgs la = {};
       la.tt = c->d_ts_s; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
       la.tops = reinterpret_cast<const uint8_t*>(dstage + o_tops); la.tprm = reinterpret_cast<const double*>(dstage + o_tprm);
-      la.tab = s->lagtab.as<double>(); la.nt = nt; la.n_tables = bt.n_lag_tables;
-      hipLaunchKernelGGL(k_lag_tables, dim3(nt, bt.n_lag_tables), dim3(256), 0, st, la);
+      la.n_tables = bt.n_lag_tables;
+      if (lagr) {
+        HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * rank_units * 256));
+        la.tab = s->lagtab.as<double>(); la.nt = (int)((c->n_max + NB - 1) / NB); la.full = 1; la.stride = rank_units * 256;
+        hipLaunchKernelGGL(k_lag_tables, dim3(rank_units, bt.n_lag_tables), dim3(256), 0, st, la);
+      } else {
+        HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * nt * 256));
+        la.tab = s->lagtab.as<double>(); la.nt = nt;
+        hipLaunchKernelGGL(k_lag_tables, dim3(nt, bt.n_lag_tables), dim3(256), 0, st, la);
+      }
       HIPCHK(c, hipGetLastError());
     }
     size_t ev_h2d = pf.mark();
@@ -1243,8 +1261,9 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         cv.tt = lag ? c->d_ts_s : c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
         cv.hdr = d_hdr + p0 + g0; cv.ops = d_ops; cv.prm = d_prm;
         cv.noise = d_noise + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
-        cv.strideA = strideA; cv.P = Pg; cv.logdt = (ge_tab && !lag) ? c->d_logdt : nullptr;
-        cv.lagtab = lag ? s->lagtab.as<double>() : nullptr;
+        cv.strideA = strideA; cv.P = Pg; cv.logdt = (ge_tab && !lag && !lagr) ? c->d_logdt : nullptr;
+        cv.lagtab = (lag || lagr) ? s->lagtab.as<double>() : nullptr;
+        cv.lagr = lagr ? c->d_rank : nullptr; cv.lag_stride = rank_units * 256;
         int i0min = 0;
         if (n_hit > 0) {
           // resident factors: forward-solve vector and partials are copied out of the store; L and the inverse blocks
@@ -1280,7 +1299,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         ca.partial = s->partial.as<double>() + (size_t)g0 * 2 * nt;
         ca.info = s->info.as<int>() + g0; ca.P = Pg; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
         set_cov(ca, cv);
-        ca.lag = lag ? 1 : 0;
+        ca.lag = (lag || lagr) ? 1 : 0;
         ca.n_fused = nf;
         ca.ready = s->ready.as<int>() + g0;
         ca.i0 = cv.i0;
@@ -1612,6 +1631,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_SPLIT_DIAG")) c->split_diag = atoi(e);
   if (const char* e = getenv("AGP_GE_TABLE")) c->ge_table = atoi(e) != 0;
   if (const char* e = getenv("AGP_LAG")) c->lag_enable = atoi(e) != 0;
+  if (const char* e = getenv("AGP_LAG_RANK")) c->lag_rank_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LAGDOM")) c->grad_lagdom = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_FORK")) c->grad_fork = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_FFT")) c->grad_fft = atoi(e) != 0;
@@ -3050,6 +3070,19 @@ int agp_get_lag_stats(agp_ctx* c, int32_t* regular_grid, int64_t* n_lag_sweeps) 
 int agp_set_lag_tables(agp_ctx* c, int32_t on) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   c->lag_enable = on != 0;
+  return AGP_OK;
+}
+
+int agp_set_lag_rank_tables(agp_ctx* c, int32_t on) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  c->lag_rank_enable = on != 0;
+  return AGP_OK;
+}
+
+int agp_get_lag_rank_stats(agp_ctx* c, int64_t* n_sweeps) {
+  if (!c || !n_sweeps) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  *n_sweeps = c->n_lag_rank_sweeps;
   return AGP_OK;
 }
 

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi", "agp_logpdf_batch_extend_multi",
     "agp_debug_flow_trace", "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
-    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats",
+    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats",
 ]
 COMM_ID_BYTES = 128
 
@@ -140,6 +140,8 @@ def load_library(path=None):
     lib.agp_get_lag_stats.argtypes = [vp, i32p, C.POINTER(C.c_int64)]; lib.agp_get_lag_stats.restype = C.c_int
     lib.agp_set_lag_tables.argtypes = [vp, C.c_int32]; lib.agp_set_lag_tables.restype = C.c_int
     lib.agp_set_grad_lag_domain.argtypes = [vp, C.c_int32]; lib.agp_set_grad_lag_domain.restype = C.c_int
+    lib.agp_set_lag_rank_tables.argtypes = [vp, C.c_int32]; lib.agp_set_lag_rank_tables.restype = C.c_int
+    lib.agp_get_lag_rank_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_get_lag_rank_stats.restype = C.c_int
     lib.agp_get_grad_lag_domain_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_get_grad_lag_domain_stats.restype = C.c_int
     lib.agp_init_multi.argtypes = [C.POINTER(vp), i32p, C.c_int32]; lib.agp_init_multi.restype = C.c_int
     lib.agp_set_data_multi.argtypes = [C.POINTER(vp), C.c_int32, dp, dp, C.c_int64]; lib.agp_set_data_multi.restype = C.c_int
@@ -344,6 +346,16 @@ class GPEngine:
     def set_lag_tables(self, on):
         """Switch the regular-grid lag-table path (takes effect at the next set_data)."""
         self._check(self._lib.agp_set_lag_tables(self._ctx, 1 if on else 0))
+
+    def set_lag_rank_tables(self, on):
+        """Switch the rank lag tables of caller-order sweeps on a regular grid (prefixes, gradient sweeps)."""
+        self._check(self._lib.agp_set_lag_rank_tables(self._ctx, 1 if on else 0))
+
+    def lag_rank_sweeps(self):
+        """Sweeps that read stationary subtrees from rank lag tables so far."""
+        k = C.c_int64()
+        self._check(self._lib.agp_get_lag_rank_stats(self._ctx, C.byref(k)))
+        return int(k.value)
 
     def set_grad_lag_domain(self, on):
         """Switch the lag-domain gradient contraction of regular grids (takes effect at the next gradient sweep)."""

@@ -352,7 +352,9 @@ def test_gradient_from_resident_factor(pkg, monkeypatch, env, n):
         assert got[3][24] > 0 and np.isnan(got[0][24])
         assert same(got[3][:24], base[3])
         ok = base[3] == 0
-        assert lp_err(got[0][:24][ok], base[0][ok]).max() <= 1e-12
+        # (on this regular grid the sweep that factors itself reads stationary subtrees from rank lag tables, the store's factors
+        # come from the general path: the two agree to the rounding of t_i - t_j, 1e-10 as everywhere in test_gpu_lag.py)
+        assert lp_err(got[0][:24][ok], base[0][ok]).max() <= 1e-10
         for i in np.flatnonzero(ok):
             assert grad_err(got[1][i], base[1][i]) <= 1e-9 and abs(got[2][i] - base[2][i]) <= 1e-9 * max(1.0, abs(base[2][i]))
         assert got[0][25] == got[0][2] and np.array_equal(got[1][25], got[1][2])          # the duplicate

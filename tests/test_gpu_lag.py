@@ -93,13 +93,15 @@ def test_what_must_not_take_the_lag_path(pkg):
         ref, _ = F.gp_logpdf_many(pkg.encode_batch(nodes), noises, ts[:300], xs[:300])
         ok = info == 0
         assert lp_err(lp[ok], ref[ok]).max() <= LP_TOL
+        assert eng.lag_rank_sweeps() == 1            # (the prefix sweep read its stationary leaves from rank tables instead)
         eng.logpdf_batch(nodes, noises, check=False)
-        assert eng.lag_stats() == (True, 1)
-        # gradient, extension and predictive entries keep the caller's order
+        assert eng.lag_stats() == (True, 1) and eng.lag_rank_sweeps() == 1
+        # gradient, extension and predictive entries keep the caller's order (the gradient sweep's factorisation: rank tables)
         eng.logpdf_grad_batch(nodes, noises, check=False)
+        assert eng.lag_rank_sweeps() == 2
         eng.logpdf_batch_extend(nodes, noises, check=False)
         eng.predict_batch(nodes[:2], noises[:2], np.linspace(0, 1.1, 20), check=False)
-        assert eng.lag_stats() == (True, 1)
+        assert eng.lag_stats() == (True, 1) and eng.lag_rank_sweeps() == 2
         # a grid jittered by 1e-9 (relative), a random series, a grid with one point missing and with a duplicate
         rng = np.random.default_rng(0)
         grid = np.linspace(0.0, 1.0, 400)
@@ -111,9 +113,51 @@ def test_what_must_not_take_the_lag_path(pkg):
             ref, rinfo = F.gp_logpdf_many(pkg.encode_batch(nodes[:4]), noises[:4], bad, np.cos(3 * bad))
             ok = (info == 0) & (rinfo == 0)
             assert lp_err(lp[ok], ref[ok]).max() <= LP_TOL
-        assert eng.lag_stats()[1] == 1
+        assert eng.lag_stats()[1] == 1 and eng.lag_rank_sweeps() == 2
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("n_max,n,P,depth", [(640, 500, 300, 3),     # per-column launches
+                                              (768, 700, 40, 3),      # dataflow schedule
+                                              (700, 650, 3, 3),       # right-looking schedule, tiles prebuilt
+                                              (300, 129, 9, 2), (300, 2, 4, 2),
+                                              (1024, 900, 24, 6),     # deep trees: many tables, most tiles prebuilt
+                                              (2048, 1845, 64, -1),   # an annealing prefix of config 3, one GPU's share
+                                              (4096, 3000, 6, 3)])    # 32 KiB tables
+def test_rank_lag_tables_prefix_sweeps(pkg, monkeypatch, n_max, n, P, depth):
+    """Prefix sweeps of a shuffled regular grid keep the caller's order and read stationary subtrees from rank tables
+    (table[|rank_a - rank_b|]): against the general path of a second context (1e-10), the oracle (1e-8), and LAPACK's info."""
+    ts, xs = pkg.prior.synthetic_series(n_max, seed=300 + n_max, shuffle=True)
+    kw = dict(max_depth=depth) if 0 < depth < 6 else (dict(max_depth=6, min_depth=5, max_size=63) if depth == 6 else dict(max_depth=-1, max_size=63))
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(n + P), P, **kw)
+    a = pkg.GPEngine(0)
+    monkeypatch.setenv("AGP_LAG_RANK", "0")
+    b = pkg.GPEngine(0)
+    monkeypatch.delenv("AGP_LAG_RANK")
+    try:
+        a.set_data(ts, xs); b.set_data(ts, xs)
+        la, ia = a.logpdf_batch(nodes, noises, n=n, check=False)
+        lb, ib = b.logpdf_batch(nodes, noises, n=n, check=False)
+        assert a.lag_rank_sweeps() == 1 and b.lag_rank_sweeps() == 0 and a.lag_stats()[1] == 0
+        assert np.sum((ia == 0) != (ib == 0)) <= 1
+        ok = (ia == 0) & (ib == 0)
+        assert ok.mean() >= 0.9 and lp_err(la[ok], lb[ok]).max() <= 1e-10
+        bad = (ia > 0) & (ib > 0)
+        assert np.array_equal(ia[bad], ib[bad])
+        if n <= 2048:
+            ref, rinfo = F.gp_logpdf_many(pkg.encode_batch(nodes), noises, ts[:n], xs[:n])
+            both = ok & (rinfo == 0)
+            assert lp_err(la[both], ref[both]).max() <= LP_TOL
+        # the value a gradient sweep reports comes from the same factorisation
+        if P <= 64 and n <= 1024:
+            lg, _, _, ig = a.logpdf_grad_batch(nodes, noises, n=n, check=False)
+            assert np.array_equal(ig, ia) and lp_err(lg[ok], la[ok]).max() <= 1e-11
+        a.set_lag_rank_tables(False)
+        lc, ic = a.logpdf_batch(nodes, noises, n=n, check=False)
+        assert a.lag_rank_sweeps() <= 2 and np.array_equal(lc[ok], lb[ok])
+    finally:
+        a.close(); b.close()
 
 
 def test_lag_path_non_positive_definite_info(pkg):
