@@ -422,10 +422,16 @@ __device__ __forceinline__ bool flow_wait(const int* flag) {
 // GM: how the fused programs' stationary leaves are evaluated — 0 directly, 1 GammaExp from the data set's log|dt| table,
 // 2 every stationary leaf from the tile's lag tables (sorted regular grid; see cov_prologue)
 template <bool FACTOR, int DCOV, bool INTRSM, int DM, int GM, bool FLOW>
-__device__ __forceinline__ void chol_tile(const CholArgs& a, const int p, const int ps, const int ti, const int tk,
-                                          const int jmax, const bool is_diag, double* sm, const int tid,
+__device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const int ps_, const int ti_, const int tk_,
+                                          const int jmax_, const bool is_diag, double* sm, const int tid,
                                           FlowProbe* wait_acc = nullptr) {
   constexpr bool TAB = GM == 1, LAGM = GM == 2;
+  // Particle and tile indices are the same for the whole workgroup; say so.  The operand streams' buffer descriptors are built
+  // from them, and a descriptor the compiler takes for lane-dependent costs a readfirstlane / compare / branch loop around EVERY
+  // buffer load of the slab loop (seen once: K-loop 31.1 -> 34.1 us per block column).
+  const int p = __builtin_amdgcn_readfirstlane(p_), ps = __builtin_amdgcn_readfirstlane(ps_);
+  const int ti = __builtin_amdgcn_readfirstlane(ti_), tk = __builtin_amdgcn_readfirstlane(tk_);
+  const int jmax = __builtin_amdgcn_readfirstlane(jmax_);
   constexpr bool ADJ = ILV;       // strips are adjacent rows
   phase_prio();
   double* rvec = sm + U_MAIN_DOUBLES;
@@ -927,9 +933,11 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
 // factorisation, forward-solve segment and partials — the body of k_chol_diag, also run by the dataflow schedule
 // (FLOW: waits for tile (tk, j) before the slabs of block column j are fetched; raises its own flag when done).
 template <int DCOV, int GM, bool FLOW>
-__device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p, const int ps, const int tk, double* sm, const int tid,
+__device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, const int ps_, const int tk_, double* sm, const int tid,
                                                FlowProbe* wait_acc = nullptr) {
   constexpr bool TAB = GM == 1, LAGM = GM == 2;
+  const int p = __builtin_amdgcn_readfirstlane(p_), ps = __builtin_amdgcn_readfirstlane(ps_);      // (wave-uniform: see chol_tile)
+  const int tk = __builtin_amdgcn_readfirstlane(tk_);
   phase_prio();
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;

@@ -170,3 +170,15 @@ def test_dist_helpers(pkg):
     assert lml == pytest.approx(math.log(1 + 3 * math.exp(-50)) - math.log(4))
     did, parents, nlw, lml = d.maybe_resample(np.zeros(4), 1.5, 2.0, seed=1)
     assert not did and lml == 1.5
+
+
+def test_no_waterfalled_buffer_accesses():
+    """tools/check_isa.py: every buffer load / store of the compiled kernels takes its descriptor from SGPRs (a descriptor the
+    compiler cannot prove wave-uniform costs a readfirstlane loop per load — a silent ~10 % in the K-loops)."""
+    import shutil, importlib.util
+    from pathlib import Path
+    if not (shutil.which("hipcc") or Path("/opt/rocm/bin/hipcc").exists()):
+        pytest.skip("hipcc not available")
+    spec = importlib.util.spec_from_file_location("check_isa", Path(__file__).resolve().parent.parent / "tools" / "check_isa.py")
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.main() == 0
