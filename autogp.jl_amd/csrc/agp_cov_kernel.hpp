@@ -323,6 +323,9 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
 #pragma unroll
     for (int cc = 0; cc < CPP; ++cc) ltn[cc] = *reinterpret_cast<const d2*>(ltile + (long long)(cb0 + cc) * NB + r0);
   }
+  const bool one_node = h.n_ops == 1;
+  const int op1 = one_node ? __builtin_amdgcn_readfirstlane((int)ops[0]) : -1;
+  const double q0 = one_node ? prm[0] : 0.0, q1 = one_node ? prm[1] : 0.0, q2 = one_node ? prm[2] : 0.0;
   for (int pass = 0; pass < NPASS; ++pass) {
     const int c0 = cb0 + pass * CPP;
     double tr[E], tc[E], out[E], lt[E];
@@ -340,7 +343,8 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
       ri[e] = r0 + (e & 1);
       ci[e] = NB + c0 + (e >> 1);
     }
-    eval_program<D, E, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lag, rk, lstride);
+    if (one_node) eval_leaf<E, 0>(op1, q0, q1, q2, sig, lag, tr, tc, ri, ci, lt, etab, out, rk);      // (no interpreter: see chol_tile)
+    else eval_program<D, E, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lag, rk, lstride);
 #pragma unroll
     for (int cc = 0; cc < CPP; ++cc) {
       const int gj = tj * NB + c0 + cc;
