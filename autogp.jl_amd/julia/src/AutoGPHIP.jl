@@ -319,6 +319,20 @@ function comm_count(eng::Engine)
 end
 "block until every asynchronously enqueued sweep of the engine has completed (reports a latched in-kernel timeout)"
 wait!(eng::Engine) = check(eng, ccall((:agp_wait, LIB), Cint, (Ptr{Cvoid},), eng.ptr))
+"""
+Regular time grids (include/autogp_hip.h): `(is_regular, sorted_sweeps)`, the sweeps that read rank tables, the particles whose
+gradient was contracted in the lag domain; the switches take effect at the next `set_data!` (lag tables) / sweep (the others).
+"""
+function lag_stats(eng::Engine)
+    reg = Ref{Int32}(0); ns = Ref{Int64}(0); nr = Ref{Int64}(0); ng = Ref{Int64}(0)
+    check(eng, ccall((:agp_get_lag_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int64}), eng.ptr, reg, ns))
+    check(eng, ccall((:agp_get_lag_rank_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), eng.ptr, nr))
+    check(eng, ccall((:agp_get_grad_lag_domain_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), eng.ptr, ng))
+    return (regular = reg[] != 0, sorted_sweeps = Int(ns[]), rank_sweeps = Int(nr[]), lag_domain_gradients = Int(ng[]))
+end
+set_lag_tables!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_lag_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
+set_lag_rank_tables!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_lag_rank_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
+set_grad_lag_domain!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_grad_lag_domain, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
 "block [lo, hi] (1-based, inclusive) of rank `rank` (0-based) — identical on every rank"
 function shard_range(P::Integer, rank::Integer, n_ranks::Integer)
     lo = Ref{Int32}(0); hi = Ref{Int32}(0)
