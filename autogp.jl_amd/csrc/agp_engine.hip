@@ -1041,16 +1041,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->grad_split && c->n_max <= LAGDOM_MAX_BINS) {
     int64_t n_cov = 0;
     // (the transform has one length, 4096: below ~1000 points the K^-1 tiles are cheaper than n/2 transforms of that length)
-    const bool use_fft = c->grad_fft && 2 * c->n_max <= FFT_N && n > c->grad_fft_min_n;      // (n: this sweep's prefix — the number of transforms)
-    if (use_fft && !c->d_fft_tw) {
-      std::vector<double> tw(2 * (size_t)FFT_N);
-      for (int k = 0; k < FFT_N; ++k) {
-        const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)FFT_N;
-        tw[2 * (size_t)k] = (double)cosl(ang); tw[2 * (size_t)k + 1] = (double)sinl(ang);
-      }
-      HIPCHK(c, hipMalloc((void**)&c->d_fft_tw, sizeof(double) * tw.size()));
-      HIPCHK(c, hipMemcpy(c->d_fft_tw, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice));
-    }
+    const bool use_fft = c->grad_fft && c->d_fft_tw != nullptr && 2 * c->n_max <= FFT_N && n > c->grad_fft_min_n;      // (n: this sweep's prefix — the number of transforms)
     for (int q = 0; q < P; ++q) {
       GProgHdr& g = bt.ghdr[q];
       if (g.n_cp > 0 || g.n_ops > 64) continue;
@@ -1782,6 +1773,19 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
       HIPCHK(c, hipMalloc((void**)&c->d_rank, sizeof(int32_t) * npad));
       HIPCHK(c, hipMemcpy(c->d_rank, rank.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice));
       c->t_ref = 0.5 * (t0 + t1); c->grid_h = h; c->grid_mid = 0.5 * (double)(n_max - 1);
+      if (!c->d_fft_tw) {
+        // twiddle factors of the gradient sweeps' spectral lag sums (k_zspec): here, where one thread runs by contract — the sweeps
+        // that read them may come from many
+        std::vector<double> tw(2 * (size_t)FFT_N);
+        for (int k = 0; k < FFT_N; ++k) {
+          const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)FFT_N;
+          tw[2 * (size_t)k] = (double)cosl(ang); tw[2 * (size_t)k + 1] = (double)sinl(ang);
+        }
+        double* d_tw = nullptr;
+        HIPCHK(c, hipMalloc((void**)&d_tw, sizeof(double) * tw.size()));
+        HIPCHK(c, hipMemcpy(d_tw, tw.data(), sizeof(double) * tw.size(), hipMemcpyHostToDevice));
+        c->d_fft_tw = d_tw;
+      }
       c->lag_ok = true;
     }
   }
