@@ -149,9 +149,9 @@ struct agp_ctx {
   double fuse_max_us = 25.0;     // (priced with the per-leaf costs of compile_batch, which predate exp_t: 25 vs 35: 29.28 vs 29.6 ms at 512 particles)
   double flow_fuse_max_us = 70.0;   // the same limit under the dataflow schedule; env AGP_FLOW_FUSE_MAX_US
   double flow_lag_fuse_max_us = 10.0;   // the dataflow schedule on a lag-table sweep (measured 2.5 / 5 / 9 / 16 / 70 us, n=2048 x 64: 3.87 / 3.83 / 3.83 / 3.86 / 4.01 ms; the tiles of larger programs come from k_cov_tiles, fast with lag tables); env AGP_FLOW_LAG_FUSE_MAX_US
-  double lag_fuse_max_us = 8.0;     // ... and for the per-column launches of a lag-table sweep (programs are priced at ~2 us per leaf there:
-                                    // up to three leaves are evaluated in-kernel; measured 4 / 6 / 8 / 10 / 15 / 25 / 40 us: 27.78 / 27.77 / 27.78 /
-                                    // 27.81 / 27.91 / 28.26 / 29.26 ms per 512-particle sweep); env AGP_LAG_FUSE_MAX_US
+  double lag_fuse_max_us = 3.0;     // ... and for the per-column launches of a lag-table sweep (programs are priced at ~2 us per node there): one-node
+                                    // programs only — they are filled without the evaluator; 2.5 / 5 / 8 / 12 / 20 us measured 25.33 /
+                                    // 25.40 / 25.57 / 25.58 / 25.94 ms per 512-particle sweep; env AGP_LAG_FUSE_MAX_US
   int dedup = 1;        // evaluate identical particles of a host-output sweep once; env AGP_DEDUP
   int64_t n_particles_seen = 0, n_particles_run = 0;
   int trtri_chain = 1;  // Z = L^-T as independent per-row chains in one launch (0: one launch per block column); env AGP_TRTRI_CHAIN
