@@ -162,6 +162,7 @@ struct agp_ctx {
   // x) and evaluate stationary leaves from per-tile lag tables (OP_LAG_*, agp_cov_kernel.hpp).  env AGP_LAG=0 disables.
   double* d_ts_s = nullptr;
   double* d_xs_s = nullptr;
+  int lag_store_enable = 1;      // ... also for the factor store's sweeps (agp_logpdf_batch_extend, coalesced agp_logpdf); env AGP_LAG_STORE
   int lag_rank_enable = 1;       // regular grid, sweeps in the CALLER's order (prefixes, gradient sweeps): rank lag tables (cov_prologue); env AGP_LAG_RANK
   int64_t n_lag_rank_sweeps = 0;
   int32_t* d_rank = nullptr;     // rank of resident point i in the sorted series (lag-domain gradient contraction, k_kinv_tiles)
@@ -1623,6 +1624,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_GE_TABLE")) c->ge_table = atoi(e) != 0;
   if (const char* e = getenv("AGP_LAG")) c->lag_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_LAG_RANK")) c->lag_rank_enable = atoi(e) != 0;
+  if (const char* e = getenv("AGP_LAG_STORE")) c->lag_store_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LAGDOM")) c->grad_lagdom = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_FORK")) c->grad_fork = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_FFT")) c->grad_fft = atoi(e) != 0;
@@ -2918,11 +2920,15 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   }
 
   Batch bt;
-  const bool ge_tab = c->logdt_ok;
+  // regular grid: stationary subtrees from rank lag tables, as in the caller-order sweeps of logpdf_batch_impl (the mode depends
+  // on the resident series alone, so an extension and a from-scratch sweep of the same entry evaluate every tile the same way)
+  const bool lagr = c->lag_rank_enable && c->lag_store_enable && c->lag_enable && c->lag_ok && c->intrsm != 0 && c->n_max <= 4096;
+  const int rank_units = (int)((c->n_max + 255) / 256);
+  const bool ge_tab = c->logdt_ok && !lagr;
   // (tiles are evaluated inside the factorisation kernels whatever the population size: the prebuilt-tile variants of
   // the split launches carry the most register spills, and the store never needs K itself)
   int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, ge_tab, /*fuse_hint=*/true,
-                         /*flow_limit=*/c->intrsm != 0 && c->flow != 0 && U <= FLOW_MAX_PARTICLES);
+                         /*flow_limit=*/c->intrsm != 0 && c->flow != 0 && U <= FLOW_MAX_PARTICLES, lagr, lagr ? rank_units : 1);
   if (rc) { poison(); return rc; }
   int i0min = nt;
   for (int u = 0; u < U; ++u) i0min = std::min(i0min, (int)i0[u]);
@@ -2940,7 +2946,10 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   const size_t o_i0 = al16(o_slot + sizeof(int32_t) * (size_t)U);
   const size_t o_ops = al16(o_i0 + sizeof(int32_t) * (size_t)U);
   const size_t o_rep = al16(o_ops + bt.ops.size() + 4);                  // caller particle -> distinct particle (d_out_caller)
-  const size_t stage_bytes = al16(o_rep + (d_out_caller ? sizeof(int32_t) * (size_t)P : 0));
+  const size_t o_thdr = al16(o_rep + (d_out_caller ? sizeof(int32_t) * (size_t)P : 0));      // lag-table programs (rank tables)
+  const size_t o_tprm = al16(o_thdr + sizeof(LagTabHdr) * bt.thdr.size());
+  const size_t o_tops = al16(o_tprm + sizeof(double) * bt.tprm.size());
+  const size_t stage_bytes = al16(o_tops + bt.tops.size() + 4);
   auto hipfail = [&](hipError_t e, const char* what) {
     poison();
     return fail(c, AGP_ERR_HIP, std::string("HIP error in the extension sweep (") + what + "): " + hipGetErrorString(e));
@@ -2964,6 +2973,11 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
       int32_t* hr = reinterpret_cast<int32_t*>(h + o_rep);
       for (int p = 0; p < P; ++p) hr[p] = rep[p];
     }
+    if (!bt.thdr.empty()) {
+      std::memcpy(h + o_thdr, bt.thdr.data(), sizeof(LagTabHdr) * bt.thdr.size());
+      std::memcpy(h + o_tprm, bt.tprm.data(), sizeof(double) * bt.tprm.size());
+      std::memcpy(h + o_tops, bt.tops.data(), bt.tops.size());
+    }
   }
   char* dstage = static_cast<char*>(s->stage.p);
   EXTCHK(hipMemcpyAsync(dstage, s->h_stage.p, stage_bytes, hipMemcpyHostToDevice, st));
@@ -2973,6 +2987,16 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   int32_t* d_info = reinterpret_cast<int32_t*>(d_lp + U);
 
   if (i0min < nt) {
+    if (lagr && bt.n_lag_tables > 0) {
+      EXTCHK(s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * rank_units * 256));
+      LagArgs la = {};
+      la.tt = c->d_ts_s; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
+      la.tops = reinterpret_cast<const uint8_t*>(dstage + o_tops); la.tprm = reinterpret_cast<const double*>(dstage + o_tprm);
+      la.n_tables = bt.n_lag_tables; la.tab = s->lagtab.as<double>(); la.nt = (int)((c->n_max + NB - 1) / NB);
+      la.full = 1; la.stride = rank_units * 256;
+      hipLaunchKernelGGL(k_lag_tables, dim3(rank_units, bt.n_lag_tables), dim3(256), 0, st, la);
+      EXTCHK(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_init_extend, dim3((n_pad + 255) / 256, U), dim3(256), 0, st, fs.vec.as<double>(), fs.nt_cap * NB,
                        n_pad, c->d_xs, (int)n, d_slot, d_i0, fs.info.as<int>(), fs.ready.as<int>());
     CovArgs cv = {};
@@ -2980,6 +3004,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     cv.hdr = reinterpret_cast<ProgHdr*>(dstage + o_hdr); cv.ops = reinterpret_cast<uint8_t*>(dstage + o_ops);
     cv.prm = reinterpret_cast<double*>(dstage + o_prm); cv.noise = reinterpret_cast<double*>(dstage + o_noise);
     cv.A = fs.A.as<double>(); cv.strideA = fs.strideA; cv.P = U; cv.logdt = ge_tab ? c->d_logdt : nullptr;
+    cv.lagtab = lagr ? s->lagtab.as<double>() : nullptr; cv.lagr = lagr ? c->d_rank : nullptr; cv.lag_stride = rank_units * 256;
     cv.slot = d_slot; cv.i0 = d_i0;
     const int nf = std::max(0, std::min(U, bt.n_fused));
     const int dcov = nf > 0 ? bt.max_depth_fused : 0;
@@ -2990,6 +3015,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     ca.vec = fs.vec.as<double>(); ca.ldv = fs.nt_cap * NB; ca.partial = fs.partial.as<double>(); ca.ntp = fs.nt_cap;
     ca.info = fs.info.as<int>(); ca.ready = fs.ready.as<int>(); ca.P = U; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
     set_cov(ca, cv);
+    ca.lag = lagr ? 1 : 0;
     ca.n_fused = nf; ca.slot = d_slot; ca.i0 = d_i0;
     // an extension touches every block column (the new rows' tiles of the old columns, then the new columns): one
     // dataflow launch instead of nt small per-column launches, whatever the amount of work

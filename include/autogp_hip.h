@@ -149,8 +149,8 @@ int agp_set_factor_cache(agp_ctx* ctx, int32_t on);
  * 279-289, 324-336) is evaluated 255 times per 128 x 128 tile into an LDS table instead of 16 384 times, and tiles are
  * evaluated inside the factorisation kernels whatever the kernel tree's size.  Results agree with the general path to
  * rounding (the table's representative t_i - t_j differs from an element's own by a few ulp of t).  Prefix sweeps
- * (n < n_max: a subset of a shuffled grid is not a grid) and gradient sweeps use rank tables instead (below); irregular series,
- * the extension / factor-store and predictive entries take the general path.  AGP_LAG=0 / agp_set_lag_tables(ctx, 0) disable it (the switch is read at
+ * (n < n_max: a subset of a shuffled grid is not a grid), gradient sweeps and the factor store's sweeps use rank tables instead
+ * (below); irregular series and the predictive entries take the general path.  AGP_LAG=0 / agp_set_lag_tables(ctx, 0) disable it (the switch is read at
  * the next agp_set_data).  agp_get_lag_stats: whether the resident series qualifies, and how many sweeps took the path. */
 int agp_get_lag_stats(agp_ctx* ctx, int32_t* regular_grid, int64_t* n_lag_sweeps);
 int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
@@ -160,8 +160,10 @@ int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
  * keeps the caller's order and reads the same stationary subtrees from RANK tables: |t_a - t_b| = |rank_a - rank_b| h whatever
  * the order of the points, so one table of n_max lags per subtree and sweep (instead of 255 per tile) serves every element.
  * Same agreement with the general path as the sorted sweeps.  AGP_LAG_RANK=0 / agp_set_lag_rank_tables(ctx, 0) disable it
- * (takes effect at the next sweep); agp_get_lag_rank_stats counts the sweeps that used it.  The store / extension and
- * predictive entries keep the general path. */
+ * (takes effect at the next sweep); agp_get_lag_rank_stats counts the sweeps of agp_logpdf_batch / agp_logpdf_grad_batch that used
+ * it.  The factor store's sweeps (agp_logpdf_batch_extend, the coalesced batches of agp_logpdf) read rank tables too (AGP_LAG_STORE=0
+ * restores the general path there; the choice depends on the resident series alone, so an extension and a from-scratch sweep of
+ * one entry still agree bit for bit); the predictive entries keep the general path. */
 int agp_set_lag_rank_tables(agp_ctx* ctx, int32_t on);
 int agp_get_lag_rank_stats(agp_ctx* ctx, int64_t* n_sweeps);
 
