@@ -10,11 +10,11 @@ import __graft_entry__ as g
 from oracle import oracle as O
 
 
-def run(pkg, eng, cases=60, seed=1):
+def run(pkg, eng, cases=60, seed=1, big=False):
     rng = np.random.default_rng(seed)
     worst = 0.0; worst_g = 0.0; t0 = time.time(); nbad = 0; nstore = 0
     for c in range(cases):
-        n = int(rng.choice([1, 2, 63, 127, 128, 129, 255, 256, 257, 383, 385, 500, 640, 777, 900]))
+        n = int(rng.choice([1, 2, 63, 127, 128, 129, 255, 256, 257, 383, 385, 500, 640, 777, 900] + ([1025, 1100, 1536, 2048] if big else [])))      # (big: the spectral lag sums of gradient sweeps start above 1024 points)
         P = int(rng.choice([1, 2, 7, 8, 9, 47, 48, 49, 63, 100, 129, 255, 256, 257, 300, 513]))
         if n * n * P > 640 * 640 * 300: P = max(1, (640 * 640 * 300) // (n * n))
         depth = int(rng.integers(1, 5))
@@ -86,4 +86,5 @@ def run(pkg, eng, cases=60, seed=1):
 
 if __name__ == "__main__":
     pkg_ = g.load_package()
-    print(run(pkg_, pkg_.GPEngine(0), int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
+    print(run(pkg_, pkg_.GPEngine(0), int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+              big=len(sys.argv) > 3 and sys.argv[3] == "big"))
