@@ -927,9 +927,9 @@ __global__ __launch_bounds__(256, 2) void k_zspec(GradArgs a) {
     }
   };
   fetch(0);
+  for (int i = tid; i < FFT_ZHI_CLEAR; i += 256) buf[i] = d2{0.0, 0.0};
+  __syncthreads();
   for (int c = 0; c < ncol; c += 2) {
-    for (int i = tid; i < FFT_ZHI_CLEAR; i += 256) buf[i] = d2{0.0, 0.0};
-    __syncthreads();
     double ut = 0.0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -946,10 +946,19 @@ __global__ __launch_bounds__(256, 2) void k_zspec(GradArgs a) {
     if (l == 0) red[w] = ut;
     __syncthreads();
     fft4096_lds<true>(buf, tw, tid);
+    // this thread's 16 spectrum values; the eight of them in the lower half (elements tid + 256 j, j < 8: together the whole
+    // zero-padded input range) are cleared on the spot for the next column pair — no separate clearing pass, one barrier less
+    d2 dc = d2{0.0, 0.0};
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { const d2 f = (buf + fft_pad(tid))[j * 272]; P[j] = fma(f.x, f.x, fma(f.y, f.y, P[j])); }
+    for (int j = 0; j < 16; ++j) {
+      d2* q = buf + fft_pad(tid) + j * 272;
+      const d2 f = *q;
+      if (j == 0) dc = f;
+      P[j] = fma(f.x, f.x, fma(f.y, f.y, P[j]));
+      if (j < 8) *q = d2{0.0, 0.0};
+    }
     if (tid == 0) {
-      const double s0 = buf[0].x, s1 = buf[0].y, u0 = (red[0] + red[1]) * a.grid_h, u1 = (red[2] + red[3]) * a.grid_h;
+      const double s0 = dc.x, s1 = dc.y, u0 = (red[0] + red[1]) * a.grid_h, u1 = (red[2] + red[3]) * a.grid_h;
       m0 += s0 * s0 + s1 * s1; m1 += 2.0 * (s0 * u0 + s1 * u1); m2 += u0 * u0 + u1 * u1;
     }
     __syncthreads();
