@@ -2,7 +2,7 @@
 // agp_debug_gemm_variant).  Same tile walk as k_chol_update for the off-diagonal tiles of one block
 // column, with parts of the pipeline switched off to see what each costs.
 #pragma once
-#include "agp_chol_kernel.hpp"
+#include "../agp_chol_kernel.hpp"
 
 namespace agp {
 
