@@ -339,11 +339,13 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
 
   if (mark && tid == 0) *mark = (long long)wall_clock64();
   // ---- write L(k,k) (upper part zero), alpha_k, partials, info ----
-  for (int bi = 0; bi < NSB * NSB; ++bi) {
-    const int rb = bi >> 3, cb = bi & 7;
-    const int c = tid >> 4, r = tid & 15;
-    const double v = (rb >= cb) ? sm[blk_idx(rb, cb) * 256 + tid] : 0.0;
-    Tt[(cb * 16 + c) * NB + rb * 16 + r] = v;
+  // (two rows per lane: 16-byte LDS reads and stores, 32 instructions per lane instead of 64)
+  for (int bi = 0; bi < NSB * NSB / 2; ++bi) {
+    const int rb = 2 * (bi >> 3) + ((tid >> 3) & 1), cb = bi & 7;
+    const int c = tid >> 4, r2 = 2 * (tid & 7);
+    d2 v = d2{0.0, 0.0};
+    if (rb >= cb) v = *reinterpret_cast<const d2*>(sm + blk_idx(rb, cb) * 256 + c * 16 + r2);
+    *reinterpret_cast<d2*>(Tt + (cb * 16 + c) * NB + rb * 16 + r2) = v;
   }
   if (tid < NB) {
     vecp[tk * NB + tid] = avec[tid];
