@@ -129,6 +129,7 @@ struct agp_ctx {
   double* d_xs = nullptr;
   int64_t n_max = 0;
   std::vector<double> h_ts;   // host copy (prediction builds a joint point list)
+  std::vector<double> h_ts_sorted;   // ascending copy when the series is a regular grid (empty otherwise)
   // config
   int64_t ws_limit = 0;
   size_t total_mem = 0;
@@ -176,6 +177,7 @@ struct agp_ctx {
   int64_t n_lagdom_particles = 0;   // particles contracted in the lag domain so far (agp_get_lag_stats)
   bool lag_ok = false;
   int lag_enable = 1;
+  double lag_tol_h = 4e-12;       // admitted deviation of a sorted point from its grid position, in units of the spacing (agp_set_data)
   int64_t n_lag_sweeps = 0;       // sweeps that took the lag path (agp_get_lag_stats)
   double* d_logdt = nullptr;      // packed lower tiles, covers the resident data
   size_t logdt_cap = 0;
@@ -239,6 +241,7 @@ struct agp_ctx {
   //      negative info word (the bounded in-kernel wait gave up) is latched here when the slot is next claimed and
   //      reported by the next device-output call / agp_wait ----
   bool async_fault = false;
+  int claimed_waits = 0;                // acquirers waiting (outside the lock) for the event of an asynchronous slot they claimed
   // ---- persistent host thread of this device for the one-process-drives-the-node entries (agp_logpdf_batch_multi) ----
   struct Worker {
     std::thread th;
@@ -248,6 +251,8 @@ struct agp_ctx {
     bool has_job = false, done = true, stop = false;
   };
   Worker* worker = nullptr;
+  std::mutex multi_mu;                  // (on the first context of agp_init_multi) one agp_logpdf_batch{,_extend}_multi call at a time:
+                                        // the per-device workers hold one job each
 };
 
 namespace {
@@ -300,9 +305,12 @@ Slot* acquire_slot(agp_ctx* c) {
       // every slot is taken and at least one only waits for the GPU: claim it (pending -> false keeps other
       // acquirers away) and wait for its work outside the lock
       waiting->pending = false;
+      ++c->claimed_waits;                  // (agp_wait: an asynchronous sweep is still running although no slot is `pending`)
       g.unlock();
       (void)hipEventSynchronize(waiting->done);
       g.lock();
+      --c->claimed_waits;
+      c->cv.notify_all();
       latch_async_info(c, waiting);
       return waiting;
     }
@@ -319,7 +327,8 @@ struct SlotGuard {
   agp_ctx* c; Slot* s;
   bool async_done = false;    // the call recorded s->done behind its work and returns without waiting for it
   SlotGuard(agp_ctx* c_) : c(c_), s(acquire_slot(c_)) {}
-  ~SlotGuard() { release_slot(c, s, async_done); }
+  ~SlotGuard() { release(); }
+  void release() { if (s) { release_slot(c, s, async_done); s = nullptr; } }
 };
 
 // ------------------------------------------------------------------------------------------
@@ -546,9 +555,9 @@ int emit_grad(const std::vector<CNode>& nodes, int id, Batch& bt, int prm_base, 
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                   const double* prm, Batch& bt, bool allow_sel = false, bool want_grad = false, bool ge_tab = false,
-                  bool fuse_hint = false, bool flow_limit = false, bool lag = false, int lag_units = 1) {
-  // (lag_units: LDS footprint of one lag table in 256-double units — 1 on a sorted sweep, n_max / 256 for rank tables, + 1 there
-  // for the tile's ranks)
+                  bool fuse_hint = false, bool flow_limit = false, bool lag = false, int lag_units = 1, bool rank_mode = false) {
+  // (lag_units: LDS footprint of one lag table in 256-double units — 1 on a sorted sweep, n_max / 256 for rank tables; rank_mode
+  // adds one unit for the tile's ranks and, in k_cov_tiles, the exponential table behind them — also when n_max <= 256)
   std::vector<Compiled> cps(P);
   std::vector<double> cost(P, 0.0);
   for (int p = 0; p < P; ++p) {
@@ -575,7 +584,7 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   // stationary leaves there — see compile_program — must be prebuilt: the GM = 2 instantiations have no transcendental code)
   auto lag_ok = [&](int p) { bool direct = false; for (uint8_t o : cps[p].ops) direct |= (o == OP_SE || o == OP_GE || o == OP_PER || o == OP_GE_TAB); return !direct; };
   auto fusable = [&](int p) {
-    if (lag) return fuse_on && cost[p] <= fuse_limit && lag_ok(p) && cps[p].n_cp + cps[p].n_lag * lag_units + (lag_units > 1 ? 1 : 0) <= U_MAX_CP;
+    if (lag) return fuse_on && cost[p] <= fuse_limit && lag_ok(p) && cps[p].n_cp + cps[p].n_lag * lag_units + (rank_mode ? 1 : 0) <= U_MAX_CP;
     return fuse_on && cost[p] <= fuse_limit && cps[p].n_cp <= U_MAX_CP;
   };
   bt.order.resize(P);
@@ -606,8 +615,8 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
     bt.hdr[q] = h;
     bt.ops.insert(bt.ops.end(), cp.ops.begin(), cp.ops.end());
     bt.prm.insert(bt.prm.end(), cp.prm.begin(), cp.prm.end());
-    const int lds_units = cp.n_cp + cp.n_lag * lag_units + (lag_units > 1 ? 1 : 0);      // LDS tables of any kind (per-point + lag), 256 doubles each
-    bt.max_cp = std::max(bt.max_cp, lag_units > 1 ? cp.n_cp + 1 : lds_units);      // (k_cov_tiles reads rank tables in place)
+    const int lds_units = cp.n_cp + cp.n_lag * lag_units + (rank_mode ? 1 : 0);      // LDS tables of any kind (per-point + lag), 256 doubles each
+    bt.max_cp = std::max(bt.max_cp, rank_mode ? cp.n_cp + 1 : lds_units);      // (k_cov_tiles reads rank tables in place)
     bt.max_depth = std::max(bt.max_depth, cp.depth_need);
     if (fusable(bt.order[q])) {
       bt.n_fused = q + 1;
@@ -1031,7 +1040,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   // reads the same leaves from RANK tables: |t_a - t_b| = |rank_a - rank_b| h in any order (cov_prologue)
   const int rank_units = (int)((c->n_max + 255) / 256);
   bool lagr = !lag && allow_lag && c->lag_rank_enable && c->lag_enable && c->lag_ok && n > 0 && c->intrsm != 0 && c->n_max <= 4096;
-  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint, lag || lagr, lagr ? rank_units : 1);
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint, lag || lagr, lagr ? rank_units : 1, lagr);
   if (rc) return rc;
   if (lagr) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_rank_sweeps; }
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
@@ -1551,6 +1560,9 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         bnoise[b] = noise[p];
       }
       if (bprm.empty()) bprm.push_back(0.0);
+      // (the results are on the host: hand the slot back first — sixteen concurrent callers that each kept theirs while waiting
+      // for a second one would wait for ever)
+      sg.release();
       const int rc2 = logpdf_batch_impl(c, n, B, bo.data(), bops.data(), bp.data(), bprm.data(), bnoise.data(), blp.data(), binfo.data(),
                                         nullptr, nullptr, nullptr, false, nullptr, /*allow_lag=*/false);
       if (rc2) return rc2;
@@ -1730,6 +1742,8 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
                         std::memcmp(xs, c->h_xs.data(), sizeof(double) * (size_t)c->n_max) == 0;
     if (!prefix) c->store.forget();
   }
+  const bool lag_was = c->lag_ok;
+  const std::vector<double> tss_was = c->h_ts_sorted;
   if (c->d_ts) { HIPCHK(c, hipFree(c->d_ts)); c->d_ts = nullptr; }
   if (c->d_xs) { HIPCHK(c, hipFree(c->d_xs)); c->d_xs = nullptr; }
   // padded to a whole tile so kernels may read (and ignore) the tail
@@ -1760,8 +1774,14 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
     for (int64_t i = 0; i < n_max; ++i) { tss[(size_t)i] = ts[perm[(size_t)i]]; xss[(size_t)i] = xs[perm[(size_t)i]]; }
     const double t0 = tss.front(), t1 = tss.back();
     const double h = (t1 - t0) / (double)(n_max - 1);
-    const double tol = 16.0 * 2.220446049250313e-16 * std::max(std::fabs(t0), std::fabs(t1));
-    bool regular = std::isfinite(h) && h > 0.0 && tol < 1e-6 * h;
+    // The tolerance is a fraction of the SPACING, not of |t|: on the lag path every t_i - t_j is replaced by the table's
+    // t_sorted[g] - t_sorted[0], which differs from the element's own difference by up to ~4 deviations, i.e. by a relative
+    // 4 dev / (g h) of the lag.  linspace(0, 1, n) sits within half an ulp of 1 of its grid (dev / h = 2.3e-13 at n = 2048,
+    // 1.8e-12 at n = 16384) and agrees with the general path to 4e-13 of the log-pdf on short-lengthscale populations; the
+    // bound admits 4e-12, which keeps that agreement below 1e-11 — three digits under the 1e-8 contract.  A series with a large
+    // offset (linspace(1000, 1001, 2048): dev / h = 1e-10) or a jitter below the old 16-ulp-of-|t| bound takes the general path.
+    const double tol = c->lag_tol_h * h;
+    bool regular = std::isfinite(h) && h > 0.0;
     for (int64_t i = 0; regular && i < n_max; ++i) regular = std::fabs(tss[(size_t)i] - (t0 + (double)i * h)) <= tol;
     if (regular) {
       HIPCHK(c, hipMalloc((void**)&c->d_ts_s, sizeof(double) * npad));
@@ -1789,7 +1809,21 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
         c->d_fft_tw = d_tw;
       }
       c->lag_ok = true;
+      c->h_ts_sorted = tss;
     }
+  }
+  if (!c->lag_ok) c->h_ts_sorted.clear();
+  {
+    // The store's sweeps read rank tables on a regular grid and the general evaluator otherwise; an extension agrees bit for bit
+    // with a from-scratch sweep of the same entry only while resident rows and new rows are evaluated the same way.  After an
+    // append that holds when the mode is unchanged and, on a grid, the old sorted series is a prefix of the new one (same ranks,
+    // same table entries t_sorted[g] - t_sorted[0] for the old lags); anything else drops the resident factors.
+    std::lock_guard<std::mutex> g(c->store.mu);
+    bool same = lag_was == c->lag_ok;
+    if (same && c->lag_ok)
+      same = tss_was.size() <= c->h_ts_sorted.size() &&
+             std::memcmp(tss_was.data(), c->h_ts_sorted.data(), sizeof(double) * tss_was.size()) == 0;
+    if (!same) c->store.forget();
   }
   // log|t_i - t_j| over the resident points, shared by the GammaExp leaves of every particle (OP_GE_TAB)
   c->logdt_ok = false;
@@ -1919,6 +1953,11 @@ int agp_wait(agp_ctx* c) {
     HIPCHK(c, hipEventSynchronize(w->done));
     std::lock_guard<std::mutex> g(c->mu);
     if (w->pending && hipEventQuery(w->done) == hipSuccess) { w->pending = false; w->busy = false; latch_async_info(c, w); }
+  }
+  {
+    // slots claimed by a waiting acquirer (acquire_slot) are no longer `pending`, but their sweeps may still run
+    std::unique_lock<std::mutex> g(c->mu);
+    c->cv.wait(g, [&] { return c->claimed_waits == 0; });
   }
   c->cv.notify_all();
   bool fault;
@@ -2928,7 +2967,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   // (tiles are evaluated inside the factorisation kernels whatever the population size: the prebuilt-tile variants of
   // the split launches carry the most register spills, and the store never needs K itself)
   int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, ge_tab, /*fuse_hint=*/true,
-                         /*flow_limit=*/c->intrsm != 0 && c->flow != 0 && U <= FLOW_MAX_PARTICLES, lagr, lagr ? rank_units : 1);
+                         /*flow_limit=*/c->intrsm != 0 && c->flow != 0 && U <= FLOW_MAX_PARTICLES, lagr, lagr ? rank_units : 1, lagr);
   if (rc) { poison(); return rc; }
   int i0min = nt;
   for (int u = 0; u < U; ++u) i0min = std::min(i0min, (int)i0[u]);
@@ -3417,6 +3456,9 @@ static int logpdf_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t 
     if (!ctxs[d] || ctxs[d]->comm_size != n_dev || ctxs[d]->comm_rank != d || (n_dev > 1 && !ctxs[d]->comm))
       return fail(c0, AGP_ERR_ARG, "contexts must come from agp_init_multi, in order");
   const int mx = (P + n_dev - 1) / n_dev;
+  // One population step at a time (what the reference's SMC loop issues, src/inference_smc_anneal_data.jl:206-232): concurrent
+  // callers are serialised here — the per-device worker threads hold a single job slot each.
+  std::lock_guard<std::mutex> multi_lock(c0->multi_mu);
   std::vector<int> rcs((size_t)n_dev, AGP_OK);
   auto shard = [&](int d) {
     agp_ctx* c = ctxs[d];

@@ -140,11 +140,13 @@ def test_invalidation(pkg, eng):
     a, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=n)            # the original key: extended 300 -> 600
     assert eng.extend_stats()["extended"] == 1
     assert lp_err(a, eng.logpdf_batch([k], np.array([0.05]), n=n)[0]).max() <= 1e-12
-    # add_data!: the series grows, the prefix is unchanged -> the factor of n=600 is extended to 900
+    # add_data! (src/api.jl:426-443) that CHANGES how tiles are evaluated — the first 600 points of a shuffled grid are no grid,
+    # all 900 are (rank tables from now on) — drops the resident factors: extension == from-scratch bit for bit is kept
     eng.set_data(ts, xs)
+    assert eng.lag_stats()[0] is True
     a, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=n + 300)
-    assert eng.extend_stats()["extended"] == 2
-    assert lp_err(a, eng.logpdf_batch([k], np.array([0.05]), n=n + 300)[0]).max() <= 1e-12
+    st = eng.extend_stats()
+    assert st["extended"] == 1 and st["from_scratch"] == 5
     ref, _ = F.gp_logpdf_many(pkg.encode_batch([k]), np.array([0.05]), ts, xs)
     assert lp_err(a, ref).max() <= LP_TOL
     # different data (one observation changed inside the prefix): nothing may be reused
@@ -152,9 +154,30 @@ def test_invalidation(pkg, eng):
     eng.set_data(ts, xs2)
     a, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=n + 300)
     st = eng.extend_stats()
-    assert st["extended"] == 2 and st["from_scratch"] == 5
+    assert st["extended"] == 1 and st["from_scratch"] == 6
     ref2, _ = F.gp_logpdf_many(pkg.encode_batch([k]), np.array([0.05]), ts, xs2)
     assert lp_err(a, ref2).max() <= LP_TOL and abs(a[0] - ref[0]) > 1e-6
+    # add_data! in time order (scripts/online.jl): the old sorted series is a prefix of the new one, an irregular series stays
+    # irregular -> the factor of the shorter series is extended, and equals the from-scratch factor of the longer one bit for bit
+    for regular in (True, False):
+        tq = np.linspace(0.0, 1.0, n + 300)
+        if not regular: tq = tq + 1e-4 * np.sin(37.0 * tq)
+        xq = np.cos(9 * tq) + 0.05 * np.sin(131 * tq)
+        eng.set_data(tq[:n], xq[:n])
+        assert eng.lag_stats()[0] is regular
+        eng.logpdf_batch_extend([k], np.array([0.05]), n=n)
+        before = eng.extend_stats()
+        eng.set_data(tq, xq)
+        assert eng.lag_stats()[0] is regular
+        a, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=n + 300)
+        st = eng.extend_stats()
+        assert st["extended"] == before["extended"] + 1 and st["from_scratch"] == before["from_scratch"]
+        eng.extend_reset()
+        b, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=n + 300)
+        assert np.array_equal(a, b)
+        refq, _ = F.gp_logpdf_many(pkg.encode_batch([k]), np.array([0.05]), tq, xq)
+        assert lp_err(a, refq).max() <= LP_TOL
+    eng.set_data(ts, xs2)
     # a shorter prefix than the resident factor's: redone, correct
     b, _ = eng.logpdf_batch_extend([k], np.array([0.05]), n=250)
     assert lp_err(b, eng.logpdf_batch([k], np.array([0.05]), n=250)[0]).max() <= 1e-12

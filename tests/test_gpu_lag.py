@@ -102,10 +102,12 @@ def test_what_must_not_take_the_lag_path(pkg):
         eng.logpdf_batch_extend(nodes, noises, check=False)
         eng.predict_batch(nodes[:2], noises[:2], np.linspace(0, 1.1, 20), check=False)
         assert eng.lag_stats() == (True, 1) and eng.lag_rank_sweeps() == 2
-        # a grid jittered by 1e-9 (relative), a random series, a grid with one point missing and with a duplicate
+        # a grid jittered by 1e-9 (relative), by 1e-14 (inside the former 16-ulp-of-|t| bound, 2e-11 spacings), a random series, a grid
+        # with one point missing and with a duplicate
         rng = np.random.default_rng(0)
         grid = np.linspace(0.0, 1.0, 400)
-        for bad in (grid * (1 + 1e-9 * rng.standard_normal(400)), np.sort(rng.random(400)), np.delete(grid, 17),
+        for bad in (grid * (1 + 1e-9 * rng.standard_normal(400)), grid + 5e-14 * np.cos(np.arange(400.0)) * (grid > 0) * (grid < 1),
+                    np.sort(rng.random(400)), np.delete(grid, 17),
                     np.concatenate([grid[:200], grid[199:]])):
             eng.set_data(bad, np.cos(3 * bad))
             assert eng.lag_stats()[0] is False
@@ -114,6 +116,62 @@ def test_what_must_not_take_the_lag_path(pkg):
             ok = (info == 0) & (rinfo == 0)
             assert lp_err(lp[ok], ref[ok]).max() <= LP_TOL
         assert eng.lag_stats()[1] == 1 and eng.lag_rank_sweeps() == 2
+    finally:
+        eng.close()
+
+
+def _short_scale_population(pkg, rng, span):
+    """Kernels whose values move fastest with the time differences: lengthscales ~0.01 of the series' span, periods ~0.015 of it
+    (the reference's raw-space calls, test/test_GP.jl:35-68, use parameters in the units of the time axis)."""
+    G = pkg
+    l, p = 0.01 * span, 0.015 * span
+    ks = [G.SquaredExponential(l, 0.9), G.Periodic(0.5, p, 1.1), G.GammaExponential(l, 1.0, 0.7), G.GammaExponential(2 * l, 1.9, 0.6),
+          G.Periodic(0.8, p, 1.0) * G.SquaredExponential(20 * l, 0.8), G.SquaredExponential(l, 0.5) + G.Periodic(0.6, 1.3 * p, 0.4),
+          G.GammaExponential(l, 0.6, 0.5) + G.Constant(0.2), G.Periodic(1.2, 0.7 * p, 0.9) + G.WhiteNoise(0.01)]
+    nz = 0.02 + 0.2 * rng.random(len(ks))
+    return ks, nz
+
+
+@pytest.mark.parametrize("case", ["offset_1e3", "offset_1e5", "appended", "inside", "outside", "unit"])
+def test_regular_grid_admission_is_tied_to_the_spacing(pkg, case):
+    """agp_set_data admits a series to the lag path when every sorted point sits within 4e-12 SPACINGS of t_0 + g h (the tables
+    replace t_i - t_j by t_sorted[g] - t_sorted[0]: the admitted relative error of the smallest lag is ~1e-11).  Grids with a
+    large offset (add_data! keeps the old transform, src/api.jl:434; raw-space calls as in test/test_GP.jl:35-68) and grids
+    jittered below the former 16-ulp-of-|t| bound must be REFUSED; what is admitted must meet 1e-8 against the oracle and 1e-10
+    against the general path with short-lengthscale kernels at n = 2048."""
+    n = 2048
+    rng = np.random.default_rng(12)
+    base = np.linspace(0.0, 1.0, n)
+    h = base[1] - base[0]
+    if case == "offset_1e3":   tg, expect = np.linspace(1000.0, 1001.0, n), False        # dev / h ~ 1e-10
+    elif case == "offset_1e5": tg, expect = np.linspace(1e5, 1e5 + 1.0, n), False        # dev / h ~ 1e-8
+    elif case == "appended":   tg, expect = np.concatenate([base, 1.0 + h * np.arange(1, 1025)]), None      # add_data!: [0, 1.5]
+    elif case == "inside":     tg, expect = base + 1e-15 * np.sign(np.sin(7.0 * np.arange(n))) * (np.arange(n) % 5 != 0), True     # 2e-12 h
+    elif case == "outside":    tg, expect = base + 4e-15 * np.sign(np.sin(7.0 * np.arange(n))) * (np.arange(n) % 5 != 0), False    # 8e-12 h
+    else:                      tg, expect = base, True
+    tg = np.asarray(tg, dtype=np.float64)
+    if case in ("inside", "outside"): tg[0], tg[-1] = base[0], base[-1]      # (end points define the grid)
+    span = tg.max() - tg.min()
+    ks, nz = _short_scale_population(pkg, rng, span)
+    perm = rng.permutation(len(tg))
+    ts = tg[perm]
+    xs = np.sin(40.0 * (ts - tg.min()) / span) + 0.3 * rng.standard_normal(len(ts))
+    la, ia, lb, ib, took, regular = both_paths(pkg, ks, nz, ts, xs)
+    if expect is not None: assert regular is expect, (case, regular)
+    assert (took >= 1) == bool(regular)
+    assert (ia == 0).all() and (ib == 0).all()
+    assert lp_err(la, lb).max() <= 1e-10, (case, lp_err(la, lb).max())
+    ref, rinfo = F.gp_logpdf_many(pkg.encode_batch(ks), nz, ts, xs)
+    assert (rinfo == 0).all() and lp_err(la, ref).max() <= LP_TOL, (case, lp_err(la, ref).max())
+    # rank tables (an annealing prefix in the caller's order) and the lag-domain gradient follow the same admission
+    eng = pkg.GPEngine(0)
+    try:
+        eng.set_data(ts, xs)
+        m = len(ts) - 200
+        lp, info = eng.logpdf_batch(ks, nz, n=m, check=False)
+        assert (eng.lag_rank_sweeps() == 1) == bool(regular) or len(ts) > 4096
+        refm, _ = F.gp_logpdf_many(pkg.encode_batch(ks), nz, ts[:m], xs[:m])
+        assert (info == 0).all() and lp_err(lp, refm).max() <= LP_TOL
     finally:
         eng.close()
 

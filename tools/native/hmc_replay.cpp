@@ -45,7 +45,17 @@ static void gen_tree(std::mt19937_64& g, int depth, Particle& p) {
   p.ops.push_back(u(g) < 0.5 ? 6 : 7);
 }
 
-struct Counters { std::atomic<long long> grad{0}, value{0}, accepted{0}, failed{0}; };
+// api_errors: the call itself failed (rc != 0) — never expected; not_pd: LAPACK info > 0 at a proposal (a legitimate rejection, as
+// LinearAlgebra.PosDefException would be in the reference); non_finite: rc == 0, info == 0 and still no finite value
+struct Counters {
+  std::atomic<long long> grad{0}, value{0}, accepted{0}, api_errors{0}, not_pd{0}, non_finite{0};
+  bool classify(int rc, int32_t info, double lp) {
+    if (rc != 0) { api_errors.fetch_add(1); return false; }
+    if (info != 0) { not_pd.fetch_add(1); return false; }
+    if (!std::isfinite(lp)) { non_finite.fetch_add(1); return false; }
+    return true;
+  }
+};
 
 // value + gradient w.r.t. q = log(theta) (and log noise)
 static bool eval_grad(agp_ctx* ctx, int n, const Particle& p, const std::vector<double>& q, double qn, double* lp,
@@ -57,7 +67,7 @@ static bool eval_grad(agp_ctx* ctx, int n, const Particle& p, const std::vector<
   double gn = 0.0; int32_t info = 0;
   const int rc = agp_logpdf_grad(ctx, n, p.ops.data(), (int32_t)p.ops.size(), th.data(), (int32_t)th.size(), nz, lp, g.data(), &gn, &info);
   c.grad.fetch_add(1);
-  if (rc != 0 || info != 0 || !std::isfinite(*lp)) { c.failed.fetch_add(1); return false; }
+  if (!c.classify(rc, info, *lp)) return false;
   for (size_t i = 0; i < q.size(); ++i) gq[i] = g[i] * th[i];
   *gqn = gn * nz;
   return true;
@@ -68,8 +78,7 @@ static bool eval_value(agp_ctx* ctx, int n, const Particle& p, const std::vector
   int32_t info = 0;
   const int rc = agp_logpdf(ctx, n, p.ops.data(), (int32_t)p.ops.size(), th.data(), (int32_t)th.size(), std::exp(qn), lp, &info);
   c.value.fetch_add(1);
-  if (rc != 0 || info != 0 || !std::isfinite(*lp)) { c.failed.fetch_add(1); return false; }
-  return true;
+  return c.classify(rc, info, *lp);
 }
 
 // One Gen.hmc move on the selected coordinates (all kernel parameters, or the noise alone): 1 + L gradient calls,
@@ -160,11 +169,11 @@ int main(int argc, char** argv) {
          "\"n\": %d, \"threads\": %d, \"hmc_iterations_per_particle\": %d, \"L\": %d, \"eps\": %g, "
          "\"seconds\": %.4f, \"hmc_iterations_per_s\": %.2f, \"seconds_per_iteration_of_the_population\": %.4f, "
          "\"gradient_calls\": %lld, \"value_calls\": %lld, \"calls_per_s\": %.1f, \"coalesced_batches\": %lld, \"mean_batch\": %.1f, "
-         "\"accepted_param_moves\": %lld, \"failed_calls\": %lld}\n",
+         "\"accepted_param_moves\": %lld, \"api_errors\": %lld, \"not_positive_definite\": %lld, \"non_finite\": %lld}\n",
          grid ? "regular grid, shuffled" : "irregular", (long long)n_lagdom, (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
          n, T, iters, L, eps, dt, it_total / dt, dt / iters, cnt.grad.load(), cnt.value.load(),
          (double)(cnt.grad.load() + cnt.value.load()) / dt, (long long)(b1 - b0),
-         (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), cnt.accepted.load(), cnt.failed.load());
+         (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), cnt.accepted.load(), cnt.api_errors.load(), cnt.not_pd.load(), cnt.non_finite.load());
   agp_destroy(ctx);
-  return 0;
+  return cnt.api_errors.load() != 0 ? 2 : 0;
 }
