@@ -222,6 +222,12 @@ __device__ __forceinline__ int sblk_idx(int jb, int lb) { return jb * (jb - 1) /
 // and panel / trailing updates on MFMA; carries the forward solve (rv = this thread's entry of r_k, tid < 128),
 // writes L(k,k), alpha_k, the log-det / alpha'alpha partials, LAPACK info and the block inverses W, and (INTRSM)
 // publishes ready[p] = k+1.  Shared by the mixed and the diagonal-only kernels.
+// (tools/native/diag_bench.hip defines AGP_DIAG_PROBE: per-phase core-clock stamps of workgroup p into a.trace[p * 32 + i])
+#ifdef AGP_DIAG_PROBE
+#define AGP_DPROBE(i) do { if (tid == 0 && a.trace) a.trace[(long long)p * 32 + (i)] = (long long)clock64(); } while (0)
+#else
+#define AGP_DPROBE(i) do { } while (0)
+#endif
 template <bool INTRSM>
 __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int tk, double* __restrict__ Tt,
                                                  double* vecp, double* sm, double* rvec, double* avec, double* Wl,
@@ -233,66 +239,126 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
 
   int bad = 0;           // first non-positive pivot (1-based global index), 0 = none
 
-  // 16x16 Cholesky of block (jb,jb) + its inverse on lane broadcasts, run by ONE wave.
-  // Lane r (= l15) holds row r of the block in s[] and column r of X in wv[] (X starts as I, ends as L^-1).
-  // Column c of L, once scaled, is broadcast lane by lane (v_readlane -> scalar pair); each scalar drives the
-  // trailing update of the block AND the forward substitution L X = I in the same step, so it is consumed at
-  // once (factoring first and inverting afterwards needs every broadcast twice, or parks 240 scalars in
-  // spill lanes).  This step is instruction-issue bound (one wave, 4 cycles per instruction).
+  // 16x16 Cholesky of block (jb,jb) + its inverse, run by ONE wave, 4 columns at a time on the matrix pipe.
+  // The block sits in the wave's registers as Y[r], lane (i = l%16, q = l/16) <-> S[i][4r + q] (= blk[64 r + l]): register
+  // r' is at once the A- and the B-operand fragment of columns 4r' .. 4r'+3.  Sub-step r':
+  //   1. the 4 x 4 diagonal sub-block goes to the scalar unit (10 v_readlane pairs); every lane factors it and inverts the
+  //      factor redundantly (W4: the only serial chain — four v_rsq_f64 + Goldschmidt steps per sub-step);
+  //   2. columns: L[:, 4r' ..] = S[:, 4r' ..] W4^T is ONE MFMA, (W4 padded to 16 x 4) x Y[r'], whose result register 0 lands in
+  //      the operand layout again (lane (i, q) <-> L[i][4r' + q]);
+  //   3. trailing columns: Y -= L[c >= 4r'+4, 4r' ..] L[:, 4r' ..]^T is ONE more MFMA (A rows of finished columns zeroed).
+  // An identity block rides along through 2. and 3.: what happens to the rows of a block below the diagonal, X = S L^-T, turns
+  // I into L^-T — its transposed storage is L^-1, the inverse the panel solves need.  About 120 vector instructions + 4 MFMAs
+  // per sub-step instead of the ~250 of a column-by-column elimination on v_readlane broadcasts (r03: 2.4 us per block, the
+  // longest phase of the tile's dependency chain).
+  auto sqrt_rsqrt = [](double d, double& sq, double& ri) {
+    // v_rsq_f64 is good to ~2^-23; ONE third-order step y (1 + e/2 + 3 e^2 / 8), e = 1 - d y^2, leaves e^3 ~ 2^-69: four
+    // dependent operations behind the estimate instead of the six of two coupled second-order steps (this is the tile's serial chain)
+    const double y = __builtin_amdgcn_rsq(d);
+    const double t = d * y;
+    const double e = fma(-t, y, 1.0);
+    const double pq = fma(e, 0.375, 0.5), ye = y * e;
+    ri = fma(ye, pq, y);
+    // sqrt(d) = d ri, corrected once with the residual (off the chain: only the stored diagonal entry reads it)
+    const double g = d * ri;
+    sq = fma(fma(-g, g, d), 0.5 * ri, g);
+  };
   auto factor16 = [&](int jb) {
     if (AGP_DBG_SKIP & 16) return;
-
-      double* blk = sm + blk_idx(jb, jb) * 256;
-      double s[16], wv[16];
+    double* blk = sm + blk_idx(jb, jb) * 256;
+    d4 Y0, Yw;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) { s[c] = blk[c * 16 + l15]; wv[c] = (c == l15) ? 1.0 : 0.0; }
+    for (int r = 0; r < 4; ++r) { Y0[r] = blk[64 * r + l]; Yw[r] = (l15 == 4 * r + lq) ? 1.0 : 0.0; }
+    const int dlt = l15 - lq;
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        const double pc = readlane_d(s[c], c);
-        if (!(pc > 0.0) && bad == 0) bad = a.k * NB + jb * 16 + c + 1;
-        const double rinv = rsqrt(pc);
-        const double lrc = s[c] * rinv;
-        s[c] = lrc;
-        const double xc = wv[c] * rinv;
-        wv[c] = xc;
-#pragma unroll
-        for (int c2 = c + 1; c2 < 16; ++c2) {
-          const double v = readlane_d(lrc, c2);      // L[c2][c] as a wave-uniform scalar
-          s[c2] = fma(-lrc, v, s[c2]);
-          wv[c2] = fma(-v, xc, wv[c2]);
-          // pin the substitution update here: left alone, the optimiser sinks all of them behind the factorisation
-          // chain and keeps every scalar alive (in spill lanes) until then
-          asm volatile("" : "+v"(wv[c2]));
-        }
+    for (int rp = 0; rp < 4; ++rp) {
+      const int c0 = 4 * rp;
+      // S[c0+a][c0+b], a >= b: register rp of lane 16 b + c0 + a
+      const double d00 = readlane_d(Y0[rp], c0), d10 = readlane_d(Y0[rp], c0 + 1), d20 = readlane_d(Y0[rp], c0 + 2),
+                   d30 = readlane_d(Y0[rp], c0 + 3), d11 = readlane_d(Y0[rp], 16 + c0 + 1), d21 = readlane_d(Y0[rp], 16 + c0 + 2),
+                   d31 = readlane_d(Y0[rp], 16 + c0 + 3), d22 = readlane_d(Y0[rp], 32 + c0 + 2), d32 = readlane_d(Y0[rp], 32 + c0 + 3),
+                   d33 = readlane_d(Y0[rp], 48 + c0 + 3);
+      const int g0 = a.k * NB + jb * 16 + c0;       // global index of the sub-block's first pivot
+      double l00, r0, l11, r1, l22, r2, l33, r3;
+      if (!(d00 > 0.0) && bad == 0) bad = g0 + 1;
+      sqrt_rsqrt(d00, l00, r0);
+      const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+      const double e11 = fma(-l10, l10, d11);
+      if (!(e11 > 0.0) && bad == 0) bad = g0 + 2;
+      sqrt_rsqrt(e11, l11, r1);
+      const double l21 = fma(-l20, l10, d21) * r1, l31 = fma(-l30, l10, d31) * r1;
+      const double e22 = fma(-l21, l21, fma(-l20, l20, d22));
+      if (!(e22 > 0.0) && bad == 0) bad = g0 + 3;
+      sqrt_rsqrt(e22, l22, r2);
+      const double l32 = fma(-l31, l21, fma(-l30, l20, d32)) * r2;
+      const double e33 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, d33)));
+      if (!(e33 > 0.0) && bad == 0) bad = g0 + 4;
+      sqrt_rsqrt(e33, l33, r3);
+      // W4 = L4^-1 (lower).  Row 3 carries the factor 1/l33 of the LAST pivot: the lanes' values are selected without it while
+      // that pivot's reciprocal root is still on its way, and multiplied afterwards (two operations behind r3 instead of six)
+      const double w10 = -(l10 * r0) * r1, w21 = -(l21 * r1) * r2;
+      const double w20 = -fma(l21, w10, l20 * r0) * r2;
+      const double u32 = -(l32 * r2), u31 = -fma(l32, w21, l31 * r1), u30 = -fma(l32, w20, fma(l31, w10, l30 * r0));
+      // A operand of the column step: lane 16 k + i <-> W4[i][k]
+      double aW = 0.0;
+      aW = (l == 0) ? r0 : aW;   aW = (l == 1) ? w10 : aW;  aW = (l == 17) ? r1 : aW;
+      aW = (l == 2) ? w20 : aW;  aW = (l == 18) ? w21 : aW; aW = (l == 34) ? r2 : aW;
+      double u3 = 1.0;
+      u3 = (l == 3) ? u30 : u3;  u3 = (l == 19) ? u31 : u3; u3 = (l == 35) ? u32 : u3;
+      aW = (l15 == 3) ? u3 * r3 : aW;
+      const d4 z4 = d4{0.0, 0.0, 0.0, 0.0};
+      const d4 T0 = mfma(aW, Y0[rp], z4);      // T0[0], lane (i, q): L[i][c0 + q] (rows i < c0: upper-triangle debris)
+      const d4 Tw = mfma(aW, Yw[rp], z4);
+      double nl = (dlt >= c0) ? T0[0] : 0.0;      // the finished columns: zero above the diagonal
+      if (rp < 3) {
+        const double nA = (l15 >= c0 + 4) ? -nl : 0.0;
+        Y0 = mfma(nA, nl, Y0);
+        Yw = mfma(nA, Tw[0], Yw);
       }
-      if (l < 16) {
-        double* Wg = a.W + (((long long)p * a.wsteps + a.k % a.wsteps) * NSB + jb) * 256;
+      // ... and the diagonal itself from the scalar factorisation
+      nl = (l == c0) ? l00 : nl; nl = (l == 17 + c0) ? l11 : nl; nl = (l == 34 + c0) ? l22 : nl; nl = (l == 51 + c0) ? l33 : nl;
+      Y0[rp] = nl;
+      Yw[rp] = Tw[0];
+    }
+    double* Wg = a.W + (((long long)p * a.wsteps + a.k % a.wsteps) * NSB + jb) * 256;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) blk[c * 16 + l] = (c <= l) ? s[c] : 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          Wl[l * 16 + r] = wv[r];
-          Wg[l * 16 + r] = wv[r];
-        }
-      }
-      };
+    for (int r = 0; r < 4; ++r) {
+      blk[64 * r + l] = Y0[r];
+      // Yw[r], lane (i, q) <-> (L^-1)[4r + q][i]; W is kept column-major like every 16 x 16 block
+      Wl[l15 * 16 + 4 * r + lq] = Yw[r];
+      Wg[l15 * 16 + 4 * r + lq] = Yw[r];
+    }
+  };
   // Look-ahead inside the tile: while waves 1-3 apply block column jb to the trailing blocks, wave 0 applies it to the
   // NEXT diagonal block only and factors that block at once — the wave-serial 16x16 step (the longest phase of an
   // iteration) runs beside the MFMA updates instead of in front of them.
+  AGP_DPROBE(2);
   if (w == 0 && !(AGP_DBG_SKIP & 2)) factor16(0);
+  AGP_DPROBE(3);
   __syncthreads();
+  AGP_DPROBE(4);
   for (int jb = 0; jb < ((AGP_DBG_SKIP & 2) ? 0 : NSB); ++jb) {
     // ---- (b) panel: L(ib,jb) = S(ib,jb) W^T for ib > jb (MFMA); alpha_jb = W r_jb ----
-    for (int ib = jb + 1 + w; ib < ((AGP_DBG_SKIP & 32) ? 0 : NSB); ib += 4) {
-      double* blk = sm + blk_idx(ib, jb) * 256;
-      double fw[4], fs[4];
+    // (at most two blocks per wave; their four-MFMA chains are interleaved — one after the other each MFMA waits for its
+    // predecessor's result)
+    if (!(AGP_DBG_SKIP & 32)) {
+      const int ib0 = jb + 1 + w, ib1 = ib0 + 4;
+      if (ib0 < NSB) {
+        double* blk0 = sm + blk_idx(ib0, jb) * 256;
+        double* blk1 = sm + blk_idx(ib1 < NSB ? ib1 : ib0, jb) * 256;
+        double fw[4], fs0[4], fs1[4];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) { fw[s4] = Wl[64 * s4 + l]; fs[s4] = blk[64 * s4 + l]; }
-      d4 x = d4{0.0, 0.0, 0.0, 0.0};
+        for (int s4 = 0; s4 < 4; ++s4) { fw[s4] = Wl[64 * s4 + l]; fs0[s4] = blk0[64 * s4 + l]; fs1[s4] = blk1[64 * s4 + l]; }
+        d4 x0 = d4{0.0, 0.0, 0.0, 0.0}, x1 = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) x = mfma(fw[s4], fs[s4], x);
+        for (int s4 = 0; s4 < 4; ++s4) { x0 = mfma(fw[s4], fs0[s4], x0); x1 = mfma(fw[s4], fs1[s4], x1); }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) blk[64 * r + l] = x[r];
+        for (int r = 0; r < 4; ++r) blk0[64 * r + l] = x0[r];
+        if (ib1 < NSB) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) blk1[64 * r + l] = x1[r];
+        }
+      }
     }
     if (w == 3 && l < 16) {
       double t = 0.0;
@@ -301,41 +367,94 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
       avec[jb * 16 + l] = t;
     }
     __syncthreads();
+    if (jb == 0) AGP_DPROBE(5);
 
     // ---- (c) trailing blocks (ib,cb), jb < cb <= ib: S(ib,cb) -= L(ib,jb) L(cb,jb)^T;
     //      r_ib -= L(ib,jb) alpha_jb ----
     {
       const int nrem = NSB - 1 - jb;              // block rows below jb
       const int npair = nrem * (nrem + 1) / 2;
-      // pair 0 is the next diagonal block (jb+1, jb+1): wave 0 takes it (and then factors it); waves 1-3 share the rest
-      for (int e = (w == 0 ? 0 : w); e < ((AGP_DBG_SKIP & 64) ? 0 : (w == 0 ? (npair > 0 ? 1 : 0) : npair)); e += 3) {
-        int ii = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-        while (ii * (ii + 1) / 2 > e) --ii;
-        while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
-        const int cc = e - ii * (ii + 1) / 2;
-        const int ib = jb + 1 + ii, cb = jb + 1 + cc;
-        double* blk = sm + blk_idx(ib, cb) * 256;
-        const double* la = sm + blk_idx(cb, jb) * 256;
-        const double* lb = sm + blk_idx(ib, jb) * 256;
-        d4 x;
+      // pair 0 is the next diagonal block (jb+1, jb+1): wave 0 takes it (and then factors it); waves 1-3 share the rest, three
+      // blocks per pass with their MFMA chains interleaved (pairs e = w, w + 3, ... in row-major order of the trailing triangle)
+      auto upd = [&](int ib, int cb, bool on, d4& x) {      // x = S(ib,cb) - L(ib,jb) L(cb,jb)^T  (on = false: a dummy on block (jb+1, jb+1), not stored)
+        (void)on;
+        const double* blk = sm + blk_idx(ib, cb) * 256;
 #pragma unroll
         for (int r = 0; r < 4; ++r) x[r] = blk[64 * r + l];
+      };
+      if (w == 0) {
+        if (npair > 0 && !(AGP_DBG_SKIP & 64)) {
+          double* blk = sm + blk_idx(jb + 1, jb + 1) * 256;
+          const double* la = sm + blk_idx(jb + 1, jb) * 256;
+          d4 x;
+          double f[4];
 #pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) x = mfma(-la[64 * s4 + l], lb[64 * s4 + l], x);
+          for (int r = 0; r < 4; ++r) { x[r] = blk[64 * r + l]; f[r] = la[64 * r + l]; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) blk[64 * r + l] = x[r];
+          for (int s4 = 0; s4 < 4; ++s4) x = mfma(-f[s4], f[s4], x);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) blk[64 * r + l] = x[r];
+        }
+      } else if (!(AGP_DBG_SKIP & 64)) {
+        // position of pair e in the triangle: row ii (0-based below jb+1), column cc <= ii
+        int e = w, ii = 1, cc = w - 1;                     // e = 1, 2, 3 -> (1,0), (1,1), (2,0)
+        if (cc > ii) { cc -= ii + 1; ++ii; }
+        auto advance = [&](int& e_, int& ii_, int& cc_) {  // three pairs on
+          e_ += 3; cc_ += 3;
+          while (cc_ > ii_) { cc_ -= ii_ + 1; ++ii_; }
+        };
+        while (e < npair) {
+          int eb[3], ib3[3], cb3[3];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            eb[u] = e; ib3[u] = jb + 1 + ii; cb3[u] = jb + 1 + cc;
+            advance(e, ii, cc);
+          }
+          d4 x[3];
+          double fa[3][4], fb[3][4];
+#pragma unroll
+          for (int u = 0; u < 3; ++u) {
+            const bool on = eb[u] < npair;
+            const int ib = on ? ib3[u] : jb + 1, cb = on ? cb3[u] : jb + 1;
+            upd(ib, cb, on, x[u]);
+            const double* la = sm + blk_idx(cb, jb) * 256;
+            const double* lb = sm + blk_idx(ib, jb) * 256;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) { fa[u][s4] = -la[64 * s4 + l]; fb[u][s4] = lb[64 * s4 + l]; }
+          }
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) x[u] = mfma(fa[u][s4], fb[u][s4], x[u]);
+#pragma unroll
+          for (int u = 0; u < 3; ++u)
+            if (eb[u] < npair) {
+              double* blk = sm + blk_idx(ib3[u], cb3[u]) * 256;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) blk[64 * r + l] = x[u][r];
+            }
+        }
       }
-      if (tid < NB && tid >= (jb + 1) * 16) {
-        const double* lb = sm + blk_idx(tid >> 4, jb) * 256;
-        double t = rvec[tid];
+      // r_ib -= L(ib,jb) alpha_jb: threads 128 .. 255 (waves 2, 3) — not the wave that carries the tile's serial chain
+      if (tid >= NB && tid - NB >= (jb + 1) * 16) {
+        const int ti_ = tid - NB;
+        const double* lb = sm + blk_idx(ti_ >> 4, jb) * 256;
+        double t0 = rvec[ti_], t1 = 0.0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) t = fma(-lb[q * 16 + (tid & 15)], avec[jb * 16 + q], t);
-        rvec[tid] = t;
+        for (int q = 0; q < 16; q += 2) {
+          t0 = fma(-lb[q * 16 + (ti_ & 15)], avec[jb * 16 + q], t0);
+          t1 = fma(-lb[(q + 1) * 16 + (ti_ & 15)], avec[jb * 16 + q + 1], t1);
+        }
+        rvec[ti_] = t0 + t1;
       }
+      if (jb == 0) AGP_DPROBE(6);
       if (w == 0 && jb + 1 < NSB) factor16(jb + 1);      // (its block was brought up to date by this wave just above)
+      if (jb == 0) AGP_DPROBE(7);
     }
     __syncthreads();
+    if (jb == 0) AGP_DPROBE(8);
   }
+  AGP_DPROBE(9);
 
   if (mark && tid == 0) *mark = (long long)wall_clock64();
   // ---- write L(k,k) (upper part zero), alpha_k, partials, info ----
@@ -347,6 +466,7 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
     if (rb >= cb) v = *reinterpret_cast<const d2*>(sm + blk_idx(rb, cb) * 256 + c * 16 + r2);
     *reinterpret_cast<d2*>(Tt + (cb * 16 + c) * NB + rb * 16 + r2) = v;
   }
+  AGP_DPROBE(10);
   if (tid < NB) {
     vecp[tk * NB + tid] = avec[tid];
     // log|K_kk-block| = 2 sum log L_ii, all 128 logs in parallel (diag of block (b,b) at 17*i)
@@ -378,6 +498,7 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
       if (a.tflag != nullptr) __hip_atomic_store(a.tflag + (long long)p * a.ntri + tri_idx(tk, tk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  AGP_DPROBE(11);
 }
 
 // the two strip values of one tile column for this lane (rows rowA and rowB of column `col`); ADJ: rowB = rowA + 1
@@ -946,6 +1067,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
   double* xv = avec + 128;     // [2][32]
   double* Wl = xv + 64;        // [256]
   constexpr int NE = NSB + 1;  // accumulator blocks per wave
+  AGP_DPROBE(0);
   const bool producer = FLOW && a.early != 0;            // early-sum item (see CholArgs::items): its chunk of the K-loop, no factorisation
   const int jfirst = FLOW ? a.jstart : 0;
   const int jmax = producer ? jfirst + a.part_ch : (a.rl ? 0 : a.k);
@@ -1227,6 +1349,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
     for (int r = 0; r < 4; ++r) blk[(4 * r + lq) * 16 + l15] = -acc[e][r];
   }
   if (FLOW) AGP_PROBE(2);
+  AGP_DPROBE(1);
   factor_diag_tile<true>(a, ps, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid, (FLOW && a.trace && wait_acc) ? &wait_acc->ph[3] : nullptr);
 }
 

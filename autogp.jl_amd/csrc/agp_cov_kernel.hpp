@@ -70,7 +70,7 @@ __device__ __forceinline__ int prm_count(int o) {
 // table of its block lag into LDS; its 16 384 elements read the subtree's value from there: one LDS access instead of
 // 40-90 fp64 instructions per leaf, one interpreter step instead of one per node, and no transcendental code in the
 // factorisation kernels at all.  An element's own t_i - t_j differs from the table's representative only by rounding
-// (agp_set_data admits a grid only when every point sits within 16 ulp of t_0 + g h).  Lags beyond the data (g >= n) only
+// (agp_set_data admits a grid only when every point sits within 1e-11 spacings of t_0 + g h).  Lags beyond the data (g >= n) only
 // occur in padding rows, which cov_finalize overwrites.
 // The time points and the lag tables are loaded in ONE round trip and the first barrier below also publishes whatever the caller
 // has just stored to LDS without synchronising (the factorisation kernels stage program and parameters there: three dependent

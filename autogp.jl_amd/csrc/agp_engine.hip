@@ -177,7 +177,7 @@ struct agp_ctx {
   int64_t n_lagdom_particles = 0;   // particles contracted in the lag domain so far (agp_get_lag_stats)
   bool lag_ok = false;
   int lag_enable = 1;
-  double lag_tol_h = 4e-12;       // admitted deviation of a sorted point from its grid position, in units of the spacing (agp_set_data)
+  double lag_tol_h = 1e-11;       // admitted deviation of a sorted point from its grid position, in units of the spacing (agp_set_data)
   int64_t n_lag_sweeps = 0;       // sweeps that took the lag path (agp_get_lag_stats)
   double* d_logdt = nullptr;      // packed lower tiles, covers the resident data
   size_t logdt_cap = 0;
@@ -1760,7 +1760,7 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
   c->h_xs.assign(xs, xs + n_max);
   c->n_max = n_max;
   // Is the series a regular grid (in any order)?  Sort, compare every point with t_0 + g h: admitted only when each sits
-  // within 16 ulp of its grid position (np.linspace / a min-max rescaled integer grid are within 1-2), so that the lag
+  // within 1e-11 spacings of its grid position (np.linspace / a min-max rescaled integer grid on [0, 1]: < 1e-12), so that the lag
   // tables' representative differences equal every element's own t_i - t_j to rounding.
   c->lag_ok = false;
   if (c->d_ts_s) { HIPCHK(c, hipFree(c->d_ts_s)); c->d_ts_s = nullptr; }
@@ -1775,13 +1775,17 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
     const double t0 = tss.front(), t1 = tss.back();
     const double h = (t1 - t0) / (double)(n_max - 1);
     // The tolerance is a fraction of the SPACING, not of |t|: on the lag path every t_i - t_j is replaced by the table's
-    // t_sorted[g] - t_sorted[0], which differs from the element's own difference by up to ~4 deviations, i.e. by a relative
-    // 4 dev / (g h) of the lag.  linspace(0, 1, n) sits within half an ulp of 1 of its grid (dev / h = 2.3e-13 at n = 2048,
-    // 1.8e-12 at n = 16384) and agrees with the general path to 4e-13 of the log-pdf on short-lengthscale populations; the
-    // bound admits 4e-12, which keeps that agreement below 1e-11 — three digits under the 1e-8 contract.  A series with a large
-    // offset (linspace(1000, 1001, 2048): dev / h = 1e-10) or a jitter below the old 16-ulp-of-|t| bound takes the general path.
-    const double tol = c->lag_tol_h * h;
-    bool regular = std::isfinite(h) && h > 0.0;
+    // t_sorted[g] - t_sorted[0], which differs from the element's own difference by up to ~4 position errors, i.e. by a relative
+    // 4 err / (g h) of the lag.  A point's position error is its measured deviation from t_0 + g h PLUS the quantisation of the
+    // time axis itself, one ulp of |t|max (t_0 + g h is evaluated in the same arithmetic as np.linspace / range, so for
+    // linspace(1000, 1001, n) the measured deviation is exactly 0 while the differences are only good to 1e-13 / h).
+    // linspace(0, 1, n): err / h = 7e-13 at n = 2048 (5e-12 at n = 16384), agreement with the general path 4e-13 of the log-pdf
+    // on short-lengthscale populations; the bound admits 1e-11, which keeps that agreement below 1e-11 — three digits under the
+    // 1e-8 contract.  A series with a large offset (linspace(1000, 1001, 2048): 4.6e-10) or a jitter below the former
+    // 16-ulp-of-|t| bound takes the general path.
+    const double quant = 2.220446049250313e-16 * std::max(std::fabs(t0), std::fabs(t1));
+    const double tol = c->lag_tol_h * h - quant;
+    bool regular = std::isfinite(h) && h > 0.0 && tol > 0.0;
     for (int64_t i = 0; regular && i < n_max; ++i) regular = std::fabs(tss[(size_t)i] - (t0 + (double)i * h)) <= tol;
     if (regular) {
       HIPCHK(c, hipMalloc((void**)&c->d_ts_s, sizeof(double) * npad));

@@ -427,6 +427,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the covariance-builder / gradient / predictive legs (N = 1)")
     ap.add_argument("--single-process", action="store_true", help="one host process drives all --gpus devices (agp_init_multi)")
+    ap.add_argument("--dump-logweights", default=None, help="rank 0 writes the complete (all-gathered) log-weight vector of the last step to this .npy file")
     args = ap.parse_args()
 
     if args.single_process:
@@ -613,6 +614,20 @@ def main():
     lp = d_lp[:P].cpu().numpy(); info = d_info[:P].cpu().numpy()
     n_bad = int((info != 0).sum())
     gather_ok = None
+    gather_us = None
+    if world > 1 and not share and nccl_group is None:
+        # the collective on its own: HIP events on the launch stream around 50 back-to-back all-gathers of the P doubles
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync()
+        e0.record()
+        for _ in range(50):
+            eng.allgather_logweights_device(d_lp.data_ptr(), P_total, d_all.data_ptr(), stream)
+        e1.record()
+        torch.cuda.current_stream().synchronize()
+        gather_us = e0.elapsed_time(e1) * 1e3 / 50
+        sync()
+    if args.dump_logweights and rank == 0:
+        np.save(args.dump_logweights, d_all.cpu().numpy() if world > 1 else lp)
     if world > 1:
         nb = torch.tensor([n_bad], dtype=torch.int64)
         dist.all_reduce(nb)
@@ -648,7 +663,8 @@ def main():
                        "launch": ("self-launched torch.distributed.run" if os.environ.get("AGP_BENCH_SELF_LAUNCHED") == "1" else
                                   "external torch.distributed.run") if world > 1 else "single rank",
                        "collective": collective, "rccl_ranks_seen": ranks_seen, "per_rank_ms_per_step": per_rank_ms,
-                       "allgather_selfcheck": gather_ok},
+                       "per_rank_ms_per_step_min_max": [min(per_rank_ms), max(per_rank_ms)],
+                       "allgather_us_hip_events": gather_us, "allgather_selfcheck": gather_ok},
             "cholesky_gflops": chol_gf,
             "sweep_frac_of_fp64_mfma_peak": chol_gf / 1e3 / (PEAK_FP64_MFMA_TFLOPS * world),
             "phase_ms_per_step": {("chol_diag_tiles_ms" if (split_diag and k == "chol_trsm_ms") else

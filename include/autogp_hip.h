@@ -142,7 +142,9 @@ int agp_grad_reuse_stats(agp_ctx* ctx, int64_t* out2);
 int agp_set_factor_cache(agp_ctx* ctx, int32_t on);
 
 /* Regular time grids.  agp_set_data checks whether the series' time points, put in ascending order, are equally spaced
- * (every point within 16 ulp of t_0 + g h: np.linspace, range(...), a min-max rescaled daily / hourly / yearly index).  If
+ * (every point within 1e-11 SPACINGS of t_0 + g h, one ulp of |t|max included: np.linspace, range(...), a min-max rescaled
+ * daily / hourly / yearly index; a grid with an offset of 1e3 spacings-per-ulp or more — linspace(1000, 1001, 2048) — or a jitter
+ * above that bound takes the general path, because the tables replace t_i - t_j by a representative of the lag).  If
  * so, value sweeps over the WHOLE series (n == n_max; agp_logpdf_batch{,_device,_multi}) run on a sorted copy of the data
  * — log N(x; 0, K) is invariant under a symmetric permutation of K and x — where an element of a tile depends on
  * (row - column) only: every stationary leaf (SquaredExponential, GammaExponential, Periodic; src/GP.jl:236-245,

@@ -312,6 +312,67 @@ def test_bench_single_process_mode():
     assert out["config"]["particles_total"] == 64 and out["value"] > 0 and out["roofline"]["achieved"] > 0
 
 
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+needs_two_gpus = pytest.mark.skipif("_n_devices() < 2", reason="needs >= 2 visible devices (real RCCL ranks)")
+
+
+@needs_two_gpus
+def test_bench_two_real_rccl_ranks(tmp_path):
+    """The first multi-GPU box verifies itself: `python bench.py --gpus 2` started plainly, one rank per DEVICE, the log-weights
+    over the engine's own RCCL communicator (no AGP_BENCH_SHARE_GPU, neither fallback may fire), the gathered vector bit-equal
+    to the one-GPU sweep of the same population (src/inference_smc_anneal_data.jl:232: every rank resamples from the same vector)."""
+    common = ["--steps", "5", "--warmup", "1", "--n-obs", "700", "--particles", "64", "--no-cpu-baseline", "--no-extra-legs"]
+    one = _bench_line(["--gpus", "1", "--dump-logweights", str(tmp_path / "lw1.npy")] + common)
+    two = _bench_line(["--gpus", "2", "--dump-logweights", str(tmp_path / "lw2.npy")] + common)
+    cfg = two["config"]
+    assert two["n_gpus"] == 2 and cfg["launch"] == "self-launched torch.distributed.run"
+    assert cfg["rccl_ranks_seen"] == 2 and cfg["allgather_selfcheck"] is True
+    assert cfg["collective"].startswith("rccl via C ABI"), cfg["collective"]
+    assert cfg["particles_total"] == 64 and cfg["particles_per_gpu"] == 32 and len(cfg["per_rank_ms_per_step"]) == 2
+    assert cfg["allgather_us_hip_events"] is not None and 0 < cfg["allgather_us_hip_events"] < 5000
+    a, b = np.load(tmp_path / "lw1.npy"), np.load(tmp_path / "lw2.npy")
+    assert a.shape == (64,) and np.array_equal(a, b, equal_nan=True)
+    assert one["config"]["not_positive_definite"] == two["config"]["not_positive_definite"]
+
+
+@needs_two_gpus
+def test_bench_single_process_two_devices():
+    """One host process driving two devices (agp_init_multi + agp_logpdf_batch_multi: ncclCommInitAll, one group call)."""
+    out = _bench_line(["--single-process", "--gpus", "2", "--steps", "5", "--warmup", "1", "--n-obs", "700", "--particles", "64"])
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and cfg["launch"].startswith("single-process")
+    assert cfg["rccl_ranks_seen"] == [2, 2] and cfg["allgather_selfcheck"] is True
+    assert cfg["collective"].startswith("rccl via C ABI"), cfg["collective"]
+    assert cfg["particles_total"] == 64 and out["value"] > 0
+
+
+@needs_two_gpus
+def test_two_rank_stream_on_two_gpus():
+    """tools/run_stream.py (config 5's stream) on two real ranks: without moves the log-marginal-likelihood estimate and the
+    resampling steps equal the one-rank run's; with the rejuvenation stand-in (blocks exchanged through the host channel,
+    log-weights through the engine's RCCL all-gather) it completes and extends resident factors on both ranks."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+
+    def run(nproc, extra):
+        port = 29100 + (os.getpid() + 7 * nproc + len(extra)) % 400
+        cmd = ([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+                "--master-port", str(port)] if nproc > 1 else [sys.executable]) + [str(ROOT / "tools" / "run_stream.py")] + extra
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=str(ROOT))
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    one, two = run(1, []), run(2, [])
+    assert two["n_gpus"] == 2 and one["resampled_steps"] == two["resampled_steps"]
+    assert abs(one["log_ml_est"] - two["log_ml_est"]) <= 1e-9 * max(1.0, abs(one["log_ml_est"]))
+    rj = run(2, ["--rejuvenate"])
+    assert rj["n_gpus"] == 2 and rj["store"]["extended"] > 0 and np.isfinite(rj["log_ml_est"])
+
+
 def test_bench_default_line_has_every_block():
     """The default single-GPU line (short run, small shapes): roofline + the legs beside the value sweep + cpu_baseline."""
     out = _bench_line(["--steps", "8", "--warmup", "1", "--n-obs", "384", "--particles", "512"])
