@@ -71,44 +71,11 @@ struct CholArgs {
   int* qnext;
   long long* trace;     // optional (agp_debug_flow_trace): per item {start, end, wait} in 100 MHz ticks + {item info}
   int schur_diag_only;  // Schur mode: only the diagonal tiles of the prediction block (marginal variances + mean; no covariance)
-  int flow_order;       // 0: sub-diagonal tiles of a block column tile-row-major (all particles' (k+1,k) first), 1: particle-major
   int lag;              // 1: sorted regular grid, the fused programs' stationary leaves are OP_LAG_* (GM = 2 instantiations)
   const double* lagtab; // ... and their tables (k_lag_tables)
   const int32_t* lagr;  // rank tables (sweeps in the caller's order; see cov_prologue): ranks of the resident points, null = sorted sweep
   int lag_stride;       // ... doubles per table
-  // Dataflow schedule with a host-built work list and EARLY SUMS (plain sweeps; see k_chol_flow): the K-loops of the tiles
-  // in the last part_tb tile rows x columns are cut into part_nch chunks of part_ch block columns.  The chunks are queued in
-  // the middle of the kernel — right behind the last block column they read — and work IN PLACE on the tile's own storage:
-  // chunk 0 leaves A(i,k) - sum_{j in chunk 0} L(i,j) L(k,j)^T there (A evaluated in-kernel or read, as the particle has
-  // it), chunk c subtracts its sum from what chunk c-1 left, and the tile's own item treats the tile as resident and only
-  // multiplies the block columns behind the last chunk.  A diagonal tile's share of the forward-solve vector is carried in
-  // `vec` the same way.  pflag[storage idx][trailing tile] counts the chunks done (release / acquire like tflag).
-  // The sums are formed in a fixed order: results are reproducible run to run (but differ in rounding from a sweep
-  // without the chunks).
-  const int4* items;    // work list: per XCD items_stride entries {kind | chunk << 8, local particle, tile row, block column}
-  int items_stride;
-  const int* n_items;   // [8] entries per XCD
-  int* pflag;           // [storage idx][part_tiles], zeroed per sweep
-  int part_tiles, part_tb, part_ch, part_nch;
-  // per item (set by k_chol_flow): first block column of the item's own K-loop; chunk + 1 for an early-sum item (0: the
-  // tile's own item); early sums to wait for before the tile / vector is read (0: none)
-  int jstart, early, need;
 };
-// index of trailing tile (ti, tk) in pflag
-__device__ __forceinline__ int part_tile(const CholArgs& a, int ti, int tk) {
-  const int r0 = a.nt - a.part_tb;
-  return (ti - r0) * (ti - r0 + 1) / 2 + (tk - r0);
-}
-// one lane: wait until a counter has reached `want` (bounded)
-__device__ __forceinline__ bool flow_wait_ge(const int* flag, int want) {
-  int spins = 0;
-  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++spins > (1 << 24)) return false;
-  }
-  return true;
-}
-
 __device__ __forceinline__ double readlane_d(double v, int lane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, lane);
@@ -149,69 +116,13 @@ constexpr int U_MAX_CP = (U_MAIN_DOUBLES - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_O
 // the workgroup waits on the particle's `ready` word (published by the diagonal-tile workgroup, which
 // is dispatched first), stages +L(k,k) blocks and -W blocks in LDS and runs the blocked substitution
 // on its accumulators — one launch per block column, no panel round trip through HBM.
-// Measurement switch: scope of the release fence that publishes a finished tile ("agent" = L2 write-back + flag;
-// "workgroup" only orders the stores — physically sufficient when producer and consumer share an XCD's L2).
-#ifndef AGP_REL_SCOPE
-#define AGP_REL_SCOPE "agent"
-#endif
-#ifndef AGP_XCD_PIN
-#define AGP_XCD_PIN 1
-#endif
-constexpr bool XCD_PIN = AGP_XCD_PIN != 0;     // 1: all tiles of a particle on one XCD; 0: spread over the 8 XCDs
-// Timing diagnostics only (results are wrong): bit 0 skip the in-register solve arithmetic, bit 1 skip the
-// diagonal-tile factorisation loop, bit 2 skip the GEMM loop, bit 3 skip the solve's staging + flag wait too,
-// bits 4 / 5 / 6 skip the factorisation's 16x16 diagonal step / panel step / trailing update, bits 7 / 8 skip the
-// diagonal kernel's forward-solve accumulation / its MFMAs.
-#ifndef AGP_DBG_SKIP
-#define AGP_DBG_SKIP 0
-#endif
-#ifndef AGP_POST_EVAL
-#define AGP_POST_EVAL 0
-#endif
-#ifndef AGP_A_DIRECT
-#define AGP_A_DIRECT 1
-#endif
-#ifndef AGP_INTERLEAVE
-#define AGP_INTERLEAVE 1
-#endif
-// Measurement switches for wave priorities.
-// AGP_PRIO_ASYM: MFMA-block priority by hardware wave slot (odd slot 2, even slot 1), so that the two workgroups of a CU stop
-// running the same phases at the same time.  Measured (r03e): no effect, 23.38 vs 23.27 ms of sub-diagonal launches per sweep.
-// AGP_CHAIN_PRIO: in the dataflow kernel the items of the per-column dependency chain — diagonal tiles and the (k+1, k) tiles —
-// run at a higher priority than the bulk tiles throughout (2, 3 inside their MFMA blocks; the bulk 0 / 1).
-#ifndef AGP_PRIO_ASYM
-#define AGP_PRIO_ASYM 0
-#endif
-#ifndef AGP_CHAIN_PRIO
-#define AGP_CHAIN_PRIO 0
-#endif
-// AGP_PHASE_PRIO: priority of a wave OUTSIDE its K-loop (tile evaluation, staging, panel solve, 128 x 128 factorisation, stores).
-// Those phases are latency-bound chains of LDS / global round trips with little arithmetic; at priority 0 beside a co-resident
-// workgroup whose MFMA blocks run at priority 1 they are starved of issue slots (flow trace r03j: 40-65 us from item start to
-// "accumulators ready" for a tile whose evaluation costs ~3 us, 10-50 us for staging 72 KB).  Raised above the MFMA blocks they
-// finish quickly and the workgroup returns to feeding the MFMA pipe.
-#ifndef AGP_PHASE_PRIO
-#define AGP_PHASE_PRIO 0
-#endif
-#ifndef AGP_DIAG_SELECT
-#define AGP_DIAG_SELECT 0        // 1: entries 1..3 of the diagonal kernel's K-loop select their row fragment in registers
-#endif
-
-__device__ __forceinline__ void phase_prio() { if (AGP_PHASE_PRIO) __builtin_amdgcn_s_setprio(AGP_PHASE_PRIO); }
-__device__ __forceinline__ void mfma_prio_on(bool hi) {
-  if ((AGP_PRIO_ASYM || AGP_CHAIN_PRIO) && hi) __builtin_amdgcn_s_setprio(AGP_CHAIN_PRIO ? 3 : 2);
-  else __builtin_amdgcn_s_setprio(1);
-}
-__device__ __forceinline__ void mfma_prio_off(bool hi) {
-  if (AGP_CHAIN_PRIO && hi) __builtin_amdgcn_s_setprio(2);
-  else __builtin_amdgcn_s_setprio(0);
-}
-__device__ __forceinline__ bool wave_slot_odd() {
-  // HW_REG_HW_ID (id 4), WAVE_ID = bits [3:0]
-  return AGP_PRIO_ASYM ? ((__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1) != 0) : false;
-}
-constexpr bool ILV = AGP_INTERLEAVE != 0;      // strips = even/odd rows (1) or rows [0,16) / [16,32) of the wave (0)
-constexpr bool A_DIRECT = AGP_A_DIRECT != 0;   // row operand: 1 = global -> registers, 0 = through LDS
+// A finished tile is published with an agent-scope release (L2 write-back + flag); all tiles of a particle live on one XCD
+// (block b runs on XCD b % 8), so the shared L(k,j) panel stays in that XCD's L2.
+// MFMA blocks of the K-loops run at wave priority 1 so that they outrank the co-resident workgroup's load / store / barrier
+// phases (measured alternatives — priorities by wave slot, by dependency-chain membership, raised outside the K-loop — changed
+// nothing: NOTES_dead_ends.md).
+__device__ __forceinline__ void mfma_prio_on() { __builtin_amdgcn_s_setprio(1); }
+__device__ __forceinline__ void mfma_prio_off() { __builtin_amdgcn_s_setprio(0); }
 constexpr int T_NBLK = NSB * (NSB - 1) / 2;              // 28 strictly-lower 16x16 blocks
 constexpr int T_LDS_DOUBLES = (T_NBLK + NSB) * 256;      // + 8 inverse blocks = 72 KiB
 static_assert(T_LDS_DOUBLES <= U_MAIN_DOUBLES, "solve staging must fit the aliased slab buffers");
@@ -264,7 +175,6 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
     sq = fma(fma(-g, g, d), 0.5 * ri, g);
   };
   auto factor16 = [&](int jb) {
-    if (AGP_DBG_SKIP & 16) return;
     double* blk = sm + blk_idx(jb, jb) * 256;
     d4 Y0, Yw;
 #pragma unroll
@@ -333,15 +243,15 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
   // NEXT diagonal block only and factors that block at once — the wave-serial 16x16 step (the longest phase of an
   // iteration) runs beside the MFMA updates instead of in front of them.
   AGP_DPROBE(2);
-  if (w == 0 && !(AGP_DBG_SKIP & 2)) factor16(0);
+  if (w == 0) factor16(0);
   AGP_DPROBE(3);
   __syncthreads();
   AGP_DPROBE(4);
-  for (int jb = 0; jb < ((AGP_DBG_SKIP & 2) ? 0 : NSB); ++jb) {
+  for (int jb = 0; jb < NSB; ++jb) {
     // ---- (b) panel: L(ib,jb) = S(ib,jb) W^T for ib > jb (MFMA); alpha_jb = W r_jb ----
     // (at most two blocks per wave; their four-MFMA chains are interleaved — one after the other each MFMA waits for its
     // predecessor's result)
-    if (!(AGP_DBG_SKIP & 32)) {
+    {
       const int ib0 = jb + 1 + w, ib1 = ib0 + 4;
       if (ib0 < NSB) {
         double* blk0 = sm + blk_idx(ib0, jb) * 256;
@@ -383,7 +293,7 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
         for (int r = 0; r < 4; ++r) x[r] = blk[64 * r + l];
       };
       if (w == 0) {
-        if (npair > 0 && !(AGP_DBG_SKIP & 64)) {
+        if (npair > 0) {
           double* blk = sm + blk_idx(jb + 1, jb + 1) * 256;
           const double* la = sm + blk_idx(jb + 1, jb) * 256;
           d4 x;
@@ -395,7 +305,7 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
 #pragma unroll
           for (int r = 0; r < 4; ++r) blk[64 * r + l] = x[r];
         }
-      } else if (!(AGP_DBG_SKIP & 64)) {
+      } else {
         // position of pair e in the triangle: row ii (0-based below jb+1), column cc <= ii
         int e = w, ii = 1, cc = w - 1;                     // e = 1, 2, 3 -> (1,0), (1,1), (2,0)
         if (cc > ii) { cc -= ii + 1; ++ii; }
@@ -492,7 +402,7 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(a.ready + p, a.k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a.tflag != nullptr) __hip_atomic_store(a.tflag + (long long)p * a.ntri + tri_idx(tk, tk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -501,22 +411,25 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
   AGP_DPROBE(11);
 }
 
-// the two strip values of one tile column for this lane (rows rowA and rowB of column `col`); ADJ: rowB = rowA + 1
-template <bool ADJ = ILV>
-__device__ __forceinline__ d2 ld_pair(const double* T, int col, int rowA, int rowB) {
-  if (ADJ) return *reinterpret_cast<const d2*>(T + col * NB + rowA);
-  d2 v; v.x = T[col * NB + rowA]; v.y = T[col * NB + rowB]; return v;
+// the two strip values of one tile column for this lane: rows rowA and rowA + 1 of column `col` (one 16-byte access)
+__device__ __forceinline__ d2 ld_pair(const double* T, int col, int rowA) {
+  return *reinterpret_cast<const d2*>(T + col * NB + rowA);
 }
-template <bool ADJ = ILV>
-__device__ __forceinline__ void st_pair(double* T, int col, int rowA, int rowB, double a0, double a1) {
-  if (ADJ) { d2 v; v.x = a0; v.y = a1; *reinterpret_cast<d2*>(T + col * NB + rowA) = v; }
-  else { T[col * NB + rowA] = a0; T[col * NB + rowB] = a1; }
+__device__ __forceinline__ void st_pair(double* T, int col, int rowA, double a0, double a1) {
+  d2 v; v.x = a0; v.y = a1;
+  *reinterpret_cast<d2*>(T + col * NB + rowA) = v;
 }
 
 // agp_debug_flow_trace: per-item probe in LDS — ticks spent waiting on operand tiles and the times (lane 0) at which the item's
 // phases ended: [0] tile evaluated / accumulators ready, [1] K-loop done, [2] solve / factorisation inputs staged, [3] arithmetic done
 struct FlowProbe { double wait; long long ph[4]; };
-#define AGP_PROBE(i) do { if (a.trace && wait_acc && tid == 0) wait_acc->ph[i] = (long long)wall_clock64(); } while (0)
+// (the trace exists in the measurement build only: -DAGP_EXPERIMENTS, libautogp_hip_exp.so)
+#ifdef AGP_EXPERIMENTS
+#define AGP_TRACE(a) ((a).trace)
+#else
+#define AGP_TRACE(a) (static_cast<long long*>(nullptr))
+#endif
+#define AGP_PROBE(i) do { if (AGP_TRACE(a) && wait_acc && tid == 0) wait_acc->ph[i] = (long long)wall_clock64(); } while (0)
 // Operand streams of the K-loops go through raw BUFFER loads: descriptor (tile row's base, in SGPRs) + per-lane byte offset
 // (one VGPR, constant for the whole loop) + wave-uniform byte offset of the slab (an SGPR advanced on the scalar unit).
 // Formed as per-lane 64-bit pointers the same loads cost ~20 vector instructions per 16-column slab — on the issue port the
@@ -555,8 +468,6 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
   const int p = __builtin_amdgcn_readfirstlane(p_), ps = __builtin_amdgcn_readfirstlane(ps_);
   const int ti = __builtin_amdgcn_readfirstlane(ti_), tk = __builtin_amdgcn_readfirstlane(tk_);
   const int jmax = __builtin_amdgcn_readfirstlane(jmax_);
-  constexpr bool ADJ = ILV;       // strips are adjacent rows
-  phase_prio();
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;
   double* xv = avec + 128;     // [2][slab depth <= 32]
@@ -565,8 +476,8 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
   const int l = tid & 63;
   const int w = tid >> 6;
   const int l15 = l & 15, lq = l >> 4;
-  const int row0 = ILV ? 32 * w + 2 * l15 : 32 * w + l15;   // this lane's row in strip 0
-  const int row1 = ILV ? row0 + 1 : row0 + 16;              // ... and in strip 1
+  const int row0 = 32 * w + 2 * l15;   // this lane's row in strip 0 (the even rows of the wave's 32)
+  const int row1 = row0 + 1;           // ... and in strip 1 (the odd rows)
 
   double* __restrict__ Ap = a.A + (long long)ps * a.strideA;
   double* vecp = a.vec + (long long)ps * a.ldv;
@@ -579,17 +490,8 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
   // the stored tile after the loop.
   double* __restrict__ Tt = Ap + tile_off(ti, tk);
   d4 acc[NSB][2];
-  // early sums (CholArgs::items): an early-sum item stops after its chunk of the K-loop and leaves A - sums in the tile; chunks
-  // behind the first and the tile's own item find the tile resident
-  const bool producer = FLOW && a.early != 0;
-  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused) || (FLOW && a.need > 0);
-  // Every tile of a per-column launch has the same K-loop length, so the two workgroups of a CU run in step: both evaluate
-  // (fp64 VALU, MFMA pipe idle), then both multiply.  Workgroups of the second half of each 512-block wave therefore evaluate
-  // their tile AFTER the K-loop (accumulators start at zero, -A(i,k) is added at the end): one workgroup's VALU phase falls
-  // into the other's MFMA phase.  The choice depends on the block index only: results are reproducible run to run.
-  const bool post_eval = AGP_POST_EVAL && !prebuilt && DM == 2 && !FLOW && ((blockIdx.x >> 8) & 1);
-  auto run_eval = [&](auto ADDC) {
-    constexpr bool ADD = decltype(ADDC)::value;
+  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused);
+  auto run_eval = [&]() {
     const ProgHdr h = a.hdr[p];
     double* tpt = sm;
     double* sig = sm + 256;
@@ -608,9 +510,6 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
     if (AGP_EXP_TABLE && !LAGM && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];      // (lag sweeps evaluate no exponential)
     // (program, parameters, time points and lag tables travel in ONE round trip; the prologue's barrier publishes all of it)
     cov_prologue<LAGM>(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt, LAGM ? a.lagr : nullptr, lstride, xrk);
-#ifdef AGP_PROBE_PROLOGUE
-    if (FLOW) AGP_PROBE(2);          // (measurement build: "stage" column of the flow trace = end of the tile prologue)
-#endif
     const double noise = a.noise[p];
     // GammaExp leaves read log|dt| from the data set's table (L2 / Infinity-Cache resident: every particle reads
     // the same 128 KiB tile); the loads are issued at the top of the pass and consumed by the first such leaf
@@ -647,7 +546,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
           } else {
             v0 = -lq_[row0 - cs]; v1 = -lq_[row1 - cs];
           }
-          if (ADD) { acc[cb][0][r] += v0; acc[cb][1][r] += v1; } else { acc[cb][0][r] = v0; acc[cb][1][r] = v1; }
+          acc[cb][0][r] = v0; acc[cb][1][r] = v1;
         }
     }
     // ... and ONE Linear leaf (src/GP.jl:194-203; a quarter of the population): bias + amp (t_i - c)(t_j - c), same tiles
@@ -660,7 +559,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
         for (int r = 0; r < 4; ++r) {
           const double tcc = tpt[NB + cb * 16 + 4 * r + lq] - q0;
           const double v0 = -(q1 + q2 * (u0 * tcc)), v1 = -(q1 + q2 * (u1 * tcc));      // (eval_leaf's expression)
-          if (ADD) { acc[cb][0][r] += v0; acc[cb][1][r] += v1; } else { acc[cb][0][r] = v0; acc[cb][1][r] = v1; }
+          acc[cb][0][r] = v0; acc[cb][1][r] = v1;
         }
     }
 #pragma unroll 1
@@ -691,7 +590,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         v[r] = -cov_finalize(out[r], ti * NB + rslot, tk * NB + cb * 16 + 4 * r + lq, a.n1, a.n1_pad, a.m2, noise);
-      auto put = [&](d4& dst) { if (ADD) dst += v; else dst = v; };
+      auto put = [&](d4& dst) { dst = v; };
       switch (t) {   // wave-uniform scalar dispatch keeps every accumulator index static
         case 0: put(acc[0][0]); break;  case 1: put(acc[0][1]); break;  case 2: put(acc[1][0]); break;  case 3: put(acc[1][1]); break;
         case 4: put(acc[2][0]); break;  case 5: put(acc[2][1]); break;  case 6: put(acc[3][0]); break;  case 7: put(acc[3][1]); break;
@@ -701,8 +600,8 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
     }
     __syncthreads();   // the sigma tables alias the GEMM slab buffers
   };
-  if (!prebuilt && !post_eval) {
-    run_eval(std::false_type{});
+  if (!prebuilt) {
+    run_eval();
   } else {
 #pragma unroll
     for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
@@ -719,8 +618,8 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
   constexpr int SLABS_PER_TILE = NB / KS;
   constexpr int SLAB_DOUBLES = KS * LDS_STRIDE;
   static_assert(4 * SLAB_DOUBLES <= U_MAIN_DOUBLES, "slab buffers");
-  const int jfirst = FACTOR ? (FLOW ? a.jstart : 0) : a.j0;          // first block column of the sum
-  const int nslab = (AGP_DBG_SKIP & 4) ? 0 : (jmax - jfirst) * SLABS_PER_TILE;
+  const int jfirst = FACTOR ? 0 : a.j0;          // first block column of the sum
+  const int nslab = (jmax - jfirst) * SLABS_PER_TILE;
   if (nslab > 0) {
     // column operand: 256 threads stage the slab of tile (k,j), NU x 16 B each (element 2*(tid+256u));
     // row operand: each lane fetches its own two rows of tile (i,j) for k-step kk at column 4kk + lq.
@@ -730,11 +629,10 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
     const int scol0 = tid >> 6;        // + 4u
     const int srow = 2 * (tid & 63);
     const unsigned offB = (unsigned)(scol0 * NB + srow);
-    const unsigned offA = A_DIRECT ? (unsigned)(lq * NB + row0) : offB;
+    const unsigned offA = (unsigned)(lq * NB + row0);
     double rx = 0.0;
     // (the tiles (i,0..i) of a tile row are contiguous: slab s of the sum sits (jfirst * SLABS_PER_TILE + s) slabs into the row)
     const __amdgpu_buffer_rsrc_t rsA = tile_row_rsrc(Ap + tile_off(ti, 0)), rsB = tile_row_rsrc(Ap + tile_off(tk, 0));
-    static_assert(ADJ || !A_DIRECT, "the direct row operand is fetched as adjacent row pairs");
     auto gload = [&](int s, d2 (&ra_)[NU], d2 (&rb_)[NU]) {
       const int sb = (jfirst * SLABS_PER_TILE + s) * (KS * NB * 8);       // byte offset of the slab in both tile rows
 #pragma unroll
@@ -746,11 +644,9 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
     };
     auto lstore = [&](int buf, const d2 (&ra_)[NU], const d2 (&rb_)[NU]) {
       double* Bs = sm + buf * SLAB_DOUBLES;
-      double* As = sm + (2 + buf) * SLAB_DOUBLES;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb_[u];
-        if (!A_DIRECT) *reinterpret_cast<d2*>(As + (scol0 + 4 * u) * LDS_STRIDE + srow) = ra_[u];
       }
       if (is_diag && tid < KS) xv[buf * KS + tid] = rx;
     };
@@ -758,13 +654,13 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
     // FLOW: the operands of block column j are tiles (ti,j) and (tk,j) of this launch; one lane waits for their
     // flags one slab before the first load of that column is issued, the slab's barrier publishes the result
     auto flow_ready = [&](int j) {
-      const long long tw0 = a.trace ? (long long)wall_clock64() : 0;
+      const long long tw0 = AGP_TRACE(a) ? (long long)wall_clock64() : 0;
       const int* tf = a.tflag + (long long)ps * a.ntri;
       bool ok = flow_wait(tf + tri_idx(tk, j));
       if (!is_diag) ok = flow_wait(tf + tri_idx(ti, j)) && ok;
       if (!ok) a.info[ps] = -7;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (a.trace && wait_acc) wait_acc->wait += (double)((long long)wall_clock64() - tw0);
+      if (AGP_TRACE(a) && wait_acc) wait_acc->wait += (double)((long long)wall_clock64() - tw0);
     };
     // A tile of block column k-1 is final only after its own K-loop has consumed (acquired) every earlier column of
     // its tile row — so when (tk,k-1) and (ti,k-1) are already raised, every operand of this K-loop is final and
@@ -785,7 +681,6 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
     // (Fetching the direct row operand TWO slabs ahead — 16 more VGPRs, still no spills — was measured: the 512-particle
     // sub-diagonal launch went 1.560 -> 1.664 ms.  The loop is not waiting for its loads; more of them in flight only
     // crowd the co-resident workgroup's.)
-    const bool prio_hi = (AGP_CHAIN_PRIO && FLOW) ? (ti == tk + 1) : wave_slot_odd();
     // Two register sets X / Y take turns as "row fragments of the slab being multiplied" and "row fragments in flight" (the
     // slab loop is unrolled by two; nslab is a multiple of 8): no register copies at the slab boundary.
     d2 fx[NU], fy[NU], rb[NU];
@@ -795,9 +690,8 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
     auto slab = [&](const int s, const int buf, const d2 (&fr)[NU], d2 (&rn)[NU]) {
       if (s + 1 < nslab) gload(s + 1, rn, rb);
       const double* Bs = sm + buf * SLAB_DOUBLES;
-      const double* As = sm + (2 + buf) * SLAB_DOUBLES;
       // waves inside their MFMA block outrank the co-resident workgroup's load/store/barrier phase
-      mfma_prio_on(prio_hi);
+      mfma_prio_on();
 #pragma unroll
       for (int kk = 0; kk < KS / 4; ++kk) {
         const int krow = (kk * 4 + lq) * LDS_STRIDE;
@@ -805,16 +699,14 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
 #pragma unroll
         for (int cb = 0; cb < NSB; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];     // columns of C: tile (k,j)
         d2 fb;                                                                   // rows of C: tile (i,j)
-        if (A_DIRECT) fb = fr[kk];
-        else if (ILV) fb = *reinterpret_cast<const d2*>(As + krow + row0);
-        else { fb.x = As[krow + row0]; fb.y = As[krow + row1]; }
+        fb = fr[kk];
 #pragma unroll
         for (int cb = 0; cb < NSB; ++cb) {
           acc[cb][0] = mfma(fa[cb], fb.x, acc[cb][0]);
           acc[cb][1] = mfma(fa[cb], fb.y, acc[cb][1]);
         }
       }
-      mfma_prio_off(prio_hi);
+      mfma_prio_off();
       if (is_diag && tid < NB) {
         // r -= L(k,j)[:, slab] * alpha_j[slab]
         const double* xs_ = xv + buf * KS;
@@ -831,17 +723,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
     }
   }
 
-  phase_prio();
   if (FLOW) AGP_PROBE(1);
-  if (post_eval) run_eval(std::true_type{});      // (its leading barrier comes after the K-loop's last one: the slab buffers are free)
-  if (FLOW && a.need > 0) {
-    // the tile holds what the early-sum items left: wait for the last of them
-    if (tid == 0) {
-      if (!flow_wait_ge(a.pflag + (long long)ps * a.part_tiles + part_tile(a, ti, tk), a.need)) a.info[ps] = -7;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-  }
   if (prebuilt) {
     // resident tile: bring the accumulators to the same -C representation (one column block at a
     // time — the scheduling fence stops the compiler from hoisting all 64 loads, which would spill)
@@ -849,7 +731,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
     for (int cb = 0; cb < NSB; ++cb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const d2 t2 = ld_pair<ADJ>(Tt, cb * 16 + 4 * r + lq, row0, row1);
+        const d2 t2 = ld_pair(Tt, cb * 16 + 4 * r + lq, row0);
         acc[cb][0][r] -= t2.x;
         acc[cb][1][r] -= t2.y;
       }
@@ -857,41 +739,30 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
     }
   }
 
-  if (!FACTOR || (!is_diag && !INTRSM) || (FLOW && producer)) {
+  if (!FACTOR || (!is_diag && !INTRSM)) {
     // ---- plain epilogue: C = -acc ----
 #pragma unroll
     for (int cb = 0; cb < NSB; ++cb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        st_pair<ADJ>(Tt, cb * 16 + 4 * r + lq, row0, row1, -acc[cb][0][r], -acc[cb][1][r]);
+        st_pair(Tt, cb * 16 + 4 * r + lq, row0, -acc[cb][0][r], -acc[cb][1][r]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (is_diag && tid < NB) vecp[tk * NB + tid] = rv;   // Schur mode: -(V^T alpha) (+x = 0)
-    if (FLOW && producer) {
-      // early-sum item: the tile holds A - (sums so far); release; count the chunk
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(a.pflag + (long long)ps * a.part_tiles + part_tile(a, ti, tk), a.early, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
     return;
   }
 
   if (!is_diag) {
     // =====================  off-diagonal tile: L(i,k) = C(i,k) L(k,k)^-T in registers  =====================
-    if (!(AGP_DBG_SKIP & 8)) {
     // (for the sub-diagonal-only launch the word is already set — the diagonal launch precedes it in stream order —
     // but the poll stays: its branch + acquire also keep the staging loads below from being hoisted into the GEMM
     // epilogue, which costs 30 VGPRs and spills)
     if (tid == 0) {
       if (FLOW) {
-        const long long tw0 = a.trace ? (long long)wall_clock64() : 0;
+        const long long tw0 = AGP_TRACE(a) ? (long long)wall_clock64() : 0;
         if (!flow_wait(a.tflag + (long long)ps * a.ntri + tri_idx(tk, tk))) a.info[ps] = -7;
-        if (a.trace && wait_acc) wait_acc->wait += (double)((long long)wall_clock64() - tw0);
+        if (AGP_TRACE(a) && wait_acc) wait_acc->wait += (double)((long long)wall_clock64() - tw0);
       } else {
         const int want = a.k + 1;
         int spins = 0;
@@ -917,18 +788,10 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
       for (int u = 0; u < NSB; ++u) sm[(T_NBLK + u) * 256 + tid] = -Wg[u * 256 + tid];
     }
     __syncthreads();
-    }
-#ifndef AGP_PROBE_PROLOGUE
     if (FLOW) AGP_PROBE(2);
-#endif
     // With acc = -C:  t = acc_jb + sum_lb L(jb,lb) X_lb = -(C_jb - sum L X),  X_jb = (-W_jb) t.
 #pragma unroll
     for (int jb = 0; jb < NSB; ++jb) {
-      if (AGP_DBG_SKIP & 9) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) st_pair(Tt, jb * 16 + 4 * r + lq, row0, row1, acc[jb][0][r], acc[jb][1][r]);
-        continue;
-      }
 #pragma unroll
       for (int lb = 0; lb < jb; ++lb) {
         const double* blk = sm + sblk_idx(jb, lb) * 256;
@@ -950,7 +813,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
       acc[jb][1] = x1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        st_pair(Tt, jb * 16 + 4 * r + lq, row0, row1, x0[r], x1[r]);
+        st_pair(Tt, jb * 16 + 4 * r + lq, row0, x0[r], x1[r]);
       }
     }
     if (FLOW) {
@@ -959,7 +822,7 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(a.tflag + (long long)ps * a.ntri + tri_idx(ti, tk), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -1012,16 +875,10 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(CholArgs a) {
     const int ndiag = 8 * ((a.P + 7) / 8);
     if (b < ndiag) {
       xcd = b & 7; pl = b >> 3; tl = 0;
-    } else if (XCD_PIN) {
+    } else {
       b -= ndiag;
       xcd = b & 7; qq = b >> 3;
       pl = qq / (T - 1); tl = 1 + (qq - pl * (T - 1));
-    } else {
-      // particle-major over all XCDs: consecutive blocks are the tiles of one particle
-      b -= ndiag;
-      const int pp = b / (T - 1);
-      tl = 1 + (b - pp * (T - 1));
-      xcd = pp & 7; pl = pp >> 3;
     }
     tk = a.k; ti = a.k + tl; jmax = a.rl ? 0 : a.k;
   } else {
@@ -1061,16 +918,14 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
   constexpr bool TAB = GM == 1, LAGM = GM == 2;
   const int p = __builtin_amdgcn_readfirstlane(p_), ps = __builtin_amdgcn_readfirstlane(ps_);      // (wave-uniform: see chol_tile)
   const int tk = __builtin_amdgcn_readfirstlane(tk_);
-  phase_prio();
   double* rvec = sm + U_MAIN_DOUBLES;
   double* avec = rvec + 128;
   double* xv = avec + 128;     // [2][32]
   double* Wl = xv + 64;        // [256]
   constexpr int NE = NSB + 1;  // accumulator blocks per wave
   AGP_DPROBE(0);
-  const bool producer = FLOW && a.early != 0;            // early-sum item (see CholArgs::items): its chunk of the K-loop, no factorisation
-  const int jfirst = FLOW ? a.jstart : 0;
-  const int jmax = producer ? jfirst + a.part_ch : (a.rl ? 0 : a.k);
+  const int jfirst = 0;
+  const int jmax = a.rl ? 0 : a.k;
   const int l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   const int wu = __builtin_amdgcn_readfirstlane(w);
   const int row0 = 16 * w + l15, row1 = 16 * (NSB - 1 - w) + l15;
@@ -1084,7 +939,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
   double* vecp = a.vec + (long long)ps * a.ldv;
   double* __restrict__ Tt = Ap + tile_off(tk, tk);
   d4 acc[NE];
-  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused) || (FLOW && a.need > 0);
+  const bool prebuilt = (DCOV == 0) || (p >= a.n_fused);
   if (!prebuilt) {
     const ProgHdr h = a.hdr[p];
     double* tpt = sm;
@@ -1180,8 +1035,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
   }
 
   double rv = 0.0;
-  const bool late = FLOW && a.need > 0;       // the vector segment is what the previous early-sum item left: read behind the wait
-  if (tid < NB && !late) rv = vecp[tk * NB + tid];
+  if (tid < NB) rv = vecp[tk * NB + tid];
   if (FLOW) AGP_PROBE(0);
 
   constexpr int KS = 2 * KB;                      // 32-column slabs
@@ -1233,10 +1087,9 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
       for (int u = 0; u < NU; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb2[u];
       if (tid < KS) xv[buf * KS + tid] = rx2;
     };
-    const bool prio_hi = (AGP_CHAIN_PRIO && FLOW) ? true : wave_slot_odd();
     auto slab = [&](int buf) {
       const double* Bs = sm + buf * SLAB_DOUBLES;
-      mfma_prio_on(prio_hi);
+      mfma_prio_on();
 #pragma unroll
       for (int kk = 0; kk < KS / 4; ++kk) {
         const double* Bk = Bs + kk * 4 * LDS_STRIDE;
@@ -1244,18 +1097,18 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
         // entry e multiplies the rows of block w (f0) for e <= w and of block 7-w (f1) after that; w <= 3, so only entries
         // 1..3 depend on the wave: a register select in front of EVERY MFMA (what `st1[e] ? f1 : f0` compiles to for all
         // nine) costs 18 vector instructions per 9 MFMAs on the port that issues them
-        if (!(AGP_DBG_SKIP & 256)) {
+        {
           acc[0] = mfma(Bk[fao[0]], f0, acc[0]);
           // (entries 1..3 read their row fragment through a per-entry LDS offset fixed before the loop: three more LDS reads
           // per k-step instead of six selects)
 #pragma unroll
-          for (int e = 1; e < 4; ++e) acc[e] = mfma(Bk[fao[e]], AGP_DIAG_SELECT ? (st1[e] ? f1 : f0) : Bk[fbo[e]], acc[e]);
+          for (int e = 1; e < 4; ++e) acc[e] = mfma(Bk[fao[e]], Bk[fbo[e]], acc[e]);
 #pragma unroll
           for (int e = 4; e < NE; ++e) acc[e] = mfma(Bk[fao[e]], f1, acc[e]);
         }
       }
-      mfma_prio_off(prio_hi);
-      if (tid < NB && !(AGP_DBG_SKIP & 128)) {
+      mfma_prio_off();
+      if (tid < NB) {
         // r -= L(k,j)[:, slab] * alpha_j[slab]
         // (Spreading this over all four waves — each half of the workgroup taking half of the slab's columns — was tried:
         // the kernel sits at exactly 256 VGPRs and the extra live values turned 1 spilled register into 97.)
@@ -1267,10 +1120,10 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
     // FLOW: block column j's slabs are 4j .. 4j+3; slab 4j is the first of them to be fetched (by gload, two slabs
     // ahead of its use), so one lane waits for tile (tk, j) at the end of the iteration before that fetch
     auto flow_ready = [&](int j) {
-      const long long tw0 = a.trace ? (long long)wall_clock64() : 0;
+      const long long tw0 = AGP_TRACE(a) ? (long long)wall_clock64() : 0;
       if (!flow_wait(a.tflag + (long long)ps * a.ntri + tri_idx(tk, j))) a.info[ps] = -7;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      if (a.trace && wait_acc) wait_acc->wait += (double)((long long)wall_clock64() - tw0);
+      if (AGP_TRACE(a) && wait_acc) wait_acc->wait += (double)((long long)wall_clock64() - tw0);
     };
     int all_ready = 0;       // (see chol_tile: tile (tk, k-1) final => every earlier tile of the row is final and visible)
     if (FLOW) {
@@ -1300,16 +1153,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
     }
   }
 
-  phase_prio();
   if (FLOW) AGP_PROBE(1);
-  if (FLOW && a.need > 0) {
-    if (tid == 0) {
-      if (!flow_wait_ge(a.pflag + (long long)ps * a.part_tiles + part_tile(a, tk, tk), a.need)) a.info[ps] = -7;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    if (tid < NB) rv += vecp[tk * NB + tid];
-  }
   if (prebuilt) {
     // resident tile: bring the accumulators to the -C representation
 #pragma unroll
@@ -1319,25 +1163,6 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
       for (int r = 0; r < 4; ++r) acc[e][r] -= Tt[(cbe[e] * 16 + 4 * r + lq) * NB + rw];
       __builtin_amdgcn_sched_barrier(0);
     }
-  }
-  if (FLOW && producer) {
-    // early-sum item: A - (sums so far) back into the tile's lower block triangle, the vector's share into vec; release; count
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-      const int rw = st1[e] ? row1 : row0;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Tt[(cbe[e] * 16 + 4 * r + lq) * NB + rw] = -acc[e][r];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (tid < NB) vecp[tk * NB + tid] = rv;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, AGP_REL_SCOPE);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a.pflag + (long long)ps * a.part_tiles + part_tile(a, tk, tk), a.early, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return;
   }
 
   // S = -acc into the 16x16 blocks of the lower block triangle (column-major blocks)
@@ -1350,7 +1175,7 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
   }
   if (FLOW) AGP_PROBE(2);
   AGP_DPROBE(1);
-  factor_diag_tile<true>(a, ps, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid, (FLOW && a.trace && wait_acc) ? &wait_acc->ph[3] : nullptr);
+  factor_diag_tile<true>(a, ps, tk, Tt, vecp, sm, rvec, avec, Wl, rv, tid, (FLOW && AGP_TRACE(a) && wait_acc) ? &wait_acc->ph[3] : nullptr);
 }
 
 template <int DCOV, int GM>
@@ -1385,84 +1210,49 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
   const int Pl = (a0.P - xcd + 7) / 8;          // particles pl*8 + xcd < P
   const int nt = a0.nt;
   const int nfac = a0.nt1;                       // block columns to factor: nt in a logpdf sweep, the training block in prediction
-  const bool listed = a0.items != nullptr;       // host-built work list (plain sweeps with early partial sums)
-  const int total = listed ? a0.n_items[xcd] : Pl * (nfac * nt - nfac * (nfac - 1) / 2);
+  const int total = Pl * (nfac * nt - nfac * (nfac - 1) / 2);
   // (Drawing the NEXT ticket early, to hide the atomic's latency behind the current tile, was measured: a drawn-but-not-
-  // started item delays its consumers by the rest of the current item — 4 % slower at 64 particles, neutral at 512.)
+  // started item delays its consumers by the rest of the current item — 4 % slower at 64 particles, neutral at 512.  Other
+  // queue orders — tile-row-major, look-ahead with the (k+1,k) tiles and the next diagonal tiles first — measured within 1 %.)
   for (;;) {
     __syncthreads();                             // the previous item's LDS and s_item are no longer read
     if (threadIdx.x == 0) s_item = atomicAdd(a0.qnext + xcd, 1);
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(s_item);      // wave-uniform: keeps the tile indices scalar
     if (item >= total) return;
+    // block column k: its diagonal tiles, then its sub-diagonal tiles particle-major
     int k = 0, rem = item, pl, tl;
-    int kind = 0, chunk = 0;
-    if (listed) {
-      const int4 it = a0.items[(long long)xcd * a0.items_stride + item];
-      kind = __builtin_amdgcn_readfirstlane(it.x & 255); chunk = __builtin_amdgcn_readfirstlane(it.x >> 8);
-      pl = __builtin_amdgcn_readfirstlane(it.y);
-      k = __builtin_amdgcn_readfirstlane(it.w); tl = __builtin_amdgcn_readfirstlane(it.z) - k;
-    } else if (a0.flow_order == 2 && nfac == nt) {
-      // Look-ahead order: after the diagonal tiles of column 0, "super-column" k = the (k+1,k) tiles of every particle,
-      // then the diagonal tiles of column k+1 (their last operand is that tile), then the rest of column k.  The
-      // factorisation of L(k+1,k+1) is thus issued a whole column of tiles before anything needs it: the panel solves
-      // of column k+1 never wait for it, and the serial chain diag -> (k+1,k) -> diag is never queued behind bulk tiles.
-      if (rem < Pl) { pl = rem; tl = 0; }
-      else {
-        rem -= Pl;
-        while (rem >= Pl * (nt - k)) { rem -= Pl * (nt - k); ++k; }
-        if (rem < Pl) { pl = rem; tl = 1; }
-        else if (rem < 2 * Pl) { pl = rem - Pl; tl = 0; ++k; }          // diagonal tile of the NEXT column
-        else {
-          rem -= 2 * Pl;
-          const int T2 = nt - k - 2;
-          pl = rem / T2; tl = 2 + rem - pl * T2;
-        }
-      }
-    } else {
-      while (rem >= Pl * (nt - k)) { rem -= Pl * (nt - k); ++k; }
-      if (rem < Pl) { pl = rem; tl = 0; }
-      else {
-        rem -= Pl;
-        const int T1 = nt - k - 1;
-        if (a0.flow_order == 0) { tl = 1 + rem / Pl; pl = rem - (tl - 1) * Pl; }
-        else { pl = rem / T1; tl = 1 + rem - pl * T1; }
-      }
+    while (rem >= Pl * (nt - k)) { rem -= Pl * (nt - k); ++k; }
+    if (rem < Pl) { pl = rem; tl = 0; }
+    else {
+      rem -= Pl;
+      const int T1 = nt - k - 1;
+      pl = rem / T1; tl = 1 + rem - pl * T1;
     }
     const int p = pl * 8 + xcd;
     if (a0.i0 != nullptr && k + tl < a0.i0[p]) continue;        // extension sweep: this tile row keeps its factor (flag pre-raised)
     const int ps = a0.slot != nullptr ? a0.slot[p] : p;
     CholArgs a = a0;
     a.k = k;
-    if (listed) {
-      // kinds: 0 diagonal tile, 1 sub-diagonal tile, 2 / 3 early partial sum of a trailing diagonal / sub-diagonal tile
-      const bool trailing = k >= nt - a0.part_tb;
-      a.early = kind >= 2 ? chunk + 1 : 0;
-      a.need = kind >= 2 ? chunk : (trailing ? a0.part_nch : 0);
-      a.jstart = kind >= 2 ? chunk * a0.part_ch : (trailing ? a0.part_nch * a0.part_ch : 0);
-    }
-    const long long t_start = a0.trace ? (long long)wall_clock64() : 0;
-    if (a0.trace && threadIdx.x == 0) { s_probe.wait = 0.0; s_probe.ph[0] = s_probe.ph[1] = s_probe.ph[2] = s_probe.ph[3] = 0; }
+    const long long t_start = AGP_TRACE(a0) ? (long long)wall_clock64() : 0;
+    if (AGP_TRACE(a0) && threadIdx.x == 0) { s_probe.wait = 0.0; s_probe.ph[0] = s_probe.ph[1] = s_probe.ph[2] = s_probe.ph[3] = 0; }
     // the lane index is made opaque per item: otherwise every lane-dependent offset of every phase of the tile body is
     // hoisted out of this loop and stays live across the K-loop (hundreds of spilled registers)
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     // diagonal tiles run the lower-triangle body of k_chol_diag, the others the sub-diagonal body (update + in-register
     // solve) of the split per-column launches
-    if (AGP_CHAIN_PRIO) { if (tl <= 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
     if (tl == 0) chol_diag_tile<DCOV, GM, true>(a, p, ps, k, sm, tid, &s_probe);
-    else chol_tile<true, DCOV, true, 2, GM, true>(a, p, ps, k + tl, k, (listed && kind >= 2) ? (chunk + 1) * a0.part_ch : k, false, sm, tid, &s_probe);
-    if (AGP_CHAIN_PRIO) __builtin_amdgcn_s_setprio(0);
-    if (a0.trace && threadIdx.x == 0) {
+    else chol_tile<true, DCOV, true, 2, GM, true>(a, p, ps, k + tl, k, k, false, sm, tid, &s_probe);
+    if (AGP_TRACE(a0) && threadIdx.x == 0) {
       // record of this item: [start, end, K-loop wait ticks, (xcd, particle, tile row, block column)]
       long long gi = item;
-      if (listed) gi += (long long)xcd * a0.items_stride;
-      else for (int x = 0; x < xcd; ++x) gi += ((a0.P - x + 7) / 8) * (nfac * nt - nfac * (nfac - 1) / 2);
-      long long* r = a0.trace + 8 * gi;
+      for (int x = 0; x < xcd; ++x) gi += ((a0.P - x + 7) / 8) * (nfac * nt - nfac * (nfac - 1) / 2);
+      long long* r = AGP_TRACE(a0) + 8 * gi;
       r[0] = t_start; r[1] = (long long)wall_clock64();
       r[2] = (long long)s_probe.wait;
       r[4] = s_probe.ph[0]; r[5] = s_probe.ph[1]; r[6] = s_probe.ph[2]; r[7] = s_probe.ph[3];
-      r[3] = ((long long)blockIdx.x << 48) | ((long long)kind << 44) | ((long long)p << 24) | ((long long)(k + tl) << 12) | k;
+      r[3] = ((long long)blockIdx.x << 48) | ((long long)(tl == 0 ? 0 : 1) << 44) | ((long long)p << 24) | ((long long)(k + tl) << 12) | k;
     }
   }
 }

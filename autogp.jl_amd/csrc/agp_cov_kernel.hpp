@@ -38,13 +38,13 @@ struct CovArgs {
   double* A;             // packed tiles, per-particle stride strideA
   long long strideA;
   int P;
-  int col0_only;         // 1: grid.x enumerates tiles (1+tix, 0) only
   int p_off;             // first particle (blockIdx.y is relative to it)
   const uint8_t* code;   // per joint point: 0 observable, i latent of component i (infer_gp_sum); null = all 0
   const double* logdt;   // packed lower tiles of log|t_i - t_j| over the resident data (programs with flags bit 0)
   const int* slot;       // extension sweeps (see CholArgs): storage index per particle, first tile row to (re)build
   const int* i0;
   int skip_pred_offdiag; // prediction without a covariance request: off-diagonal tiles of the K22 block are never read
+  int pred_only;         // 1: only the tiles of the prediction block (both indices past the training rows)
   const double* lagtab;  // lag tables of the sweep's OP_LAG_* leaves (k_lag_tables): [table][block lag 0..nt-1][256]
   const int32_t* lagr;   // RANK lag tables (regular grid, points in the caller's order; null: sorted sweep): rank of every resident
   int lag_stride;        //   point in the sorted series; a leaf's table then holds all lag_stride lags 0 .. n_max-1 (see cov_prologue)
@@ -282,17 +282,14 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
   const int p = blockIdx.y + a.p_off;
   const int tix = blockIdx.x;
   int ti, tj;
-  if (a.col0_only) {
-    ti = 1 + tix; tj = 0;
-  } else {
-    // lower-triangular tile index -> (ti, tj)
-    ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
-    while (ti * (ti + 1) / 2 > tix) --ti;
-    while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
-    tj = tix - ti * (ti + 1) / 2;
-  }
+  // lower-triangular tile index -> (ti, tj)
+  ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
+  while (ti * (ti + 1) / 2 > tix) --ti;
+  while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
+  tj = tix - ti * (ti + 1) / 2;
   if (a.i0 != nullptr && ti < a.i0[p]) return;        // extension sweep: this tile row keeps its factor
   if (a.skip_pred_offdiag && ti != tj && tj * NB >= a.n1_pad) return;
+  if (a.pred_only && tj * NB < a.n1_pad) return;
   const int tid = threadIdx.x;
   const ProgHdr h = a.hdr[p];
   const uint8_t* __restrict__ ops = a.ops + h.op_off;

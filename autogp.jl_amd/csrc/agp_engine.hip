@@ -6,6 +6,7 @@
 #include "agp_cov_kernel.hpp"
 #include "agp_chol_kernel.hpp"
 #ifdef AGP_EXPERIMENTS
+#include "experiments/agp_experiments_abi.h"
 #include "experiments/agp_experiments.hpp"   // ablation kernels of the update GEMM (measurement builds only: libautogp_hip_exp.so)
 #endif
 #include "agp_grad_kernel.hpp"
@@ -68,12 +69,8 @@ struct Slot {
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
       Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq, lagtab,
-      flowlist, flowpflag;
-  long long flowlist_key = -1;        // (P, nt, order, tb, ch) the device-resident work list was built for
-  int flowlist_stride = 0;
+      pl_rank, pl_tl, pl_prog;
   std::vector<hipEvent_t> events;
-  std::vector<hipStream_t> sub;       // extra streams for sub-batch overlap
-  std::vector<hipEvent_t> sub_ev;     // fork / join events
   hipStream_t gq[3] = {nullptr, nullptr, nullptr};     // gradient sweeps: the contraction's launch classes run side by side
   hipEvent_t gq_ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   bool busy = false;
@@ -87,15 +84,11 @@ struct Slot {
     if (done) { (void)hipEventDestroy(done); done = nullptr; }
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
-                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab, &flowlist, &flowpflag})
+                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab, &pl_rank, &pl_tl, &pl_prog})
       b->release();
     stage.release(); h_stage.release(); h_out.release(); h_async_info.release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
-    for (auto e : sub_ev) (void)hipEventDestroy(e);
-    sub_ev.clear();
-    for (auto q : sub) (void)hipStreamDestroy(q);
-    sub.clear();
     for (auto& q : gq) { if (q) (void)hipStreamDestroy(q); q = nullptr; }
     for (auto& e : gq_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     if (stream) (void)hipStreamDestroy(stream);
@@ -130,32 +123,20 @@ struct agp_ctx {
   int64_t n_max = 0;
   std::vector<double> h_ts;   // host copy (prediction builds a joint point list)
   std::vector<double> h_ts_sorted;   // ascending copy when the series is a regular grid (empty otherwise)
+  std::vector<int32_t> h_rank;       // ... and the rank of resident point i in it (host copy of d_rank)
+  int64_t n_lag_pred = 0;            // predictive passes whose query points sat on the series' lattice (rank tables; agp_get_lag_predict_stats)
   // config
   int64_t ws_limit = 0;
   size_t total_mem = 0;
   int n_cu = 256;
   bool profiling = false;
-  int grad_lds_tape = 1;   // 1: trees of <= 8 nodes keep the contraction's tape in LDS; env AGP_GRAD_LDS_TAPE
   int64_t pred_reused = 0, pred_factored = 0;   // predictive passes: particles served from a resident factor / factored (under mu)
   int64_t grad_reused = 0, grad_factored = 0;   // gradient sweeps likewise
   int factor_cache = 1;    // 1: coalesced agp_logpdf batches leave their factors in the store (a later call on a longer prefix extends
                            // them, a gradient call at the same parameters skips the factorisation); env AGP_FACTOR_CACHE, agp_set_factor_cache
   int predict_reuse = 1;   // 1: predictive passes take L11 / alpha of a particle from the factor store when it holds them; env AGP_PREDICT_REUSE
-  int grad_split = 1;   // 1: K^-1 tiles to memory + lean contraction kernel; 0: fused tile kernel (env AGP_GRAD_SPLIT)
-  int intrsm = 1;       // 1: triangular solve inside k_chol_update (one launch per block column); env AGP_INTRSM
-  int n_streams = 1;    // sub-batches of one call run on this many streams (env AGP_STREAMS)
-  // A tile evaluation longer than this (cost model op_cost_us, measured per-leaf cost of one 128x128 tile
-  // with two workgroups per CU) is not hidden by the co-resident workgroup's GEMM phase and would set the
-  // duration of the short launches; such particles get their tiles from k_cov_tiles.  env AGP_FUSE_MAX_US
-  double fuse_max_us = 25.0;     // (priced with the per-leaf costs of compile_batch, which predate exp_t: 25 vs 35: 29.28 vs 29.6 ms at 512 particles)
-  double flow_fuse_max_us = 70.0;   // the same limit under the dataflow schedule; env AGP_FLOW_FUSE_MAX_US
-  double flow_lag_fuse_max_us = 10.0;   // the dataflow schedule on a lag-table sweep (measured 2.5 / 5 / 9 / 16 / 70 us, n=2048 x 64: 3.87 / 3.83 / 3.83 / 3.86 / 4.01 ms; the tiles of larger programs come from k_cov_tiles, fast with lag tables); env AGP_FLOW_LAG_FUSE_MAX_US
-  double lag_fuse_max_us = 3.0;     // ... and for the per-column launches of a lag-table sweep (programs are priced at ~2 us per node there): one-node
-                                    // programs only — they are filled without the evaluator; 2.5 / 5 / 8 / 12 / 20 us measured 25.33 /
-                                    // 25.40 / 25.57 / 25.58 / 25.94 ms per 512-particle sweep; env AGP_LAG_FUSE_MAX_US
   int dedup = 1;        // evaluate identical particles of a host-output sweep once; env AGP_DEDUP
   int64_t n_particles_seen = 0, n_particles_run = 0;
-  int trtri_chain = 1;  // Z = L^-T as independent per-row chains in one launch (0: one launch per block column); env AGP_TRTRI_CHAIN
   int split_diag = -1;  // diagonal tiles in their own specialised launch: -1 auto (when they fill the GPU), 0, 1; env AGP_SPLIT_DIAG
   int ge_table = 1;     // GammaExp leaves read log|dt| from a table built by agp_set_data (env AGP_GE_TABLE)
   // Sorted regular grid (agp_set_data): when the resident time points, put in ascending order, are equally spaced, value
@@ -163,15 +144,12 @@ struct agp_ctx {
   // x) and evaluate stationary leaves from per-tile lag tables (OP_LAG_*, agp_cov_kernel.hpp).  env AGP_LAG=0 disables.
   double* d_ts_s = nullptr;
   double* d_xs_s = nullptr;
-  int lag_store_enable = 1;      // ... also for the factor store's sweeps (agp_logpdf_batch_extend, coalesced agp_logpdf); env AGP_LAG_STORE
   int lag_rank_enable = 1;       // regular grid, sweeps in the CALLER's order (prefixes, gradient sweeps): rank lag tables (cov_prologue); env AGP_LAG_RANK
   int64_t n_lag_rank_sweeps = 0;
   int32_t* d_rank = nullptr;     // rank of resident point i in the sorted series (lag-domain gradient contraction, k_kinv_tiles)
   double t_ref = 0.0;            // middle of the series: reference time of the Linear moments there
   double grid_h = 0.0, grid_mid = 0.0;      // grid spacing; t_sorted[r] - t_ref = (r - grid_mid) h
-  int grad_fork = 1;             // the gradient contraction's launch classes on separate streams; env AGP_GRAD_FORK
   int grad_fft = 1;              // lag-domain particles of series of <= FFT_N / 2 points: lag sums from Z's power spectrum; env AGP_GRAD_FFT
-  int grad_fft_min_n = 1024;     // env AGP_GRAD_FFT_MIN_N
   double* d_fft_tw = nullptr;    // twiddle factors of that transform
   int grad_lagdom = 1;           // gradient sweeps on a regular grid: lag-domain contraction where the kernel allows; env AGP_GRAD_LAGDOM
   int64_t n_lagdom_particles = 0;   // particles contracted in the lag domain so far (agp_get_lag_stats)
@@ -182,17 +160,10 @@ struct agp_ctx {
   double* d_logdt = nullptr;      // packed lower tiles, covers the resident data
   size_t logdt_cap = 0;
   bool logdt_ok = false;
-  int hybrid_blocks = 512;  // medium populations: switch to right-looking once a column has fewer workgroups; 0 = never; env AGP_HYBRID_BLOCKS
   int right_looking = -1;   // right-looking factorisation for small populations: -1 auto, 0, 1; env AGP_RIGHT_LOOKING
-  int stride_pad = 0;   // doubles added to a particle's matrix stride (multiple of 2: 16-byte tile accesses); env AGP_STRIDE_PAD
   int flow = -1;        // dataflow schedule (whole factorisation in one launch of persistent workgroups): -1 auto, 0, 1; env AGP_FLOW
-  int flow_order = 1;   // queue order of a block column's sub-diagonal tiles: 0 tile-row-major, 1 particle-major; env AGP_FLOW_ORDER
   long long* d_flow_trace = nullptr;   // agp_debug_flow_trace: 8 x int64 per work item of the next dataflow sweep
   size_t flow_trace_items = 0;
-  int flow_fuse = 1;    // 1: dataflow sweeps evaluate tiles in-kernel like the large-population path; env AGP_FLOW_FUSE
-  // Early partial sums in the dataflow schedule (plain sweeps): the K-loops of the tiles of the last flow_part_tb tile rows
-  // are cut into chunks of flow_part_ch block columns queued mid-kernel (CholArgs::items); 0 disables.  env AGP_FLOW_PART_TB / _CH
-  int flow_part_tb = 0, flow_part_ch = 4;      // (measured r03i: 4.28 vs 4.20 ms at 64 particles with tb = 4 — the extra items cost what the shorter tail saves: off)
   int fuse_mode = -1;   // -1 auto (fuse when the batch has >= 256 particles), 0 never, 1 always; env AGP_FUSE
   double timing[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    // [8..11]: gradient sweep: L^-T chain, K^-1 tiles, contraction, alpha + reduction
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
@@ -519,6 +490,15 @@ struct Batch {
   int g_max_nodes = 0, g_max_prm = 0, g_max_cp = 0;
 };
 
+// A tile evaluation longer than this (cost model op_cost_us: measured per-leaf cost of one 128x128 tile with two workgroups per
+// CU) would set the duration of the short launches; such particles get their tiles from k_cov_tiles.  Measured: per-column
+// launches 25 vs 35 us: 29.28 vs 29.6 ms at 512 particles; dataflow schedule 35 / 70 / 150 / 1000 us: config 2 0.99 / 0.92 / 0.92 /
+// 0.91 ms; lag-table sweeps price programs at ~2 us per node: dataflow 2.5 / 5 / 9 / 16 / 70 us: 3.87 / 3.83 / 3.83 / 3.86 / 4.01 ms at
+// n=2048 x 64, per-column launches 2.5 / 5 / 8 / 12 / 20 us: 25.33 / 25.40 / 25.57 / 25.58 / 25.94 ms (one-node programs only).
+constexpr double FUSE_MAX_US = 25.0, FLOW_FUSE_MAX_US = 70.0, FLOW_LAG_FUSE_MAX_US = 10.0, LAG_FUSE_MAX_US = 3.0;
+constexpr int HYBRID_BLOCKS = 512;        // medium populations: right-looking once a block column offers fewer workgroups (run_factor)
+constexpr int GRAD_FFT_MIN_N = 1024;      // below ~1000 points the K^-1 tiles are cheaper than n/2 transforms of length 4096
+
 // Measured cost of evaluating one 128x128 tile of a leaf inside k_chol_update (microseconds, MI355X).
 double op_cost_us(int op) {
   switch (op) {
@@ -576,8 +556,7 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   const bool fuse_on = c->fuse_mode == 1 || (c->fuse_mode < 0 && (P >= 256 || fuse_hint));
   // (the dataflow schedule has no launch tail for a long evaluation to hold up: its limit is higher — measured 35 / 70 /
   // 150 / 1000 us: config 2 0.99 / 0.92 / 0.92 / 0.91 ms, 2048 x 64 4.47 / 4.45 / 4.61 / 4.62 ms, config 4 62.9 / 61.9 / 63.6 / 63.6 ms)
-  const double fuse_limit = flow_limit ? (lag ? c->flow_lag_fuse_max_us : std::max(c->fuse_max_us, c->flow_fuse_max_us))
-                                       : (lag ? std::min(c->fuse_max_us, c->lag_fuse_max_us) : c->fuse_max_us);
+  const double fuse_limit = flow_limit ? (lag ? FLOW_LAG_FUSE_MAX_US : FLOW_FUSE_MAX_US) : (lag ? LAG_FUSE_MAX_US : FUSE_MAX_US);
   // (lag sweeps: the same price limit with the lag leaves' price — a 30-leaf tree still costs ~80 us per tile in interpreter
   // latency, measured: fusing everything made every diagonal-tile launch wait 110 us for the largest tree and forced the
   // depth-8 instantiation on the whole batch, 29.4 -> 31.0 ms per 512-particle sweep; a program that carries direct
@@ -756,9 +735,9 @@ struct Prof {
 
 // Factor block columns [0, nfac) of the joint (nt x nt tiles) matrices of Pc particles.
 // Factor block columns [0, nfac) of the joint (nt x nt tiles) matrices of ca.P particles.
-// intrsm: one launch per block column (the panel solve runs inside k_chol_update behind the
-// per-particle ready word); otherwise update + k_chol_trsm launches.
-hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intrsm, Prof* pf, double* counts,
+// One launch per block column (the panel solve runs inside k_chol_update behind the per-particle ready word), or two with the
+// diagonal tiles in their own specialised launch.
+hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, Prof* pf, double* counts,
                       bool split_diag = false, bool right_looking = false, int hybrid_blocks = 0) {
   if (dcov != 0 || nfac != ca.nt) right_looking = false;      // needs resident tiles and a full factorisation
   // (profiling marks are recorded on the stream the kernels are launched on)
@@ -811,7 +790,7 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intr
       }
       continue;
     }
-    if (intrsm && split_diag) {
+    if (split_diag) {
       ca.t0 = 1;
       // diagonal tiles in their own (specialised, lower-triangle-only) launch, then the sub-diagonal tiles, which
       // wait on the per-particle ready word only formally: stream order has already completed the diagonal launch
@@ -830,32 +809,13 @@ hipError_t run_factor(hipStream_t st, CholArgs ca, int nfac, int dcov, bool intr
       }
       continue;
     }
-    if (intrsm) {
+    {
       ca.tiles = ca.nt - k;
       size_t e0 = pf ? pf->mark(st) : 0;
       launch_update<true, true>(dcov, 8 * Pg * ca.tiles, st, ca);
       size_t e1 = pf ? pf->mark(st) : 0;
       if (pf) pf->span(2, e0, e1);
       if (counts) counts[0] += 1;
-      continue;
-    }
-    {
-      // block column 0 has nothing to subtract: only the diagonal tiles need a workgroup
-      const int T = (k == 0) ? 1 : ca.nt - k;
-      ca.tiles = T;
-      size_t e0 = pf ? pf->mark(st) : 0;
-      launch_update<true, false>(dcov, 8 * Pg * T, st, ca);
-      size_t e1 = pf ? pf->mark(st) : 0;
-      if (pf) pf->span(2, e0, e1);
-      if (counts) counts[0] += 1;
-    }
-    const int T2 = ca.nt - k - 1;
-    if (T2 > 0) {
-      size_t e0 = pf ? pf->mark(st) : 0;
-      hipLaunchKernelGGL(k_chol_trsm, dim3(8 * Pg * T2), dim3(256), 0, st, ca);
-      size_t e1 = pf ? pf->mark(st) : 0;
-      if (pf) pf->span(3, e0, e1);
-      if (counts) counts[1] += 1;
     }
   }
   return hipGetLastError();
@@ -876,37 +836,6 @@ inline void launch_flow(int dcov, int n_wg, hipStream_t st, const CholArgs& ca) 
     else hipLaunchKernelGGL((k_chol_flow<8, 0>), grid, block, 0, st, ca);
   }
 }
-// Work list of a plain dataflow sweep with early partial sums (CholArgs::items): per XCD, block column by block column —
-// diagonal tiles, then the sub-diagonal tiles particle-major (order 1) or tile-row-major (order 0) — and behind the last
-// column of every chunk the partial-sum items of the trailing tiles for that chunk.  Every item's producers precede it.
-struct FlowItem { int32_t x, y, z, w; };
-static int build_flow_list(int P, int nt, int order, int tb, int ch, std::vector<FlowItem>& out, int counts[8]) {
-  const int r0 = nt - tb, nch = r0 / ch;
-  size_t stride = 0;
-  std::vector<std::vector<FlowItem>> per(8);
-  for (int x = 0; x < 8; ++x) {
-    const int Pl = (P - x + 7) / 8;
-    auto& v = per[x];
-    for (int k = 0; k < nt; ++k) {
-      for (int pl = 0; pl < Pl; ++pl) v.push_back({0, pl, k, k});
-      if (order == 0) { for (int i = k + 1; i < nt; ++i) for (int pl = 0; pl < Pl; ++pl) v.push_back({1, pl, i, k}); }
-      else { for (int pl = 0; pl < Pl; ++pl) for (int i = k + 1; i < nt; ++i) v.push_back({1, pl, i, k}); }
-      if ((k + 1) % ch == 0 && (k + 1) / ch <= nch) {
-        const int c = (k + 1) / ch - 1;
-        // longest remaining K-loops first: the tiles of the last rows
-        for (int pl = 0; pl < Pl; ++pl)
-          for (int i = nt - 1; i >= r0; --i)
-            for (int kk = r0; kk <= i; ++kk) v.push_back({(i == kk ? 2 : 3) | (c << 8), pl, i, kk});
-      }
-    }
-    counts[x] = (int)v.size();
-    stride = std::max(stride, v.size());
-  }
-  out.assign(stride * 8, FlowItem{0, 0, 0, 0});
-  for (int x = 0; x < 8; ++x) std::copy(per[x].begin(), per[x].end(), out.begin() + (size_t)x * stride);
-  return (int)stride;
-}
-
 // Medium populations — more particles than the right-looking schedule serves, fewer than fill the GPU with the tiles
 // of one block column — take the dataflow schedule.
 // Measured on MI355X (tools/gpu_flow_perf.py, profiles/r02_flow_perf.txt): it beats the per-column launches (right-looking,
@@ -921,7 +850,7 @@ constexpr long long FLOW_MIN_WORK = 2000;
 inline bool use_flow(const agp_ctx* c, int P, int nt, int nfac = 0) {
   if (nfac <= 0) nfac = nt;
   const double avg_tiles = nt - 0.5 * (nfac - 1);
-  return c->intrsm != 0 && (c->flow > 0 || (c->flow < 0 && P <= FLOW_MAX_PARTICLES && (double)P * avg_tiles <= 3400.0 &&
+  return (c->flow > 0 || (c->flow < 0 && P <= FLOW_MAX_PARTICLES && (double)P * avg_tiles <= 3400.0 &&
                                             (long long)P * nt * nt >= FLOW_MIN_WORK));
 }
 
@@ -930,6 +859,14 @@ inline bool use_flow(const agp_ctx* c, int P, int nt, int nfac = 0) {
 constexpr int SPLIT_DIAG_MIN_PARTICLES = 256;
 inline bool use_split_diag(const agp_ctx* c, int P) {
   return c->split_diag > 0 || (c->split_diag < 0 && P >= SPLIT_DIAG_MIN_PARTICLES);
+}
+
+// Predictive passes carry nt - nt1 extra tile rows through every block column of the training block (V = L^-1 K12): from ~100
+// particles on, the sub-diagonal tiles of a column fill the GPU several times over and the specialised split launches (the
+// headline's kernels, tiles evaluated in-kernel) beat the mixed launch although the diagonal launch itself is under-filled
+// (n=2048, m=4096, 128 particles: 58.8 -> see profiles/r04*_predict_kernel_stats.txt).
+inline bool pred_split(const agp_ctx* c, int P, int nt, int nt1) {
+  return c->split_diag != 0 && P >= 96 && (long long)P * (nt - nt1) >= 2048;
 }
 
 // Right-looking schedule (see run_factor): below this many particles the left-looking launches cannot fill the GPU.
@@ -946,12 +883,6 @@ struct GradOut {
 template <int MAXS>
 hipError_t launch_grad_contract(hipStream_t st, const GradArgs& ga, int ntiles, int P, size_t lds) {
   hipLaunchKernelGGL(k_grad_contract<MAXS>, dim3(ntiles, P), dim3(256), lds, st, ga);
-  return hipGetLastError();
-}
-
-template <int MAXS>
-hipError_t launch_grad_tiles(hipStream_t st, const GradArgs& ga, int ntiles, int P, size_t lds) {
-  hipLaunchKernelGGL(k_grad_tiles<MAXS>, dim3(ntiles, P), dim3(256), lds, st, ga);
   return hipGetLastError();
 }
 
@@ -1031,15 +962,15 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   std::vector<std::vector<int32_t>> pls;     // per-group particle orders of the gradient contraction
   pls.reserve(64);
   // (the log|dt|-table kernels exist for the in-kernel-solve factorisation launches, see launch_update)
-  const bool ge_tab = c->logdt_ok && c->intrsm != 0;
+  const bool ge_tab = c->logdt_ok;
   // (the schedule is chosen per call from P and n; chunked / multi-stream sub-batches re-check with their own size)
-  const bool flow_hint = n > 0 && c->flow_fuse && use_flow(c, P, (int)((n + NB - 1) / NB));
+  const bool flow_hint = n > 0 && use_flow(c, P, (int)((n + NB - 1) / NB));
   // value sweeps over the whole of a regular grid run on the sorted copy with lag tables (see agp_ctx::d_ts_s)
-  const bool lag = allow_lag && c->lag_enable && c->lag_ok && !go && n > 0 && n == c->n_max && c->intrsm != 0;
+  const bool lag = allow_lag && c->lag_enable && c->lag_ok && !go && n > 0 && n == c->n_max;
   // ... every other sweep over (a prefix of) a regular grid — annealing prefixes, gradient sweeps — keeps the caller's order and
   // reads the same leaves from RANK tables: |t_a - t_b| = |rank_a - rank_b| h in any order (cov_prologue)
   const int rank_units = (int)((c->n_max + 255) / 256);
-  bool lagr = !lag && allow_lag && c->lag_rank_enable && c->lag_enable && c->lag_ok && n > 0 && c->intrsm != 0 && c->n_max <= 4096;
+  bool lagr = !lag && allow_lag && c->lag_rank_enable && c->lag_enable && c->lag_ok && n > 0 && c->n_max <= 4096;
   int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint, lag || lagr, lagr ? rank_units : 1, lagr);
   if (rc) return rc;
   if (lagr) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_rank_sweeps; }
@@ -1048,10 +979,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   if (lag) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_sweeps; }
   // Gradient sweeps on a regular grid (any order of the points): particles whose kernel is a sum of stationary subtrees and
   // Linear leaves are contracted in the lag domain (k_kinv_tiles / k_lag_grad, agp_grad_kernel.hpp)
-  if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->grad_split && c->n_max <= LAGDOM_MAX_BINS) {
+  if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->n_max <= LAGDOM_MAX_BINS) {
     int64_t n_cov = 0;
     // (the transform has one length, 4096: below ~1000 points the K^-1 tiles are cheaper than n/2 transforms of that length)
-    const bool use_fft = c->grad_fft && c->d_fft_tw != nullptr && 2 * c->n_max <= FFT_N && n > c->grad_fft_min_n;      // (n: this sweep's prefix — the number of transforms)
+    const bool use_fft = c->grad_fft && c->d_fft_tw != nullptr && 2 * c->n_max <= FFT_N && n > GRAD_FFT_MIN_N;      // (n: this sweep's prefix — the number of transforms)
     for (int q = 0; q < P; ++q) {
       GProgHdr& g = bt.ghdr[q];
       if (g.n_cp > 0 || g.n_ops > 64) continue;
@@ -1083,7 +1014,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   std::vector<int32_t> src_slot, i0v;
   int n_hit = 0;
   std::unique_lock<std::mutex> store_lk;       // held to the end of the sweep when anything is resident
-  if (go && n > 0 && c->factor_cache && c->intrsm && c->store.n_slots > 0) {
+  if (go && n > 0 && c->factor_cache && c->store.n_slots > 0) {
     std::vector<std::string> keys((size_t)P);
     for (int p = 0; p < P; ++p)
       keys[p] = particle_key(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p], prm_off[p + 1] - prm_off[p], noise[p]);
@@ -1117,14 +1048,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     const int n_pad = round_up(n, NB);
     const int nt = n_pad / NB;
     const int ntiles = nt * (nt + 1) / 2;
-    // Per-particle skew: with a stride of ntiles * 128 KiB every particle's tile (i,j) starts at the same address modulo
-    // 128 KiB, and the workgroups of a launch — one per particle, all reading the same tile offset at the same time —
-    // would queue on the same HBM channels.  stride_pad doubles shift each particle's matrix (env AGP_STRIDE_PAD).
-    const long long strideA = (long long)ntiles * NB2 + c->stride_pad;
+    const long long strideA = (long long)ntiles * NB2;
     const int64_t bytes_pp = strideA * 8 * (go ? 2 : 1);      // + Z = L^-T for the gradient
     int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(P, ws_limit_bytes(c) / bytes_pp));
     // (the dataflow schedule has several block columns of a particle in flight: every column keeps its inverse blocks)
-    const int wsteps = (go || (c->intrsm && c->flow != 0)) ? nt : 1;
+    const int wsteps = (go || c->flow != 0) ? nt : 1;
     const int gstride = go ? bt.g_max_prm + 1 : 0;
 
     HIPCHK(c, s->A.ensure((size_t)strideA * 8 * chunk));
@@ -1147,7 +1075,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
     HIPCHK(c, s->info.ensure(sizeof(int) * (size_t)chunk));
     HIPCHK(c, s->ready.ensure(sizeof(int) * (size_t)chunk));
-    if (c->intrsm && c->flow != 0) {
+    if (c->flow != 0) {
       HIPCHK(c, s->tflag.ensure(sizeof(int) * (size_t)chunk * ntiles));
       HIPCHK(c, s->flowq.ensure(sizeof(int) * 8 * 8));
     }
@@ -1233,28 +1161,12 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     size_t ev_h2d = pf.mark();
     pf.span(7, ev_begin, ev_h2d);
 
-    // Sub-batches of a chunk run on separate streams so that the tail of one sub-batch's launch
-    // (few workgroups left, serial diagonal factorisations) is filled by another sub-batch's bulk.
-    const int S = std::max(1, std::min(c->n_streams, (P + 63) / 64));
-    if (S > 1) {
-      while ((int)s->sub.size() < S - 1) {
-        hipStream_t q; HIPCHK(c, hipStreamCreateWithFlags(&q, hipStreamNonBlocking)); s->sub.push_back(q);
-      }
-      while ((int)s->sub_ev.size() < S) {
-        hipEvent_t e; HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); s->sub_ev.push_back(e);
-      }
-    }
     for (int p0 = 0; p0 < P; p0 += chunk) {
       const int Pc = std::min(chunk, P - p0);
-      if (S > 1) {
-        HIPCHK(c, hipEventRecord(s->sub_ev[0], st));
-        for (int g = 1; g < S; ++g) HIPCHK(c, hipStreamWaitEvent(s->sub[g - 1], s->sub_ev[0], 0));
-      }
-      for (int g = 0; g < S; ++g) {
-        const int g0 = (int)((long long)Pc * g / S), g1 = (int)((long long)Pc * (g + 1) / S);
-        const int Pg = g1 - g0;
-        if (Pg <= 0) continue;
-        hipStream_t q = (g == 0) ? st : s->sub[g - 1];
+      {
+        // (one group per chunk; sub-batches on several streams were measured: no gain, removed)
+        const int g0 = 0, Pg = Pc;
+        hipStream_t q = st;
         hipLaunchKernelGGL(k_init_vec, dim3((n_pad + 255) / 256, Pg), dim3(256), 0, q,
                            s->vec.as<double>() + (size_t)g0 * n_pad, n_pad, Pg, lag ? c->d_xs_s : c->d_xs, (const double*)nullptr, (int)n,
                            s->info.as<int>() + g0, s->ready.as<int>() + g0);
@@ -1282,13 +1194,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         // where 136 tiles per particle absorb the cost instead of one workgroup per launch.
         const int nf = std::max(0, std::min(Pg, bt.n_fused - p0 - g0));
         const int dcov = nf > 0 ? bt.max_depth_fused : 0;
-        const bool intrsm = c->intrsm != 0;
         size_t e0 = pf.mark(q);
-        if (!intrsm) {      // separate solve launches: k_chol_trsm(0) reads the sub-diagonal tiles of column 0
-          cv.col0_only = 1; cv.p_off = 0;
-          HIPCHK(c, launch_cov(q, cv, nt - 1, nf, bt.max_cp_fused, bt.max_depth_fused));
-        }
-        cv.col0_only = 0; cv.p_off = nf;
+        cv.p_off = nf;
         HIPCHK(c, launch_cov(q, cv, ntiles, Pg - nf, bt.max_cp, bt.max_depth));
         size_t e1 = pf.mark(q);
         pf.span(1, e0, e1);
@@ -1310,40 +1217,17 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           // dataflow schedule: every tile of the batch in ONE launch of persistent workgroups (2 per CU)
           const int ntri = nt * (nt + 1) / 2;
           ca.tflag = s->tflag.as<int>() + (size_t)g0 * ntri; ca.ntri = ntri;
-          ca.qnext = s->flowq.as<int>() + 8 * g; ca.flow_order = c->flow_order;
+          ca.qnext = s->flowq.as<int>();
           {
             size_t items = 0;
             for (int x = 0; x < 8; ++x) items += (size_t)((Pg - x + 7) / 8) * ntri;
-            ca.trace = (c->d_flow_trace && items <= c->flow_trace_items && S == 1 && P <= chunk) ? c->d_flow_trace : nullptr;
+            ca.trace = (c->d_flow_trace && items <= c->flow_trace_items && P <= chunk) ? c->d_flow_trace : nullptr;
           }
           if (n_hit > 0)
             hipLaunchKernelGGL(k_init_flow_flags, dim3((ntri + 255) / 256, Pg), dim3(256), 0, q, ca.tflag, ntri, ntri, (const int*)nullptr, ca.i0);
           else
             HIPCHK(c, hipMemsetAsync(ca.tflag, 0, sizeof(int) * (size_t)Pg * ntri, q));
           HIPCHK(c, hipMemsetAsync(ca.qnext, 0, sizeof(int) * 8, q));
-          // early partial sums for the trailing tile rows (plain sweeps, one stream, one chunk)
-          const int tb = c->flow_part_tb, chw = c->flow_part_ch;
-          if (n_hit == 0 && S == 1 && P <= chunk && tb > 0 && nt - tb >= chw) {
-            const int nch = (nt - tb) / chw, ptiles = tb * (tb + 1) / 2;
-            const long long key = (((((long long)Pg * 4096 + nt) * 4 + c->flow_order) * 64 + tb) * 64 + chw);
-            if (s->flowlist_key != key) {
-              std::vector<FlowItem> list; int counts[8];
-              const int stride = build_flow_list(Pg, nt, c->flow_order == 0 ? 0 : 1, tb, chw, list, counts);
-              HIPCHK(c, s->flowlist.ensure(sizeof(FlowItem) * list.size() + 64));
-              HIPCHK(c, hipStreamSynchronize(q));            // (an earlier sweep may still read the old list)
-              HIPCHK(c, hipMemcpy(static_cast<char*>(s->flowlist.p) + 64, list.data(), sizeof(FlowItem) * list.size(), hipMemcpyHostToDevice));
-              HIPCHK(c, hipMemcpy(s->flowlist.p, counts, sizeof(int) * 8, hipMemcpyHostToDevice));
-              s->flowlist_key = key; s->flowlist_stride = stride;
-            }
-            HIPCHK(c, s->flowpflag.ensure(sizeof(int) * (size_t)Pg * ptiles));
-            HIPCHK(c, hipMemsetAsync(s->flowpflag.p, 0, sizeof(int) * (size_t)Pg * ptiles, q));
-            ca.n_items = s->flowlist.as<int>();
-            ca.items = reinterpret_cast<const int4*>(static_cast<char*>(s->flowlist.p) + 64);
-            ca.items_stride = s->flowlist_stride;
-            ca.pflag = s->flowpflag.as<int>();
-            ca.part_tiles = ptiles; ca.part_tb = tb; ca.part_ch = chw; ca.part_nch = nch;
-            if (ca.trace && (size_t)8 * s->flowlist_stride > c->flow_trace_items) ca.trace = nullptr;
-          }
           size_t f0 = pf.mark(q);
           launch_flow(dcov, 2 * c->n_cu, q, ca);
           size_t f1 = pf.mark(q);
@@ -1353,8 +1237,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         } else if (n_hit > 0) {
           HIPCHK(c, run_factor_extend(q, ca, dcov, use_split_diag(c, ca.P), i0min));
         } else {
-          HIPCHK(c, run_factor(q, ca, nt, dcov, intrsm, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr, use_split_diag(c, ca.P),
-                               use_right_looking(c, ca.P), c->hybrid_blocks));
+          HIPCHK(c, run_factor(q, ca, nt, dcov, c->profiling ? &pf : nullptr, c->profiling ? &tacc[5] : nullptr, use_split_diag(c, ca.P),
+                               use_right_looking(c, ca.P), HYBRID_BLOCKS));
         }
 
         size_t e2 = pf.mark(q);
@@ -1381,17 +1265,9 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           }
           const int Pg8 = (Pg + 7) / 8;
           const size_t gm0 = pf.mark(q);
-          if (c->trtri_chain) {
-            hipLaunchKernelGGL(k_trtri_chain, dim3(8 * Pg8 * nt), dim3(256), 0, q, ga);
-          } else {
-            for (int i = 0; i < nt; ++i) {
-              ga.step = i;
-              hipLaunchKernelGGL(k_trtri_step, dim3(8 * Pg8 * (i + 1)), dim3(256), 0, q, ga);
-            }
-          }
+          hipLaunchKernelGGL(k_trtri_chain, dim3(8 * Pg8 * nt), dim3(256), 0, q, ga);      // (forms alpha = Z beta as well)
           const size_t gm1 = pf.mark(q);
           pf.span(8, gm0, gm1);
-          if (!c->trtri_chain) hipLaunchKernelGGL(k_alpha, dim3(nt, Pg), dim3(256), 0, q, ga);      // (the chain kernel forms alpha itself)
           size_t gm2 = pf.mark(q);
           pf.span(11, gm1, gm2);
           // One contraction launch per group, largest trees first (their workgroups run longest); the 16-node
@@ -1413,12 +1289,12 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           ga.plist = d_pl;
           const size_t lds = sizeof(double) * std::max<size_t>(2 * U_SLAB, 256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes);
           const int Pall = ga.P;
-          if (c->grad_split) {
+          {
             const bool any_fft = Pn < Pg && (bt.ghdr[p0 + g0 + pl[Pn]].flags & GFLAG_LAGFFT) != 0;      // (all lag-domain particles or none)
             // Two independent branches behind the inverse chain: [power spectra of Z -> lag-domain gradients] of the lag-domain
             // particles and [K^-1 tiles -> element-wise contraction] of the others.  On separate streams a CU holds one workgroup
             // of each (256 registers x 4 waves each): LDS / vector transforms beside MFMA tile products.
-            const bool fork = c->grad_fork != 0;
+            const bool fork = true;
             hipStream_t qs[4] = {q, q, q, q};
             if (fork) {
               for (int i2 = 0; i2 < 3; ++i2) if (!s->gq[i2]) HIPCHK(c, hipStreamCreateWithFlags(&s->gq[i2], hipStreamNonBlocking));
@@ -1445,7 +1321,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             int n_big = 0, n_mid = 0;
             for (int r = 0; r < Pn; ++r) {
               const int no = bt.ghdr[p0 + g0 + pl[r]].n_ops;
-              n_big += no > 16; n_mid += (no <= 16 && (no > LDS_TAPE_NODES || !c->grad_lds_tape));
+              n_big += no > 16; n_mid += (no <= 16 && no > LDS_TAPE_NODES);
             }
             const int n_small = Pn - n_big - n_mid;
             // The launch classes are independent and each ends on a few long-running workgroups (the largest trees; the
@@ -1474,10 +1350,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             }
             if (fork)
               for (int i2 = 0; i2 < 3; ++i2) { HIPCHK(c, hipEventRecord(s->gq_ev[i2], s->gq[i2])); HIPCHK(c, hipStreamWaitEvent(q, s->gq_ev[i2], 0)); }
-            (void)max_nodes;
-          } else {
-            if (max_nodes <= 16) HIPCHK(c, launch_grad_tiles<16>(q, ga, ntiles, Pg, lds));
-            else HIPCHK(c, launch_grad_tiles<64>(q, ga, ntiles, Pg, lds));
+            (void)max_nodes; (void)lds;
           }
           ga.P = Pall;
           const size_t gm3 = pf.mark(q);
@@ -1485,10 +1358,6 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           hipLaunchKernelGGL(k_grad_finish, dim3(Pg), dim3(64), 0, q, ga);
           pf.span(11, gm3, pf.mark(q));
           HIPCHK(c, hipGetLastError());
-        }
-        if (g > 0) {
-          HIPCHK(c, hipEventRecord(s->sub_ev[g], q));
-          HIPCHK(c, hipStreamWaitEvent(st, s->sub_ev[g], 0));
         }
       }
     }
@@ -1611,8 +1480,7 @@ int agp_init(agp_ctx** out, int device_id) {
     // raise the dynamic-LDS ceiling of the table-carrying kernels once (launches then never touch function attributes)
     const void* fns[] = {reinterpret_cast<const void*>(&k_cov_tiles<4>), reinterpret_cast<const void*>(&k_cov_tiles<8>),
                          reinterpret_cast<const void*>(&k_grad_contract<16>), reinterpret_cast<const void*>(&k_grad_contract<64>),
-                         reinterpret_cast<const void*>(&k_grad_contract<0>), reinterpret_cast<const void*>(&k_lag_grad),
-                         reinterpret_cast<const void*>(&k_grad_tiles<16>), reinterpret_cast<const void*>(&k_grad_tiles<64>)};
+                         reinterpret_cast<const void*>(&k_grad_contract<0>), reinterpret_cast<const void*>(&k_lag_grad)};
     for (const void* f : fns) {
       hipFuncAttributes fa;
       hipError_t ea = hipFuncGetAttributes(&fa, f);
@@ -1631,36 +1499,18 @@ int agp_init(agp_ctx** out, int device_id) {
   c->total_mem = free_b ? free_b : tot_b;
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
-  if (const char* e = getenv("AGP_TRTRI_CHAIN")) c->trtri_chain = atoi(e) != 0;
   if (const char* e = getenv("AGP_SPLIT_DIAG")) c->split_diag = atoi(e);
   if (const char* e = getenv("AGP_GE_TABLE")) c->ge_table = atoi(e) != 0;
   if (const char* e = getenv("AGP_LAG")) c->lag_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_LAG_RANK")) c->lag_rank_enable = atoi(e) != 0;
-  if (const char* e = getenv("AGP_LAG_STORE")) c->lag_store_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LAGDOM")) c->grad_lagdom = atoi(e) != 0;
-  if (const char* e = getenv("AGP_GRAD_FORK")) c->grad_fork = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_FFT")) c->grad_fft = atoi(e) != 0;
-  if (const char* e = getenv("AGP_GRAD_FFT_MIN_N")) c->grad_fft_min_n = atoi(e);
   if (const char* e = getenv("AGP_RIGHT_LOOKING")) c->right_looking = atoi(e);
-  if (const char* e = getenv("AGP_HYBRID_BLOCKS")) c->hybrid_blocks = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
-  if (const char* e = getenv("AGP_FUSE_MAX_US")) { c->fuse_max_us = atof(e); c->flow_fuse_max_us = std::min(c->flow_fuse_max_us, c->fuse_max_us); }
-  if (const char* e = getenv("AGP_FLOW_FUSE_MAX_US")) c->flow_fuse_max_us = atof(e);
-  if (const char* e = getenv("AGP_LAG_FUSE_MAX_US")) c->lag_fuse_max_us = atof(e);
-  if (const char* e = getenv("AGP_FLOW_LAG_FUSE_MAX_US")) c->flow_lag_fuse_max_us = atof(e);
-  if (const char* e = getenv("AGP_GRAD_SPLIT")) c->grad_split = atoi(e) != 0;
-  if (const char* e = getenv("AGP_GRAD_LDS_TAPE")) c->grad_lds_tape = atoi(e) != 0;
   if (const char* e = getenv("AGP_PREDICT_REUSE")) c->predict_reuse = atoi(e) != 0;
   if (const char* e = getenv("AGP_FACTOR_CACHE")) c->factor_cache = atoi(e) != 0;
-  if (const char* e = getenv("AGP_INTRSM")) c->intrsm = atoi(e) != 0;
   if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));
-  if (const char* e = getenv("AGP_STREAMS")) c->n_streams = std::max(1, std::min(8, atoi(e)));
-  if (const char* e = getenv("AGP_STRIDE_PAD")) c->stride_pad = std::max(0, atoi(e)) & ~1;
   if (const char* e = getenv("AGP_FLOW")) c->flow = atoi(e);
-  if (const char* e = getenv("AGP_FLOW_ORDER")) c->flow_order = std::max(0, std::min(2, atoi(e)));
-  if (const char* e = getenv("AGP_FLOW_FUSE")) c->flow_fuse = atoi(e) != 0;
-  if (const char* e = getenv("AGP_FLOW_PART_TB")) c->flow_part_tb = std::max(0, std::min(16, atoi(e)));
-  if (const char* e = getenv("AGP_FLOW_PART_CH")) c->flow_part_ch = std::max(1, std::min(64, atoi(e)));
   if (const char* e = getenv("AGP_EXTEND_FRAC")) c->store.max_frac = std::max(0.0, std::min(0.8, atof(e)));
   *out = c;
   return AGP_OK;
@@ -1814,9 +1664,10 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
       }
       c->lag_ok = true;
       c->h_ts_sorted = tss;
+      c->h_rank.assign(rank.begin(), rank.begin() + n_max);
     }
   }
-  if (!c->lag_ok) c->h_ts_sorted.clear();
+  if (!c->lag_ok) { c->h_ts_sorted.clear(); c->h_rank.clear(); }
   {
     // The store's sweeps read rank tables on a regular grid and the general evaluator otherwise; an extension agrees bit for bit
     // with a from-scratch sweep of the same entry only while resident rows and new rows are evaluated the same way.  After an
@@ -1991,7 +1842,7 @@ static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
     if (want_grad) return agp_logpdf_grad_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_g, out_gn, out_info);
     // value calls go through the factor store: the reweight on a longer prefix becomes an extension sweep, the gradient
     // call that follows at the same parameters (HMC leapfrog) and a predictive call find the factor resident
-    return (c->factor_cache && c->intrsm) ? extend_impl(c, n, Pn, oo, o, po, q, nz, out_lp, out_info)
+    return c->factor_cache ? extend_impl(c, n, Pn, oo, o, po, q, nz, out_lp, out_info)
                                           : agp_logpdf_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_info);
   };
   int rc = sweep(batch[0]->n, P, op_off.data(), ops.data(), prm_off.data(), prm.data(), noise.data(), lp.data(),
@@ -2134,18 +1985,62 @@ namespace {
 // points and an extra diagonal term.  `keys` (nullable; per particle, caller order) are the factor-store keys of the
 // particles: one whose factor of exactly this prefix is resident (an extension sweep scored it: the per-step callback of
 // the streaming workload, scripts/online.jl:43, predicts right after the reweight) skips K11 and its factorisation.
+// Query points on the series' own lattice.  In every use of the reference the query set is `train + test + future` at the
+// data's cadence (scripts/online.jl:41-43: ds_query = vcat(model.ds, ds_next, ds_test); src/GP.jl:743 evaluates the kernel on
+// [ts; ts_pred]): on a regular grid every joint point then has an integer RANK round((t - t_0) / h) — duplicates of training
+// times share one, future points exceed n_max - 1, earlier ones are negative — and |t_a - t_b| = |rank_a - rank_b| h for every
+// pair of the joint set: the stationary subtrees of the predictive pass read the same rank tables as the factor store's sweeps,
+// extended to max rank - min rank + 1 lags.  One off-lattice point (same tolerance as agp_set_data) -> general path.
+struct PredLattice {
+  bool on = false;
+  int R = 0, rank_units = 1;
+  std::vector<int32_t> rank;      // joint padded layout [ts(1:n), pad, ts_pred, pad], shifted so that the smallest rank is 0
+  std::vector<double> tl;         // time of lag g: t_sorted[g] inside the data (the store's tables), t_0 + g h beyond
+};
+constexpr int PRED_MAX_LAGS = 4096;     // (LDS capacity of the fused evaluators, as for the resident series: n_max <= 4096)
+
+void predict_lattice(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, PredLattice& pl) {
+  pl.on = false;
+  if (!(c->lag_ok && c->lag_enable && c->lag_rank_enable) || n <= 0 || m <= 0 || c->h_rank.empty()) return;
+  const double t0 = c->h_ts_sorted.front(), h = c->grid_h;
+  const int n1_pad = round_up(n, NB), m_pad = round_up(m, NB);
+  std::vector<long long> gq((size_t)m);
+  long long gmin = 0, gmax = (long long)c->n_max - 1;
+  for (int64_t j = 0; j < m; ++j) {
+    const double t = ts_pred[j];
+    const double gf = std::nearbyint((t - t0) / h);
+    if (!std::isfinite(gf) || std::fabs(gf) > 1e6) return;
+    const double tol = c->lag_tol_h * h - 2.220446049250313e-16 * std::max(std::fabs(t), std::max(std::fabs(t0), std::fabs(c->h_ts_sorted.back())));
+    if (!(tol > 0.0) || std::fabs(t - (t0 + gf * h)) > tol) return;
+    gq[(size_t)j] = (long long)gf;
+    gmin = std::min(gmin, gq[(size_t)j]); gmax = std::max(gmax, gq[(size_t)j]);
+  }
+  const long long R = gmax - gmin + 1;
+  if (R > PRED_MAX_LAGS) return;
+  pl.R = (int)R; pl.rank_units = (int)((R + 255) / 256);
+  pl.rank.assign((size_t)n1_pad + m_pad, 0);
+  for (int64_t i = 0; i < n; ++i) pl.rank[(size_t)i] = (int32_t)(c->h_rank[(size_t)i] - gmin);
+  for (int64_t j = 0; j < m; ++j) pl.rank[(size_t)n1_pad + j] = (int32_t)(gq[(size_t)j] - gmin);
+  pl.tl.assign((size_t)pl.rank_units * 256, 0.0);
+  for (long long g = 0; g < (long long)pl.tl.size(); ++g)
+    pl.tl[(size_t)g] = g < c->n_max ? c->h_ts_sorted[(size_t)g] : t0 + (double)g * h;
+  pl.on = true;
+}
+
 int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P, Batch& bt,
                  const double* noise, const double* noise_pred, const uint8_t* pred_code, const double* diag_add,
                  const double* mean_train, const double* mean_pred, double* out_mean, double* out_var,
-                 double* out_cov, int32_t* out_info, const std::vector<std::string>* keys = nullptr) {
+                 double* out_cov, int32_t* out_info, const std::vector<std::string>* keys = nullptr,
+                 const PredLattice* pl = nullptr) {
   const int n1_pad = round_up(n, NB);           // 0 when n == 0
   const int m_pad = round_up(m, NB);
+  const bool lagr = pl != nullptr && pl->on;
   const int nt1 = n1_pad / NB, nt2 = m_pad / NB, nt = nt1 + nt2;
   // resident factors (sorted order): store slot per particle, first tile row to compute
   std::vector<int32_t> src_slot, i0v;
   int n_hit = 0;
   std::unique_lock<std::mutex> store_lk;
-  if (keys && c->predict_reuse && c->intrsm && nt1 > 0 && !mean_train && !pred_code) {
+  if (keys && c->predict_reuse && nt1 > 0 && !mean_train && !pred_code) {
     n_hit = store_lookup(c, *keys, bt.order, P, n, nt1, src_slot, i0v, store_lk);
     std::lock_guard<std::mutex> g(c->mu);
     c->pred_reused += n_hit; c->pred_factored += P - n_hit;
@@ -2224,6 +2119,40 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     d_src = d; d_i0 = d + P;
   }
 
+  if (lagr) {
+    // ranks of the joint points, lag times, table programs; one table of R lags per stationary subtree of the batch
+    auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_tprm = al16(sizeof(LagTabHdr) * bt.thdr.size());
+    const size_t o_tops = al16(o_tprm + sizeof(double) * bt.tprm.size());
+    const size_t prog_bytes = al16(o_tops + bt.tops.size() + 4);
+    std::vector<char> hp(prog_bytes, 0);
+    if (!bt.thdr.empty()) {
+      std::memcpy(hp.data(), bt.thdr.data(), sizeof(LagTabHdr) * bt.thdr.size());
+      std::memcpy(hp.data() + o_tprm, bt.tprm.data(), sizeof(double) * bt.tprm.size());
+      std::memcpy(hp.data() + o_tops, bt.tops.data(), bt.tops.size());
+    }
+    HIPCHK(c, s->pl_prog.ensure(prog_bytes));
+    HIPCHK(c, s->pl_rank.ensure(sizeof(int32_t) * pl->rank.size()));
+    HIPCHK(c, s->pl_tl.ensure(sizeof(double) * pl->tl.size()));
+    HIPCHK(c, hipMemcpyAsync(s->pl_prog.p, hp.data(), prog_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(s->pl_rank.p, pl->rank.data(), sizeof(int32_t) * pl->rank.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(s->pl_tl.p, pl->tl.data(), sizeof(double) * pl->tl.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));      // `hp` is a local
+    if (bt.n_lag_tables > 0) {
+      HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * pl->rank_units * 256));
+      LagArgs la = {};
+      la.tt = s->pl_tl.as<double>(); la.thdr = s->pl_prog.as<LagTabHdr>();
+      la.tprm = reinterpret_cast<const double*>(static_cast<char*>(s->pl_prog.p) + o_tprm);
+      la.tops = reinterpret_cast<const uint8_t*>(static_cast<char*>(s->pl_prog.p) + o_tops);
+      la.n_tables = bt.n_lag_tables; la.tab = s->lagtab.as<double>();
+      la.nt = 2 * pl->rank_units; la.full = 1; la.stride = pl->rank_units * 256;      // (every entry of the table is live)
+      hipLaunchKernelGGL(k_lag_tables, dim3(pl->rank_units, bt.n_lag_tables), dim3(256), 0, st, la);
+      HIPCHK(c, hipGetLastError());
+    }
+    std::lock_guard<std::mutex> g(c->mu);
+    ++c->n_lag_pred;
+  }
+
   std::vector<double> h_mean, h_var;
   for (int p0 = 0; p0 < P; p0 += chunk) {
     const int Pc = std::min(chunk, P - p0);
@@ -2247,14 +2176,10 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     cv.hdr = s->hdr.as<ProgHdr>() + p0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
     cv.noise = s->noise.as<double>() + p0; cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = Pc;
     cv.code = pred_code ? s->code.as<uint8_t>() : nullptr;
+    if (lagr) { cv.lagtab = s->lagtab.as<double>(); cv.lagr = s->pl_rank.as<int32_t>(); cv.lag_stride = pl->rank_units * 256; }
     const int nf = std::max(0, std::min(Pc, bt.n_fused - p0));
     const int dcov = nf > 0 ? bt.max_depth_fused : 0;
-    const bool intrsm = c->intrsm != 0;
-    if (!intrsm) {
-      cv.col0_only = 1; cv.p_off = 0;
-      HIPCHK(c, launch_cov(st, cv, nt1 > 0 ? nt - 1 : 0, nf, bt.max_cp_fused, bt.max_depth_fused));
-    }
-    cv.col0_only = 0; cv.p_off = nf;
+    cv.p_off = nf;
     cv.skip_pred_offdiag = out_cov ? 0 : 1;
     cv.i0 = n_hit > 0 ? d_i0 + p0 : nullptr;
     HIPCHK(c, launch_cov(st, cv, ntiles, Pc - nf, bt.max_cp, bt.max_depth));
@@ -2264,6 +2189,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     ca.vec = s->vec.as<double>(); ca.ldv = ntot; ca.partial = s->partial.as<double>();
     ca.info = s->info.as<int>() + p0; ca.P = Pc; ca.nt = nt; ca.k = 0; ca.nt1 = nt1;
     set_cov(ca, cv);
+    ca.lag = lagr ? 1 : 0;
     ca.n_fused = nf;
     ca.ready = s->ready.as<int>() + p0;
     if (n_hit > 0) { ca.i0 = d_i0 + p0; ca.wsteps = nt1; }      // panel solves of the prediction rows read every column's inverse blocks
@@ -2272,7 +2198,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       const int ntri = nt * (nt + 1) / 2;
       HIPCHK(c, s->tflag.ensure(sizeof(int) * (size_t)Pc * ntri));
       HIPCHK(c, s->flowq.ensure(sizeof(int) * 8 * 8));
-      ca.tflag = s->tflag.as<int>(); ca.ntri = ntri; ca.qnext = s->flowq.as<int>(); ca.flow_order = c->flow_order;
+      ca.tflag = s->tflag.as<int>(); ca.ntri = ntri; ca.qnext = s->flowq.as<int>();
       ca.wsteps = nt1;
       if (n_hit > 0)
         hipLaunchKernelGGL(k_init_flow_flags, dim3((ntri + 255) / 256, Pc), dim3(256), 0, st, ca.tflag, ntri, ntri, (const int*)nullptr, ca.i0);
@@ -2285,9 +2211,9 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       // per-column launches restricted to the rows some particle still has to compute
       int i0min = nt1;
       for (int q = 0; q < Pc; ++q) i0min = std::min(i0min, (int)i0v[(size_t)p0 + q]);
-      HIPCHK(c, run_factor_extend(st, ca, dcov, use_split_diag(c, ca.P), i0min, nt1));
+      HIPCHK(c, run_factor_extend(st, ca, dcov, use_split_diag(c, ca.P) || pred_split(c, ca.P, nt, nt1), i0min, nt1));
     } else {
-      HIPCHK(c, run_factor(st, ca, nt1, dcov, intrsm, nullptr, nullptr, use_split_diag(c, ca.P)));
+      HIPCHK(c, run_factor(st, ca, nt1, dcov, nullptr, nullptr, use_split_diag(c, ca.P) || pred_split(c, ca.P, nt, nt1)));
     }
     {
       // Schur complement of the prediction block + (-V^T alpha); with nt1 == 0 this just
@@ -2297,7 +2223,16 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       ca.schur_diag_only = out_cov ? 0 : 1;
       const int T = out_cov ? nt2 * (nt2 + 1) / 2 : nt2;
       const int Pg = (Pc + 7) / 8;
-      launch_update<false, false>(dcov, 8 * Pg * T, st, ca);
+      int dcov_s = dcov;
+      if (lagr && nf > 0) {
+        // (the Schur kernel has no table-reading instantiation: the prediction block's tiles of the particles that evaluated
+        // their other tiles in-kernel come from k_cov_tiles, which reads the rank tables in place)
+        CovArgs cp = cv;
+        cp.p_off = 0; cp.pred_only = 1; cp.i0 = nullptr;
+        HIPCHK(c, launch_cov(st, cp, ntiles, nf, bt.max_cp, bt.max_depth));
+        ca.n_fused = 0; dcov_s = 0;
+      }
+      launch_update<false, false>(dcov_s, 8 * Pg * T, st, ca);
     }
     PredArgs pa = {};
     pa.A = s->A.as<double>(); pa.strideA = strideA; pa.vec = s->vec.as<double>(); pa.ldv = ntot;
@@ -2385,18 +2320,22 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   }
   const int U = (int)uniq.size();
   // (a store that holds nothing is not consulted: no key strings are built)
-  const bool want_keys = c->predict_reuse && c->intrsm && n > 0 && !mean_train && c->store.n_slots > 0;
+  const bool want_keys = c->predict_reuse && n > 0 && !mean_train && c->store.n_slots > 0;
+  PredLattice pl;
+  predict_lattice(c, n, ts_pred, m, pl);
   if (U == 0 || U == P) {
     Batch bt;
-    const bool fh = c->flow_fuse && n > 0 && use_flow(c, P, (int)((n + NB - 1) / NB + (m + NB - 1) / NB), (int)((n + NB - 1) / NB));
-    int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, false, false, fh, fh);
+    const int nt1_ = (int)((n + NB - 1) / NB), nt_ = nt1_ + (int)((m + NB - 1) / NB);
+    const bool ff = n > 0 && use_flow(c, P, nt_, nt1_);
+    const bool fh = ff || (n > 0 && pred_split(c, P, nt_, nt1_));
+    int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, false, false, fh, ff, pl.on, pl.on ? pl.rank_units : 1, pl.on);
     if (rc) return rc;
     std::vector<std::string> keys;
     if (want_keys)
       for (int p = 0; p < P; ++p)
         keys.push_back(particle_key(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p], prm_off[p + 1] - prm_off[p], noise[p]));
     return predict_core(c, n, ts_pred, m, P, bt, noise, noise_pred, nullptr, nullptr, mean_train, mean_pred, out_mean,
-                        out_var, out_cov, out_info, want_keys ? &keys : nullptr);
+                        out_var, out_cov, out_info, want_keys ? &keys : nullptr, &pl);
   }
   std::vector<int32_t> uo(U + 1, 0), up(U + 1, 0), uinfo(U, 0);
   std::vector<uint8_t> uops; std::vector<double> uprm, unoise(U), unp(noise_pred ? U : 0);
@@ -2411,15 +2350,17 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   if (uprm.empty()) uprm.push_back(0.0);
   std::vector<double> umean((size_t)U * m), uvar((size_t)U * m), ucov(out_cov ? (size_t)U * m * m : 0);
   Batch bt;
-  const bool fh = c->flow_fuse && n > 0 && use_flow(c, U, (int)((n + NB - 1) / NB + (m + NB - 1) / NB), (int)((n + NB - 1) / NB));
-  int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, false, fh, fh);
+  const int nt1_ = (int)((n + NB - 1) / NB), nt_ = nt1_ + (int)((m + NB - 1) / NB);
+  const bool ff = n > 0 && use_flow(c, U, nt_, nt1_);
+  const bool fh = ff || (n > 0 && pred_split(c, U, nt_, nt1_));
+  int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, false, fh, ff, pl.on, pl.on ? pl.rank_units : 1, pl.on);
   if (rc) return rc;
   std::vector<std::string> keys;
   if (want_keys)
     for (int u = 0; u < U; ++u)
       keys.push_back(particle_key(uops.data() + uo[u], uo[u + 1] - uo[u], uprm.data() + up[u], up[u + 1] - up[u], unoise[u]));
   rc = predict_core(c, n, ts_pred, m, U, bt, unoise.data(), noise_pred ? unp.data() : nullptr, nullptr, nullptr, mean_train,
-                    mean_pred, umean.data(), uvar.data(), out_cov ? ucov.data() : nullptr, uinfo.data(), want_keys ? &keys : nullptr);
+                    mean_pred, umean.data(), uvar.data(), out_cov ? ucov.data() : nullptr, uinfo.data(), want_keys ? &keys : nullptr, &pl);
   if (rc) return rc;
   for (int p = 0; p < P; ++p) {
     const size_t u = (size_t)rep[p];
@@ -2517,7 +2458,7 @@ int agp_cov_matrix(agp_ctx* c, const double* ts, int64_t n, const uint8_t* ops, 
   cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
   cv.hdr = s->hdr.as<ProgHdr>(); cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
   cv.noise = s->noise.as<double>(); cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = 1;
-  cv.col0_only = 0; cv.p_off = 0;
+  cv.p_off = 0;
   HIPCHK(c, launch_cov(st, cv, ntiles, 1, bt.max_cp, bt.max_depth));
   const long long nel = (long long)n * n;
   hipLaunchKernelGGL(k_unpack_dense, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, s->A.as<double>(),
@@ -2557,7 +2498,7 @@ int agp_debug_cholesky(agp_ctx* c, const double* K, int64_t n, double* out_L, in
   ca.ldv = n_pad; ca.partial = s->partial.as<double>(); ca.info = s->info.as<int>(); ca.P = 1; ca.nt = nt;
   ca.k = 0; ca.nt1 = nt;
   ca.tt = nullptr; ca.hdr = nullptr; ca.ops = nullptr; ca.prm = nullptr; ca.noise = nullptr; ca.n1 = ca.n1_pad = ca.m2 = 0; ca.n_fused = 0; ca.ready = s->ready.as<int>();
-  HIPCHK(c, run_factor(st, ca, nt, 0, c->intrsm != 0, nullptr, nullptr, use_split_diag(c, ca.P)));
+  HIPCHK(c, run_factor(st, ca, nt, 0, nullptr, nullptr, use_split_diag(c, ca.P)));
   hipLaunchKernelGGL(k_unpack_dense, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, st, s->A.as<double>(),
                      (int)n, 1, s->dense.as<double>());
   HIPCHK(c, hipGetLastError());
@@ -2597,11 +2538,9 @@ int agp_debug_mfma_peak(agp_ctx* c, int32_t iters, int32_t wg_per_cu, double* ou
   return AGP_OK;
 }
 
+// ---- measurement build only (-DAGP_EXPERIMENTS -> libautogp_hip_exp.so; declared in csrc/experiments/agp_experiments_abi.h) ----
+#ifdef AGP_EXPERIMENTS
 int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t variant, int32_t reps, double* out_ms) {
-#ifndef AGP_EXPERIMENTS
-  (void)P; (void)nt; (void)k; (void)variant; (void)reps; (void)out_ms;
-  return fail(c, AGP_ERR_ARG, "ablation kernels are compiled only with -DAGP_EXPERIMENTS (python __graft_entry__.py --experiments)");
-#else
   if (!c || !out_ms || P <= 0 || nt < 2 || k < 1 || k >= nt - 0) return fail(c, AGP_ERR_ARG, "bad arguments");
   HIPCHK(c, hipSetDevice(c->device));
   SlotGuard sg(c);
@@ -2698,7 +2637,6 @@ int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   HIPCHK(c, hipGetLastError());
   return AGP_OK;
-#endif
 }
 
 // Timeline of the next dataflow sweeps (k_chol_flow): out has 4 int64 per work item — start, end (100 MHz ticks),
@@ -2720,6 +2658,7 @@ int agp_debug_flow_trace(agp_ctx* c, int32_t enable, int64_t max_items, int64_t*
   HIPCHK(c, hipMemcpy(out, c->d_flow_trace, sizeof(long long) * 8 * (size_t)max_items, hipMemcpyDeviceToHost));
   return AGP_OK;
 }
+#endif  // AGP_EXPERIMENTS
 
 int agp_debug_math(agp_ctx* c, int32_t which, const double* x, const double* g, double* y, int32_t n) {
   if (!c || !x || !y || n <= 0 || (which == 3 && !g)) return fail(c, AGP_ERR_ARG, "bad arguments");
@@ -2878,7 +2817,6 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     return AGP_OK;
   }
   auto plain = [&]() { return agp_logpdf_batch(c, n, P, op_off, ops, prm_off, prm, noise, out_lp, out_info); };
-  if (!c->intrsm) return plain();            // the extension needs the in-kernel panel solve (resident inverse blocks)
   HIPCHK(c, hipSetDevice(c->device));
 
   // distinct particles (a resampled population holds copies)
@@ -2965,13 +2903,13 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   Batch bt;
   // regular grid: stationary subtrees from rank lag tables, as in the caller-order sweeps of logpdf_batch_impl (the mode depends
   // on the resident series alone, so an extension and a from-scratch sweep of the same entry evaluate every tile the same way)
-  const bool lagr = c->lag_rank_enable && c->lag_store_enable && c->lag_enable && c->lag_ok && c->intrsm != 0 && c->n_max <= 4096;
+  const bool lagr = c->lag_rank_enable && c->lag_enable && c->lag_ok && c->n_max <= 4096;
   const int rank_units = (int)((c->n_max + 255) / 256);
   const bool ge_tab = c->logdt_ok && !lagr;
   // (tiles are evaluated inside the factorisation kernels whatever the population size: the prebuilt-tile variants of
   // the split launches carry the most register spills, and the store never needs K itself)
   int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, ge_tab, /*fuse_hint=*/true,
-                         /*flow_limit=*/c->intrsm != 0 && c->flow != 0 && U <= FLOW_MAX_PARTICLES, lagr, lagr ? rank_units : 1, lagr);
+                         /*flow_limit=*/c->flow != 0 && U <= FLOW_MAX_PARTICLES, lagr, lagr ? rank_units : 1, lagr);
   if (rc) { poison(); return rc; }
   int i0min = nt;
   for (int u = 0; u < U; ++u) i0min = std::min(i0min, (int)i0[u]);
@@ -3051,7 +2989,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     cv.slot = d_slot; cv.i0 = d_i0;
     const int nf = std::max(0, std::min(U, bt.n_fused));
     const int dcov = nf > 0 ? bt.max_depth_fused : 0;
-    cv.col0_only = 0; cv.p_off = nf;
+    cv.p_off = nf;
     EXTCHK(launch_cov(st, cv, nt * (nt + 1) / 2, U - nf, bt.max_cp, bt.max_depth));
     CholArgs ca = {};
     ca.A = cv.A; ca.strideA = fs.strideA; ca.W = fs.W.as<double>(); ca.wsteps = fs.nt_cap;
@@ -3062,14 +3000,14 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     ca.n_fused = nf; ca.slot = d_slot; ca.i0 = d_i0;
     // an extension touches every block column (the new rows' tiles of the old columns, then the new columns): one
     // dataflow launch instead of nt small per-column launches, whatever the amount of work
-    if (c->intrsm != 0 && (c->flow > 0 || (c->flow < 0 && U <= FLOW_MAX_PARTICLES && (nt >= 3 || use_flow(c, U, nt))))) {
+    if (c->flow > 0 || (c->flow < 0 && U <= FLOW_MAX_PARTICLES && (nt >= 3 || use_flow(c, U, nt)))) {
       // dataflow schedule over the rows to compute: flags of the resident rows are pre-raised
       const int ntri_cap = fs.nt_cap * (fs.nt_cap + 1) / 2, ntri = nt * (nt + 1) / 2;
       EXTCHK(fs.tflag.ensure(sizeof(int) * (size_t)fs.n_slots * ntri_cap));
       EXTCHK(fs.flowq.ensure(sizeof(int) * 8));
       hipLaunchKernelGGL(k_init_flow_flags, dim3((ntri + 255) / 256, U), dim3(256), 0, st, fs.tflag.as<int>(), ntri_cap, ntri, d_slot, d_i0);
       EXTCHK(hipMemsetAsync(fs.flowq.p, 0, sizeof(int) * 8, st));
-      ca.tflag = fs.tflag.as<int>(); ca.ntri = ntri_cap; ca.qnext = fs.flowq.as<int>(); ca.flow_order = c->flow_order;
+      ca.tflag = fs.tflag.as<int>(); ca.ntri = ntri_cap; ca.qnext = fs.flowq.as<int>();
       launch_flow(dcov, 2 * c->n_cu, st, ca);
       EXTCHK(hipGetLastError());
     } else {
@@ -3156,6 +3094,13 @@ int agp_get_lag_rank_stats(agp_ctx* c, int64_t* n_sweeps) {
   if (!c || !n_sweeps) return fail(c, AGP_ERR_ARG, "null pointer");
   std::lock_guard<std::mutex> g(c->mu);
   *n_sweeps = c->n_lag_rank_sweeps;
+  return AGP_OK;
+}
+
+int agp_get_lag_predict_stats(agp_ctx* c, int64_t* n_passes) {
+  if (!c || !n_passes) return fail(c, AGP_ERR_ARG, "null argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  *n_passes = c->n_lag_pred;
   return AGP_OK;
 }
 

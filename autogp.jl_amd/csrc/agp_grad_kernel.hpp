@@ -7,15 +7,14 @@
 //   d logpdf / d noise = tr G.
 //
 // After the Cholesky sweep (L in the packed lower tiles, beta = L^-1 x in the vector):
-//   k_trtri_step(i)  Z = L^-T, one block column per launch, Z(j,i) = [d_ji I - sum_{k=j}^{i-1} Z(j,k) L(i,k)^T] L(i,i)^-T:
-//                    the same "128x128xK MFMA GEMM + in-register blocked solve" as the factorisation
-//                    (the per-step 16x16 inverses W are kept for this).  Z(r,k), r <= k, is stored in the
-//                    slot of lower tile (k,r) of a second packed buffer, so both K^-1 = Z Z^T and the
-//                    recurrence contract over contiguous 16-column slabs exactly like L L^T does.
-//   k_alpha          alpha_j = sum_{k>=j} Z(j,k) beta_k
-//   k_grad_tiles     per lower tile (i,j): K^-1(i,j) = sum_{k>=i} Z(i,k) Z(j,k)^T in MFMA accumulators (never
-//                    written to HBM), G on the fly, then a reverse-mode pass over the kernel program per
-//                    element accumulates G_ab dK_ab/dtheta; per-tile partial sums go to a small buffer
+//   k_trtri_chain    Z = L^-T, one workgroup per block ROW of Z: Z(j,i) = [d_ji I - sum_{k=j}^{i-1} Z(j,k) L(i,k)^T] L(i,i)^-T,
+//                    the same "128x128xK MFMA GEMM + in-register blocked solve" as the factorisation (the per-step 16x16
+//                    inverses W are kept for this).  Z(r,k), r <= k, is stored in the slot of lower tile (k,r) of a second
+//                    packed buffer, so both K^-1 = Z Z^T and the recurrence contract over contiguous 16-column slabs exactly
+//                    like L L^T does.  alpha_j = sum_{k>=j} Z(j,k) beta_k is formed from the tiles in registers.
+//   k_kinv_tiles     per lower tile (i,j): K^-1(i,j) = sum_{k>=i} Z(i,k) Z(j,k)^T (or, lag-domain particles, its lag histogram)
+//   k_grad_contract  G on the fly, then a reverse-mode pass over the kernel program per element accumulates
+//                    G_ab dK_ab/dtheta; per-tile partial sums go to a small buffer (k_zspec / k_lag_grad: the lag domain)
 //   k_grad_finish    fixed-order sum over tiles (deterministic), scatter to the caller's parameter order
 #pragma once
 #include <type_traits>
@@ -131,7 +130,6 @@ struct GradArgs {
   double* alpha;         // [P][ldv]  K^-1 x
   int ldv;
   int P, nt, n;          // n = valid points (no prediction segment here)
-  int step;              // k_trtri_step: block column i
   // gradient programs (device order; see GProgHdr)
   const struct GProgHdr* ghdr;
   const uint8_t* gops;   // opcode per node
@@ -146,7 +144,7 @@ struct GradArgs {
   const int32_t* gmap;   // per particle parameter slot -> index in the caller's parameter array
   const int32_t* out_off;   // [P] offset of the particle's gradient block in out_grad (caller order, via map)
   const int32_t* pmap;   // sorted particle -> caller particle
-  const int32_t* plist;  // k_grad_tiles: particles of this launch (indices into the sorted group)
+  const int32_t* plist;  // k_grad_contract / k_lag_grad: particles of this launch (indices into the sorted group)
   int tape_off;          // k_grad_contract<0>: offset (doubles) of the LDS tape inside the dynamic shared memory
   // resident factors (nullable): particle p with lslot[p] >= 0 reads L and the inverse blocks from the factor store
   // (slot lslot[p]; Lstride doubles per slot, Wnt block columns per slot) instead of A / W — nothing is copied
@@ -177,66 +175,6 @@ constexpr int LAGDOM_MAX_BINS = 4096;      // LDS histogram of k_kinv_tiles (32 
 constexpr int FFT_N = 4096;                // transform length of the spectral variant: series of up to FFT_N / 2 points
 
 __device__ __forceinline__ long long zoff(int r, int k) { return tile_off(k, r); }   // r <= k
-
-// ---- Z = L^-T, block column `step` -------------------------------------------------------------
-#ifndef AGP_TRTRI_TAIL_GROUPS
-#define AGP_TRTRI_TAIL_GROUPS 8
-#endif
-constexpr int TRTRI_TAIL_GROUPS = AGP_TRTRI_TAIL_GROUPS;
-__global__ __launch_bounds__(256, 2) void k_trtri_step(GradArgs a) {
-  __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES];
-  // grid: particle-major (a particle's tiles run together and share its Z / L panels in one XCD's L2 —
-  // measured 10 % faster than a longest-contraction-first order); block b -> XCD b%8, particle = pl*8 + xcd
-  // The tiles of a block column differ in length (tile j contracts over i-j tiles), so the launch would end with
-  // the last particle's longest tile running alone; the last TRTRI_TAIL_GROUPS x 8 particles are therefore laid
-  // out tile-major (all their j = 0 tiles, then j = 1, ...) and the launch drains on the short tiles.
-  const int i = a.step;
-  const int T = i + 1;
-  const int npl = (a.P + 7) / 8;
-  const int tailg = npl < TRTRI_TAIL_GROUPS ? npl : TRTRI_TAIL_GROUPS;
-  const int maing = npl - tailg;
-  int b = blockIdx.x;
-  int pl, j;
-  const int xcd = b & 7;
-  if (b < 8 * maing * T) {
-    const int qq = b >> 3;
-    pl = qq / T; j = qq - pl * T;
-  } else {
-    const int qq = (b - 8 * maing * T) >> 3;
-    j = qq / tailg; pl = maing + (qq - j * tailg);
-  }
-  const int p = pl * 8 + xcd;
-  if (p >= a.P) return;
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
-  const int row0 = 32 * w + 2 * l15;
-  const int lsl = a.lslot != nullptr ? a.lslot[p] : -1;
-  const double* __restrict__ Lp = lsl >= 0 ? a.Lsrc + (long long)lsl * a.Lstride : a.A + (long long)p * a.strideA;
-  const double* __restrict__ Wp = lsl >= 0 ? a.Wsrc + (long long)lsl * a.Wnt * NSB * 256 : a.W + (long long)p * a.nt * NSB * 256;
-  double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
-
-  // acc = -C,  C = d_ji I - sum_k Z(j,k) L(i,k)^T
-  d4 acc[NSB][2];
-#pragma unroll
-  for (int cb = 0; cb < NSB; ++cb)
-#pragma unroll
-    for (int st = 0; st < 2; ++st)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[cb][st][r] = (j == i && (cb * 16 + 4 * r + lq) == row0 + st) ? -1.0 : 0.0;
-  const int nslab = (i - j) * (NB / KB);
-  gemm_slabs(acc, nslab,
-             Zp, [&](int s) { return (int)((zoff(j, j + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
-             Lp, [&](int s) { return (int)((tile_off(i, j + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
-             sm, tid, l15, lq, row0);
-  solve_in_regs(acc, Lp + tile_off(i, i), Wp + (long long)i * NSB * 256, sm, tid, l);
-  double* __restrict__ Tt = Zp + zoff(j, i);
-#pragma unroll
-  for (int cb = 0; cb < NSB; ++cb)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      d2 o2; o2.x = acc[cb][0][r]; o2.y = acc[cb][1][r];
-      *reinterpret_cast<d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
-    }
-}
 
 // ---- Z = L^-T, one workgroup per (particle, block ROW j of Z): the whole chain Z(j,j), Z(j,j+1), ... in one launch.
 // Row j of Z only depends on itself (Z(j,i) needs Z(j,k), k < i, and row i of L), so the nt rows of a particle are
@@ -294,25 +232,6 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
     d2 o2; o2.x = al0; o2.y = al1;
     *reinterpret_cast<d2*>(a.alpha + (long long)p * a.ldv + j * NB + row0) = o2;
   }
-}
-
-// ---- alpha_j = sum_{k >= j} Z(j,k) beta_k --------------------------------------------------------
-__global__ __launch_bounds__(256) void k_alpha(GradArgs a) {
-  __shared__ double part[256];
-  const int j = blockIdx.x, p = blockIdx.y;
-  const int tid = threadIdx.x, r = tid & 127, h = tid >> 7;     // two column halves
-  const double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
-  const double* __restrict__ bp = a.beta + (long long)p * a.ldv;
-  double s = 0.0;
-  for (int k = j; k < a.nt; ++k) {
-    const double* __restrict__ Zt = Zp + zoff(j, k);
-    const double* __restrict__ bk = bp + k * NB;
-#pragma unroll 8
-    for (int c = h * 64; c < h * 64 + 64; ++c) s = fma(Zt[c * NB + r], bk[c], s);
-  }
-  part[tid] = s;
-  __syncthreads();
-  if (tid < 128) a.alpha[(long long)p * a.ldv + j * NB + tid] = part[tid] + part[tid + 128];
 }
 
 // ---- reverse-mode pass over E elements in lockstep ----------------------------------------------
@@ -542,124 +461,7 @@ __device__ __forceinline__ void grad_elements(const GProgHdr& h, const uint8_t* 
   }
 }
 
-template <int MAXS>
-__global__ __launch_bounds__(256, 1) void k_grad_tiles(GradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];   // slab buffers, then tpt | sig | reduction
-  // grid (tile, particle): consecutive blocks are tiles of ONE particle spread over all 8 XCDs.  Measured
-  // faster than pinning a particle to one XCD (163 vs 171 ms per sweep): its Z panels (17.8 MB) overflow a
-  // single 4 MiB L2 but mostly fit the 8 L2s together, and faster than a longest-tile-first order (179 ms).
-  const int tix = blockIdx.x;
-  const int p = a.plist[blockIdx.y];
-  int ti = (int)((sqrt(8.0 * (double)tix + 1.0) - 1.0) * 0.5);
-  while (ti * (ti + 1) / 2 > tix) --ti;
-  while ((ti + 1) * (ti + 2) / 2 <= tix) ++ti;
-  const int tj = tix - ti * (ti + 1) / 2;
-  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
-  const int row0 = 32 * w + 2 * l15;
-  const double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
-
-  // ---- K^-1(ti,tj) = sum_{k >= ti} Z(ti,k) Z(tj,k)^T ----
-  d4 acc[NSB][2];
-#pragma unroll
-  for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
-  gemm_slabs(acc, (a.nt - ti) * (NB / KB),
-             Zp, [&](int s) { return (int)((zoff(ti, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
-             Zp, [&](int s) { return (int)((zoff(tj, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
-             smem, tid, l15, lq, row0);
-
-  // ---- per-element reverse-mode contraction ----
-  // LDS map (aliases the slab buffers): tpt[256] | sig[n_cp][256] | prm[n_prm+3] | poff[n_ops] | ops/lc/rc/mv[n_ops] bytes
-  const GProgHdr h = a.ghdr[p];
-  double* tpt = smem;
-  double* sig = smem + 256;
-  double* prm = sig + h.n_cp * 256;
-  int32_t* poff = reinterpret_cast<int32_t*>(prm + h.n_prm + 3);
-  uint8_t* ops = reinterpret_cast<uint8_t*>(poff + h.n_ops);
-  uint8_t* lc = ops + h.n_ops;
-  uint8_t* rc = lc + h.n_ops;
-  uint8_t* mv = rc + h.n_ops;     // 1: stationary leaf with non-zero amplitude (see grad_elements)
-  {
-    for (int i = tid; i < h.n_prm + 3; i += 256) prm[i] = a.gprm[h.prm_off + i];
-    for (int i = tid; i < h.n_ops; i += 256) {
-      const int po = a.gpoff[h.node_off + i];
-      const int o = a.gops[h.node_off + i];
-      poff[i] = po;
-      ops[i] = (uint8_t)o; lc[i] = a.glc[h.node_off + i]; rc[i] = a.grc[h.node_off + i];
-      const bool stat = (o == OP_SE || o == OP_GE || o == OP_PER);
-      mv[i] = (stat && a.gprm[h.prm_off + po + (o == OP_SE ? 1 : 2)] != 0.0) ? 1 : 0;
-    }
-    const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
-    tpt[tid] = a.tt[g];
-    __syncthreads();
-    if (h.n_cp > 0) {
-      const double t = tpt[tid];
-      int c = 0;
-      for (int ip = 0; ip < h.n_ops; ++ip)
-        if (ops[ip] == OP_CP) {
-          const double* q = prm + poff[ip];
-          sig[c * 256 + tid] = 0.5 * (1.0 + tanh((q[0] - t) / q[1]));
-          ++c;
-        }
-    }
-    __syncthreads();
-  }
-  constexpr int E = 4;     // elements walked in lockstep
-  RegTape<MAXS, E> tape;
-  double gacc[3 * MAXS + 2];
-  ScratchAcc<3 * MAXS + 2> sacc{gacc};
-  for (int q = 0; q <= h.n_prm + 2; ++q) gacc[q] = 0.0;     // (+2: leaves add three slots unconditionally)
-  const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
-  const double wfac = (ti == tj) ? 1.0 : 2.0;
-  double gnoise = 0.0;
-  const bool use_tab = a.logdt != nullptr && (h.flags & 1) != 0;
-  const double* __restrict__ ltile = a.logdt + tile_off(ti, tj);       // only dereferenced when use_tab
-#pragma unroll 1
-  for (int t = 0; t < 16; ++t) {
-    const int cb = t >> 1, st = t & 1;
-    d4 v;
-    switch (t) {
-      case 0: v = acc[0][0]; break;  case 1: v = acc[0][1]; break;  case 2: v = acc[1][0]; break;  case 3: v = acc[1][1]; break;
-      case 4: v = acc[2][0]; break;  case 5: v = acc[2][1]; break;  case 6: v = acc[3][0]; break;  case 7: v = acc[3][1]; break;
-      case 8: v = acc[4][0]; break;  case 9: v = acc[4][1]; break;  case 10: v = acc[5][0]; break; case 11: v = acc[5][1]; break;
-      case 12: v = acc[6][0]; break; case 13: v = acc[6][1]; break; case 14: v = acc[7][0]; break; default: v = acc[7][1]; break;
-    }
-    const int rslot = row0 + st;
-    const int ga = ti * NB + rslot;
-#pragma unroll 1
-    for (int r0 = 0; r0 < 4; r0 += E) {
-      int ri[E], ci[E];
-      double ta[E], tb[E], wg[E], lt[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const int r = r0 + e;
-        const int cslot = cb * 16 + 4 * r + lq;
-        lt[e] = use_tab ? ltile[cslot * NB + rslot] : 0.0;
-        const int gb = tj * NB + cslot;
-        const bool valid = ga < a.n && gb < a.n;       // padding rows / columns carry no parameter dependence
-        const double kinv = (r == 0) ? v[0] : (r == 1) ? v[1] : (r == 2) ? v[2] : v[3];
-        const double G = valid ? 0.5 * (al[valid ? ga : 0] * al[valid ? gb : 0] - kinv) : 0.0;
-        if (ga == gb) gnoise += G;                       // d/d noise = tr G
-        ri[e] = rslot; ci[e] = NB + cslot; ta[e] = tpt[rslot]; tb[e] = tpt[NB + cslot]; wg[e] = wfac * G;
-      }
-      grad_elements<MAXS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, lt, use_tab, tape, sacc);
-    }
-  }
-  gacc[h.n_prm] = gnoise;       // overwrites whatever the unconditional three-slot adds left there
-  // ---- reduce over the 256 threads, one parameter slot at a time ----
-  __syncthreads();
-  double* red = smem + 256;      // [4] per-wave sums (tpt no longer needed; sig/prm region is free too)
-  for (int q = 0; q <= h.n_prm; ++q) {
-    double s = gacc[q];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (l == 0) red[w] = s;
-    __syncthreads();
-    if (tid == 0) a.gpart[((long long)p * (a.nt * (a.nt + 1) / 2) + tix) * a.gstride + q] = red[0] + red[1] + red[2] + red[3];
-    __syncthreads();
-  }
-}
-
-// ---- split variant: K^-1 tiles to memory (over the L buffer, dead by now), then a lean contraction ----
+// ---- K^-1 tiles to memory (over the L buffer, dead by now), then a lean contraction ----
 //
 // Lag-domain particles (GFLAG_LAGDOM; regular time grid, kernel = sum of stationary subtrees and Linear leaves): on a regular
 // grid a stationary kernel's dK_ab/dtheta depends on the lag |rank_a - rank_b| alone, so
@@ -1104,7 +906,7 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
 // (now fetched one group ahead); (2) the tape: node values and adjoints in private memory, a dependent global-memory round
 // trip per tree node in the backward sweep — ~6 ms per node of the tree and sweep, whatever the leaf kind
 // (tools/gpu_grad_contract_probe.py); trees of <= 8 nodes (every tree of depth <= 3) now keep it in LDS (instantiation
-// MAXS = 0; AGP_GRAD_LDS_TAPE=0 restores the private tape).  Together 31 -> ~20 ms.  Measured and dropped: 3 / 4 waves per
+// MAXS = 0).  Together 31 -> ~20 ms.  Measured and dropped: 3 / 4 waves per
 // SIMD by register cap (-2 % / +9 %), a fully register-resident variant (value stack + operand history + adjoint stack;
 // 353 registers, one wave per SIMD: +6 %), register accumulators instead of the private gacc[] (no change).
 // (An LDS tape with 2 / 1 elements in lockstep for trees of <= 16 / <= 32 nodes was measured too: no gain over the private

@@ -26,12 +26,12 @@ LIB_PATH = _PKG_DIR / "lib" / "libautogp_hip.so"
 EXPORTED_SYMBOLS = [
     "agp_init", "agp_destroy", "agp_last_error", "agp_version", "agp_set_data", "agp_logpdf",
     "agp_logpdf_batch", "agp_logpdf_grad_batch", "agp_logpdf_grad", "agp_logpdf_batch_device", "agp_predict_batch", "agp_infer_gp_sum", "agp_cov_matrix",
-    "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_debug_mfma_peak", "agp_debug_math", "agp_debug_gemm_variant", "agp_set_profiling", "agp_get_timing", "agp_get_launch_times",
+    "agp_debug_cholesky", "agp_debug_mfma_probe", "agp_debug_mfma_peak", "agp_debug_math", "agp_set_profiling", "agp_get_timing", "agp_get_launch_times",
     "agp_set_workspace_limit", "agp_set_coalesce_window", "agp_get_coalesce_stats", "agp_get_dedup_stats",
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi", "agp_logpdf_batch_extend_multi",
-    "agp_debug_flow_trace", "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
-    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats",
+    "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
+    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
 ]
 COMM_ID_BYTES = 128
 
@@ -112,7 +112,8 @@ def load_library(path=None):
     lib.agp_debug_mfma_probe.argtypes = [vp, dp, dp, dp]; lib.agp_debug_mfma_probe.restype = C.c_int
     lib.agp_debug_mfma_peak.argtypes = [vp, C.c_int32, C.c_int32, dp, dp]; lib.agp_debug_mfma_peak.restype = C.c_int
     lib.agp_debug_math.argtypes = [vp, C.c_int32, dp, dp, dp, C.c_int32]; lib.agp_debug_math.restype = C.c_int
-    lib.agp_debug_gemm_variant.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp]; lib.agp_debug_gemm_variant.restype = C.c_int
+    if hasattr(lib, "agp_debug_gemm_variant"):      # measurement build only (libautogp_hip_exp.so)
+        lib.agp_debug_gemm_variant.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, dp]; lib.agp_debug_gemm_variant.restype = C.c_int
     lib.agp_set_profiling.argtypes = [vp, C.c_int]; lib.agp_set_profiling.restype = C.c_int
     lib.agp_get_timing.argtypes = [vp, dp, C.c_int32]; lib.agp_get_timing.restype = C.c_int
     lib.agp_get_launch_times.argtypes = [vp, C.c_int32, dp, C.c_int32]; lib.agp_get_launch_times.restype = C.c_int
@@ -122,7 +123,8 @@ def load_library(path=None):
     lib.agp_get_dedup_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.agp_get_dedup_stats.restype = C.c_int
     lib.agp_logpdf_batch_extend.argtypes = [vp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, ip]
     lib.agp_logpdf_batch_extend.restype = C.c_int
-    lib.agp_debug_flow_trace.argtypes = [vp, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]; lib.agp_debug_flow_trace.restype = C.c_int
+    if hasattr(lib, "agp_debug_flow_trace"):
+        lib.agp_debug_flow_trace.argtypes = [vp, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]; lib.agp_debug_flow_trace.restype = C.c_int
     lib.agp_debug_compact_shards.argtypes = [vp, dp, C.c_int32, C.c_int32, dp]; lib.agp_debug_compact_shards.restype = C.c_int
     lib.agp_extend_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_extend_stats.restype = C.c_int
     lib.agp_extend_reset.argtypes = [vp, C.c_int]; lib.agp_extend_reset.restype = C.c_int
@@ -142,6 +144,7 @@ def load_library(path=None):
     lib.agp_set_grad_lag_domain.argtypes = [vp, C.c_int32]; lib.agp_set_grad_lag_domain.restype = C.c_int
     lib.agp_set_lag_rank_tables.argtypes = [vp, C.c_int32]; lib.agp_set_lag_rank_tables.restype = C.c_int
     lib.agp_get_lag_rank_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_get_lag_rank_stats.restype = C.c_int
+    lib.agp_get_lag_predict_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_get_lag_predict_stats.restype = C.c_int
     lib.agp_get_grad_lag_domain_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_get_grad_lag_domain_stats.restype = C.c_int
     lib.agp_init_multi.argtypes = [C.POINTER(vp), i32p, C.c_int32]; lib.agp_init_multi.restype = C.c_int
     lib.agp_set_data_multi.argtypes = [C.POINTER(vp), C.c_int32, dp, dp, C.c_int64]; lib.agp_set_data_multi.restype = C.c_int
@@ -357,6 +360,12 @@ class GPEngine:
         self._check(self._lib.agp_get_lag_rank_stats(self._ctx, C.byref(k)))
         return int(k.value)
 
+    def lag_predict_passes(self):
+        """Predictive passes whose query points sat on the series' lattice (rank tables) so far."""
+        k = C.c_int64()
+        self._check(self._lib.agp_get_lag_predict_stats(self._ctx, C.byref(k)))
+        return int(k.value)
+
     def set_grad_lag_domain(self, on):
         """Switch the lag-domain gradient contraction of regular grids (takes effect at the next gradient sweep)."""
         self._check(self._lib.agp_set_grad_lag_domain(self._ctx, 1 if on else 0))
@@ -471,13 +480,20 @@ class GPEngine:
         self._check(self._lib.agp_debug_math(self._ctx, int(which), _dp(x), _dp(g), _dp(y), x.size))
         return y
 
+    def _measurement_only(self, name):
+        if not hasattr(self._lib, name):
+            raise AGPError(f"{name} exists in the measurement build only: python __graft_entry__.py --experiments, then "
+                           f"AUTOGP_HIP_LIB=autogp.jl_amd/lib/libautogp_hip_exp.so")
+
     def debug_gemm_variant(self, P, nt, k, variant, reps=5):
+        self._measurement_only("agp_debug_gemm_variant")
         ms = C.c_double()
         self._check(self._lib.agp_debug_gemm_variant(self._ctx, P, nt, k, variant, reps, C.byref(ms)))
         return ms.value
 
     def flow_trace(self, enable, max_items):
         """agp_debug_flow_trace: enable=True starts recording; enable=False returns an (items, 8) int64 array."""
+        self._measurement_only("agp_debug_flow_trace")
         if enable:
             self._check(self._lib.agp_debug_flow_trace(self._ctx, 1, int(max_items), None))
             return None

@@ -324,11 +324,13 @@ Regular time grids (include/autogp_hip.h): `(is_regular, sorted_sweeps)`, the sw
 gradient was contracted in the lag domain; the switches take effect at the next `set_data!` (lag tables) / sweep (the others).
 """
 function lag_stats(eng::Engine)
-    reg = Ref{Int32}(0); ns = Ref{Int64}(0); nr = Ref{Int64}(0); ng = Ref{Int64}(0)
+    reg = Ref{Int32}(0); ns = Ref{Int64}(0); nr = Ref{Int64}(0); ng = Ref{Int64}(0); np = Ref{Int64}(0)
     check(eng, ccall((:agp_get_lag_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int64}), eng.ptr, reg, ns))
     check(eng, ccall((:agp_get_lag_rank_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), eng.ptr, nr))
     check(eng, ccall((:agp_get_grad_lag_domain_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), eng.ptr, ng))
-    return (regular = reg[] != 0, sorted_sweeps = Int(ns[]), rank_sweeps = Int(nr[]), lag_domain_gradients = Int(ng[]))
+    check(eng, ccall((:agp_get_lag_predict_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), eng.ptr, np))
+    return (regular = reg[] != 0, sorted_sweeps = Int(ns[]), rank_sweeps = Int(nr[]), lag_domain_gradients = Int(ng[]),
+            lattice_predictions = Int(np[]))
 end
 set_lag_tables!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_lag_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
 set_lag_rank_tables!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_lag_rank_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))

@@ -240,18 +240,31 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
     try:
         Pp = min(P, 128)
         m = 2 * n
-        tq = np.linspace(0.0, 1.25, m)
-        eng.predict_batch(nodes[:Pp], noises[:Pp], tq, n=n, check=False)
-        reps = 2
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            eng.predict_batch(nodes[:Pp], noises[:Pp], tq, n=n, check=False)
-        dt = (time.perf_counter() - t0) / reps
+        # the reference's query set (scripts/online.jl:41-43: ds_query = vcat(model.ds, ds_next, ds_test)): the observed time
+        # points and as many future ones at the series' cadence — on a regular grid all of them lattice points
+        tsort = np.sort(ts[:n]); hq = (tsort[-1] - tsort[0]) / max(n - 1, 1)
+        tq = np.concatenate([ts[:n], tsort[0] + hq * np.arange(n, m)])
+        tq_off = np.linspace(0.0, 1.25, m)                 # (not commensurate with the data's spacing: the general evaluator)
+
+        def timed(q):
+            eng.predict_batch(nodes[:Pp], noises[:Pp], q, n=n, check=False)
+            reps = 2
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                eng.predict_batch(nodes[:Pp], noises[:Pp], q, n=n, check=False)
+            return (time.perf_counter() - t0) / reps
+        k0 = eng.lag_predict_passes()
+        dt = timed(tq)
+        on_lattice = eng.lag_predict_passes() > k0
+        dt_off = timed(tq_off)
         fl = Pp * (cholesky_flops(n) + float(n) * n * m)
-        out["predict"] = {"what": f"agp_predict_batch, first {Pp} particles, n={n}, m={m} query points, marginal variances (out_cov = NULL), "
-                                  f"host outputs, K11 factored by the pass", "ms": dt * 1e3, "particles": Pp, "m": m,
+        out["predict"] = {"what": f"agp_predict_batch, first {Pp} particles, n={n}, m={m} query points = the observed times + {m - n} future "
+                                  f"points at the series' cadence, marginal variances (out_cov = NULL), host outputs, K11 factored by the pass",
+                          "ms": dt * 1e3, "particles": Pp, "m": m, "rank_tables": bool(on_lattice),
                           "tflops": fl / dt / 1e12, "frac_of_fp64_mfma_peak": fl / dt / 1e12 / PEAK_FP64_MFMA_TFLOPS,
-                          "flop_count": "n^3/3 + n^2 m per particle"}
+                          "flop_count": "n^3/3 + n^2 m per particle",
+                          "off_lattice_queries": {"what": f"the same with {m} query points linspace(0, 1.25): general evaluator",
+                                                  "ms": dt_off * 1e3, "frac_of_fp64_mfma_peak": fl / dt_off / 1e12 / PEAK_FP64_MFMA_TFLOPS}}
     except Exception as e:      # noqa: BLE001
         out["predict"] = {"error": str(e)[:300]}
     return out
@@ -284,11 +297,10 @@ def build_roofline(pkg, acc, n_prof, args, n, P, world, prof_every):
     # large-population schedule (>= 256 particles on the rank): diagonal tiles in their own launch (reported
     # under the engine's "trsm" timing keys), sub-diagonal tiles (update + in-register solve) in the dominant
     # kernel, nt-1 launches per sweep.  Smaller shards take the dataflow schedule: one launch per sweep.
-    intrsm = os.environ.get("AGP_INTRSM", "1") != "0"
     sd_env = os.environ.get("AGP_SPLIT_DIAG", "-1")
-    split_diag = intrsm and (sd_env == "1" or (sd_env not in ("0", "1") and P >= 256))
-    # (what actually ran decides: non-default schedule switches — AGP_STREAMS, AGP_FLOW — move a large shard onto the
-    # dataflow kernel, which has no separate diagonal launches)
+    split_diag = sd_env == "1" or (sd_env not in ("0", "1") and P >= 256)
+    # (what actually ran decides: a non-default schedule switch — AGP_FLOW — moves a large shard onto the dataflow kernel,
+    # which has no separate diagonal launches)
     split_diag = split_diag and acc.get("n_trsm_launches", 0.0) > 0 and acc.get("chol_trsm_ms", 0.0) > 0
     diag_block = None
     if split_diag:

@@ -152,7 +152,7 @@ int agp_set_factor_cache(agp_ctx* ctx, int32_t on);
  * evaluated inside the factorisation kernels whatever the kernel tree's size.  Results agree with the general path to
  * rounding (the table's representative t_i - t_j differs from an element's own by a few ulp of t).  Prefix sweeps
  * (n < n_max: a subset of a shuffled grid is not a grid), gradient sweeps and the factor store's sweeps use rank tables instead
- * (below); irregular series and the predictive entries take the general path.  AGP_LAG=0 / agp_set_lag_tables(ctx, 0) disable it (the switch is read at
+ * (below), predictive passes on lattice query points too; irregular series take the general path.  AGP_LAG=0 / agp_set_lag_tables(ctx, 0) disable it (the switch is read at
  * the next agp_set_data).  agp_get_lag_stats: whether the resident series qualifies, and how many sweeps took the path. */
 int agp_get_lag_stats(agp_ctx* ctx, int32_t* regular_grid, int64_t* n_lag_sweeps);
 int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
@@ -163,11 +163,19 @@ int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
  * the order of the points, so one table of n_max lags per subtree and sweep (instead of 255 per tile) serves every element.
  * Same agreement with the general path as the sorted sweeps.  AGP_LAG_RANK=0 / agp_set_lag_rank_tables(ctx, 0) disable it
  * (takes effect at the next sweep); agp_get_lag_rank_stats counts the sweeps of agp_logpdf_batch / agp_logpdf_grad_batch that used
- * it.  The factor store's sweeps (agp_logpdf_batch_extend, the coalesced batches of agp_logpdf) read rank tables too (AGP_LAG_STORE=0
- * restores the general path there; the choice depends on the resident series alone, so an extension and a from-scratch sweep of
- * one entry still agree bit for bit); the predictive entries keep the general path. */
+ * it.  The factor store's sweeps (agp_logpdf_batch_extend, the coalesced batches of agp_logpdf) read rank tables too (the choice depends on the resident series alone, so an extension and a from-scratch sweep of
+ * one entry still agree bit for bit — agp_set_data drops the store when an append changes the mode or the old points' ranks). */
 int agp_set_lag_rank_tables(agp_ctx* ctx, int32_t on);
 int agp_get_lag_rank_stats(agp_ctx* ctx, int64_t* n_sweeps);
+
+/* Predictive passes whose query points sit on the series' own lattice — in every use of the reference the query set is
+ * `train + test + future` at the data's cadence (scripts/online.jl:41-43; src/GP.jl:743 evaluates the kernel on [ts; ts_pred]):
+ * every joint point then has an integer rank round((t - t_0) / h) (duplicates of training times share one, future points exceed
+ * n_max - 1, earlier ones are negative), and agp_predict_batch reads the stationary subtrees from rank tables of max rank -
+ * min rank + 1 <= 4096 lags, as the factor store's sweeps do.  One query point off the lattice (agp_set_data's tolerance) and
+ * the call takes the general path.  No switch of its own (AGP_LAG=0 / AGP_LAG_RANK=0 cover it); agp_get_lag_predict_stats counts
+ * the calls that took it. */
+int agp_get_lag_predict_stats(agp_ctx* ctx, int64_t* n_passes);
 
 /* Gradient sweeps on a regular time grid (the points in any order, any prefix n <= n_max <= 4096): for a stationary kernel
  * dK_ab/dtheta depends on the lag |rank_a - rank_b| alone, so sum_ab G_ab dK_ab/dtheta = sum_g D_g dk(g h)/dtheta with D_g the
@@ -320,21 +328,8 @@ int agp_debug_math(agp_ctx* ctx, int32_t which, const double* x, const double* g
  * each (by block-index parity / by halves of 256 blocks); the TFLOP/s figure always assumes 16 MFMAs per wave and iteration. */
 int agp_debug_mfma_peak(agp_ctx* ctx, int32_t iters, int32_t wg_per_cu, double* out_tflops, double* out_ghz);
 
-/* Ablation harness for the update GEMM (off-diagonal tiles of block column k on pseudo-random data):
- * average milliseconds per launch for `variant` (see csrc/experiments/agp_experiments.hpp).  Compiled only into the
- * measurement library (libautogp_hip_exp.so: -DAGP_EXPERIMENTS, `python __graft_entry__.py --experiments`); the product library
- * returns AGP_ERR_ARG. */
-int agp_debug_gemm_variant(agp_ctx* ctx, int32_t P, int32_t nt, int32_t k, int32_t variant, int32_t reps, double* out_ms);
-
 /* Test hook: the un-padding of unequal shards after the padded all-gather (`padded`: n_ranks blocks of ceil(P/n_ranks)). */
 int agp_debug_compact_shards(agp_ctx* ctx, const double* padded, int32_t P, int32_t n_ranks, double* out /* P */);
-
-/* Timeline of the dataflow factorisation schedule (one launch of persistent workgroups, medium populations):
- * enable != 0 allocates room for max_items work items (tiles) and records the following sweeps; enable == 0 copies
- * the records out — 8 int64 per item: start, end (100 MHz ticks), ticks spent waiting for operand tiles,
- * (workgroup << 48 | item kind << 44 | particle << 24 | tile row << 12 | block column), then the times at which the item's
- * phases ended: tile evaluated, K-loop done, solve / factorisation inputs staged, arithmetic done (0: phase not run). */
-int agp_debug_flow_trace(agp_ctx* ctx, int32_t enable, int64_t max_items, int64_t* out);
 
 /* When enabled, batch calls bracket their phases with HIP events on the launch stream.
  * agp_get_timing fills out[0..7] = { total_ms, cov_build_ms, chol_update_ms, chol_trsm_ms,

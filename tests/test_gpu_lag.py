@@ -218,6 +218,84 @@ def test_rank_lag_tables_prefix_sweeps(pkg, monkeypatch, n_max, n, P, depth):
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("case", ["duplicates", "future", "interleaved", "backcast", "prefix", "off_grid", "too_long", "many"])
+def test_predictive_pass_on_lattice_query_points(pkg, case):
+    """agp_predict_batch with query points on the series' own lattice (scripts/online.jl:41-43: ds_query = vcat(model.ds, ds_next,
+    ds_test); src/GP.jl:743) reads the stationary subtrees from rank tables: duplicates of training times, future-only points,
+    both interleaved, points before the series, a prefix n < n_max; one off-lattice point or more than 4096 lags -> general path.
+    Mean, variance and covariance against the oracle (1e-8) and against a context without lag tables (1e-10 of the scale)."""
+    from oracle import oracle as O
+    G = pkg
+    n_max, n = 300, 300
+    grid = np.linspace(0.0, 1.0, n_max)
+    h = grid[1] - grid[0]
+    rng = np.random.default_rng(17)
+    perm = rng.permutation(n_max)
+    ts = grid[perm]; xs = np.sin(7 * ts) + 0.2 * rng.standard_normal(n_max)
+    fut = grid[0] + h * np.arange(n_max, n_max + 40)
+    if case == "duplicates":    tq, on = ts[rng.permutation(n_max)[:200]], True
+    elif case == "future":      tq, on = fut, True
+    elif case == "interleaved": tq, on = np.concatenate([ts[:150], fut[:25], ts[150:], fut[25:]]), True
+    elif case == "backcast":    tq, on = np.concatenate([grid[0] - h * np.arange(1, 30), ts[:20], fut[:5]]), True
+    elif case == "prefix":      tq, on, n = np.concatenate([ts, fut]), True, 170          # (the rest of the series is "ds_next")
+    elif case == "off_grid":    tq, on = np.concatenate([ts[:50], [grid[10] + 0.3 * h], fut[:5]]), False
+    elif case == "too_long":    tq, on = grid[0] + h * np.arange(0, 5000, 100), False      # ranks up to 4900 > 4096 lags
+    else:                       tq, on = np.concatenate([ts, fut]), True
+    ks = [G.SquaredExponential(0.1, 0.8), G.Periodic(0.7, 0.21, 1.1) * G.SquaredExponential(0.5, 0.9) + G.Linear(0.3, 0.2, 0.5),
+          G.GammaExponential(0.3, 1.2, 0.7) + G.WhiteNoise(0.05), G.ChangePoint(G.Periodic(0.5, 0.1, 1.0), G.SquaredExponential(0.2, 0.6), 0.45, 0.01),
+          G.Linear(0.1, 0.3, 0.7), G.Constant(0.3) + G.GammaExponential(0.15, 0.8, 0.5) * G.Periodic(1.0, 0.3, 0.8)]
+    nz = np.linspace(0.05, 0.2, len(ks))
+    if case == "many":      # a population on the dataflow / per-column schedules, duplicates among the particles
+        nodes, nzs = pkg.prior.sample_particles(np.random.default_rng(3), 70, max_depth=3)
+        ks = list(nodes) + ks + [ks[0]]; nz = np.concatenate([nzs, nz, nz[:1]])
+    a = pkg.GPEngine(0); b = pkg.GPEngine(0)
+    try:
+        b.set_lag_tables(False)
+        a.set_data(ts, xs); b.set_data(ts, xs)
+        for want_cov in (False, True):
+            k0 = a.lag_predict_passes()
+            ma, va, ca, ia = a.predict_batch(ks, nz, tq, n=n, want_cov=want_cov, check=False)
+            assert (a.lag_predict_passes() - k0 == 1) == on, case
+            mb, vb, cb, ib = b.predict_batch(ks, nz, tq, n=n, want_cov=want_cov, check=False)
+            assert b.lag_predict_passes() == 0 and np.array_equal(ia, ib)
+            ok = ia == 0
+            assert ok.mean() >= 0.9
+            sc = np.maximum(1.0, np.abs(mb[ok]).max(axis=1))[:, None]
+            assert (np.abs(ma[ok] - mb[ok]) / sc).max() <= 1e-10 and (np.abs(va[ok] - vb[ok]) / np.maximum(1.0, vb[ok])).max() <= 1e-10
+            if want_cov:
+                assert np.abs(ca[ok] - cb[ok]).max() <= 1e-10 * max(1.0, np.abs(cb[ok]).max())
+        for i in range(len(ks) - 6 - (case == "many"), len(ks) - (case == "many")):          # the hand-written kernels against the oracle
+            mu, cv = O.predict_mvn(ks[i].to_tuple(), float(nz[i]), ts[:n], xs[:n], tq)
+            assert np.abs(ma[i] - mu).max() <= LP_TOL * max(1.0, np.abs(mu).max()), (case, i)
+            assert np.abs(ca[i] - cv).max() <= LP_TOL * max(1.0, np.abs(cv).max()), (case, i)
+    finally:
+        a.close(); b.close()
+
+
+def test_predictive_lattice_pass_reuses_resident_factors(pkg):
+    """The per-step callback of the streaming workload (scripts/online.jl:43,59): factors left by the reweight sweep (rank
+    tables) are reused by a predictive pass on lattice query points; same result as a pass that factors itself."""
+    n_max, n = 512, 384
+    ts, xs = pkg.prior.synthetic_series(n_max, seed=21, shuffle=True)
+    nodes, nz = pkg.prior.sample_particles(np.random.default_rng(9), 40, max_depth=3)
+    grid = np.sort(ts); h = grid[1] - grid[0]
+    tq = np.concatenate([ts[:n + 64], grid[0] + h * np.arange(n_max, n_max + 50)])
+    a = pkg.GPEngine(0); b = pkg.GPEngine(0)
+    try:
+        a.set_data(ts, xs); b.set_data(ts, xs)
+        a.logpdf_batch_extend(nodes, nz, n=n, check=False)
+        m1, v1, _, i1 = a.predict_batch(nodes, nz, tq, n=n, check=False)
+        assert a.predict_reuse_stats()["reused"] > 0 and a.lag_predict_passes() == 1
+        m2, v2, _, i2 = b.predict_batch(nodes, nz, tq, n=n, check=False)
+        assert b.predict_reuse_stats()["reused"] == 0 and b.lag_predict_passes() == 1
+        ok = (i1 == 0) & (i2 == 0)
+        assert np.array_equal(i1, i2) and ok.mean() >= 0.9
+        sc = np.maximum(1.0, np.abs(m2[ok]).max(axis=1))[:, None]
+        assert (np.abs(m1[ok] - m2[ok]) / sc).max() <= 1e-10 and (np.abs(v1[ok] - v2[ok]) / np.maximum(1.0, v2[ok])).max() <= 1e-10
+    finally:
+        a.close(); b.close()
+
+
 def test_lag_path_non_positive_definite_info(pkg):
     """A matrix that is not positive definite: the lag sweep flags it, and the info it hands back is LAPACK's for the caller's
     order of the observations (the reference raises PosDefException(info) with that index)."""

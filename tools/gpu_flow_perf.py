@@ -10,10 +10,7 @@ pkg = g.load_package()
 cases = [(2048, 64), (2048, 128), (2048, 256), (2048, 512), (1024, 64), (4096, 128), (2048, 32), (1024, 256)]
 if len(sys.argv) > 1:
     cases = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]]
-modes = [("cols", {"AGP_FLOW": "0"}), ("flow", {"AGP_FLOW": "1"}), ("flow_pm", {"AGP_FLOW": "1", "AGP_FLOW_ORDER": "1"}),
-         ("flow_fused", {"AGP_FLOW": "1", "AGP_FLOW_FUSE": "1", "AGP_FUSE": "1"}),
-         ("flow_fused_pm", {"AGP_FLOW": "1", "AGP_FLOW_FUSE": "1", "AGP_FUSE": "1", "AGP_FLOW_ORDER": "1"}),
-         ("flow_la", {"AGP_FLOW": "1", "AGP_FLOW_ORDER": "2"})]
+modes = [("cols", {"AGP_FLOW": "0"}), ("flow", {"AGP_FLOW": "1"}), ("flow_prebuilt", {"AGP_FLOW": "1", "AGP_FUSE": "0"})]
 if os.environ.get("FLOW_MODES"):
     modes = [m for m in modes if m[0] in os.environ["FLOW_MODES"].split(",")]
 out = {}
@@ -24,7 +21,7 @@ for n, P in cases:
     progs = pkg.encode_batch(nodes)
     ref = None
     for name, env in modes:
-        for k in ("AGP_FLOW", "AGP_FLOW_ORDER", "AGP_FLOW_FUSE", "AGP_FUSE"):
+        for k in ("AGP_FLOW", "AGP_FUSE"):
             os.environ.pop(k, None)
         os.environ.update(env)
         eng = pkg.GPEngine(0); eng.set_data(ts, xs)

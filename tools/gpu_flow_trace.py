@@ -7,6 +7,8 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 os.environ["AGP_FLOW"] = "1"
 import __graft_entry__ as g
+# measurement build (python __graft_entry__.py --experiments): the product library has neither the trace nor the ablation kernels
+os.environ.setdefault("AUTOGP_HIP_LIB", str(ROOT / "autogp.jl_amd" / "lib" / "libautogp_hip_exp.so"))
 pkg = g.load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 64

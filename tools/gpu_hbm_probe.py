@@ -1,5 +1,5 @@
 """What this box's HBM delivers to plain streaming kernels (torch reductions / copies over 8 GB of fp64): the ceiling against
-which the row-panel stream of k_chol_diag (3.3 TB/s during its K-loop, tools ablation with AGP_DBG_SKIP) is to be read."""
+which the row-panel stream of k_chol_diag (3.3 TB/s during its K-loop, an ablation build of round 2) is to be read."""
 import time
 import torch
 x = torch.ones(1 << 30, dtype=torch.float64, device="cuda")      # 8 GiB

@@ -9,11 +9,11 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 python bench.py 2>gpurun_out/bench.err | tail -1 > gpurun_out/${TAG}_bench_n1.json; cut -c1-300 gpurun_out/${TAG}_bench_n1.json
 python bench.py --particles 64 --no-cpu-baseline --no-extra-legs 2>>gpurun_out/bench.err | tail -1 > gpurun_out/${TAG}_bench_n1_P64_rank_share.json
 python tools/run_configs.py ${TAG} 2>&1 | grep -v amdgpu | tail -8
-FLOW_MODES=cols,flow_fused_pm python tools/gpu_flow_perf.py 2048x8 2048x16 2048x32 2048x64 2048x128 2048x256 2048x384 2048x512 1024x64 1024x128 512x256 4096x32 4096x128 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_flow_perf.txt; tail -3 gpurun_out/${TAG}_flow_perf.txt
+FLOW_MODES=cols,flow python tools/gpu_flow_perf.py 2048x8 2048x16 2048x32 2048x64 2048x128 2048x256 2048x384 2048x512 1024x64 1024x128 512x256 4096x32 4096x128 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_flow_perf.txt; tail -3 gpurun_out/${TAG}_flow_perf.txt
 python tools/gpu_extend_perf.py ${TAG} 2>&1 | grep -v amdgpu | tail -4
 python tools/gpu_grad_perf.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_perf.txt; cat gpurun_out/${TAG}_grad_perf.txt
 # gradient sweep: lag-domain contraction on / off (spans of the sweep's kernels), then with the histogram instead of the spectra
-(python tools/gpu_grad_lagdom_ab.py; AGP_GRAD_FFT=0 python tools/gpu_grad_lagdom_ab.py | head -1; AGP_GRAD_FORK=0 python tools/gpu_grad_lagdom_ab.py | head -1) 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_lagdom_ab.txt; head -2 gpurun_out/${TAG}_grad_lagdom_ab.txt
+(python tools/gpu_grad_lagdom_ab.py; AGP_GRAD_FFT=0 python tools/gpu_grad_lagdom_ab.py | head -1) 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_lagdom_ab.txt; head -2 gpurun_out/${TAG}_grad_lagdom_ab.txt
 python tools/gpu_grad_lagdom_check.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_lagdom_check.txt; tail -1 gpurun_out/${TAG}_grad_lagdom_check.txt
 (python tools/run_stream.py --rejuvenate; python tools/run_stream.py --rejuvenate --no-extend; python tools/run_stream.py --rejuvenate --predict; AGP_PREDICT_REUSE=0 python tools/run_stream.py --rejuvenate --predict) 2>&1 | grep -v amdgpu | grep "^{" > gpurun_out/${TAG}_stream.jsonl; cut -c1-200 gpurun_out/${TAG}_stream.jsonl
 python tools/gpu_scratch_via_store.py 2>&1 | grep "^n=" > gpurun_out/${TAG}_store_scratch.txt; cat gpurun_out/${TAG}_store_scratch.txt

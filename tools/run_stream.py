@@ -32,7 +32,7 @@ if world > 1:
         dist.all_gather_object(out, obj)
         return out
 eng.set_data(ts, xs)
-future = np.linspace(1.0, 1.05, 100)
+_g = np.sort(ts); future = _g[0] + (_g[-1] - _g[0]) / (n_max - 1) * np.arange(n_max, n_max + 100)      # ds_test: the series' cadence continued (scripts/online.jl:41-43)
 res = []
 for rep in range(2):          # first pass warms the allocations up
     eng.extend_reset()
