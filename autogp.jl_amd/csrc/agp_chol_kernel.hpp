@@ -30,52 +30,6 @@
 
 namespace agp {
 
-struct CholArgs {
-  double* A;            // packed tiles
-  long long strideA;    // doubles per particle
-  double* W;            // [P][NSB][256] inverses of the current diagonal tile's 16x16 blocks
-  double* vec;          // [P][ldv]: x on entry, alpha (factored part) / -(V^T alpha) (Schur part) on exit
-  int ldv;
-  double* partial;      // [P][nt][2]: {log det, alpha'alpha} per block column
-  int* info;            // [P]
-  int P;
-  int nt;               // tile rows of the (joint) matrix
-  int k;                // factor mode: block column; Schur mode: unused
-  int nt1;              // Schur mode: number of factored block columns
-  int tiles;            // factor mode: tiles per particle in this launch (nt-k, or 1 for k = 0)
-  int t0;               // sub-diagonal-only launches (DM = 2): the first of them is tile (k + t0, k)
-  // fused covariance evaluation (DCOV > 0): the tile is computed from the particle's program
-  const double* tt;     // time points, padded joint layout
-  int n1, n1_pad, m2;
-  const ProgHdr* hdr;
-  const uint8_t* ops;
-  const double* prm;
-  const double* noise;
-  const uint8_t* code;  // per-point component codes (infer_gp_sum) or null
-  const double* logdt;  // log|dt| table of the resident data (see CovArgs)
-  int n_fused;          // particles [0, n_fused) evaluate their tiles; the rest have them prebuilt in A
-  int* ready;           // [P] block columns whose L(k,k) is published (in-kernel solve); zeroed per sweep
-  int wsteps;           // 1: W holds the current step's inverses only; nt: W keeps every step (gradient path)
-  int rl;               // factor mode, right-looking schedule: the tile already holds C(k,k) (no left-looking sum)
-  int j0;               // Schur mode: the sum runs over block columns [j0, nt1) (right-looking: one column)
-  // Block-extension sweeps over the resident factor store (agp_logpdf_batch_extend): particle p's storage (A, W, vec,
-  // partial, info, ready) is slot[p] instead of p, and tile rows below i0[p] already hold its factor from an earlier
-  // sweep on a shorter prefix of the data — their workgroups leave at once.  Both null in ordinary sweeps.
-  const int* slot;
-  const int* i0;
-  int ntp;              // row stride of `partial` per storage index (0: nt)
-  // Dataflow schedule (k_chol_flow): one int per tile and storage index (row-major lower triangle, ntri per
-  // particle), raised when the tile holds its final L(i,k); per-XCD ticket counters of the work queue.
-  int* tflag;
-  int ntri;
-  int* qnext;
-  long long* trace;     // optional (agp_debug_flow_trace): per item {start, end, wait} in 100 MHz ticks + {item info}
-  int schur_diag_only;  // Schur mode: only the diagonal tiles of the prediction block (marginal variances + mean; no covariance)
-  int lag;              // 1: sorted regular grid, the fused programs' stationary leaves are OP_LAG_* (GM = 2 instantiations)
-  const double* lagtab; // ... and their tables (k_lag_tables)
-  const int32_t* lagr;  // rank tables (sweeps in the caller's order; see cov_prologue): ranks of the resident points, null = sorted sweep
-  int lag_stride;       // ... doubles per table
-};
 __device__ __forceinline__ double readlane_d(double v, int lane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, lane);
@@ -87,21 +41,8 @@ __device__ __forceinline__ d4 mfma(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
-// LDS byte budget of the update kernel: GEMM double buffers and the potrf block store alias.
-constexpr int U_SLAB = KB * LDS_STRIDE;                // doubles per slab buffer
-constexpr int U_GEMM_DOUBLES = 4 * U_SLAB;             // As[2], Bs[2]      = 9216
-constexpr int U_BLK_DOUBLES = (NSB * (NSB + 1) / 2) * 256;  // 36 blocks   = 9216
-constexpr int U_MAIN_DOUBLES = (U_GEMM_DOUBLES > U_BLK_DOUBLES) ? U_GEMM_DOUBLES : U_BLK_DOUBLES;
-// extras: rvec[128], avec[128] (alpha_k), xv[2][16] (alpha_j slab staging), Wl[256]
-constexpr int U_EXTRA_DOUBLES = 128 + 128 + 64 + 256;
-constexpr int U_LDS_BYTES = (U_MAIN_DOUBLES + U_EXTRA_DOUBLES) * 8;
-
 __device__ __forceinline__ int blk_idx(int rb, int cb) { return rb * (rb + 1) / 2 + cb; }
 __device__ __forceinline__ int tri_idx(int i, int j) { return i * (i + 1) / 2 + j; }     // tile (i,j) in the packed lower triangle
-
-// Largest number of ChangePoint nodes whose sigma tables fit the (aliased) LDS of the fused path.
-// LDS map of the fused phase (aliases the slab buffers): tpt[256] | sig[n_cp][256] | prm[n_prm] | ops[n_ops] (int)
-constexpr int U_MAX_CP = (U_MAIN_DOUBLES - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_OPS_DEV / 2 - 8) / 256;
 
 // Wave tiling: wave w owns rows [32w, 32w+32) of the tile across all 128 columns (accumulators
 // acc[cb][st]: column block cb = 0..7, strip st = 0 / 1 = the even / odd rows of the wave's 32).
@@ -123,9 +64,6 @@ constexpr int U_MAX_CP = (U_MAIN_DOUBLES - 256 - 3 * AGP_MAX_OPS_DEV - AGP_MAX_O
 // nothing: NOTES_dead_ends.md).
 __device__ __forceinline__ void mfma_prio_on() { __builtin_amdgcn_s_setprio(1); }
 __device__ __forceinline__ void mfma_prio_off() { __builtin_amdgcn_s_setprio(0); }
-constexpr int T_NBLK = NSB * (NSB - 1) / 2;              // 28 strictly-lower 16x16 blocks
-constexpr int T_LDS_DOUBLES = (T_NBLK + NSB) * 256;      // + 8 inverse blocks = 72 KiB
-static_assert(T_LDS_DOUBLES <= U_MAIN_DOUBLES, "solve staging must fit the aliased slab buffers");
 __device__ __forceinline__ int sblk_idx(int jb, int lb) { return jb * (jb - 1) / 2 + lb; }   // lb < jb
 
 // Factor the 128x128 diagonal tile whose -C(k,k) lower 16x16 blocks have been staged in `sm` (block (rb,cb) at
@@ -1257,6 +1195,8 @@ __global__ __launch_bounds__(256, 2) void k_chol_flow(CholArgs a0) {
   }
 }
 
+// ---- non-template kernels: compiled by the translation unit that launches them (agp_kernels.hip) ----
+#ifdef AGP_KERNEL_TU_MAIN
 // K2a — the diagonal tiles of block column k, one workgroup per particle.  Only the lower block triangle of
 // C(k,k) = A(k,k) - sum_j L(k,j) L(k,j)^T is formed: wave w owns the 16-row blocks w (strip 0) and 7-w (strip 1),
 // i.e. NINE 16x16 accumulator blocks per wave whatever w is — entry e of the wave's list is (strip 0, column block
@@ -1416,13 +1356,6 @@ __global__ void k_init_flow_flags(int* tflag, int ntri_stride, int ntri, const i
 // prefix): particle p takes tile rows < nt1 of L, the per-column inverse blocks and alpha = L^-1 y from store slot
 // src_slot[p] (< 0: no resident factor, nothing copied).  The first nt1 tile rows of the packed layout are a contiguous
 // prefix, so this is three straight copies per particle; ready[p] = nt1 publishes the columns to the panel solves.
-struct GatherArgs {
-  double* dstA; long long dst_strideA; const double* srcA; long long src_strideA; long long nA;      // doubles
-  double* dstW; long long dst_strideW; const double* srcW; long long src_strideW; long long nW;
-  double* dstV; long long dst_strideV; const double* srcV; long long src_strideV; long long nV;
-  double* dstP; long long dst_strideP; const double* srcP; long long src_strideP; long long nP;      // log-det / quadratic-form partials (nP = 0: not wanted)
-  const int* src_slot; int* ready; int nt1;
-};
 __global__ __launch_bounds__(256) void k_gather_factor(GatherArgs g) {
   const int p = blockIdx.y;
   const int sl = g.src_slot[p];
@@ -1462,18 +1395,6 @@ __global__ void k_init_vec(double* vec, int ldv, int P, const double* xs, const 
 
 // Predictive read-out (src/GP.jl:753-757): mean = mu2 + K21 K11^-1 (x - mu1),
 // cov = sym(K22 - K21 K11^-1 K12) + noise_pred I, var = diag(cov).
-struct PredArgs {
-  const double* A; long long strideA;
-  const double* vec; int ldv;
-  const double* mu2;        // [m] or null
-  const double* noise_pred; // [P]
-  const double* diag_add;   // [m] extra diagonal term per prediction point (infer_gp_sum) or null
-  int nt1, n1_pad, m, P;
-  double* out_mean;         // [P][m]
-  double* out_var;          // [P][m]
-  double* out_cov;          // [P][m*m] or null
-};
-
 __global__ void k_pred_extract(PredArgs a) {
   const int p = blockIdx.y;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1589,5 +1510,7 @@ __global__ __launch_bounds__(256, 2) void k_mfma_peak(double* out, long long* cy
   out[(long long)blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
+
+#endif  // AGP_KERNEL_TU_MAIN
 
 }  // namespace agp

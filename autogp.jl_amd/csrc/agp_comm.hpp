@@ -65,16 +65,4 @@ __host__ __device__ inline void shard_range(int P, int rank, int n_ranks, int* l
   *hi = *lo + base + (rank < rem ? 1 : 0);
 }
 
-// Uneven shards travel padded to the largest shard (ncclAllGather moves equal counts); this un-pads.
-__global__ void k_compact_shards(const double* __restrict__ padded, int mx, int P, int n_ranks, double* __restrict__ out) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= P) return;
-  const int base = P / n_ranks, rem = P % n_ranks;
-  // owner of particle g under shard_range
-  int r = (g < rem * (base + 1)) ? g / (base + 1) : rem + (base > 0 ? (g - rem * (base + 1)) / base : 0);
-  int lo, hi;
-  shard_range(P, r, n_ranks, &lo, &hi);
-  out[g] = padded[(long long)r * mx + (g - lo)];
-}
-
 }  // namespace agp

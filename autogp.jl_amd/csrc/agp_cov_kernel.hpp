@@ -21,36 +21,10 @@
 #define AGP_EXP_TABLE 1
 #endif
 #include "agp_common.hpp"
+#include "agp_args.hpp"
 #include "agp_math.hpp"
 
 namespace agp {
-
-struct CovArgs {
-  const double* tt;      // time points in padded joint layout, length nt*NB
-  int n1;                // valid training points  [0, n1)
-  int n1_pad;            // start of the prediction segment (multiple of NB)
-  int m2;                // valid prediction points [n1_pad, n1_pad+m2)
-  int nt;                // tiles per dimension
-  const ProgHdr* hdr;    // [P]
-  const uint8_t* ops;
-  const double* prm;
-  const double* noise;   // [P] added on the diagonal of the training block
-  double* A;             // packed tiles, per-particle stride strideA
-  long long strideA;
-  int P;
-  int p_off;             // first particle (blockIdx.y is relative to it)
-  const uint8_t* code;   // per joint point: 0 observable, i latent of component i (infer_gp_sum); null = all 0
-  const double* logdt;   // packed lower tiles of log|t_i - t_j| over the resident data (programs with flags bit 0)
-  const int* slot;       // extension sweeps (see CholArgs): storage index per particle, first tile row to (re)build
-  const int* i0;
-  int skip_pred_offdiag; // prediction without a covariance request: off-diagonal tiles of the K22 block are never read
-  int pred_only;         // 1: only the tiles of the prediction block (both indices past the training rows)
-  const double* lagtab;  // lag tables of the sweep's OP_LAG_* leaves (k_lag_tables): [table][block lag 0..nt-1][256]
-  const int32_t* lagr;   // RANK lag tables (regular grid, points in the caller's order; null: sorted sweep): rank of every resident
-  int lag_stride;        //   point in the sorted series; a leaf's table then holds all lag_stride lags 0 .. n_max-1 (see cov_prologue)
-  int csplit;            // 4: a tile is shared by four workgroups (grid.z; 32 columns each) — launches of a few large trees,
-                         // whose length is ONE workgroup's walk over its tile (launch_cov); otherwise one workgroup per tile
-};
 
 __device__ __forceinline__ int prm_count(int o) {
   // WN, CONST, LIN, SE, GE, PER, PLUS, TIMES, CP, CP_SWAP
@@ -353,18 +327,10 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
   }
 }
 
+#ifdef AGP_KERNEL_TU_MAIN      // (non-template kernels: compiled by agp_kernels.hip only)
 // The lag tables of a sweep on a sorted regular grid (see cov_prologue): block (bl, t) evaluates table t's program — a
 // stationary subtree in the direct device form — at the 255 lags 128 bl + d, d = -127 .. 127 (entry d + 127; entry 255 unused),
 // with the evaluator of the general path on the "element" (t_|g|, t_0).
-struct LagArgs {
-  const double* tt;        // sorted time points
-  const LagTabHdr* thdr;   // [n_tables]
-  const uint8_t* tops;
-  const double* tprm;
-  double* tab;             // [table][nt][256]; full: [table][stride]
-  int nt, n_tables;
-  int full, stride;        // full = 1: rank tables — grid.x = stride / 256 blocks of lags 256 bl + tid, 0 .. stride-1
-};
 __global__ __launch_bounds__(256) void k_lag_tables(LagArgs a) {
   const int t = blockIdx.y, bl = blockIdx.x, tid = threadIdx.x;
   __shared__ double etab[AGP_EXP_TAB_N];
@@ -399,5 +365,7 @@ __global__ __launch_bounds__(256) void k_logdt_tiles(const double* __restrict__ 
     out[e] = dt > 0.0 ? fm::log_f(dt) : LOGDT_ZERO;
   }
 }
+
+#endif  // AGP_KERNEL_TU_MAIN
 
 }  // namespace agp

@@ -121,59 +121,6 @@ __device__ __forceinline__ void solve_in_regs(d4 (&acc)[NSB][2], const double* _
   }
 }
 
-struct GradArgs {
-  const double* A;       // packed lower tiles of L
-  double* Z;             // packed buffer holding Z(r,k), r <= k, in the slot of lower tile (k,r)
-  long long strideA;
-  const double* W;       // [P][nt][NSB][256] per-step 16x16 inverses
-  const double* beta;    // [P][ldv]  L^-1 x
-  double* alpha;         // [P][ldv]  K^-1 x
-  int ldv;
-  int P, nt, n;          // n = valid points (no prediction segment here)
-  // gradient programs (device order; see GProgHdr)
-  const struct GProgHdr* ghdr;
-  const uint8_t* gops;   // opcode per node
-  const uint8_t* glc;    // left / right child node index per node (binary nodes)
-  const uint8_t* grc;
-  const int32_t* gpoff;  // per node: offset of its parameters inside the particle's parameter block
-  const double* gprm;    // ORIGINAL (untransformed-by-us) parameter values, device node order
-  const double* tt;      // time points (padded)
-  const double* logdt;   // log|dt| table of the resident data (null: GammaExp leaves compute the power); see CovArgs
-  double* gpart;         // [P][ntiles][gstride] per-tile partial sums (slot 0..n_prm-1 params, n_prm = noise)
-  int gstride;
-  const int32_t* gmap;   // per particle parameter slot -> index in the caller's parameter array
-  const int32_t* out_off;   // [P] offset of the particle's gradient block in out_grad (caller order, via map)
-  const int32_t* pmap;   // sorted particle -> caller particle
-  const int32_t* plist;  // k_grad_contract / k_lag_grad: particles of this launch (indices into the sorted group)
-  int tape_off;          // k_grad_contract<0>: offset (doubles) of the LDS tape inside the dynamic shared memory
-  // resident factors (nullable): particle p with lslot[p] >= 0 reads L and the inverse blocks from the factor store
-  // (slot lslot[p]; Lstride doubles per slot, Wnt block columns per slot) instead of A / W — nothing is copied
-  const int32_t* lslot; const double* Lsrc; long long Lstride; const double* Wsrc; int Wnt;
-  double* out_grad;
-  double* out_gnoise;
-  // lag-domain contraction (regular time grids; see k_lag_grad): rank of every resident point in the sorted series, the sorted
-  // series itself, number of lag bins (= resident points), reference time of the Linear moments
-  const int32_t* rank; const double* tts; int nbins; double tref;
-  const double* tw;      // exp(-2 pi i k / 4096), k = 0 .. 4095, (re, im) pairs (k_zspec / k_lag_grad)
-  const int32_t* klist; int kn;      // k_kinv_tiles: the particles whose K^-1 tiles are wanted (null: all P)
-  double grid_h, grid_mid;           // regular grid: spacing, and the (fractional) rank of t_ref: t_sorted[r] - t_ref = (r - grid_mid) h
-};
-
-struct GProgHdr {
-  int32_t node_off;   // offset into gops / glc / grc / gpoff
-  int32_t prm_off;    // offset into gprm / gmap
-  int32_t n_ops;
-  int32_t n_prm;
-  int32_t n_cp;
-  int32_t flags;      // bit 0: the tree has GammaExp leaves (reads the log|dt| table when there is one)
-                      // bit 1: lag-domain contraction (k_kinv_tiles bins G by lag, k_lag_grad differentiates n lags instead of n^2 elements)
-};
-                      // bit 2 (with bit 1): the lag sums of K^-1 come from the power spectrum of Z's columns (k_zspec), no K^-1 tiles at all
-constexpr int GFLAG_LAGDOM = 2;
-constexpr int GFLAG_LAGFFT = 4;
-constexpr int LAGDOM_MAX_BINS = 4096;      // LDS histogram of k_kinv_tiles (32 KiB)
-constexpr int FFT_N = 4096;                // transform length of the spectral variant: series of up to FFT_N / 2 points
-
 __device__ __forceinline__ long long zoff(int r, int k) { return tile_off(k, r); }   // r <= k
 
 // ---- Z = L^-T, one workgroup per (particle, block ROW j of Z): the whole chain Z(j,j), Z(j,j+1), ... in one launch.
@@ -244,7 +191,6 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
 // scratch memory; any tree size).  LdsTape: one column of a [node][element][thread] array in LDS (trees of <= LDS_TAPE_NODES
 // nodes): the backward sweep is a chain of dependent tape round trips per node, ~60 cycles each in LDS instead of a
 // global-memory round trip (measured: ~6 ms per tree node and 512-particle sweep at n=2048 with the scratch tape).
-constexpr int LDS_TAPE_NODES = 8;
 template <int MAXS, int E>
 struct RegTape {
   double v[MAXS][E];
@@ -613,7 +559,6 @@ __device__ __forceinline__ int rev4_12(int x) {                 // reverse the s
 // Three radix-16 passes (each = two radix-4 stages on 16 numbers a thread holds in registers: half the LDS traffic and barriers of
 // six radix-4 stages); element i lives at i + i/16 (one pad per 16: the last pass reads 16 consecutive numbers per lane).  The
 // twiddle factors a thread needs depend on its index alone.
-constexpr int FFT_BUF = FFT_N + FFT_N / 16;
 __device__ __forceinline__ int fft_pad(int i) { return i + (i >> 4); }
 // x * exp(-2 pi i k / 16), k a compile-time constant 0..9
 template <int K>

@@ -98,7 +98,7 @@ AGP_HD double exp_f(double x) {
     1.9571441241754002, 1.9677712232331759, 1.978456026387951, 1.9891988469672663
 static const double EXP_TAB[AGP_EXP_TAB_N] = {AGP_EXP_TAB_VALUES};
 #if defined(__HIPCC__)
-__device__ __constant__ double c_exp_tab[AGP_EXP_TAB_N] = {AGP_EXP_TAB_VALUES};      // copied into LDS by the kernels that evaluate covariances
+static __device__ __constant__ double c_exp_tab[AGP_EXP_TAB_N] = {AGP_EXP_TAB_VALUES};      // copied into LDS by the kernels that evaluate covariances
 #endif
 AGP_HD double exp_t(double x, const double* tab) {
   const double INV = 184.6649652337873;                 // 128 / ln 2

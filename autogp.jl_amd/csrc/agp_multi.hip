@@ -1,0 +1,354 @@
+// Host side of the C ABI, unit 4: the log-weight all-gather over RCCL and the one-process-drives-the-node entries.
+#include "agp_host.hpp"
+
+
+// ==========================================================================================
+// Multi-GPU: particles are block-sharded over the ranks (independent units, matrices never leave their GPU); the
+// only exchange of the path is the all-gather of the per-particle log-weights before ESS / resampling
+// (src/inference_smc_anneal_data.jl:22-31,232).  RCCL over xGMI, on the engine's own stream or the caller's.
+// ==========================================================================================
+namespace {
+
+#define NCCLCHK(ctx, expr)                                                                   \
+  do {                                                                                       \
+    ncclResult_t r_ = (expr);                                                                \
+    if (r_ != ncclSuccess) {                                                                 \
+      char buf_[512];                                                                        \
+      snprintf(buf_, sizeof buf_, "RCCL error %d (%s) at %s:%d: %s", (int)r_,                \
+               rccl().GetErrorString ? rccl().GetErrorString(r_) : "?", __FILE__, __LINE__, #expr); \
+      return fail(ctx, AGP_ERR_COMM, buf_);                                                  \
+    }                                                                                        \
+  } while (0)
+
+int need_rccl(agp_ctx* c) {
+  if (!rccl().ok()) return fail(c, AGP_ERR_COMM, rccl().error.empty() ? "librccl unavailable" : rccl().error);
+  return AGP_OK;
+}
+
+// Enqueue the all-gather of this rank's shard (device, hi - lo doubles) into d_all (device, P doubles) on `st`.
+// Equal shards go straight through ncclAllGather; uneven ones travel padded to the largest shard and are compacted.
+// `in_group`: the caller brackets several contexts' gathers in one ncclGroupStart/End (single-process multi-device),
+// the compaction is then enqueued by finish_gather after the group has been issued.
+int enqueue_gather(agp_ctx* c, const double* d_local, int P, double* d_all, hipStream_t st) {
+  int lo, hi;
+  shard_range(P, c->comm_rank, c->comm_size, &lo, &hi);
+  const int R = c->comm_size, mx = (P + R - 1) / R;
+  if (P % R == 0) {
+    NCCLCHK(c, rccl().AllGather(d_local, d_all, (size_t)mx, ncclDouble, c->comm, st));
+    return AGP_OK;
+  }
+  HIPCHK(c, c->comm_in.ensure(sizeof(double) * (size_t)mx));
+  HIPCHK(c, c->comm_out.ensure(sizeof(double) * (size_t)mx * R));
+  HIPCHK(c, hipMemsetAsync(c->comm_in.p, 0, sizeof(double) * (size_t)mx, st));
+  if (hi > lo) HIPCHK(c, hipMemcpyAsync(c->comm_in.p, d_local, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToDevice, st));
+  NCCLCHK(c, rccl().AllGather(c->comm_in.p, c->comm_out.p, (size_t)mx, ncclDouble, c->comm, st));
+  return AGP_OK;
+}
+int finish_gather(agp_ctx* c, int P, double* d_all, hipStream_t st) {
+  const int R = c->comm_size, mx = (P + R - 1) / R;
+  if (P % R == 0) return AGP_OK;
+  launch_compact_shards(st, c->comm_out.as<double>(), mx, P, R, d_all);
+  HIPCHK(c, hipGetLastError());
+  return AGP_OK;
+}
+
+int ensure_comm_stream(agp_ctx* c) {
+  if (!c->comm_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  return AGP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void agp_shard_range(int32_t P, int32_t rank, int32_t n_ranks, int32_t* lo, int32_t* hi) {
+  int l = 0, h = 0;
+  if (n_ranks > 0 && rank >= 0 && rank < n_ranks && P >= 0) shard_range(P, rank, n_ranks, &l, &h);
+  if (lo) *lo = l;
+  if (hi) *hi = h;
+}
+
+int agp_comm_get_unique_id(void* out_id) {
+  if (!out_id) return fail(nullptr, AGP_ERR_ARG, "null id pointer");
+  int rc = need_rccl(nullptr);
+  if (rc) return rc;
+  static_assert(sizeof(ncclUniqueId) == AGP_COMM_ID_BYTES, "AGP_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+  ncclUniqueId id;
+  NCCLCHK(nullptr, rccl().GetUniqueId(&id));
+  std::memcpy(out_id, &id, sizeof id);
+  return AGP_OK;
+}
+
+int agp_comm_init_rank(agp_ctx* c, const void* id_bytes, int32_t n_ranks, int32_t rank) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (!id_bytes || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(c, AGP_ERR_ARG, "bad communicator arguments");
+  int rc = need_rccl(c);
+  if (rc) return rc;
+  std::lock_guard<std::mutex> g(c->comm_mu);
+  if (c->comm) return fail(c, AGP_ERR_ARG, "this context already has a communicator");
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId id;
+  std::memcpy(&id, id_bytes, sizeof id);
+  NCCLCHK(c, rccl().CommInitRank(&c->comm, n_ranks, id, rank));
+  c->comm_rank = rank; c->comm_size = n_ranks;
+  return ensure_comm_stream(c);
+}
+
+int agp_comm_info(agp_ctx* c, int32_t* rank, int32_t* n_ranks) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (rank) *rank = c->comm_rank;
+  if (n_ranks) *n_ranks = c->comm_size;
+  return c->comm ? 1 : 0;
+}
+
+int agp_comm_count(agp_ctx* c, int32_t* out_n_ranks) {
+  if (!c || !out_n_ranks) return fail(c, AGP_ERR_ARG, "null pointer");
+  *out_n_ranks = 0;
+  if (!c->comm) return AGP_OK;
+  int rc = need_rccl(c);
+  if (rc) return rc;
+  int cnt = 0;
+  NCCLCHK(c, rccl().CommCount(c->comm, &cnt));
+  *out_n_ranks = cnt;
+  return AGP_OK;
+}
+
+int agp_init_multi(agp_ctx** out, const int32_t* device_ids, int32_t n_dev) {
+  if (!out || !device_ids || n_dev < 1) return fail(nullptr, AGP_ERR_ARG, "bad arguments");
+  for (int i = 0; i < n_dev; ++i) out[i] = nullptr;
+  for (int i = 0; i < n_dev; ++i)
+    for (int j = 0; j < i; ++j)
+      if (device_ids[i] == device_ids[j]) return fail(nullptr, AGP_ERR_ARG, "duplicate device id");
+  int rc = need_rccl(nullptr);
+  if (rc) return rc;
+  auto undo = [&]() { for (int i = 0; i < n_dev; ++i) { if (out[i]) agp_destroy(out[i]); out[i] = nullptr; } };
+  for (int i = 0; i < n_dev; ++i) {
+    rc = agp_init(&out[i], device_ids[i]);
+    if (rc) { undo(); return rc; }
+  }
+  std::vector<ncclComm_t> comms((size_t)n_dev, nullptr);
+  std::vector<int> devs(device_ids, device_ids + n_dev);
+  ncclResult_t r = rccl().CommInitAll(comms.data(), n_dev, devs.data());
+  if (r != ncclSuccess) {
+    undo();
+    return fail(nullptr, AGP_ERR_COMM, std::string("ncclCommInitAll failed: ") + rccl().GetErrorString(r));
+  }
+  for (int i = 0; i < n_dev; ++i) {
+    out[i]->comm = comms[i]; out[i]->comm_rank = i; out[i]->comm_size = n_dev;
+    if (hipSetDevice(device_ids[i]) != hipSuccess || ensure_comm_stream(out[i]) != AGP_OK) { undo(); return fail(nullptr, AGP_ERR_HIP, "stream creation failed"); }
+  }
+  return AGP_OK;
+}
+
+int agp_set_data_multi(agp_ctx* const* ctxs, int32_t n_dev, const double* ts, const double* xs, int64_t n_max) {
+  if (!ctxs || n_dev < 1) return fail(nullptr, AGP_ERR_ARG, "bad arguments");
+  for (int i = 0; i < n_dev; ++i) {
+    const int rc = agp_set_data(ctxs[i], ts, xs, n_max);
+    if (rc) return rc;
+  }
+  return AGP_OK;
+}
+
+// (c->comm_mu held by the caller)
+static int allgather_device_locked(agp_ctx* c, const double* d_local, int32_t P, double* d_all, void* hip_stream) {
+  if (!c->comm) {
+    // no communicator: a population that lives on this GPU alone
+    if (c->comm_size != 1) return fail(c, AGP_ERR_COMM, "no communicator");
+    int rc = ensure_comm_stream(c);
+    if (rc) return rc;
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->comm_stream;
+    if (d_all != d_local) HIPCHK(c, hipMemcpyAsync(d_all, d_local, sizeof(double) * (size_t)P, hipMemcpyDeviceToDevice, st));
+    if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
+    return AGP_OK;
+  }
+  hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->comm_stream;
+  int rc = enqueue_gather(c, d_local, P, d_all, st);
+  if (rc) return rc;
+  rc = finish_gather(c, P, d_all, st);
+  if (rc) return rc;
+  if (!hip_stream) HIPCHK(c, hipStreamSynchronize(st));
+  return AGP_OK;
+}
+
+int agp_allgather_logweights_device(agp_ctx* c, const double* d_local, int32_t P, double* d_all, void* hip_stream) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (P < 0 || (P > 0 && !d_all)) return fail(c, AGP_ERR_ARG, "bad arguments");
+  if (P == 0) return AGP_OK;
+  int lo, hi;
+  shard_range(P, c->comm_rank, c->comm_size, &lo, &hi);
+  if (hi > lo && !d_local) return fail(c, AGP_ERR_ARG, "null shard pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::lock_guard<std::mutex> g(c->comm_mu);
+  return allgather_device_locked(c, d_local, P, d_all, hip_stream);
+}
+
+// Test hook for the un-padding step of unequal shards (a one-GPU box can only form a one-rank communicator, where every
+// block is "equal"): `padded` holds n_ranks blocks of ceil(P / n_ranks) doubles as ncclAllGather would deliver them.
+int agp_debug_compact_shards(agp_ctx* c, const double* padded, int32_t P, int32_t n_ranks, double* out) {
+  if (!c || !padded || !out || P <= 0 || n_ranks <= 0) return fail(c, AGP_ERR_ARG, "bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int mx = (P + n_ranks - 1) / n_ranks;
+  double *d_in = nullptr, *d_out = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_in, sizeof(double) * (size_t)mx * n_ranks));
+  HIPCHK(c, hipMalloc((void**)&d_out, sizeof(double) * (size_t)P));
+  HIPCHK(c, hipMemcpy(d_in, padded, sizeof(double) * (size_t)mx * n_ranks, hipMemcpyHostToDevice));
+  launch_compact_shards(0, d_in, mx, P, n_ranks, d_out);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpy(out, d_out, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost));
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return AGP_OK;
+}
+
+int agp_allgather_logweights(agp_ctx* c, double* inout_lw, int32_t P) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (P < 0 || (P > 0 && !inout_lw)) return fail(c, AGP_ERR_ARG, "bad arguments");
+  if (P == 0 || c->comm_size == 1) return AGP_OK;          // a one-rank population is already complete
+  if (!c->comm) return fail(c, AGP_ERR_COMM, "no communicator: call agp_comm_init_rank or agp_init_multi first");
+  HIPCHK(c, hipSetDevice(c->device));
+  int lo, hi;
+  shard_range(P, c->comm_rank, c->comm_size, &lo, &hi);
+  // the staging buffer belongs to the context: the lock covers its (re)allocation AND its use
+  std::lock_guard<std::mutex> g(c->comm_mu);
+  HIPCHK(c, c->comm_all.ensure(sizeof(double) * (size_t)P * 2));
+  double* d_all = c->comm_all.as<double>();
+  double* d_loc = d_all + P;
+  if (hi > lo) HIPCHK(c, hipMemcpyAsync(d_loc, inout_lw + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyHostToDevice, c->comm_stream));
+  int rc = allgather_device_locked(c, d_loc, P, d_all, c->comm_stream);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(inout_lw, d_all, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, c->comm_stream));
+  HIPCHK(c, hipStreamSynchronize(c->comm_stream));
+  return AGP_OK;
+}
+
+// One host process driving every GPU of the node (the deployment of a single Julia process): block-shard the P
+// particles over the contexts of agp_init_multi, run each shard's sweep from its own host thread with the results
+// left on its device, all-gather the log-weights over RCCL (one group call over the node's communicators), and
+// hand the complete vector back from device 0.  Every device ends up holding the full vector.
+static agp_ctx::Worker* ensure_worker(agp_ctx* c) {
+  if (c->worker) return c->worker;
+  agp_ctx::Worker* w = new agp_ctx::Worker();
+  c->worker = w;
+  const int dev = c->device;
+  w->th = std::thread([w, dev]() {
+    (void)hipSetDevice(dev);
+    std::unique_lock<std::mutex> g(w->mu);
+    for (;;) {
+      w->cv.wait(g, [&] { return w->has_job || w->stop; });
+      if (w->stop) return;
+      std::function<void()> job;
+      job.swap(w->job);
+      w->has_job = false;
+      g.unlock();
+      job();
+      g.lock();
+      w->done = true;
+      w->cv.notify_all();
+    }
+  });
+  return w;
+}
+
+static int logpdf_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off,
+                                   const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
+                                   double* out_logpdf, int32_t* out_info, bool extend) {
+  if (!ctxs || n_dev < 1 || !ctxs[0]) return fail(nullptr, AGP_ERR_ARG, "bad context list");
+  agp_ctx* c0 = ctxs[0];
+  if (P < 0 || n < 0) return fail(c0, AGP_ERR_ARG, "negative size");
+  if (P == 0) return AGP_OK;
+  if (!op_off || !ops || !prm_off || !prm || !noise || !out_logpdf || !out_info) return fail(c0, AGP_ERR_ARG, "null pointer argument");
+  for (int d = 0; d < n_dev; ++d)
+    if (!ctxs[d] || ctxs[d]->comm_size != n_dev || ctxs[d]->comm_rank != d || (n_dev > 1 && !ctxs[d]->comm))
+      return fail(c0, AGP_ERR_ARG, "contexts must come from agp_init_multi, in order");
+  const int mx = (P + n_dev - 1) / n_dev;
+  // One population step at a time (what the reference's SMC loop issues, src/inference_smc_anneal_data.jl:206-232): concurrent
+  // callers are serialised here — the per-device worker threads hold a single job slot each.
+  std::lock_guard<std::mutex> multi_lock(c0->multi_mu);
+  std::vector<int> rcs((size_t)n_dev, AGP_OK);
+  auto shard = [&](int d) {
+    agp_ctx* c = ctxs[d];
+    int lo, hi;
+    shard_range(P, d, n_dev, &lo, &hi);
+    if (hipSetDevice(c->device) != hipSuccess) { rcs[d] = fail(c, AGP_ERR_HIP, "hipSetDevice failed"); return; }
+    {
+      std::lock_guard<std::mutex> g(c->comm_mu);
+      if (c->comm_all.ensure(sizeof(double) * ((size_t)P + mx)) != hipSuccess) { rcs[d] = fail(c, AGP_ERR_HIP, "allocation failed"); return; }
+    }
+    if (hi == lo) return;
+    const int Pl = hi - lo;
+    std::vector<int32_t> oo((size_t)Pl + 1), po((size_t)Pl + 1);
+    for (int i = 0; i <= Pl; ++i) { oo[i] = op_off[lo + i] - op_off[lo]; po[i] = prm_off[lo + i] - prm_off[lo]; }
+    double* d_loc = c->comm_all.as<double>() + P;
+    if (extend) {
+      // every device keeps the factors of ITS shard resident (block sharding is stable while the population order is;
+      // a particle that lands on another device after resampling is simply factored from scratch there).  The shard's
+      // log-weights are also left on the device, in caller order, for the gather (no host round trip).
+      std::vector<double> hl((size_t)Pl);
+      bool on_device = false;
+      rcs[d] = extend_impl(c, n, Pl, oo.data(), ops + op_off[lo], po.data(), prm + prm_off[lo], noise + lo, hl.data(), out_info + lo,
+                           d_loc, &on_device);
+      if (rcs[d] == AGP_OK && !on_device &&      // (n = 0, or the sweep fell back to the plain entry: host results only)
+          hipMemcpy(d_loc, hl.data(), sizeof(double) * (size_t)Pl, hipMemcpyHostToDevice) != hipSuccess)
+        rcs[d] = fail(c, AGP_ERR_HIP, "copy of the shard's log-weights failed");
+    } else {
+      rcs[d] = logpdf_batch_impl(c, n, Pl, oo.data(), ops + op_off[lo], po.data(), prm + prm_off[lo], noise + lo, nullptr,
+                                 out_info + lo, d_loc, nullptr, nullptr, false);
+    }
+  };
+  // devices 1 .. n_dev-1 run on their contexts' persistent host threads (created at the first call, joined by
+  // agp_destroy), device 0's shard on the calling thread
+  for (int d = 1; d < n_dev; ++d) {
+    agp_ctx::Worker* w = ensure_worker(ctxs[d]);
+    { std::lock_guard<std::mutex> g(w->mu); w->job = [&shard, d]() { shard(d); }; w->has_job = true; w->done = false; }
+    w->cv.notify_all();
+  }
+  shard(0);
+  for (int d = 1; d < n_dev; ++d) {
+    agp_ctx::Worker* w = ctxs[d]->worker;
+    std::unique_lock<std::mutex> g(w->mu);
+    w->cv.wait(g, [&] { return w->done; });
+  }
+  for (int d = 0; d < n_dev; ++d)
+    if (rcs[d]) { if (d) fail(c0, rcs[d], agp_last_error(ctxs[d])); return rcs[d]; }
+  if (n_dev == 1) {
+    HIPCHK(c0, hipSetDevice(c0->device));
+    HIPCHK(c0, hipMemcpy(out_logpdf, c0->comm_all.as<double>() + P, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost));
+    return AGP_OK;
+  }
+  NCCLCHK(c0, rccl().GroupStart());
+  for (int d = 0; d < n_dev; ++d) {
+    agp_ctx* c = ctxs[d];
+    HIPCHK(c0, hipSetDevice(c->device));
+    const int rc = enqueue_gather(c, c->comm_all.as<double>() + P, P, c->comm_all.as<double>(), c->comm_stream);
+    if (rc) { (void)rccl().GroupEnd(); return rc; }
+  }
+  NCCLCHK(c0, rccl().GroupEnd());
+  for (int d = 0; d < n_dev; ++d) {
+    agp_ctx* c = ctxs[d];
+    HIPCHK(c0, hipSetDevice(c->device));
+    const int rc = finish_gather(c, P, c->comm_all.as<double>(), c->comm_stream);
+    if (rc) return rc;
+  }
+  for (int d = n_dev - 1; d >= 0; --d) {
+    HIPCHK(c0, hipSetDevice(ctxs[d]->device));
+    if (d == 0) HIPCHK(c0, hipMemcpyAsync(out_logpdf, c0->comm_all.p, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, c0->comm_stream));
+    HIPCHK(c0, hipStreamSynchronize(ctxs[d]->comm_stream));
+  }
+  return AGP_OK;
+}
+
+int agp_logpdf_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off,
+                           const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
+                           double* out_logpdf, int32_t* out_info) {
+  return logpdf_batch_multi_impl(ctxs, n_dev, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, false);
+}
+
+// The same with resident factors: every device runs its shard as an extension sweep (agp_logpdf_batch_extend) — the
+// reweight step of data annealing for ONE process driving the node.
+int agp_logpdf_batch_extend_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off,
+                                  const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
+                                  double* out_logpdf, int32_t* out_info) {
+  return logpdf_batch_multi_impl(ctxs, n_dev, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, true);
+}
+
+}  // extern "C"
+

@@ -1,0 +1,724 @@
+// Host side of the C ABI, unit 2: predictive entries (src/GP.jl:731-758, 904-993), matrix assembly and the probe entries.
+#include "agp_host.hpp"
+#ifdef AGP_EXPERIMENTS
+#include "experiments/agp_experiments_abi.h"
+#include "experiments/agp_experiments.hpp"   // ablation kernels of the update GEMM (measurement builds only: libautogp_hip_exp.so)
+#endif
+
+
+#ifdef AGP_EXPERIMENTS
+template <int VAR>
+static void launch_variant(hipStream_t st, int grid, const CholArgs& ca) {
+  hipLaunchKernelGGL(k_gemm_variant<VAR>, dim3(grid), dim3(256), 0, st, ca);
+}
+#endif
+namespace {
+
+// Core of the predictive path (src/GP.jl:739-757) for a compiled batch.  `pred_code` / `diag_add`
+// (both per prediction point, nullable) are what infer_gp_sum adds: component codes of the query
+// points and an extra diagonal term.  `keys` (nullable; per particle, caller order) are the factor-store keys of the
+// particles: one whose factor of exactly this prefix is resident (an extension sweep scored it: the per-step callback of
+// the streaming workload, scripts/online.jl:43, predicts right after the reweight) skips K11 and its factorisation.
+// Query points on the series' own lattice.  In every use of the reference the query set is `train + test + future` at the
+// data's cadence (scripts/online.jl:41-43: ds_query = vcat(model.ds, ds_next, ds_test); src/GP.jl:743 evaluates the kernel on
+// [ts; ts_pred]): on a regular grid every joint point then has an integer RANK round((t - t_0) / h) — duplicates of training
+// times share one, future points exceed n_max - 1, earlier ones are negative — and |t_a - t_b| = |rank_a - rank_b| h for every
+// pair of the joint set: the stationary subtrees of the predictive pass read the same rank tables as the factor store's sweeps,
+// extended to max rank - min rank + 1 lags.  One off-lattice point (same tolerance as agp_set_data) -> general path.
+struct PredLattice {
+  bool on = false;
+  int R = 0, rank_units = 1;
+  std::vector<int32_t> rank;      // joint padded layout [ts(1:n), pad, ts_pred, pad], shifted so that the smallest rank is 0
+  std::vector<double> tl;         // time of lag g: t_sorted[g] inside the data (the store's tables), t_0 + g h beyond
+};
+constexpr int PRED_MAX_LAGS = 4096;     // (LDS capacity of the fused evaluators, as for the resident series: n_max <= 4096)
+
+void predict_lattice(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, PredLattice& pl) {
+  pl.on = false;
+  if (!(c->lag_ok && c->lag_enable && c->lag_rank_enable) || n <= 0 || m <= 0 || c->h_rank.empty()) return;
+  const double t0 = c->h_ts_sorted.front(), h = c->grid_h;
+  const int n1_pad = round_up(n, NB), m_pad = round_up(m, NB);
+  std::vector<long long> gq((size_t)m);
+  long long gmin = 0, gmax = (long long)c->n_max - 1;
+  for (int64_t j = 0; j < m; ++j) {
+    const double t = ts_pred[j];
+    const double gf = std::nearbyint((t - t0) / h);
+    if (!std::isfinite(gf) || std::fabs(gf) > 1e6) return;
+    const double tol = c->lag_tol_h * h - 2.220446049250313e-16 * std::max(std::fabs(t), std::max(std::fabs(t0), std::fabs(c->h_ts_sorted.back())));
+    if (!(tol > 0.0) || std::fabs(t - (t0 + gf * h)) > tol) return;
+    gq[(size_t)j] = (long long)gf;
+    gmin = std::min(gmin, gq[(size_t)j]); gmax = std::max(gmax, gq[(size_t)j]);
+  }
+  const long long R = gmax - gmin + 1;
+  if (R > PRED_MAX_LAGS) return;
+  pl.R = (int)R; pl.rank_units = (int)((R + 255) / 256);
+  pl.rank.assign((size_t)n1_pad + m_pad, 0);
+  for (int64_t i = 0; i < n; ++i) pl.rank[(size_t)i] = (int32_t)(c->h_rank[(size_t)i] - gmin);
+  for (int64_t j = 0; j < m; ++j) pl.rank[(size_t)n1_pad + j] = (int32_t)(gq[(size_t)j] - gmin);
+  pl.tl.assign((size_t)pl.rank_units * 256, 0.0);
+  for (long long g = 0; g < (long long)pl.tl.size(); ++g)
+    pl.tl[(size_t)g] = g < c->n_max ? c->h_ts_sorted[(size_t)g] : t0 + (double)g * h;
+  pl.on = true;
+}
+
+int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P, Batch& bt,
+                 const double* noise, const double* noise_pred, const uint8_t* pred_code, const double* diag_add,
+                 const double* mean_train, const double* mean_pred, double* out_mean, double* out_var,
+                 double* out_cov, int32_t* out_info, const std::vector<std::string>* keys = nullptr,
+                 const PredLattice* pl = nullptr) {
+  const int n1_pad = round_up(n, NB);           // 0 when n == 0
+  const int m_pad = round_up(m, NB);
+  const bool lagr = pl != nullptr && pl->on;
+  const int nt1 = n1_pad / NB, nt2 = m_pad / NB, nt = nt1 + nt2;
+  // resident factors (sorted order): store slot per particle, first tile row to compute
+  std::vector<int32_t> src_slot, i0v;
+  int n_hit = 0;
+  std::unique_lock<std::mutex> store_lk;
+  if (keys && c->predict_reuse && nt1 > 0 && !mean_train && !pred_code) {
+    n_hit = store_lookup(c, *keys, bt.order, P, n, nt1, src_slot, i0v, store_lk);
+    std::lock_guard<std::mutex> g(c->mu);
+    c->pred_reused += n_hit; c->pred_factored += P - n_hit;
+  }
+
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+
+  const int ntot = n1_pad + m_pad;
+  const int ntiles = nt * (nt + 1) / 2;
+  const long long strideA = (long long)ntiles * NB2;
+  const int64_t bytes_pp = strideA * 8;
+  const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(P, ws_limit_bytes(c) / bytes_pp));
+
+  // joint point list [ts(1:n), pad, ts_pred, pad]
+  std::vector<double> tt((size_t)ntot, 0.0);
+  std::copy(c->h_ts.begin(), c->h_ts.begin() + n, tt.begin());
+  std::copy(ts_pred, ts_pred + m, tt.begin() + n1_pad);
+  std::vector<double> npred(P), noise_sorted(P);
+  for (int q = 0; q < P; ++q) {
+    const int p = bt.order[q];
+    noise_sorted[q] = noise[p];
+    npred[q] = noise_pred ? noise_pred[p] : noise[p];
+  }
+
+  HIPCHK(c, s->A.ensure((size_t)bytes_pp * chunk));
+  HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256 * (size_t)chunk * std::max(1, nt1)));     // (the dataflow schedule keeps every column's inverse blocks)
+  HIPCHK(c, s->vec.ensure(sizeof(double) * (size_t)ntot * chunk));
+  HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
+  HIPCHK(c, s->info.ensure(sizeof(int) * (size_t)P));
+  HIPCHK(c, s->ready.ensure(sizeof(int) * (size_t)P));
+  HIPCHK(c, s->hdr.ensure(sizeof(ProgHdr) * (size_t)P));
+  HIPCHK(c, s->ops.ensure(bt.ops.size()));
+  HIPCHK(c, s->prm.ensure(sizeof(double) * std::max<size_t>(1, bt.prm.size())));
+  HIPCHK(c, s->noise.ensure(sizeof(double) * (size_t)P));
+  HIPCHK(c, s->noise_pred.ensure(sizeof(double) * (size_t)P));
+  HIPCHK(c, s->tt.ensure(sizeof(double) * (size_t)ntot));
+  HIPCHK(c, s->pred_mean.ensure(sizeof(double) * (size_t)m * chunk));
+  HIPCHK(c, s->pred_var.ensure(sizeof(double) * (size_t)m * chunk));
+  if (out_cov) HIPCHK(c, s->pred_cov.ensure(sizeof(double) * (size_t)m * m * chunk));
+  if (mean_train && n > 0) {
+    HIPCHK(c, s->mu1.ensure(sizeof(double) * (size_t)n));
+    HIPCHK(c, hipMemcpyAsync(s->mu1.p, mean_train, sizeof(double) * n, hipMemcpyHostToDevice, st));
+  }
+  if (mean_pred) {
+    HIPCHK(c, s->mu2.ensure(sizeof(double) * (size_t)m));
+    HIPCHK(c, hipMemcpyAsync(s->mu2.p, mean_pred, sizeof(double) * m, hipMemcpyHostToDevice, st));
+  }
+  HIPCHK(c, hipMemcpyAsync(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr) * P, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->ops.p, bt.ops.data(), bt.ops.size(), hipMemcpyHostToDevice, st));
+  if (!bt.prm.empty())
+    HIPCHK(c, hipMemcpyAsync(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->noise.p, noise_sorted.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->noise_pred.p, npred.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->tt.p, tt.data(), sizeof(double) * ntot, hipMemcpyHostToDevice, st));
+  if (pred_code) {
+    std::vector<uint8_t> code((size_t)ntot, 0);
+    std::copy(pred_code, pred_code + m, code.begin() + n1_pad);
+    HIPCHK(c, s->code.ensure((size_t)ntot));
+    HIPCHK(c, hipMemcpyAsync(s->code.p, code.data(), (size_t)ntot, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));     // `code` is a local
+  }
+  if (diag_add) {
+    HIPCHK(c, s->diag_add.ensure(sizeof(double) * (size_t)m));
+    HIPCHK(c, hipMemcpyAsync(s->diag_add.p, diag_add, sizeof(double) * m, hipMemcpyHostToDevice, st));
+  }
+
+  const int32_t* d_src = nullptr; const int32_t* d_i0 = nullptr;
+  if (n_hit > 0) {
+    HIPCHK(c, s->stage.ensure(sizeof(int32_t) * 2 * (size_t)P));
+    int32_t* d = s->stage.as<int32_t>();
+    HIPCHK(c, hipMemcpyAsync(d, src_slot.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d + P, i0v.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+    d_src = d; d_i0 = d + P;
+  }
+
+  if (lagr) {
+    // ranks of the joint points, lag times, table programs; one table of R lags per stationary subtree of the batch
+    auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t o_tprm = al16(sizeof(LagTabHdr) * bt.thdr.size());
+    const size_t o_tops = al16(o_tprm + sizeof(double) * bt.tprm.size());
+    const size_t prog_bytes = al16(o_tops + bt.tops.size() + 4);
+    std::vector<char> hp(prog_bytes, 0);
+    if (!bt.thdr.empty()) {
+      std::memcpy(hp.data(), bt.thdr.data(), sizeof(LagTabHdr) * bt.thdr.size());
+      std::memcpy(hp.data() + o_tprm, bt.tprm.data(), sizeof(double) * bt.tprm.size());
+      std::memcpy(hp.data() + o_tops, bt.tops.data(), bt.tops.size());
+    }
+    HIPCHK(c, s->pl_prog.ensure(prog_bytes));
+    HIPCHK(c, s->pl_rank.ensure(sizeof(int32_t) * pl->rank.size()));
+    HIPCHK(c, s->pl_tl.ensure(sizeof(double) * pl->tl.size()));
+    HIPCHK(c, hipMemcpyAsync(s->pl_prog.p, hp.data(), prog_bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(s->pl_rank.p, pl->rank.data(), sizeof(int32_t) * pl->rank.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(s->pl_tl.p, pl->tl.data(), sizeof(double) * pl->tl.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipStreamSynchronize(st));      // `hp` is a local
+    if (bt.n_lag_tables > 0) {
+      HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * pl->rank_units * 256));
+      LagArgs la = {};
+      la.tt = s->pl_tl.as<double>(); la.thdr = s->pl_prog.as<LagTabHdr>();
+      la.tprm = reinterpret_cast<const double*>(static_cast<char*>(s->pl_prog.p) + o_tprm);
+      la.tops = reinterpret_cast<const uint8_t*>(static_cast<char*>(s->pl_prog.p) + o_tops);
+      la.n_tables = bt.n_lag_tables; la.tab = s->lagtab.as<double>();
+      la.nt = 2 * pl->rank_units; la.full = 1; la.stride = pl->rank_units * 256;      // (every entry of the table is live)
+      launch_lag_tables(st, la, pl->rank_units, bt.n_lag_tables);
+      HIPCHK(c, hipGetLastError());
+    }
+    std::lock_guard<std::mutex> g(c->mu);
+    ++c->n_lag_pred;
+  }
+
+  std::vector<double> h_mean, h_var;
+  for (int p0 = 0; p0 < P; p0 += chunk) {
+    const int Pc = std::min(chunk, P - p0);
+    launch_init_vec(st, ntot, Pc, s->vec.as<double>(), c->d_xs, (mean_train && n > 0) ? s->mu1.as<double>() : (const double*)nullptr, (int)n, s->info.as<int>() + p0, s->ready.as<int>() + p0);
+    if (n_hit > 0) {
+      launch_gather(c, st, Pc, nt1, s->A.as<double>(), strideA, s->W.as<double>(), nt1, s->vec.as<double>(), ntot, nullptr, 0,
+                    d_src + p0, s->ready.as<int>() + p0);
+      HIPCHK(c, hipGetLastError());
+      // (Reading L11 and the inverse blocks in place — a second base pointer for the training rows in chol_tile — was
+      // measured: the streamed config 5 went 412 -> 406 ms, the dataflow kernel gained 4 spilled VGPRs; the copy stays.)
+      if (p0 + chunk >= P) {
+        // the store may change again once the last copy has been made
+        HIPCHK(c, hipStreamSynchronize(st));
+        store_lk.unlock();
+      }
+    }
+    CovArgs cv = {};
+    cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n1_pad; cv.m2 = (int)m; cv.nt = nt;
+    cv.hdr = s->hdr.as<ProgHdr>() + p0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
+    cv.noise = s->noise.as<double>() + p0; cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = Pc;
+    cv.code = pred_code ? s->code.as<uint8_t>() : nullptr;
+    if (lagr) { cv.lagtab = s->lagtab.as<double>(); cv.lagr = s->pl_rank.as<int32_t>(); cv.lag_stride = pl->rank_units * 256; }
+    const int nf = std::max(0, std::min(Pc, bt.n_fused - p0));
+    const int dcov = nf > 0 ? bt.max_depth_fused : 0;
+    cv.p_off = nf;
+    cv.skip_pred_offdiag = out_cov ? 0 : 1;
+    cv.i0 = n_hit > 0 ? d_i0 + p0 : nullptr;
+    HIPCHK(c, launch_cov(st, cv, ntiles, Pc - nf, bt.max_cp, bt.max_depth));
+
+    CholArgs ca = {};
+    ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>();
+    ca.vec = s->vec.as<double>(); ca.ldv = ntot; ca.partial = s->partial.as<double>();
+    ca.info = s->info.as<int>() + p0; ca.P = Pc; ca.nt = nt; ca.k = 0; ca.nt1 = nt1;
+    set_cov(ca, cv);
+    ca.lag = lagr ? 1 : 0;
+    ca.n_fused = nf;
+    ca.ready = s->ready.as<int>() + p0;
+    if (n_hit > 0) { ca.i0 = d_i0 + p0; ca.wsteps = nt1; }      // panel solves of the prediction rows read every column's inverse blocks
+    if (nt1 > 0 && use_flow(c, Pc, nt, nt1)) {
+      // dataflow schedule over the block columns of the training block (all rows: V = L^-1 K12 comes out of the same tiles)
+      const int ntri = nt * (nt + 1) / 2;
+      HIPCHK(c, s->tflag.ensure(sizeof(int) * (size_t)Pc * ntri));
+      HIPCHK(c, s->flowq.ensure(sizeof(int) * 8 * 8));
+      ca.tflag = s->tflag.as<int>(); ca.ntri = ntri; ca.qnext = s->flowq.as<int>();
+      ca.wsteps = nt1;
+      if (n_hit > 0)
+        launch_init_flow_flags(st, Pc, ca.tflag, ntri, ntri, (const int*)nullptr, ca.i0);
+      else
+        HIPCHK(c, hipMemsetAsync(ca.tflag, 0, sizeof(int) * (size_t)Pc * ntri, st));
+      HIPCHK(c, hipMemsetAsync(ca.qnext, 0, sizeof(int) * 8, st));
+      launch_flow(dcov, 2 * c->n_cu, st, ca);
+      HIPCHK(c, hipGetLastError());
+    } else if (n_hit > 0) {
+      // per-column launches restricted to the rows some particle still has to compute
+      int i0min = nt1;
+      for (int q = 0; q < Pc; ++q) i0min = std::min(i0min, (int)i0v[(size_t)p0 + q]);
+      HIPCHK(c, run_factor_extend(st, ca, dcov, use_split_diag(c, ca.P) || pred_split(c, ca.P, nt, nt1), i0min, nt1));
+    } else {
+      HIPCHK(c, run_factor(st, ca, nt1, dcov, nullptr, nullptr, use_split_diag(c, ca.P) || pred_split(c, ca.P, nt, nt1)));
+    }
+    {
+      // Schur complement of the prediction block + (-V^T alpha); with nt1 == 0 this just
+      // passes K22 through.
+      // without a covariance request only the diagonal tiles are updated: mean and marginal variances cost
+      // n^3/3 + n^2 m instead of n^3/3 + n^2 m + n m^2
+      ca.schur_diag_only = out_cov ? 0 : 1;
+      const int T = out_cov ? nt2 * (nt2 + 1) / 2 : nt2;
+      const int Pg = (Pc + 7) / 8;
+      int dcov_s = dcov;
+      if (lagr && nf > 0) {
+        // (the Schur kernel has no table-reading instantiation: the prediction block's tiles of the particles that evaluated
+        // their other tiles in-kernel come from k_cov_tiles, which reads the rank tables in place)
+        CovArgs cp = cv;
+        cp.p_off = 0; cp.pred_only = 1; cp.i0 = nullptr;
+        HIPCHK(c, launch_cov(st, cp, ntiles, nf, bt.max_cp, bt.max_depth));
+        ca.n_fused = 0; dcov_s = 0;
+      }
+      launch_update_schur(dcov_s, 8 * Pg * T, st, ca);
+    }
+    PredArgs pa = {};
+    pa.A = s->A.as<double>(); pa.strideA = strideA; pa.vec = s->vec.as<double>(); pa.ldv = ntot;
+    pa.mu2 = mean_pred ? s->mu2.as<double>() : nullptr; pa.noise_pred = s->noise_pred.as<double>() + p0;
+    pa.nt1 = nt1; pa.n1_pad = n1_pad; pa.m = (int)m; pa.P = Pc;
+    pa.diag_add = diag_add ? s->diag_add.as<double>() : nullptr;
+    pa.out_mean = s->pred_mean.as<double>(); pa.out_var = s->pred_var.as<double>();
+    pa.out_cov = out_cov ? s->pred_cov.as<double>() : nullptr;
+    const long long nel = out_cov ? (long long)m * m : (long long)m;
+    launch_pred_extract(st, nel, Pc, pa);
+    HIPCHK(c, hipGetLastError());
+    // results come back in sorted order: scatter to the caller's particle order
+    h_mean.resize((size_t)m * Pc); h_var.resize((size_t)m * Pc);
+    HIPCHK(c, hipMemcpyAsync(h_mean.data(), s->pred_mean.p, sizeof(double) * m * Pc, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_var.data(), s->pred_var.p, sizeof(double) * m * Pc, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int q = 0; q < Pc; ++q) {
+      const size_t o = (size_t)bt.order[p0 + q];
+      std::memcpy(out_mean + o * m, h_mean.data() + (size_t)q * m, sizeof(double) * m);
+      std::memcpy(out_var + o * m, h_var.data() + (size_t)q * m, sizeof(double) * m);
+      if (out_cov)
+        HIPCHK(c, hipMemcpyAsync(out_cov + o * m * m, s->pred_cov.as<double>() + (size_t)q * m * m,
+                                 sizeof(double) * m * m, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
+  {
+    // always inspected: a caller that passes out_info = NULL must still never receive unmarked garbage
+    std::vector<int32_t> info_sorted(P);
+    HIPCHK(c, hipMemcpyAsync(info_sorted.data(), s->info.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int q = 0; q < P; ++q) {
+      if (info_sorted[q] < 0) return fail(c, AGP_ERR_HIP, "in-kernel panel solve timed out waiting for its diagonal factor");
+      const int p = bt.order[q];
+      if (out_info) out_info[p] = info_sorted[q];
+      if (info_sorted[q] != 0) {
+        const double nanv = std::nan("");
+        for (int64_t g = 0; g < m; ++g) { out_mean[(size_t)p * m + g] = nanv; out_var[(size_t)p * m + g] = nanv; }
+        if (out_cov) for (int64_t g = 0; g < m * m; ++g) out_cov[(size_t)p * m * m + g] = nanv;
+      }
+    }
+  }
+  return AGP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P,
+                      const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                      const double* noise, const double* noise_pred, const double* mean_train,
+                      const double* mean_pred, double* out_mean, double* out_var, double* out_cov,
+                      int32_t* out_info) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (P < 0 || n < 0 || m < 0) return fail(c, AGP_ERR_ARG, "negative size");
+  if (P == 0 || m == 0) return AGP_OK;
+  if (!op_off || !ops || !prm_off || !prm || !noise || !ts_pred || !out_mean || !out_var)
+    return fail(c, AGP_ERR_ARG, "null pointer argument");
+  if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
+  HIPCHK(c, hipSetDevice(c->device));
+  // A resampled population holds copies of the survivors (src/inference_smc_anneal_data.jl:198-204) and the reference
+  // predicts particle by particle (src/api.jl:508-520): each distinct (program, parameters, noise, noise_pred) runs once.
+  std::vector<int> rep(P), uniq;
+  if (c->dedup && P > 1) {
+    bool sane = true;
+    for (int p = 0; p < P && sane; ++p)
+      sane = op_off[p + 1] >= op_off[p] && prm_off[p + 1] >= prm_off[p] && op_off[p] >= 0 && prm_off[p] >= 0;
+    if (sane) {
+      std::unordered_map<std::string, int> seen;
+      seen.reserve((size_t)P * 2);
+      for (int p = 0; p < P; ++p) {
+        const int no = op_off[p + 1] - op_off[p], np = prm_off[p + 1] - prm_off[p];
+        const int32_t lens[2] = {no, np};
+        std::string key(reinterpret_cast<const char*>(lens), sizeof lens);
+        key.append(reinterpret_cast<const char*>(ops + op_off[p]), (size_t)no);
+        key.append(reinterpret_cast<const char*>(prm + prm_off[p]), sizeof(double) * (size_t)np);
+        key.append(reinterpret_cast<const char*>(noise + p), sizeof(double));
+        if (noise_pred) key.append(reinterpret_cast<const char*>(noise_pred + p), sizeof(double));
+        auto it = seen.find(key);
+        if (it == seen.end()) { seen.emplace(std::move(key), (int)uniq.size()); rep[p] = (int)uniq.size(); uniq.push_back(p); }
+        else rep[p] = it->second;
+      }
+    }
+  }
+  const int U = (int)uniq.size();
+  // (a store that holds nothing is not consulted: no key strings are built)
+  const bool want_keys = c->predict_reuse && n > 0 && !mean_train && c->store.n_slots > 0;
+  PredLattice pl;
+  predict_lattice(c, n, ts_pred, m, pl);
+  if (U == 0 || U == P) {
+    Batch bt;
+    const int nt1_ = (int)((n + NB - 1) / NB), nt_ = nt1_ + (int)((m + NB - 1) / NB);
+    const bool ff = n > 0 && use_flow(c, P, nt_, nt1_);
+    const bool fh = ff || (n > 0 && pred_split(c, P, nt_, nt1_));
+    int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, false, false, fh, ff, pl.on, pl.on ? pl.rank_units : 1, pl.on);
+    if (rc) return rc;
+    std::vector<std::string> keys;
+    if (want_keys)
+      for (int p = 0; p < P; ++p)
+        keys.push_back(particle_key(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p], prm_off[p + 1] - prm_off[p], noise[p]));
+    return predict_core(c, n, ts_pred, m, P, bt, noise, noise_pred, nullptr, nullptr, mean_train, mean_pred, out_mean,
+                        out_var, out_cov, out_info, want_keys ? &keys : nullptr, &pl);
+  }
+  std::vector<int32_t> uo(U + 1, 0), up(U + 1, 0), uinfo(U, 0);
+  std::vector<uint8_t> uops; std::vector<double> uprm, unoise(U), unp(noise_pred ? U : 0);
+  for (int u = 0; u < U; ++u) {
+    const int p = uniq[u];
+    uops.insert(uops.end(), ops + op_off[p], ops + op_off[p + 1]);
+    uprm.insert(uprm.end(), prm + prm_off[p], prm + prm_off[p + 1]);
+    uo[u + 1] = (int32_t)uops.size(); up[u + 1] = (int32_t)uprm.size();
+    unoise[u] = noise[p];
+    if (noise_pred) unp[u] = noise_pred[p];
+  }
+  if (uprm.empty()) uprm.push_back(0.0);
+  std::vector<double> umean((size_t)U * m), uvar((size_t)U * m), ucov(out_cov ? (size_t)U * m * m : 0);
+  Batch bt;
+  const int nt1_ = (int)((n + NB - 1) / NB), nt_ = nt1_ + (int)((m + NB - 1) / NB);
+  const bool ff = n > 0 && use_flow(c, U, nt_, nt1_);
+  const bool fh = ff || (n > 0 && pred_split(c, U, nt_, nt1_));
+  int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, false, fh, ff, pl.on, pl.on ? pl.rank_units : 1, pl.on);
+  if (rc) return rc;
+  std::vector<std::string> keys;
+  if (want_keys)
+    for (int u = 0; u < U; ++u)
+      keys.push_back(particle_key(uops.data() + uo[u], uo[u + 1] - uo[u], uprm.data() + up[u], up[u + 1] - up[u], unoise[u]));
+  rc = predict_core(c, n, ts_pred, m, U, bt, unoise.data(), noise_pred ? unp.data() : nullptr, nullptr, nullptr, mean_train,
+                    mean_pred, umean.data(), uvar.data(), out_cov ? ucov.data() : nullptr, uinfo.data(), want_keys ? &keys : nullptr, &pl);
+  if (rc) return rc;
+  for (int p = 0; p < P; ++p) {
+    const size_t u = (size_t)rep[p];
+    std::memcpy(out_mean + (size_t)p * m, umean.data() + u * m, sizeof(double) * (size_t)m);
+    std::memcpy(out_var + (size_t)p * m, uvar.data() + u * m, sizeof(double) * (size_t)m);
+    if (out_cov) std::memcpy(out_cov + (size_t)p * m * m, ucov.data() + u * m * m, sizeof(double) * (size_t)m * m);
+    if (out_info) out_info[p] = uinfo[u];
+  }
+  return AGP_OK;
+}
+
+// infer_gp_sum (src/GP.jl:904-993): posterior over Z = [F_1(T*); ...; F_M(T*); X(T*)] given X(T) = xs, for the
+// sum-of-GPs model X = sum_i F_i + noise.  The joint prior covariance over [X(T); Z] is the single program
+// sum_i SEL_i * K_i evaluated on coded points (SEL_i(a,b) = 1 when both points are the observable or the
+// latent of component i), so the whole computation is one pass of the predictive machinery:
+// Cholesky of Sigma_bb = S_tt + noise I (src/GP.jl:982), Schur complement (984), + JITTER I (986).
+int agp_infer_gp_sum(agp_ctx* c, int64_t n, const double* ts_pred, int64_t p, int32_t M,
+                     const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                     double noise, double noise_pred, double* out_mean, double* out_cov, int32_t* out_info) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (n < 0 || p <= 0 || M <= 0 || M > 200) return fail(c, AGP_ERR_ARG, "bad sizes");
+  if (!op_off || !ops || !prm_off || !prm || !ts_pred || !out_mean) return fail(c, AGP_ERR_ARG, "null pointer argument");
+  if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
+  HIPCHK(c, hipSetDevice(c->device));
+  // composite program: K_1 SEL_1 *  K_2 SEL_2 * +  ...  K_M SEL_M * +
+  std::vector<uint8_t> cops; std::vector<double> cprm;
+  for (int i = 0; i < M; ++i) {
+    for (int q = op_off[i]; q < op_off[i + 1]; ++q) {
+      if (ops[q] > OP_CP) return fail(c, AGP_ERR_PROGRAM, "unknown opcode");
+      cops.push_back(ops[q]);
+    }
+    cprm.insert(cprm.end(), prm + prm_off[i], prm + prm_off[i + 1]);
+    cops.push_back((uint8_t)OP_SEL); cprm.push_back((double)(i + 1));
+    cops.push_back((uint8_t)OP_TIMES);
+    if (i > 0) cops.push_back((uint8_t)OP_PLUS);
+  }
+  if ((int)cops.size() > AGP_MAX_OPS) return fail(c, AGP_ERR_PROGRAM, "composite program too long");
+  const int32_t coff[2] = {0, (int32_t)cops.size()}, cpoff[2] = {0, (int32_t)cprm.size()};
+  Batch bt;
+  int rc = compile_batch(c, 1, coff, cops.data(), cpoff, cprm.data(), bt, /*allow_sel=*/true);
+  if (rc) return rc;
+  // query points: F_1(T*) ... F_M(T*) (codes 1..M), then X(T*) (code 0)
+  const int64_t ma = (int64_t)(M + 1) * p;
+  std::vector<double> tq((size_t)ma), dadd((size_t)ma), mean((size_t)ma), var((size_t)ma);
+  std::vector<uint8_t> code((size_t)ma);
+  for (int i = 0; i <= M; ++i)
+    for (int64_t j = 0; j < p; ++j) {
+      const size_t g = (size_t)i * p + j;
+      tq[g] = ts_pred[j];
+      code[g] = (uint8_t)(i < M ? i + 1 : 0);
+      dadd[g] = 1e-8 + (i == M ? noise_pred : 0.0);       // JITTER (src/GP.jl:760,986) + noise_pred on X(T*)
+    }
+  const double zero = 0.0;
+  int32_t info = 0;
+  rc = predict_core(c, n, tq.data(), ma, 1, bt, &noise, &zero, code.data(), dadd.data(), nullptr, nullptr, out_mean,
+                    var.data(), out_cov, &info);
+  if (out_info) *out_info = info;
+  return rc;
+}
+
+int agp_cov_matrix(agp_ctx* c, const double* ts, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm,
+                   int32_t n_prm, double noise, double* out_K) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (n < 0) return fail(c, AGP_ERR_ARG, "negative size");
+  if (n == 0) return AGP_OK;
+  if (!ts || !ops || !out_K) return fail(c, AGP_ERR_ARG, "null pointer argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int32_t op_off[2] = {0, n_ops}, prm_off[2] = {0, n_prm};
+  double dummy = 0.0;
+  Batch bt;
+  int rc = compile_batch(c, 1, op_off, ops, prm_off, prm ? prm : &dummy, bt);
+  if (rc) return rc;
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+  const int n_pad = round_up(n, NB), nt = n_pad / NB, ntiles = nt * (nt + 1) / 2;
+  const long long strideA = (long long)ntiles * NB2;
+  std::vector<double> tt((size_t)n_pad, 0.0);
+  std::copy(ts, ts + n, tt.begin());
+  HIPCHK(c, s->A.ensure((size_t)strideA * 8));
+  HIPCHK(c, s->hdr.ensure(sizeof(ProgHdr)));
+  HIPCHK(c, s->ops.ensure(bt.ops.size()));
+  HIPCHK(c, s->prm.ensure(sizeof(double) * std::max<size_t>(1, bt.prm.size())));
+  HIPCHK(c, s->noise.ensure(sizeof(double)));
+  HIPCHK(c, s->tt.ensure(sizeof(double) * (size_t)n_pad));
+  HIPCHK(c, s->dense.ensure(sizeof(double) * (size_t)n * n));
+  HIPCHK(c, hipMemcpyAsync(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->ops.p, bt.ops.data(), bt.ops.size(), hipMemcpyHostToDevice, st));
+  if (!bt.prm.empty())
+    HIPCHK(c, hipMemcpyAsync(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size(), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->noise.p, &noise, sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemcpyAsync(s->tt.p, tt.data(), sizeof(double) * n_pad, hipMemcpyHostToDevice, st));
+  CovArgs cv = {};
+  cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
+  cv.hdr = s->hdr.as<ProgHdr>(); cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
+  cv.noise = s->noise.as<double>(); cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = 1;
+  cv.p_off = 0;
+  HIPCHK(c, launch_cov(st, cv, ntiles, 1, bt.max_cp, bt.max_depth));
+  const long long nel = (long long)n * n;
+  launch_unpack_dense(st, s->A.as<double>(), (int)n, 0, s->dense.as<double>());
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out_K, s->dense.p, sizeof(double) * nel, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return AGP_OK;
+}
+
+int agp_debug_cholesky(agp_ctx* c, const double* K, int64_t n, double* out_L, int32_t* out_info) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (n <= 0 || !K || !out_L) return fail(c, AGP_ERR_ARG, "bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+  const int n_pad = round_up(n, NB), nt = n_pad / NB, ntiles = nt * (nt + 1) / 2;
+  const long long strideA = (long long)ntiles * NB2;
+  const long long nel = (long long)n * n;
+  HIPCHK(c, s->A.ensure((size_t)strideA * 8));
+  HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256));
+  HIPCHK(c, s->vec.ensure(sizeof(double) * (size_t)n_pad));
+  HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt));
+  HIPCHK(c, s->info.ensure(sizeof(int)));
+  HIPCHK(c, s->dense.ensure(sizeof(double) * (size_t)nel));
+  HIPCHK(c, hipMemcpyAsync(s->dense.p, K, sizeof(double) * nel, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipMemsetAsync(s->vec.p, 0, sizeof(double) * n_pad, st));
+  HIPCHK(c, hipMemsetAsync(s->info.p, 0, sizeof(int), st));
+  HIPCHK(c, s->ready.ensure(sizeof(int)));
+  HIPCHK(c, hipMemsetAsync(s->ready.p, 0, sizeof(int), st));
+  launch_pack_dense(st, s->dense.as<double>(), (int)n, nt, strideA, s->A.as<double>());
+  CholArgs ca = {};
+  ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = s->W.as<double>(); ca.vec = s->vec.as<double>();
+  ca.ldv = n_pad; ca.partial = s->partial.as<double>(); ca.info = s->info.as<int>(); ca.P = 1; ca.nt = nt;
+  ca.k = 0; ca.nt1 = nt;
+  ca.tt = nullptr; ca.hdr = nullptr; ca.ops = nullptr; ca.prm = nullptr; ca.noise = nullptr; ca.n1 = ca.n1_pad = ca.m2 = 0; ca.n_fused = 0; ca.ready = s->ready.as<int>();
+  HIPCHK(c, run_factor(st, ca, nt, 0, nullptr, nullptr, use_split_diag(c, ca.P)));
+  launch_unpack_dense(st, s->A.as<double>(), (int)n, 1, s->dense.as<double>());
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out_L, s->dense.p, sizeof(double) * nel, hipMemcpyDeviceToHost, st));
+  if (out_info) HIPCHK(c, hipMemcpyAsync(out_info, s->info.p, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  return AGP_OK;
+}
+
+int agp_debug_mfma_peak(agp_ctx* c, int32_t iters, int32_t wg_per_cu, double* out_tflops, double* out_ghz) {
+  if (!c || !out_tflops || !out_ghz) return fail(c, AGP_ERR_ARG, "null pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipDeviceProp_t prop;
+  HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+  const int mode = wg_per_cu >> 8;          // (high bits: what the waves execute, see k_mfma_peak)
+  wg_per_cu &= 255;
+  const int nblk = prop.multiProcessorCount * (wg_per_cu > 0 ? wg_per_cu : 2);
+  double* d_out = nullptr; long long* d_cyc = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_out, sizeof(double) * 256 * (size_t)nblk));
+  HIPCHK(c, hipMalloc((void**)&d_cyc, sizeof(long long) * (size_t)nblk));
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  launch_mfma_peak(nblk, d_out, d_cyc, 64, mode);   // warm-up
+  HIPCHK(c, hipEventRecord(e0, 0));
+  launch_mfma_peak(nblk, d_out, d_cyc, iters, mode);
+  HIPCHK(c, hipEventRecord(e1, 0));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  std::vector<long long> cyc(nblk);
+  HIPCHK(c, hipMemcpy(cyc.data(), d_cyc, sizeof(long long) * nblk, hipMemcpyDeviceToHost));
+  double mean_cyc = 0; for (auto v : cyc) mean_cyc += (double)v; mean_cyc /= nblk;
+  const double flops = (double)nblk * 4.0 * 16.0 * (double)iters * 2048.0;
+  *out_tflops = flops / (ms * 1e-3) / 1e12;
+  *out_ghz = mean_cyc / (ms * 1e-3) / 1e9;     // shader cycles per second while the kernel ran
+  (void)hipFree(d_out); (void)hipFree(d_cyc); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return AGP_OK;
+}
+
+// ---- measurement build only (-DAGP_EXPERIMENTS -> libautogp_hip_exp.so; declared in csrc/experiments/agp_experiments_abi.h) ----
+#ifdef AGP_EXPERIMENTS
+int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t variant, int32_t reps, double* out_ms) {
+  if (!c || !out_ms || P <= 0 || nt < 2 || k < 1 || k >= nt - 0) return fail(c, AGP_ERR_ARG, "bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+  const int ntiles = nt * (nt + 1) / 2;
+  const long long strideA = (long long)ntiles * NB2;
+  HIPCHK(c, s->A.ensure((size_t)strideA * 8 * P));
+  hipLaunchKernelGGL(k_fill_pseudo, dim3(4096), dim3(256), 0, st, s->A.as<double>(), strideA * P);
+  CholArgs ca = {};
+  ca.A = s->A.as<double>(); ca.strideA = strideA; ca.W = nullptr; ca.vec = nullptr; ca.ldv = 0; ca.partial = nullptr;
+  ca.info = nullptr; ca.P = P; ca.nt = nt; ca.k = k; ca.nt1 = nt; ca.tiles = nt - k - 1;
+  if (ca.tiles < 1) return fail(c, AGP_ERR_ARG, "no off-diagonal tiles");
+  const int grid = 8 * ((P + 7) / 8) * ca.tiles;
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  const int Pg8 = 8 * ((P + 7) / 8);
+  for (int r = 0; r < reps + 1; ++r) {
+    if (r == 1) HIPCHK(c, hipEventRecord(e0, st));
+    switch (variant) {
+      case 2000: {   // every block column 1..nt-2 in ONE launch (k is ignored)
+        int blocks = 0;
+        for (int kk = 1; kk < nt - 1; ++kk) blocks += Pg8 * (nt - kk - 1);
+        hipLaunchKernelGGL((k_gemm_strip<16, true, true>), dim3(blocks), dim3(256), 0, st, ca);
+        break;
+      }
+      case 2002: {   // as 2000 with twice the prefetch distance
+        int blocks = 0;
+        for (int kk = 1; kk < nt - 1; ++kk) blocks += Pg8 * (nt - kk - 1);
+        hipLaunchKernelGGL((k_gemm_strip<16, true, true, true>), dim3(blocks), dim3(256), 0, st, ca);
+        break;
+      }
+      case 2003: {   // as 2000 without LDS / barriers: both operands global -> registers
+        int blocks = 0;
+        for (int kk = 1; kk < nt - 1; ++kk) blocks += Pg8 * (nt - kk - 1);
+        hipLaunchKernelGGL((k_gemm_nolds<true>), dim3(blocks), dim3(256), 0, st, ca);
+        break;
+      }
+      case 3000: {   // every block column in one launch, EIGHT waves per workgroup (column halves)
+        int blocks = 0;
+        for (int kk = 1; kk < nt - 1; ++kk) blocks += Pg8 * (nt - kk - 1);
+        hipLaunchKernelGGL((k_gemm_strip8<16, true>), dim3(blocks), dim3(512), 0, st, ca);
+        break;
+      }
+      case 3001: {   // one launch per block column, eight waves per workgroup
+        CholArgs cb = ca;
+        for (int kk = 1; kk < nt - 1; ++kk) {
+          cb.k = kk; cb.tiles = nt - kk - 1;
+          hipLaunchKernelGGL((k_gemm_strip8<16, false>), dim3(Pg8 * cb.tiles), dim3(512), 0, st, cb);
+        }
+        break;
+      }
+      case 3032: {   // as 3001 with 32-column slabs
+        CholArgs cb = ca;
+        for (int kk = 1; kk < nt - 1; ++kk) {
+          cb.k = kk; cb.tiles = nt - kk - 1;
+          hipLaunchKernelGGL((k_gemm_strip8<32, false>), dim3(Pg8 * cb.tiles), dim3(512), 0, st, cb);
+        }
+        break;
+      }
+      case 2001: {   // the same tiles, one launch per block column
+        CholArgs cb = ca;
+        for (int kk = 1; kk < nt - 1; ++kk) {
+          cb.k = kk; cb.tiles = nt - kk - 1;
+          hipLaunchKernelGGL((k_gemm_strip<16, true, false>), dim3(Pg8 * cb.tiles), dim3(256), 0, st, cb);
+        }
+        break;
+      }
+      case 0: launch_variant<0>(st, grid, ca); break;
+      case 1: launch_variant<1>(st, grid, ca); break;
+      case 3: launch_variant<3>(st, grid, ca); break;
+      case 7: launch_variant<7>(st, grid, ca); break;
+      case 8: launch_variant<8>(st, grid, ca); break;
+      case 16: launch_variant<16>(st, grid, ca); break;
+      case 19: launch_variant<19>(st, grid, ca); break;
+      case 23: launch_variant<23>(st, grid, ca); break;
+      case 24: launch_variant<24>(st, grid, ca); break;
+      case 40: launch_variant<40>(st, grid, ca); break;
+      case 104: launch_variant<104>(st, grid, ca); break;
+      case 168: launch_variant<168>(st, grid, ca); break;
+      case 152: launch_variant<152>(st, grid, ca); break;
+      case 1016: hipLaunchKernelGGL((k_gemm_strip<16, true>), dim3(grid), dim3(256), 0, st, ca); break;
+      case 1032: hipLaunchKernelGGL((k_gemm_strip<32, true>), dim3(grid), dim3(256), 0, st, ca); break;
+      case 1008: hipLaunchKernelGGL((k_gemm_strip<8, true>), dim3(grid), dim3(256), 0, st, ca); break;
+      default: return fail(c, AGP_ERR_ARG, "unknown variant");
+    }
+  }
+  HIPCHK(c, hipEventRecord(e1, st));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  *out_ms = ms / reps;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  HIPCHK(c, hipGetLastError());
+  return AGP_OK;
+}
+
+// Timeline of the next dataflow sweeps (k_chol_flow): out has 4 int64 per work item — start, end (100 MHz ticks),
+// ticks spent waiting for operand tiles inside the K-loop, and (workgroup << 48 | particle << 24 | tile row << 12 |
+// block column).  enable: allocate for max_items and start recording; otherwise copy out what was recorded.
+int agp_debug_flow_trace(agp_ctx* c, int32_t enable, int64_t max_items, int64_t* out) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipDeviceSynchronize());
+  if (enable) {
+    if (c->d_flow_trace) { (void)hipFree(c->d_flow_trace); c->d_flow_trace = nullptr; }
+    if (max_items <= 0) { c->flow_trace_items = 0; return AGP_OK; }
+    HIPCHK(c, hipMalloc((void**)&c->d_flow_trace, sizeof(long long) * 8 * (size_t)max_items));
+    HIPCHK(c, hipMemset(c->d_flow_trace, 0, sizeof(long long) * 8 * (size_t)max_items));
+    c->flow_trace_items = (size_t)max_items;
+    return AGP_OK;
+  }
+  if (!out || !c->d_flow_trace || (size_t)max_items > c->flow_trace_items) return fail(c, AGP_ERR_ARG, "no trace recorded");
+  HIPCHK(c, hipMemcpy(out, c->d_flow_trace, sizeof(long long) * 8 * (size_t)max_items, hipMemcpyDeviceToHost));
+  return AGP_OK;
+}
+#endif  // AGP_EXPERIMENTS
+
+int agp_debug_math(agp_ctx* c, int32_t which, const double* x, const double* g, double* y, int32_t n) {
+  if (!c || !x || !y || n <= 0 || (which == 3 && !g)) return fail(c, AGP_ERR_ARG, "bad arguments");
+  HIPCHK(c, hipSetDevice(c->device));
+  double *dx = nullptr, *dg = nullptr, *dy = nullptr;
+  HIPCHK(c, hipMalloc((void**)&dx, sizeof(double) * n));
+  HIPCHK(c, hipMalloc((void**)&dg, sizeof(double) * n));
+  HIPCHK(c, hipMalloc((void**)&dy, sizeof(double) * n));
+  HIPCHK(c, hipMemcpy(dx, x, sizeof(double) * n, hipMemcpyHostToDevice));
+  if (g) HIPCHK(c, hipMemcpy(dg, g, sizeof(double) * n, hipMemcpyHostToDevice));
+  launch_math_probe(which, dx, dg, dy, n);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpy(y, dy, sizeof(double) * n, hipMemcpyDeviceToHost));
+  (void)hipFree(dx); (void)hipFree(dg); (void)hipFree(dy);
+  return AGP_OK;
+}
+
+int agp_debug_mfma_probe(agp_ctx* c, const double* A, const double* B, double* D) {
+  if (!c || !A || !B || !D) return fail(c, AGP_ERR_ARG, "null pointer");
+  HIPCHK(c, hipSetDevice(c->device));
+  double *dA = nullptr, *dB = nullptr, *dD = nullptr;
+  HIPCHK(c, hipMalloc((void**)&dA, 64 * 8));
+  HIPCHK(c, hipMalloc((void**)&dB, 64 * 8));
+  HIPCHK(c, hipMalloc((void**)&dD, 256 * 8));
+  HIPCHK(c, hipMemcpy(dA, A, 64 * 8, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(dB, B, 64 * 8, hipMemcpyHostToDevice));
+  launch_mfma_probe(dA, dB, dD);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpy(D, dD, 256 * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
+  return AGP_OK;
+}
+
+}  // extern "C"

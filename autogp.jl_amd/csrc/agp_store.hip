@@ -1,0 +1,454 @@
+// Host side of the C ABI, unit 3: the resident factor store, block-extension sweeps and the regular-grid /
+// store statistics and switches.
+#include "agp_host.hpp"
+
+
+// ==========================================================================================
+// Block-extension sweeps.  The data-annealing loop re-scores every particle on a longer prefix of
+// the same series with UNCHANGED kernel parameters (reweight step, src/inference_smc_anneal_data.jl:206-217;
+// add_data!, src/api.jl:426-443; scripts/online.jl:200 extends by single points), and the reference refactorises
+// from scratch each time.  With ts[1:n_old] a prefix of ts[1:n_new], K_new = [K_old B'; B C] and
+// L_new = [L_old 0; B L_old^-T  chol(C - ...)]: only tile rows >= floor(n_old / 128) change (the row holding the
+// old identity padding is redone in full).  The store keeps each particle's packed tiles, per-column inverse
+// blocks, forward-solve vector and log-det / quadratic-form partials resident, keyed by the exact bits of
+// (program, parameters, noise); a sweep on a longer prefix runs the same left-looking kernels restricted to the
+// new tile rows — (n_new^3 - n_old^3)/3 flops instead of n_new^3/3 — and any change of a parameter bit, of the
+// structure or of the resident data is simply a different key (or an emptied store): it factors from scratch.
+// ==========================================================================================
+
+
+inline size_t store_bytes_per_slot(int nt_cap) {
+  const size_t tiles = (size_t)nt_cap * (nt_cap + 1) / 2;
+  return tiles * NB2 * 8 + (size_t)nt_cap * NSB * 256 * 8 + (size_t)nt_cap * NB * 8 + (size_t)nt_cap * 2 * 8 + 8;
+}
+
+// (Re)size the store to n_slots x nt_cap tile rows, keeping what it holds: the packed layout is row-major over the
+// lower triangle, so the tiles (and W blocks, vector segments, partials) of the first nt_old tile rows of a slot are a
+// contiguous prefix of the slot — growth is one strided copy per buffer.
+int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
+  agp_ctx::FactorStore& fs = c->store;
+  if (nt_cap == fs.nt_cap && n_slots == fs.n_slots) return AGP_OK;
+  const long long strideA = (long long)nt_cap * (nt_cap + 1) / 2 * NB2;
+  const size_t want_bytes = (size_t)n_slots * store_bytes_per_slot(nt_cap);
+  // (an allocation of this size already failed: do not retry the multi-GB allocations and copies on every call —
+  // agp_extend_reset / agp_set_data on another series clear the memo)
+  if (fs.failed_bytes && want_bytes >= fs.failed_bytes) return fail(c, AGP_ERR_HIP, "factor store: an allocation of this size failed before");
+  DevBuf A, W, vec, partial, info, ready;
+  // (a failed (re)allocation leaves the store as it was: the caller then runs without caching)
+  auto bail = [&](hipError_t e, const char* what) {
+    A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release();
+    (void)hipGetLastError();
+    fs.failed_bytes = want_bytes;
+    return fail(c, AGP_ERR_HIP, std::string("factor store: ") + what + ": " + hipGetErrorString(e));
+  };
+#define STORECHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(e_, #expr); } while (0)
+  STORECHK(A.ensure((size_t)strideA * 8 * n_slots));
+  STORECHK(W.ensure(sizeof(double) * NSB * 256 * (size_t)nt_cap * n_slots));
+  STORECHK(vec.ensure(sizeof(double) * (size_t)nt_cap * NB * n_slots));
+  STORECHK(partial.ensure(sizeof(double) * 2 * (size_t)nt_cap * n_slots));
+  STORECHK(info.ensure(sizeof(int) * (size_t)n_slots));
+  STORECHK(ready.ensure(sizeof(int) * (size_t)n_slots));
+  STORECHK(hipMemset(info.p, 0, sizeof(int) * (size_t)n_slots));
+  const int keep = std::min(n_slots, fs.n_slots), nto = std::min(nt_cap, fs.nt_cap);
+  if (keep > 0 && nto > 0) {
+    // strided copy by a small kernel (row = slot): the per-slot stride is ~1 GiB at n = 16k and passes 2 GiB from n ~ 23k —
+    // pitches hipMemcpy2D may refuse
+    auto cp = [&](DevBuf& dst, size_t dpitch, DevBuf& src, size_t spitch, size_t width) {
+      const long long words = (long long)(width / 8);
+      const int gx = (int)std::max<long long>(1, std::min<long long>(2048, (words / 2 + 255) / 256));
+      launch_copy_rows(0, gx, keep, dst.as<double>(), (long long)(dpitch / 8), src.as<double>(), (long long)(spitch / 8), words);
+      return hipGetLastError();
+    };
+    const size_t tiles_o = (size_t)nto * (nto + 1) / 2;
+    STORECHK(cp(A, (size_t)strideA * 8, fs.A, (size_t)fs.strideA * 8, tiles_o * NB2 * 8));
+    STORECHK(cp(W, (size_t)nt_cap * NSB * 256 * 8, fs.W, (size_t)fs.nt_cap * NSB * 256 * 8, (size_t)nto * NSB * 256 * 8));
+    STORECHK(cp(vec, (size_t)nt_cap * NB * 8, fs.vec, (size_t)fs.nt_cap * NB * 8, (size_t)nto * NB * 8));
+    STORECHK(cp(partial, (size_t)nt_cap * 16, fs.partial, (size_t)fs.nt_cap * 16, (size_t)nto * 16));
+    STORECHK(hipMemcpy(info.p, fs.info.p, sizeof(int) * (size_t)keep, hipMemcpyDeviceToDevice));
+    STORECHK(hipDeviceSynchronize());
+  }
+#undef STORECHK
+  fs.A.release(); fs.W.release(); fs.vec.release(); fs.partial.release(); fs.info.release(); fs.ready.release();
+  fs.A = A; fs.W = W; fs.vec = vec; fs.partial = partial; fs.info = info; fs.ready = ready;
+  // slots beyond the kept range disappear; factors longer than the new capacity cannot exist (nt_cap only grows)
+  for (int sl = n_slots; sl < fs.n_slots; ++sl)
+    if (!fs.key[sl].empty()) fs.index.erase(fs.key[sl]);
+  fs.key.resize((size_t)n_slots); fs.n_cached.resize((size_t)n_slots, 0); fs.stamp.resize((size_t)n_slots, 0);
+  fs.info_h.resize((size_t)n_slots, 0);
+  fs.nt_cap = nt_cap; fs.n_slots = n_slots; fs.strideA = strideA;
+  fs.footprint = A.cap + W.cap + vec.cap + partial.cap + info.cap + ready.cap + fs.tflag.cap + fs.flowq.cap;
+  return AGP_OK;
+}
+
+hipError_t run_factor_extend(hipStream_t st, CholArgs ca, int dcov, bool split_diag, int i0min, int nfac) {
+  const int Pg = (ca.P + 7) / 8;
+  if (nfac < 0) nfac = ca.nt;
+  for (int k = 0; k < nfac; ++k) {
+    ca.k = k;
+    if (k < i0min) {
+      // every particle already holds block column k down to tile row i0min - 1: only the new rows' tiles, whose
+      // solve reads the resident L(k,k) and its inverse blocks (ready[p] >= i0[p] > k from the start)
+      ca.t0 = i0min - k; ca.tiles = ca.nt - i0min;
+      if (ca.tiles > 0) launch_update_subdiag(dcov, 8 * Pg * ca.tiles, st, ca);
+      continue;
+    }
+    if (split_diag) {
+      ca.t0 = 1; ca.tiles = 1;
+      launch_diag(dcov, 8 * Pg, st, ca);
+      ca.tiles = ca.nt - k - 1;
+      if (ca.tiles > 0) launch_update_subdiag(dcov, 8 * Pg * ca.tiles, st, ca);
+    } else {
+      ca.tiles = ca.nt - k;
+      launch_update_factor(dcov, 8 * Pg * ca.tiles, st, ca);
+    }
+  }
+  return hipGetLastError();
+}
+
+// d_out_caller (optional, device, P doubles): the log-pdfs in the CALLER's particle order (duplicates expanded) are also left
+// there, ordered behind the sweep on the slot's stream and complete on return; *wrote_device says whether that happened
+// (not for n = 0 or when the sweep fell back to the plain entry).
+int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
+                const double* prm, const double* noise, double* out_lp, int32_t* out_info,
+                double* d_out_caller, bool* wrote_device) {
+  if (wrote_device) *wrote_device = false;
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (P < 0 || n < 0) return fail(c, AGP_ERR_ARG, "negative size");
+  if (P == 0) return AGP_OK;
+  if (!op_off || !ops || !prm_off || !prm || !noise || !out_lp || !out_info) return fail(c, AGP_ERR_ARG, "null pointer argument");
+  if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
+  for (int p = 0; p < P; ++p)
+    if (op_off[p + 1] < op_off[p] || prm_off[p + 1] < prm_off[p] || op_off[p] < 0 || prm_off[p] < 0)
+      return fail(c, AGP_ERR_ARG, "offsets must be non-decreasing");
+  if (n == 0) {
+    for (int p = 0; p < P; ++p) { out_lp[p] = 0.0; out_info[p] = 0; }
+    return AGP_OK;
+  }
+  auto plain = [&]() { return agp_logpdf_batch(c, n, P, op_off, ops, prm_off, prm, noise, out_lp, out_info); };
+  HIPCHK(c, hipSetDevice(c->device));
+
+  // distinct particles (a resampled population holds copies)
+  std::unordered_map<std::string, int> seen;
+  seen.reserve((size_t)P * 2);
+  std::vector<int> rep(P), uniq;
+  std::vector<std::string> keys;
+  for (int p = 0; p < P; ++p) {
+    std::string key = particle_key(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p], prm_off[p + 1] - prm_off[p], noise[p]);
+    auto it = seen.find(key);
+    if (it == seen.end()) { seen.emplace(key, (int)uniq.size()); rep[p] = (int)uniq.size(); uniq.push_back(p); keys.push_back(std::move(key)); }
+    else rep[p] = it->second;
+  }
+  const int U = (int)uniq.size();
+  std::vector<int32_t> uo(U + 1, 0), up(U + 1, 0);
+  std::vector<uint8_t> uops; std::vector<double> uprm, unoise(U);
+  for (int u = 0; u < U; ++u) {
+    const int p = uniq[u];
+    uops.insert(uops.end(), ops + op_off[p], ops + op_off[p + 1]);
+    uprm.insert(uprm.end(), prm + prm_off[p], prm + prm_off[p + 1]);
+    uo[u + 1] = (int32_t)uops.size(); up[u + 1] = (int32_t)uprm.size();
+    unoise[u] = noise[p];
+  }
+  if (uprm.empty()) uprm.push_back(0.0);
+
+  const int n_pad = round_up(n, NB), nt = n_pad / NB;
+  agp_ctx::FactorStore& fs = c->store;
+  std::unique_lock<std::mutex> lk(fs.mu);
+  {
+    // capacity: slots sized for the resident data, at least as many as this population (twice, so that a population
+    // mid-rejuvenation keeps its previous states), within the store's share of device memory
+    const int want_nt = std::max(fs.nt_cap, std::max(nt, round_up(c->n_max, NB) / NB));
+    int want_slots = std::max(fs.n_slots, std::max(2 * U, 32));
+    if (want_slots > fs.n_slots && fs.n_slots > 0) want_slots = std::max(want_slots, fs.n_slots + fs.n_slots / 2);   // (growth copies the store: few, larger steps)
+    const size_t budget = (size_t)(fs.max_frac * (double)c->total_mem);
+    const size_t per = store_bytes_per_slot(want_nt);
+    if ((size_t)want_slots * per > budget) want_slots = (int)std::min<size_t>((size_t)want_slots, budget / per);
+    if (want_slots < U) { lk.unlock(); return plain(); }      // population larger than the store may hold: no caching
+    const int rc = store_resize(c, want_nt, want_slots);
+    if (rc) { lk.unlock(); return plain(); }                  // no memory for the store right now: no caching
+  }
+  const uint64_t call = ++fs.clock;
+  std::vector<int32_t> slot(U, -1), i0(U, 0);
+  int64_t rows_reused = 0;
+  for (int u = 0; u < U; ++u) {
+    auto it = fs.index.find(keys[u]);
+    if (it == fs.index.end()) continue;
+    const int sl = it->second;
+    slot[u] = sl; fs.stamp[sl] = call;
+    const int64_t nc = fs.n_cached[sl];
+    i0[u] = nc == n ? nt : (nc < n ? (int32_t)(nc / NB) : 0);     // a factor of a LONGER prefix is redone
+    rows_reused += i0[u];
+  }
+  {
+    std::vector<int> cand;
+    for (int sl = 0; sl < fs.n_slots; ++sl) if (fs.stamp[sl] != call) cand.push_back(sl);
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) {
+      const bool ea = fs.key[a].empty(), eb = fs.key[b].empty();
+      if (ea != eb) return ea;                    // free slots first, then least recently used
+      return fs.stamp[a] < fs.stamp[b];
+    });
+    size_t ci = 0;
+    for (int u = 0; u < U; ++u) {
+      if (slot[u] >= 0) continue;
+      const int sl = cand[ci++];                  // ci < cand.size(): n_slots >= U
+      if (!fs.key[sl].empty()) fs.index.erase(fs.key[sl]);
+      fs.key[sl].clear(); fs.n_cached[sl] = 0; fs.stamp[sl] = call;
+      slot[u] = sl; i0[u] = 0;
+    }
+  }
+  // from here on the touched slots are in flux: forget them on any failure
+  auto poison = [&]() {
+    for (int u = 0; u < U; ++u) {
+      const int sl = slot[u];
+      if (!fs.key[sl].empty()) fs.index.erase(fs.key[sl]);
+      fs.key[sl].clear(); fs.n_cached[sl] = 0;
+    }
+  };
+  for (int u = 0; u < U; ++u) {                   // entries are re-registered after the sweep
+    const int sl = slot[u];
+    if (!fs.key[sl].empty()) { fs.index.erase(fs.key[sl]); fs.key[sl].clear(); }
+  }
+
+  Batch bt;
+  // regular grid: stationary subtrees from rank lag tables, as in the caller-order sweeps of logpdf_batch_impl (the mode depends
+  // on the resident series alone, so an extension and a from-scratch sweep of the same entry evaluate every tile the same way)
+  const bool lagr = c->lag_rank_enable && c->lag_enable && c->lag_ok && c->n_max <= 4096;
+  const int rank_units = (int)((c->n_max + 255) / 256);
+  const bool ge_tab = c->logdt_ok && !lagr;
+  // (tiles are evaluated inside the factorisation kernels whatever the population size: the prebuilt-tile variants of
+  // the split launches carry the most register spills, and the store never needs K itself)
+  int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, ge_tab, /*fuse_hint=*/true,
+                         /*flow_limit=*/c->flow != 0 && U <= FLOW_MAX_PARTICLES, lagr, lagr ? rank_units : 1, lagr);
+  if (rc) { poison(); return rc; }
+  int i0min = nt;
+  for (int u = 0; u < U; ++u) i0min = std::min(i0min, (int)i0[u]);
+
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+  auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_hdr = 0;
+  const size_t o_prm = al16(o_hdr + sizeof(ProgHdr) * (size_t)U);
+  const size_t o_noise = al16(o_prm + sizeof(double) * std::max<size_t>(1, bt.prm.size()));
+  const size_t o_map = al16(o_noise + sizeof(double) * (size_t)U);
+  const size_t o_slot = al16(o_map + sizeof(int32_t) * (size_t)U);
+  const size_t o_i0 = al16(o_slot + sizeof(int32_t) * (size_t)U);
+  const size_t o_ops = al16(o_i0 + sizeof(int32_t) * (size_t)U);
+  const size_t o_rep = al16(o_ops + bt.ops.size() + 4);                  // caller particle -> distinct particle (d_out_caller)
+  const size_t o_thdr = al16(o_rep + (d_out_caller ? sizeof(int32_t) * (size_t)P : 0));      // lag-table programs (rank tables)
+  const size_t o_tprm = al16(o_thdr + sizeof(LagTabHdr) * bt.thdr.size());
+  const size_t o_tops = al16(o_tprm + sizeof(double) * bt.tprm.size());
+  const size_t stage_bytes = al16(o_tops + bt.tops.size() + 4);
+  auto hipfail = [&](hipError_t e, const char* what) {
+    poison();
+    return fail(c, AGP_ERR_HIP, std::string("HIP error in the extension sweep (") + what + "): " + hipGetErrorString(e));
+  };
+#define EXTCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hipfail(e_, #expr); } while (0)
+  EXTCHK(s->stage.ensure(stage_bytes));
+  EXTCHK(s->h_stage.ensure(stage_bytes));
+  EXTCHK(s->out_lp.ensure(sizeof(double) * U + sizeof(int32_t) * U));
+  EXTCHK(s->h_out.ensure(sizeof(double) * U + sizeof(int32_t) * U));
+  {
+    char* h = static_cast<char*>(s->h_stage.p);
+    std::memcpy(h + o_hdr, bt.hdr.data(), sizeof(ProgHdr) * (size_t)U);
+    if (!bt.prm.empty()) std::memcpy(h + o_prm, bt.prm.data(), sizeof(double) * bt.prm.size());
+    double* hn = reinterpret_cast<double*>(h + o_noise);
+    int32_t* hs = reinterpret_cast<int32_t*>(h + o_slot);
+    int32_t* hi = reinterpret_cast<int32_t*>(h + o_i0);
+    for (int q = 0; q < U; ++q) { const int u = bt.order[q]; hn[q] = unoise[u]; hs[q] = slot[u]; hi[q] = i0[u]; }
+    std::memcpy(h + o_map, bt.order.data(), sizeof(int32_t) * (size_t)U);
+    std::memcpy(h + o_ops, bt.ops.data(), bt.ops.size());
+    if (d_out_caller) {
+      int32_t* hr = reinterpret_cast<int32_t*>(h + o_rep);
+      for (int p = 0; p < P; ++p) hr[p] = rep[p];
+    }
+    if (!bt.thdr.empty()) {
+      std::memcpy(h + o_thdr, bt.thdr.data(), sizeof(LagTabHdr) * bt.thdr.size());
+      std::memcpy(h + o_tprm, bt.tprm.data(), sizeof(double) * bt.tprm.size());
+      std::memcpy(h + o_tops, bt.tops.data(), bt.tops.size());
+    }
+  }
+  char* dstage = static_cast<char*>(s->stage.p);
+  EXTCHK(hipMemcpyAsync(dstage, s->h_stage.p, stage_bytes, hipMemcpyHostToDevice, st));
+  const int32_t* d_slot = reinterpret_cast<int32_t*>(dstage + o_slot);
+  const int32_t* d_i0 = reinterpret_cast<int32_t*>(dstage + o_i0);
+  double* d_lp = s->out_lp.as<double>();
+  int32_t* d_info = reinterpret_cast<int32_t*>(d_lp + U);
+
+  if (i0min < nt) {
+    if (lagr && bt.n_lag_tables > 0) {
+      EXTCHK(s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * rank_units * 256));
+      LagArgs la = {};
+      la.tt = c->d_ts_s; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
+      la.tops = reinterpret_cast<const uint8_t*>(dstage + o_tops); la.tprm = reinterpret_cast<const double*>(dstage + o_tprm);
+      la.n_tables = bt.n_lag_tables; la.tab = s->lagtab.as<double>(); la.nt = (int)((c->n_max + NB - 1) / NB);
+      la.full = 1; la.stride = rank_units * 256;
+      launch_lag_tables(st, la, rank_units, bt.n_lag_tables);
+      EXTCHK(hipGetLastError());
+    }
+    launch_init_extend(st, U, fs.vec.as<double>(), fs.nt_cap * NB, n_pad, c->d_xs, (int)n, d_slot, d_i0, fs.info.as<int>(), fs.ready.as<int>());
+    CovArgs cv = {};
+    cv.tt = c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
+    cv.hdr = reinterpret_cast<ProgHdr*>(dstage + o_hdr); cv.ops = reinterpret_cast<uint8_t*>(dstage + o_ops);
+    cv.prm = reinterpret_cast<double*>(dstage + o_prm); cv.noise = reinterpret_cast<double*>(dstage + o_noise);
+    cv.A = fs.A.as<double>(); cv.strideA = fs.strideA; cv.P = U; cv.logdt = ge_tab ? c->d_logdt : nullptr;
+    cv.lagtab = lagr ? s->lagtab.as<double>() : nullptr; cv.lagr = lagr ? c->d_rank : nullptr; cv.lag_stride = rank_units * 256;
+    cv.slot = d_slot; cv.i0 = d_i0;
+    const int nf = std::max(0, std::min(U, bt.n_fused));
+    const int dcov = nf > 0 ? bt.max_depth_fused : 0;
+    cv.p_off = nf;
+    EXTCHK(launch_cov(st, cv, nt * (nt + 1) / 2, U - nf, bt.max_cp, bt.max_depth));
+    CholArgs ca = {};
+    ca.A = cv.A; ca.strideA = fs.strideA; ca.W = fs.W.as<double>(); ca.wsteps = fs.nt_cap;
+    ca.vec = fs.vec.as<double>(); ca.ldv = fs.nt_cap * NB; ca.partial = fs.partial.as<double>(); ca.ntp = fs.nt_cap;
+    ca.info = fs.info.as<int>(); ca.ready = fs.ready.as<int>(); ca.P = U; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
+    set_cov(ca, cv);
+    ca.lag = lagr ? 1 : 0;
+    ca.n_fused = nf; ca.slot = d_slot; ca.i0 = d_i0;
+    // an extension touches every block column (the new rows' tiles of the old columns, then the new columns): one
+    // dataflow launch instead of nt small per-column launches, whatever the amount of work
+    if (c->flow > 0 || (c->flow < 0 && U <= FLOW_MAX_PARTICLES && (nt >= 3 || use_flow(c, U, nt)))) {
+      // dataflow schedule over the rows to compute: flags of the resident rows are pre-raised
+      const int ntri_cap = fs.nt_cap * (fs.nt_cap + 1) / 2, ntri = nt * (nt + 1) / 2;
+      EXTCHK(fs.tflag.ensure(sizeof(int) * (size_t)fs.n_slots * ntri_cap));
+      EXTCHK(fs.flowq.ensure(sizeof(int) * 8));
+      launch_init_flow_flags(st, U, fs.tflag.as<int>(), ntri_cap, ntri, d_slot, d_i0);
+      EXTCHK(hipMemsetAsync(fs.flowq.p, 0, sizeof(int) * 8, st));
+      ca.tflag = fs.tflag.as<int>(); ca.ntri = ntri_cap; ca.qnext = fs.flowq.as<int>();
+      launch_flow(dcov, 2 * c->n_cu, st, ca);
+      EXTCHK(hipGetLastError());
+    } else {
+      EXTCHK(run_factor_extend(st, ca, dcov, use_split_diag(c, U), i0min));
+    }
+  }
+  launch_finish_logpdf(st, fs.partial.as<double>(), fs.info.as<int>(), nt, U, (int)n, reinterpret_cast<const int*>(dstage + o_map), d_lp, d_info, d_slot, fs.nt_cap);
+  EXTCHK(hipGetLastError());
+  if (d_out_caller) {
+    launch_expand_rep(st, P, d_lp, reinterpret_cast<const int32_t*>(dstage + o_rep), d_out_caller);
+    EXTCHK(hipGetLastError());
+  }
+  EXTCHK(hipMemcpyAsync(s->h_out.p, d_lp, sizeof(double) * U + sizeof(int32_t) * U, hipMemcpyDeviceToHost, st));
+  EXTCHK(hipStreamSynchronize(st));
+  if (d_out_caller && wrote_device) *wrote_device = true;
+#undef EXTCHK
+  const double* hl = static_cast<const double*>(s->h_out.p);
+  const int32_t* hinfo = reinterpret_cast<const int32_t*>(hl + U);
+  for (int u = 0; u < U; ++u)
+    if (hinfo[u] < 0) { poison(); return fail(c, AGP_ERR_HIP, "in-kernel panel solve timed out waiting for its diagonal factor"); }
+  for (int u = 0; u < U; ++u) {
+    const int sl = slot[u];
+    fs.key[sl] = keys[u]; fs.index[keys[u]] = sl; fs.n_cached[sl] = n; fs.info_h[sl] = hinfo[u];
+    if (i0[u] > 0) ++fs.hits; else ++fs.misses;
+  }
+  fs.tile_rows_reused += rows_reused; fs.tile_rows_total += (int64_t)U * nt;
+  for (int p = 0; p < P; ++p) { out_lp[p] = hl[rep[p]]; out_info[p] = hinfo[rep[p]]; }
+  return AGP_OK;
+}
+
+
+
+extern "C" {
+
+int agp_logpdf_batch_extend(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
+                            const int32_t* prm_off, const double* prm, const double* noise, double* out_logpdf,
+                            int32_t* out_info) {
+  return extend_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info);
+}
+
+int agp_extend_stats(agp_ctx* c, int64_t* out4) {
+  if (!c || !out4) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->store.mu);
+  out4[0] = c->store.hits; out4[1] = c->store.misses; out4[2] = c->store.tile_rows_reused; out4[3] = c->store.tile_rows_total;
+  return AGP_OK;
+}
+
+int agp_predict_reuse_stats(agp_ctx* c, int64_t* out2) {
+  if (!c || !out2) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  out2[0] = c->pred_reused; out2[1] = c->pred_factored;
+  return AGP_OK;
+}
+
+int agp_grad_reuse_stats(agp_ctx* c, int64_t* out2) {
+  if (!c || !out2) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  out2[0] = c->grad_reused; out2[1] = c->grad_factored;
+  return AGP_OK;
+}
+
+int agp_get_lag_stats(agp_ctx* c, int32_t* regular_grid, int64_t* n_lag_sweeps) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  std::lock_guard<std::mutex> g(c->mu);
+  if (regular_grid) *regular_grid = (c->lag_enable && c->lag_ok) ? 1 : 0;
+  if (n_lag_sweeps) *n_lag_sweeps = c->n_lag_sweeps;
+  return AGP_OK;
+}
+
+int agp_set_lag_tables(agp_ctx* c, int32_t on) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  c->lag_enable = on != 0;
+  return AGP_OK;
+}
+
+int agp_set_lag_rank_tables(agp_ctx* c, int32_t on) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  c->lag_rank_enable = on != 0;
+  return AGP_OK;
+}
+
+int agp_get_lag_rank_stats(agp_ctx* c, int64_t* n_sweeps) {
+  if (!c || !n_sweeps) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  *n_sweeps = c->n_lag_rank_sweeps;
+  return AGP_OK;
+}
+
+int agp_get_lag_predict_stats(agp_ctx* c, int64_t* n_passes) {
+  if (!c || !n_passes) return fail(c, AGP_ERR_ARG, "null argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  *n_passes = c->n_lag_pred;
+  return AGP_OK;
+}
+
+int agp_set_grad_lag_domain(agp_ctx* c, int32_t on) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  c->grad_lagdom = on != 0;
+  return AGP_OK;
+}
+
+int agp_get_grad_lag_domain_stats(agp_ctx* c, int64_t* n_particles) {
+  if (!c || !n_particles) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  *n_particles = c->n_lagdom_particles;
+  return AGP_OK;
+}
+
+int agp_set_factor_cache(agp_ctx* c, int32_t on) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  c->factor_cache = on != 0;
+  return AGP_OK;
+}
+
+int agp_extend_reset(agp_ctx* c, int release_memory) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::lock_guard<std::mutex> g(c->store.mu);
+  if (release_memory) { HIPCHK(c, hipDeviceSynchronize()); c->store.release(); }
+  else c->store.forget();
+  return AGP_OK;
+}
+
+int agp_extend_reserve(agp_ctx* c, int64_t n_cap, int32_t n_slots) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (n_cap < 0 || n_slots < 0) return fail(c, AGP_ERR_ARG, "negative size");
+  HIPCHK(c, hipSetDevice(c->device));
+  std::lock_guard<std::mutex> g(c->store.mu);
+  const int nt_cap = std::max(c->store.nt_cap, round_up(std::max<int64_t>(n_cap, 1), NB) / NB);
+  const int slots = std::max(c->store.n_slots, (int)n_slots);
+  if ((size_t)slots * store_bytes_per_slot(nt_cap) > (size_t)(c->store.max_frac * (double)c->total_mem))
+    return fail(c, AGP_ERR_ARG, "reservation exceeds the store's share of device memory");
+  HIPCHK(c, hipDeviceSynchronize());
+  return store_resize(c, nt_cap, slots);
+}
+
+}  // extern "C"
