@@ -305,14 +305,17 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
   AGP_DPROBE(9);
 
   if (mark && tid == 0) *mark = (long long)wall_clock64();
-  // ---- write L(k,k) (upper part zero), alpha_k, partials, info ----
-  // (two rows per lane: 16-byte LDS reads and stores, 32 instructions per lane instead of 64)
+  // ---- write L(k,k), alpha_k, partials, info ----
+  // Only the 36 blocks of the lower block triangle are written (the diagonal blocks carry their zeros above the diagonal): no
+  // consumer reads the 28 blocks above — panel solves and the L^-T chains stage the strictly lower blocks and the inverse
+  // blocks, the K-loops never take a diagonal tile as an operand, the read-out kernels mirror the lower triangle — and with 512
+  // workgroups storing at the same time these 56 KiB per tile were 44 % of the launch's write traffic.
+  // (two rows per lane: 16-byte LDS reads and stores)
   for (int bi = 0; bi < NSB * NSB / 2; ++bi) {
     const int rb = 2 * (bi >> 3) + ((tid >> 3) & 1), cb = bi & 7;
     const int c = tid >> 4, r2 = 2 * (tid & 7);
-    d2 v = d2{0.0, 0.0};
-    if (rb >= cb) v = *reinterpret_cast<const d2*>(sm + blk_idx(rb, cb) * 256 + c * 16 + r2);
-    *reinterpret_cast<d2*>(Tt + (cb * 16 + c) * NB + rb * 16 + r2) = v;
+    if (rb >= cb)
+      *reinterpret_cast<d2*>(Tt + (cb * 16 + c) * NB + rb * 16 + r2) = *reinterpret_cast<const d2*>(sm + blk_idx(rb, cb) * 256 + c * 16 + r2);
   }
   AGP_DPROBE(10);
   if (tid < NB) {

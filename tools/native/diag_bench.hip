@@ -120,7 +120,7 @@ int main(int argc, char** argv) {
       }
     }
     const double* oL = oA.data() + (size_t)p * strideA + tile_off(K, K);
-    for (int c = 0; c < NB; ++c) for (int rr = 0; rr < NB; ++rr) eL = std::max(eL, (double)fabsl(L[c * NB + rr] - oL[c * NB + rr]));
+    for (int c = 0; c < NB; ++c) for (int rr = c; rr < NB; ++rr) eL = std::max(eL, (double)fabsl(L[c * NB + rr] - oL[c * NB + rr]));      // (lower triangle: the blocks above the diagonal are not written)
     // alpha = L^-1 r, partials
     std::vector<long double> al(NB);
     long double ld = 0, ss = 0;
