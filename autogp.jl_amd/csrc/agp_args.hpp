@@ -158,6 +158,8 @@ struct GradArgs {
   const double* tw;      // exp(-2 pi i k / 4096), k = 0 .. 4095, (re, im) pairs (k_zspec / k_lag_grad)
   const int32_t* klist; int kn;      // k_kinv_tiles: the particles whose K^-1 tiles are wanted (null: all P)
   double grid_h, grid_mid;           // regular grid: spacing, and the (fractional) rank of t_ref: t_sorted[r] - t_ref = (r - grid_mid) h
+  long long strideZ;                 // doubles per particle in Z (0: strideA)
+  double* dinv;                      // [P][ldv] diag(K^-1) = row sums of squares of Z (k_trtri_chain; null: not wanted)
 };
 
 struct GProgHdr {

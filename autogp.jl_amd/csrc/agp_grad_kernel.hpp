@@ -91,7 +91,6 @@ __device__ __forceinline__ void solve_in_regs(d4 (&acc)[NSB][2], const double* _
     for (int jb = 1; jb < NSB; ++jb) {
 #pragma unroll
       for (int lb = 0; lb < jb; ++lb) sm[sblk_idx(jb, lb) * 256 + tid] = Lkk[(lb * 16 + c) * NB + jb * 16 + r];
-      __builtin_amdgcn_sched_barrier(0);     // at most 7 staging loads in flight: the accumulators are live
     }
 #pragma unroll
     for (int u = 0; u < NSB; ++u) sm[(T_NBLK + u) * 256 + tid] = -Wg[u * 256 + tid];
@@ -128,6 +127,7 @@ __device__ __forceinline__ long long zoff(int r, int k) { return tile_off(k, r);
 // independent chains and no workgroup ever waits for another: one launch instead of nt, no launch tails, and the
 // row operand of every contraction is a tile this workgroup wrote itself (each lane re-reads exactly the elements it
 // stored).  Longest chains (j = 0: nt(nt-1)/2 tile contractions) are dispatched first.
+template <bool WANT_D>
 __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES];
   const int npl = (a.P + 7) / 8;
@@ -140,11 +140,14 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
   const int lsl = a.lslot != nullptr ? a.lslot[p] : -1;
   const double* __restrict__ Lp = lsl >= 0 ? a.Lsrc + (long long)lsl * a.Lstride : a.A + (long long)p * a.strideA;
   const double* __restrict__ Wp = lsl >= 0 ? a.Wsrc + (long long)lsl * a.Wnt * NSB * 256 : a.W + (long long)p * a.nt * NSB * 256;
-  double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
+  double* __restrict__ Zp = a.Z + (long long)p * (a.strideZ ? a.strideZ : a.strideA);
   // alpha_j = sum_{i >= j} Z(j,i) beta_i is formed here, from the tiles while they are in registers (a separate pass over Z
   // — k_alpha, what the per-column variant runs — read all 9 GB of it again: 2.3 ms per 512-particle sweep at n=2048)
   const double* __restrict__ bp = a.beta + (long long)p * a.ldv;
   double al0 = 0.0, al1 = 0.0;
+  // ... and diag(K^-1)_r = sum_c Z_rc^2 (K^-1 = Z Z^T) for the predictive shortcut at observed points (agp_predict.hip)
+  constexpr bool want_d = WANT_D;
+  double dz0 = 0.0, dz1 = 0.0;
 #pragma unroll 1
   for (int i = j; i < a.nt; ++i) {
     // acc = -C,  C = d_ji I - sum_{k=j}^{i-1} Z(j,k) L(i,k)^T
@@ -169,6 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
         *reinterpret_cast<d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
         const double bk = bp[i * NB + cb * 16 + 4 * r + lq];
         al0 = fma(acc[cb][0][r], bk, al0); al1 = fma(acc[cb][1][r], bk, al1);
+        if (want_d) { dz0 = fma(acc[cb][0][r], acc[cb][0][r], dz0); dz1 = fma(acc[cb][1][r], acc[cb][1][r], dz1); }
       }
     __syncthreads();      // the solve's LDS blocks are overwritten by the next contraction's first slab
   }
@@ -178,6 +182,14 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
   if (lq == 0) {
     d2 o2; o2.x = al0; o2.y = al1;
     *reinterpret_cast<d2*>(a.alpha + (long long)p * a.ldv + j * NB + row0) = o2;
+  }
+  if (want_d) {
+    dz0 += __shfl_xor(dz0, 16); dz1 += __shfl_xor(dz1, 16);
+    dz0 += __shfl_xor(dz0, 32); dz1 += __shfl_xor(dz1, 32);
+    if (lq == 0) {
+      d2 o2; o2.x = dz0; o2.y = dz1;
+      *reinterpret_cast<d2*>(a.dinv + (long long)p * a.ldv + j * NB + row0) = o2;
+    }
   }
 }
 
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
   const bool lagdom = (pflags & GFLAG_LAGDOM) != 0;
   if (lagdom)
     for (int i = tid; i < a.nbins; i += 256) bins[i] = 0.0;       // (published by the barriers of the slab loop)
-  const double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
+  const double* __restrict__ Zp = a.Z + (long long)p * (a.strideZ ? a.strideZ : a.strideA);
   d4 acc[NSB][2];
 #pragma unroll
   for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
@@ -640,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void k_zspec(GradArgs a) {
   __shared__ double red[4];
   const int kc = blockIdx.x, p = a.plist[blockIdx.y];
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, half = tid >> 7, row = tid & 127;
-  const double* __restrict__ Zp = a.Z + (long long)p * a.strideA;
+  const double* __restrict__ Zp = a.Z + (long long)p * (a.strideZ ? a.strideZ : a.strideA);
   const d2* __restrict__ tw = reinterpret_cast<const d2*>(a.tw);
   const int ncol = (a.n - kc * NB) < NB ? (a.n - kc * NB) : NB;
   // this thread's rows (one per tile row r <= kc): LDS slot of the row's rank, t - t_ref

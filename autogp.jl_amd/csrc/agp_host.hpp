@@ -320,14 +320,6 @@ inline bool use_split_diag(const agp_ctx* c, int P) {
   return c->split_diag > 0 || (c->split_diag < 0 && P >= SPLIT_DIAG_MIN_PARTICLES);
 }
 
-// Predictive passes carry nt - nt1 extra tile rows through every block column of the training block (V = L^-1 K12): from ~100
-// particles on, the sub-diagonal tiles of a column fill the GPU several times over and the specialised split launches (the
-// headline's kernels, tiles evaluated in-kernel) beat the mixed launch although the diagonal launch itself is under-filled
-// (n=2048, m=4096, 128 particles: 58.8 -> see profiles/r04*_predict_kernel_stats.txt).
-inline bool pred_split(const agp_ctx* c, int P, int nt, int nt1) {
-  return c->split_diag != 0 && P >= 96 && (long long)P * (nt - nt1) >= 2048;
-}
-
 // Right-looking schedule (see run_factor): below this many particles the left-looking launches cannot fill the GPU.
 constexpr int RIGHT_LOOKING_MAX_PARTICLES = 48;
 inline bool use_right_looking(const agp_ctx* c, int P) {

@@ -18,7 +18,10 @@ hipError_t kernels_init_grad() {
   return hipSuccess;
 }
 
-void launch_trtri_chain(hipStream_t st, int grid, const GradArgs& ga) { hipLaunchKernelGGL(k_trtri_chain, dim3(grid), dim3(256), 0, st, ga); }
+void launch_trtri_chain(hipStream_t st, int grid, const GradArgs& ga) {
+  if (ga.dinv != nullptr) hipLaunchKernelGGL(k_trtri_chain<true>, dim3(grid), dim3(256), 0, st, ga);
+  else hipLaunchKernelGGL(k_trtri_chain<false>, dim3(grid), dim3(256), 0, st, ga);
+}
 void launch_zspec(hipStream_t st, int nt, int P, const GradArgs& ga) { hipLaunchKernelGGL(k_zspec, dim3(nt, P), dim3(256), 0, st, ga); }
 void launch_kinv_tiles(hipStream_t st, int grid, const GradArgs& ga) { hipLaunchKernelGGL(k_kinv_tiles, dim3(grid), dim3(256), 0, st, ga); }
 hipError_t launch_grad_contract(int maxs, hipStream_t st, const GradArgs& ga, int ntiles, int P, size_t lds) {

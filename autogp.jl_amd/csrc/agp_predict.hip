@@ -61,14 +61,53 @@ void predict_lattice(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, Pr
   pl.on = true;
 }
 
+// Query points that are training points (see predict_core): positions in ts_pred + training indices, and the other queries.
+// Empty lists when the shortcut does not apply or would not pay.
+void split_queries(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, bool eligible,
+                   std::vector<int32_t>& dq, std::vector<int32_t>& di, std::vector<int32_t>& fq) {
+  dq.clear(); di.clear(); fq.clear();
+  if (!eligible || n < 2 * NB || m < NB) return;
+  auto bits = [](double x) { if (x == 0.0) x = 0.0; uint64_t u; std::memcpy(&u, &x, 8); return u; };
+  std::unordered_map<uint64_t, int32_t> at;
+  at.reserve((size_t)n * 2);
+  for (int64_t i = 0; i < n; ++i) at.emplace(bits(c->h_ts[(size_t)i]), (int32_t)i);
+  for (int64_t j = 0; j < m; ++j) {
+    auto it = ts_pred[j] == ts_pred[j] ? at.find(bits(ts_pred[j])) : at.end();
+    if (it != at.end()) { dq.push_back((int32_t)j); di.push_back(it->second); }
+    else fq.push_back((int32_t)j);
+  }
+  // (worth it once the duplicates' share of V costs more than the n^3/3 of Z)
+  if ((int64_t)dq.size() * 3 < n || (int64_t)dq.size() < NB) { dq.clear(); di.clear(); fq.clear(); }
+}
+
 int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P, Batch& bt,
                  const double* noise, const double* noise_pred, const uint8_t* pred_code, const double* diag_add,
                  const double* mean_train, const double* mean_pred, double* out_mean, double* out_var,
                  double* out_cov, int32_t* out_info, const std::vector<std::string>* keys = nullptr,
                  const PredLattice* pl = nullptr) {
   const int n1_pad = round_up(n, NB);           // 0 when n == 0
-  const int m_pad = round_up(m, NB);
   const bool lagr = pl != nullptr && pl->on;
+  // ---- query points that ARE training points, no covariance requested ----------------------------------------------
+  // For t*_j == t_i the cross-covariance row is K21[j,:] = K11[i,:] - noise e_i^T (src/GP.jl:743-747 evaluates the kernel
+  // on the joint list; the noise sits on K11's diagonal only), so with alpha = K11^-1 (y - mu1):
+  //     mean*_j = mu2_j + (y - mu1)_i - noise alpha_i,      var*_j = noise - noise^2 (K11^-1)_ii + noise_pred,
+  // and (K11^-1)_ii = sum_c Z(i,c)^2 with Z = L^-T: k_trtri_chain forms Z and alpha in n^3/3 flops per particle where the
+  // joint path spends n^2 flops PER SUCH POINT on V = L^-1 K12 (the reference's query set is train + test + future,
+  // scripts/online.jl:41-43: n of its points are of this kind).  The other query points take the joint path below.
+  std::vector<int32_t> dq, di, fq;      // duplicates: position in ts_pred, training index; the remaining queries
+  split_queries(c, n, ts_pred, m, !out_cov && !pred_code, dq, di, fq);
+  const bool diag_path = !dq.empty();
+  const int64_t mJ = diag_path ? (int64_t)fq.size() : m;      // query points of the joint matrix
+  std::vector<double> tsF, meanF, daddF;
+  const double* tsJ = ts_pred; const double* meanJ = mean_pred; const double* daddJ = diag_add;
+  if (diag_path) {
+    tsF.resize((size_t)mJ);
+    for (int64_t g = 0; g < mJ; ++g) tsF[(size_t)g] = ts_pred[fq[(size_t)g]];
+    tsJ = tsF.data();
+    if (mean_pred) { meanF.resize((size_t)mJ); for (int64_t g = 0; g < mJ; ++g) meanF[(size_t)g] = mean_pred[fq[(size_t)g]]; meanJ = meanF.data(); }
+    if (diag_add) { daddF.resize((size_t)mJ); for (int64_t g = 0; g < mJ; ++g) daddF[(size_t)g] = diag_add[fq[(size_t)g]]; daddJ = daddF.data(); }
+  }
+  const int m_pad = round_up(mJ, NB);
   const int nt1 = n1_pad / NB, nt2 = m_pad / NB, nt = nt1 + nt2;
   // resident factors (sorted order): store slot per particle, first tile row to compute
   std::vector<int32_t> src_slot, i0v;
@@ -88,13 +127,14 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
   const int ntot = n1_pad + m_pad;
   const int ntiles = nt * (nt + 1) / 2;
   const long long strideA = (long long)ntiles * NB2;
-  const int64_t bytes_pp = strideA * 8;
+  const long long strideZ = diag_path ? (long long)(nt1 * (nt1 + 1) / 2) * NB2 : 0;      // Z = L11^-T (training tiles only)
+  const int64_t bytes_pp = (strideA + strideZ) * 8;
   const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(P, ws_limit_bytes(c) / bytes_pp));
 
   // joint point list [ts(1:n), pad, ts_pred, pad]
   std::vector<double> tt((size_t)ntot, 0.0);
   std::copy(c->h_ts.begin(), c->h_ts.begin() + n, tt.begin());
-  std::copy(ts_pred, ts_pred + m, tt.begin() + n1_pad);
+  std::copy(tsJ, tsJ + mJ, tt.begin() + n1_pad);
   std::vector<double> npred(P), noise_sorted(P);
   for (int q = 0; q < P; ++q) {
     const int p = bt.order[q];
@@ -102,7 +142,12 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     npred[q] = noise_pred ? noise_pred[p] : noise[p];
   }
 
-  HIPCHK(c, s->A.ensure((size_t)bytes_pp * chunk));
+  HIPCHK(c, s->A.ensure((size_t)strideA * 8 * chunk));
+  if (diag_path) {
+    HIPCHK(c, s->Z.ensure((size_t)strideZ * 8 * chunk));
+    HIPCHK(c, s->alpha.ensure(sizeof(double) * (size_t)ntot * chunk));
+    HIPCHK(c, s->gpart.ensure(sizeof(double) * (size_t)ntot * chunk));      // diag(K11^-1) (the gradient path's scratch, idle here)
+  }
   HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256 * (size_t)chunk * std::max(1, nt1)));     // (the dataflow schedule keeps every column's inverse blocks)
   HIPCHK(c, s->vec.ensure(sizeof(double) * (size_t)ntot * chunk));
   HIPCHK(c, s->partial.ensure(sizeof(double) * 2 * (size_t)nt * chunk));
@@ -114,16 +159,16 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
   HIPCHK(c, s->noise.ensure(sizeof(double) * (size_t)P));
   HIPCHK(c, s->noise_pred.ensure(sizeof(double) * (size_t)P));
   HIPCHK(c, s->tt.ensure(sizeof(double) * (size_t)ntot));
-  HIPCHK(c, s->pred_mean.ensure(sizeof(double) * (size_t)m * chunk));
-  HIPCHK(c, s->pred_var.ensure(sizeof(double) * (size_t)m * chunk));
+  HIPCHK(c, s->pred_mean.ensure(sizeof(double) * (size_t)std::max<int64_t>(1, mJ) * chunk));
+  HIPCHK(c, s->pred_var.ensure(sizeof(double) * (size_t)std::max<int64_t>(1, mJ) * chunk));
   if (out_cov) HIPCHK(c, s->pred_cov.ensure(sizeof(double) * (size_t)m * m * chunk));
   if (mean_train && n > 0) {
     HIPCHK(c, s->mu1.ensure(sizeof(double) * (size_t)n));
     HIPCHK(c, hipMemcpyAsync(s->mu1.p, mean_train, sizeof(double) * n, hipMemcpyHostToDevice, st));
   }
-  if (mean_pred) {
-    HIPCHK(c, s->mu2.ensure(sizeof(double) * (size_t)m));
-    HIPCHK(c, hipMemcpyAsync(s->mu2.p, mean_pred, sizeof(double) * m, hipMemcpyHostToDevice, st));
+  if (mean_pred && mJ > 0) {
+    HIPCHK(c, s->mu2.ensure(sizeof(double) * (size_t)mJ));
+    HIPCHK(c, hipMemcpyAsync(s->mu2.p, meanJ, sizeof(double) * mJ, hipMemcpyHostToDevice, st));
   }
   HIPCHK(c, hipMemcpyAsync(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr) * P, hipMemcpyHostToDevice, st));
   HIPCHK(c, hipMemcpyAsync(s->ops.p, bt.ops.data(), bt.ops.size(), hipMemcpyHostToDevice, st));
@@ -139,9 +184,9 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     HIPCHK(c, hipMemcpyAsync(s->code.p, code.data(), (size_t)ntot, hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));     // `code` is a local
   }
-  if (diag_add) {
-    HIPCHK(c, s->diag_add.ensure(sizeof(double) * (size_t)m));
-    HIPCHK(c, hipMemcpyAsync(s->diag_add.p, diag_add, sizeof(double) * m, hipMemcpyHostToDevice, st));
+  if (diag_add && mJ > 0) {
+    HIPCHK(c, s->diag_add.ensure(sizeof(double) * (size_t)mJ));
+    HIPCHK(c, hipMemcpyAsync(s->diag_add.p, daddJ, sizeof(double) * mJ, hipMemcpyHostToDevice, st));
   }
 
   const int32_t* d_src = nullptr; const int32_t* d_i0 = nullptr;
@@ -166,10 +211,18 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       std::memcpy(hp.data() + o_tops, bt.tops.data(), bt.tops.size());
     }
     HIPCHK(c, s->pl_prog.ensure(prog_bytes));
-    HIPCHK(c, s->pl_rank.ensure(sizeof(int32_t) * pl->rank.size()));
+    // (the joint layout keeps the queries that are not training points only)
+    std::vector<int32_t> rankF;
+    if (diag_path) {
+      rankF.assign((size_t)ntot, 0);
+      std::copy(pl->rank.begin(), pl->rank.begin() + n1_pad, rankF.begin());
+      for (int64_t g = 0; g < mJ; ++g) rankF[(size_t)n1_pad + g] = pl->rank[(size_t)n1_pad + fq[(size_t)g]];
+    }
+    const std::vector<int32_t>& rankJ = diag_path ? rankF : pl->rank;
+    HIPCHK(c, s->pl_rank.ensure(sizeof(int32_t) * rankJ.size()));
     HIPCHK(c, s->pl_tl.ensure(sizeof(double) * pl->tl.size()));
     HIPCHK(c, hipMemcpyAsync(s->pl_prog.p, hp.data(), prog_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(s->pl_rank.p, pl->rank.data(), sizeof(int32_t) * pl->rank.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(s->pl_rank.p, rankJ.data(), sizeof(int32_t) * rankJ.size(), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipMemcpyAsync(s->pl_tl.p, pl->tl.data(), sizeof(double) * pl->tl.size(), hipMemcpyHostToDevice, st));
     HIPCHK(c, hipStreamSynchronize(st));      // `hp` is a local
     if (bt.n_lag_tables > 0) {
@@ -187,7 +240,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     ++c->n_lag_pred;
   }
 
-  std::vector<double> h_mean, h_var;
+  std::vector<double> h_mean, h_var, h_alpha, h_dinv;
   for (int p0 = 0; p0 < P; p0 += chunk) {
     const int Pc = std::min(chunk, P - p0);
     launch_init_vec(st, ntot, Pc, s->vec.as<double>(), c->d_xs, (mean_train && n > 0) ? s->mu1.as<double>() : (const double*)nullptr, (int)n, s->info.as<int>() + p0, s->ready.as<int>() + p0);
@@ -204,7 +257,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       }
     }
     CovArgs cv = {};
-    cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n1_pad; cv.m2 = (int)m; cv.nt = nt;
+    cv.tt = s->tt.as<double>(); cv.n1 = (int)n; cv.n1_pad = n1_pad; cv.m2 = (int)mJ; cv.nt = nt;
     cv.hdr = s->hdr.as<ProgHdr>() + p0; cv.ops = s->ops.as<uint8_t>(); cv.prm = s->prm.as<double>();
     cv.noise = s->noise.as<double>() + p0; cv.A = s->A.as<double>(); cv.strideA = strideA; cv.P = Pc;
     cv.code = pred_code ? s->code.as<uint8_t>() : nullptr;
@@ -224,7 +277,8 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     ca.lag = lagr ? 1 : 0;
     ca.n_fused = nf;
     ca.ready = s->ready.as<int>() + p0;
-    if (n_hit > 0) { ca.i0 = d_i0 + p0; ca.wsteps = nt1; }      // panel solves of the prediction rows read every column's inverse blocks
+    if (n_hit > 0 || diag_path) ca.wsteps = nt1;      // panel solves of the prediction rows / the chains of Z read every column's inverse blocks
+    if (n_hit > 0) ca.i0 = d_i0 + p0;
     if (nt1 > 0 && use_flow(c, Pc, nt, nt1)) {
       // dataflow schedule over the block columns of the training block (all rows: V = L^-1 K12 comes out of the same tiles)
       const int ntri = nt * (nt + 1) / 2;
@@ -243,11 +297,23 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       // per-column launches restricted to the rows some particle still has to compute
       int i0min = nt1;
       for (int q = 0; q < Pc; ++q) i0min = std::min(i0min, (int)i0v[(size_t)p0 + q]);
-      HIPCHK(c, run_factor_extend(st, ca, dcov, use_split_diag(c, ca.P) || pred_split(c, ca.P, nt, nt1), i0min, nt1));
+      HIPCHK(c, run_factor_extend(st, ca, dcov, use_split_diag(c, ca.P), i0min, nt1));
     } else {
-      HIPCHK(c, run_factor(st, ca, nt1, dcov, nullptr, nullptr, use_split_diag(c, ca.P) || pred_split(c, ca.P, nt, nt1)));
+      HIPCHK(c, run_factor(st, ca, nt1, dcov, nullptr, nullptr, use_split_diag(c, ca.P)));
     }
-    {
+    if (diag_path) {
+      // Z = L11^-T row chains; alpha = Z beta and diag(K11^-1) = row sums of Z.^2 come out of the same registers
+      GradArgs ga = {};
+      ga.A = s->A.as<double>(); ga.strideA = strideA; ga.Z = s->Z.as<double>(); ga.strideZ = strideZ; ga.W = s->W.as<double>();
+      ga.beta = s->vec.as<double>(); ga.alpha = s->alpha.as<double>(); ga.dinv = s->gpart.as<double>(); ga.ldv = ntot;
+      ga.P = Pc; ga.nt = nt1; ga.n = (int)n;
+      launch_trtri_chain(st, 8 * ((Pc + 7) / 8) * nt1, ga);
+      HIPCHK(c, hipGetLastError());
+      h_alpha.resize((size_t)ntot * Pc); h_dinv.resize((size_t)ntot * Pc);
+      HIPCHK(c, hipMemcpyAsync(h_alpha.data(), s->alpha.p, sizeof(double) * ntot * Pc, hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(h_dinv.data(), s->gpart.p, sizeof(double) * ntot * Pc, hipMemcpyDeviceToHost, st));
+    }
+    if (mJ > 0) {
       // Schur complement of the prediction block + (-V^T alpha); with nt1 == 0 this just
       // passes K22 through.
       // without a covariance request only the diagonal tiles are updated: mean and marginal variances cost
@@ -266,23 +332,38 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       }
       launch_update_schur(dcov_s, 8 * Pg * T, st, ca);
     }
+    if (mJ > 0) {
     PredArgs pa = {};
     pa.A = s->A.as<double>(); pa.strideA = strideA; pa.vec = s->vec.as<double>(); pa.ldv = ntot;
     pa.mu2 = mean_pred ? s->mu2.as<double>() : nullptr; pa.noise_pred = s->noise_pred.as<double>() + p0;
-    pa.nt1 = nt1; pa.n1_pad = n1_pad; pa.m = (int)m; pa.P = Pc;
+    pa.nt1 = nt1; pa.n1_pad = n1_pad; pa.m = (int)mJ; pa.P = Pc;
     pa.diag_add = diag_add ? s->diag_add.as<double>() : nullptr;
     pa.out_mean = s->pred_mean.as<double>(); pa.out_var = s->pred_var.as<double>();
     pa.out_cov = out_cov ? s->pred_cov.as<double>() : nullptr;
-    const long long nel = out_cov ? (long long)m * m : (long long)m;
+    const long long nel = out_cov ? (long long)mJ * mJ : (long long)mJ;
     launch_pred_extract(st, nel, Pc, pa);
     HIPCHK(c, hipGetLastError());
     // results come back in sorted order: scatter to the caller's particle order
-    h_mean.resize((size_t)m * Pc); h_var.resize((size_t)m * Pc);
-    HIPCHK(c, hipMemcpyAsync(h_mean.data(), s->pred_mean.p, sizeof(double) * m * Pc, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(h_var.data(), s->pred_var.p, sizeof(double) * m * Pc, hipMemcpyDeviceToHost, st));
+    h_mean.resize((size_t)mJ * Pc); h_var.resize((size_t)mJ * Pc);
+    HIPCHK(c, hipMemcpyAsync(h_mean.data(), s->pred_mean.p, sizeof(double) * mJ * Pc, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(h_var.data(), s->pred_var.p, sizeof(double) * mJ * Pc, hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(c, hipStreamSynchronize(st));
     for (int q = 0; q < Pc; ++q) {
       const size_t o = (size_t)bt.order[p0 + q];
+      if (diag_path) {
+        double* om = out_mean + o * m; double* ov = out_var + o * m;
+        for (int64_t g = 0; g < mJ; ++g) { om[fq[(size_t)g]] = h_mean[(size_t)q * mJ + g]; ov[fq[(size_t)g]] = h_var[(size_t)q * mJ + g]; }
+        const double s2 = noise_sorted[(size_t)p0 + q], np2 = npred[(size_t)p0 + q];
+        const double* al = h_alpha.data() + (size_t)q * ntot; const double* dv = h_dinv.data() + (size_t)q * ntot;
+        for (size_t d = 0; d < dq.size(); ++d) {
+          const int32_t j = dq[d], i = di[d];
+          const double ymu = c->h_xs[(size_t)i] - (mean_train ? mean_train[i] : 0.0);
+          om[j] = (mean_pred ? mean_pred[j] : 0.0) + ymu - s2 * al[i];
+          ov[j] = s2 - s2 * s2 * dv[i] + np2 + (diag_add ? diag_add[j] : 0.0);
+        }
+        continue;
+      }
       std::memcpy(out_mean + o * m, h_mean.data() + (size_t)q * m, sizeof(double) * m);
       std::memcpy(out_var + o * m, h_var.data() + (size_t)q * m, sizeof(double) * m);
       if (out_cov)
@@ -355,11 +436,17 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   const bool want_keys = c->predict_reuse && n > 0 && !mean_train && c->store.n_slots > 0;
   PredLattice pl;
   predict_lattice(c, n, ts_pred, m, pl);
+  int64_t m_joint = m;       // query points predict_core keeps in the joint matrix (it makes the same split)
+  {
+    std::vector<int32_t> dq, di, fq;
+    split_queries(c, n, ts_pred, m, !out_cov, dq, di, fq);
+    if (!dq.empty()) m_joint = (int64_t)fq.size();
+  }
   if (U == 0 || U == P) {
     Batch bt;
-    const int nt1_ = (int)((n + NB - 1) / NB), nt_ = nt1_ + (int)((m + NB - 1) / NB);
+    const int nt1_ = (int)((n + NB - 1) / NB), nt_ = nt1_ + (int)((m_joint + NB - 1) / NB);
     const bool ff = n > 0 && use_flow(c, P, nt_, nt1_);
-    const bool fh = ff || (n > 0 && pred_split(c, P, nt_, nt1_));
+    const bool fh = ff;
     int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, false, false, fh, ff, pl.on, pl.on ? pl.rank_units : 1, pl.on);
     if (rc) return rc;
     std::vector<std::string> keys;
@@ -382,9 +469,9 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   if (uprm.empty()) uprm.push_back(0.0);
   std::vector<double> umean((size_t)U * m), uvar((size_t)U * m), ucov(out_cov ? (size_t)U * m * m : 0);
   Batch bt;
-  const int nt1_ = (int)((n + NB - 1) / NB), nt_ = nt1_ + (int)((m + NB - 1) / NB);
+  const int nt1_ = (int)((n + NB - 1) / NB), nt_ = nt1_ + (int)((m_joint + NB - 1) / NB);
   const bool ff = n > 0 && use_flow(c, U, nt_, nt1_);
-  const bool fh = ff || (n > 0 && pred_split(c, U, nt_, nt1_));
+  const bool fh = ff;
   int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, false, fh, ff, pl.on, pl.on ? pl.rank_units : 1, pl.on);
   if (rc) return rc;
   std::vector<std::string> keys;

@@ -272,6 +272,66 @@ def test_predictive_pass_on_lattice_query_points(pkg, case):
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("case", ["train_only", "train_future", "scattered", "means", "general_times", "reuse", "population", "below_threshold"])
+def test_predictive_pass_on_training_point_queries(pkg, case):
+    """Query points that are training points (scripts/online.jl:41-43: ds_query starts with model.ds) and no covariance request:
+    mean and marginal variance come from alpha and diag(K11^-1) (row sums of squares of L^-T), the remaining queries from the
+    joint matrix.  Against the oracle (src/GP.jl:739-757 restated) and against the same call with the covariance requested,
+    which never takes this route."""
+    from oracle import oracle as O
+    G = pkg
+    rng = np.random.default_rng(5)
+    n_max, n = 420, 390
+    if case == "general_times":
+        ts = np.sort(rng.uniform(0.0, 1.0, n_max)); ts[7] = 0.0          # (+0.0 / -0.0 compare equal)
+    else:
+        ts = np.linspace(0.0, 1.0, n_max)[rng.permutation(n_max)]
+    xs = np.cos(9 * ts) + 0.3 * ts + 0.1 * rng.standard_normal(n_max)
+    h = 1.0 / (n_max - 1)
+    fut = 1.0 + h * np.arange(1, 61)
+    if case == "train_only":        tq = ts[:n].copy()
+    elif case == "scattered":       tq = np.concatenate([fut[:7], ts[rng.permutation(n)[:300]], [0.3337], ts[:40], fut[7:]])    # repeats among the queries
+    elif case == "below_threshold": tq = np.concatenate([ts[:100], fut])          # too few duplicates: joint path
+    else:                           tq = np.concatenate([ts[:n_max], fut])
+    if case == "general_times":     tq[7] = -0.0
+    ks = [G.SquaredExponential(0.1, 0.8), G.Periodic(0.7, 0.21, 1.1) * G.SquaredExponential(0.5, 0.9) + G.Linear(0.3, 0.2, 0.5),
+          G.GammaExponential(0.3, 1.2, 0.7) + G.WhiteNoise(0.05), G.ChangePoint(G.Periodic(0.5, 0.1, 1.0), G.SquaredExponential(0.2, 0.6), 0.45, 0.01),
+          G.Linear(0.1, 0.3, 0.7), G.Constant(0.3) + G.GammaExponential(0.15, 0.8, 0.5) * G.Periodic(1.0, 0.3, 0.8)]
+    nz = np.linspace(0.01, 0.2, len(ks)); npred = np.linspace(0.3, 0.02, len(ks))
+    n_or = len(ks)
+    if case == "population":
+        nodes, nzs = pkg.prior.sample_particles(np.random.default_rng(3), 90, max_depth=3)
+        ks = ks + list(nodes); nz = np.concatenate([nz, nzs]); npred = np.concatenate([npred, 0.5 * nzs])
+    kw = {}
+    mean_fn = None
+    if case == "means":
+        mean_fn = lambda t: 0.4 - 1.3 * t
+        kw = dict(mean_train=np.array([mean_fn(t) for t in ts[:n]]), mean_pred=np.array([mean_fn(t) for t in tq]))
+    e = pkg.GPEngine(0)
+    try:
+        e.set_data(ts, xs)
+        if case == "reuse":         # factors of exactly this prefix are resident
+            e.logpdf_batch_extend(ks, nz, n=n, check=False)
+        r0 = e.predict_reuse_stats()["reused"]
+        m1, v1, _, i1 = e.predict_batch(ks, nz, tq, n=n, noise_pred=npred, want_cov=False, check=False, **kw)
+        assert (e.predict_reuse_stats()["reused"] - r0 > 0) == (case == "reuse")
+        m2, v2, c2, i2 = e.predict_batch(ks, nz, tq, n=n, noise_pred=npred, want_cov=True, check=False, **kw)
+        assert np.array_equal(i1, i2)
+        ok = i1 == 0
+        assert ok[:n_or].all() and ok.mean() >= 0.9
+        assert np.isnan(m1[~ok]).all() and np.isnan(v1[~ok]).all()
+        sc = np.maximum(1.0, np.abs(m2[ok]).max(axis=1))[:, None]
+        assert (np.abs(m1[ok] - m2[ok]) / sc).max() <= 1e-9
+        assert (np.abs(v1[ok] - v2[ok]) / np.maximum(1.0, v2[ok])).max() <= 1e-9
+        assert np.allclose(np.diagonal(c2[ok], axis1=1, axis2=2), v2[ok], rtol=0, atol=1e-12)
+        for i in range(n_or):
+            mu, cv = O.predict_mvn(ks[i].to_tuple(), float(nz[i]), ts[:n], xs[:n], tq, noise_pred=float(npred[i]), mean=mean_fn)
+            assert np.abs(m1[i] - mu).max() <= LP_TOL * max(1.0, np.abs(mu).max()), (case, i)
+            assert np.abs(v1[i] - np.diag(cv)).max() <= LP_TOL * max(1.0, np.abs(cv).max()), (case, i)
+    finally:
+        e.close()
+
+
 def test_predictive_lattice_pass_reuses_resident_factors(pkg):
     """The per-step callback of the streaming workload (scripts/online.jl:43,59): factors left by the reweight sweep (rank
     tables) are reused by a predictive pass on lattice query points; same result as a pass that factors itself."""

@@ -7,6 +7,6 @@ prof() { name=$1; shift; cd /tmp && export TMPDIR=/tmp; rm -rf $R/gpurun_out/px_
   rocprofv3 --kernel-trace --stats -d $R/gpurun_out/px_$name -o x -- "$@" > $R/gpurun_out/px_$name.log 2>&1
   cd $R; python tools/rocprof_summary.py $(find gpurun_out/px_$name -name "*.db" | head -1) gpurun_out/${TAG}_${name}_kernel_stats.txt --cmd "$*" | head -14; }
 prof grad python $R/tools/gpu_grad_perf.py 2048x512
-prof predict python $R/tools/gpu_predict_perf.py
-prof extend python $R/tools/gpu_extend_perf.py ${TAG}x
+prof predict python $R/tools/gpu_predict_perf.py 2048:2048:128
+prof extend python $R/tools/gpu_extend_profile.py 512
 prof stream python $R/tools/run_stream.py --rejuvenate --predict
