@@ -160,6 +160,12 @@ struct GradArgs {
   double grid_h, grid_mid;           // regular grid: spacing, and the (fractional) rank of t_ref: t_sorted[r] - t_ref = (r - grid_mid) h
   long long strideZ;                 // doubles per particle in Z (0: strideA)
   double* dinv;                      // [P][ldv] diag(K^-1) = row sums of squares of Z (k_trtri_chain; null: not wanted)
+  // Toeplitz variant of the lag-domain particles (k_toep_solve / k_lag_grad): K^-1 [e_first, 1, t - t_ref] per particle
+  // ([P][3][ldv]), and the rank of the sweep's first point in time (its points occupy ranks rank0 .. rank0 + n - 1)
+  double* tsol; int rank0;
+  const double* noise;               // [P] observation noise of the group's particles
+  double toep_max_amp;               // largest accepted entry of U' T^-1 U C (k_lag_grad)
+  int32_t* retry;                    // [caller's P] set when the Linear leaves' downdate is too ill-conditioned: the host repeats that particle with L^-T
 };
 
 struct GProgHdr {
@@ -174,6 +180,9 @@ struct GProgHdr {
                       // bit 2 (with bit 1): the lag sums of K^-1 come from the power spectrum of Z's columns (k_zspec), no K^-1 tiles at all
 constexpr int GFLAG_LAGDOM = 2;
 constexpr int GFLAG_LAGFFT = 4;
+                      // bit 3 (with bit 1): the sweep's points are n consecutive grid points, so K = Toeplitz + the Linear leaves' rank-2
+                      // term: the lag sums of K^-1 follow from four solves with L (Gohberg-Semencul) — no L^-T, no K^-1 tiles
+constexpr int GFLAG_LAGTOEP = 8;
 constexpr int LAGDOM_MAX_BINS = 4096;      // LDS histogram of k_kinv_tiles (32 KiB)
 constexpr int FFT_N = 4096;                // transform length of the spectral variant: series of up to FFT_N / 2 points
 

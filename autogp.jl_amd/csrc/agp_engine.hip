@@ -542,6 +542,9 @@ void launch_gather(agp_ctx* c, hipStream_t st, int Pc, int nt1, double* dstA, lo
   launch_gather_factor(st, gx, Pc, ga);
 }
 
+// (set around the repeat of particles whose Toeplitz downdate was rejected: the nested sweep takes L^-T for them)
+static thread_local bool tl_no_toep = false;
+
 int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
                       const int32_t* prm_off, const double* prm, const double* noise,
                       double* h_out_lp, int32_t* h_out_info, double* d_user_lp, int32_t* d_user_info,
@@ -574,10 +577,22 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   if (lag) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_sweeps; }
   // Gradient sweeps on a regular grid (any order of the points): particles whose kernel is a sum of stationary subtrees and
   // Linear leaves are contracted in the lag domain (k_kinv_tiles / k_lag_grad, agp_grad_kernel.hpp)
+  int32_t toep_rank0 = 0;
+  bool any_toep_sweep = false;                 // some particle of this sweep took the Toeplitz solves
+  std::vector<int32_t> toep_retry;             // ... and (caller order) whether its downdate was rejected on the device
   if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->n_max <= LAGDOM_MAX_BINS) {
     int64_t n_cov = 0;
     // (the transform has one length, 4096: below ~1000 points the K^-1 tiles are cheaper than n/2 transforms of that length)
     const bool use_fft = c->grad_fft && c->d_fft_tw != nullptr && 2 * c->n_max <= FFT_N && n > GRAD_FFT_MIN_N;      // (n: this sweep's prefix — the number of transforms)
+    // the sweep's points are n consecutive grid points (the whole series; a prefix of a series in time order): K is Toeplitz
+    // plus the Linear leaves' rank-2 term in sorted order — lag sums of K^-1 from four solves (k_toep_solve)
+    bool use_toep = !tl_no_toep && c->grad_fft >= 2 && c->d_fft_tw != nullptr && 2 * c->n_max <= FFT_N && n >= GRAD_TOEP_MIN_N && (int64_t)c->h_rank.size() >= n;
+    if (use_toep) {
+      int32_t lo = c->h_rank[0], hi = c->h_rank[0];
+      for (int64_t i = 1; i < n; ++i) { lo = std::min(lo, c->h_rank[(size_t)i]); hi = std::max(hi, c->h_rank[(size_t)i]); }
+      use_toep = (int64_t)hi - lo + 1 == n;
+      toep_rank0 = lo;
+    }
     for (int q = 0; q < P; ++q) {
       GProgHdr& g = bt.ghdr[q];
       if (g.n_cp > 0 || g.n_ops > 64) continue;
@@ -592,10 +607,12 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           cov[i] = stat[i] || o == OP_LIN;
         }
       }
-      if (g.n_ops > 0 && cov[g.n_ops - 1]) { g.flags |= GFLAG_LAGDOM | (use_fft ? GFLAG_LAGFFT : 0); ++n_cov; }
+      if (g.n_ops > 0 && cov[g.n_ops - 1]) { g.flags |= GFLAG_LAGDOM | (use_toep ? GFLAG_LAGTOEP : use_fft ? GFLAG_LAGFFT : 0); ++n_cov; }
     }
     std::lock_guard<std::mutex> g(c->mu);
     c->n_lagdom_particles += n_cov;
+    if (use_toep) c->n_toep_particles += n_cov;
+    any_toep_sweep = use_toep && n_cov > 0;
   }
   const int n_prm_total = prm_off[P];
   if (go && n == 0) {
@@ -655,6 +672,9 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     if (go) {
       HIPCHK(c, s->Z.ensure((size_t)strideA * 8 * chunk));
       HIPCHK(c, s->alpha.ensure(sizeof(double) * (size_t)n_pad * chunk));
+      HIPCHK(c, s->tsol.ensure(sizeof(double) * 3 * (size_t)n_pad * chunk));
+      HIPCHK(c, s->tretry.ensure(sizeof(int32_t) * (size_t)P));
+      HIPCHK(c, hipMemsetAsync(s->tretry.p, 0, sizeof(int32_t) * (size_t)P, st));
       HIPCHK(c, s->gpart.ensure(sizeof(double) * (size_t)chunk * ntiles * gstride));
       HIPCHK(c, s->ghdr.ensure(sizeof(GProgHdr) * (size_t)P));
       HIPCHK(c, s->gops.ensure(bt.gops.size() + 4)); HIPCHK(c, s->glc.ensure(bt.glc.size() + 4)); HIPCHK(c, s->grc.ensure(bt.grc.size() + 4));
@@ -855,20 +875,15 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             ga.lslot = d_src + p0 + g0; ga.Lsrc = c->store.A.as<double>(); ga.Lstride = c->store.strideA;
             ga.Wsrc = c->store.W.as<double>(); ga.Wnt = c->store.nt_cap;
           }
-          const int Pg8 = (Pg + 7) / 8;
-          const size_t gm0 = pf.mark(q);
-          launch_trtri_chain(q, 8 * Pg8 * nt, ga);      // (forms alpha = Z beta as well)
-          const size_t gm1 = pf.mark(q);
-          pf.span(8, gm0, gm1);
-          size_t gm2 = pf.mark(q);
-          pf.span(11, gm1, gm2);
-          // One contraction launch per group, largest trees first (their workgroups run longest); the 16-node
-          // (800 B private memory) variant serves groups without a larger tree.
+          ga.tsol = s->tsol.as<double>() + (size_t)g0 * 3 * n_pad; ga.rank0 = toep_rank0;
+          ga.noise = cv.noise; ga.retry = s->tretry.as<int32_t>(); ga.toep_max_amp = GRAD_TOEP_MAX_AMP;
+          // Particle list of the group, largest trees first (their workgroups run longest), lag-domain particles behind the
+          // others: the contraction launches below take the first Pn entries, k_lag_grad the rest; the 16-node (800 B private
+          // memory) variant serves groups without a larger tree.
           pls.emplace_back(Pg);
           std::vector<int32_t>& pl = pls.back();          // outlives the async upload (synchronised at the end of the call)
           int max_nodes = 0;
           for (int r = 0; r < Pg; ++r) { pl[r] = r; max_nodes = std::max(max_nodes, (int)bt.ghdr[p0 + g0 + r].n_ops); }
-          // (lag-domain particles behind the others: the contraction launches below take the first Pn entries, k_lag_grad the rest)
           auto lagdom = [&](int r) { return (bt.ghdr[p0 + g0 + r].flags & GFLAG_LAGDOM) != 0; };
           std::stable_sort(pl.begin(), pl.end(), [&](int a_, int b_) {
             if (lagdom(a_) != lagdom(b_)) return lagdom(b_);
@@ -879,19 +894,41 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           int32_t* d_pl = s->plist.as<int32_t>() + p0 + g0;
           HIPCHK(c, hipMemcpyAsync(d_pl, pl.data(), sizeof(int32_t) * Pg, hipMemcpyHostToDevice, q));
           ga.plist = d_pl;
+          // (all lag-domain particles of a sweep take the same source of their lag sums)
+          const bool any_fft = Pn < Pg && (bt.ghdr[p0 + g0 + pl[Pn]].flags & GFLAG_LAGFFT) != 0;
+          const bool any_toep = Pn < Pg && (bt.ghdr[p0 + g0 + pl[Pn]].flags & GFLAG_LAGTOEP) != 0;
+          const bool fork = true;
+          hipStream_t qs[4] = {q, q, q, q};
+          if (fork) {
+            for (int i2 = 0; i2 < 3; ++i2) if (!s->gq[i2]) HIPCHK(c, hipStreamCreateWithFlags(&s->gq[i2], hipStreamNonBlocking));
+            for (int i2 = 0; i2 < 5; ++i2) if (!s->gq_ev[i2]) HIPCHK(c, hipEventCreateWithFlags(&s->gq_ev[i2], hipEventDisableTiming));
+            for (int i2 = 0; i2 < 3; ++i2) qs[i2 + 1] = s->gq[i2];
+          }
+          const size_t gm0 = pf.mark(q);
+          if (any_toep) {
+            // Toeplitz particles need no L^-T: their four solves with L run beside the inverse chains of the others
+            if (fork) { HIPCHK(c, hipEventRecord(s->gq_ev[4], q)); HIPCHK(c, hipStreamWaitEvent(qs[3], s->gq_ev[4], 0)); }
+            GradArgs gz = ga; gz.plist = d_pl + Pn;
+            launch_toep_solve(qs[3], Pg - Pn, sizeof(double) * 4 * (size_t)n_pad, gz);
+            HIPCHK(c, hipGetLastError());
+            if (Pn > 0) {
+              GradArgs gt = ga; gt.klist = d_pl; gt.kn = Pn;
+              launch_trtri_chain(q, 8 * ((Pn + 7) / 8) * nt, gt);
+            }
+          } else {
+            launch_trtri_chain(q, 8 * ((Pg + 7) / 8) * nt, ga);      // (forms alpha = Z beta as well)
+          }
+          const size_t gm1 = pf.mark(q);
+          pf.span(8, gm0, gm1);
+          size_t gm2 = pf.mark(q);
+          pf.span(11, gm1, gm2);
           const size_t lds = sizeof(double) * std::max<size_t>(2 * U_SLAB, 256 + 256 * (size_t)bt.g_max_cp + bt.g_max_prm + 3 + bt.g_max_nodes);
           const int Pall = ga.P;
           {
-            const bool any_fft = Pn < Pg && (bt.ghdr[p0 + g0 + pl[Pn]].flags & GFLAG_LAGFFT) != 0;      // (all lag-domain particles or none)
             // Two independent branches behind the inverse chain: [power spectra of Z -> lag-domain gradients] of the lag-domain
             // particles and [K^-1 tiles -> element-wise contraction] of the others.  On separate streams a CU holds one workgroup
             // of each (256 registers x 4 waves each): LDS / vector transforms beside MFMA tile products.
-            const bool fork = true;
-            hipStream_t qs[4] = {q, q, q, q};
-            if (fork) {
-              for (int i2 = 0; i2 < 3; ++i2) if (!s->gq[i2]) HIPCHK(c, hipStreamCreateWithFlags(&s->gq[i2], hipStreamNonBlocking));
-              for (int i2 = 0; i2 < 5; ++i2) if (!s->gq_ev[i2]) HIPCHK(c, hipEventCreateWithFlags(&s->gq_ev[i2], hipEventDisableTiming));
-              for (int i2 = 0; i2 < 3; ++i2) qs[i2 + 1] = s->gq[i2];
+            if (fork && !any_toep) {
               HIPCHK(c, hipEventRecord(s->gq_ev[4], q));
               HIPCHK(c, hipStreamWaitEvent(qs[3], s->gq_ev[4], 0));
             }
@@ -902,8 +939,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             {
               // (spectral lag-domain particles have no K^-1 tiles: the launch covers the first Pn entries of the list only)
               GradArgs gk = ga;
-              if (any_fft) { gk.klist = d_pl; gk.kn = Pn; }
-              const int nk = any_fft ? Pn : Pg;
+              if (any_fft || any_toep) { gk.klist = d_pl; gk.kn = Pn; }
+              const int nk = (any_fft || any_toep) ? Pn : Pg;
               if (nk > 0) launch_kinv_tiles(q, 8 * ((nk + 7) / 8) * ntiles, gk);
             }
             { const size_t gk = pf.mark(q); pf.span(9, gm2, gk); gm2 = gk; }
@@ -922,7 +959,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             if (fork) {
               HIPCHK(c, hipEventRecord(s->gq_ev[3], q));
               for (int i2 = 0; i2 < 2; ++i2) HIPCHK(c, hipStreamWaitEvent(qs[i2 + 1], s->gq_ev[3], 0));
-              if (!any_fft) HIPCHK(c, hipStreamWaitEvent(qs[3], s->gq_ev[3], 0));      // (k_lag_grad then reads the tiles' histograms)
+              if (!any_fft && !any_toep) HIPCHK(c, hipStreamWaitEvent(qs[3], s->gq_ev[3], 0));      // (k_lag_grad then reads the tiles' histograms)
             }
             GradArgs gs = ga;
             if (n_big > 0) HIPCHK(c, launch_grad_contract(64, qs[0], gs, ntiles, n_big, lds2));
@@ -936,7 +973,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             }
             if (Pn < Pg) {
               gs.plist = d_pl + Pn;
-              const size_t lds4 = sizeof(double) * ((any_fft ? 2 * (size_t)FFT_BUF : 0) + (size_t)c->n_max + 8 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
+              const size_t lds4 = sizeof(double) * (((any_fft || any_toep) ? 2 * (size_t)FFT_BUF : 0) + (size_t)c->n_max + 40 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
               launch_lag_grad(qs[3], Pg - Pn, lds4, gs);
               HIPCHK(c, hipGetLastError());
             }
@@ -955,7 +992,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     }
     size_t ev_end = pf.mark();
     pf.span(0, ev_begin, ev_end);
-    if (c->profiling) {
+    if (c->profiling && !tl_no_toep) {      // (a nested repeat of refused particles keeps the sweep's own figures)
       HIPCHK(c, hipStreamSynchronize(st));
       pf.collect(tacc);
       std::lock_guard<std::mutex> g(c->mu);
@@ -988,6 +1025,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     if (n_prm_total > 0)
       HIPCHK(c, hipMemcpyAsync(go->grad, s->dgrad.p, sizeof(double) * n_prm_total, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipMemcpyAsync(go->gnoise, s->dgnoise.p, sizeof(double) * P, hipMemcpyDeviceToHost, st));
+    if (any_toep_sweep) {
+      toep_retry.resize((size_t)P);
+      HIPCHK(c, hipMemcpyAsync(toep_retry.data(), s->tretry.p, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToHost, st));
+    }
   }
   std::vector<int32_t> info_chk;
   int32_t* h_info = h_out_info;
@@ -1003,6 +1044,42 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   }
   for (int p = 0; p < P; ++p)
     if (h_info[p] < 0) return fail(c, AGP_ERR_HIP, "in-kernel panel solve timed out waiting for its diagonal factor");
+  if (go && !toep_retry.empty()) {
+    // Particles whose Linear leaves dominate T so much that T^-1 = K^-1 + V Q V' is not accurate (k_lag_grad measured it): their
+    // gradient is taken once more, from L^-T.  (Rare: a Linear leaf beside a stationary subtree of far smaller amplitude.)
+    std::vector<int> rp;
+    for (int p = 0; p < P; ++p) if (toep_retry[(size_t)p] != 0) rp.push_back(p);
+    if (!rp.empty()) {
+      const int B = (int)rp.size();
+      std::vector<int32_t> bo(B + 1, 0), bp(B + 1, 0), binfo(B, 0);
+      std::vector<uint8_t> bops; std::vector<double> bprm, bnoise(B), blp(B), bgn(B);
+      for (int b = 0; b < B; ++b) {
+        const int p = rp[b];
+        bops.insert(bops.end(), ops + op_off[p], ops + op_off[p + 1]);
+        bprm.insert(bprm.end(), prm + prm_off[p], prm + prm_off[p + 1]);
+        bo[b + 1] = (int32_t)bops.size(); bp[b + 1] = (int32_t)bprm.size();
+        bnoise[b] = noise[p];
+      }
+      std::vector<double> bgrad(std::max<size_t>(1, bprm.size()));
+      if (bprm.empty()) bprm.push_back(0.0);
+      GradOut bgo{bgrad.data(), bgn.data()};
+      if (store_lk.owns_lock()) store_lk.unlock();
+      sg.release();
+      tl_no_toep = true;
+      const int rc2 = logpdf_batch_impl(c, n, B, bo.data(), bops.data(), bp.data(), bprm.data(), bnoise.data(), blp.data(), binfo.data(),
+                                        nullptr, nullptr, nullptr, false, &bgo, allow_lag);
+      tl_no_toep = false;
+      if (rc2) return rc2;
+      for (int b = 0; b < B; ++b) {
+        const int p = rp[b];
+        std::copy(bgrad.begin() + bp[b], bgrad.begin() + bp[b + 1], go->grad + prm_off[p]);
+        go->gnoise[p] = bgn[b];
+      }
+      std::lock_guard<std::mutex> g(c->mu);
+      c->n_toep_particles -= B;
+      c->n_lagdom_particles -= B;          // (the nested sweep counted them again)
+    }
+  }
   if (lag && h_out_info) {
     // LAPACK's info names the first non-positive leading minor IN THE CALLER'S ORDER of the observations
     // (LinearAlgebra.PosDefException(info) in the reference); the sorted sweep found the matrix not positive definite
@@ -1082,7 +1159,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_LAG")) c->lag_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_LAG_RANK")) c->lag_rank_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LAGDOM")) c->grad_lagdom = atoi(e) != 0;
-  if (const char* e = getenv("AGP_GRAD_FFT")) c->grad_fft = atoi(e) != 0;
+  if (const char* e = getenv("AGP_GRAD_FFT")) c->grad_fft = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("AGP_RIGHT_LOOKING")) c->right_looking = atoi(e);
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
   if (const char* e = getenv("AGP_PREDICT_REUSE")) c->predict_reuse = atoi(e) != 0;

@@ -130,11 +130,13 @@ __device__ __forceinline__ long long zoff(int r, int k) { return tile_off(k, r);
 template <bool WANT_D>
 __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
   __shared__ __attribute__((aligned(16))) double sm[U_MAIN_DOUBLES];
-  const int npl = (a.P + 7) / 8;
+  const int np = a.klist ? a.kn : a.P;          // (klist: the particles that need Z at all)
+  const int npl = (np + 7) / 8;
   const int b = blockIdx.x, xcd = b & 7, qq = b >> 3;
   const int j = qq / npl, pl = qq - j * npl;
-  const int p = pl * 8 + xcd;
-  if (p >= a.P) return;
+  const int pi = pl * 8 + xcd;
+  if (pi >= np) return;
+  const int p = a.klist ? a.klist[pi] : pi;
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
   const int row0 = 32 * w + 2 * l15;
   const int lsl = a.lslot != nullptr ? a.lslot[p] : -1;
@@ -728,6 +730,177 @@ __global__ __launch_bounds__(256, 2) void k_zspec(GradArgs a) {
   if (tid == 0) { out[FFT_N] = m0; out[FFT_N + 1] = m1; out[FFT_N + 2] = m2; }
 }
 
+// ---- Toeplitz variant of the lag sums (GFLAG_LAGTOEP) -----------------------------------------------------------------------
+// When the sweep's points are n CONSECUTIVE points of the grid (the whole series, or an annealing prefix of a series given in
+// time order), the covariance of a lag-domain particle in sorted order is  K = T + U C U^T:  T symmetric Toeplitz (stationary
+// subtrees + noise), U = [1, t - t_ref], C the 2x2 matrix of the Linear leaves.  Then the lag sums of K^-1 need no inverse:
+//   x = T^-1 e_first  gives  sum_a (T^-1)_{a,a+g} = [ (n - g) R_g - 2 Q_g ] / x_0,   R_g = sum_u x_u x_{u+g},  Q_g = sum_u u x_u x_{u+g}
+// (Gohberg-Semencul: T^-1 = [L(x) L(x)^T - L(y) L(y)^T] / x_0 with lower-triangular Toeplitz factors of x and of its shifted
+// reverse y; summing either product along a diagonal leaves a weighted autocorrelation), and with V = K^-1 U, M = U^T V,
+// Q = C (I - M C)^-1:   T^-1 = K^-1 + V Q V^T,  so  x = k_0 + V Q U^T k_0  (k_0 = K^-1 e_first)  and
+//   lag sums of K^-1 = lag sums of T^-1 - sum_ij Q_ij corr(v_i, v_j).
+// Everything comes from FOUR solves with the factor the sweep already has — right-hand sides x (-> alpha), e_first, 1, t - t_ref —
+// i.e. two passes over L (n^2/2 elements each) instead of the n^3/3 flops of L^-T and n/2 transforms: k_toep_solve below; the
+// correlations are seven transforms in k_lag_grad.  Rounding: as the explicit inverse, cond(K) eps (checked against it in
+// tests/test_gpu_lag.py).
+//
+// One workgroup per particle.  X (n_pad x 4, LDS) holds the right-hand sides, overwritten by the solutions.  Products with the
+// off-diagonal tiles are MFMA 16x16x4 with the four right-hand sides in columns 0..3 of the B operand (the pass is bound by
+// reading L; the idle columns cost nothing): forward, lanes (row, k) read L(i,j)[row, k] (rows contiguous: 128-byte segments);
+// backward, lanes (column, k-quad) read 32 bytes of a column, so every 128-byte line of L is still fetched once, whole.
+// In-tile solves: block substitution with the 16x16 inverses W the factorisation left, one barrier per block.
+__global__ __launch_bounds__(256, 2) void k_toep_solve(GradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double X[];      // [n_pad][4]
+  const int p = a.plist[blockIdx.x];
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  const int nt = a.nt, n_pad = nt * NB;
+  const int lsl = a.lslot != nullptr ? a.lslot[p] : -1;
+  const double* __restrict__ Lp = lsl >= 0 ? a.Lsrc + (long long)lsl * a.Lstride : a.A + (long long)p * a.strideA;
+  const double* __restrict__ Wp = lsl >= 0 ? a.Wsrc + (long long)lsl * a.Wnt * NSB * 256 : a.W + (long long)p * a.nt * NSB * 256;
+  const bool rl = l15 < 4;                 // lanes that carry a right-hand side
+  for (int r = tid; r < n_pad; r += 256) {
+    const bool in = r < a.n;
+    const int rk = in ? a.rank[r] : -1;
+    d4 v;
+    v[0] = 0.0;                            // (column 0 joins for the backward pass: beta is forward-solved already)
+    v[1] = (in && rk == a.rank0) ? 1.0 : 0.0;
+    v[2] = in ? 1.0 : 0.0;
+    v[3] = in ? ((double)rk - a.grid_mid) * a.grid_h : 0.0;
+    *reinterpret_cast<d4*>(X + 4 * r) = v;
+  }
+  __syncthreads();
+  // ---- forward: L Y = B ----
+#pragma unroll 1
+  for (int i = 0; i < nt; ++i) {
+    const double* __restrict__ Lii = Lp + tile_off(i, i);
+    const double* __restrict__ Wi = Wp + (long long)i * NSB * 256;
+    // this wave's operands of the in-tile solve travel under the products
+    double wf[2][4], ld[2][NSB - 1][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int rb = 2 * w + b;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wf[b][s] = Wi[rb * 256 + 64 * s + l];
+#pragma unroll
+      for (int jb = 0; jb < NSB - 1; ++jb)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ld[b][jb][s] = jb < rb ? Lii[(16 * jb + 4 * s + lq) * NB + 16 * rb + l15] : 0.0;
+    }
+    d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+    for (int j = 0; j < i; ++j) {
+      const double* __restrict__ T = Lp + tile_off(i, j) + lq * NB + 32 * w + l15;
+      const double* __restrict__ Xj = X + 4 * (j * NB + lq) + l15;
+#pragma unroll 8
+      for (int ks = 0; ks < NB / 4; ++ks) {
+        const double a0 = T[ks * 4 * NB], a1 = T[ks * 4 * NB + 16];
+        const double bv = rl ? Xj[16 * ks] : 0.0;
+        acc[0] = mfma(a0, bv, acc[0]);
+        acc[1] = mfma(a1, bv, acc[1]);
+      }
+    }
+    d4 r[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        r[b][s] = (rl ? X[4 * (i * NB + 32 * w + 16 * b + 4 * s + lq) + l15] : 0.0) - acc[b][s];
+#pragma unroll
+    for (int jb = 0; jb < NSB; ++jb) {
+      double* __restrict__ Xb = X + 4 * (i * NB + 16 * jb + lq) + l15;
+      if (w == (jb >> 1)) {
+        d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x = mfma(wf[jb & 1][s], r[jb & 1][s], x);
+        if (rl) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) Xb[16 * s] = x[s];
+        }
+      }
+      __syncthreads();
+      if (jb < NSB - 1) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (2 * w + b > jb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) r[b] = mfma(-ld[b][jb][s], rl ? Xb[16 * s] : 0.0, r[b]);
+          }
+      }
+    }
+  }
+  // ---- backward: L^T S = Y, column 0 = beta ----
+  {
+    const double* __restrict__ bp = a.beta + (long long)p * a.ldv;
+    for (int r = tid; r < n_pad; r += 256) X[4 * r] = bp[r];
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int j = nt - 1; j >= 0; --j) {
+    const double* __restrict__ Ljj = Lp + tile_off(j, j);
+    const double* __restrict__ Wj = Wp + (long long)j * NSB * 256;
+    double wf[2][4];
+    d4 ld[2][NSB - 1];           // ld[b][jb - 1]: block (jb, cb) of L(j,j), rows 4 lq .. 4 lq + 3 of column l15
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int cb = 2 * w + b;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) wf[b][s] = Wj[cb * 256 + l15 * 16 + 4 * s + lq];          // (W^T)[i][k] = W[k][i]
+#pragma unroll
+      for (int jb = 1; jb < NSB; ++jb)
+        ld[b][jb - 1] = jb > cb ? *reinterpret_cast<const d4*>(Ljj + (16 * cb + l15) * NB + 16 * jb + 4 * lq) : d4{0.0, 0.0, 0.0, 0.0};
+    }
+    d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+    for (int i = j + 1; i < nt; ++i) {
+      const double* __restrict__ T = Lp + tile_off(i, j) + (32 * w + l15) * NB + 4 * lq;
+      const double* __restrict__ Xi = X + 4 * (i * NB + 4 * lq) + l15;
+#pragma unroll 4
+      for (int R = 0; R < NB; R += 16) {
+        const d4 v0 = *reinterpret_cast<const d4*>(T + R), v1 = *reinterpret_cast<const d4*>(T + 16 * NB + R);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const double bv = rl ? Xi[4 * (R + s)] : 0.0;
+          acc[0] = mfma(v0[s], bv, acc[0]);
+          acc[1] = mfma(v1[s], bv, acc[1]);
+        }
+      }
+    }
+    d4 r[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+        r[b][s] = (rl ? X[4 * (j * NB + 32 * w + 16 * b + 4 * s + lq) + l15] : 0.0) - acc[b][s];
+#pragma unroll
+    for (int jb = NSB - 1; jb >= 0; --jb) {
+      if (w == (jb >> 1)) {
+        d4 x = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x = mfma(wf[jb & 1][s], r[jb & 1][s], x);
+        if (rl) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) X[4 * (j * NB + 16 * jb + 4 * s + lq) + l15] = x[s];
+        }
+      }
+      __syncthreads();
+      if (jb > 0) {
+        const double* __restrict__ Xb = X + 4 * (j * NB + 16 * jb + 4 * lq) + l15;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          if (2 * w + b < jb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) r[b] = mfma(-ld[b][jb - 1][s], rl ? Xb[4 * s] : 0.0, r[b]);
+          }
+      }
+    }
+  }
+  // alpha and the three auxiliary solutions
+  for (int r = tid; r < n_pad; r += 256) {
+    const d4 v = *reinterpret_cast<const d4*>(X + 4 * r);
+    a.alpha[(long long)p * a.ldv + r] = v[0];
+    double* __restrict__ o = a.tsol + (long long)p * 3 * a.ldv + r;
+    o[0] = v[1]; o[a.ldv] = v[2]; o[2 * a.ldv] = v[3];
+  }
+}
+
 // ---- lag-domain contraction: one workgroup per GFLAG_LAGDOM particle.  D_g = fixed-order sum over the particle's tiles of
 // the histograms k_kinv_tiles left in the tile slots; then the reverse-mode pass of the contraction kernel over the n "virtual
 // elements" (t_g, t_0) of the SORTED series with weight D_g — every stationary subtree's parameters; the Linear leaves (children
@@ -740,9 +913,10 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
   const int tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const GProgHdr h = a.ghdr[p];
   const int ntiles = a.nt * (a.nt + 1) / 2;
+  const bool toep = (h.flags & GFLAG_LAGTOEP) != 0;
   const bool fft = (h.flags & GFLAG_LAGFFT) != 0;
-  double* D = smem + (fft ? 2 * FFT_BUF : 0);          // [nbins] (behind the transform buffer of the spectral variant)
-  double* prm = D + a.nbins + 8;
+  double* D = smem + ((fft || toep) ? 2 * FFT_BUF : 0);          // [nbins] (behind the transform buffer of the spectral variants)
+  double* prm = D + a.nbins + 40;
   int32_t* poff = reinterpret_cast<int32_t*>(prm + h.n_prm + 3);
   uint8_t* ops = reinterpret_cast<uint8_t*>(poff + h.n_ops);
   uint8_t* lc = ops + h.n_ops;
@@ -759,7 +933,155 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
   }
   const double* __restrict__ Ap = a.A + (long long)p * a.strideA;
   double mom[3] = {0.0, 0.0, 0.0};
-  if (fft) {
+  if (toep) {
+    // Toeplitz variant (see k_toep_solve): D from alpha, k0 = K^-1 e_first, v1 = K^-1 1, vt = K^-1 (t - t_ref)
+    d2* buf = reinterpret_cast<d2*>(smem);
+    double* fred = D + a.nbins;      // behind D: 40 doubles (host sizes the LDS for them)
+    const d2* __restrict__ tw = reinterpret_cast<const d2*>(a.tw);
+    const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
+    const double* __restrict__ k0 = a.tsol + (long long)p * 3 * a.ldv;
+    const double* __restrict__ v1 = k0 + a.ldv;
+    const double* __restrict__ vt = v1 + a.ldv;
+    // a particle of Linear, Constant and WhiteNoise leaves only: T = s2 I exactly (the constants join C), nothing to downdate
+    bool diagc = true;
+    for (int i = 0; i < h.n_ops; ++i) {
+      const int o = a.gops[h.node_off + i];
+      diagc = diagc && (o == OP_LIN || o == OP_CONST || o == OP_WN || o == OP_PLUS);
+    }
+    // nine sums: 1'v1, 1'vt, tau'vt, 1'k0, tau'k0, 1'alpha, tau'alpha, 1'tau, tau'tau
+    double sm7[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int ga = tid; ga < a.n; ga += 256) {
+      const double tau = ((double)a.rank[ga] - a.grid_mid) * a.grid_h;
+      const double x1 = v1[ga], xt = vt[ga], x0 = k0[ga], xa = al[ga];
+      sm7[0] += x1; sm7[1] += xt; sm7[2] = fma(tau, xt, sm7[2]); sm7[3] += x0; sm7[4] = fma(tau, x0, sm7[4]);
+      sm7[5] += xa; sm7[6] = fma(tau, xa, sm7[6]); sm7[7] += tau; sm7[8] = fma(tau, tau, sm7[8]);
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sm7[q] += __shfl_xor(sm7[q], off);
+      if (l == 0) fred[9 * w + q] = sm7[q];
+    }
+    for (int i = tid; i < FFT_BUF; i += 256) buf[i] = d2{0.0, 0.0};
+    __syncthreads();          // (also: the program tables above are complete)
+#pragma unroll
+    for (int q = 0; q < 9; ++q) sm7[q] = (fred[q] + fred[9 + q]) + (fred[18 + q] + fred[27 + q]);
+    // C: the Linear leaves (children of the top-level sum), bias + amp (t - c)(t' - c) in the basis [1, t - t_ref]
+    double C00 = 0.0, C01 = 0.0, C11 = 0.0, s2 = a.noise[p];
+    for (int ip = 0; ip < h.n_ops; ++ip) {
+      const double* q = prm + poff[ip];
+      if (ops[ip] == OP_LIN) {
+        const double cc = q[0] - a.tref;
+        C00 += q[1] + q[2] * cc * cc; C01 -= q[2] * cc; C11 += q[2];
+      } else if (diagc && ops[ip] == OP_CONST) {
+        C00 += q[0];
+      } else if (diagc && ops[ip] == OP_WN) {
+        s2 += q[0];
+      }
+    }
+    double M00, M01, M11, Q00, Q01, Q11, w0 = 0.0, w1 = 0.0;
+    if (diagc) {
+      // K^-1 = I/s2 - (U/s2) S (U/s2)',  S = C (I + N C)^-1,  N = U'U / s2;  U' K^-1 U = N - N S N
+      const double is2 = 1.0 / s2;
+      const double N00 = (double)a.n * is2, N01 = sm7[7] * is2, N11 = sm7[8] * is2;
+      const double t00 = 1.0 + (N00 * C00 + N01 * C01), t01 = N00 * C01 + N01 * C11;
+      const double t10 = N01 * C00 + N11 * C01, t11 = 1.0 + (N01 * C01 + N11 * C11);
+      const double idet = 1.0 / (t00 * t11 - t01 * t10);
+      const double i00 = t11 * idet, i01 = -t01 * idet, i10 = -t10 * idet, i11 = t00 * idet;
+      const double S00 = C00 * i00 + C01 * i10, S01 = C00 * i01 + C01 * i11, S11 = C01 * i01 + C11 * i11;
+      const double a00 = S00 * N00 + S01 * N01, a01 = S00 * N01 + S01 * N11, a10 = S01 * N00 + S11 * N01, a11 = S01 * N01 + S11 * N11;   // S N
+      M00 = N00 - (N00 * a00 + N01 * a10); M01 = N01 - (N00 * a01 + N01 * a11); M11 = N11 - (N01 * a01 + N11 * a11);
+      Q00 = S00 * is2 * is2; Q01 = S01 * is2 * is2; Q11 = S11 * is2 * is2;          // (lag sums of K^-1 = n/s2 at lag 0 - sum Q_ij corr(u_i, u_j))
+    } else {
+      M00 = sm7[0]; M01 = sm7[1]; M11 = sm7[2];
+      // Q = C (I - M C)^-1 (symmetric);  x = k0 + V Q U'k0
+      const double t00 = 1.0 - (M00 * C00 + M01 * C01), t01 = -(M00 * C01 + M01 * C11);
+      const double t10 = -(M01 * C00 + M11 * C01), t11 = 1.0 - (M01 * C01 + M11 * C11);
+      const double idet = 1.0 / (t00 * t11 - t01 * t10);
+      const double i00 = t11 * idet, i01 = -t01 * idet, i10 = -t10 * idet, i11 = t00 * idet;
+      Q00 = C00 * i00 + C01 * i10; Q01 = C00 * i01 + C01 * i11; Q11 = C01 * i01 + C11 * i11;
+      w0 = Q00 * sm7[3] + Q01 * sm7[4]; w1 = Q01 * sm7[3] + Q11 * sm7[4];
+      // (I - M C)^-1 = I + U'T^-1 U C: its size is what the downdate T^-1 = K^-1 + V Q V' loses; too large -> the host repeats the
+      // particle with the explicit inverse
+      const double amp = fmax(fmax(fabs(i00 - 1.0), fabs(i11 - 1.0)), fmax(fabs(i01), fabs(i10)));
+      if (tid == 0 && !(amp <= a.toep_max_amp)) a.retry[a.pmap[p]] = 1;
+    }
+    if (tid < 3) {
+      const double sa = sm7[5], ua = sm7[6];
+      const double am = tid == 0 ? sa * sa : tid == 1 ? 2.0 * sa * ua : ua * ua;
+      const double z = tid == 0 ? M00 : tid == 1 ? 2.0 * M01 : M11;
+      mom[0] = 0.5 * (am - z);
+    }
+    // one transform per vector; this thread's 16 spectrum values (elements tid + 256 j, digit-reversed order, as k_zspec)
+    d2 f[16];
+    auto transform = [&](auto val) {
+      for (int ga = tid; ga < a.n; ga += 256) buf[fft_pad(a.rank[ga] - a.rank0)].x = val(ga);
+      __syncthreads();
+      fft4096_lds<true>(buf, tw, tid);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        d2* q = buf + fft_pad(tid) + j * 272;
+        f[j] = *q;
+        *q = d2{0.0, 0.0};
+      }
+      __syncthreads();
+    };
+    double P[16], PR[16];
+    d2 g1[16];
+    transform([&](int ga) { return al[ga]; });
+#pragma unroll
+    for (int j = 0; j < 16; ++j) P[j] = fma(f[j].x, f[j].x, f[j].y * f[j].y);
+    transform([&](int ga) { return diagc ? 1.0 : v1[ga]; });
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { g1[j] = f[j]; P[j] = fma(Q00, fma(f[j].x, f[j].x, f[j].y * f[j].y), P[j]); }
+    transform([&](int ga) { return diagc ? ((double)a.rank[ga] - a.grid_mid) * a.grid_h : vt[ga]; });
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      P[j] += Q11 * fma(f[j].x, f[j].x, f[j].y * f[j].y) + 2.0 * Q01 * fma(g1[j].x, f[j].x, g1[j].y * f[j].y);
+    auto xv = [&](int ga) { return fma(vt[ga], w1, fma(v1[ga], w0, k0[ga])); };
+    if (!diagc) {
+      transform(xv);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { g1[j] = f[j]; PR[j] = fma(f[j].x, f[j].x, f[j].y * f[j].y); }
+      transform([&](int ga) { return (double)(a.rank[ga] - a.rank0) * xv(ga); });
+      // (u x) conj(x): its transform's real part is N Q_g
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        d2 t2; t2.x = fma(f[j].x, g1[j].x, f[j].y * g1[j].y); t2.y = fma(f[j].y, g1[j].x, -f[j].x * g1[j].y);
+        g1[j] = t2;
+      }
+      // x_0: the solution at the first point in time
+      for (int ga = tid; ga < a.n; ga += 256) if (a.rank[ga] == a.rank0) fred[36] = xv(ga);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { PR[j] = 0.0; g1[j] = d2{0.0, 0.0}; }
+      if (tid == 0) fred[36] = 1.0;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) buf[fft_pad(rev4_12(tid + 256 * j))] = d2{P[j], PR[j]};
+    __syncthreads();
+    fft4096_lds(buf, tw, tid);
+    // lags g = tid + 256 j, j < 8 (n <= FFT_N / 2): r_g and R_g stay in registers across the last transform
+    double rg[8], Rg[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const d2 v = buf[fft_pad(rev4_12(tid + 256 * j))]; rg[j] = v.x; Rg[j] = v.y; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) buf[fft_pad(rev4_12(tid + 256 * j))] = g1[j];
+    __syncthreads();
+    fft4096_lds(buf, tw, tid);
+    const double ix0 = 1.0 / fred[36];
+    const double dT0 = diagc ? (double)a.n / s2 * (double)FFT_N : 0.0;          // (T^-1 = I / s2; the transforms carry a factor N)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int g = tid + 256 * j;
+      if (g < a.nbins) {
+        const double Qg = buf[fft_pad(rev4_12(g))].x;
+        const double dT = diagc ? (g == 0 ? dT0 : 0.0) : ((double)(a.n - g) * Rg[j] - 2.0 * Qg) * ix0;
+        D[g] = g < a.n ? (rg[j] - dT) * ((g == 0 ? 0.5 : 1.0) / (double)FFT_N) : 0.0;
+      }
+    }
+  } else if (fft) {
     // spectral variant: S = |DFT(alpha)|^2 - sum over Z's block columns of their power spectra (k_zspec), D = Re DFT(S) / N
     d2* buf = reinterpret_cast<d2*>(smem);
     double* fred = D + a.nbins;      // behind D: 8 doubles (host sizes the LDS for them)

@@ -63,7 +63,7 @@ struct Slot {
   HostBuf h_stage, h_out;   // its pinned source, and the pinned landing zone of [logpdf | info]
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
-      Z, alpha, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq, lagtab,
+      Z, alpha, tsol, tretry, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq, lagtab,
       pl_rank, pl_tl, pl_prog;
   std::vector<hipEvent_t> events;
   hipStream_t gq[3] = {nullptr, nullptr, nullptr};     // gradient sweeps: the contraction's launch classes run side by side
@@ -79,7 +79,7 @@ struct Slot {
     if (done) { (void)hipEventDestroy(done); done = nullptr; }
     for (DevBuf* b : {&A, &W, &vec, &partial, &info, &out_lp, &out_info, &hdr, &ops, &prm, &noise,
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
-                      &Z, &alpha, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab, &pl_rank, &pl_tl, &pl_prog})
+                      &Z, &alpha, &tsol, &tretry, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab, &pl_rank, &pl_tl, &pl_prog})
       b->release();
     stage.release(); h_stage.release(); h_out.release(); h_async_info.release();
     for (auto e : events) (void)hipEventDestroy(e);
@@ -143,10 +143,12 @@ struct agp_ctx {
   int32_t* d_rank = nullptr;     // rank of resident point i in the sorted series (lag-domain gradient contraction, k_kinv_tiles)
   double t_ref = 0.0;            // middle of the series: reference time of the Linear moments there
   double grid_h = 0.0, grid_mid = 0.0;      // grid spacing; t_sorted[r] - t_ref = (r - grid_mid) h
-  int grad_fft = 1;              // lag-domain particles of series of <= FFT_N / 2 points: lag sums from Z's power spectrum; env AGP_GRAD_FFT
+  int grad_fft = 2;              // lag-domain particles of series of <= FFT_N / 2 points: lag sums from Z's power spectrum (1), or — the sweep's
+                                 // points being consecutive grid points — from four solves with L, no L^-T (2: where possible, else 1); env AGP_GRAD_FFT
   double* d_fft_tw = nullptr;    // twiddle factors of that transform
   int grad_lagdom = 1;           // gradient sweeps on a regular grid: lag-domain contraction where the kernel allows; env AGP_GRAD_LAGDOM
   int64_t n_lagdom_particles = 0;   // particles contracted in the lag domain so far (agp_get_lag_stats)
+  int64_t n_toep_particles = 0;      // ... of which: lag sums from the Toeplitz solves (k_toep_solve)
   bool lag_ok = false;
   int lag_enable = 1;
   double lag_tol_h = 1e-11;       // admitted deviation of a sorted point from its grid position, in units of the spacing (agp_set_data)
@@ -278,6 +280,8 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
 // n=2048 x 64, per-column launches 2.5 / 5 / 8 / 12 / 20 us: 25.33 / 25.40 / 25.57 / 25.58 / 25.94 ms (one-node programs only).
 constexpr double FUSE_MAX_US = 25.0, FLOW_FUSE_MAX_US = 70.0, FLOW_LAG_FUSE_MAX_US = 10.0, LAG_FUSE_MAX_US = 3.0;
 constexpr int HYBRID_BLOCKS = 512;        // medium populations: right-looking once a block column offers fewer workgroups (run_factor)
+constexpr double GRAD_TOEP_MAX_AMP = 1e4;  // ... and the largest entry of U' T^-1 U C it accepts (the downdate loses that factor times ~100 eps)
+constexpr int GRAD_TOEP_MIN_N = 256;      // Toeplitz variant of the lag sums: four solves + seven transforms per particle, whatever n
 constexpr int GRAD_FFT_MIN_N = 1024;      // below ~1000 points the K^-1 tiles are cheaper than n/2 transforms of length 4096
 
 inline int round_up(int64_t n, int m) { return (int)(((n + m - 1) / m) * m); }

@@ -8,7 +8,8 @@ constexpr int DYN_LDS_MAX_BYTES_G = 160 * 1024;
 
 hipError_t kernels_init_grad() {
   const void* fns[] = {reinterpret_cast<const void*>(&k_grad_contract<16>), reinterpret_cast<const void*>(&k_grad_contract<64>),
-                       reinterpret_cast<const void*>(&k_grad_contract<0>), reinterpret_cast<const void*>(&k_lag_grad)};
+                       reinterpret_cast<const void*>(&k_grad_contract<0>), reinterpret_cast<const void*>(&k_lag_grad),
+                       reinterpret_cast<const void*>(&k_toep_solve)};
   for (const void* f : fns) {
     hipFuncAttributes fa;
     hipError_t e = hipFuncGetAttributes(&fa, f);
@@ -22,6 +23,7 @@ void launch_trtri_chain(hipStream_t st, int grid, const GradArgs& ga) {
   if (ga.dinv != nullptr) hipLaunchKernelGGL(k_trtri_chain<true>, dim3(grid), dim3(256), 0, st, ga);
   else hipLaunchKernelGGL(k_trtri_chain<false>, dim3(grid), dim3(256), 0, st, ga);
 }
+void launch_toep_solve(hipStream_t st, int P, size_t lds, const GradArgs& ga) { hipLaunchKernelGGL(k_toep_solve, dim3(P), dim3(256), lds, st, ga); }
 void launch_zspec(hipStream_t st, int nt, int P, const GradArgs& ga) { hipLaunchKernelGGL(k_zspec, dim3(nt, P), dim3(256), 0, st, ga); }
 void launch_kinv_tiles(hipStream_t st, int grid, const GradArgs& ga) { hipLaunchKernelGGL(k_kinv_tiles, dim3(grid), dim3(256), 0, st, ga); }
 hipError_t launch_grad_contract(int maxs, hipStream_t st, const GradArgs& ga, int ntiles, int P, size_t lds) {

@@ -43,6 +43,7 @@ void launch_mfma_peak(int nblk, double* out, long long* cycles, int iters, int m
 hipError_t kernels_init_grad();
 void launch_trtri_chain(hipStream_t st, int grid, const GradArgs& ga);
 void launch_zspec(hipStream_t st, int nt, int P, const GradArgs& ga);
+void launch_toep_solve(hipStream_t st, int P, size_t lds, const GradArgs& ga);      // ga.plist: the particles, one workgroup each
 void launch_kinv_tiles(hipStream_t st, int grid, const GradArgs& ga);
 hipError_t launch_grad_contract(int maxs, hipStream_t st, const GradArgs& ga, int ntiles, int P, size_t lds);      // maxs: 64 / 16 / 0 (LDS tape)
 void launch_lag_grad(hipStream_t st, int P, size_t lds, const GradArgs& ga);

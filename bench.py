@@ -210,9 +210,9 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
                 acc[k] = acc.get(k, 0.0) + v
         dt = (time.perf_counter() - t0) / reps
         eng.set_profiling(False)
-        k0 = eng.grad_lag_domain_particles()
+        k0, k0t = eng.grad_lag_domain_particles(), eng.grad_toeplitz_particles()
         eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
-        n_lagdom = eng.grad_lag_domain_particles() - k0
+        n_lagdom, n_toep = eng.grad_lag_domain_particles() - k0, eng.grad_toeplitz_particles() - k0t
         # the same sweep with every particle contracted element by element (what an irregular series costs)
         eng.set_grad_lag_domain(False)
         eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
@@ -224,9 +224,10 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
         tf = P * float(n) ** 3 / dt_el / 1e12
         out["grad"] = {"what": "value + gradient sweep of the same population (agp_logpdf_grad_batch, host outputs; HIP-event marks on)",
                        "evals_per_s": P / dt, "ms_per_sweep": dt * 1e3,
-                       "lag_domain_particles": n_lagdom,
+                       "lag_domain_particles": n_lagdom, "toeplitz_particles": n_toep,
                        "lag_domain": "regular grid: particles whose kernel is a sum of stationary subtrees and Linear leaves are contracted over n lags; "
-                                     "their K^-1 lag sums come from the power spectrum of Z's columns (n <= 2048), so their n^3/3 of K^-1 tiles is not formed",
+                                     "the sweep's points being consecutive grid points, K is Toeplitz + a rank-2 term in sorted order and the lag sums "
+                                     "of K^-1 follow from four solves with L (Gohberg-Semencul; k_toep_solve): no L^-T and no K^-1 tiles for them",
                        "elementwise": {"what": "agp_set_grad_lag_domain(0): K^-1 tiles and the per-element reverse sweep for every particle (any series)",
                                        "evals_per_s": P / dt_el, "ms_per_sweep": dt_el * 1e3, "tflops_on_n3": tf,
                                        "frac_of_fp64_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
@@ -257,12 +258,18 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
         dt = timed(tq)
         on_lattice = eng.lag_predict_passes() > k0
         dt_off = timed(tq_off)
-        fl = Pp * (cholesky_flops(n) + float(n) * n * m)
+        fl = Pp * (cholesky_flops(n) + float(n) * n * m)            # as the reference computes it: V = L^-1 K12 for all m points
+        # what the pass executes: the n query points that are observed points come from alpha and diag(K11^-1) (L^-T: n^3/3),
+        # V only for the m - n future points
+        fl_done = Pp * (2.0 * cholesky_flops(n) + float(n) * n * (m - n))
         out["predict"] = {"what": f"agp_predict_batch, first {Pp} particles, n={n}, m={m} query points = the observed times + {m - n} future "
                                   f"points at the series' cadence, marginal variances (out_cov = NULL), host outputs, K11 factored by the pass",
                           "ms": dt * 1e3, "particles": Pp, "m": m, "rank_tables": bool(on_lattice),
-                          "tflops": fl / dt / 1e12, "frac_of_fp64_mfma_peak": fl / dt / 1e12 / PEAK_FP64_MFMA_TFLOPS,
-                          "flop_count": "n^3/3 + n^2 m per particle",
+                          "tflops": fl_done / dt / 1e12, "frac_of_fp64_mfma_peak": fl_done / dt / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                          "flop_count": "executed: n^3/3 (factor) + n^3/3 (L^-T: mean and variance at the n observed points from alpha and "
+                                        "diag(K11^-1)) + n^2 (m - n) (V for the future points) per particle",
+                          "reference_equivalent_tflops": fl / dt / 1e12,
+                          "reference_equivalent_flop_count": "n^3/3 + n^2 m per particle (V = L^-1 K12 for every query point, src/GP.jl:743-757)",
                           "off_lattice_queries": {"what": f"the same with {m} query points linspace(0, 1.25): general evaluator",
                                                   "ms": dt_off * 1e3, "frac_of_fp64_mfma_peak": fl / dt_off / 1e12 / PEAK_FP64_MFMA_TFLOPS}}
     except Exception as e:      # noqa: BLE001

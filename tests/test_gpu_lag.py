@@ -383,7 +383,8 @@ def _grad_shapes(G):
 
 
 @pytest.mark.parametrize("n_max,n,fft", [(300, 300, 1), (300, 250, 1), (128, 128, 1), (640, 513, 1), (17, 17, 1), (2, 2, 1),
-                                          (300, 300, 0), (300, 250, 0), (129, 129, 0), (17, 17, 0)])
+                                          (300, 300, 0), (300, 250, 0), (129, 129, 0), (17, 17, 0),
+                                          (300, 300, 2), (300, 250, 2), (640, 640, 2), (257, 257, 2), (128, 128, 2)])
 def test_gradient_lag_domain_vs_elementwise_and_oracle(pkg, monkeypatch, n_max, n, fft):
     """A sum of stationary subtrees and Linear leaves on a (shuffled) regular grid is contracted over n lags instead of n^2
     elements: same gradient as the element-wise contraction (1e-10 of the gradient's scale) and as the oracle (1e-7), on the
@@ -404,6 +405,8 @@ def test_gradient_lag_domain_vs_elementwise_and_oracle(pkg, monkeypatch, n_max, 
         k0 = eng.grad_lag_domain_particles()
         lp, g, gn, info = eng.logpdf_grad_batch(kernels, noises, n=n)
         assert eng.grad_lag_domain_particles() - k0 == len(covered)
+        # (fft = 2: consecutive grid points -> the Toeplitz solves; a prefix of the shuffled grid is not such a set)
+        assert eng.grad_toeplitz_particles() == (len(covered) if fft == 2 and n == n_max and n >= 256 else 0)
         lp_r, g_r, gn_r, _ = eng.logpdf_grad_batch(kernels, noises, n=n)          # reproducible sums
         assert np.array_equal(gn, gn_r) and all(np.array_equal(a, b) for a, b in zip(g, g_r))
         eng.set_grad_lag_domain(False)
@@ -418,6 +421,60 @@ def test_gradient_lag_domain_vs_elementwise_and_oracle(pkg, monkeypatch, n_max, 
             assert np.abs(g[i] - go).max() <= 1e-7 * sc and abs(gn[i] - gno) <= 1e-7 * sc, (i, k, g[i], go)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("case", ["prefix_in_time_order", "resident_factor", "population_2048", "offset_grid"])
+def test_gradient_toeplitz_lag_sums(pkg, case):
+    """Lag sums of K^-1 from four solves with L (Gohberg-Semencul + the Linear leaves' 2x2 Woodbury term; k_toep_solve) where the
+    sweep's points are consecutive grid points: a prefix of a series in time order (data annealing, src/inference_smc_anneal_data.jl:
+    206-217), factors read in place from the store (update -> choice_gradients, :63-67), a prior-sampled population at n = 2048,
+    a grid away from the origin.  Against the element-wise contraction (1e-9 of the gradient's scale) and, small cases, the oracle."""
+    from oracle import oracle as O
+    G = pkg
+    covered, elementwise = _grad_shapes(G)
+    # a Linear leaf that dominates its stationary neighbour: the downdate T^-1 = K^-1 + V Q V' is refused on the device and the
+    # particle repeated with the explicit inverse
+    dominated = G.Linear(0.3, 0.2, 2000.0) + G.SquaredExponential(0.3, 1e-5)
+    kernels = covered + elementwise + [dominated]
+    n_refused = 1
+    noises = np.linspace(0.02, 0.3, len(kernels))
+    oracle_check = True
+    if case == "prefix_in_time_order":
+        ts, xs = pkg.prior.synthetic_series(600, seed=5, shuffle=False); n = 400
+    elif case == "resident_factor":
+        ts, xs = pkg.prior.synthetic_series(384, seed=6, shuffle=True); n = 384
+    elif case == "offset_grid":
+        ts, xs = pkg.prior.synthetic_series(320, seed=7, shuffle=True); ts = ts + 40.0; n = 320
+    else:
+        ts, xs = pkg.prior.synthetic_series(2048, seed=8, shuffle=True); n = 2048
+        kernels, noises = pkg.prior.sample_particles(np.random.default_rng(12), 64, max_depth=-1, max_size=31)
+        oracle_check = False; n_refused = None
+    a = pkg.GPEngine(0); b = pkg.GPEngine(0)
+    try:
+        a.set_data(ts, xs); b.set_data(ts, xs)
+        b.set_grad_lag_domain(False)
+        if case == "resident_factor":
+            a.logpdf_batch_extend(kernels, noises, n=n, check=False)
+        lp, g, gn, info = a.logpdf_grad_batch(kernels, noises, n=n, check=False)
+        if n_refused is None:
+            assert 0 < a.grad_lag_domain_particles() - 4 <= a.grad_toeplitz_particles() <= a.grad_lag_domain_particles()
+        else:
+            # (away from the origin the cross term -amp (c - t_ref)(t + t') of every Linear leaf is large: more particles are refused)
+            refused = a.grad_lag_domain_particles() - a.grad_toeplitz_particles()
+            assert a.grad_lag_domain_particles() == len(covered) + 1 and (refused == n_refused or (case == "offset_grid" and 1 <= refused <= 4))
+        if case == "resident_factor":
+            assert a.grad_reuse_stats()["reused"] > 0
+        lp2, g2, gn2, info2 = b.logpdf_grad_batch(kernels, noises, n=n, check=False)
+        assert np.array_equal(info, info2) and (info == 0).mean() >= 0.9
+        for i in np.flatnonzero(info == 0):
+            sc = max(1.0, np.abs(g2[i]).max(), abs(gn2[i]))
+            assert np.abs(g[i] - g2[i]).max() <= 1e-9 * sc and abs(gn[i] - gn2[i]) <= 1e-9 * sc, (case, i, kernels[i], g[i], g2[i])
+            if oracle_check:
+                lpo, go, gno = O.gp_logpdf_grad(kernels[i].to_tuple(), float(noises[i]), ts[:n], xs[:n])
+                sc = max(1.0, np.abs(go).max(), abs(gno))
+                assert np.abs(g[i] - go).max() <= 1e-7 * sc and abs(gn[i] - gno) <= 1e-7 * sc, (case, i, kernels[i], g[i], go)
+    finally:
+        a.close(); b.close()
 
 
 def test_gradient_lag_domain_population_and_switches(pkg, monkeypatch):
