@@ -164,6 +164,7 @@ struct GradArgs {
   // ([P][3][ldv]), and the rank of the sweep's first point in time (its points occupy ranks rank0 .. rank0 + n - 1)
   double* tsol; int rank0;
   const double* noise;               // [P] observation noise of the group's particles
+  double poly_mmax;                  // bound of |midpoint| over the resident series (fixed-point scale of the moment histograms)
   double toep_max_amp;               // largest accepted entry of U' T^-1 U C (k_lag_grad)
   int32_t* retry;                    // [caller's P] set when the Linear leaves' downdate is too ill-conditioned: the host repeats that particle with L^-T
 };
@@ -183,6 +184,12 @@ constexpr int GFLAG_LAGFFT = 4;
                       // bit 3 (with bit 1): the sweep's points are n consecutive grid points, so K = Toeplitz + the Linear leaves' rank-2
                       // term: the lag sums of K^-1 follow from four solves with L (Gohberg-Semencul) — no L^-T, no K^-1 tiles
 constexpr int GFLAG_LAGTOEP = 8;
+                      // bit 4: Linear leaves inside products (at most d = bits 8-9 of them along any product path, no ChangePoint): at a
+                      // fixed lag the kernel is a polynomial of degree 2d in the pair's midpoint m = (t_a + t_b)/2 - t_ref, so
+                      // sum_ab G_ab dK_ab = sum over lags and 2d+1 probe midpoints of [moment-matched weights] x dK(probe):
+                      // k_kinv_tiles bins G m^k (k = 0..2d) by lag, k_lag_grad differentiates (2d+1) n virtual elements
+constexpr int GFLAG_LAGPOLY = 16;
+constexpr int GFLAG_POLY_DEG_SHIFT = 8;
 constexpr int LAGDOM_MAX_BINS = 4096;      // LDS histogram of k_kinv_tiles (32 KiB)
 constexpr int FFT_N = 4096;                // transform length of the spectral variant: series of up to FFT_N / 2 points
 

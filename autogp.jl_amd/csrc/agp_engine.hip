@@ -581,7 +581,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   bool any_toep_sweep = false;                 // some particle of this sweep took the Toeplitz solves
   std::vector<int32_t> toep_retry;             // ... and (caller order) whether its downdate was rejected on the device
   if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->n_max <= LAGDOM_MAX_BINS) {
-    int64_t n_cov = 0;
+    int64_t n_cov = 0, n_sum = 0;          // lag-domain particles; of which sums of stationary subtrees and Linear leaves
     // (the transform has one length, 4096: below ~1000 points the K^-1 tiles are cheaper than n/2 transforms of that length)
     const bool use_fft = c->grad_fft && c->d_fft_tw != nullptr && 2 * c->n_max <= FFT_N && n > GRAD_FFT_MIN_N;      // (n: this sweep's prefix — the number of transforms)
     // the sweep's points are n consecutive grid points (the whole series; a prefix of a series in time order): K is Toeplitz
@@ -596,23 +596,30 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     for (int q = 0; q < P; ++q) {
       GProgHdr& g = bt.ghdr[q];
       if (g.n_cp > 0 || g.n_ops > 64) continue;
-      uint8_t stat[64], cov[64];
+      uint8_t stat[64], cov[64], deg[64];          // deg: most Linear leaves along a product path below the node
       for (int i = 0; i < g.n_ops; ++i) {
         const int o = bt.gops[g.node_off + i], li = bt.glc[g.node_off + i], ri = bt.grc[g.node_off + i];
         if (o == OP_PLUS || o == OP_TIMES) {
           stat[i] = stat[li] && stat[ri];
           cov[i] = stat[i] || (o == OP_PLUS && cov[li] && cov[ri]);
+          deg[i] = (uint8_t)std::min(100, o == OP_PLUS ? std::max<int>(deg[li], deg[ri]) : deg[li] + deg[ri]);
         } else {
           stat[i] = (o == OP_SE || o == OP_GE || o == OP_PER || o == OP_CONST || o == OP_WN);
           cov[i] = stat[i] || o == OP_LIN;
+          deg[i] = o == OP_LIN ? 1 : 0;
         }
       }
-      if (g.n_ops > 0 && cov[g.n_ops - 1]) { g.flags |= GFLAG_LAGDOM | (use_toep ? GFLAG_LAGTOEP : use_fft ? GFLAG_LAGFFT : 0); ++n_cov; }
+      if (g.n_ops > 0 && cov[g.n_ops - 1]) { g.flags |= GFLAG_LAGDOM | (use_toep ? GFLAG_LAGTOEP : use_fft ? GFLAG_LAGFFT : 0); ++n_cov; ++n_sum; }
+      else if (g.n_ops > 0 && c->grad_lagdom >= 2 && deg[g.n_ops - 1] >= 1 && deg[g.n_ops - 1] <= 2 &&
+               (2 * deg[g.n_ops - 1] + 1) * c->n_max + 8 <= NB2) {
+        // Linear leaves inside products: moment histograms of G over the lags (k_kinv_tiles), (2d+1) n virtual elements (k_lag_grad)
+        g.flags |= GFLAG_LAGPOLY | ((int)deg[g.n_ops - 1] << GFLAG_POLY_DEG_SHIFT); ++n_cov;
+      }
     }
     std::lock_guard<std::mutex> g(c->mu);
     c->n_lagdom_particles += n_cov;
-    if (use_toep) c->n_toep_particles += n_cov;
-    any_toep_sweep = use_toep && n_cov > 0;
+    if (use_toep) c->n_toep_particles += n_sum;
+    any_toep_sweep = use_toep && n_sum > 0;
   }
   const int n_prm_total = prm_off[P];
   if (go && n == 0) {
@@ -877,6 +884,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           }
           ga.tsol = s->tsol.as<double>() + (size_t)g0 * 3 * n_pad; ga.rank0 = toep_rank0;
           ga.noise = cv.noise; ga.retry = s->tretry.as<int32_t>(); ga.toep_max_amp = GRAD_TOEP_MAX_AMP;
+          ga.poly_mmax = c->poly_mmax;
           // Particle list of the group, largest trees first (their workgroups run longest), lag-domain particles behind the
           // others: the contraction launches below take the first Pn entries, k_lag_grad the rest; the 16-node (800 B private
           // memory) variant serves groups without a larger tree.
@@ -884,13 +892,15 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           std::vector<int32_t>& pl = pls.back();          // outlives the async upload (synchronised at the end of the call)
           int max_nodes = 0;
           for (int r = 0; r < Pg; ++r) { pl[r] = r; max_nodes = std::max(max_nodes, (int)bt.ghdr[p0 + g0 + r].n_ops); }
+          // classes: 0 element-wise contraction, 1 polynomial (K^-1 tiles' moment histograms -> k_lag_grad), 2 lag domain
           auto lagdom = [&](int r) { return (bt.ghdr[p0 + g0 + r].flags & GFLAG_LAGDOM) != 0; };
+          auto cls = [&](int r) { const int f = bt.ghdr[p0 + g0 + r].flags; return (f & GFLAG_LAGDOM) ? 2 : (f & GFLAG_LAGPOLY) ? 1 : 0; };
           std::stable_sort(pl.begin(), pl.end(), [&](int a_, int b_) {
-            if (lagdom(a_) != lagdom(b_)) return lagdom(b_);
+            if (cls(a_) != cls(b_)) return cls(a_) < cls(b_);
             return bt.ghdr[p0 + g0 + a_].n_ops > bt.ghdr[p0 + g0 + b_].n_ops;
           });
-          int Pn = 0;
-          for (int r = 0; r < Pg; ++r) Pn += !lagdom(r);
+          int Pn = 0, Pe = 0;          // Pn: particles that need L^-T and K^-1 tiles (classes 0, 1);  Pe: class 0
+          for (int r = 0; r < Pg; ++r) { Pn += !lagdom(r); Pe += cls(r) == 0; }
           int32_t* d_pl = s->plist.as<int32_t>() + p0 + g0;
           HIPCHK(c, hipMemcpyAsync(d_pl, pl.data(), sizeof(int32_t) * Pg, hipMemcpyHostToDevice, q));
           ga.plist = d_pl;
@@ -948,11 +958,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             // three classes by tree size (the particle list is sorted by it): > 16 nodes and 9 .. 16 nodes keep their tape
             // in private memory, trees of <= 8 nodes — the bulk of a prior-sampled population — keep it in LDS
             int n_big = 0, n_mid = 0;
-            for (int r = 0; r < Pn; ++r) {
+            for (int r = 0; r < Pe; ++r) {
               const int no = bt.ghdr[p0 + g0 + pl[r]].n_ops;
               n_big += no > 16; n_mid += (no <= 16 && no > LDS_TAPE_NODES);
             }
-            const int n_small = Pn - n_big - n_mid;
+            const int n_small = Pe - n_big - n_mid;
             // The launch classes are independent and each ends on a few long-running workgroups (the largest trees; the
             // 64-node class alone: ~2 000 workgroups of ~1 ms at n=2048): they run side by side on three more streams,
             // forked behind the K^-1 tiles and joined in front of the reduction.
@@ -970,6 +980,14 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
               gs.tape_off = (int)((lds2 + 15) / 16 * 2);                                  // doubles, 16-byte aligned
               const size_t lds3 = (size_t)gs.tape_off * 8 + sizeof(double) * LDS_TAPE_NODES * 4 * 256;
               HIPCHK(c, launch_grad_contract(0, qs[2], gs, ntiles, n_small, lds3));
+            }
+            if (Pe < Pn) {
+              // polynomial particles: behind the K^-1 tiles' moment histograms
+              HIPCHK(c, hipStreamWaitEvent(qs[3], s->gq_ev[3], 0));
+              GradArgs gp = ga; gp.plist = d_pl + Pe;
+              const size_t ldsp = sizeof(double) * (5 * (size_t)c->n_max + 40 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
+              launch_lag_grad(qs[3], Pn - Pe, ldsp, gp);
+              HIPCHK(c, hipGetLastError());
             }
             if (Pn < Pg) {
               gs.plist = d_pl + Pn;
@@ -1158,7 +1176,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_GE_TABLE")) c->ge_table = atoi(e) != 0;
   if (const char* e = getenv("AGP_LAG")) c->lag_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_LAG_RANK")) c->lag_rank_enable = atoi(e) != 0;
-  if (const char* e = getenv("AGP_GRAD_LAGDOM")) c->grad_lagdom = atoi(e) != 0;
+  if (const char* e = getenv("AGP_GRAD_LAGDOM")) c->grad_lagdom = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("AGP_GRAD_FFT")) c->grad_fft = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("AGP_RIGHT_LOOKING")) c->right_looking = atoi(e);
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
@@ -1304,6 +1322,7 @@ int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) 
       HIPCHK(c, hipMalloc((void**)&c->d_rank, sizeof(int32_t) * npad));
       HIPCHK(c, hipMemcpy(c->d_rank, rank.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice));
       c->t_ref = 0.5 * (t0 + t1); c->grid_h = h; c->grid_mid = 0.5 * (double)(n_max - 1);
+      c->poly_mmax = std::max(0.5 * (t1 - t0) * (1.0 + 1e-9), h);
       if (!c->d_fft_tw) {
         // twiddle factors of the gradient sweeps' spectral lag sums (k_zspec): here, where one thread runs by contract — the sweeps
         // that read them may come from many

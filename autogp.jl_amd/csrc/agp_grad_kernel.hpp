@@ -453,7 +453,8 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
   const int pflags = a.ghdr[p].flags;
   if (pflags & GFLAG_LAGFFT) return;                  // (its lag sums come from k_zspec; the host's list leaves these out anyway)
   const bool lagdom = (pflags & GFLAG_LAGDOM) != 0;
-  if (lagdom)
+  const bool poly = (pflags & GFLAG_LAGPOLY) != 0;
+  if (lagdom || poly)
     for (int i = tid; i < a.nbins; i += 256) bins[i] = 0.0;       // (published by the barriers of the slab loop)
   const double* __restrict__ Zp = a.Z + (long long)p * (a.strideZ ? a.strideZ : a.strideA);
   d4 acc[NSB][2];
@@ -464,6 +465,86 @@ __global__ __launch_bounds__(256, 2) void k_kinv_tiles(GradArgs a) {
              Zp, [&](int s) { return (int)((zoff(tj, ti + (s >> 3)) + (long long)((s & 7) * KB) * NB) * 8); },
              sm, tid, l15, lq, row0);
   double* __restrict__ Kt = const_cast<double*>(a.A) + (long long)p * a.strideA + tile_off(ti, tj);
+  if (poly) {
+    // moment histograms G m^k, k = 0 .. 2d, one pass over the accumulators per moment through the one LDS histogram (a pass is
+    // ~4 us beside the ~200 us of the tile's products); same fixed-point sums as below: reproducible
+    const int nk = 2 * ((pflags >> GFLAG_POLY_DEG_SHIFT) & 3) + 1;
+    double* cal = sm;
+    double* ctm = sm + NB;
+    int* crk = reinterpret_cast<int*>(sm + 2 * NB);
+    const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
+    __syncthreads();
+    if (tid < NB) {
+      const int gb = tj * NB + tid;
+      cal[tid] = gb < a.n ? al[gb] : 0.0;
+      ctm[tid] = a.tt[gb] - a.tref;
+      crk[tid] = gb < a.n ? a.rank[gb] : -1;
+    }
+    __syncthreads();
+    const double wfac = (ti == tj) ? 0.5 : 1.0;
+    double ar[2], tr[2]; int rr[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int ga = ti * NB + row0 + s2;
+      ar[s2] = ga < a.n ? al[ga] : 0.0;
+      tr[s2] = a.tt[ga] - a.tref;
+      rr[s2] = ga < a.n ? a.rank[ga] : -1;
+    }
+    double gmax = 0.0, gsum = 0.0;
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = cb * 16 + 4 * r + lq;
+        const double ab = cal[c];
+        const bool cv = crk[c] >= 0;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const double G = (cv && rr[s2] >= 0) ? wfac * (ar[s2] * ab - acc[cb][s2][r]) : 0.0;
+          acc[cb][s2][r] = G;
+          gmax = fmax(gmax, fabs(G)); gsum += G;
+        }
+      }
+    auto nmax = [](double x, double y) { return (y > x || y != y) ? y : x; };
+    if (gsum != gsum) gmax = gsum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmax = nmax(gmax, __shfl_xor(gmax, off));
+    if (l == 0) sm[4 * NB + w] = gmax;
+    __syncthreads();
+    gmax = nmax(nmax(sm[4 * NB], sm[4 * NB + 1]), nmax(sm[4 * NB + 2], sm[4 * NB + 3]));
+    const bool finite = gmax < 1e300;
+    const double magic = 6755399441055744.0;
+    unsigned long long* ibins = reinterpret_cast<unsigned long long*>(bins);
+    double mk_bound = 1.0;
+    for (int k = 0; k < nk; ++k) {
+      const double gk = gmax * mk_bound;                  // >= |G m^k| of every element
+      const int ex = (gk > 0.0 && finite) ? ilogb(gk) : 0;
+      const double scale = ldexp(1.0, 50 - ex), rscale = finite ? ldexp(1.0, ex - 50) : __builtin_nan("");
+#pragma unroll
+      for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = cb * 16 + 4 * r + lq;
+          const int rk = crk[c];
+          const double tb = ctm[c];
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int d = rr[s2] - rk;
+            const double m = 0.5 * (tr[s2] + tb);
+            double v = acc[cb][s2][r];
+            for (int e = 0; e < k; ++e) v *= m;
+            const double y = fma(v, scale, magic);
+            const unsigned long long q = (unsigned long long)(__double_as_longlong(y) - __double_as_longlong(magic));
+            __hip_atomic_fetch_add(&ibins[(d < 0 ? -d : d) & (LAGDOM_MAX_BINS - 1)], q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      __syncthreads();
+      for (int i = tid; i < a.nbins; i += 256) { Kt[(long long)k * a.nbins + i] = (double)(long long)ibins[i] * rscale; ibins[i] = 0ull; }
+      __syncthreads();
+      mk_bound *= a.poly_mmax;
+    }
+    return;
+  }
   if (lagdom) {
     // column side of the tile in LDS (the slab buffers are free): alpha_b, rank_b, t_b - t_ref
     double* cal = sm;
@@ -915,8 +996,10 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
   const int ntiles = a.nt * (a.nt + 1) / 2;
   const bool toep = (h.flags & GFLAG_LAGTOEP) != 0;
   const bool fft = (h.flags & GFLAG_LAGFFT) != 0;
+  const bool poly = (h.flags & GFLAG_LAGPOLY) != 0;
+  const int pd = (h.flags >> GFLAG_POLY_DEG_SHIFT) & 3, nk = 2 * pd + 1;
   double* D = smem + ((fft || toep) ? 2 * FFT_BUF : 0);          // [nbins] (behind the transform buffer of the spectral variants)
-  double* prm = D + a.nbins + 40;
+  double* prm = D + (poly ? nk * a.nbins : a.nbins) + 40;          // (poly: 2d+1 moment histograms)
   int32_t* poff = reinterpret_cast<int32_t*>(prm + h.n_prm + 3);
   uint8_t* ops = reinterpret_cast<uint8_t*>(poff + h.n_ops);
   uint8_t* lc = ops + h.n_ops;
@@ -933,7 +1016,14 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
   }
   const double* __restrict__ Ap = a.A + (long long)p * a.strideA;
   double mom[3] = {0.0, 0.0, 0.0};
-  if (toep) {
+  if (poly) {
+    // moment histograms D_k[g] = sum over the pairs at lag g of G m^k: fixed-order sum over the particle's tiles
+    for (int idx = tid; idx < nk * a.nbins; idx += 256) {
+      double s = 0.0;
+      for (int t = 0; t < ntiles; ++t) s += Ap[(long long)t * NB2 + idx];
+      D[idx] = s;
+    }
+  } else if (toep) {
     // Toeplitz variant (see k_toep_solve): D from alpha, k0 = K^-1 e_first, v1 = K^-1 1, vt = K^-1 (t - t_ref)
     d2* buf = reinterpret_cast<d2*>(smem);
     double* fred = D + a.nbins;      // behind D: 40 doubles (host sizes the LDS for them)
@@ -1139,15 +1229,35 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
   ScratchAcc<3 * GS + 2> sacc{gacc};
   for (int q = 0; q <= h.n_prm + 2; ++q) gacc[q] = 0.0;
   const double t0 = a.tts[0];
-  for (int g0 = 0; g0 < a.nbins; g0 += 256 * E) {
+  // Polynomial particles: at lag g the kernel is a polynomial of degree 2d in the pair's midpoint m, so the sum over the pairs at
+  // that lag equals a sum over 2d+1 probe midpoints mu x_j (x_j equally spaced in [-1, 1]) with weights w_j = sum_k a_jk D_k[g] / mu^k,
+  // a_jk the monomial coefficients of the Lagrange basis polynomial of x_j — (2d+1) n virtual elements (t_ref + m_j +- g h / 2)
+  const double LB1[3][3] = {{0.0, -0.5, 0.5}, {1.0, 0.0, -1.0}, {0.0, 0.5, 0.5}};
+  const double LB2[5][5] = {{0.0, 1.0 / 6.0, -1.0 / 6.0, -2.0 / 3.0, 2.0 / 3.0}, {0.0, -4.0 / 3.0, 8.0 / 3.0, 4.0 / 3.0, -8.0 / 3.0},
+                            {1.0, 0.0, -5.0, 0.0, 4.0}, {0.0, 4.0 / 3.0, 8.0 / 3.0, -4.0 / 3.0, -8.0 / 3.0},
+                            {0.0, -1.0 / 6.0, -1.0 / 6.0, 2.0 / 3.0, 2.0 / 3.0}};
+  const double pmu = a.poly_mmax, ipmu = 1.0 / a.poly_mmax;
+  const int nv = poly ? nk * a.nbins : a.nbins;
+  for (int g0 = 0; g0 < nv; g0 += 256 * E) {
     int ri[E], ci[E];
     double ta[E], tb[E], wg[E], lt[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       const int g = g0 + e * 256 + tid;
-      const bool in = g < a.nbins;
+      const bool in = g < nv;
       ri[e] = 0; ci[e] = 0; lt[e] = 0.0;
-      ta[e] = in ? a.tts[g] : t0; tb[e] = t0; wg[e] = in ? D[g] : 0.0;
+      if (poly) {
+        const int j = in ? g / a.nbins : 0, gg = in ? g - j * a.nbins : 0;
+        double wsum = 0.0, sc = 1.0;
+        for (int k = 0; k < nk; ++k) {
+          wsum = fma((pd == 1 ? LB1[j][k] : LB2[j][k]) * sc, D[k * a.nbins + gg], wsum);
+          sc *= ipmu;
+        }
+        const double mj = pmu * (-1.0 + (double)j / (double)pd), hl = 0.5 * (double)gg * a.grid_h;
+        ta[e] = a.tref + mj + hl; tb[e] = a.tref + mj - hl; wg[e] = in ? wsum : 0.0;
+      } else {
+        ta[e] = in ? a.tts[g] : t0; tb[e] = t0; wg[e] = in ? D[g] : 0.0;
+      }
     }
     grad_elements<GS, E>(h, ops, lc, rc, mv, poff, prm, nullptr, ri, ci, ta, tb, wg, lt, false, tape, sacc);
   }
@@ -1166,7 +1276,7 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
   __syncthreads();
   if (tid == 0) {
     const double M0 = red[4], M1 = red[5], M2 = red[6];
-    for (int ip = 0; ip < h.n_ops; ++ip)
+    for (int ip = 0; ip < h.n_ops && !poly; ++ip)          // (polynomial particles: the probes carry the Linear leaves too)
       if (ops[ip] == OP_LIN) {
         const double* q = prm + poff[ip];
         const double cc = q[0] - a.tref;
@@ -1301,7 +1411,7 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
 __global__ void k_grad_finish(GradArgs a) {
   const int p = blockIdx.x;
   const GProgHdr h = a.ghdr[p];
-  if (h.flags & GFLAG_LAGDOM) return;          // (k_lag_grad wrote this particle's outputs)
+  if (h.flags & (GFLAG_LAGDOM | GFLAG_LAGPOLY)) return;          // (k_lag_grad wrote this particle's outputs)
   const int ntiles = a.nt * (a.nt + 1) / 2;
   for (int q = threadIdx.x; q <= h.n_prm; q += blockDim.x) {
     double s = 0.0;

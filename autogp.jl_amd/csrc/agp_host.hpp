@@ -146,7 +146,9 @@ struct agp_ctx {
   int grad_fft = 2;              // lag-domain particles of series of <= FFT_N / 2 points: lag sums from Z's power spectrum (1), or — the sweep's
                                  // points being consecutive grid points — from four solves with L, no L^-T (2: where possible, else 1); env AGP_GRAD_FFT
   double* d_fft_tw = nullptr;    // twiddle factors of that transform
-  int grad_lagdom = 1;           // gradient sweeps on a regular grid: lag-domain contraction where the kernel allows; env AGP_GRAD_LAGDOM
+  int grad_lagdom = 2;           // gradient sweeps on a regular grid: lag-domain contraction where the kernel allows (1: sums of stationary subtrees
+                                 // and Linear leaves; 2: also Linear leaves inside products, by moment histograms); env AGP_GRAD_LAGDOM
+  double poly_mmax = 1.0;        // half the resident series' time range: bound of a pair's midpoint t - t_ref
   int64_t n_lagdom_particles = 0;   // particles contracted in the lag domain so far (agp_get_lag_stats)
   int64_t n_toep_particles = 0;      // ... of which: lag sums from the Toeplitz solves (k_toep_solve)
   bool lag_ok = false;

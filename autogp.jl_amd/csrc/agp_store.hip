@@ -412,7 +412,7 @@ int agp_get_lag_predict_stats(agp_ctx* c, int64_t* n_passes) {
 
 int agp_set_grad_lag_domain(agp_ctx* c, int32_t on) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
-  c->grad_lagdom = on != 0;
+  c->grad_lagdom = on <= 0 ? 0 : on == 1 ? 1 : 2;
   return AGP_OK;
 }
 

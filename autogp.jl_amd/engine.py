@@ -369,7 +369,7 @@ class GPEngine:
 
     def set_grad_lag_domain(self, on):
         """Switch the lag-domain gradient contraction of regular grids (takes effect at the next gradient sweep)."""
-        self._check(self._lib.agp_set_grad_lag_domain(self._ctx, 1 if on else 0))
+        self._check(self._lib.agp_set_grad_lag_domain(self._ctx, (2 if on else 0) if isinstance(on, bool) else int(on)))
 
     def grad_lag_domain_particles(self):
         """Particles whose gradient was contracted in the lag domain so far."""
