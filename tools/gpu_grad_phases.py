@@ -1,3 +1,4 @@
+"""Phases of the element-wise gradient sweep (lag domain off: what an irregular series costs), 512 prior-sampled particles, n = 2048."""
 import sys, numpy as np
 sys.path.insert(0,'/root/repo')
 import __graft_entry__ as g
