@@ -751,16 +751,16 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     if (go) {
       goff_sorted.resize(P);
       for (int q = 0; q < P; ++q) goff_sorted[q] = prm_off[bt.order[q]];
-      HIPCHK(c, hipMemcpyAsync(s->ghdr.p, bt.ghdr.data(), sizeof(GProgHdr) * P, hipMemcpyHostToDevice, st));
-      HIPCHK(c, hipMemcpyAsync(s->gops.p, bt.gops.data(), bt.gops.size(), hipMemcpyHostToDevice, st));
-      HIPCHK(c, hipMemcpyAsync(s->glc.p, bt.glc.data(), bt.glc.size(), hipMemcpyHostToDevice, st));
-      HIPCHK(c, hipMemcpyAsync(s->grc.p, bt.grc.data(), bt.grc.size(), hipMemcpyHostToDevice, st));
-      HIPCHK(c, hipMemcpyAsync(s->gpoff.p, bt.gpoff.data(), sizeof(int32_t) * bt.gpoff.size(), hipMemcpyHostToDevice, st));
-      HIPCHK(c, hipMemcpyAsync(s->gprm.p, bt.gprm.data(), sizeof(double) * bt.gprm.size(), hipMemcpyHostToDevice, st));
-      if (!bt.gmap.empty())
-        HIPCHK(c, hipMemcpyAsync(s->gmap.p, bt.gmap.data(), sizeof(int32_t) * bt.gmap.size(), hipMemcpyHostToDevice, st));
-      HIPCHK(c, hipMemcpyAsync(s->goff.p, goff_sorted.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
-      HIPCHK(c, hipStreamSynchronize(st));     // goff_sorted is a local
+      PinnedUploads up;
+      up.add(s->ghdr.p, bt.ghdr.data(), sizeof(GProgHdr) * P);
+      up.add(s->gops.p, bt.gops.data(), bt.gops.size());
+      up.add(s->glc.p, bt.glc.data(), bt.glc.size());
+      up.add(s->grc.p, bt.grc.data(), bt.grc.size());
+      up.add(s->gpoff.p, bt.gpoff.data(), sizeof(int32_t) * bt.gpoff.size());
+      up.add(s->gprm.p, bt.gprm.data(), sizeof(double) * bt.gprm.size());
+      up.add(s->gmap.p, bt.gmap.data(), sizeof(int32_t) * bt.gmap.size());
+      up.add(s->goff.p, goff_sorted.data(), sizeof(int32_t) * P);
+      HIPCHK(c, up.flush(s->h_stage2, st));
     }
     if ((lag || lagr) && bt.n_lag_tables > 0) {
       // the sweep's lag tables: every stationary leaf of every particle at the 255 lags of each of the nt block diagonals

@@ -57,10 +57,39 @@ struct HostBuf {
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+// A call's small host arrays travel through ONE pinned staging buffer (the slot's): copies out of pageable memory cost the
+// runtime a staging allocation + a blocking hand-over each (measured: 20 ms on the second predictive call of a process, ~1 ms
+// later), and their sources would have to outlive the copy.
+struct PinnedUploads {
+  struct Item { void* dev; size_t off, bytes; };
+  std::vector<char> blob;
+  std::vector<Item> items;
+  void add(void* dev, const void* host, size_t bytes) {
+    if (bytes == 0) return;
+    const size_t off = (blob.size() + 15) & ~(size_t)15;
+    blob.resize(off + bytes);
+    std::memcpy(blob.data() + off, host, bytes);
+    items.push_back({dev, off, bytes});
+  }
+  hipError_t flush(HostBuf& hb, hipStream_t st) {
+    if (items.empty()) return hipSuccess;
+    hipError_t e = hb.ensure(blob.size());
+    if (e != hipSuccess) return e;
+    std::memcpy(hb.p, blob.data(), blob.size());
+    for (const Item& it : items) {
+      e = hipMemcpyAsync(it.dev, static_cast<char*>(hb.p) + it.off, it.bytes, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) return e;
+    }
+    items.clear(); blob.clear();
+    return hipSuccess;
+  }
+};
+
 struct Slot {
   hipStream_t stream = nullptr;
   DevBuf stage;             // one upload per sweep: [hdr | prm | noise | map | ops]
   HostBuf h_stage, h_out;   // its pinned source, and the pinned landing zone of [logpdf | info]
+  HostBuf h_stage2;         // pinned source of the gradient programs (the sweep's stage copy may still be reading h_stage)
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
       Z, alpha, tsol, tretry, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq, lagtab,
@@ -81,7 +110,7 @@ struct Slot {
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
                       &Z, &alpha, &tsol, &tretry, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab, &pl_rank, &pl_tl, &pl_prog})
       b->release();
-    stage.release(); h_stage.release(); h_out.release(); h_async_info.release();
+    stage.release(); h_stage.release(); h_stage2.release(); h_out.release(); h_async_info.release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
     for (auto& q : gq) { if (q) (void)hipStreamDestroy(q); q = nullptr; }

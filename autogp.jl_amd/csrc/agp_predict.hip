@@ -162,41 +162,41 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
   HIPCHK(c, s->pred_mean.ensure(sizeof(double) * (size_t)std::max<int64_t>(1, mJ) * chunk));
   HIPCHK(c, s->pred_var.ensure(sizeof(double) * (size_t)std::max<int64_t>(1, mJ) * chunk));
   if (out_cov) HIPCHK(c, s->pred_cov.ensure(sizeof(double) * (size_t)m * m * chunk));
+  PinnedUploads up;
   if (mean_train && n > 0) {
     HIPCHK(c, s->mu1.ensure(sizeof(double) * (size_t)n));
-    HIPCHK(c, hipMemcpyAsync(s->mu1.p, mean_train, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    up.add(s->mu1.p, mean_train, sizeof(double) * n);
   }
   if (mean_pred && mJ > 0) {
     HIPCHK(c, s->mu2.ensure(sizeof(double) * (size_t)mJ));
-    HIPCHK(c, hipMemcpyAsync(s->mu2.p, meanJ, sizeof(double) * mJ, hipMemcpyHostToDevice, st));
+    up.add(s->mu2.p, meanJ, sizeof(double) * mJ);
   }
-  HIPCHK(c, hipMemcpyAsync(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr) * P, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(s->ops.p, bt.ops.data(), bt.ops.size(), hipMemcpyHostToDevice, st));
-  if (!bt.prm.empty())
-    HIPCHK(c, hipMemcpyAsync(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size(), hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(s->noise.p, noise_sorted.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(s->noise_pred.p, npred.data(), sizeof(double) * P, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipMemcpyAsync(s->tt.p, tt.data(), sizeof(double) * ntot, hipMemcpyHostToDevice, st));
+  up.add(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr) * P);
+  up.add(s->ops.p, bt.ops.data(), bt.ops.size());
+  up.add(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size());
+  up.add(s->noise.p, noise_sorted.data(), sizeof(double) * P);
+  up.add(s->noise_pred.p, npred.data(), sizeof(double) * P);
+  up.add(s->tt.p, tt.data(), sizeof(double) * ntot);
   if (pred_code) {
     std::vector<uint8_t> code((size_t)ntot, 0);
     std::copy(pred_code, pred_code + m, code.begin() + n1_pad);
     HIPCHK(c, s->code.ensure((size_t)ntot));
-    HIPCHK(c, hipMemcpyAsync(s->code.p, code.data(), (size_t)ntot, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));     // `code` is a local
+    up.add(s->code.p, code.data(), (size_t)ntot);
   }
   if (diag_add && mJ > 0) {
     HIPCHK(c, s->diag_add.ensure(sizeof(double) * (size_t)mJ));
-    HIPCHK(c, hipMemcpyAsync(s->diag_add.p, daddJ, sizeof(double) * mJ, hipMemcpyHostToDevice, st));
+    up.add(s->diag_add.p, daddJ, sizeof(double) * mJ);
   }
 
   const int32_t* d_src = nullptr; const int32_t* d_i0 = nullptr;
   if (n_hit > 0) {
     HIPCHK(c, s->stage.ensure(sizeof(int32_t) * 2 * (size_t)P));
     int32_t* d = s->stage.as<int32_t>();
-    HIPCHK(c, hipMemcpyAsync(d, src_slot.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d + P, i0v.data(), sizeof(int32_t) * P, hipMemcpyHostToDevice, st));
+    up.add(d, src_slot.data(), sizeof(int32_t) * P);
+    up.add(d + P, i0v.data(), sizeof(int32_t) * P);
     d_src = d; d_i0 = d + P;
   }
+  if (!lagr) HIPCHK(c, up.flush(s->h_stage, st));
 
   if (lagr) {
     // ranks of the joint points, lag times, table programs; one table of R lags per stationary subtree of the batch
@@ -221,10 +221,10 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     const std::vector<int32_t>& rankJ = diag_path ? rankF : pl->rank;
     HIPCHK(c, s->pl_rank.ensure(sizeof(int32_t) * rankJ.size()));
     HIPCHK(c, s->pl_tl.ensure(sizeof(double) * pl->tl.size()));
-    HIPCHK(c, hipMemcpyAsync(s->pl_prog.p, hp.data(), prog_bytes, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(s->pl_rank.p, rankJ.data(), sizeof(int32_t) * rankJ.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(s->pl_tl.p, pl->tl.data(), sizeof(double) * pl->tl.size(), hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipStreamSynchronize(st));      // `hp` is a local
+    up.add(s->pl_prog.p, hp.data(), prog_bytes);
+    up.add(s->pl_rank.p, rankJ.data(), sizeof(int32_t) * rankJ.size());
+    up.add(s->pl_tl.p, pl->tl.data(), sizeof(double) * pl->tl.size());
+    HIPCHK(c, up.flush(s->h_stage, st));
     if (bt.n_lag_tables > 0) {
       HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * pl->rank_units * 256));
       LagArgs la = {};
@@ -240,9 +240,15 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     ++c->n_lag_pred;
   }
 
-  std::vector<double> h_mean, h_var, h_alpha, h_dinv;
+  const double* h_mean = nullptr; const double* h_var = nullptr; const double* h_alpha = nullptr; const double* h_dinv = nullptr;      // in the slot's pinned landing zone
   for (int p0 = 0; p0 < P; p0 += chunk) {
     const int Pc = std::min(chunk, P - p0);
+    {
+      const size_t nm = (size_t)std::max<int64_t>(1, mJ) * Pc, nd = diag_path ? (size_t)ntot * Pc : 0;
+      HIPCHK(c, s->h_out.ensure(sizeof(double) * (2 * nm + 2 * nd)));
+      double* hz = static_cast<double*>(s->h_out.p);
+      h_mean = hz; h_var = hz + nm; h_alpha = hz + 2 * nm; h_dinv = hz + 2 * nm + nd;
+    }
     launch_init_vec(st, ntot, Pc, s->vec.as<double>(), c->d_xs, (mean_train && n > 0) ? s->mu1.as<double>() : (const double*)nullptr, (int)n, s->info.as<int>() + p0, s->ready.as<int>() + p0);
     if (n_hit > 0) {
       launch_gather(c, st, Pc, nt1, s->A.as<double>(), strideA, s->W.as<double>(), nt1, s->vec.as<double>(), ntot, nullptr, 0,
@@ -309,9 +315,8 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       ga.P = Pc; ga.nt = nt1; ga.n = (int)n;
       launch_trtri_chain(st, 8 * ((Pc + 7) / 8) * nt1, ga);
       HIPCHK(c, hipGetLastError());
-      h_alpha.resize((size_t)ntot * Pc); h_dinv.resize((size_t)ntot * Pc);
-      HIPCHK(c, hipMemcpyAsync(h_alpha.data(), s->alpha.p, sizeof(double) * ntot * Pc, hipMemcpyDeviceToHost, st));
-      HIPCHK(c, hipMemcpyAsync(h_dinv.data(), s->gpart.p, sizeof(double) * ntot * Pc, hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(const_cast<double*>(h_alpha), s->alpha.p, sizeof(double) * ntot * Pc, hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(const_cast<double*>(h_dinv), s->gpart.p, sizeof(double) * ntot * Pc, hipMemcpyDeviceToHost, st));
     }
     if (mJ > 0) {
       // Schur complement of the prediction block + (-V^T alpha); with nt1 == 0 this just
@@ -344,9 +349,8 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     launch_pred_extract(st, nel, Pc, pa);
     HIPCHK(c, hipGetLastError());
     // results come back in sorted order: scatter to the caller's particle order
-    h_mean.resize((size_t)mJ * Pc); h_var.resize((size_t)mJ * Pc);
-    HIPCHK(c, hipMemcpyAsync(h_mean.data(), s->pred_mean.p, sizeof(double) * mJ * Pc, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(h_var.data(), s->pred_var.p, sizeof(double) * mJ * Pc, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(const_cast<double*>(h_mean), s->pred_mean.p, sizeof(double) * mJ * Pc, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(const_cast<double*>(h_var), s->pred_var.p, sizeof(double) * mJ * Pc, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(c, hipStreamSynchronize(st));
     for (int q = 0; q < Pc; ++q) {
@@ -355,7 +359,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
         double* om = out_mean + o * m; double* ov = out_var + o * m;
         for (int64_t g = 0; g < mJ; ++g) { om[fq[(size_t)g]] = h_mean[(size_t)q * mJ + g]; ov[fq[(size_t)g]] = h_var[(size_t)q * mJ + g]; }
         const double s2 = noise_sorted[(size_t)p0 + q], np2 = npred[(size_t)p0 + q];
-        const double* al = h_alpha.data() + (size_t)q * ntot; const double* dv = h_dinv.data() + (size_t)q * ntot;
+        const double* al = h_alpha + (size_t)q * ntot; const double* dv = h_dinv + (size_t)q * ntot;
         for (size_t d = 0; d < dq.size(); ++d) {
           const int32_t j = dq[d], i = di[d];
           const double ymu = c->h_xs[(size_t)i] - (mean_train ? mean_train[i] : 0.0);
@@ -364,8 +368,8 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
         }
         continue;
       }
-      std::memcpy(out_mean + o * m, h_mean.data() + (size_t)q * m, sizeof(double) * m);
-      std::memcpy(out_var + o * m, h_var.data() + (size_t)q * m, sizeof(double) * m);
+      std::memcpy(out_mean + o * m, h_mean + (size_t)q * m, sizeof(double) * m);
+      std::memcpy(out_var + o * m, h_var + (size_t)q * m, sizeof(double) * m);
       if (out_cov)
         HIPCHK(c, hipMemcpyAsync(out_cov + o * m * m, s->pred_cov.as<double>() + (size_t)q * m * m,
                                  sizeof(double) * m * m, hipMemcpyDeviceToHost, st));

@@ -253,8 +253,9 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
         tq_off = np.linspace(0.0, 1.25, m)                 # (not commensurate with the data's spacing: the general evaluator)
 
         def timed(q):
-            eng.predict_batch(nodes[:Pp], noises[:Pp], q, n=n, check=False)
-            reps = 2
+            for _ in range(2):
+                eng.predict_batch(nodes[:Pp], noises[:Pp], q, n=n, check=False)
+            reps = 3
             t0 = time.perf_counter()
             for _ in range(reps):
                 eng.predict_batch(nodes[:Pp], noises[:Pp], q, n=n, check=False)
