@@ -41,6 +41,21 @@ struct LagArgs {
   int nt, n_tables;
   int full, stride;        // full = 1: rank tables — grid.x = stride / 256 blocks of lags 256 bl + tid, 0 .. stride-1
 };
+// structured value sweep (agp_toep_kernel.hpp)
+struct ToepArgs {
+  const double* xs;          // observations in SORTED order
+  int n, P;
+  const ProgHdr* hdr;        // programs compiled for a lag sweep: OP_LAG / OP_LIN leaves under OP_PLUS
+  const uint8_t* ops;
+  const double* prm;
+  const double* noise;       // [P]
+  const double* lagtab;      // rank-table layout: table t at lagtab + t * lag_stride, lags 0 .. n-1
+  int lag_stride;
+  double grid_h, grid_mid, tref;
+  double* out_lp;            // [P] (sorted particle order)
+  int32_t* out_info;         // [P] 0, or 1: refused (the host repeats the particle on the dense path)
+};
+
 struct CholArgs {
   double* A;            // packed tiles
   long long strideA;    // doubles per particle

@@ -542,6 +542,103 @@ void launch_gather(agp_ctx* c, hipStream_t st, int Pc, int nt1, double* dstA, lo
   launch_gather_factor(st, gx, Pc, ga);
 }
 
+// ---- structured value sweep (opt-in, AGP_LAG=2): see agp_toep_kernel.hpp ------------------------------------------------
+// Class test on the caller's postfix program: a sum (top-level + chain) of Linear leaves and subtrees without Linear / ChangePoint.
+static bool toeplitz_class(const uint8_t* ops, int n_ops) {
+  // per stack entry: bit 0 = stationary subtree, bit 1 = member of the class
+  uint8_t st[AGP_MAX_OPS_DEV];
+  int sp = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    const int o = ops[i];
+    if (o == OP_PLUS || o == OP_TIMES || o == OP_CP) {
+      if (sp < 2) return false;
+      const uint8_t r = st[--sp], l = st[--sp];
+      const bool stat = o != OP_CP && (l & 1) && (r & 1);
+      const bool cls = stat || (o == OP_PLUS && (l & 2) && (r & 2));
+      st[sp++] = (uint8_t)((stat ? 1 : 0) | (cls ? 2 : 0));
+    } else if (o == OP_LIN) {
+      if (sp >= AGP_MAX_OPS_DEV) return false;
+      st[sp++] = 2;
+    } else if (o == OP_WN || o == OP_CONST || o == OP_SE || o == OP_GE || o == OP_PER) {
+      if (sp >= AGP_MAX_OPS_DEV) return false;
+      st[sp++] = 3;
+    } else {
+      return false;
+    }
+  }
+  return sp == 1 && (st[0] & 2) != 0;
+}
+
+// The class's particles of one value sweep over the whole (regular, sorted) series: rank-layout lag tables, then one workgroup
+// per particle.  Outputs in the sub-batch's order; info 1 = refused (not positive definite to rounding).
+static int toeplitz_sweep(agp_ctx* c, int64_t n, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
+                          const double* prm, const double* noise, double* out_lp, int32_t* out_info) {
+  Batch bt;
+  const int rank_units = (int)((c->n_max + 255) / 256);
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, false, false, false, false, true, rank_units, true);
+  if (rc) return rc;
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+  auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_tprm = al16(sizeof(LagTabHdr) * bt.thdr.size());
+  const size_t o_tops = al16(o_tprm + sizeof(double) * bt.tprm.size());
+  const size_t prog_bytes = al16(o_tops + bt.tops.size() + 4);
+  std::vector<char> hp(prog_bytes, 0);
+  if (!bt.thdr.empty()) {
+    std::memcpy(hp.data(), bt.thdr.data(), sizeof(LagTabHdr) * bt.thdr.size());
+    std::memcpy(hp.data() + o_tprm, bt.tprm.data(), sizeof(double) * bt.tprm.size());
+    std::memcpy(hp.data() + o_tops, bt.tops.data(), bt.tops.size());
+  }
+  std::vector<double> nz((size_t)P);
+  for (int q = 0; q < P; ++q) nz[(size_t)q] = noise[bt.order[q]];
+  HIPCHK(c, s->hdr.ensure(sizeof(ProgHdr) * (size_t)P));
+  HIPCHK(c, s->ops.ensure(bt.ops.size() + 4));
+  HIPCHK(c, s->prm.ensure(sizeof(double) * std::max<size_t>(1, bt.prm.size())));
+  HIPCHK(c, s->noise.ensure(sizeof(double) * (size_t)P));
+  HIPCHK(c, s->pl_prog.ensure(prog_bytes));
+  HIPCHK(c, s->out_lp.ensure(sizeof(double) * (size_t)P + sizeof(int32_t) * (size_t)P));
+  PinnedUploads up;
+  up.add(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr) * (size_t)P);
+  up.add(s->ops.p, bt.ops.data(), bt.ops.size());
+  up.add(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size());
+  up.add(s->noise.p, nz.data(), sizeof(double) * (size_t)P);
+  up.add(s->pl_prog.p, hp.data(), prog_bytes);
+  HIPCHK(c, up.flush(s->h_stage, st));
+  const int stride = rank_units * 256;
+  if (bt.n_lag_tables > 0) {
+    HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * stride));
+    LagArgs la = {};
+    la.tt = c->d_ts_s; la.thdr = s->pl_prog.as<LagTabHdr>();
+    la.tprm = reinterpret_cast<const double*>(static_cast<char*>(s->pl_prog.p) + o_tprm);
+    la.tops = reinterpret_cast<const uint8_t*>(static_cast<char*>(s->pl_prog.p) + o_tops);
+    la.n_tables = bt.n_lag_tables; la.tab = s->lagtab.as<double>();
+    la.nt = (int)((c->n_max + NB - 1) / NB); la.full = 1; la.stride = stride;
+    launch_lag_tables(st, la, rank_units, bt.n_lag_tables);
+    HIPCHK(c, hipGetLastError());
+  } else {
+    HIPCHK(c, s->lagtab.ensure(sizeof(double) * 16));
+  }
+  ToepArgs ta = {};
+  ta.xs = c->d_xs_s; ta.n = (int)n; ta.P = P;
+  ta.hdr = s->hdr.as<ProgHdr>(); ta.ops = s->ops.as<uint8_t>(); ta.prm = s->prm.as<double>(); ta.noise = s->noise.as<double>();
+  ta.lagtab = s->lagtab.as<double>(); ta.lag_stride = stride;
+  ta.grid_h = c->grid_h; ta.grid_mid = c->grid_mid; ta.tref = c->t_ref;
+  ta.out_lp = s->out_lp.as<double>(); ta.out_info = reinterpret_cast<int32_t*>(s->out_lp.as<double>() + P);
+  HIPCHK(c, launch_toep_logpdf(st, ta));
+  const size_t out_bytes = sizeof(double) * (size_t)P + sizeof(int32_t) * (size_t)P;
+  HIPCHK(c, s->h_out.ensure(out_bytes));
+  HIPCHK(c, hipMemcpyAsync(s->h_out.p, s->out_lp.p, out_bytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  const double* hl = static_cast<const double*>(s->h_out.p);
+  const int32_t* hi = reinterpret_cast<const int32_t*>(hl + P);
+  for (int q = 0; q < P; ++q) { out_lp[bt.order[q]] = hl[q]; out_info[bt.order[q]] = hi[q]; }
+  return AGP_OK;
+}
+
+static thread_local bool tl_in_toeplitz = false;
+
 // (set around the repeat of particles whose Toeplitz downdate was rejected: the nested sweep takes L^-T for them)
 static thread_local bool tl_no_toep = false;
 
@@ -555,6 +652,56 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   if (!op_off || !ops || !prm_off || !prm || !noise) return fail(c, AGP_ERR_ARG, "null program/noise pointer");
   if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
   HIPCHK(c, hipSetDevice(c->device));
+
+  // Structured value sweep (opt-in): on a regular grid, the particles whose kernel is a sum of stationary subtrees and Linear
+  // leaves need no factorisation at all — Toeplitz + rank 2: Schur algorithm, O(n^2) — the others (and every particle the
+  // structured sweep refuses) take the dense path below.
+  if (!go && c->toeplitz && !tl_in_toeplitz && allow_lag && c->lag_enable && c->lag_ok && n > 0 && n == c->n_max && n <= 4096 &&
+      h_out_lp && !d_user_lp && !d_user_info && !use_user_stream && !c->profiling) {
+    std::vector<int> part[2];
+    bool sane = true;
+    for (int p = 0; p < P && sane; ++p) sane = op_off[p + 1] >= op_off[p] && op_off[p + 1] - op_off[p] <= AGP_MAX_OPS_DEV;
+    if (sane)
+      for (int p = 0; p < P; ++p) part[toeplitz_class(ops + op_off[p], op_off[p + 1] - op_off[p]) ? 1 : 0].push_back(p);
+    // (worth it when the class's share of a dense sweep costs more than the n sequential steps of the recursion:
+    // ~50 us per particle at n = 2048 against ~0.7 us per step + ~0.4 ms of sub-batch overheads; level 3 forces it)
+    const double dense_us = 50.0 * (double)part[1].size() * std::pow((double)n / 2048.0, 3.0), schur_us = 0.7 * (double)n + 400.0;
+    if (sane && !part[1].empty() && (c->toeplitz >= 2 || dense_us > 1.5 * schur_us)) {
+      auto gather = [&](const std::vector<int>& ix, std::vector<int32_t>& oo, std::vector<uint8_t>& so, std::vector<int32_t>& po,
+                        std::vector<double>& sp, std::vector<double>& nz) {
+        oo.assign(ix.size() + 1, 0); po.assign(ix.size() + 1, 0); nz.resize(ix.size()); so.clear(); sp.clear();
+        for (size_t b = 0; b < ix.size(); ++b) {
+          const int p = ix[b];
+          so.insert(so.end(), ops + op_off[p], ops + op_off[p + 1]);
+          sp.insert(sp.end(), prm + prm_off[p], prm + prm_off[p + 1]);
+          oo[b + 1] = (int32_t)so.size(); po[b + 1] = (int32_t)sp.size(); nz[b] = noise[p];
+        }
+        if (sp.empty()) sp.push_back(0.0);
+      };
+      std::vector<int32_t> oo, po, binfo; std::vector<uint8_t> so; std::vector<double> sp, nz, blp;
+      gather(part[1], oo, so, po, sp, nz);
+      blp.resize(part[1].size()); binfo.assign(part[1].size(), 0);
+      int rc1 = toeplitz_sweep(c, n, (int)part[1].size(), oo.data(), so.data(), po.data(), sp.data(), nz.data(), blp.data(), binfo.data());
+      if (rc1) return rc1;
+      int64_t n_done = 0;
+      for (size_t b = 0; b < part[1].size(); ++b) {
+        if (binfo[b] == 0) { h_out_lp[part[1][b]] = blp[b]; if (h_out_info) h_out_info[part[1][b]] = 0; ++n_done; }
+        else part[0].push_back(part[1][b]);          // refused: the dense path decides (and names LAPACK's info)
+      }
+      { std::lock_guard<std::mutex> g(c->mu); c->n_toeplitz_value += n_done; }
+      if (!part[0].empty()) {
+        gather(part[0], oo, so, po, sp, nz);
+        blp.resize(part[0].size()); binfo.assign(part[0].size(), 0);
+        tl_in_toeplitz = true;
+        const int rc0 = logpdf_batch_impl(c, n, (int)part[0].size(), oo.data(), so.data(), po.data(), sp.data(), nz.data(), blp.data(),
+                                          binfo.data(), nullptr, nullptr, nullptr, false, nullptr, allow_lag);
+        tl_in_toeplitz = false;
+        if (rc0) return rc0;
+        for (size_t b = 0; b < part[0].size(); ++b) { h_out_lp[part[0][b]] = blp[b]; if (h_out_info) h_out_info[part[0][b]] = binfo[b]; }
+      }
+      return AGP_OK;
+    }
+  }
 
   Batch bt;
   std::vector<std::vector<int32_t>> pls;     // per-group particle orders of the gradient contraction
@@ -1174,7 +1321,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_FUSE")) c->fuse_mode = atoi(e);
   if (const char* e = getenv("AGP_SPLIT_DIAG")) c->split_diag = atoi(e);
   if (const char* e = getenv("AGP_GE_TABLE")) c->ge_table = atoi(e) != 0;
-  if (const char* e = getenv("AGP_LAG")) c->lag_enable = atoi(e) != 0;
+  if (const char* e = getenv("AGP_LAG")) { c->lag_enable = atoi(e) != 0; c->toeplitz = atoi(e) >= 3 ? 2 : atoi(e) >= 2 ? 1 : 0; }
   if (const char* e = getenv("AGP_LAG_RANK")) c->lag_rank_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LAGDOM")) c->grad_lagdom = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("AGP_GRAD_FFT")) c->grad_fft = std::max(0, std::min(2, atoi(e)));

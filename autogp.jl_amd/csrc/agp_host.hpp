@@ -181,6 +181,9 @@ struct agp_ctx {
   int64_t n_lagdom_particles = 0;   // particles contracted in the lag domain so far (agp_get_lag_stats)
   int64_t n_toep_particles = 0;      // ... of which: lag sums from the Toeplitz solves (k_toep_solve)
   bool lag_ok = false;
+  int toeplitz = 0;              // structured value sweeps (Schur algorithm) for the Toeplitz + rank-2 class; env AGP_LAG=2 / agp_set_lag_tables(ctx, 2)
+                                 // (2 = whatever the class's size: AGP_LAG=3, tests)
+  int64_t n_toeplitz_value = 0;  // particles scored that way so far
   int lag_enable = 1;
   double lag_tol_h = 1e-11;       // admitted deviation of a sorted point from its grid position, in units of the spacing (agp_set_data)
   int64_t n_lag_sweeps = 0;       // sweeps that took the lag path (agp_get_lag_stats)

@@ -3,6 +3,7 @@
 #include "agp_launch.hpp"
 #include "agp_cov_kernel.hpp"
 #include "agp_chol_kernel.hpp"
+#include "agp_toep_kernel.hpp"
 #include "agp_comm.hpp"
 
 namespace agp {
@@ -51,6 +52,13 @@ hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int 
 
 void launch_lag_tables(hipStream_t st, const LagArgs& la, int units, int n_tables) {
   hipLaunchKernelGGL(k_lag_tables, dim3(units, n_tables), dim3(256), 0, st, la);
+}
+
+hipError_t launch_toep_logpdf(hipStream_t st, const ToepArgs& ta) {
+  if (ta.n > 256 * TOEP_MAX_R) return hipErrorInvalidValue;
+  if (ta.n <= 2048) hipLaunchKernelGGL(k_toep_logpdf<8>, dim3(ta.P), dim3(256), sizeof(double) * (8 * 256 + 16), st, ta);
+  else hipLaunchKernelGGL(k_toep_logpdf<TOEP_MAX_R>, dim3(ta.P), dim3(256), sizeof(double) * (TOEP_MAX_R * 256 + 16), st, ta);
+  return hipGetLastError();
 }
 
 void launch_logdt_tiles(hipStream_t st, unsigned ntiles, const double* ts, double* out) {

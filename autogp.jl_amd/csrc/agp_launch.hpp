@@ -13,6 +13,7 @@ hipError_t kernels_init();          // raises the dynamic-LDS ceiling of the tab
 // tile builder: ntiles lower tiles of particles [ca.p_off, ca.p_off + P) (LDS for max_cp per-point tables, stack depth 4 / 8)
 hipError_t launch_cov(hipStream_t st, const CovArgs& ca, int ntiles, int P, int max_cp, int depth);
 void launch_lag_tables(hipStream_t st, const LagArgs& la, int units, int n_tables);
+hipError_t launch_toep_logpdf(hipStream_t st, const ToepArgs& ta);      // structured value sweep: one workgroup per particle (ta.P)
 void launch_logdt_tiles(hipStream_t st, unsigned ntiles, const double* ts, double* out);
 // DCOV selection (dcov): 0 = tiles are resident, 4 / 8 = evaluate the kernel program in the kernel with that evaluation-stack
 // depth; ca.lag / ca.logdt select the table-reading instantiations (GM 2 / 1, see chol_tile).

@@ -387,6 +387,14 @@ int agp_get_lag_stats(agp_ctx* c, int32_t* regular_grid, int64_t* n_lag_sweeps) 
 int agp_set_lag_tables(agp_ctx* c, int32_t on) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   c->lag_enable = on != 0;
+  c->toeplitz = on >= 3 ? 2 : on >= 2 ? 1 : 0;
+  return AGP_OK;
+}
+
+int agp_get_toeplitz_stats(agp_ctx* c, int64_t* n_particles) {
+  if (!c || !n_particles) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  *n_particles = c->n_toeplitz_value;
   return AGP_OK;
 }
 

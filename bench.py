@@ -198,6 +198,36 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
                                "steps": reps, "logpdf": lp_gen}
     except Exception as e:      # noqa: BLE001
         out["general_path"] = {"error": str(e)[:300]}
+    # ---- opt-in structured value sweep (agp_set_lag_tables(ctx, 2)): Toeplitz + rank-2 particles by the Schur algorithm ----
+    try:
+        e4 = pkg.GPEngine(device)
+        e4.set_lag_tables(2)
+        e4.set_data(ts, xs)
+        e4.logpdf_batch(None, noises, n=n, check=False, programs=programs)
+        k0 = e4.toeplitz_particles()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lp_s, info_s = e4.logpdf_batch(None, noises, n=n, check=False, programs=programs)
+        dt = (time.perf_counter() - t0) / reps
+        k_s = (e4.toeplitz_particles() - k0) // reps
+        e4.close()
+        # the dense sweep through the same host-output entry
+        eng.logpdf_batch(None, noises, n=n, check=False, programs=programs)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            lp_d, info_d = eng.logpdf_batch(None, noises, n=n, check=False, programs=programs)
+        dt_d = (time.perf_counter() - t0) / reps
+        okp = (info_s == 0) & (info_d == 0)
+        out["structured_sweep"] = {
+            "what": "OPT-IN (AGP_LAG=2, off by default; NOT the headline): on the regular grid the particles whose kernel is a sum of stationary "
+                    "subtrees and Linear leaves are Toeplitz + rank 2 in sorted order and are scored by the Schur algorithm (O(n^2), no "
+                    "factorisation; k_toep_logpdf), the others by the dense sweep, in one agp_logpdf_batch call with host outputs",
+            "evals_per_s": P / dt, "ms_per_sweep": dt * 1e3, "particles_through_schur": int(k_s), "particles": P,
+            "dense_same_entry_ms_per_sweep": dt_d * 1e3, "info_equal": bool(np.array_equal(info_s, info_d)),
+            "max_rel_diff_vs_dense": float(np.max(np.abs(lp_s[okp] - lp_d[okp]) / np.maximum(1.0, np.abs(lp_d[okp])))) if okp.any() else None}
+    except Exception as e:      # noqa: BLE001
+        out["structured_sweep"] = {"error": str(e)[:300]}
     # ---- value + gradient sweep (agp_logpdf_grad_batch): Cholesky, L^-T, K^-1 tiles, per-element reverse sweep of the programs ----
     try:
         eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)

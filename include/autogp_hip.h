@@ -157,6 +157,19 @@ int agp_set_factor_cache(agp_ctx* ctx, int32_t on);
 int agp_get_lag_stats(agp_ctx* ctx, int32_t* regular_grid, int64_t* n_lag_sweeps);
 int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
 
+/* OPT-IN structured value sweep (AGP_LAG=2 / agp_set_lag_tables(ctx, 2); off by default: the default path mirrors the reference's
+ * dense Cholesky, src/Model.jl:134-136).  On the sorted copy of a regular grid a kernel that is a sum of stationary subtrees and
+ * Linear leaves gives K = T + U C U' — T symmetric Toeplitz, U = [1, t], C 2x2 — and log N(x; 0, K) follows from log|T| and
+ * L^-1 [x, 1, t] (T = L L') by the matrix determinant lemma and Woodbury's identity.  The Schur algorithm generates L column by
+ * column from the generators of T's displacement (a hyperbolic rotation and a shift per column) without ever storing it: O(n^2)
+ * flops per particle instead of n^3/3, stable for positive definite T.  Applies to agp_logpdf_batch with host outputs over the
+ * WHOLE series (n == n_max <= 4096); the other particles of the call, and any particle the structured sweep refuses (a reflection
+ * coefficient of modulus >= 1: not positive definite to rounding), take the dense path, which also supplies LAPACK's info.
+ * Taken when the class's share of the dense sweep would cost more than the recursion's n sequential steps (level 3 / AGP_LAG=3:
+ * always).  Agreement with the dense path: <= 1e-10 of |logpdf| (tests/test_gpu_lag.py).  agp_get_toeplitz_stats counts the
+ * particles scored that way. */
+int agp_get_toeplitz_stats(agp_ctx* ctx, int64_t* n_particles);
+
 /* Every OTHER sweep of agp_logpdf_batch{,_device,_multi} / agp_logpdf_grad_batch over (a prefix of) a regular grid of up to 4096
  * points — the annealing prefixes n < n_max of src/inference_smc_anneal_data.jl:206-217, the factorisation of a gradient sweep —
  * keeps the caller's order and reads the same stationary subtrees from RANK tables: |t_a - t_b| = |rank_a - rank_b| h whatever

@@ -356,6 +356,67 @@ def test_predictive_lattice_pass_reuses_resident_factors(pkg):
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("case", ["population_2048", "shapes_300", "n4096", "refused", "irregular", "prefix"])
+def test_structured_value_sweep(pkg, case):
+    """Opt-in structured value sweep (agp_set_lag_tables(ctx, 2) / AGP_LAG=2; csrc/agp_toep_kernel.hpp): on a regular grid the
+    particles whose kernel is a sum of stationary subtrees and Linear leaves are scored by the Schur algorithm on T + U C U'
+    (no factorisation), the others densely in the same call.  Against the dense engine (1e-10 of |logpdf|) and the oracle
+    (src/Model.jl:134-136 restated, 1e-8); a matrix that is not positive definite is refused and handed to the dense path, whose
+    info (LAPACK's, caller's order) the call returns; irregular series and prefixes take the dense path."""
+    G = pkg
+    level = 3
+    if case == "population_2048":
+        n_max = n = 2048; level = 2          # (the class is large enough for the heuristic)
+        nodes, nz = pkg.prior.sample_particles(np.random.default_rng(31), 160, max_depth=-1, max_size=31)
+        ts, xs = pkg.prior.synthetic_series(n_max, seed=13, shuffle=True)
+    elif case == "n4096":
+        n_max = n = 4096
+        nodes, nz = pkg.prior.sample_particles(np.random.default_rng(32), 24, max_depth=3)
+        ts, xs = pkg.prior.synthetic_series(n_max, seed=14, shuffle=False)
+    else:
+        n_max = n = 300
+        covered, elementwise, n_poly = _grad_shapes(G)
+        nodes = covered + elementwise; nz = np.linspace(0.02, 0.3, len(nodes))
+        ts, xs = pkg.prior.synthetic_series(n_max, seed=15, shuffle=True)
+        if case == "refused":
+            nodes = [G.SquaredExponential(5.0, 1.0), G.SquaredExponential(0.1, 1.0) + G.Linear(0.2, 0.1, 1.0), G.Linear(0.3, 0.2, 0.5)]
+            nz = np.array([0.0, 0.05, 0.1]); n_max = n = 256
+            ts, xs = pkg.prior.synthetic_series(n_max, seed=11, shuffle=True)
+        elif case == "irregular":
+            ts = ts.copy(); ts[7] += 3e-4
+        elif case == "prefix":
+            n = 250
+    a = G.GPEngine(0); b = G.GPEngine(0)
+    try:
+        a.set_lag_tables(level)
+        a.set_data(ts, xs); b.set_data(ts, xs)
+        la, ia = a.logpdf_batch(nodes, nz, n=n, check=False)
+        lb, ib = b.logpdf_batch(nodes, nz, n=n, check=False)
+        k = a.toeplitz_particles()
+        assert b.toeplitz_particles() == 0
+        if case in ("irregular", "prefix"):
+            assert k == 0
+        elif case == "refused":
+            assert k == 2 and ia[0] > 0 and np.isnan(la[0])          # (particle 0 went to the dense path)
+        elif case == "shapes_300":
+            assert k == len(covered) - n_poly
+        else:
+            assert k >= len(nodes) // 2
+        assert np.array_equal(ia, ib)
+        ok = ia == 0
+        assert lp_err(la[ok], lb[ok]).max() <= 1e-10
+        if n <= 2048:
+            sel = np.flatnonzero(ok)[:48]
+            ref, rinfo = F.gp_logpdf_many(pkg.encode_batch([nodes[i] for i in sel]), np.asarray(nz)[sel], ts[:n], xs[:n])
+            both = rinfo == 0
+            assert lp_err(la[sel][both], ref[both]).max() <= LP_TOL
+        # the same call again: nothing is cached, same bits
+        la2, ia2 = a.logpdf_batch(nodes, nz, n=n, check=False)
+        assert np.array_equal(la[ok], la2[ok]) and np.array_equal(ia, ia2)
+    finally:
+        a.close(); b.close()
+
+
 def test_lag_path_non_positive_definite_info(pkg):
     """A matrix that is not positive definite: the lag sweep flags it, and the info it hands back is LAPACK's for the caller's
     order of the observations (the reference raises PosDefException(info) with that index)."""
