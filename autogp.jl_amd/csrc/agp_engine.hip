@@ -757,7 +757,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         }
       }
       if (g.n_ops > 0 && cov[g.n_ops - 1]) { g.flags |= GFLAG_LAGDOM | (use_toep ? GFLAG_LAGTOEP : use_fft ? GFLAG_LAGFFT : 0); ++n_cov; ++n_sum; }
-      else if (g.n_ops > 0 && c->grad_lagdom >= 2 && deg[g.n_ops - 1] >= 1 && deg[g.n_ops - 1] <= 2 &&
+      else if (g.n_ops > 0 && c->grad_lagdom >= 2 && deg[g.n_ops - 1] >= 1 && deg[g.n_ops - 1] <= 3 &&
                (2 * deg[g.n_ops - 1] + 1) * c->n_max + 8 <= NB2) {
         // Linear leaves inside products: moment histograms of G over the lags (k_kinv_tiles), (2d+1) n virtual elements (k_lag_grad)
         g.flags |= GFLAG_LAGPOLY | ((int)deg[g.n_ops - 1] << GFLAG_POLY_DEG_SHIFT); ++n_cov;
@@ -1132,7 +1132,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
               // polynomial particles: behind the K^-1 tiles' moment histograms
               HIPCHK(c, hipStreamWaitEvent(qs[3], s->gq_ev[3], 0));
               GradArgs gp = ga; gp.plist = d_pl + Pe;
-              const size_t ldsp = sizeof(double) * (5 * (size_t)c->n_max + 40 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
+              const size_t ldsp = sizeof(double) * (7 * (size_t)c->n_max + 40 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
               launch_lag_grad(qs[3], Pn - Pe, ldsp, gp);
               HIPCHK(c, hipGetLastError());
             }

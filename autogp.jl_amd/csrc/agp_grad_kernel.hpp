@@ -982,6 +982,20 @@ __global__ __launch_bounds__(256, 2) void k_toep_solve(GradArgs a) {
   }
 }
 
+// monomial coefficients a_jk of the Lagrange basis polynomials of 2d+1 equally spaced nodes in [-1, 1] (polynomial particles of
+// k_lag_grad: d = 1, 2, 3)
+static __device__ __constant__ double c_LB1[3][3] = {{0.0, -0.5, 0.5}, {1.0, 0.0, -1.0}, {0.0, 0.5, 0.5}};
+static __device__ __constant__ double c_LB2[5][5] = {{0.0, 1.0 / 6.0, -1.0 / 6.0, -2.0 / 3.0, 2.0 / 3.0}, {0.0, -4.0 / 3.0, 8.0 / 3.0, 4.0 / 3.0, -8.0 / 3.0},
+                            {1.0, 0.0, -5.0, 0.0, 4.0}, {0.0, 4.0 / 3.0, 8.0 / 3.0, -4.0 / 3.0, -8.0 / 3.0},
+                            {0.0, -1.0 / 6.0, -1.0 / 6.0, 2.0 / 3.0, 2.0 / 3.0}};
+static __device__ __constant__ double c_LB3[7][7] = {{0.0, -1.0 / 20.0, 1.0 / 20.0, 9.0 / 16.0, -9.0 / 16.0, -81.0 / 80.0, 81.0 / 80.0},
+                            {0.0, 9.0 / 20.0, -27.0 / 40.0, -9.0 / 2.0, 27.0 / 4.0, 81.0 / 20.0, -243.0 / 40.0},
+                            {0.0, -9.0 / 4.0, 27.0 / 4.0, 117.0 / 16.0, -351.0 / 16.0, -81.0 / 16.0, 243.0 / 16.0},
+                            {1.0, 0.0, -49.0 / 4.0, 0.0, 63.0 / 2.0, 0.0, -81.0 / 4.0},
+                            {0.0, 9.0 / 4.0, 27.0 / 4.0, -117.0 / 16.0, -351.0 / 16.0, 81.0 / 16.0, 243.0 / 16.0},
+                            {0.0, -9.0 / 20.0, -27.0 / 40.0, 9.0 / 2.0, 27.0 / 4.0, -81.0 / 20.0, -243.0 / 40.0},
+                            {0.0, 1.0 / 20.0, 1.0 / 20.0, -9.0 / 16.0, -9.0 / 16.0, 81.0 / 80.0, 81.0 / 80.0}};
+
 // ---- lag-domain contraction: one workgroup per GFLAG_LAGDOM particle.  D_g = fixed-order sum over the particle's tiles of
 // the histograms k_kinv_tiles left in the tile slots; then the reverse-mode pass of the contraction kernel over the n "virtual
 // elements" (t_g, t_0) of the SORTED series with weight D_g — every stationary subtree's parameters; the Linear leaves (children
@@ -1232,10 +1246,6 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
   // Polynomial particles: at lag g the kernel is a polynomial of degree 2d in the pair's midpoint m, so the sum over the pairs at
   // that lag equals a sum over 2d+1 probe midpoints mu x_j (x_j equally spaced in [-1, 1]) with weights w_j = sum_k a_jk D_k[g] / mu^k,
   // a_jk the monomial coefficients of the Lagrange basis polynomial of x_j — (2d+1) n virtual elements (t_ref + m_j +- g h / 2)
-  const double LB1[3][3] = {{0.0, -0.5, 0.5}, {1.0, 0.0, -1.0}, {0.0, 0.5, 0.5}};
-  const double LB2[5][5] = {{0.0, 1.0 / 6.0, -1.0 / 6.0, -2.0 / 3.0, 2.0 / 3.0}, {0.0, -4.0 / 3.0, 8.0 / 3.0, 4.0 / 3.0, -8.0 / 3.0},
-                            {1.0, 0.0, -5.0, 0.0, 4.0}, {0.0, 4.0 / 3.0, 8.0 / 3.0, -4.0 / 3.0, -8.0 / 3.0},
-                            {0.0, -1.0 / 6.0, -1.0 / 6.0, 2.0 / 3.0, 2.0 / 3.0}};
   const double pmu = a.poly_mmax, ipmu = 1.0 / a.poly_mmax;
   const int nv = poly ? nk * a.nbins : a.nbins;
   for (int g0 = 0; g0 < nv; g0 += 256 * E) {
@@ -1250,7 +1260,7 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
         const int j = in ? g / a.nbins : 0, gg = in ? g - j * a.nbins : 0;
         double wsum = 0.0, sc = 1.0;
         for (int k = 0; k < nk; ++k) {
-          wsum = fma((pd == 1 ? LB1[j][k] : LB2[j][k]) * sc, D[k * a.nbins + gg], wsum);
+          wsum = fma((pd == 1 ? c_LB1[j < 3 ? j : 0][k < 3 ? k : 0] : pd == 2 ? c_LB2[j < 5 ? j : 0][k < 5 ? k : 0] : c_LB3[j][k]) * sc, D[k * a.nbins + gg], wsum);
           sc *= ipmu;
         }
         const double mj = pmu * (-1.0 + (double)j / (double)pd), hl = 0.5 * (double)gg * a.grid_h;

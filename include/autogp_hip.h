@@ -197,7 +197,7 @@ int agp_get_lag_predict_stats(agp_ctx* ctx, int64_t* n_passes);
  * are contracted that way: the K^-1 tile kernel bins G by lag instead of writing the tile, and the reverse-mode pass of
  * Gen.choice_gradients' replacement (src/inference_smc_anneal_data.jl:63-67) runs over n lags instead of n^2 elements
  * (Linear leaves: three moments of G).  Same result as the element-wise contraction to rounding.
- * Linear leaves INSIDE products (no ChangePoint; at most d <= 2 of them along any product path; (2d+1) n_max <= 16376): at a
+ * Linear leaves INSIDE products (no ChangePoint; at most d <= 3 of them along any product path; (2d+1) n_max <= 16376): at a
  * fixed lag the kernel is a polynomial of degree 2d in the pair's midpoint m = (t_a + t_b)/2, so the sum over the pairs at that
  * lag equals a sum over 2d+1 probe midpoints with moment-matched weights: the K^-1 tile kernel bins G m^k (k = 0..2d) by lag and
  * the reverse-mode pass runs over (2d+1) n virtual elements.  on = 2 (default; AGP_GRAD_LAGDOM=2) includes this class, 1 leaves it

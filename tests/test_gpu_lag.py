@@ -439,9 +439,11 @@ def _grad_shapes(G):
     lin, lin2, cst, wn = G.Linear(0.3, 0.2, 0.7), G.Linear(-0.4, 0.1, 0.5), G.Constant(0.4), G.WhiteNoise(0.05)
     covered = [se, ge, per, cst + wn, per * se, per * se + ge, lin, lin + ge, ge + lin, lin + lin2, (lin + per * se) + (ge + lin2),
                cst * per + wn]
-    # Linear leaves inside products: moment histograms over the lags, (2d+1) n virtual elements (d = 1, 2)
-    poly = [lin * se, lin * lin2, (lin + se) * per, se + lin * ge, (lin * per) * (lin2 + se) + wn, cst * lin + ge * lin2]
-    elementwise = [G.ChangePoint(se, per, 0.5, 0.05), lin * lin2 * G.Linear(0.1, 0.3, 0.4), G.ChangePoint(lin, se, 0.4, 0.02) + ge]
+    # Linear leaves inside products: moment histograms over the lags, (2d+1) n virtual elements (d = 1, 2, 3)
+    lin3 = G.Linear(0.1, 0.3, 0.4)
+    poly = [lin * se, lin * lin2, (lin + se) * per, se + lin * ge, (lin * per) * (lin2 + se) + wn, cst * lin + ge * lin2, lin * lin2 * lin3,
+            (lin * se + lin2) * (lin3 * per) * lin]
+    elementwise = [G.ChangePoint(se, per, 0.5, 0.05), lin * lin2 * lin3 * lin, G.ChangePoint(lin, se, 0.4, 0.02) + ge]
     return covered + poly, elementwise, len(poly)
 
 

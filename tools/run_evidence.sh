@@ -12,6 +12,8 @@ python tools/run_configs.py ${TAG} 2>&1 | grep -v amdgpu | tail -8
 FLOW_MODES=cols,flow python tools/gpu_flow_perf.py 2048x8 2048x16 2048x32 2048x64 2048x128 2048x256 2048x384 2048x512 1024x64 1024x128 512x256 4096x32 4096x128 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_flow_perf.txt; tail -3 gpurun_out/${TAG}_flow_perf.txt
 python tools/gpu_extend_perf.py ${TAG} 2>&1 | grep -v amdgpu | tail -4
 python tools/gpu_grad_perf.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_perf.txt; cat gpurun_out/${TAG}_grad_perf.txt
+# opt-in structured value sweep (Schur algorithm) against the dense sweep: bench population, config 4's shape, kernel statistics
+(python tools/gpu_toeplitz_sweep.py; python tools/gpu_toeplitz_sweep.py 4096 128) 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_toeplitz_sweep.txt; cat gpurun_out/${TAG}_toeplitz_sweep.txt
 # gradient sweep: lag-domain contraction on / off (spans of the sweep's kernels), then with the histogram instead of the spectra
 (python tools/gpu_grad_lagdom_ab.py; AGP_GRAD_FFT=0 python tools/gpu_grad_lagdom_ab.py | head -1) 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_lagdom_ab.txt; head -2 gpurun_out/${TAG}_grad_lagdom_ab.txt
 python tools/gpu_grad_lagdom_check.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_lagdom_check.txt; tail -1 gpurun_out/${TAG}_grad_lagdom_check.txt

@@ -10,3 +10,4 @@ prof grad python $R/tools/gpu_grad_perf.py 2048x512
 prof predict python $R/tools/gpu_predict_perf.py 2048:2048:128
 prof extend python $R/tools/gpu_extend_profile.py 512
 prof stream python $R/tools/run_stream.py --rejuvenate --predict
+prof toeplitz python $R/tools/gpu_toeplitz_sweep.py
