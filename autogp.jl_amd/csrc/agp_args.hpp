@@ -54,6 +54,13 @@ struct ToepArgs {
   double grid_h, grid_mid, tref;
   double* out_lp;            // [P] (sorted particle order)
   int32_t* out_info;         // [P] 0, or 1: refused (the host repeats the particle on the dense path)
+  int rank0;                 // rank of the sweep's first point in time (xs already points there; t - t_ref = (rank0 + j - grid_mid) h)
+  // gradient sweeps (STORE instantiations / k_toep_back): the columns of L, packed (column k at k n - k (k - 1) / 2, rows k .. n-1),
+  // the forward-solved right-hand sides L^-1 [x, e_first, 1, t - t_ref] and the solutions T^-1 [...] (sorted coordinates)
+  double* Lcols; long long Lstride;
+  double* fwd;               // [P][4][ldv]
+  double* sol;               // [P][4][ldv]
+  int ldv;
 };
 
 struct CholArgs {
@@ -204,6 +211,9 @@ constexpr int GFLAG_LAGTOEP = 8;
                       // sum_ab G_ab dK_ab = sum over lags and 2d+1 probe midpoints of [moment-matched weights] x dK(probe):
                       // k_kinv_tiles bins G m^k (k = 0..2d) by lag, k_lag_grad differentiates (2d+1) n virtual elements
 constexpr int GFLAG_LAGPOLY = 16;
+                      // bit 5 (with bits 1, 3): tsol holds T^-1 [x, e_first, 1, t - t_ref] in SORTED coordinates (structured gradient sweep:
+                      // Schur recursion + backward substitution, no dense factor): no downdate, alpha is formed in k_lag_grad
+constexpr int GFLAG_LAGTSOL = 32;
 constexpr int GFLAG_POLY_DEG_SHIFT = 8;
 constexpr int LAGDOM_MAX_BINS = 4096;      // LDS histogram of k_kinv_tiles (32 KiB)
 constexpr int FFT_N = 4096;                // transform length of the spectral variant: series of up to FFT_N / 2 points

@@ -637,7 +637,133 @@ static int toeplitz_sweep(agp_ctx* c, int64_t n, int P, const int32_t* op_off, c
   return AGP_OK;
 }
 
+// Structured GRADIENT sweep of the same class (consecutive grid points rank0 .. rank0 + n - 1, n <= 2048): the recursion also stores
+// the columns of L and the forward-solved right-hand sides, a backward substitution turns them into T^-1 [x, e_first, 1, t], and
+// k_lag_grad (GFLAG_LAGTSOL) forms alpha, the lag sums of K^-1 (Gohberg-Semencul + W S W') and the gradient — no dense factor.
+// Outputs in the sub-batch's order; info 1 = refused.
+static int toeplitz_grad_sweep(agp_ctx* c, int64_t n, int32_t rank0, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
+                               const double* prm, const double* noise, double* out_lp, int32_t* out_info, double* out_grad,
+                               double* out_gnoise) {
+  Batch bt;
+  const int rank_units = (int)((c->n_max + 255) / 256);
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, true, false, false, false, true, rank_units, true);
+  if (rc) return rc;
+  if (bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
+  for (int q = 0; q < P; ++q) bt.ghdr[q].flags |= GFLAG_LAGDOM | GFLAG_LAGTOEP | GFLAG_LAGTSOL;
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+  auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_tprm = al16(sizeof(LagTabHdr) * bt.thdr.size());
+  const size_t o_tops = al16(o_tprm + sizeof(double) * bt.tprm.size());
+  const size_t prog_bytes = al16(o_tops + bt.tops.size() + 4);
+  std::vector<char> hp(prog_bytes, 0);
+  if (!bt.thdr.empty()) {
+    std::memcpy(hp.data(), bt.thdr.data(), sizeof(LagTabHdr) * bt.thdr.size());
+    std::memcpy(hp.data() + o_tprm, bt.tprm.data(), sizeof(double) * bt.tprm.size());
+    std::memcpy(hp.data() + o_tops, bt.tops.data(), bt.tops.size());
+  }
+  const int n_pad = round_up(n, NB);
+  const int n_prm_total = prm_off[P];
+  std::vector<double> nz((size_t)P);
+  std::vector<int32_t> goff((size_t)P), plist((size_t)P);
+  for (int q = 0; q < P; ++q) { nz[(size_t)q] = noise[bt.order[q]]; goff[(size_t)q] = prm_off[bt.order[q]]; plist[(size_t)q] = q; }
+  const long long Lstride = (long long)n * (n + 1) / 2;
+  const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(P, ws_limit_bytes(c) / (Lstride * 8)));
+  HIPCHK(c, s->hdr.ensure(sizeof(ProgHdr) * (size_t)P));
+  HIPCHK(c, s->ops.ensure(bt.ops.size() + 4));
+  HIPCHK(c, s->prm.ensure(sizeof(double) * std::max<size_t>(1, bt.prm.size())));
+  HIPCHK(c, s->noise.ensure(sizeof(double) * (size_t)P));
+  HIPCHK(c, s->pl_prog.ensure(prog_bytes));
+  HIPCHK(c, s->out_lp.ensure(sizeof(double) * (size_t)P + sizeof(int32_t) * (size_t)P));
+  HIPCHK(c, s->A.ensure((size_t)Lstride * 8 * chunk));
+  HIPCHK(c, s->tsol.ensure(sizeof(double) * 4 * (size_t)n_pad * chunk));
+  HIPCHK(c, s->alpha.ensure(sizeof(double) * 4 * (size_t)n_pad * chunk));          // forward-solved right-hand sides
+  HIPCHK(c, s->ghdr.ensure(sizeof(GProgHdr) * (size_t)P));
+  HIPCHK(c, s->gops.ensure(bt.gops.size() + 4)); HIPCHK(c, s->glc.ensure(bt.glc.size() + 4)); HIPCHK(c, s->grc.ensure(bt.grc.size() + 4));
+  HIPCHK(c, s->gpoff.ensure(sizeof(int32_t) * (bt.gpoff.size() + 1)));
+  HIPCHK(c, s->gprm.ensure(sizeof(double) * bt.gprm.size()));
+  HIPCHK(c, s->gmap.ensure(sizeof(int32_t) * (bt.gmap.size() + 1)));
+  HIPCHK(c, s->goff.ensure(sizeof(int32_t) * (size_t)P));
+  HIPCHK(c, s->map.ensure(sizeof(int32_t) * (size_t)P));
+  HIPCHK(c, s->plist.ensure(sizeof(int32_t) * (size_t)P));
+  HIPCHK(c, s->dgrad.ensure(sizeof(double) * (size_t)std::max(1, n_prm_total)));
+  HIPCHK(c, s->dgnoise.ensure(sizeof(double) * (size_t)P));
+  HIPCHK(c, s->tretry.ensure(sizeof(int32_t) * (size_t)P));
+  PinnedUploads up;
+  up.add(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr) * (size_t)P);
+  up.add(s->ops.p, bt.ops.data(), bt.ops.size());
+  up.add(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size());
+  up.add(s->noise.p, nz.data(), sizeof(double) * (size_t)P);
+  up.add(s->pl_prog.p, hp.data(), prog_bytes);
+  up.add(s->ghdr.p, bt.ghdr.data(), sizeof(GProgHdr) * (size_t)P);
+  up.add(s->gops.p, bt.gops.data(), bt.gops.size());
+  up.add(s->glc.p, bt.glc.data(), bt.glc.size());
+  up.add(s->grc.p, bt.grc.data(), bt.grc.size());
+  up.add(s->gpoff.p, bt.gpoff.data(), sizeof(int32_t) * bt.gpoff.size());
+  up.add(s->gprm.p, bt.gprm.data(), sizeof(double) * bt.gprm.size());
+  up.add(s->gmap.p, bt.gmap.data(), sizeof(int32_t) * bt.gmap.size());
+  up.add(s->goff.p, goff.data(), sizeof(int32_t) * (size_t)P);
+  up.add(s->map.p, bt.order.data(), sizeof(int32_t) * (size_t)P);
+  up.add(s->plist.p, plist.data(), sizeof(int32_t) * (size_t)P);
+  HIPCHK(c, up.flush(s->h_stage, st));
+  HIPCHK(c, hipMemsetAsync(s->dgrad.p, 0, sizeof(double) * (size_t)std::max(1, n_prm_total), st));
+  HIPCHK(c, hipMemsetAsync(s->dgnoise.p, 0, sizeof(double) * (size_t)P, st));
+  const int stride = rank_units * 256;
+  if (bt.n_lag_tables > 0) {
+    HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * stride));
+    LagArgs la = {};
+    la.tt = c->d_ts_s; la.thdr = s->pl_prog.as<LagTabHdr>();
+    la.tprm = reinterpret_cast<const double*>(static_cast<char*>(s->pl_prog.p) + o_tprm);
+    la.tops = reinterpret_cast<const uint8_t*>(static_cast<char*>(s->pl_prog.p) + o_tops);
+    la.n_tables = bt.n_lag_tables; la.tab = s->lagtab.as<double>();
+    la.nt = (int)((c->n_max + NB - 1) / NB); la.full = 1; la.stride = stride;
+    launch_lag_tables(st, la, rank_units, bt.n_lag_tables);
+    HIPCHK(c, hipGetLastError());
+  } else {
+    HIPCHK(c, s->lagtab.ensure(sizeof(double) * 16));
+  }
+  for (int p0 = 0; p0 < P; p0 += chunk) {
+    const int Pc = std::min(chunk, P - p0);
+    ToepArgs ta = {};
+    ta.xs = c->d_xs_s + rank0; ta.n = (int)n; ta.P = Pc; ta.rank0 = rank0;
+    ta.hdr = s->hdr.as<ProgHdr>() + p0; ta.ops = s->ops.as<uint8_t>(); ta.prm = s->prm.as<double>(); ta.noise = s->noise.as<double>() + p0;
+    ta.lagtab = s->lagtab.as<double>(); ta.lag_stride = stride;
+    ta.grid_h = c->grid_h; ta.grid_mid = c->grid_mid; ta.tref = c->t_ref;
+    ta.out_lp = s->out_lp.as<double>() + p0; ta.out_info = reinterpret_cast<int32_t*>(s->out_lp.as<double>() + P) + p0;
+    ta.Lcols = s->A.as<double>(); ta.Lstride = Lstride; ta.fwd = s->alpha.as<double>(); ta.sol = s->tsol.as<double>(); ta.ldv = n_pad;
+    HIPCHK(c, launch_toep_logpdf(st, ta));
+    GradArgs ga = {};
+    ga.A = s->A.as<double>(); ga.strideA = Lstride; ga.alpha = s->alpha.as<double>(); ga.tsol = s->tsol.as<double>(); ga.ldv = n_pad;
+    ga.P = Pc; ga.nt = n_pad / NB; ga.n = (int)n;
+    ga.ghdr = s->ghdr.as<GProgHdr>() + p0; ga.gops = s->gops.as<uint8_t>(); ga.glc = s->glc.as<uint8_t>(); ga.grc = s->grc.as<uint8_t>();
+    ga.gpoff = s->gpoff.as<int32_t>(); ga.gprm = s->gprm.as<double>(); ga.gmap = s->gmap.as<int32_t>();
+    ga.out_off = s->goff.as<int32_t>() + p0; ga.pmap = s->map.as<int32_t>() + p0; ga.plist = s->plist.as<int32_t>();
+    ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
+    ga.rank = c->d_rank; ga.tts = c->d_ts_s; ga.nbins = (int)c->n_max; ga.tref = c->t_ref; ga.tw = c->d_fft_tw; ga.grid_h = c->grid_h; ga.grid_mid = c->grid_mid;
+    ga.rank0 = rank0; ga.noise = s->noise.as<double>() + p0; ga.retry = s->tretry.as<int32_t>(); ga.toep_max_amp = GRAD_TOEP_MAX_AMP;
+    ga.poly_mmax = c->poly_mmax;
+    const size_t lds4 = sizeof(double) * (2 * (size_t)FFT_BUF + (size_t)c->n_max + 40 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
+    launch_lag_grad(st, Pc, lds4, ga);
+    HIPCHK(c, hipGetLastError());
+  }
+  const size_t out_bytes = sizeof(double) * (size_t)P + sizeof(int32_t) * (size_t)P;
+  HIPCHK(c, s->h_out.ensure(out_bytes));
+  HIPCHK(c, hipMemcpyAsync(s->h_out.p, s->out_lp.p, out_bytes, hipMemcpyDeviceToHost, st));
+  if (n_prm_total > 0) HIPCHK(c, hipMemcpyAsync(out_grad, s->dgrad.p, sizeof(double) * (size_t)n_prm_total, hipMemcpyDeviceToHost, st));
+  std::vector<double> gn((size_t)P);
+  HIPCHK(c, hipMemcpyAsync(gn.data(), s->dgnoise.p, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  const double* hl = static_cast<const double*>(s->h_out.p);
+  const int32_t* hi = reinterpret_cast<const int32_t*>(hl + P);
+  for (int q = 0; q < P; ++q) { out_lp[bt.order[q]] = hl[q]; out_info[bt.order[q]] = hi[q]; }
+  for (int b = 0; b < P; ++b) out_gnoise[b] = gn[(size_t)b];          // (k_lag_grad writes out_gnoise[pmap[p]]: the sub-batch's order)
+  return AGP_OK;
+}
+
 static thread_local bool tl_in_toeplitz = false;
+static thread_local bool tl_in_tgrad = false;
 
 // (set around the repeat of particles whose Toeplitz downdate was rejected: the nested sweep takes L^-T for them)
 static thread_local bool tl_no_toep = false;
@@ -779,6 +905,68 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         // Linear leaves inside products: moment histograms of G over the lags (k_kinv_tiles), (2d+1) n virtual elements (k_lag_grad)
         g.flags |= GFLAG_LAGPOLY | ((int)deg[g.n_ops - 1] << GFLAG_POLY_DEG_SHIFT); ++n_cov;
       }
+    }
+    // Structured gradient sweep: with no factor resident anywhere, the Toeplitz class needs no dense factorisation at all
+    // (toeplitz_grad_sweep: Schur recursion + backward substitution + k_lag_grad); it runs beside the dense sweep of the others.
+    // (it pays when the class's share of the dense factorisation costs more than the ~2.2 us per point of the two sequential passes)
+    const bool struct_pays = c->grad_struct >= 2 || 50.0 * (double)n_sum * std::pow((double)n / 2048.0, 3.0) > 1.5 * 2.2 * (double)n;
+    if (use_toep && n_sum > 0 && struct_pays && n <= 2048 && !tl_in_tgrad && !tl_no_toep && !c->profiling && c->grad_struct &&
+        h_out_lp && !d_user_lp && !d_user_info && !use_user_stream && !(c->factor_cache && c->store.n_slots > 0)) {
+      std::vector<int> part[2];
+      for (int q = 0; q < P; ++q) part[(bt.ghdr[q].flags & GFLAG_LAGTOEP) ? 1 : 0].push_back(bt.order[q]);
+      struct Sub { std::vector<int32_t> oo, po, info; std::vector<uint8_t> so; std::vector<double> sp, nz, lp, grad, gn; int rc = 0; } sT, sD;
+      auto gather = [&](const std::vector<int>& ix, Sub& S) {
+        S.oo.assign(ix.size() + 1, 0); S.po.assign(ix.size() + 1, 0); S.nz.resize(ix.size()); S.so.clear(); S.sp.clear();
+        for (size_t b = 0; b < ix.size(); ++b) {
+          const int p = ix[b];
+          S.so.insert(S.so.end(), ops + op_off[p], ops + op_off[p + 1]);
+          S.sp.insert(S.sp.end(), prm + prm_off[p], prm + prm_off[p + 1]);
+          S.oo[b + 1] = (int32_t)S.so.size(); S.po[b + 1] = (int32_t)S.sp.size(); S.nz[b] = noise[p];
+        }
+        S.grad.assign(std::max<size_t>(1, S.sp.size()), 0.0);
+        if (S.sp.empty()) S.sp.push_back(0.0);
+        S.lp.assign(ix.size(), 0.0); S.gn.assign(ix.size(), 0.0); S.info.assign(ix.size(), 0);
+      };
+      auto scatter = [&](const std::vector<int>& ix, const Sub& S, std::vector<int>* refused) {
+        for (size_t b = 0; b < ix.size(); ++b) {
+          const int p = ix[b];
+          if (refused && S.info[b] != 0) { refused->push_back(p); continue; }
+          h_out_lp[p] = S.lp[b];
+          if (h_out_info) h_out_info[p] = S.info[b];
+          std::copy(S.grad.begin() + S.po[b], S.grad.begin() + S.po[b + 1], go->grad + prm_off[p]);
+          go->gnoise[p] = S.gn[b];
+        }
+      };
+      auto dense = [&](const std::vector<int>& ix) {
+        if (ix.empty()) return 0;
+        gather(ix, sD);
+        GradOut dgo{sD.grad.data(), sD.gn.data()};
+        tl_in_tgrad = true;
+        const int rc0 = logpdf_batch_impl(c, n, (int)ix.size(), sD.oo.data(), sD.so.data(), sD.po.data(), sD.sp.data(), sD.nz.data(), sD.lp.data(),
+                                          sD.info.data(), nullptr, nullptr, nullptr, false, &dgo, allow_lag);
+        tl_in_tgrad = false;
+        if (rc0) return rc0;
+        scatter(ix, sD, nullptr);
+        return 0;
+      };
+      gather(part[1], sT);
+      std::thread side([&] {
+        sT.rc = toeplitz_grad_sweep(c, n, toep_rank0, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(), sT.sp.data(), sT.nz.data(),
+                                    sT.lp.data(), sT.info.data(), sT.grad.data(), sT.gn.data());
+      });
+      const int rcD = dense(part[0]);
+      side.join();
+      if (lagr) { std::lock_guard<std::mutex> g(c->mu); if (!part[0].empty()) --c->n_lag_rank_sweeps; }          // (one sweep, as far as the counters go)
+      if (rcD) return rcD;
+      if (sT.rc) return sT.rc;
+      std::vector<int> refused;
+      scatter(part[1], sT, &refused);
+      {
+        std::lock_guard<std::mutex> g(c->mu);
+        const int64_t done = (int64_t)part[1].size() - (int64_t)refused.size();
+        c->n_lagdom_particles += done; c->n_toep_particles += done; c->n_struct_grad += done;
+      }
+      return dense(refused);
     }
     std::lock_guard<std::mutex> g(c->mu);
     c->n_lagdom_particles += n_cov;
@@ -1341,7 +1529,7 @@ int agp_init(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_LAG")) { c->lag_enable = atoi(e) != 0; c->toeplitz = atoi(e) >= 3 ? 2 : atoi(e) >= 2 ? 1 : 0; }
   if (const char* e = getenv("AGP_LAG_RANK")) c->lag_rank_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LAGDOM")) c->grad_lagdom = std::max(0, std::min(2, atoi(e)));
-  if (const char* e = getenv("AGP_GRAD_FFT")) c->grad_fft = std::max(0, std::min(2, atoi(e)));
+  if (const char* e = getenv("AGP_GRAD_FFT")) { c->grad_fft = std::max(0, std::min(2, atoi(e))); c->grad_struct = atoi(e) >= 4 ? 2 : atoi(e) >= 3 ? 1 : 0; }
   if (const char* e = getenv("AGP_RIGHT_LOOKING")) c->right_looking = atoi(e);
   if (const char* e = getenv("AGP_DEDUP")) c->dedup = atoi(e) != 0;
   if (const char* e = getenv("AGP_PREDICT_REUSE")) c->predict_reuse = atoi(e) != 0;

@@ -1042,12 +1042,18 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
     d2* buf = reinterpret_cast<d2*>(smem);
     double* fred = D + a.nbins;      // behind D: 40 doubles (host sizes the LDS for them)
     const d2* __restrict__ tw = reinterpret_cast<const d2*>(a.tw);
-    const double* __restrict__ al = a.alpha + (long long)p * a.ldv;
-    const double* __restrict__ k0 = a.tsol + (long long)p * 3 * a.ldv;
+    // T-solve mode (GFLAG_LAGTSOL; structured gradient sweep): the four vectors are T^-1 [x, e_first, 1, t - t_ref] in SORTED
+    // coordinates — no dense factor behind them, nothing to downdate: K^-1 = T^-1 - W S W' (S = C (I + N C)^-1, N = U'W) and
+    // alpha = T^-1 x - W S U'T^-1 x are formed here
+    const bool tsm = (h.flags & GFLAG_LAGTSOL) != 0;
+    const double* __restrict__ al = tsm ? a.tsol + (long long)p * 4 * a.ldv : a.alpha + (long long)p * a.ldv;
+    const double* __restrict__ k0 = tsm ? al + a.ldv : a.tsol + (long long)p * 3 * a.ldv;
     const double* __restrict__ v1 = k0 + a.ldv;
     const double* __restrict__ vt = v1 + a.ldv;
+    auto uidx = [&](int ga) { return tsm ? ga : a.rank[ga] - a.rank0; };          // position in the sorted sweep
+    auto tauf = [&](int ga) { return ((double)(tsm ? ga + a.rank0 : a.rank[ga]) - a.grid_mid) * a.grid_h; };
     // a particle of Linear, Constant and WhiteNoise leaves only: T = s2 I exactly (the constants join C), nothing to downdate
-    bool diagc = true;
+    bool diagc = !tsm;
     for (int i = 0; i < h.n_ops; ++i) {
       const int o = a.gops[h.node_off + i];
       diagc = diagc && (o == OP_LIN || o == OP_CONST || o == OP_WN || o == OP_PLUS);
@@ -1055,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
     // nine sums: 1'v1, 1'vt, tau'vt, 1'k0, tau'k0, 1'alpha, tau'alpha, 1'tau, tau'tau
     double sm7[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     for (int ga = tid; ga < a.n; ga += 256) {
-      const double tau = ((double)a.rank[ga] - a.grid_mid) * a.grid_h;
+      const double tau = tauf(ga);
       const double x1 = v1[ga], xt = vt[ga], x0 = k0[ga], xa = al[ga];
       sm7[0] += x1; sm7[1] += xt; sm7[2] = fma(tau, xt, sm7[2]); sm7[3] += x0; sm7[4] = fma(tau, x0, sm7[4]);
       sm7[5] += xa; sm7[6] = fma(tau, xa, sm7[6]); sm7[7] += tau; sm7[8] = fma(tau, tau, sm7[8]);
@@ -1084,7 +1090,22 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
       }
     }
     double M00, M01, M11, Q00, Q01, Q11, w0 = 0.0, w1 = 0.0;
-    if (diagc) {
+    double as0 = 0.0, as1 = 0.0;          // T-solve mode: alpha = T^-1 x - w_1 as0 - w_t as1
+    if (tsm) {
+      const double N00 = sm7[0], N01 = sm7[1], N11 = sm7[2];
+      const double t00 = 1.0 + (N00 * C00 + N01 * C01), t01 = N00 * C01 + N01 * C11;
+      const double t10 = N01 * C00 + N11 * C01, t11 = 1.0 + (N01 * C01 + N11 * C11);
+      const double idet = 1.0 / (t00 * t11 - t01 * t10);
+      const double i00 = t11 * idet, i01 = -t01 * idet, i10 = -t10 * idet, i11 = t00 * idet;
+      const double S00 = C00 * i00 + C01 * i10, S01 = C00 * i01 + C01 * i11, S11 = C01 * i01 + C11 * i11;
+      const double a00 = S00 * N00 + S01 * N01, a01 = S00 * N01 + S01 * N11, a10 = S01 * N00 + S11 * N01, a11 = S01 * N01 + S11 * N11;   // S N
+      M00 = N00 - (N00 * a00 + N01 * a10); M01 = N01 - (N00 * a01 + N01 * a11); M11 = N11 - (N01 * a01 + N11 * a11);
+      Q00 = S00; Q01 = S01; Q11 = S11;
+      as0 = S00 * sm7[5] + S01 * sm7[6]; as1 = S01 * sm7[5] + S11 * sm7[6];          // S U'T^-1 x
+      // sums of alpha from the sums of its parts (1'w_t = tau'w_1 = N01)
+      const double sa = sm7[5] - (N00 * as0 + N01 * as1), ua = sm7[6] - (N01 * as0 + N11 * as1);
+      sm7[5] = sa; sm7[6] = ua;
+    } else if (diagc) {
       // K^-1 = I/s2 - (U/s2) S (U/s2)',  S = C (I + N C)^-1,  N = U'U / s2;  U' K^-1 U = N - N S N
       const double is2 = 1.0 / s2;
       const double N00 = (double)a.n * is2, N01 = sm7[7] * is2, N11 = sm7[8] * is2;
@@ -1119,7 +1140,7 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
     // one transform per vector; this thread's 16 spectrum values (elements tid + 256 j, digit-reversed order, as k_zspec)
     d2 f[16];
     auto transform = [&](auto val) {
-      for (int ga = tid; ga < a.n; ga += 256) buf[fft_pad(a.rank[ga] - a.rank0)].x = val(ga);
+      for (int ga = tid; ga < a.n; ga += 256) buf[fft_pad(uidx(ga))].x = val(ga);
       __syncthreads();
       fft4096_lds<true>(buf, tw, tid);
 #pragma unroll
@@ -1132,13 +1153,13 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
     };
     double P[16], PR[16];
     d2 g1[16];
-    transform([&](int ga) { return al[ga]; });
+    transform([&](int ga) { return tsm ? al[ga] - (v1[ga] * as0 + vt[ga] * as1) : al[ga]; });
 #pragma unroll
     for (int j = 0; j < 16; ++j) P[j] = fma(f[j].x, f[j].x, f[j].y * f[j].y);
     transform([&](int ga) { return diagc ? 1.0 : v1[ga]; });
 #pragma unroll
     for (int j = 0; j < 16; ++j) { g1[j] = f[j]; P[j] = fma(Q00, fma(f[j].x, f[j].x, f[j].y * f[j].y), P[j]); }
-    transform([&](int ga) { return diagc ? ((double)a.rank[ga] - a.grid_mid) * a.grid_h : vt[ga]; });
+    transform([&](int ga) { return diagc ? tauf(ga) : vt[ga]; });
 #pragma unroll
     for (int j = 0; j < 16; ++j)
       P[j] += Q11 * fma(f[j].x, f[j].x, f[j].y * f[j].y) + 2.0 * Q01 * fma(g1[j].x, f[j].x, g1[j].y * f[j].y);
@@ -1147,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
       transform(xv);
 #pragma unroll
       for (int j = 0; j < 16; ++j) { g1[j] = f[j]; PR[j] = fma(f[j].x, f[j].x, f[j].y * f[j].y); }
-      transform([&](int ga) { return (double)(a.rank[ga] - a.rank0) * xv(ga); });
+      transform([&](int ga) { return (double)uidx(ga) * xv(ga); });
       // (u x) conj(x): its transform's real part is N Q_g
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
@@ -1155,7 +1176,7 @@ __global__ __launch_bounds__(256) void k_lag_grad(GradArgs a) {
         g1[j] = t2;
       }
       // x_0: the solution at the first point in time
-      for (int ga = tid; ga < a.n; ga += 256) if (a.rank[ga] == a.rank0) fred[36] = xv(ga);
+      for (int ga = tid; ga < a.n; ga += 256) if (uidx(ga) == 0) fred[36] = xv(ga);
     } else {
 #pragma unroll
       for (int j = 0; j < 16; ++j) { PR[j] = 0.0; g1[j] = d2{0.0, 0.0}; }

@@ -179,6 +179,9 @@ struct agp_ctx {
                                  // and Linear leaves; 2: also Linear leaves inside products, by moment histograms); env AGP_GRAD_LAGDOM
   double poly_mmax = 1.0;        // half the resident series' time range: bound of a pair's midpoint t - t_ref
   int64_t n_lagdom_particles = 0;   // particles contracted in the lag domain so far (agp_get_lag_stats)
+  int64_t n_struct_grad = 0;        // ... of which: no dense factor at all (toeplitz_grad_sweep)
+  int grad_struct = 1;              // structured gradient sweeps for the Toeplitz class when no factor is resident and it pays; env AGP_GRAD_FFT=3
+                                    // (2: always with a dense factor; 4: whenever the class is not empty)
   int64_t n_toep_particles = 0;      // ... of which: lag sums from the Toeplitz solves (k_toep_solve)
   bool lag_ok = false;
   int toeplitz = 0;              // structured value sweeps (Schur algorithm) for the Toeplitz + rank-2 class; env AGP_LAG=2 / agp_set_lag_tables(ctx, 2)

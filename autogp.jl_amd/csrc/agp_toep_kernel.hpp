@@ -26,11 +26,11 @@ namespace agp {
 
 constexpr int TOEP_MAX_R = 16;          // elements per thread: n <= 4096
 
-template <int NR>
+template <int NR, bool STORE = false>
 __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double tsm[];
   double* ul = tsm;                      // [256 NR]  u at position j - k
-  double* piv = tsm + NR * 256;          // 2 x 8: {v_k, x_k, one_k, tau_k} of the coming step
+  double* piv = tsm + NR * 256;          // 2 x 8: {v_k, x_k, one_k, tau_k, e_k} of the coming step
   const int p = blockIdx.x, tid = threadIdx.x;
   const ProgHdr h = a.hdr[p];
   const int n = a.n;
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
   }
   const bool lin = C00 != 0.0 || C01 != 0.0 || C11 != 0.0;
   // first column of T, generators, right-hand sides
-  double v[NR], bx[NR], b1[NR], bt[NR];
+  double v[NR], bx[NR], b1[NR], bt[NR], be[STORE ? NR : 1];
   const double* __restrict__ tab = a.lagtab + (long long)h.lag_off * a.lag_stride;
   double r0 = a.noise[p] + r_all + r_zero;
   for (int li = 0; li < h.n_lag; ++li) r0 += tab[(long long)li * a.lag_stride];
@@ -82,9 +82,12 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
     v[r] = j == 0 ? 0.0 : aj;
     bx[r] = j < n ? a.xs[j] : 0.0;
     b1[r] = j < n ? 1.0 : 0.0;
-    bt[r] = j < n ? ((double)j - a.grid_mid) * a.grid_h : 0.0;
+    bt[r] = j < n ? ((double)(j + a.rank0) - a.grid_mid) * a.grid_h : 0.0;
+    if (STORE) be[r] = j == 0 ? 1.0 : 0.0;
   }
-  if (tid == 0) { piv[0] = 0.0; piv[1] = bx[0]; piv[2] = b1[0]; piv[3] = bt[0]; }
+  if (tid == 0) { piv[0] = 0.0; piv[1] = bx[0]; piv[2] = b1[0]; piv[3] = bt[0]; piv[4] = 1.0; }
+  double* __restrict__ Lc = STORE ? a.Lcols + (long long)p * a.Lstride : nullptr;
+  double* __restrict__ fw = STORE ? a.fwd + (long long)p * 4 * a.ldv : nullptr;
   __syncthreads();
   // pu = L(k-1,k-1) (the shifted generator's pivot; k = 0: sqrt(r0)) and its reciprocal are carried in registers by every thread:
   // L(k,k) = pu (1 - rho^2) c,  1 / L(k,k) = c / pu  (c = (1 - rho^2)^-1/2) — no division and no broadcast on the chain
@@ -110,6 +113,9 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
     const double il = ipu * cs;                     // 1 / L(k,k)
     pu = pu * om * cs; ipu = il;
     const double yx = pk[1] * il, y1 = pk[2] * il, yt = pk[3] * il;      // entries k of L^-1 [x, 1, tau]
+    const double ye = STORE ? pk[4] * il : 0.0;                          // ... and of L^-1 e_first
+    if (STORE && tid == 0) { fw[k] = yx; fw[a.ldv + k] = ye; fw[2 * a.ldv + k] = y1; fw[3 * a.ldv + k] = yt; }
+    const long long coff = STORE ? (long long)k * n - (long long)k * (k - 1) / 2 - k : 0;      // column k, row j at coff + j
     if (w0ave) {
       lprod *= pu;
       if ((k & 7) == 7) { logdet += fm::log_f(lprod); lprod = 1.0; }
@@ -127,10 +133,12 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
         const double vn = cs * (vj - rho * uj);
         ul[j - k] = un;                              // (read next step by the owner of element j + 1)
         v[r] = vn;
+        if (STORE) Lc[coff + j] = un;
         if (j > k) {
           bx[r] = fma(-un, yx, bx[r]);
           if (lin) { b1[r] = fma(-un, y1, b1[r]); bt[r] = fma(-un, yt, bt[r]); }
-          if (j == k + 1) { pn[0] = vn; pn[1] = bx[r]; pn[2] = b1[r]; pn[3] = bt[r]; }
+          if (STORE) be[r] = fma(-un, ye, be[r]);
+          if (j == k + 1) { pn[0] = vn; pn[1] = bx[r]; pn[2] = b1[r]; pn[3] = bt[r]; if (STORE) pn[4] = be[r]; }
         }
       }
     }
@@ -155,6 +163,66 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
       }
       a.out_lp[p] = -0.5 * ((double)n * 1.8378770664093454835606594728112 + ld + qf);
       a.out_info[p] = 0;
+    }
+  }
+}
+
+// Backward substitution L' S = F for the four forward-solved right-hand sides the STORE recursion left (gradient sweeps):
+// S = T^-1 [x, e_first, 1, t - t_ref].  One workgroup per particle, solution entries in registers (element j with thread j % 256),
+// column k of L read once (contiguous), four block-wide dot products per column (wave shuffles + one LDS round).
+template <int NR>
+__global__ __launch_bounds__(256) void k_toep_back(ToepArgs a) {
+  __shared__ double red[2][4][4];
+  const int p = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int n = a.n;
+  if (a.out_info[p] != 0) return;                    // (refused by the recursion: the dense path takes the particle)
+  const double* __restrict__ Lc = a.Lcols + (long long)p * a.Lstride;
+  const double* __restrict__ fw = a.fwd + (long long)p * 4 * a.ldv;
+  double y[4][NR];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) y[m][r] = 0.0;
+  for (int k = n - 1; k >= 0; --k) {
+    const long long coff = (long long)k * n - (long long)k * (k - 1) / 2 - k;
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    const int rlo = k >> 8;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      if (r < rlo) continue;
+      const int j = 256 * r + tid;
+      if (j > k && j < n) {
+        const double lj = Lc[coff + j];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) s[m] = fma(lj, y[m][r], s[m]);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s[m] += __shfl_xor(s[m], off);
+      if (l == 0) red[k & 1][w][m] = s[m];
+    }
+    const double ilkk = 1.0 / Lc[coff + k];
+    __syncthreads();
+    if ((k & 255) == tid) {
+      const int r = k >> 8;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double tot = (red[k & 1][0][m] + red[k & 1][1][m]) + (red[k & 1][2][m] + red[k & 1][3][m]);
+        const double val = (fw[m * a.ldv + k] - tot) * ilkk;
+#pragma unroll
+        for (int r2 = 0; r2 < NR; ++r2) if (r2 == r) y[m][r2] = val;
+      }
+    }
+  }
+  double* __restrict__ so = a.sol + (long long)p * 4 * a.ldv;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int j = 256 * r + tid;
+    if (j < n) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) so[m * a.ldv + j] = y[m][r];
     }
   }
 }

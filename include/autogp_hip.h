@@ -204,17 +204,24 @@ int agp_get_lag_predict_stats(agp_ctx* ctx, int64_t* n_passes);
  * to the element-wise contraction, 0 (AGP_GRAD_LAGDOM=0) disables the lag domain; the stats call counts the particles
  * contracted in the lag domain so far.
  *
- * Source of the lag sums of K^-1 (AGP_GRAD_FFT, default 2):
+ * Source of the lag sums of K^-1 (AGP_GRAD_FFT, default 3):
  *   0  histograms of the K^-1 tiles (any n_max <= 4096);
  *   1  power spectrum of the columns of L^-T (n_max <= 2048, n > 1024): no K^-1 tiles;
  *   2  where the sweep's n points are n CONSECUTIVE grid points — the whole series, or a prefix of a series given in time
  *      order, as data annealing adds it (src/inference_smc_anneal_data.jl:206-217) — and 256 <= n, n_max <= 2048:
  *      K = Toeplitz + the Linear leaves' rank-2 term in sorted order, and the lag sums follow from four solves with the
  *      Cholesky factor (right-hand sides x, e_first, 1, t) by the Gohberg-Semencul formula and a 2x2 Woodbury correction:
- *      O(n^2) per particle, no L^-T and no K^-1 at all.  Elsewhere as 1.  agp_get_grad_toeplitz_stats counts those particles. */
+ *      O(n^2) per particle, no L^-T and no K^-1 at all.  Elsewhere as 1.  agp_get_grad_toeplitz_stats counts those particles.
+ *   3  (default) as 2, and where no factor of the call's particles can be resident (empty factor store) and the class is large
+ *      enough to pay for two sequential passes over n points, its particles skip the dense factorisation too: the Schur recursion
+ *      on T (value, columns of L, forward substitution), a backward substitution, then the same lag-domain contraction with
+ *      K^-1 = T^-1 - W S W' formed in the update direction (no downdate).  The value such a sweep reports agrees with the dense
+ *      sweep's to ~1e-11 of |logpdf| (not bit for bit).  4 forces it whatever the class's size.
+ *      agp_get_grad_structured_stats counts those particles. */
 int agp_set_grad_lag_domain(agp_ctx* ctx, int32_t on);
 int agp_get_grad_lag_domain_stats(agp_ctx* ctx, int64_t* n_particles);
 int agp_get_grad_toeplitz_stats(agp_ctx* ctx, int64_t* n_particles);
+int agp_get_grad_structured_stats(agp_ctx* ctx, int64_t* n_particles);
 
 /* Value AND gradient: d logpdf / d theta for every (transformed) kernel parameter — out_grad has the
  * layout of `prm` (prm_off offsets; ChangePoint contributes d/dlocation, d/dscale) — and d logpdf / d noise.

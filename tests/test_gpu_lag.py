@@ -546,6 +546,69 @@ def test_gradient_toeplitz_lag_sums(pkg, case):
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("case", ["shapes_full", "shapes_prefix_in_time_order", "population_2048", "refused", "store_present"])
+def test_gradient_structured_sweep(pkg, monkeypatch, case):
+    """Gradient sweeps of the Toeplitz class WITHOUT a dense factor (AGP_GRAD_FFT >= 3: Schur recursion on T with the columns of L
+    stored, backward substitution, K^-1 = T^-1 - W S W' in the update direction; csrc/agp_toep_kernel.hpp, toeplitz_grad_sweep):
+    value, gradient and noise gradient against the element-wise contraction of a dense sweep (1e-9 of the gradient's scale, 1e-10 of
+    |logpdf|) and the oracle; a matrix that is not positive definite goes to the dense path; nothing changes while factors can be
+    resident (HMC's update -> choice_gradients pairs, src/inference_smc_anneal_data.jl:63-67, keep reading them)."""
+    from oracle import oracle as O
+    G = pkg
+    covered, elementwise, n_poly = _grad_shapes(G)
+    n_cls = len(covered) - n_poly
+    kernels = covered + elementwise
+    noises = np.linspace(0.02, 0.3, len(kernels))
+    oracle_check = True
+    force = "4"
+    if case == "shapes_prefix_in_time_order":
+        ts, xs = pkg.prior.synthetic_series(600, seed=5, shuffle=False); n = 400
+    elif case == "population_2048":
+        ts, xs = pkg.prior.synthetic_series(2048, seed=8, shuffle=True); n = 2048
+        kernels, noises = pkg.prior.sample_particles(np.random.default_rng(12), 320, max_depth=-1, max_size=31)
+        oracle_check = False; force = "3"; n_cls = None          # (the default: the class is large enough to pay)
+    elif case == "refused":
+        ts, xs = pkg.prior.synthetic_series(256, seed=11, shuffle=True); n = 256
+        kernels = [G.SquaredExponential(5.0, 1.0), G.SquaredExponential(0.1, 1.0) + G.Linear(0.2, 0.1, 1.0), G.Linear(0.3, 0.2, 0.5)]
+        noises = np.array([0.0, 0.05, 0.1]); n_cls = 3
+    else:
+        ts, xs = pkg.prior.synthetic_series(384, seed=6, shuffle=True); n = 384
+    monkeypatch.setenv("AGP_GRAD_FFT", force)
+    a = pkg.GPEngine(0)
+    monkeypatch.delenv("AGP_GRAD_FFT")
+    b = pkg.GPEngine(0)
+    try:
+        a.set_data(ts, xs); b.set_data(ts, xs)
+        b.set_grad_lag_domain(False)
+        if case == "store_present":
+            a.logpdf_batch_extend(kernels[:2], noises[:2], n=n, check=False)
+        lp, g, gn, info = a.logpdf_grad_batch(kernels, noises, n=n, check=False)
+        k = a.grad_structured_particles()
+        if case == "store_present":
+            assert k == 0
+        elif case == "refused":
+            assert k == 2 and info[0] > 0
+        elif n_cls is None:
+            assert k >= len(kernels) // 2
+        else:
+            assert k == n_cls and a.grad_lag_domain_particles() == len(covered)
+        lp2, g2, gn2, info2 = b.logpdf_grad_batch(kernels, noises, n=n, check=False)
+        assert np.array_equal(info, info2)
+        ok = info == 0
+        assert lp_err(lp[ok], lp2[ok]).max() <= 1e-10
+        for i in np.flatnonzero(ok):
+            sc = max(1.0, np.abs(g2[i]).max(), abs(gn2[i]))
+            assert np.abs(g[i] - g2[i]).max() <= 1e-9 * sc and abs(gn[i] - gn2[i]) <= 1e-9 * sc, (case, i, kernels[i], g[i], g2[i])
+            if oracle_check:
+                lpo, go, gno = O.gp_logpdf_grad(kernels[i].to_tuple(), float(noises[i]), ts[:n], xs[:n])
+                sc = max(1.0, np.abs(go).max(), abs(gno))
+                assert np.abs(g[i] - go).max() <= 1e-7 * sc and abs(gn[i] - gno) <= 1e-7 * sc and abs(lp[i] - lpo) <= LP_TOL * max(1.0, abs(lpo))
+        lp_r, g_r, gn_r, _ = a.logpdf_grad_batch(kernels, noises, n=n, check=False)          # reproducible
+        assert np.array_equal(gn[ok], gn_r[ok]) and all(np.array_equal(g[i], g_r[i]) for i in np.flatnonzero(ok))
+    finally:
+        a.close(); b.close()
+
+
 def test_gradient_lag_domain_population_and_switches(pkg, monkeypatch):
     """Prior-sampled population at n=1024 (several launch classes of the element-wise contraction beside the lag-domain particles,
     chunked workspace), the environment switch, and an irregular series (nothing contracted in the lag domain)."""

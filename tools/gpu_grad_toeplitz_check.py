@@ -13,7 +13,7 @@ P = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 ts, xs = pkg.prior.synthetic_series(n, seed=2048, shuffle=True)
 nodes, noises = pkg.prior.sample_particles(np.random.default_rng(2048), P, max_depth=-1, max_size=63)
 res = {}
-for mode in ("2", "1", "off"):
+for mode in ("3", "2", "1", "off"):
     if mode == "off": os.environ.pop("AGP_GRAD_FFT", None)
     else: os.environ["AGP_GRAD_FFT"] = mode
     e = pkg.GPEngine(0)
@@ -25,10 +25,10 @@ for mode in ("2", "1", "off"):
     dt = (time.time() - t0) / 3
     k1 = (e.grad_lag_domain_particles(), e.grad_toeplitz_particles())
     res[mode] = (gr, gn, info)
-    print(f"AGP_GRAD_FFT={mode}: {dt*1e3:7.2f} ms/sweep, lag-domain particles per sweep {(k1[0]-k0[0])//3}, Toeplitz {(k1[1]-k0[1])//3}")
+    print(f"AGP_GRAD_FFT={mode}: {dt*1e3:7.2f} ms/sweep, lag-domain particles per sweep {(k1[0]-k0[0])//3}, Toeplitz {(k1[1]-k0[1])//3}, without a dense factor {e.grad_structured_particles()//4}")
     e.close()
 ok = res["off"][2] == 0
-for mode in ("2", "1"):
+for mode in ("3", "2", "1"):
     worst = 0.0
     for i in np.flatnonzero(ok):
         sc = max(1.0, np.abs(res["off"][0][i]).max(), abs(res["off"][1][i]))
