@@ -236,7 +236,9 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
         for _ in range(reps):
             eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
         dt = (time.perf_counter() - t0) / reps
-        # per-kernel spans: a second set of sweeps with the HIP-event marks on
+        # per-kernel spans: a second set of sweeps with the HIP-event marks on — which also keeps every particle on the dense-factor
+        # pipeline (unmarked sweeps run the Toeplitz class without a dense factor, beside the others: the spans are the single-stream
+        # pipeline's and add up to more than ms_per_sweep)
         eng.set_profiling(True)
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -245,9 +247,9 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
                 acc[k] = acc.get(k, 0.0) + v
         dt_marked = (time.perf_counter() - t0) / reps
         eng.set_profiling(False)
-        k0, k0t = eng.grad_lag_domain_particles(), eng.grad_toeplitz_particles()
+        k0, k0t, k0s = eng.grad_lag_domain_particles(), eng.grad_toeplitz_particles(), eng.grad_structured_particles()
         eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
-        n_lagdom, n_toep = eng.grad_lag_domain_particles() - k0, eng.grad_toeplitz_particles() - k0t
+        n_lagdom, n_toep, n_struct = eng.grad_lag_domain_particles() - k0, eng.grad_toeplitz_particles() - k0t, eng.grad_structured_particles() - k0s
         # the same sweep with every particle contracted element by element (what an irregular series costs)
         eng.set_grad_lag_domain(False)
         eng.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
@@ -258,11 +260,13 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
         eng.set_grad_lag_domain(True)
         tf = P * float(n) ** 3 / dt_el / 1e12
         out["grad"] = {"what": "value + gradient sweep of the same population (agp_logpdf_grad_batch, host outputs)",
-                       "evals_per_s": P / dt, "ms_per_sweep": dt * 1e3, "ms_per_sweep_with_marks": dt_marked * 1e3,
-                       "lag_domain_particles": n_lagdom, "toeplitz_particles": n_toep,
+                       "evals_per_s": P / dt, "ms_per_sweep": dt * 1e3, "ms_per_sweep_dense_factor_pipeline_with_marks": dt_marked * 1e3,
+                       "lag_domain_particles": n_lagdom, "toeplitz_particles": n_toep, "particles_without_dense_factor": n_struct,
                        "lag_domain": "regular grid: particles whose kernel is a sum of stationary subtrees and Linear leaves are contracted over n lags; "
                                      "the sweep's points being consecutive grid points, K is Toeplitz + a rank-2 term in sorted order and the lag sums "
-                                     "of K^-1 follow from four solves with L (Gohberg-Semencul; k_toep_solve): no L^-T and no K^-1 tiles for them",
+                                     "of K^-1 follow from four solves (Gohberg-Semencul): no L^-T and no K^-1 tiles for them; with no factor resident "
+                                     "(this sweep) those particles skip the dense factorisation too: Schur recursion on T + backward substitution "
+                                     "(k_toep_logpdf<STORE>, k_toep_back), beside the dense sweep of the others",
                        "elementwise": {"what": "agp_set_grad_lag_domain(0): K^-1 tiles and the per-element reverse sweep for every particle (any series)",
                                        "evals_per_s": P / dt_el, "ms_per_sweep": dt_el * 1e3, "tflops_on_n3": tf,
                                        "frac_of_fp64_mfma_peak": tf / PEAK_FP64_MFMA_TFLOPS,
