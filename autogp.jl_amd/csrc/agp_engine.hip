@@ -573,6 +573,7 @@ static bool toeplitz_class(const uint8_t* ops, int n_ops) {
 // per particle.  Outputs in the sub-batch's order; info 1 = refused (not positive definite to rounding).
 static int toeplitz_sweep(agp_ctx* c, int64_t n, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                           const double* prm, const double* noise, double* out_lp, int32_t* out_info) {
+  HIPCHK(c, hipSetDevice(c->device));          // (may run on a helper thread: the device is per thread)
   Batch bt;
   const int rank_units = (int)((c->n_max + 255) / 256);
   int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, false, false, false, false, true, rank_units, true);
@@ -644,6 +645,7 @@ static int toeplitz_sweep(agp_ctx* c, int64_t n, int P, const int32_t* op_off, c
 static int toeplitz_grad_sweep(agp_ctx* c, int64_t n, int32_t rank0, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                                const double* prm, const double* noise, double* out_lp, int32_t* out_info, double* out_grad,
                                double* out_gnoise) {
+  HIPCHK(c, hipSetDevice(c->device));          // (runs on a helper thread: the device is per thread)
   Batch bt;
   const int rank_units = (int)((c->n_max + 255) / 256);
   int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, true, false, false, false, true, rank_units, true);
