@@ -325,16 +325,23 @@ gradient was contracted in the lag domain; the switches take effect at the next 
 """
 function lag_stats(eng::Engine)
     reg = Ref{Int32}(0); ns = Ref{Int64}(0); nr = Ref{Int64}(0); ng = Ref{Int64}(0); np = Ref{Int64}(0)
+    nt = Ref{Int64}(0); nsg = Ref{Int64}(0); nsv = Ref{Int64}(0)
     check(eng, ccall((:agp_get_lag_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int64}), eng.ptr, reg, ns))
     check(eng, ccall((:agp_get_lag_rank_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), eng.ptr, nr))
     check(eng, ccall((:agp_get_grad_lag_domain_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), eng.ptr, ng))
     check(eng, ccall((:agp_get_lag_predict_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), eng.ptr, np))
+    check(eng, ccall((:agp_get_grad_toeplitz_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), eng.ptr, nt))
+    check(eng, ccall((:agp_get_grad_structured_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), eng.ptr, nsg))
+    check(eng, ccall((:agp_get_toeplitz_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int64}), eng.ptr, nsv))
     return (regular = reg[] != 0, sorted_sweeps = Int(ns[]), rank_sweeps = Int(nr[]), lag_domain_gradients = Int(ng[]),
-            lattice_predictions = Int(np[]))
+            lattice_predictions = Int(np[]), toeplitz_gradients = Int(nt[]), structured_gradients = Int(nsg[]),
+            structured_values = Int(nsv[]))
 end
 set_lag_tables!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_lag_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
+"level 2: additionally the OPT-IN structured value sweep (Toeplitz + rank-2 particles by the Schur algorithm; include/autogp_hip.h)"
+set_lag_tables!(eng::Engine, level::Integer) = check(eng, ccall((:agp_set_lag_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, Int32(level)))
 set_lag_rank_tables!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_lag_rank_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
-set_grad_lag_domain!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_grad_lag_domain, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
+set_grad_lag_domain!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_grad_lag_domain, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 2 : 0))
 "block [lo, hi] (1-based, inclusive) of rank `rank` (0-based) — identical on every rank"
 function shard_range(P::Integer, rank::Integer, n_ranks::Integer)
     lo = Ref{Int32}(0); hi = Ref{Int32}(0)
