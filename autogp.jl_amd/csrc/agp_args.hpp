@@ -61,6 +61,10 @@ struct ToepArgs {
   double* fwd;               // [P][4][ldv]
   double* sol;               // [P][4][ldv]
   int ldv;
+  // predictive sweeps (JOINT instantiation): size of the joint grid (n training points + the future points that follow them), and
+  // per future point j: L21 L11^-1 [x, 1, t - t_ref] (rows 0..2) and the Schur complement's diagonal (row 3)
+  int nj;
+  double* pacc; int pstride;      // [P][4][pstride]
 };
 
 struct CholArgs {

@@ -544,7 +544,7 @@ void launch_gather(agp_ctx* c, hipStream_t st, int Pc, int nt1, double* dstA, lo
 
 // ---- structured value sweep (opt-in, AGP_LAG=2): see agp_toep_kernel.hpp ------------------------------------------------
 // Class test on the caller's postfix program: a sum (top-level + chain) of Linear leaves and subtrees without Linear / ChangePoint.
-static bool toeplitz_class(const uint8_t* ops, int n_ops) {
+bool toeplitz_class(const uint8_t* ops, int n_ops) {
   // per stack entry: bit 0 = stationary subtree, bit 1 = member of the class
   uint8_t st[AGP_MAX_OPS_DEV];
   int sp = 0;

@@ -179,6 +179,7 @@ struct agp_ctx {
                                  // and Linear leaves; 2: also Linear leaves inside products, by moment histograms); env AGP_GRAD_LAGDOM
   double poly_mmax = 1.0;        // half the resident series' time range: bound of a pair's midpoint t - t_ref
   int64_t n_lagdom_particles = 0;   // particles contracted in the lag domain so far (agp_get_lag_stats)
+  int64_t n_struct_pred = 0;        // particles of predictive passes served without a dense factor (toeplitz_predict_sweep)
   int64_t n_struct_grad = 0;        // ... of which: no dense factor at all (toeplitz_grad_sweep)
   int grad_struct = 1;              // structured gradient sweeps for the Toeplitz class when no factor is resident and it pays; env AGP_GRAD_FFT=3
                                     // (2: always with a dense factor; 4: whenever the class is not empty)
@@ -371,6 +372,9 @@ struct GradOut {
   double* grad;      // host, caller's parameter layout (prm_off), d logpdf / d parameter
   double* gnoise;    // host [P], d logpdf / d noise
 };
+
+// a sum (top-level + chain) of Linear leaves and subtrees without Linear / ChangePoint: Toeplitz + rank 2 on consecutive grid points
+bool toeplitz_class(const uint8_t* ops, int n_ops);
 
 // key of a particle in the factor store: the bits of (program, parameters, noise)
 std::string particle_key(const uint8_t* ops, int no, const double* prm, int np, double noise);

@@ -397,6 +397,172 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
 
 }  // namespace
 
+namespace {
+
+// Structured predictive pass (no dense factor) for the Toeplitz + rank-2 class: training points = n consecutive grid points, query
+// points = any of them and/or grid points that follow them.  One Schur recursion over the JOINT grid (n + m_f points) leaves, per
+// future point, L21 L11^-1 [x, 1, t] and the diagonal of T22 - T21 T11^-1 T12 (k_toep_logpdf<.., JOINT>); the backward substitution
+// over the training block gives T11^-1 [x, e_first, 1, t].  The rest is O(n + m) per particle on the host:
+//   K11^-1 x = alpha = a - W S U'a,   (K11^-1)_uu = (T11^-1)_uu - w_u' S w_u,   (T11^-1)_uu = sum_{i<=u} (x_i^2 - y_i^2) / x_0  (Gohberg-Semencul),
+//   future point f:  mean = m_x - m_U' S U'a + h_f' C (U'a - N S U'a),   var = s_f - noise + r' S r + noise_pred,  r = h_f - m_U
+// (a Gaussian process plus a Bayesian linear model in the basis [1, t]: Rasmussen & Williams (2.42)), S = C (I + N C)^-1, N = U'W;
+// training point u:  mean = x_u - noise alpha_u,  var = noise - noise^2 (K11^-1)_uu + noise_pred  (zero mean functions only).
+// qkind[j] >= 0: query j is training point with sorted position qkind[j];  < 0: future point -1 - qkind[j].
+int toeplitz_predict_sweep(agp_ctx* c, int64_t n, int32_t rank0, int mF, const PredLattice& pl, const std::vector<int32_t>& qkind,
+                           const std::vector<double>& xq, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
+                           const double* prm, const double* noise, const double* noise_pred, double* out_mean, double* out_var,
+                           int32_t* out_info) {
+  HIPCHK(c, hipSetDevice(c->device));
+  const int64_t m = (int64_t)qkind.size();
+  Batch bt;
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, false, false, false, false, true, pl.rank_units, true);
+  if (rc) return rc;
+  SlotGuard sg(c);
+  Slot* s = sg.s;
+  if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  hipStream_t st = s->stream;
+  auto al16 = [](size_t x) { return (x + 15) & ~(size_t)15; };
+  const size_t o_tprm = al16(sizeof(LagTabHdr) * bt.thdr.size());
+  const size_t o_tops = al16(o_tprm + sizeof(double) * bt.tprm.size());
+  const size_t prog_bytes = al16(o_tops + bt.tops.size() + 4);
+  std::vector<char> hp(prog_bytes, 0);
+  if (!bt.thdr.empty()) {
+    std::memcpy(hp.data(), bt.thdr.data(), sizeof(LagTabHdr) * bt.thdr.size());
+    std::memcpy(hp.data() + o_tprm, bt.tprm.data(), sizeof(double) * bt.tprm.size());
+    std::memcpy(hp.data() + o_tops, bt.tops.data(), bt.tops.size());
+  }
+  const int n_pad = round_up(n, NB), mF_pad = std::max(NB, round_up(mF, NB));
+  const int N = (int)n + mF;
+  std::vector<double> nz((size_t)P);
+  for (int q = 0; q < P; ++q) nz[(size_t)q] = noise[bt.order[q]];
+  const long long Lstride = (long long)n * (n + 1) / 2;
+  const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(P, ws_limit_bytes(c) / (Lstride * 8)));
+  const int stride = pl.rank_units * 256;
+  HIPCHK(c, s->hdr.ensure(sizeof(ProgHdr) * (size_t)P));
+  HIPCHK(c, s->ops.ensure(bt.ops.size() + 4));
+  HIPCHK(c, s->prm.ensure(sizeof(double) * std::max<size_t>(1, bt.prm.size())));
+  HIPCHK(c, s->noise.ensure(sizeof(double) * (size_t)P));
+  HIPCHK(c, s->pl_prog.ensure(prog_bytes));
+  HIPCHK(c, s->pl_tl.ensure(sizeof(double) * pl.tl.size()));
+  HIPCHK(c, s->out_lp.ensure(sizeof(double) * (size_t)P + sizeof(int32_t) * (size_t)P));
+  HIPCHK(c, s->A.ensure((size_t)Lstride * 8 * chunk));
+  HIPCHK(c, s->tsol.ensure(sizeof(double) * 4 * (size_t)n_pad * chunk));
+  HIPCHK(c, s->alpha.ensure(sizeof(double) * 4 * (size_t)n_pad * chunk));
+  HIPCHK(c, s->pred_mean.ensure(sizeof(double) * 4 * (size_t)mF_pad * chunk));
+  HIPCHK(c, s->lagtab.ensure(sizeof(double) * std::max<size_t>(16, (size_t)bt.n_lag_tables * stride)));
+  PinnedUploads up;
+  up.add(s->hdr.p, bt.hdr.data(), sizeof(ProgHdr) * (size_t)P);
+  up.add(s->ops.p, bt.ops.data(), bt.ops.size());
+  up.add(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size());
+  up.add(s->noise.p, nz.data(), sizeof(double) * (size_t)P);
+  up.add(s->pl_prog.p, hp.data(), prog_bytes);
+  up.add(s->pl_tl.p, pl.tl.data(), sizeof(double) * pl.tl.size());
+  HIPCHK(c, up.flush(s->h_stage, st));
+  if (bt.n_lag_tables > 0) {
+    LagArgs la = {};
+    la.tt = s->pl_tl.as<double>(); la.thdr = s->pl_prog.as<LagTabHdr>();
+    la.tprm = reinterpret_cast<const double*>(static_cast<char*>(s->pl_prog.p) + o_tprm);
+    la.tops = reinterpret_cast<const uint8_t*>(static_cast<char*>(s->pl_prog.p) + o_tops);
+    la.n_tables = bt.n_lag_tables; la.tab = s->lagtab.as<double>();
+    la.nt = 2 * pl.rank_units; la.full = 1; la.stride = stride;
+    launch_lag_tables(st, la, pl.rank_units, bt.n_lag_tables);
+    HIPCHK(c, hipGetLastError());
+  }
+  const double h = c->grid_h;
+  auto tau_of = [&](int u) { return ((double)(rank0 + u) - c->grid_mid) * h; };
+  std::vector<double> Tdiag((size_t)n), alpha((size_t)n);
+  for (int p0 = 0; p0 < P; p0 += chunk) {
+    const int Pc = std::min(chunk, P - p0);
+    ToepArgs ta = {};
+    ta.xs = c->d_xs_s + rank0; ta.n = (int)n; ta.nj = N; ta.P = Pc; ta.rank0 = rank0;
+    ta.hdr = s->hdr.as<ProgHdr>() + p0; ta.ops = s->ops.as<uint8_t>(); ta.prm = s->prm.as<double>(); ta.noise = s->noise.as<double>() + p0;
+    ta.lagtab = s->lagtab.as<double>(); ta.lag_stride = stride;
+    ta.grid_h = h; ta.grid_mid = c->grid_mid; ta.tref = c->t_ref;
+    ta.out_lp = s->out_lp.as<double>() + p0; ta.out_info = reinterpret_cast<int32_t*>(s->out_lp.as<double>() + P) + p0;
+    ta.Lcols = s->A.as<double>(); ta.Lstride = Lstride; ta.fwd = s->alpha.as<double>(); ta.sol = s->tsol.as<double>(); ta.ldv = n_pad;
+    ta.pacc = s->pred_mean.as<double>(); ta.pstride = mF_pad;
+    HIPCHK(c, launch_toep_logpdf(st, ta));
+    const size_t nsol = (size_t)4 * n_pad * Pc, nacc = (size_t)4 * mF_pad * Pc;
+    HIPCHK(c, s->h_out.ensure(sizeof(double) * (nsol + nacc) + sizeof(int32_t) * (size_t)Pc));
+    double* hs = static_cast<double*>(s->h_out.p);
+    double* ha = hs + nsol;
+    int32_t* hi = reinterpret_cast<int32_t*>(ha + nacc);
+    HIPCHK(c, hipMemcpyAsync(hs, s->tsol.p, sizeof(double) * nsol, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(ha, s->pred_mean.p, sizeof(double) * nacc, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(hi, ta.out_info, sizeof(int32_t) * (size_t)Pc, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    for (int q = 0; q < Pc; ++q) {
+      const int pc = bt.order[p0 + q];
+      out_info[pc] = hi[q];
+      double* om = out_mean + (size_t)pc * m; double* ov = out_var + (size_t)pc * m;
+      if (hi[q] != 0) continue;
+      const double s2 = noise[pc], s2p = noise_pred ? noise_pred[pc] : noise[pc];
+      const double* a_ = hs + (size_t)q * 4 * n_pad; const double* x_ = a_ + n_pad; const double* w1 = x_ + n_pad; const double* wt = w1 + n_pad;
+      const double* mx = ha + (size_t)q * 4 * mF_pad; const double* m1 = mx + mF_pad; const double* mt = m1 + mF_pad; const double* sT = mt + mF_pad;
+      // C: the Linear leaves (device form: intercept, bias, amplitude) in the basis [1, t - t_ref]
+      double C00 = 0.0, C01 = 0.0, C11 = 0.0;
+      {
+        const ProgHdr& ph = bt.hdr[p0 + q];
+        int qi = 0;
+        for (int ip = 0; ip < ph.n_ops; ++ip) {
+          const int o = bt.ops[(size_t)ph.op_off + ip];
+          if (o == OP_LIN) {
+            const double* pr = bt.prm.data() + ph.prm_off + qi;
+            const double cc = pr[0] - c->t_ref;
+            C00 += pr[1] + pr[2] * cc * cc; C01 -= pr[2] * cc; C11 += pr[2];
+          }
+          qi += (o == OP_WN || o == OP_CONST) ? 1 : (o == OP_LIN) ? 3 : 0;
+        }
+      }
+      double N00 = 0.0, N01 = 0.0, N11 = 0.0, ux0 = 0.0, ux1 = 0.0;
+      const bool lin = C00 != 0.0 || C01 != 0.0 || C11 != 0.0;
+      if (lin)
+        for (int u = 0; u < n; ++u) { const double t = tau_of(u); N00 += w1[u]; N01 += wt[u]; N11 += t * wt[u]; ux0 += a_[u]; ux1 += t * a_[u]; }
+      const double t00 = 1.0 + (N00 * C00 + N01 * C01), t01 = N00 * C01 + N01 * C11, t10 = N01 * C00 + N11 * C01, t11 = 1.0 + (N01 * C01 + N11 * C11);
+      const double idet = 1.0 / (t00 * t11 - t01 * t10);
+      const double i00 = t11 * idet, i01 = -t01 * idet, i10 = -t10 * idet, i11 = t00 * idet;
+      const double S00 = C00 * i00 + C01 * i10, S01 = C00 * i01 + C01 * i11, S11 = C01 * i01 + C11 * i11;
+      const double as0 = S00 * ux0 + S01 * ux1, as1 = S01 * ux0 + S11 * ux1;
+      const double ga0 = ux0 - (N00 * as0 + N01 * as1), ga1 = ux1 - (N01 * as0 + N11 * as1);          // U' alpha
+      // diag(T11^-1) by Gohberg-Semencul (cumulative), alpha
+      {
+        const double ix0 = 1.0 / x_[0];
+        double cum = 0.0;
+        for (int u = 0; u < n; ++u) {
+          const double xu = x_[u], yu = u == 0 ? 0.0 : x_[n - u];
+          cum += (xu - yu) * (xu + yu);
+          Tdiag[(size_t)u] = cum * ix0;
+          alpha[(size_t)u] = lin ? a_[u] - (w1[u] * as0 + wt[u] * as1) : a_[u];
+        }
+      }
+      for (int64_t j = 0; j < m; ++j) {
+        const int kq = qkind[(size_t)j];
+        if (kq >= 0) {
+          const int u = kq;
+          const double kd = lin ? Tdiag[(size_t)u] - (w1[u] * (S00 * w1[u] + S01 * wt[u]) + wt[u] * (S01 * w1[u] + S11 * wt[u])) : Tdiag[(size_t)u];
+          om[j] = xq[(size_t)j] - s2 * alpha[(size_t)u];
+          ov[j] = s2 - s2 * s2 * kd + s2p;
+        } else {
+          const int f = -1 - kq;
+          double mean = mx[f], var = sT[f] - s2;
+          if (lin) {
+            const double tf = tau_of((int)n + f);
+            const double r0_ = 1.0 - m1[f], r1_ = tf - mt[f];
+            mean += -(m1[f] * as0 + mt[f] * as1) + (C00 * ga0 + C01 * ga1) + tf * (C01 * ga0 + C11 * ga1);
+            var += r0_ * (S00 * r0_ + S01 * r1_) + r1_ * (S01 * r0_ + S11 * r1_);
+          }
+          om[j] = mean; ov[j] = var + s2p;
+        }
+      }
+    }
+  }
+  return AGP_OK;
+}
+
+thread_local bool tl_in_tpredict = false;
+
+}  // namespace
+
 extern "C" {
 
 int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P,
@@ -411,6 +577,96 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
     return fail(c, AGP_ERR_ARG, "null pointer argument");
   if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
   HIPCHK(c, hipSetDevice(c->device));
+  // Structured pass (no dense factor; toeplitz_predict_sweep): marginal predictions, zero mean functions, the n training points
+  // consecutive grid points, every query one of them or a grid point after them, nothing resident to start from — the Toeplitz +
+  // rank-2 particles of the call go there, the others (and any particle the recursion refuses) through the dense path below.
+  if (!out_cov && !mean_train && !mean_pred && !tl_in_tpredict && c->grad_struct && n >= 256 && n <= 2048 &&
+      !(c->predict_reuse && c->store.n_slots > 0) && (int64_t)c->h_rank.size() >= n) {
+    PredLattice plq;
+    predict_lattice(c, n, ts_pred, m, plq);
+    int32_t lo = 0, hi = 0;
+    bool ok = plq.on;
+    if (ok) {
+      lo = hi = plq.rank[0];
+      for (int64_t i = 1; i < n; ++i) { lo = std::min(lo, plq.rank[(size_t)i]); hi = std::max(hi, plq.rank[(size_t)i]); }
+      ok = (int64_t)hi - lo + 1 == n;
+    }
+    std::vector<int32_t> qkind((size_t)m);
+    std::vector<double> xq((size_t)m, 0.0);
+    int mF = 0;
+    if (ok) {
+      const int n1_pad = round_up(n, NB);
+      std::vector<int32_t> at((size_t)n);          // sorted position -> training index
+      for (int64_t i = 0; i < n; ++i) at[(size_t)(plq.rank[(size_t)i] - lo)] = (int32_t)i;
+      for (int64_t j = 0; j < m && ok; ++j) {
+        const int32_t r = plq.rank[(size_t)n1_pad + j];
+        if (r < lo) { ok = false; break; }          // (a point before the series: the dense path)
+        if (r <= hi) { qkind[(size_t)j] = r - lo; xq[(size_t)j] = c->h_xs[(size_t)at[(size_t)(r - lo)]]; }
+        else { const int f = r - hi - 1; qkind[(size_t)j] = -1 - f; mF = std::max(mF, f + 1); }
+      }
+      ok = ok && n + mF <= 4096 && n + mF <= (int64_t)plq.rank_units * 256;
+    }
+    std::vector<int> part[2];
+    if (ok) {
+      bool sane = true;
+      for (int p = 0; p < P && sane; ++p) sane = op_off[p + 1] >= op_off[p] && op_off[p + 1] - op_off[p] <= AGP_MAX_OPS_DEV && prm_off[p + 1] >= prm_off[p];
+      ok = sane;
+      if (ok) for (int p = 0; p < P; ++p) part[toeplitz_class(ops + op_off[p], op_off[p + 1] - op_off[p]) ? 1 : 0].push_back(p);
+    }
+    // (two sequential passes over the joint grid: ~1.2 us per point + ~1 us per training point, whatever the class's size)
+    if (ok && (int)part[1].size() >= 32) {
+      const int32_t rank0_abs = c->h_rank[0] - (plq.rank[0] - lo);          // rank of the first training point in the resident series
+      auto gather = [&](const std::vector<int>& ix, std::vector<int32_t>& oo, std::vector<uint8_t>& so, std::vector<int32_t>& po,
+                        std::vector<double>& sp, std::vector<double>& nz, std::vector<double>& nzp) {
+        oo.assign(ix.size() + 1, 0); po.assign(ix.size() + 1, 0); nz.resize(ix.size()); nzp.resize(ix.size()); so.clear(); sp.clear();
+        for (size_t b = 0; b < ix.size(); ++b) {
+          const int p = ix[b];
+          so.insert(so.end(), ops + op_off[p], ops + op_off[p + 1]);
+          sp.insert(sp.end(), prm + prm_off[p], prm + prm_off[p + 1]);
+          oo[b + 1] = (int32_t)so.size(); po[b + 1] = (int32_t)sp.size(); nz[b] = noise[p]; nzp[b] = noise_pred ? noise_pred[p] : noise[p];
+        }
+        if (sp.empty()) sp.push_back(0.0);
+      };
+      struct Sub { std::vector<int32_t> oo, po, info; std::vector<uint8_t> so; std::vector<double> sp, nz, nzp, mean, var; int rc = 0; } sT, sD;
+      gather(part[1], sT.oo, sT.so, sT.po, sT.sp, sT.nz, sT.nzp);
+      sT.mean.resize(part[1].size() * (size_t)m); sT.var.resize(part[1].size() * (size_t)m); sT.info.assign(part[1].size(), 0);
+      std::thread side([&] {
+        sT.rc = toeplitz_predict_sweep(c, n, rank0_abs, mF, plq, qkind, xq, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(),
+                                       sT.sp.data(), sT.nz.data(), sT.nzp.data(), sT.mean.data(), sT.var.data(), sT.info.data());
+      });
+      auto dense = [&](const std::vector<int>& ix) {
+        if (ix.empty()) return 0;
+        gather(ix, sD.oo, sD.so, sD.po, sD.sp, sD.nz, sD.nzp);
+        sD.mean.resize(ix.size() * (size_t)m); sD.var.resize(ix.size() * (size_t)m); sD.info.assign(ix.size(), 0);
+        tl_in_tpredict = true;
+        const int rc0 = agp_predict_batch(c, n, ts_pred, m, (int32_t)ix.size(), sD.oo.data(), sD.so.data(), sD.po.data(), sD.sp.data(), sD.nz.data(),
+                                          sD.nzp.data(), nullptr, nullptr, sD.mean.data(), sD.var.data(), nullptr, sD.info.data());
+        tl_in_tpredict = false;
+        if (rc0) return rc0;
+        for (size_t b = 0; b < ix.size(); ++b) {
+          std::memcpy(out_mean + (size_t)ix[b] * m, sD.mean.data() + b * (size_t)m, sizeof(double) * (size_t)m);
+          std::memcpy(out_var + (size_t)ix[b] * m, sD.var.data() + b * (size_t)m, sizeof(double) * (size_t)m);
+          if (out_info) out_info[ix[b]] = sD.info[b];
+        }
+        return 0;
+      };
+      const int rcD = dense(part[0]);
+      side.join();
+      if (rcD) return rcD;
+      if (sT.rc) return sT.rc;
+      std::vector<int> refused;
+      int64_t done = 0;
+      for (size_t b = 0; b < part[1].size(); ++b) {
+        if (sT.info[b] != 0) { refused.push_back(part[1][b]); continue; }
+        std::memcpy(out_mean + (size_t)part[1][b] * m, sT.mean.data() + b * (size_t)m, sizeof(double) * (size_t)m);
+        std::memcpy(out_var + (size_t)part[1][b] * m, sT.var.data() + b * (size_t)m, sizeof(double) * (size_t)m);
+        if (out_info) out_info[part[1][b]] = 0;
+        ++done;
+      }
+      { std::lock_guard<std::mutex> g(c->mu); c->n_struct_pred += done; }
+      return dense(refused);
+    }
+  }
   // A resampled population holds copies of the survivors (src/inference_smc_anneal_data.jl:198-204) and the reference
   // predicts particle by particle (src/api.jl:508-520): each distinct (program, parameters, noise, noise_pred) runs once.
   std::vector<int> rep(P), uniq;

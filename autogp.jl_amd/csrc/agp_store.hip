@@ -438,6 +438,13 @@ int agp_get_grad_toeplitz_stats(agp_ctx* c, int64_t* n_particles) {
   return AGP_OK;
 }
 
+int agp_get_predict_structured_stats(agp_ctx* c, int64_t* n_particles) {
+  if (!c || !n_particles) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->mu);
+  *n_particles = c->n_struct_pred;
+  return AGP_OK;
+}
+
 int agp_get_grad_structured_stats(agp_ctx* c, int64_t* n_particles) {
   if (!c || !n_particles) return fail(c, AGP_ERR_ARG, "null pointer");
   std::lock_guard<std::mutex> g(c->mu);

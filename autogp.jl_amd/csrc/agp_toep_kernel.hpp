@@ -26,7 +26,7 @@ namespace agp {
 
 constexpr int TOEP_MAX_R = 16;          // elements per thread: n <= 4096
 
-template <int NR, bool STORE = false>
+template <int NR, bool STORE = false, bool JOINT = false>
 __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double tsm[];
   double* ul = tsm;                      // [256 NR]  u at position j - k
@@ -34,6 +34,11 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
   const int p = blockIdx.x, tid = threadIdx.x;
   const ProgHdr h = a.hdr[p];
   const int n = a.n;
+  // JOINT (predictive sweeps): the recursion runs over N = n + m_future consecutive grid points; the right-hand sides live on the
+  // first n of them, and for the rows j >= n the same registers accumulate what the predictive equations need — bx, b1, bt end as
+  // -L21 L11^-1 [x, 1, tau] (entry j - n), be as the diagonal of the Schur complement T22 - T21 T11^-1 T12 (sum of squares of the row's
+  // entries in columns >= n)
+  const int N = JOINT ? a.nj : n;
   // C and the list of tables (thread-uniform walk over the program)
   // (Constant and WhiteNoise leaves the compiler left outside a table join T directly; anything else — a stationary leaf kept in
   // its direct form because the sweep ran out of tables, a product — is not this kernel's: refused, the dense path takes it)
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
   for (int r = 0; r < NR; ++r) {
     const int j = 256 * r + tid;
     double s = 0.0;
-    if (j < n) {
+    if (j < N) {
       s = r_all;
       for (int li = 0; li < h.n_lag; ++li) s += tab[(long long)li * a.lag_stride + j];
       if (j == 0) s += a.noise[p] + r_zero;
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
   const bool w0ave = tid < 64;
   double lprod = 1.0, logdet = 0.0, qxx = 0.0, n00 = 0.0, n01 = 0.0, n11 = 0.0, w0 = 0.0, w1 = 0.0;
   bool bad = false;
-  for (int k = 0; k < n; ++k) {
+  for (int k = 0; k < N; ++k) {
+    const bool ktr = !JOINT || k < n;          // a training column (uniform)
     const double* pk = piv + 8 * (k & 1);
     double* pn = piv + 8 * ((k + 1) & 1);
     const double rho = pk[0] * ipu;
@@ -112,11 +118,11 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
     }
     const double il = ipu * cs;                     // 1 / L(k,k)
     pu = pu * om * cs; ipu = il;
-    const double yx = pk[1] * il, y1 = pk[2] * il, yt = pk[3] * il;      // entries k of L^-1 [x, 1, tau]
-    const double ye = STORE ? pk[4] * il : 0.0;                          // ... and of L^-1 e_first
-    if (STORE && tid == 0) { fw[k] = yx; fw[a.ldv + k] = ye; fw[2 * a.ldv + k] = y1; fw[3 * a.ldv + k] = yt; }
+    const double yx = ktr ? pk[1] * il : 0.0, y1 = ktr ? pk[2] * il : 0.0, yt = ktr ? pk[3] * il : 0.0;      // entries k of L^-1 [x, 1, tau]
+    const double ye = (STORE && ktr) ? pk[4] * il : 0.0;                 // ... and of L^-1 e_first
+    if (STORE && ktr && tid == 0) { fw[k] = yx; fw[a.ldv + k] = ye; fw[2 * a.ldv + k] = y1; fw[3 * a.ldv + k] = yt; }
     const long long coff = STORE ? (long long)k * n - (long long)k * (k - 1) / 2 - k : 0;      // column k, row j at coff + j
-    if (w0ave) {
+    if (w0ave && ktr) {
       lprod *= pu;
       if ((k & 7) == 7) { logdet += fm::log_f(lprod); lprod = 1.0; }
       qxx = fma(yx, yx, qxx);
@@ -127,22 +133,31 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
     for (int r = 0; r < NR; ++r) {
       if (r < rlo) continue;
       const int j = 256 * r + tid;
-      if (j >= k && j < n) {
+      if (j >= k && j < N) {
         const double uj = ul[j - k], vj = v[r];
         const double un = cs * (uj - rho * vj);      // L(j,k)
         const double vn = cs * (vj - rho * uj);
         ul[j - k] = un;                              // (read next step by the owner of element j + 1)
         v[r] = vn;
-        if (STORE) Lc[coff + j] = un;
+        if (STORE && (!JOINT || (ktr && j < n))) Lc[coff + j] = un;
+        if (JOINT && !ktr) be[r] = fma(un, un, be[r]);      // (rows j >= k >= n: the Schur complement's diagonal)
         if (j > k) {
           bx[r] = fma(-un, yx, bx[r]);
           if (lin) { b1[r] = fma(-un, y1, b1[r]); bt[r] = fma(-un, yt, bt[r]); }
-          if (STORE) be[r] = fma(-un, ye, be[r]);
+          if (STORE && (!JOINT || j < n)) be[r] = fma(-un, ye, be[r]);
           if (j == k + 1) { pn[0] = vn; pn[1] = bx[r]; pn[2] = b1[r]; pn[3] = bt[r]; if (STORE) pn[4] = be[r]; }
         }
       }
     }
     __syncthreads();
+  }
+  if (JOINT && !bad) {
+    double* __restrict__ pa = a.pacc + (long long)p * 4 * a.pstride;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int j = 256 * r + tid;
+      if (j >= n && j < N) { pa[j - n] = -bx[r]; pa[a.pstride + j - n] = -b1[r]; pa[2 * a.pstride + j - n] = -bt[r]; pa[3 * a.pstride + j - n] = STORE ? be[r] : 0.0; }
+    }
   }
   logdet = 2.0 * (logdet + fm::log_f(lprod));       // log|T| = sum_k log L(k,k)^2
   if (tid == 0) {

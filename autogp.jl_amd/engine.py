@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi", "agp_logpdf_batch_extend_multi",
     "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
-    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
+    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_predict_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
 ]
 COMM_ID_BYTES = 128
 
@@ -149,6 +149,7 @@ def load_library(path=None):
     lib.agp_get_grad_toeplitz_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_get_grad_toeplitz_stats.restype = C.c_int
     lib.agp_get_toeplitz_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_get_toeplitz_stats.restype = C.c_int
     lib.agp_get_grad_structured_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_get_grad_structured_stats.restype = C.c_int
+    lib.agp_get_predict_structured_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_get_predict_structured_stats.restype = C.c_int
     lib.agp_init_multi.argtypes = [C.POINTER(vp), i32p, C.c_int32]; lib.agp_init_multi.restype = C.c_int
     lib.agp_set_data_multi.argtypes = [C.POINTER(vp), C.c_int32, dp, dp, C.c_int64]; lib.agp_set_data_multi.restype = C.c_int
     lib.agp_allgather_logweights.argtypes = [vp, dp, C.c_int32]; lib.agp_allgather_logweights.restype = C.c_int
@@ -383,6 +384,12 @@ class GPEngine:
         """Particles scored by the structured (Toeplitz + rank 2, Schur algorithm) value sweep so far (set_lag_tables(2))."""
         k = C.c_int64()
         self._check(self._lib.agp_get_toeplitz_stats(self._ctx, C.byref(k)))
+        return int(k.value)
+
+    def predict_structured_particles(self):
+        """Particles of predictive passes served without a dense factor (joint Schur recursion) so far."""
+        k = C.c_int64()
+        self._check(self._lib.agp_get_predict_structured_stats(self._ctx, C.byref(k)))
         return int(k.value)
 
     def grad_structured_particles(self):

@@ -294,20 +294,23 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
             for _ in range(reps):
                 eng.predict_batch(nodes[:Pp], noises[:Pp], q, n=n, check=False)
             return (time.perf_counter() - t0) / reps
-        k0 = eng.lag_predict_passes()
+        k0, k0s = eng.lag_predict_passes(), eng.predict_structured_particles()
         dt = timed(tq)
         on_lattice = eng.lag_predict_passes() > k0
+        n_struct = (eng.predict_structured_particles() - k0s) // 5
         dt_off = timed(tq_off)
         fl = Pp * (cholesky_flops(n) + float(n) * n * m)            # as the reference computes it: V = L^-1 K12 for all m points
         # what the pass executes: the n query points that are observed points come from alpha and diag(K11^-1) (L^-T: n^3/3),
         # V only for the m - n future points
         fl_done = Pp * (2.0 * cholesky_flops(n) + float(n) * n * (m - n))
         out["predict"] = {"what": f"agp_predict_batch, first {Pp} particles, n={n}, m={m} query points = the observed times + {m - n} future "
-                                  f"points at the series' cadence, marginal variances (out_cov = NULL), host outputs, K11 factored by the pass",
+                                  f"points at the series' cadence, marginal variances (out_cov = NULL), host outputs, nothing resident",
                           "ms": dt * 1e3, "particles": Pp, "m": m, "rank_tables": bool(on_lattice),
-                          "tflops": fl_done / dt / 1e12, "frac_of_fp64_mfma_peak": fl_done / dt / 1e12 / PEAK_FP64_MFMA_TFLOPS,
-                          "flop_count": "executed: n^3/3 (factor) + n^3/3 (L^-T: mean and variance at the n observed points from alpha and "
-                                        "diag(K11^-1)) + n^2 (m - n) (V for the future points) per particle",
+                          "particles_without_dense_factor": int(n_struct),
+                          "path": "particles whose kernel is a sum of stationary subtrees and Linear leaves (Toeplitz + rank 2 on the joint grid): one "
+                                  "Schur recursion over the 4096 joint points + a backward substitution, O((n + m)^2) (toeplitz_predict_sweep); the others, "
+                                  "beside them: dense factor of K11, observed points from alpha and diag(K11^-1) (L^-T), V = L^-1 K12 for the future points",
+                          "dense_path_flops_if_all_particles_took_it": fl_done,
                           "reference_equivalent_tflops": fl / dt / 1e12,
                           "reference_equivalent_flop_count": "n^3/3 + n^2 m per particle (V = L^-1 K12 for every query point, src/GP.jl:743-757)",
                           "off_lattice_queries": {"what": f"the same with {m} query points linspace(0, 1.25): general evaluator",

@@ -189,6 +189,15 @@ int agp_get_lag_rank_stats(agp_ctx* ctx, int64_t* n_sweeps);
  * the call takes the general path.  No switch of its own (AGP_LAG=0 / AGP_LAG_RANK=0 cover it); agp_get_lag_predict_stats counts
  * the calls that took it. */
 int agp_get_lag_predict_stats(agp_ctx* ctx, int64_t* n_passes);
+/* ... and where, in addition, the n training points are consecutive grid points (256 <= n <= 2048), every query point is one of them
+ * or a grid point after them (n + future points <= 4096), no covariance and no mean function is requested and nothing is resident in
+ * the factor store, the particles whose kernel is a sum of stationary subtrees and Linear leaves (at least 32 of them) need no dense
+ * factor: one Schur recursion over the JOINT grid leaves L21 L11^-1 [x, 1, t] and the diagonal of T22 - T21 T11^-1 T12 per future
+ * point, a backward substitution T11^-1 [x, e_first, 1, t]; predictions at training points come from alpha and diag(K11^-1)
+ * (Gohberg-Semencul), the Linear leaves enter as a Bayesian linear model in [1, t] (Woodbury, update direction).  The other
+ * particles of the call take the dense path; same results to ~1e-10 of their scale (tests/test_gpu_lag.py).  Part of AGP_GRAD_FFT >= 3
+ * ("no dense factor where the structure allows"); agp_get_predict_structured_stats counts the particles served that way. */
+int agp_get_predict_structured_stats(agp_ctx* ctx, int64_t* n_particles);
 
 /* Gradient sweeps on a regular time grid (the points in any order, any prefix n <= n_max <= 4096): for a stationary kernel
  * dK_ab/dtheta depends on the lag |rank_a - rank_b| alone, so sum_ab G_ab dK_ab/dtheta = sum_g D_g dk(g h)/dtheta with D_g the

@@ -332,6 +332,70 @@ def test_predictive_pass_on_training_point_queries(pkg, case):
         e.close()
 
 
+@pytest.mark.parametrize("case", ["train_and_future", "future_only", "train_only", "prefix_in_time_order", "population_2048", "backcast", "refused"])
+def test_predictive_pass_structured(pkg, monkeypatch, case):
+    """Predictive pass WITHOUT a dense factor for the Toeplitz + rank-2 class (csrc/agp_predict.hip toeplitz_predict_sweep: joint
+    Schur recursion, backward substitution, Gohberg-Semencul diagonal, Bayesian linear model for the Linear leaves): training points
+    consecutive on the grid, queries = any of them and / or grid points after them (scripts/online.jl:41-43).  Against the dense pass
+    (AGP_GRAD_FFT=2: 1e-9 of the scale) and the oracle (src/GP.jl:739-757 restated); a point before the series, or a matrix that is
+    not positive definite, goes to the dense path."""
+    from oracle import oracle as O
+    G = pkg
+    rng = np.random.default_rng(3)
+    covered, elementwise, n_poly = _grad_shapes(G)
+    base = covered[:len(covered) - n_poly]
+    ks = base * 3 + elementwise
+    nz = np.linspace(0.01, 0.25, len(ks)); npred = np.linspace(0.3, 0.02, len(ks))
+    n_max = 420
+    grid = np.linspace(0.0, 1.0, n_max); h = grid[1] - grid[0]
+    perm = rng.permutation(n_max)
+    ts = grid[perm]; n = n_max
+    fut = 1.0 + h * np.arange(1, 90)
+    n_cls = 3 * len(base)
+    if case == "future_only":      tq = fut[rng.permutation(fut.size)]
+    elif case == "train_only":     tq = ts[rng.permutation(n_max)[:300]]
+    elif case == "backcast":       tq = np.concatenate([ts[:50], [grid[0] - h], fut[:5]]); n_cls = 0
+    elif case == "prefix_in_time_order":
+        ts = grid.copy(); n = 333
+        tq = np.concatenate([ts[:n][::-1], grid[n:], fut])          # (the rest of the series are "future" points here)
+    elif case == "population_2048":
+        n_max = n = 2048
+        ts, _ = pkg.prior.synthetic_series(n_max, seed=13, shuffle=True)
+        gs = np.sort(ts); h = gs[1] - gs[0]
+        ks, nz = pkg.prior.sample_particles(np.random.default_rng(31), 96, max_depth=-1, max_size=31)
+        npred = 0.5 * nz
+        tq = np.concatenate([ts, gs[-1] + h * np.arange(1, 513)]); n_cls = None
+    else:                          tq = np.concatenate([fut[:7], ts[rng.permutation(n_max)[:200]], ts[:40], fut[7:]])
+    if case == "refused":
+        ks = [G.SquaredExponential(5.0, 1.0)] + ks; nz = np.concatenate([[0.0], nz]); npred = np.concatenate([[0.1], npred]); n_cls = n_cls  # particle 0: singular
+    xs = np.cos(9 * ts) + 0.3 * ts + 0.1 * rng.standard_normal(ts.size)
+    a = pkg.GPEngine(0)
+    monkeypatch.setenv("AGP_GRAD_FFT", "2")
+    b = pkg.GPEngine(0)
+    monkeypatch.delenv("AGP_GRAD_FFT")
+    try:
+        a.set_data(ts, xs); b.set_data(ts, xs)
+        m1, v1, _, i1 = a.predict_batch(ks, nz, tq, n=n, noise_pred=npred, check=False)
+        m2, v2, _, i2 = b.predict_batch(ks, nz, tq, n=n, noise_pred=npred, check=False)
+        k = a.predict_structured_particles()
+        assert b.predict_structured_particles() == 0
+        if n_cls is None: assert k >= len(ks) // 2
+        else: assert k == n_cls, (case, k)
+        assert np.array_equal(i1 > 0, i2 > 0)
+        if case == "refused": assert i1[0] > 0 and np.isnan(m1[0]).all()
+        ok = i1 == 0
+        sc = np.maximum(1.0, np.abs(m2[ok]).max(axis=1))[:, None]
+        assert (np.abs(m1[ok] - m2[ok]) / sc).max() <= 1e-9
+        assert (np.abs(v1[ok] - v2[ok]) / np.maximum(1.0, v2[ok])).max() <= 1e-9
+        if n <= 420:
+            for i in list(range(1 if case == "refused" else 0, 6)) + [len(ks) - 1]:
+                mu, cv = O.predict_mvn(ks[i].to_tuple(), float(nz[i]), ts[:n], xs[:n], tq, noise_pred=float(npred[i]))
+                assert np.abs(m1[i] - mu).max() <= LP_TOL * max(1.0, np.abs(mu).max()), (case, i)
+                assert np.abs(v1[i] - np.diag(cv)).max() <= LP_TOL * max(1.0, np.abs(cv).max()), (case, i)
+    finally:
+        a.close(); b.close()
+
+
 def test_predictive_lattice_pass_reuses_resident_factors(pkg):
     """The per-step callback of the streaming workload (scripts/online.jl:43,59): factors left by the reweight sweep (rank
     tables) are reused by a predictive pass on lattice query points; same result as a pass that factors itself."""
