@@ -59,7 +59,8 @@ hipError_t launch_toep_logpdf(hipStream_t st, const ToepArgs& ta) {
   if (ta.pacc != nullptr) {
     // predictive sweeps: recursion over the joint grid (<= 4096 points), backward substitution over the training block (<= 2048)
     if (ta.nj > 256 * TOEP_MAX_R || ta.n > 2048 || ta.Lcols == nullptr) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((k_toep_logpdf<TOEP_MAX_R, true, true>), dim3(ta.P), dim3(256), sizeof(double) * (TOEP_MAX_R * 256 + 16), st, ta);
+    // (512 threads, 8 elements each: a column step costs half the vector instructions per wave of the 256 x 16 layout)
+    hipLaunchKernelGGL((k_toep_logpdf<8, true, true, 512>), dim3(ta.P), dim3(512), sizeof(double) * (8 * 512 + 16), st, ta);
     hipLaunchKernelGGL(k_toep_back<8>, dim3(ta.P), dim3(256), 0, st, ta);
   } else if (ta.Lcols != nullptr) {
     // gradient sweeps (n <= 2048: the transforms of k_lag_grad): columns of L and forward-solved right-hand sides stored, then the

@@ -13,7 +13,8 @@
 // benchmark population (cond up to 1e8).  The reference (src/Model.jl:134-136: Gen.mvnormal = dense Cholesky) is what the default
 // path mirrors; this one is what a regular grid allows.
 //
-// One workgroup (256 threads) per particle, element j of every vector with thread j % 256 (register j / 256): v and the three
+// One workgroup (NT = 256 threads; 512 for the joint grids of predictive sweeps) per particle, element j of every vector with thread
+// j % NT (register j / NT): v and the three
 // right-hand sides stay in registers in natural coordinates; u lives in LDS at position j - k (it is the vector that shifts:
 // element j reads what element j - 1 wrote one step earlier), pivots and the step's right-hand-side entries go through a
 // double-buffered LDS slot; the pivot L(k,k) and its reciprocal are recurrences every thread carries — ONE barrier per column,
@@ -26,11 +27,15 @@ namespace agp {
 
 constexpr int TOEP_MAX_R = 16;          // elements per thread: n <= 4096
 
-template <int NR, bool STORE = false, bool JOINT = false>
-__global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
+// Barrier of the per-column loops: only LDS traffic has to be complete (s_waitcnt lgkmcnt(0)); __syncthreads() would also wait for
+// the global stores of L's column and for the next column's prefetch (vmcnt(0)) on every one of the n steps.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NR, bool STORE = false, bool JOINT = false, int NT = 256>
+__global__ __launch_bounds__(NT) void k_toep_logpdf(ToepArgs a) {
   extern __shared__ __attribute__((aligned(16))) double tsm[];
-  double* ul = tsm;                      // [256 NR]  u at position j - k
-  double* piv = tsm + NR * 256;          // 2 x 8: {v_k, x_k, one_k, tau_k, e_k} of the coming step
+  double* ul = tsm;                      // [NT NR]  u at position j - k
+  double* piv = tsm + NR * NT;          // 2 x 8: {v_k, x_k, one_k, tau_k, e_k} of the coming step
   const int p = blockIdx.x, tid = threadIdx.x;
   const ProgHdr h = a.hdr[p];
   const int n = a.n;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
   const double ir0 = 1.0 / sqrt(r0);
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
-    const int j = 256 * r + tid;
+    const int j = NT * r + tid;
     double s = 0.0;
     if (j < N) {
       s = r_all;
@@ -128,11 +133,11 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
       qxx = fma(yx, yx, qxx);
       if (lin) { n00 = fma(y1, y1, n00); n01 = fma(y1, yt, n01); n11 = fma(yt, yt, n11); w0 = fma(y1, yx, w0); w1 = fma(yt, yx, w1); }
     }
-    const int rlo = k >> 8;
+    const int rlo = k / NT;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       if (r < rlo) continue;
-      const int j = 256 * r + tid;
+      const int j = NT * r + tid;
       if (j >= k && j < N) {
         const double uj = ul[j - k], vj = v[r];
         const double un = cs * (uj - rho * vj);      // L(j,k)
@@ -149,13 +154,13 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
   if (JOINT && !bad) {
     double* __restrict__ pa = a.pacc + (long long)p * 4 * a.pstride;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      const int j = 256 * r + tid;
+      const int j = NT * r + tid;
       if (j >= n && j < N) { pa[j - n] = -bx[r]; pa[a.pstride + j - n] = -b1[r]; pa[2 * a.pstride + j - n] = -bt[r]; pa[3 * a.pstride + j - n] = STORE ? be[r] : 0.0; }
     }
   }
@@ -182,12 +187,15 @@ __global__ __launch_bounds__(256) void k_toep_logpdf(ToepArgs a) {
   }
 }
 
-// Backward substitution L' S = F for the four forward-solved right-hand sides the STORE recursion left (gradient sweeps):
-// S = T^-1 [x, e_first, 1, t - t_ref].  One workgroup per particle, solution entries in registers (element j with thread j % 256),
-// column k of L read once (contiguous), four block-wide dot products per column (wave shuffles + one LDS round).
+// Backward substitution L' S = F for the four forward-solved right-hand sides the STORE recursion left (gradient and predictive
+// sweeps): S = T^-1 [x, e_first, 1, t - t_ref].  One workgroup per particle, solution entries in registers (element j with thread
+// j % 256).  FOUR columns per step: the 16 dot products of their entries below the block with the four solutions are reduced
+// together (independent shuffle chains pipeline; one at a time a column cost ~1 400 clocks of dependent ds_bpermute round trips:
+// 7.6 ms for n = 2048), then every thread solves the block's 4 x 4 triangle itself.  The next block's entries travel under the
+// reduction (the loop's barrier only waits for LDS).
 template <int NR>
 __global__ __launch_bounds__(256) void k_toep_back(ToepArgs a) {
-  __shared__ double red[2][4][4];
+  __shared__ double red[2][4][16];
   const int p = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int n = a.n;
   if (a.out_info[p] != 0) return;                    // (refused by the recursion: the dense path takes the particle)
@@ -198,37 +206,98 @@ __global__ __launch_bounds__(256) void k_toep_back(ToepArgs a) {
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int r = 0; r < NR; ++r) y[m][r] = 0.0;
-  for (int k = n - 1; k >= 0; --k) {
-    const long long coff = (long long)k * n - (long long)k * (k - 1) / 2 - k;
-    double s[4] = {0.0, 0.0, 0.0, 0.0};
-    const int rlo = k >> 8;
+  auto col_off = [&](int k) { return (long long)k * n - (long long)k * (k - 1) / 2 - k; };          // column k, row j at + j
+  // block of columns kb, kb-1, kb-2, kb-3 (c = 0..3; those < 0 do not exist): entries of rows j > kb, the block's own triangle
+  // tri[c][i] = L(kb - i, kb - c), i <= c, and the right-hand-side entries f[c][m]
+  struct Blk { double lc[4][NR]; double tri[4][4]; double f[4][4]; };
+  // (every load is issued unconditionally, from a clamped address, and masked where it is used: with a fixed number of loads per
+  // block the compiler can wait for the OLDER block alone — s_waitcnt vmcnt(58) — while the next one is in flight; with predicated
+  // loads it waited for everything, vmcnt(0), and each block paid a full memory round trip: 10.7 us)
+  auto fetch = [&](int kb, Blk& B) {
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      if (r < rlo) continue;
-      const int j = 256 * r + tid;
-      if (j > k && j < n) {
-        const double lj = Lc[coff + j];
+    for (int c = 0; c < 4; ++c) {
+      const int col = kb - c < 0 ? 0 : kb - c;
+      const long long coff = col_off(col);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) s[m] = fma(lj, y[m][r], s[m]);
+      for (int r = 0; r < NR; ++r) {
+        const int j = 256 * r + tid;
+        B.lc[c][r] = Lc[coff + (j < n ? j : n - 1)];
       }
-    }
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+      for (int i = 0; i < 4; ++i) B.tri[c][i] = Lc[coff + (kb - i < col ? col : kb - i)];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) s[m] += __shfl_xor(s[m], off);
-      if (l == 0) red[k & 1][w][m] = s[m];
+      for (int m = 0; m < 4; ++m) B.f[c][m] = fw[m * a.ldv + col];
     }
-    const double ilkk = 1.0 / Lc[coff + k];
-    __syncthreads();
-    if ((k & 255) == tid) {
-      const int r = k >> 8;
+  };
+  // one block: 16 dot products, a TRANSPOSING reduction (each exchange halves the values a lane carries: 8 + 4 + 2 + 1 + 1 + 1 = 17
+  // shuffles instead of 6 x 16; lane l ends with the total of value 8 b0 + 4 b1 + 2 b2 + b3, b = bits of l), the 4 x 4 triangle
+  auto step = [&](int kb, int it, const Blk& B) {
+    double s[16];
+    // (rows at or above the block, rows beyond n and columns before the first contribute nothing: y is zero beyond n; the rest is
+    // masked here)
+    bool live[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) live[r] = 256 * r + tid > kb;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
-        const double tot = (red[k & 1][0][m] + red[k & 1][1][m]) + (red[k & 1][2][m] + red[k & 1][3][m]);
-        const double val = (fw[m * a.ldv + k] - tot) * ilkk;
+        double t = 0.0;
 #pragma unroll
-        for (int r2 = 0; r2 < NR; ++r2) if (r2 == r) y[m][r2] = val;
+        for (int r = 0; r < NR; ++r) t = fma((live[r] && kb - c >= 0) ? B.lc[c][r] : 0.0, y[m][r], t);
+        s[4 * c + m] = t;
       }
+#pragma unroll
+    for (int lvl = 0; lvl < 4; ++lvl) {
+      const int half = 8 >> lvl, bit = 1 << lvl;
+      const bool up = (l & bit) != 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i < half) {
+          const double send = up ? s[i] : s[i + half];
+          const double keep = up ? s[i + half] : s[i];
+          s[i] = keep + __shfl_xor(send, bit);
+        }
+      }
+    }
+    s[0] += __shfl_xor(s[0], 16);
+    s[0] += __shfl_xor(s[0], 32);
+    if (l < 16) red[it & 1][w][8 * (l & 1) + 4 * ((l >> 1) & 1) + 2 * ((l >> 2) & 1) + ((l >> 3) & 1)] = s[0];
+    lds_barrier();
+    double yb[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool ex = kb - c >= 0;          // (a column before the first: an identity row, nothing is stored for it)
+      const double ild = ex ? 1.0 / B.tri[c][c] : 1.0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        double t = (ex ? B.f[c][m] : 0.0) - ((red[it & 1][0][4 * c + m] + red[it & 1][1][4 * c + m]) + (red[it & 1][2][4 * c + m] + red[it & 1][3][4 * c + m]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) if (i < c) t = fma(ex ? -B.tri[c][i] : 0.0, yb[i][m], t);
+        yb[c][m] = t * ild;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int col = kb - c;
+      if (col >= 0 && (col & 255) == tid) {
+        const int r = col >> 8;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r2 = 0; r2 < NR; ++r2) if (r2 == r) y[m][r2] = yb[c][m];
+      }
+    }
+  };
+  // two buffers take turns (no copies): block kb from X while Y receives block kb - 4
+  Blk X, Y;
+  fetch(n - 1, X);
+  for (int kb = n - 1, it = 0; kb >= 0; kb -= 8, it += 2) {
+    if (kb - 4 >= 0) fetch(kb - 4, Y);
+    step(kb, it, X);
+    if (kb - 4 >= 0) {
+      if (kb - 8 >= 0) fetch(kb - 8, X);
+      step(kb - 4, it + 1, Y);
     }
   }
   double* __restrict__ so = a.sol + (long long)p * 4 * a.ldv;
