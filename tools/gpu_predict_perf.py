@@ -23,5 +23,9 @@ for n, m_extra, P in shapes:
     t0 = time.time(); reps = 3
     for _ in range(reps): mean, var, _, info = eng.predict_batch(nodes, noises, tp, check=False)
     dt = (time.time() - t0) / reps
-    fl = P * (n ** 3 / 3 + n * n * m + n * m * 128)      # factor K11, V = L^-1 K12, diagonal tiles of K22 - V'V (no covariance requested)
-    print(f"predict n={n} m={m} P={P} rank_tables={lat}: {dt*1e3:8.2f} ms  {P/dt:8.0f} particles/s  ~{fl/dt/1e12:5.1f} TF/s  npd={(info>0).sum()}")
+    # (no TF/s figure: particles of the Toeplitz + rank-2 class take the structured pass — O((n + m)^2) — when the conditions of
+    # include/autogp_hip.h hold, the others the dense one: n^3/3 + n^3/3 + n^2 (m - n))
+    ks = eng.predict_structured_particles()
+    eng.predict_batch(nodes, noises, tp, check=False)
+    ks = eng.predict_structured_particles() - ks
+    print(f"predict n={n} m={m} P={P} rank_tables={lat}: {dt*1e3:8.2f} ms  {P/dt:8.0f} particles/s  structured pass: {ks} of {P} particles  npd={(info>0).sum()}")
