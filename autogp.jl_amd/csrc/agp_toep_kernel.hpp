@@ -1,25 +1,32 @@
-// Structured value sweep for regular grids (opt-in: AGP_LAG=2 / agp_set_lag_tables(ctx, 2)).
+// Structured sweeps for regular grids: the Schur algorithm on T + U C U' (value sweeps: opt-in, AGP_LAG=2; gradient and predictive
+// sweeps: default where include/autogp_hip.h says so).
 //
-// On the sorted copy of a regularly sampled series a kernel that is a sum of stationary subtrees and Linear leaves gives
+// On consecutive points of a regularly sampled series, in sorted order, a kernel that is a sum of stationary subtrees and Linear
+// leaves gives
 //     K = T + U C U',   T symmetric Toeplitz (first column r_g = sum of the subtrees' lag tables, + noise at g = 0),
 //     U = [1, t - t_ref],  C = the 2x2 matrix of the Linear leaves (bias + amp (t - c)(t' - c) in that basis),
 // and  log N(x; 0, K)  needs only  log|T|,  B = L^-1 [x, 1, t - t_ref]  (T = L L'):
 //     log|K| = log|T| + log|I + N C|,  x'K^-1 x = b_x'b_x - w'C (I + N C)^-1 w,   N = B_U'B_U,  w = B_U'b_x
 // (matrix determinant lemma + Woodbury, in the UPDATE direction: no cancellation).  The Schur algorithm produces the columns of L
 // one after the other from the generator pair (u, v) of T - Z T Z' = u u' - v v' — a hyperbolic rotation by the reflection
-// coefficient rho_k = v_k / u_k and a shift per column — so L is never stored: column k updates the right-hand sides
+// coefficient rho_k = v_k / u_k and a shift per column — so L need not be stored: column k updates the right-hand sides
 // (column-oriented forward substitution) and is gone.  O(n^2) flops per particle instead of n^3/3; stable for positive definite
 // Toeplitz matrices (Bojanczyk, Brent, de Hoog, Sweet 1995), measured 5e-12 of |logpdf| against the dense factorisation on the
 // benchmark population (cond up to 1e8).  The reference (src/Model.jl:134-136: Gen.mvnormal = dense Cholesky) is what the default
-// path mirrors; this one is what a regular grid allows.
+// value path mirrors; this one is what a regular grid allows.
+//
+//   k_toep_logpdf<NR>                     value sweep: log|T|, L^-1 [x, 1, t], the 2x2 corrections -> logpdf
+//   k_toep_logpdf<NR, STORE>              gradient sweeps: also the columns of L (packed) and L^-1 [x, e_first, 1, t]
+//   k_toep_logpdf<NR, STORE, JOINT, 512>  predictive sweeps: the recursion continues over the future grid points; their rows leave
+//                                         L21 L11^-1 [x, 1, t] and the diagonal of T22 - T21 T11^-1 T12
+//   k_toep_back<NR>                       L' S = F: T^-1 [x, e_first, 1, t] (k_lag_grad / the predictive host code take it from there)
 //
 // One workgroup (NT = 256 threads; 512 for the joint grids of predictive sweeps) per particle, element j of every vector with thread
-// j % NT (register j / NT): v and the three
-// right-hand sides stay in registers in natural coordinates; u lives in LDS at position j - k (it is the vector that shifts:
-// element j reads what element j - 1 wrote one step earlier), pivots and the step's right-hand-side entries go through a
-// double-buffered LDS slot; the pivot L(k,k) and its reciprocal are recurrences every thread carries — ONE barrier per column,
-// no division on the chain.  |rho| >= 1 (not positive definite to rounding) flags the particle: the host
-// repeats it with the dense path in the caller's order, which also supplies LAPACK's info.
+// j % NT (register j / NT): v and the right-hand sides stay in registers in natural coordinates; u lives in LDS at position j - k
+// (it is the vector that shifts: element j reads what element j - 1 wrote one step earlier), pivots and the step's right-hand-side
+// entries go through a double-buffered LDS slot; the pivot L(k,k) and its reciprocal are recurrences every thread carries — ONE
+// barrier per column, no division on the chain.  |rho| >= 1 (not positive definite to rounding) flags the particle: the host repeats
+// it with the dense path in the caller's order, which also supplies LAPACK's info.
 #pragma once
 #include "agp_cov_kernel.hpp"
 
