@@ -392,6 +392,13 @@ def test_predictive_pass_structured(pkg, monkeypatch, case):
                 mu, cv = O.predict_mvn(ks[i].to_tuple(), float(nz[i]), ts[:n], xs[:n], tq, noise_pred=float(npred[i]))
                 assert np.abs(m1[i] - mu).max() <= LP_TOL * max(1.0, np.abs(mu).max()), (case, i)
                 assert np.abs(v1[i] - np.diag(cv)).max() <= LP_TOL * max(1.0, np.abs(cv).max()), (case, i)
+        if case == "train_and_future":
+            a.set_workspace_limit(5 * n * (n + 1) // 2 * 8 + 1)          # five particles per chunk of the structured pass
+            try:
+                m3, v3, _, i3 = a.predict_batch(ks, nz, tq, n=n, noise_pred=npred, check=False)
+            finally:
+                a.set_workspace_limit(0)
+            assert np.array_equal(i1, i3) and np.array_equal(m1[ok], m3[ok]) and np.array_equal(v1[ok], v3[ok])
     finally:
         a.close(); b.close()
 
@@ -672,6 +679,14 @@ def test_gradient_structured_sweep(pkg, monkeypatch, case):
                 assert np.abs(g[i] - go).max() <= 1e-7 * sc and abs(gn[i] - gno) <= 1e-7 * sc and abs(lp[i] - lpo) <= LP_TOL * max(1.0, abs(lpo))
         lp_r, g_r, gn_r, _ = a.logpdf_grad_batch(kernels, noises, n=n, check=False)          # reproducible
         assert np.array_equal(gn[ok], gn_r[ok]) and all(np.array_equal(g[i], g_r[i]) for i in np.flatnonzero(ok))
+        if case == "shapes_full":
+            # a small workspace: the structured sweep runs its particles a few at a time, same bits
+            a.set_workspace_limit(3 * n * (n + 1) // 2 * 8 + 1)
+            try:
+                lp_c, g_c, gn_c, _ = a.logpdf_grad_batch(kernels, noises, n=n, check=False)
+            finally:
+                a.set_workspace_limit(0)
+            assert np.array_equal(lp[ok], lp_c[ok]) and np.array_equal(gn[ok], gn_c[ok]) and all(np.array_equal(g[i], g_c[i]) for i in np.flatnonzero(ok))
     finally:
         a.close(); b.close()
 
