@@ -406,12 +406,14 @@ namespace {
 //   K11^-1 x = alpha = a - W S U'a,   (K11^-1)_uu = (T11^-1)_uu - w_u' S w_u,   (T11^-1)_uu = sum_{i<=u} (x_i^2 - y_i^2) / x_0  (Gohberg-Semencul),
 //   future point f:  mean = m_x - m_U' S U'a + h_f' C (U'a - N S U'a),   var = s_f - noise + r' S r + noise_pred,  r = h_f - m_U
 // (a Gaussian process plus a Bayesian linear model in the basis [1, t]: Rasmussen & Williams (2.42)), S = C (I + N C)^-1, N = U'W;
-// training point u:  mean = x_u - noise alpha_u,  var = noise - noise^2 (K11^-1)_uu + noise_pred  (zero mean functions only).
+// training point u:  mean = x_u - noise alpha_u,  var = noise - noise^2 (K11^-1)_uu + noise_pred  (x: the residual x - mean_train; mean_pred is added to every prediction).
 // qkind[j] >= 0: query j is training point with sorted position qkind[j];  < 0: future point -1 - qkind[j].
 int toeplitz_predict_sweep(agp_ctx* c, int64_t n, int32_t rank0, int mF, const PredLattice& pl, const std::vector<int32_t>& qkind,
                            const std::vector<double>& xq, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                            const double* prm, const double* noise, const double* noise_pred, double* out_mean, double* out_var,
-                           int32_t* out_info) {
+                           int32_t* out_info, const double* xs_sorted_host = nullptr, const double* mean_pred = nullptr) {
+  // xs_sorted_host (nullable): x - mean_train at the n training points in sorted order (mean functions: the recursion then runs on
+  // the residuals; xq holds the same residuals for the observed query points); mean_pred (nullable, per query) is added at the end
   HIPCHK(c, hipSetDevice(c->device));
   const int64_t m = (int64_t)qkind.size();
   Batch bt;
@@ -457,6 +459,10 @@ int toeplitz_predict_sweep(agp_ctx* c, int64_t n, int32_t rank0, int mF, const P
   up.add(s->noise.p, nz.data(), sizeof(double) * (size_t)P);
   up.add(s->pl_prog.p, hp.data(), prog_bytes);
   up.add(s->pl_tl.p, pl.tl.data(), sizeof(double) * pl.tl.size());
+  if (xs_sorted_host) {
+    HIPCHK(c, s->mu1.ensure(sizeof(double) * (size_t)n));
+    up.add(s->mu1.p, xs_sorted_host, sizeof(double) * (size_t)n);
+  }
   HIPCHK(c, up.flush(s->h_stage, st));
   if (bt.n_lag_tables > 0) {
     LagArgs la = {};
@@ -474,7 +480,7 @@ int toeplitz_predict_sweep(agp_ctx* c, int64_t n, int32_t rank0, int mF, const P
   for (int p0 = 0; p0 < P; p0 += chunk) {
     const int Pc = std::min(chunk, P - p0);
     ToepArgs ta = {};
-    ta.xs = c->d_xs_s + rank0; ta.n = (int)n; ta.nj = N; ta.P = Pc; ta.rank0 = rank0;
+    ta.xs = xs_sorted_host ? s->mu1.as<double>() : c->d_xs_s + rank0; ta.n = (int)n; ta.nj = N; ta.P = Pc; ta.rank0 = rank0;
     ta.hdr = s->hdr.as<ProgHdr>() + p0; ta.ops = s->ops.as<uint8_t>(); ta.prm = s->prm.as<double>(); ta.noise = s->noise.as<double>() + p0;
     ta.lagtab = s->lagtab.as<double>(); ta.lag_stride = stride;
     ta.grid_h = h; ta.grid_mid = c->grid_mid; ta.tref = c->t_ref;
@@ -553,6 +559,7 @@ int toeplitz_predict_sweep(agp_ctx* c, int64_t n, int32_t rank0, int mF, const P
           }
           om[j] = mean; ov[j] = var + s2p;
         }
+        if (mean_pred) om[j] += mean_pred[j];
       }
     }
   }
@@ -577,10 +584,10 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
     return fail(c, AGP_ERR_ARG, "null pointer argument");
   if (n > c->n_max) return fail(c, AGP_ERR_NODATA, "n exceeds the data uploaded with agp_set_data");
   HIPCHK(c, hipSetDevice(c->device));
-  // Structured pass (no dense factor; toeplitz_predict_sweep): marginal predictions, zero mean functions, the n training points
+  // Structured pass (no dense factor; toeplitz_predict_sweep): marginal predictions, the n training points
   // consecutive grid points, every query one of them or a grid point after them, nothing resident to start from — the Toeplitz +
   // rank-2 particles of the call go there, the others (and any particle the recursion refuses) through the dense path below.
-  if (!out_cov && !mean_train && !mean_pred && !tl_in_tpredict && c->grad_struct && n >= 256 && n <= 2048 &&
+  if (!out_cov && !tl_in_tpredict && c->grad_struct && n >= 256 && n <= 2048 &&
       !(c->predict_reuse && c->store.n_slots > 0) && (int64_t)c->h_rank.size() >= n) {
     PredLattice plq;
     predict_lattice(c, n, ts_pred, m, plq);
@@ -592,7 +599,7 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
       ok = (int64_t)hi - lo + 1 == n;
     }
     std::vector<int32_t> qkind((size_t)m);
-    std::vector<double> xq((size_t)m, 0.0);
+    std::vector<double> xq((size_t)m, 0.0), xres;          // xres: x - mean_train in sorted order (mean functions)
     int mF = 0;
     if (ok) {
       const int n1_pad = round_up(n, NB);
@@ -601,10 +608,14 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
       for (int64_t j = 0; j < m && ok; ++j) {
         const int32_t r = plq.rank[(size_t)n1_pad + j];
         if (r < lo) { ok = false; break; }          // (a point before the series: the dense path)
-        if (r <= hi) { qkind[(size_t)j] = r - lo; xq[(size_t)j] = c->h_xs[(size_t)at[(size_t)(r - lo)]]; }
+        if (r <= hi) { const int32_t i = at[(size_t)(r - lo)]; qkind[(size_t)j] = r - lo; xq[(size_t)j] = c->h_xs[(size_t)i] - (mean_train ? mean_train[i] : 0.0); }
         else { const int f = r - hi - 1; qkind[(size_t)j] = -1 - f; mF = std::max(mF, f + 1); }
       }
       ok = ok && n + mF <= 4096 && n + mF <= (int64_t)plq.rank_units * 256;
+      if (ok && mean_train) {
+        xres.resize((size_t)n);
+        for (int64_t u = 0; u < n; ++u) { const int32_t i = at[(size_t)u]; xres[(size_t)u] = c->h_xs[(size_t)i] - mean_train[i]; }
+      }
     }
     std::vector<int> part[2];
     if (ok) {
@@ -632,7 +643,8 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
       sT.mean.resize(part[1].size() * (size_t)m); sT.var.resize(part[1].size() * (size_t)m); sT.info.assign(part[1].size(), 0);
       std::thread side([&] {
         sT.rc = toeplitz_predict_sweep(c, n, rank0_abs, mF, plq, qkind, xq, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(),
-                                       sT.sp.data(), sT.nz.data(), sT.nzp.data(), sT.mean.data(), sT.var.data(), sT.info.data());
+                                       sT.sp.data(), sT.nz.data(), sT.nzp.data(), sT.mean.data(), sT.var.data(), sT.info.data(),
+                                       mean_train ? xres.data() : nullptr, mean_pred);
       });
       auto dense = [&](const std::vector<int>& ix) {
         if (ix.empty()) return 0;
@@ -640,7 +652,7 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
         sD.mean.resize(ix.size() * (size_t)m); sD.var.resize(ix.size() * (size_t)m); sD.info.assign(ix.size(), 0);
         tl_in_tpredict = true;
         const int rc0 = agp_predict_batch(c, n, ts_pred, m, (int32_t)ix.size(), sD.oo.data(), sD.so.data(), sD.po.data(), sD.sp.data(), sD.nz.data(),
-                                          sD.nzp.data(), nullptr, nullptr, sD.mean.data(), sD.var.data(), nullptr, sD.info.data());
+                                          sD.nzp.data(), mean_train, mean_pred, sD.mean.data(), sD.var.data(), nullptr, sD.info.data());
         tl_in_tpredict = false;
         if (rc0) return rc0;
         for (size_t b = 0; b < ix.size(); ++b) {

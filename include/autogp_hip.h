@@ -190,7 +190,7 @@ int agp_get_lag_rank_stats(agp_ctx* ctx, int64_t* n_sweeps);
  * the calls that took it. */
 int agp_get_lag_predict_stats(agp_ctx* ctx, int64_t* n_passes);
 /* ... and where, in addition, the n training points are consecutive grid points (256 <= n <= 2048), every query point is one of them
- * or a grid point after them (n + future points <= 4096), no covariance and no mean function is requested and nothing is resident in
+ * or a grid point after them (n + future points <= 4096), no covariance is requested and nothing is resident in
  * the factor store, the particles whose kernel is a sum of stationary subtrees and Linear leaves (at least 32 of them) need no dense
  * factor: one Schur recursion over the JOINT grid leaves L21 L11^-1 [x, 1, t] and the diagonal of T22 - T21 T11^-1 T12 per future
  * point, a backward substitution T11^-1 [x, e_first, 1, t]; predictions at training points come from alpha and diag(K11^-1)

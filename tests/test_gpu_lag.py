@@ -332,7 +332,7 @@ def test_predictive_pass_on_training_point_queries(pkg, case):
         e.close()
 
 
-@pytest.mark.parametrize("case", ["train_and_future", "future_only", "train_only", "prefix_in_time_order", "population_2048", "backcast", "refused"])
+@pytest.mark.parametrize("case", ["train_and_future", "means", "future_only", "train_only", "prefix_in_time_order", "population_2048", "backcast", "refused"])
 def test_predictive_pass_structured(pkg, monkeypatch, case):
     """Predictive pass WITHOUT a dense factor for the Toeplitz + rank-2 class (csrc/agp_predict.hip toeplitz_predict_sweep: joint
     Schur recursion, backward substitution, Gohberg-Semencul diagonal, Bayesian linear model for the Linear leaves): training points
@@ -369,14 +369,18 @@ def test_predictive_pass_structured(pkg, monkeypatch, case):
     if case == "refused":
         ks = [G.SquaredExponential(5.0, 1.0)] + ks; nz = np.concatenate([[0.0], nz]); npred = np.concatenate([[0.1], npred]); n_cls = n_cls  # particle 0: singular
     xs = np.cos(9 * ts) + 0.3 * ts + 0.1 * rng.standard_normal(ts.size)
+    kw = {}; mean_fn = None
+    if case == "means":
+        mean_fn = lambda t: 0.4 - 1.3 * t
+        kw = dict(mean_train=np.array([mean_fn(t) for t in ts[:n]]), mean_pred=np.array([mean_fn(t) for t in tq]))
     a = pkg.GPEngine(0)
     monkeypatch.setenv("AGP_GRAD_FFT", "2")
     b = pkg.GPEngine(0)
     monkeypatch.delenv("AGP_GRAD_FFT")
     try:
         a.set_data(ts, xs); b.set_data(ts, xs)
-        m1, v1, _, i1 = a.predict_batch(ks, nz, tq, n=n, noise_pred=npred, check=False)
-        m2, v2, _, i2 = b.predict_batch(ks, nz, tq, n=n, noise_pred=npred, check=False)
+        m1, v1, _, i1 = a.predict_batch(ks, nz, tq, n=n, noise_pred=npred, check=False, **kw)
+        m2, v2, _, i2 = b.predict_batch(ks, nz, tq, n=n, noise_pred=npred, check=False, **kw)
         k = a.predict_structured_particles()
         assert b.predict_structured_particles() == 0
         if n_cls is None: assert k >= len(ks) // 2
@@ -389,7 +393,7 @@ def test_predictive_pass_structured(pkg, monkeypatch, case):
         assert (np.abs(v1[ok] - v2[ok]) / np.maximum(1.0, v2[ok])).max() <= 1e-9
         if n <= 420:
             for i in list(range(1 if case == "refused" else 0, 6)) + [len(ks) - 1]:
-                mu, cv = O.predict_mvn(ks[i].to_tuple(), float(nz[i]), ts[:n], xs[:n], tq, noise_pred=float(npred[i]))
+                mu, cv = O.predict_mvn(ks[i].to_tuple(), float(nz[i]), ts[:n], xs[:n], tq, noise_pred=float(npred[i]), mean=mean_fn)
                 assert np.abs(m1[i] - mu).max() <= LP_TOL * max(1.0, np.abs(mu).max()), (case, i)
                 assert np.abs(v1[i] - np.diag(cv)).max() <= LP_TOL * max(1.0, np.abs(cv).max()), (case, i)
         if case == "train_and_future":
