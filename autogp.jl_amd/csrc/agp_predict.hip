@@ -588,7 +588,9 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
   // consecutive grid points, every query one of them or a grid point after them, nothing resident to start from — the Toeplitz +
   // rank-2 particles of the call go there, the others (and any particle the recursion refuses) through the dense path below.
   if (!out_cov && !tl_in_tpredict && c->grad_struct && n >= 256 && n <= 2048 &&
-      !(c->predict_reuse && c->store.n_slots > 0) && (int64_t)c->h_rank.size() >= n) {
+      // (with factors resident, starting from them costs (n / 2048)^3 x ~14 ms of L^-T per 256 particles: the two sequential passes of
+      // the structured sweep, ~3.8 us per point, are cheaper from n ~ 768 on)
+      (!(c->predict_reuse && c->store.n_slots > 0) || n >= 768) && (int64_t)c->h_rank.size() >= n) {
     PredLattice plq;
     predict_lattice(c, n, ts_pred, m, plq);
     int32_t lo = 0, hi = 0;

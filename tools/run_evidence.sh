@@ -19,7 +19,7 @@ python tools/gpu_grad_perf.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_per
 python tools/gpu_grad_lagdom_check.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_lagdom_check.txt; tail -1 gpurun_out/${TAG}_grad_lagdom_check.txt
 # sources of the lag sums: Toeplitz solves / spectra of L^-T / element-wise, accuracy against the element-wise contraction; phases of the element-wise sweep
 (python tools/gpu_grad_toeplitz_check.py; python tools/gpu_grad_phases.py) 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_toeplitz_check.txt; cat gpurun_out/${TAG}_grad_toeplitz_check.txt
-(python tools/run_stream.py --rejuvenate; python tools/run_stream.py --rejuvenate --no-extend; python tools/run_stream.py --rejuvenate --predict; AGP_PREDICT_REUSE=0 python tools/run_stream.py --rejuvenate --predict) 2>&1 | grep -v amdgpu | grep "^{" > gpurun_out/${TAG}_stream.jsonl; cut -c1-200 gpurun_out/${TAG}_stream.jsonl
+(python tools/run_stream.py --rejuvenate; python tools/run_stream.py --rejuvenate --no-extend; python tools/run_stream.py --rejuvenate --predict; AGP_PREDICT_REUSE=0 python tools/run_stream.py --rejuvenate --predict; python tools/run_stream.py --rejuvenate --predict --time-order) 2>&1 | grep -v amdgpu | grep "^{" > gpurun_out/${TAG}_stream.jsonl; cut -c1-200 gpurun_out/${TAG}_stream.jsonl
 python tools/gpu_scratch_via_store.py 2>&1 | grep "^n=" > gpurun_out/${TAG}_store_scratch.txt; cat gpurun_out/${TAG}_store_scratch.txt
 (for T in 64 512; do tools/native/hmc_replay 2048 $T 2; tools/native/hmc_replay 2048 $T 2 10 0.02 grid; AGP_FACTOR_CACHE=0 tools/native/hmc_replay 2048 $T 2; done; tools/native/hmc_replay 512 256 4; tools/native/threads_bench 2048 512 8; tools/native/threads_bench 2048 64 8; tools/native/threads_bench 2048 512 4 grad) 2>&1 | grep "^{" > gpurun_out/${TAG}_native.jsonl; cut -c1-220 gpurun_out/${TAG}_native.jsonl
 # stand-alone diagonal-tile harness (per-phase clocks), predictive passes, extension sweeps alone, dataflow traces (measurement library)

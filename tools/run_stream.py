@@ -14,7 +14,10 @@ predict = "--predict" in sys.argv
 rejuv = "--rejuvenate" in sys.argv      # stand-in for the MCMC / HMC moves: every particle gets new parameter values each step
 extend = "--no-extend" not in sys.argv
 P = 256; n_max = 2048
-ts, xs = pkg.prior.synthetic_series(n_max, seed=128, shuffle=True)
+# --time-order: the observations arrive in time order, as in scripts/online.jl (every prefix is a run of consecutive grid points);
+# default: a shuffled grid (prefixes are arbitrary subsets: the general case of the rank-table paths)
+time_order = "--time-order" in sys.argv
+ts, xs = pkg.prior.synthetic_series(n_max, seed=128, shuffle=not time_order)
 nodes, noises = pkg.prior.sample_particles(np.random.default_rng(128), P, max_depth=-1, max_size=63)
 eng = pkg.GPEngine(lrank)
 gather = None; gather_obj = None
@@ -67,7 +70,7 @@ for rep in range(2):          # first pass warms the allocations up
             tq = np.concatenate([ts[:min(n + 128, n_max)], future])        # observed + next + future, as the callback does
             st.predict_block(eng, tq, n); t_pred.append((time.perf_counter() - b) * 1e3)
     total = time.perf_counter() - t0
-    res = {"config": "online stream n=128..2048 x16, P=256", "n_gpus": world, "extend": extend, "predict_callback": predict, "rejuvenate_stand_in": rejuv,
+    res = {"config": "online stream n=128..2048 x16, P=256", "time_order": time_order, "n_gpus": world, "extend": extend, "predict_callback": predict, "rejuvenate_stand_in": rejuv,
            "total_ms": total * 1e3, "step_ms": t_steps, "predict_ms_per_step": t_pred,
            "resampled_steps": [h["n"] for h in st.history if h["resampled"]], "log_ml_est": st.log_ml_estimate(),
            "store": eng.extend_stats()}
