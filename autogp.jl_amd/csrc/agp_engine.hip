@@ -818,7 +818,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       // with their own waves and only delay the dense kernels: 8.6 -> 9.2 ms — those go first, alone)
       const bool side_by_side = part[1].size() <= 256;
       std::thread side;
-      if (side_by_side) side = std::thread(structured); else structured();
+      if (side_by_side) { try { side = std::thread(structured); } catch (const std::system_error&) { structured(); } } else structured();
       auto dense = [&](const std::vector<int>& ix) {
         if (ix.empty()) return 0;
         gather(ix, sD.oo, sD.so, sD.po, sD.sp, sD.nz);
@@ -952,7 +952,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         return 0;
       };
       gather(part[1], sT);
-      std::thread side([&] {
+      Beside side([&] {
         sT.rc = toeplitz_grad_sweep(c, n, toep_rank0, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(), sT.sp.data(), sT.nz.data(),
                                     sT.lp.data(), sT.info.data(), sT.grad.data(), sT.gn.data());
       });

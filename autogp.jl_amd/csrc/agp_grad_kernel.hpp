@@ -142,16 +142,21 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
   const int lsl = a.lslot != nullptr ? a.lslot[p] : -1;
   const double* __restrict__ Lp = lsl >= 0 ? a.Lsrc + (long long)lsl * a.Lstride : a.A + (long long)p * a.strideA;
   const double* __restrict__ Wp = lsl >= 0 ? a.Wsrc + (long long)lsl * a.Wnt * NSB * 256 : a.W + (long long)p * a.nt * NSB * 256;
-  double* __restrict__ Zp = a.Z + (long long)p * (a.strideZ ? a.strideZ : a.strideA);
+  const bool zres = lsl >= 0 && a.Zsrc != nullptr;          // Z lives in the factor store beside L
+  double* __restrict__ Zp = zres ? a.Zsrc + (long long)lsl * a.Zstride : a.Z + (long long)p * (a.strideZ ? a.strideZ : a.strideA);
+  const int zi0 = zres ? a.zi0[p] : 0;                       // tile columns of Z already resident
+  const int i_start = j > zi0 ? j : zi0;
   // alpha_j = sum_{i >= j} Z(j,i) beta_i is formed here, from the tiles while they are in registers (a separate pass over Z
   // — k_alpha, what the per-column variant runs — read all 9 GB of it again: 2.3 ms per 512-particle sweep at n=2048)
   const double* __restrict__ bp = a.beta + (long long)p * a.ldv;
   double al0 = 0.0, al1 = 0.0;
+  if (i_start > j && lq == 0) { al0 = a.zalpha[(long long)lsl * a.zld + j * NB + row0]; al1 = a.zalpha[(long long)lsl * a.zld + j * NB + row0 + 1]; }          // (the resident columns' share)
   // ... and diag(K^-1)_r = sum_c Z_rc^2 (K^-1 = Z Z^T) for the predictive shortcut at observed points (agp_predict.hip)
   constexpr bool want_d = WANT_D;
   double dz0 = 0.0, dz1 = 0.0;
+  if (want_d && i_start > j && lq == 0) { dz0 = a.zdinv[(long long)lsl * a.zld + j * NB + row0]; dz1 = a.zdinv[(long long)lsl * a.zld + j * NB + row0 + 1]; }
 #pragma unroll 1
-  for (int i = j; i < a.nt; ++i) {
+  for (int i = i_start; i < a.nt; ++i) {
     // acc = -C,  C = d_ji I - sum_{k=j}^{i-1} Z(j,k) L(i,k)^T
     d4 acc[NSB][2];
 #pragma unroll
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
   if (lq == 0) {
     d2 o2; o2.x = al0; o2.y = al1;
     *reinterpret_cast<d2*>(a.alpha + (long long)p * a.ldv + j * NB + row0) = o2;
+    if (zres) *reinterpret_cast<d2*>(a.zalpha + (long long)lsl * a.zld + j * NB + row0) = o2;
   }
   if (want_d) {
     dz0 += __shfl_xor(dz0, 16); dz1 += __shfl_xor(dz1, 16);
@@ -191,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
     if (lq == 0) {
       d2 o2; o2.x = dz0; o2.y = dz1;
       *reinterpret_cast<d2*>(a.dinv + (long long)p * a.ldv + j * NB + row0) = o2;
+      if (zres) *reinterpret_cast<d2*>(a.zdinv + (long long)lsl * a.zld + j * NB + row0) = o2;
     }
   }
 }

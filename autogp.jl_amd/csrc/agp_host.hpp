@@ -19,6 +19,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -223,6 +224,11 @@ struct agp_ctx {
     int n_slots = 0;
     long long strideA = 0;              // doubles per slot
     DevBuf A, W, vec, partial, info, ready, tflag, flowq;
+    // L^-T of the resident factors, kept by the predictive passes that start from them (allocated on their first use): Z in A's layout,
+    // the rows' running alpha = Z beta and diag(K^-1), and how many tile columns of Z each slot holds (<= its factor's tile rows)
+    DevBuf Z, zalpha, zdinv;
+    std::vector<int32_t> zrows;
+    void z_release() { Z.release(); zalpha.release(); zdinv.release(); std::fill(zrows.begin(), zrows.end(), 0); }
     std::vector<std::string> key;       // per slot; empty = free
     std::vector<int64_t> n_cached;      // observations the slot's factor covers
     std::vector<uint64_t> stamp;        // last use (LRU)
@@ -233,8 +239,8 @@ struct agp_ctx {
     double max_frac = 0.45;             // share of the device memory the store may take
     std::atomic<size_t> footprint{0};   // bytes the store holds right now (read by ws_limit_bytes without the lock)
     size_t failed_bytes = 0;            // size of the last (re)allocation that failed: not retried at that size or above
-    void forget() { failed_bytes = 0; index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); }
-    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); n_slots = 0; nt_cap = 0; footprint = 0; failed_bytes = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); }
+    void forget() { failed_bytes = 0; index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); std::fill(zrows.begin(), zrows.end(), 0); }
+    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); z_release(); zrows.clear(); n_slots = 0; nt_cap = 0; footprint = 0; failed_bytes = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); }
   } store;
   // ---- RCCL communicator of the particle-sharded deployment (agp_comm_init_rank / agp_init_multi) ----
   ncclComm_t comm = nullptr;
@@ -371,6 +377,16 @@ inline bool use_right_looking(const agp_ctx* c, int P) {
 struct GradOut {
   double* grad;      // host, caller's parameter layout (prm_off), d logpdf / d parameter
   double* gnoise;    // host [P], d logpdf / d noise
+};
+
+// f on a helper thread beside the caller's own work; here and now if no thread can be had (the caller joins either way)
+struct Beside {
+  std::thread th;
+  template <class F> explicit Beside(F&& f) {
+    try { th = std::thread(f); } catch (const std::system_error&) { f(); }
+  }
+  void join() { if (th.joinable()) th.join(); }
+  ~Beside() { join(); }
 };
 
 // a sum (top-level + chain) of Linear leaves and subtrees without Linear / ChangePoint: Toeplitz + rank 2 on consecutive grid points

@@ -189,11 +189,33 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
   }
 
   const int32_t* d_src = nullptr; const int32_t* d_i0 = nullptr;
+  // Resident L^-T: a pass that starts from resident factors AND serves observed points from alpha / diag(K11^-1) keeps Z = L^-T in
+  // the store beside L (same layout) with the rows' running sums — the next pass on a longer prefix (the per-step callback of a
+  // stream, scripts/online.jl:43) forms the new tile columns of Z only: nt^2/2 tile products instead of nt^3/6.
+  bool zstore = false;
+  std::vector<int32_t> zi0v;
+  const int32_t* d_zi0 = nullptr;
+  if (n_hit > 0 && diag_path) {
+    agp_ctx::FactorStore& fs = c->store;
+    const size_t before = fs.Z.cap + fs.zalpha.cap + fs.zdinv.cap;
+    const size_t rowb = sizeof(double) * (size_t)fs.nt_cap * NB * (size_t)fs.n_slots;
+    zstore = fs.Z.ensure((size_t)fs.strideA * 8 * (size_t)fs.n_slots) == hipSuccess && fs.zalpha.ensure(rowb) == hipSuccess &&
+             fs.zdinv.ensure(rowb) == hipSuccess;
+    if (!zstore) { (void)hipGetLastError(); fs.z_release(); }
+    const size_t after = fs.Z.cap + fs.zalpha.cap + fs.zdinv.cap;
+    fs.footprint = fs.footprint.load() + after - std::min(before, after);
+    if (zstore) {
+      if (fs.zrows.size() != (size_t)fs.n_slots) fs.zrows.assign((size_t)fs.n_slots, 0);
+      zi0v.assign((size_t)P, 0);
+      for (int q = 0; q < P; ++q) if (src_slot[(size_t)q] >= 0) zi0v[(size_t)q] = fs.zrows[(size_t)src_slot[(size_t)q]];
+    }
+  }
   if (n_hit > 0) {
-    HIPCHK(c, s->stage.ensure(sizeof(int32_t) * 2 * (size_t)P));
+    HIPCHK(c, s->stage.ensure(sizeof(int32_t) * 3 * (size_t)P));
     int32_t* d = s->stage.as<int32_t>();
     up.add(d, src_slot.data(), sizeof(int32_t) * P);
     up.add(d + P, i0v.data(), sizeof(int32_t) * P);
+    if (zstore) { up.add(d + 2 * P, zi0v.data(), sizeof(int32_t) * P); d_zi0 = d + 2 * P; }
     d_src = d; d_i0 = d + P;
   }
   if (!lagr) HIPCHK(c, up.flush(s->h_stage, st));
@@ -256,8 +278,8 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       HIPCHK(c, hipGetLastError());
       // (Reading L11 and the inverse blocks in place — a second base pointer for the training rows in chol_tile — was
       // measured: the streamed config 5 went 412 -> 406 ms, the dataflow kernel gained 4 spilled VGPRs; the copy stays.)
-      if (p0 + chunk >= P) {
-        // the store may change again once the last copy has been made
+      if (p0 + chunk >= P && !zstore) {
+        // the store may change again once the last copy has been made (resident L^-T: once its new columns are in, below)
         HIPCHK(c, hipStreamSynchronize(st));
         store_lk.unlock();
       }
@@ -313,7 +335,19 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
       ga.A = s->A.as<double>(); ga.strideA = strideA; ga.Z = s->Z.as<double>(); ga.strideZ = strideZ; ga.W = s->W.as<double>();
       ga.beta = s->vec.as<double>(); ga.alpha = s->alpha.as<double>(); ga.dinv = s->gpart.as<double>(); ga.ldv = ntot;
       ga.P = Pc; ga.nt = nt1; ga.n = (int)n;
+      if (zstore) {
+        agp_ctx::FactorStore& fs = c->store;
+        ga.lslot = d_src + p0; ga.Lsrc = fs.A.as<double>(); ga.Lstride = fs.strideA; ga.Wsrc = fs.W.as<double>(); ga.Wnt = fs.nt_cap;
+        ga.Zsrc = fs.Z.as<double>(); ga.Zstride = fs.strideA; ga.zi0 = d_zi0 + p0;
+        ga.zalpha = fs.zalpha.as<double>(); ga.zdinv = fs.zdinv.as<double>(); ga.zld = (long long)fs.nt_cap * NB;
+      }
       launch_trtri_chain(st, 8 * ((Pc + 7) / 8) * nt1, ga);
+      if (zstore && p0 + chunk >= P) {
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(st));
+        for (int q = 0; q < P; ++q) if (src_slot[(size_t)q] >= 0) c->store.zrows[(size_t)src_slot[(size_t)q]] = nt1;
+        store_lk.unlock();
+      }
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipMemcpyAsync(const_cast<double*>(h_alpha), s->alpha.p, sizeof(double) * ntot * Pc, hipMemcpyDeviceToHost, st));
       HIPCHK(c, hipMemcpyAsync(const_cast<double*>(h_dinv), s->gpart.p, sizeof(double) * ntot * Pc, hipMemcpyDeviceToHost, st));
@@ -643,7 +677,7 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
       struct Sub { std::vector<int32_t> oo, po, info; std::vector<uint8_t> so; std::vector<double> sp, nz, nzp, mean, var; int rc = 0; } sT, sD;
       gather(part[1], sT.oo, sT.so, sT.po, sT.sp, sT.nz, sT.nzp);
       sT.mean.resize(part[1].size() * (size_t)m); sT.var.resize(part[1].size() * (size_t)m); sT.info.assign(part[1].size(), 0);
-      std::thread side([&] {
+      Beside side([&] {
         sT.rc = toeplitz_predict_sweep(c, n, rank0_abs, mF, plq, qkind, xq, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(),
                                        sT.sp.data(), sT.nz.data(), sT.nzp.data(), sT.mean.data(), sT.var.data(), sT.info.data(),
                                        mean_train ? xres.data() : nullptr, mean_pred);

@@ -74,6 +74,7 @@ int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
   for (int sl = n_slots; sl < fs.n_slots; ++sl)
     if (!fs.key[sl].empty()) fs.index.erase(fs.key[sl]);
   fs.key.resize((size_t)n_slots); fs.n_cached.resize((size_t)n_slots, 0); fs.stamp.resize((size_t)n_slots, 0);
+  fs.z_release(); fs.zrows.assign((size_t)n_slots, 0);          // (the resident L^-T does not survive a resize: rare, rebuilt on demand)
   fs.info_h.resize((size_t)n_slots, 0);
   fs.nt_cap = nt_cap; fs.n_slots = n_slots; fs.strideA = strideA;
   fs.footprint = A.cap + W.cap + vec.cap + partial.cap + info.cap + ready.cap + fs.tflag.cap + fs.flowq.cap;
@@ -195,6 +196,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
       slot[u] = sl; i0[u] = 0;
     }
   }
+  // (a slot's resident L^-T covers at most the tile rows of L that stay as they are)
+  for (int u = 0; u < U; ++u) fs.zrows[(size_t)slot[u]] = std::min(fs.zrows[(size_t)slot[u]], i0[u]);
   // from here on the touched slots are in flux: forget them on any failure
   auto poison = [&]() {
     for (int u = 0; u < U; ++u) {

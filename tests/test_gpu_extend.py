@@ -427,3 +427,45 @@ def test_single_particle_calls_use_the_store(pkg, monkeypatch):
         assert e.extend_stats() == before and abs(a3 - e0.logpdf(k, 0.08, n=700)) <= 1e-11 * abs(a3)
     finally:
         e.close(); e0.close()
+
+
+def test_predictive_passes_keep_the_inverse_factor_resident(pkg):
+    """The per-step callback of a stream (scripts/online.jl:43,59): predictive passes that start from resident factors and serve the
+    observed points from alpha / diag(K11^-1) keep Z = L^-T in the store; after the next extension only the new tile columns of Z are
+    formed.  Same predictions as an engine without a store (1e-11), across two extensions, a rejuvenated particle (new parameters:
+    from scratch), a shorter prefix (factors redone) and agp_extend_reset."""
+    n_max = 1024
+    ts, xs = pkg.prior.synthetic_series(n_max, seed=33, shuffle=True)
+    nodes, nz = pkg.prior.sample_particles(np.random.default_rng(21), 48, max_depth=3)
+    grid = np.sort(ts); h = grid[1] - grid[0]
+    fut = grid[-1] + h * np.arange(1, 65)
+    a = pkg.GPEngine(0); b = pkg.GPEngine(0)
+    try:
+        a.set_data(ts, xs); b.set_data(ts, xs)
+        b.set_factor_cache(False)
+
+        def check(n, nd, zz):
+            tq = np.concatenate([ts[:min(n + 128, n_max)], fut])
+            a.logpdf_batch_extend(nd, zz, n=n, check=False)
+            r0 = a.predict_reuse_stats()["reused"]
+            m1, v1, _, i1 = a.predict_batch(nd, zz, tq, n=n, check=False)
+            assert a.predict_reuse_stats()["reused"] > r0
+            m2, v2, _, i2 = b.predict_batch(nd, zz, tq, n=n, check=False)
+            assert b.predict_reuse_stats()["reused"] == 0 and np.array_equal(i1, i2)
+            ok = i1 == 0
+            sc = np.maximum(1.0, np.abs(m2[ok]).max(axis=1))[:, None]
+            assert (np.abs(m1[ok] - m2[ok]) / sc).max() <= 1e-11 and (np.abs(v1[ok] - v2[ok]) / np.maximum(1.0, v2[ok])).max() <= 1e-11
+            # ... and once more: everything resident now, nothing to add
+            m3, v3, _, _ = a.predict_batch(nd, zz, tq, n=n, check=False)
+            assert np.array_equal(m1[ok], m3[ok]) and np.array_equal(v1[ok], v3[ok])
+
+        check(384, nodes, nz)
+        check(640, nodes, nz)                      # two new tile rows of L, two new tile columns of Z
+        nodes2 = list(nodes); nodes2[3] = pkg.SquaredExponential(0.21, 0.9) + pkg.Linear(0.1, 0.2, 0.4)      # a rejuvenated particle
+        check(768, nodes2, nz)
+        check(700, nodes2, nz)                     # a partial last tile row: redone, Z follows
+        check(512, nodes2, nz)                     # a shorter prefix: the factors are redone
+        a.extend_reset()
+        check(1024, nodes2, nz)
+    finally:
+        a.close(); b.close()
