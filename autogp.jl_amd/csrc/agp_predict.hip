@@ -438,7 +438,7 @@ namespace {
 // future point, L21 L11^-1 [x, 1, t] and the diagonal of T22 - T21 T11^-1 T12 (k_toep_logpdf<.., JOINT>); the backward substitution
 // over the training block gives T11^-1 [x, e_first, 1, t].  The rest is O(n + m) per particle on the host:
 //   K11^-1 x = alpha = a - W S U'a,   (K11^-1)_uu = (T11^-1)_uu - w_u' S w_u,   (T11^-1)_uu = sum_{i<=u} (x_i^2 - y_i^2) / x_0  (Gohberg-Semencul),
-//   future point f:  mean = m_x - m_U' S U'a + h_f' C (U'a - N S U'a),   var = s_f - noise + r' S r + noise_pred,  r = h_f - m_U
+//   future point f:  mean = m_x + r' S U'a  (= m_x - m_U' S U'a + h_f' C U'alpha, since C (I - N S) = S),   var = s_f - noise + r' S r + noise_pred,  r = h_f - m_U
 // (a Gaussian process plus a Bayesian linear model in the basis [1, t]: Rasmussen & Williams (2.42)), S = C (I + N C)^-1, N = U'W;
 // training point u:  mean = x_u - noise alpha_u,  var = noise - noise^2 (K11^-1)_uu + noise_pred  (x: the residual x - mean_train; mean_pred is added to every prediction).
 // qkind[j] >= 0: query j is training point with sorted position qkind[j];  < 0: future point -1 - qkind[j].
@@ -563,7 +563,6 @@ int toeplitz_predict_sweep(agp_ctx* c, int64_t n, int32_t rank0, int mF, const P
       const double i00 = t11 * idet, i01 = -t01 * idet, i10 = -t10 * idet, i11 = t00 * idet;
       const double S00 = C00 * i00 + C01 * i10, S01 = C00 * i01 + C01 * i11, S11 = C01 * i01 + C11 * i11;
       const double as0 = S00 * ux0 + S01 * ux1, as1 = S01 * ux0 + S11 * ux1;
-      const double ga0 = ux0 - (N00 * as0 + N01 * as1), ga1 = ux1 - (N01 * as0 + N11 * as1);          // U' alpha
       // diag(T11^-1) by Gohberg-Semencul (cumulative), alpha
       {
         const double ix0 = 1.0 / x_[0];
@@ -588,7 +587,7 @@ int toeplitz_predict_sweep(agp_ctx* c, int64_t n, int32_t rank0, int mF, const P
           if (lin) {
             const double tf = tau_of((int)n + f);
             const double r0_ = 1.0 - m1[f], r1_ = tf - mt[f];
-            mean += -(m1[f] * as0 + mt[f] * as1) + (C00 * ga0 + C01 * ga1) + tf * (C01 * ga0 + C11 * ga1);
+            mean += r0_ * as0 + r1_ * as1;     // h_f' C U'alpha = h_f' S U'a exactly (C (I - N S) = S): no difference of near-equal terms
             var += r0_ * (S00 * r0_ + S01 * r1_) + r1_ * (S01 * r0_ + S11 * r1_);
           }
           om[j] = mean; ov[j] = var + s2p;

@@ -1,0 +1,122 @@
+"""Randomised soak test of the structured (Toeplitz + rank 2) sweeps on the GPU box: regular grids of random length, order
+(shuffled / time order), offset and prefix; prior-sampled populations.  One engine runs with the structured sweeps forced
+(AGP_GRAD_FFT=4, set_lag_tables(3): no population-size thresholds), a second one with AGP_GRAD_FFT=0
+AGP_GRAD_LAGDOM=0 AGP_LAG=0 (dense factorisation, element-wise gradient, dense predictive pass); the two are compared on
+every particle and against the oracle on a few.  Usage: gpu_fuzz_structured.py [cases] [seed]"""
+import os, sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as g
+from oracle import oracle as O
+
+
+def predict_longdouble(tree, noise, ts, xs, tp):
+    """Predictive mean / marginal variance with the factorisation and the solves in 80-bit arithmetic (covariance entries from
+    the oracle in double): decides which of two double-precision paths lost the digits when they disagree."""
+    n = ts.shape[0]
+    K = O.compute_cov_matrix_vectorized(tree, 0.0, np.concatenate([ts, tp])).astype(np.longdouble)
+    A = K[:n, :n] + np.longdouble(noise) * np.eye(n, dtype=np.longdouble)
+    L = np.zeros_like(A)
+    for j in range(n):
+        d = A[j, j] - L[j, :j] @ L[j, :j]
+        L[j, j] = np.sqrt(d)
+        L[j + 1:, j] = (A[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+    B = np.concatenate([xs.astype(np.longdouble)[:, None], K[:n, n:]], axis=1)
+    for j in range(n):
+        B[j] = (B[j] - L[j, :j] @ B[:j]) / L[j, j]
+    mean = B[:, 1:].T @ B[:, 0]
+    var = np.diag(K[n:, n:]) - (B[:, 1:] ** 2).sum(axis=0) + np.longdouble(noise)
+    return mean.astype(np.float64), var.astype(np.float64)
+
+
+def run(pkg, cases=40, seed=1):
+    os.environ["AGP_GRAD_FFT"] = "4"          # structured gradient sweeps whatever the population size
+    eng = pkg.GPEngine(0)
+    for k, v in (("AGP_GRAD_FFT", "0"), ("AGP_GRAD_LAGDOM", "0"), ("AGP_LAG", "0")): os.environ[k] = v
+    ref = pkg.GPEngine(0)
+    for k in ("AGP_GRAD_FFT", "AGP_GRAD_LAGDOM", "AGP_LAG"): del os.environ[k]
+    rng = np.random.default_rng(seed)
+    t0 = time.time(); w_val = w_grad = w_pred = w_or = 0.0; n_sv = n_sg = n_sp = 0; n_bad = 0; n_dis = 0
+    for c in range(cases):
+        N = int(rng.choice([256, 300, 511, 512, 640, 777, 1024, 1100, 1536, 2048]))
+        P = int(rng.choice([33, 64, 100, 129, 256])) if N <= 1024 else int(rng.choice([33, 64, 96]))
+        ts, xs = pkg.prior.synthetic_series(N, seed=int(rng.integers(1 << 30)), shuffle=bool(rng.integers(2)))
+        if rng.random() < 0.25: ts = ts * float(rng.choice([3.0, 0.37])) + float(rng.choice([0.5, -1.0, 2.0]))   # other origin / spacing
+        nodes, noises = pkg.prior.sample_particles(rng, P, max_depth=int(rng.integers(1, 5)), max_size=31)
+        n = N if rng.random() < 0.6 else int(rng.integers(256, N + 1))           # annealing prefix (time order: consecutive points)
+        eng.set_data(ts, xs); ref.set_data(ts, xs)
+        # ---- value: structured sweep against the dense one ----
+        lp0, i0 = ref.logpdf_batch(nodes, noises, n=n, check=False)
+        eng.set_lag_tables(3)
+        s0 = eng.toeplitz_particles()
+        lp1, i1 = eng.logpdf_batch(nodes, noises, n=n, check=False)
+        n_sv += eng.toeplitz_particles() - s0
+        eng.set_lag_tables(1)
+        ok = (i0 == 0) & (i1 == 0); n_bad += int((i0 != 0).sum())
+        # (a particle that is indefinite to rounding may be rejected by one path only; values are compared where both accept)
+        assert (i0 != i1).sum() <= max(2, P // 20), ("value info", c, N, n, P, np.flatnonzero(i0 != i1))
+        if ok.any():
+            e = np.abs(lp1[ok] - lp0[ok]) / np.maximum(1.0, np.abs(lp0[ok])); w_val = max(w_val, e.max())
+            assert e.max() <= 1e-8, ("value", c, N, n, P, int(np.argmax(e)), e.max())
+        # ---- gradient: structured sweep (empty store) against the element-wise one ----
+        sel = [j for j in range(P) if nodes[j].size() <= 63]
+        eng.extend_reset(); ref.extend_reset()
+        s0 = eng.grad_structured_particles()
+        g1 = eng.logpdf_grad_batch([nodes[j] for j in sel], noises[sel], n=n, check=False)
+        n_sg += eng.grad_structured_particles() - s0
+        g0 = ref.logpdf_grad_batch([nodes[j] for j in sel], noises[sel], n=n, check=False)
+        for q in range(len(sel)):
+            if g0[3][q] != 0 or g1[3][q] != 0: continue
+            sc = max(1.0, np.abs(g0[1][q]).max() if g0[1][q].size else 0.0, abs(g0[2][q]))
+            e = max(np.abs(g1[1][q] - g0[1][q]).max() if g0[1][q].size else 0.0, abs(g1[2][q] - g0[2][q])) / sc
+            w_grad = max(w_grad, e)
+            if e > 5e-8:
+                j = sel[q]
+                lo, go, gno = O.gp_logpdf_grad(nodes[j].to_tuple(), float(noises[j]), ts[:n], xs[:n])
+                es = max(np.abs(g1[1][q] - go).max() if go.size else 0.0, abs(g1[2][q] - gno)) / sc
+                ed = max(np.abs(g0[1][q] - go).max() if go.size else 0.0, abs(g0[2][q] - gno)) / sc
+                print(f"  case {c} N={N} n={n} particle {j} (noise {noises[j]:.3g}, {nodes[j]}): gradient structured vs element-wise {e:.2e}; vs oracle: structured {es:.2e}, element-wise {ed:.2e}; scale {sc:.3g}", flush=True)
+            assert abs(g1[0][q] - g0[0][q]) <= 1e-8 * max(1.0, abs(g0[0][q])), ("gradient value", c, N, n, P, q)
+            assert e <= 2e-6, ("gradient", c, N, n, P, q, e)
+        # ---- predictive pass: training points and the grid's continuation ----
+        if n <= 2048:
+            order = np.argsort(ts[:n], kind="stable")
+            h = (ts.max() - ts.min()) / (N - 1)
+            sub = ts[:n][order][:: int(rng.integers(1, 4))]
+            tp = np.concatenate([sub, ts[:n].max() + h * np.arange(1, int(rng.integers(1, 200)))])
+            s0 = eng.predict_structured_particles()
+            pm1, pv1, _, pi1 = eng.predict_batch(nodes, noises, tp, n=n, check=False)
+            n_sp += eng.predict_structured_particles() - s0
+            pm0, pv0, _, pi0 = ref.predict_batch(nodes, noises, tp, n=n, check=False)
+            okp = (pi0 == 0) & (pi1 == 0)
+            assert (pi0 != pi1).sum() <= max(2, P // 20), ("predict info", c, N, n, P)
+            if okp.any():
+                sc = np.maximum(1.0, np.maximum(np.abs(pm0[okp]).max(axis=1), np.abs(pv0[okp]).max(axis=1)))[:, None]
+                ep = np.maximum((np.abs(pm1 - pm0)[okp] / sc).max(axis=1), (np.abs(pv1 - pv0)[okp] / sc).max(axis=1))
+                e = ep.max(); w_pred = max(w_pred, e)
+                if e > 1e-7:
+                    # the two double-precision passes disagree: an 80-bit factorisation says which one lost the digits
+                    j = int(np.flatnonzero(okp)[int(np.argmax(ep))])
+                    ml, vl = predict_longdouble(nodes[j].to_tuple(), float(noises[j]), ts[:n], xs[:n], tp)
+                    scj = max(1.0, np.abs(ml).max(), np.abs(vl).max())
+                    es = max(np.abs(pm1[j] - ml).max(), np.abs(pv1[j] - vl).max()) / scj
+                    ed = max(np.abs(pm0[j] - ml).max(), np.abs(pv0[j] - vl).max()) / scj
+                    print(f"  case {c} particle {j} (noise {noises[j]:.3g}, {nodes[j]}): structured vs dense {e:.2e}; vs 80-bit: structured {es:.2e}, dense {ed:.2e}", flush=True)
+                    n_dis += 1
+                    assert es <= max(1e-7, 4.0 * ed), ("predict", c, N, n, P, j, e, es, ed)
+            if c % 4 == 0 and okp.any() and n <= 1024:
+                j = int(np.flatnonzero(okp)[0])
+                mo, co = O.predict_mvn(nodes[j].to_tuple(), float(noises[j]), ts[:n], xs[:n], tp)
+                sc = max(1.0, np.abs(mo).max(), np.abs(np.diag(co)).max())
+                e = max(np.abs(pm1[j] - mo).max(), np.abs(pv1[j] - np.diag(co)).max()) / sc; w_or = max(w_or, e)
+                assert e <= 1e-7, ("predict vs oracle", c, N, n, P, j, e)
+        print(f"case {c}: N={N} n={n} P={P} ok  ({time.time()-t0:.0f}s)", flush=True)
+    return (f"structured fuzz ok: {cases} cases; structured particles value {n_sv} / gradient {n_sg} / predictive {n_sp}; worst rel diff vs dense "
+            f"value {w_val:.2e}, gradient {w_grad:.2e}, predictive {w_pred:.2e}; predictive vs oracle {w_or:.2e}; predictive disagreements above 1e-7 settled by 80-bit arithmetic {n_dis}; not-PD particles {n_bad}; {time.time()-t0:.0f}s")
+
+
+if __name__ == "__main__":
+    pkg_ = g.load_package()
+    print(run(pkg_, int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
