@@ -332,6 +332,24 @@ def test_predictive_pass_on_training_point_queries(pkg, case):
         e.close()
 
 
+def _predict_80bit(O, tree, noise, ts, xs, tp, noise_pred):
+    """Predictive mean / marginal variance with the factorisation and the solves in 80-bit arithmetic (covariance entries from the
+    oracle in double): the judge where the conditioning leaves double-precision passes only 1e-9."""
+    n = ts.shape[0]
+    K = O.compute_cov_matrix_vectorized(tree, 0.0, np.concatenate([ts, tp])).astype(np.longdouble)
+    A = K[:n, :n] + np.longdouble(noise) * np.eye(n, dtype=np.longdouble)
+    L = np.zeros_like(A)
+    for j in range(n):
+        L[j, j] = np.sqrt(A[j, j] - L[j, :j] @ L[j, :j])
+        L[j + 1:, j] = (A[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+    B = np.concatenate([xs.astype(np.longdouble)[:, None], K[:n, n:]], axis=1)
+    for j in range(n):
+        B[j] = (B[j] - L[j, :j] @ B[:j]) / L[j, j]
+    mean = B[:, 1:].T @ B[:, 0]
+    var = np.diag(K[n:, n:]) - (B[:, 1:] ** 2).sum(axis=0) + np.longdouble(noise_pred)
+    return mean.astype(np.float64), var.astype(np.float64)
+
+
 @pytest.mark.parametrize("case", ["train_and_future", "means", "future_only", "train_only", "prefix_in_time_order", "population_2048", "backcast", "refused", "linear_far_centre"])
 def test_predictive_pass_structured(pkg, monkeypatch, case):
     """Predictive pass WITHOUT a dense factor for the Toeplitz + rank-2 class (csrc/agp_predict.hip toeplitz_predict_sweep: joint
@@ -394,9 +412,15 @@ def test_predictive_pass_structured(pkg, monkeypatch, case):
         if case == "refused": assert i1[0] > 0 and np.isnan(m1[0]).all()
         ok = i1 == 0
         sc = np.maximum(1.0, np.abs(m2[ok]).max(axis=1))[:, None]
-        assert (np.abs(m1[ok] - m2[ok]) / sc).max() <= (1e-10 if case == "linear_far_centre" else 1e-9)
+        far = case == "linear_far_centre"      # (conditioning 1e7..1e8: the dense pass and the oracle keep 1e-9; an 80-bit factorisation is the judge)
+        assert (np.abs(m1[ok] - m2[ok]) / sc).max() <= (1e-7 if far else 1e-9)
         assert (np.abs(v1[ok] - v2[ok]) / np.maximum(1.0, v2[ok])).max() <= 1e-9
-        if n <= 420:
+        if far:
+            for i in range(0, len(ks), 3):
+                ml, vl = _predict_80bit(O, ks[i].to_tuple(), float(nz[i]), ts[:n], xs[:n], tq, float(npred[i]))
+                assert np.abs(m1[i] - ml).max() <= 1e-9 * max(1.0, np.abs(ml).max()), (case, i)   # (the entries of K are rounded to double: 1e-16 x conditioning)
+                assert np.abs(v1[i] - vl).max() <= 1e-9 * max(1.0, np.abs(vl).max()), (case, i)
+        elif n <= 420:
             for i in list(range(1 if case == "refused" else 0, 6)) + [len(ks) - 1]:
                 mu, cv = O.predict_mvn(ks[i].to_tuple(), float(nz[i]), ts[:n], xs[:n], tq, noise_pred=float(npred[i]), mean=mean_fn)
                 assert np.abs(m1[i] - mu).max() <= LP_TOL * max(1.0, np.abs(mu).max()), (case, i)
