@@ -188,8 +188,10 @@ struct GradArgs {
   double* dinv;                      // [P][ldv] diag(K^-1) = row sums of squares of Z (k_trtri_chain; null: not wanted)
   // resident L^-T (predictive passes that start from the factor store): particle p with lslot[p] >= 0 keeps its Z in the store's
   // slot (Zstride doubles per slot) together with the running alpha and diag(K^-1) of its rows ([slot][zld]); the first zi0[p] tile
-  // columns are there already — Z(j, i) for i < zi0 — and only the new columns are formed (null Zsrc: none of this)
-  double* Zsrc; long long Zstride; const int32_t* zi0; double* zalpha; double* zdinv; long long zld;
+  // columns are there already — Z(j, i) for i < zi0 — and only the new columns are formed (null Zsrc: none of this; zi0[p] < 0: a copy of
+  // another particle of the sweep with the same slot — it forms its Z in the sweep's scratch and leaves the slot alone)
+  // zfull = floor(n / 128): the complete tile columns, the only ones a slot's running sums and its resident-column count cover
+  double* Zsrc; long long Zstride; const int32_t* zi0; double* zalpha; double* zdinv; long long zld; int zfull;
   // Toeplitz variant of the lag-domain particles (k_toep_solve / k_lag_grad): K^-1 [e_first, 1, t - t_ref] per particle
   // ([P][3][ldv]), and the rank of the sweep's first point in time (its points occupy ranks rank0 .. rank0 + n - 1)
   double* tsol; int rank0;

@@ -142,9 +142,12 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
   const int lsl = a.lslot != nullptr ? a.lslot[p] : -1;
   const double* __restrict__ Lp = lsl >= 0 ? a.Lsrc + (long long)lsl * a.Lstride : a.A + (long long)p * a.strideA;
   const double* __restrict__ Wp = lsl >= 0 ? a.Wsrc + (long long)lsl * a.Wnt * NSB * 256 : a.W + (long long)p * a.nt * NSB * 256;
-  const bool zres = lsl >= 0 && a.Zsrc != nullptr;          // Z lives in the factor store beside L
+  // Z lives in the factor store beside L — for ONE particle per store entry: the copies of a resampled population (same entry,
+  // zi0 < 0) form their Z in the sweep's scratch, or two workgroups would extend the entry's running row sums at once
+  const int zi0r = (lsl >= 0 && a.Zsrc != nullptr) ? a.zi0[p] : -1;
+  const bool zres = zi0r >= 0;
   double* __restrict__ Zp = zres ? a.Zsrc + (long long)lsl * a.Zstride : a.Z + (long long)p * (a.strideZ ? a.strideZ : a.strideA);
-  const int zi0 = zres ? a.zi0[p] : 0;                       // tile columns of Z already resident
+  const int zi0 = zres ? zi0r : 0;                           // tile columns of Z already resident
   const int i_start = j > zi0 ? j : zi0;
   // alpha_j = sum_{i >= j} Z(j,i) beta_i is formed here, from the tiles while they are in registers (a separate pass over Z
   // — k_alpha, what the per-column variant runs — read all 9 GB of it again: 2.3 ms per 512-particle sweep at n=2048)
@@ -181,6 +184,20 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
         al0 = fma(acc[cb][0][r], bk, al0); al1 = fma(acc[cb][1][r], bk, al1);
         if (want_d) { dz0 = fma(acc[cb][0][r], acc[cb][0][r], dz0); dz1 = fma(acc[cb][1][r], acc[cb][1][r], dz1); }
       }
+    if (zres && i + 1 == a.zfull) {
+      // the slot keeps the rows' sums over the COMPLETE tile columns (i < floor(n / 128)): a tile column that holds the prefix's
+      // last, partly filled tile is formed again once the prefix has grown, and must not be in the sums the next pass starts from
+      double s0 = al0, s1 = al1;
+      s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16);
+      s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
+      if (lq == 0) { d2 o2; o2.x = s0; o2.y = s1; *reinterpret_cast<d2*>(a.zalpha + (long long)lsl * a.zld + j * NB + row0) = o2; }
+      if (want_d) {
+        double q0 = dz0, q1 = dz1;
+        q0 += __shfl_xor(q0, 16); q1 += __shfl_xor(q1, 16);
+        q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
+        if (lq == 0) { d2 o2; o2.x = q0; o2.y = q1; *reinterpret_cast<d2*>(a.zdinv + (long long)lsl * a.zld + j * NB + row0) = o2; }
+      }
+    }
     __syncthreads();      // the solve's LDS blocks are overwritten by the next contraction's first slab
   }
   // the four column groups of a row (lanes l15 + 16 lq) in a fixed order
@@ -189,7 +206,6 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
   if (lq == 0) {
     d2 o2; o2.x = al0; o2.y = al1;
     *reinterpret_cast<d2*>(a.alpha + (long long)p * a.ldv + j * NB + row0) = o2;
-    if (zres) *reinterpret_cast<d2*>(a.zalpha + (long long)lsl * a.zld + j * NB + row0) = o2;
   }
   if (want_d) {
     dz0 += __shfl_xor(dz0, 16); dz1 += __shfl_xor(dz1, 16);
@@ -197,7 +213,6 @@ __global__ __launch_bounds__(256, 2) void k_trtri_chain(GradArgs a) {
     if (lq == 0) {
       d2 o2; o2.x = dz0; o2.y = dz1;
       *reinterpret_cast<d2*>(a.dinv + (long long)p * a.ldv + j * NB + row0) = o2;
-      if (zres) *reinterpret_cast<d2*>(a.zdinv + (long long)lsl * a.zld + j * NB + row0) = o2;
     }
   }
 }

@@ -206,8 +206,15 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     fs.footprint = fs.footprint.load() + after - std::min(before, after);
     if (zstore) {
       if (fs.zrows.size() != (size_t)fs.n_slots) fs.zrows.assign((size_t)fs.n_slots, 0);
+      // one particle per store entry extends the entry's Z; its copies (a resampled population) work in the sweep's scratch (-1)
       zi0v.assign((size_t)P, 0);
-      for (int q = 0; q < P; ++q) if (src_slot[(size_t)q] >= 0) zi0v[(size_t)q] = fs.zrows[(size_t)src_slot[(size_t)q]];
+      std::vector<char> taken((size_t)fs.n_slots, 0);
+      for (int q = 0; q < P; ++q) {
+        const int sl = src_slot[(size_t)q];
+        if (sl < 0) continue;
+        zi0v[(size_t)q] = taken[(size_t)sl] ? -1 : fs.zrows[(size_t)sl];
+        taken[(size_t)sl] = 1;
+      }
     }
   }
   if (n_hit > 0) {
@@ -340,12 +347,14 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
         ga.lslot = d_src + p0; ga.Lsrc = fs.A.as<double>(); ga.Lstride = fs.strideA; ga.Wsrc = fs.W.as<double>(); ga.Wnt = fs.nt_cap;
         ga.Zsrc = fs.Z.as<double>(); ga.Zstride = fs.strideA; ga.zi0 = d_zi0 + p0;
         ga.zalpha = fs.zalpha.as<double>(); ga.zdinv = fs.zdinv.as<double>(); ga.zld = (long long)fs.nt_cap * NB;
+        ga.zfull = (int)(n / NB);
       }
       launch_trtri_chain(st, 8 * ((Pc + 7) / 8) * nt1, ga);
       if (zstore && p0 + chunk >= P) {
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(st));
-        for (int q = 0; q < P; ++q) if (src_slot[(size_t)q] >= 0) c->store.zrows[(size_t)src_slot[(size_t)q]] = nt1;
+        // (complete tile columns only: the column of a partly filled last tile is formed again on a longer prefix)
+        for (int q = 0; q < P; ++q) if (src_slot[(size_t)q] >= 0) c->store.zrows[(size_t)src_slot[(size_t)q]] = (int32_t)(n / NB);
         store_lk.unlock();
       }
       HIPCHK(c, hipGetLastError());

@@ -197,7 +197,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     }
   }
   // (a slot's resident L^-T covers at most the tile rows of L that stay as they are)
-  for (int u = 0; u < U; ++u) fs.zrows[(size_t)slot[u]] = std::min(fs.zrows[(size_t)slot[u]], i0[u]);
+  // (the slot's running row sums cover exactly zrows columns: fewer surviving rows of L than that and the resident Z starts over)
+  for (int u = 0; u < U; ++u) if (i0[u] < fs.zrows[(size_t)slot[u]]) fs.zrows[(size_t)slot[u]] = 0;
   // from here on the touched slots are in flux: forget them on any failure
   auto poison = [&]() {
     for (int u = 0; u < U; ++u) {

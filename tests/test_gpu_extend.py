@@ -433,7 +433,7 @@ def test_predictive_passes_keep_the_inverse_factor_resident(pkg):
     """The per-step callback of a stream (scripts/online.jl:43,59): predictive passes that start from resident factors and serve the
     observed points from alpha / diag(K11^-1) keep Z = L^-T in the store; after the next extension only the new tile columns of Z are
     formed.  Same predictions as an engine without a store (1e-11), across two extensions, a rejuvenated particle (new parameters:
-    from scratch), a shorter prefix (factors redone) and agp_extend_reset."""
+    from scratch), a shorter prefix (factors redone), agp_extend_reset, prefixes that end inside a tile and copies of a particle."""
     n_max = 1024
     ts, xs = pkg.prior.synthetic_series(n_max, seed=33, shuffle=True)
     nodes, nz = pkg.prior.sample_particles(np.random.default_rng(21), 48, max_depth=3)
@@ -457,7 +457,9 @@ def test_predictive_passes_keep_the_inverse_factor_resident(pkg):
             assert (np.abs(m1[ok] - m2[ok]) / sc).max() <= 1e-11 and (np.abs(v1[ok] - v2[ok]) / np.maximum(1.0, v2[ok])).max() <= 1e-11
             # ... and once more: everything resident now, nothing to add
             m3, v3, _, _ = a.predict_batch(nd, zz, tq, n=n, check=False)
-            assert np.array_equal(m1[ok], m3[ok]) and np.array_equal(v1[ok], v3[ok])
+            if n % 128 == 0: assert np.array_equal(m1[ok], m3[ok]) and np.array_equal(v1[ok], v3[ok])
+            else:            # (the last, partly filled tile column is formed again and added to the resident columns' sums: same to rounding)
+                assert (np.abs(m1[ok] - m3[ok]) / sc).max() <= 1e-12 and (np.abs(v1[ok] - v3[ok]) / np.maximum(1.0, v2[ok])).max() <= 1e-12
 
         check(384, nodes, nz)
         check(640, nodes, nz)                      # two new tile rows of L, two new tile columns of Z
@@ -467,5 +469,13 @@ def test_predictive_passes_keep_the_inverse_factor_resident(pkg):
         check(512, nodes2, nz)                     # a shorter prefix: the factors are redone
         a.extend_reset()
         check(1024, nodes2, nz)
+        # prefixes that end inside a tile: the tile column of the partly filled last tile is formed again on the longer prefix and must
+        # not be part of the row sums the next pass starts from (a randomised life-cycle run, tools/gpu_fuzz_stream.py, found sums that
+        # counted it twice); copies of a particle (a resampled population) share a store entry — one of them extends its Z
+        a.extend_reset()
+        nodes3 = list(nodes2); nz3 = np.array(nz)
+        for j in (5, 6, 17): nodes3[j] = nodes3[4]; nz3[j] = nz3[4]
+        for n in (200, 450, 451, 700, 900, 1000):
+            check(n, nodes3, nz3)
     finally:
         a.close(); b.close()

@@ -1,0 +1,112 @@
+"""Randomised soak test of the factor store's life cycle on the GPU box: one engine lives through random sequences of the calls a
+streaming run makes (scripts/online.jl) — extension sweeps on growing prefixes, predictive passes (resident factors, resident
+L^-T, structured pass), gradient sweeps, rejuvenated / resampled particles, appended data (add_data!), store resets — and every
+result is compared with a second engine that keeps nothing (AGP_FACTOR_CACHE=0 AGP_PREDICT_REUSE=0, dense / element-wise sweeps).
+Usage: gpu_fuzz_stream.py [sequences] [seed]"""
+import os, sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import __graft_entry__ as g
+
+
+def run(pkg, sequences=20, seed=1, steps=14):
+    eng = pkg.GPEngine(0)
+    env = (("AGP_GRAD_FFT", "0"), ("AGP_GRAD_LAGDOM", "0"), ("AGP_LAG", "0"), ("AGP_LAG_RANK", "0"), ("AGP_FACTOR_CACHE", "0"), ("AGP_PREDICT_REUSE", "0"))
+    for k, v in env: os.environ[k] = v
+    ref = pkg.GPEngine(0)
+    for k, _ in env: del os.environ[k]
+    rng = np.random.default_rng(seed)
+    t0 = time.time(); w = {"value": 0.0, "predict": 0.0, "gradient": 0.0}; n_ops = {"extend": 0, "predict": 0, "gradient": 0, "append": 0, "reset": 0}
+    for q in range(sequences):
+        N = int(rng.choice([300, 640, 900, 1280, 2048]))
+        P = int(rng.choice([8, 40, 64, 130])) if N <= 1280 else int(rng.choice([8, 40, 64]))
+        regular = rng.random() < 0.7
+        ordered = rng.random() < 0.5
+        ts, xs = pkg.prior.synthetic_series(N, seed=int(rng.integers(1 << 30)), shuffle=not ordered)
+        if not regular: ts = ts + rng.uniform(-0.3, 0.3, N) / N
+        n_avail = N if rng.random() < 0.5 else int(rng.integers(N // 2, N))           # the rest arrives by add_data!
+        eng.set_data(ts[:n_avail], xs[:n_avail]); ref.set_data(ts[:n_avail], xs[:n_avail])
+        eng.extend_reset()
+        nodes, noises = pkg.prior.sample_particles(rng, P, max_depth=int(rng.integers(1, 5)), max_size=31)
+        nodes = list(nodes); noises = np.array(noises)
+        n = int(rng.integers(2, max(3, n_avail // 3)))
+        for st in range(steps):
+            r = rng.random()
+            if r < 0.15 and n_avail < N:                                    # add_data!: the series grows, the old one is its prefix
+                n_avail = min(N, n_avail + int(rng.integers(1, N - n_avail + 1)))
+                eng.set_data(ts[:n_avail], xs[:n_avail]); ref.set_data(ts[:n_avail], xs[:n_avail]); n_ops["append"] += 1
+            elif r < 0.2:
+                eng.extend_reset(release_memory=bool(rng.integers(2))); n_ops["reset"] += 1
+            if rng.random() < 0.6: n = min(n_avail, n + int(rng.integers(0, max(2, n_avail // 4))))
+            if rng.random() < 0.4:                                          # rejuvenation / resampling: new particles, copies of others
+                for j in rng.choice(P, size=int(rng.integers(1, P // 2 + 2)), replace=False):
+                    if rng.random() < 0.5:
+                        k2, z2 = pkg.prior.sample_particles(rng, 1, max_depth=int(rng.integers(1, 5)), max_size=31)
+                        nodes[j] = k2[0]; noises[j] = z2[0]
+                    else:
+                        i2 = int(rng.integers(P)); nodes[j] = nodes[i2]; noises[j] = noises[i2]
+            op = rng.choice(["extend", "extend", "predict", "predict", "gradient"])
+            tag = (q, st, op, N, n_avail, n, P, regular, ordered)
+            if op == "extend":
+                lp1, i1 = eng.logpdf_batch_extend(nodes, noises, n=n, check=False)
+                lp0, i0 = ref.logpdf_batch(nodes, noises, n=n, check=False)
+                assert np.array_equal(i0 != 0, i1 != 0), ("extend info", tag)
+                ok = i0 == 0
+                if ok.any():
+                    e = (np.abs(lp1[ok] - lp0[ok]) / np.maximum(1.0, np.abs(lp0[ok]))).max(); w["value"] = max(w["value"], e)
+                    assert e <= 1e-9, ("extend value", tag, e)
+            elif op == "predict":
+                h = 1.0 / (N - 1)
+                kind = rng.integers(3)
+                srt = np.sort(ts[:n])
+                if kind == 0:   tp = np.concatenate([srt[:: int(rng.integers(1, 4))], srt[-1] + h * np.arange(1, int(rng.integers(2, 120)))])   # scripts/online.jl:41-43
+                elif kind == 1: tp = np.concatenate([ts[:n][rng.permutation(n)[: max(1, n // 2)]], rng.uniform(-0.1, 1.3, 7)])
+                else:           tp = srt[-1] + h * np.arange(1, int(rng.integers(2, 60)))
+                pm1, pv1, _, i1 = eng.predict_batch(nodes, noises, tp, n=n, check=False)
+                pm0, pv0, _, i0 = ref.predict_batch(nodes, noises, tp, n=n, check=False)
+                assert np.array_equal(i0 != 0, i1 != 0), ("predict info", tag)
+                ok = i0 == 0
+                if ok.any():
+                    sc = np.maximum(1.0, np.maximum(np.abs(pm0[ok]).max(axis=1), np.abs(pv0[ok]).max(axis=1)))[:, None]
+                    e = max((np.abs(pm1[ok] - pm0[ok]) / sc).max(), (np.abs(pv1[ok] - pv0[ok]) / sc).max()); w["predict"] = max(w["predict"], e)
+                    if e > 1e-7:
+                        ep = np.maximum((np.abs(pm1 - pm0) / np.maximum(1.0, np.abs(pm0))).max(axis=1), (np.abs(pv1 - pv0) / np.maximum(1.0, np.abs(pv0))).max(axis=1))
+                        bad = np.flatnonzero(ep > 1e-7)
+                        print("predict mismatch", tag, "kind", kind, "particles", bad[:10], "of", P, "errors", ep[bad[:10]], flush=True)
+                        j = int(bad[0])
+                        qb = np.flatnonzero(np.maximum(np.abs(pm1[j] - pm0[j]), np.abs(pv1[j] - pv0[j])) > 1e-7)
+                        print("  particle", j, nodes[j], noises[j], "bad queries", qb[:12], "of", tp.size, "n", n, "duplicate of", [i for i in range(P) if nodes[i] is nodes[j] and noises[i] == noises[j]], flush=True)
+                        print("  mean eng/ref", pm1[j][qb[:4]], pm0[j][qb[:4]], "var", pv1[j][qb[:4]], pv0[j][qb[:4]], flush=True)
+                        print("  stats", eng.extend_stats(), eng.predict_reuse_stats(), eng.predict_structured_particles(), flush=True)
+                        pm2, pv2, _, i2 = eng.predict_batch(nodes, noises, tp, n=n, check=False)
+                        print("  same call again: equal to first", np.array_equal(pm1, pm2, equal_nan=True), "max diff to ref", np.nanmax(np.abs(pm2 - pm0)), flush=True)
+                        eng.extend_reset()
+                        pm3, pv3, _, i3 = eng.predict_batch(nodes, noises, tp, n=n, check=False)
+                        print("  after extend_reset: max diff to ref", np.nanmax(np.abs(pm3 - pm0)), np.nanmax(np.abs(pv3 - pv0)), flush=True)
+                        from oracle import oracle as O
+                        mo, co = O.predict_mvn(nodes[j].to_tuple(), float(noises[j]), ts[:n], xs[:n], tp)
+                        print("  vs oracle: eng", np.abs(pm1[j] - mo).max(), "ref", np.abs(pm0[j] - mo).max(), flush=True)
+                        raise AssertionError(("predict", tag, e))
+            else:
+                sel = [j for j in range(P) if nodes[j].size() <= 63]
+                g1 = eng.logpdf_grad_batch([nodes[j] for j in sel], noises[sel], n=n, check=False)
+                g0 = ref.logpdf_grad_batch([nodes[j] for j in sel], noises[sel], n=n, check=False)
+                assert np.array_equal(g0[3] != 0, g1[3] != 0), ("gradient info", tag)
+                for u in range(len(sel)):
+                    if g0[3][u] != 0: continue
+                    sc = max(1.0, np.abs(g0[1][u]).max() if g0[1][u].size else 0.0, abs(g0[2][u]))
+                    e = max(np.abs(g1[1][u] - g0[1][u]).max() if g0[1][u].size else 0.0, abs(g1[2][u] - g0[2][u])) / sc; w["gradient"] = max(w["gradient"], e)
+                    assert abs(g1[0][u] - g0[0][u]) <= 1e-9 * max(1.0, abs(g0[0][u])), ("gradient value", tag, u)
+                    assert e <= 2e-6, ("gradient", tag, u, e)
+            n_ops[op] += 1
+        print(f"sequence {q}: N={N} P={P} regular={regular} time-order={ordered} ok ({time.time()-t0:.0f}s)", flush=True)
+    st = eng.extend_stats(); pr = eng.predict_reuse_stats(); gr = eng.grad_reuse_stats()
+    return (f"stream fuzz ok: {sequences} sequences, calls {n_ops}; worst rel diff vs the engine that keeps nothing: {w}; "
+            f"store {st}; predictive reuse {pr}; structured predictive particles {eng.predict_structured_particles()}; gradient reuse {gr}; {time.time()-t0:.0f}s")
+
+
+if __name__ == "__main__":
+    pkg_ = g.load_package()
+    print(run(pkg_, int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
