@@ -64,10 +64,17 @@ def run(pkg, sequences=20, seed=1, steps=14):
                 if kind == 0:   tp = np.concatenate([srt[:: int(rng.integers(1, 4))], srt[-1] + h * np.arange(1, int(rng.integers(2, 120)))])   # scripts/online.jl:41-43
                 elif kind == 1: tp = np.concatenate([ts[:n][rng.permutation(n)[: max(1, n // 2)]], rng.uniform(-0.1, 1.3, 7)])
                 else:           tp = srt[-1] + h * np.arange(1, int(rng.integers(2, 60)))
-                pm1, pv1, _, i1 = eng.predict_batch(nodes, noises, tp, n=n, check=False)
-                pm0, pv0, _, i0 = ref.predict_batch(nodes, noises, tp, n=n, check=False)
+                kw = {}
+                if rng.random() < 0.3: kw.update(mean_train=0.4 - 1.3 * ts[:n], mean_pred=0.4 - 1.3 * tp)
+                if rng.random() < 0.3: kw.update(noise_pred=rng.uniform(0.01, 0.3, P))
+                if rng.random() < 0.2 and tp.size > 40: tp = tp[rng.permutation(tp.size)[:40]]; kw.update(want_cov=True); kw.pop("mean_pred", None); kw.pop("mean_train", None)
+                pm1, pv1, pc1, i1 = eng.predict_batch(nodes, noises, tp, n=n, check=False, **kw)
+                pm0, pv0, pc0, i0 = ref.predict_batch(nodes, noises, tp, n=n, check=False, **kw)
                 assert np.array_equal(i0 != 0, i1 != 0), ("predict info", tag)
                 ok = i0 == 0
+                if pc0 is not None and ok.any():
+                    ec = (np.abs(pc1[ok] - pc0[ok]).reshape(int(ok.sum()), -1).max(axis=1) / np.maximum(1.0, np.abs(pc0[ok]).reshape(int(ok.sum()), -1).max(axis=1))).max()
+                    assert ec <= 1e-7, ("predict covariance", tag, ec)
                 if ok.any():
                     sc = np.maximum(1.0, np.maximum(np.abs(pm0[ok]).max(axis=1), np.abs(pv0[ok]).max(axis=1)))[:, None]
                     e = max((np.abs(pm1[ok] - pm0[ok]) / sc).max(), (np.abs(pv1[ok] - pv0[ok]) / sc).max()); w["predict"] = max(w["predict"], e)
@@ -80,10 +87,10 @@ def run(pkg, sequences=20, seed=1, steps=14):
                         print("  particle", j, nodes[j], noises[j], "bad queries", qb[:12], "of", tp.size, "n", n, "duplicate of", [i for i in range(P) if nodes[i] is nodes[j] and noises[i] == noises[j]], flush=True)
                         print("  mean eng/ref", pm1[j][qb[:4]], pm0[j][qb[:4]], "var", pv1[j][qb[:4]], pv0[j][qb[:4]], flush=True)
                         print("  stats", eng.extend_stats(), eng.predict_reuse_stats(), eng.predict_structured_particles(), flush=True)
-                        pm2, pv2, _, i2 = eng.predict_batch(nodes, noises, tp, n=n, check=False)
+                        pm2, pv2, _, i2 = eng.predict_batch(nodes, noises, tp, n=n, check=False, **kw)
                         print("  same call again: equal to first", np.array_equal(pm1, pm2, equal_nan=True), "max diff to ref", np.nanmax(np.abs(pm2 - pm0)), flush=True)
                         eng.extend_reset()
-                        pm3, pv3, _, i3 = eng.predict_batch(nodes, noises, tp, n=n, check=False)
+                        pm3, pv3, _, i3 = eng.predict_batch(nodes, noises, tp, n=n, check=False, **kw)
                         print("  after extend_reset: max diff to ref", np.nanmax(np.abs(pm3 - pm0)), np.nanmax(np.abs(pv3 - pv0)), flush=True)
                         from oracle import oracle as O
                         mo, co = O.predict_mvn(nodes[j].to_tuple(), float(noises[j]), ts[:n], xs[:n], tp)

@@ -40,8 +40,8 @@ def run(pkg, cases=40, seed=1):
     rng = np.random.default_rng(seed)
     t0 = time.time(); w_val = w_grad = w_pred = w_or = 0.0; n_sv = n_sg = n_sp = 0; n_bad = 0; n_dis = 0
     for c in range(cases):
-        N = int(rng.choice([256, 300, 511, 512, 640, 777, 1024, 1100, 1536, 2048]))
-        P = int(rng.choice([33, 64, 100, 129, 256])) if N <= 1024 else int(rng.choice([33, 64, 96]))
+        N = int(rng.choice([256, 300, 511, 512, 640, 777, 1024, 1100, 1536, 2048, 2049, 3000, 4096], p=[.09, .09, .09, .09, .09, .09, .09, .09, .09, .09, .03, .04, .03]))
+        P = int(rng.choice([33, 64, 100, 129, 256])) if N <= 1024 else int(rng.choice([33, 64, 96])) if N <= 2048 else 33
         ts, xs = pkg.prior.synthetic_series(N, seed=int(rng.integers(1 << 30)), shuffle=bool(rng.integers(2)))
         if rng.random() < 0.25: ts = ts * float(rng.choice([3.0, 0.37])) + float(rng.choice([0.5, -1.0, 2.0]))   # other origin / spacing
         nodes, noises = pkg.prior.sample_particles(rng, P, max_depth=int(rng.integers(1, 5)), max_size=31)
