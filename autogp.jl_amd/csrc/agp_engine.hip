@@ -1339,7 +1339,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
               // polynomial particles: behind the K^-1 tiles' moment histograms
               HIPCHK(c, hipStreamWaitEvent(qs[3], s->gq_ev[3], 0));
               GradArgs gp = ga; gp.plist = d_pl + Pe;
-              const size_t ldsp = sizeof(double) * (7 * (size_t)c->n_max + 40 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
+              // (2 d + 1 moment histograms of n_max lags for the class's largest degree d: admission keeps them within one tile of LDS)
+              int dmax = 1;
+              for (int r = Pe; r < Pn; ++r) dmax = std::max(dmax, (bt.ghdr[p0 + g0 + pl[r]].flags >> GFLAG_POLY_DEG_SHIFT) & 3);
+              const size_t ldsp = sizeof(double) * ((size_t)(2 * dmax + 1) * c->n_max + 40 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
               launch_lag_grad(qs[3], Pn - Pe, ldsp, gp);
               HIPCHK(c, hipGetLastError());
             }

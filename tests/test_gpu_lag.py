@@ -761,3 +761,32 @@ def test_gradient_lag_domain_population_and_switches(pkg, monkeypatch):
         assert a.grad_lag_domain_particles() == k0 and not a.lag_stats()[0]
     finally:
         a.close(); b.close(); h.close()
+
+
+@pytest.mark.parametrize("n_max", [2300, 3000, 4096])
+def test_gradient_polynomial_class_above_2048_points(pkg, n_max):
+    """Polynomial lag-domain class on long series: a particle of degree d keeps 2d+1 moment histograms of n_max lags in LDS and is
+    admitted while they fit one tile (csrc/agp_engine.hip, (2d+1) n_max + 8 <= 128 x 128) — degree 3 up to 2339 points, degree 2 up
+    to 3275, degree 1 up to 5458.  k_lag_grad's launch is sized by the largest ADMITTED degree (sized for degree 3 whatever the
+    class held, it failed from 2926 points on; found by tools/gpu_fuzz_structured.py).  Against the element-wise contraction."""
+    G = pkg
+    ts, xs = pkg.prior.synthetic_series(n_max, seed=4, shuffle=True)
+    se, per, lin = G.SquaredExponential(0.2, 0.8), G.Periodic(0.3, 0.25, 0.7), G.Linear(0.3, 0.2, 0.9)
+    lin2, lin3 = G.Linear(0.6, 0.1, 0.5), G.Linear(-0.2, 0.3, 0.4)
+    kernels = [lin * se, lin * per + se, lin * lin2 * se, lin * lin2 * lin3 * per, se + lin]
+    noises = np.array([0.05, 0.1, 0.08, 0.12, 0.07])
+    n_adm = sum((2 * d + 1) * n_max + 8 <= 128 * 128 for d in (1, 1, 2, 3))
+    a = pkg.GPEngine(0); b = pkg.GPEngine(0)
+    try:
+        a.set_data(ts, xs); b.set_data(ts, xs)
+        b.set_grad_lag_domain(False)
+        lp, g, gn, info = a.logpdf_grad_batch(kernels, noises, check=False)
+        assert a.grad_lag_domain_particles() == n_adm + 1
+        lp2, g2, gn2, info2 = b.logpdf_grad_batch(kernels, noises, check=False)
+        assert np.array_equal(info, info2) and (info == 0).all()
+        assert lp_err(lp, lp2).max() <= 1e-10
+        for i in range(len(kernels)):
+            sc = max(1.0, np.abs(g2[i]).max(), abs(gn2[i]))
+            assert np.abs(g[i] - g2[i]).max() <= 1e-7 * sc and abs(gn[i] - gn2[i]) <= 1e-7 * sc, (n_max, i)
+    finally:
+        a.close(); b.close()
