@@ -47,6 +47,7 @@ def run(pkg, sequences=20, seed=1, steps=14):
                         nodes[j] = k2[0]; noises[j] = z2[0]
                     else:
                         i2 = int(rng.integers(P)); nodes[j] = nodes[i2]; noises[j] = noises[i2]
+            if rng.random() < 0.3: eng.set_workspace_limit(int(rng.choice([0, 40e6, 100e6, 300e6])))      # sweeps in chunks of a few particles
             op = rng.choice(["extend", "extend", "predict", "predict", "gradient"])
             tag = (q, st, op, N, n_avail, n, P, regular, ordered)
             if op == "extend":

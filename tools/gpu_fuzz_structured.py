@@ -47,6 +47,7 @@ def run(pkg, cases=40, seed=1):
         nodes, noises = pkg.prior.sample_particles(rng, P, max_depth=int(rng.integers(1, 5)), max_size=31)
         n = N if rng.random() < 0.6 else int(rng.integers(256, N + 1))           # annealing prefix (time order: consecutive points)
         eng.set_data(ts, xs); ref.set_data(ts, xs)
+        eng.set_workspace_limit(int(rng.choice([0, 0, 60e6, 200e6])))      # structured and dense sweeps in chunks of a few particles
         # ---- value: structured sweep against the dense one ----
         lp0, i0 = ref.logpdf_batch(nodes, noises, n=n, check=False)
         eng.set_lag_tables(3)
