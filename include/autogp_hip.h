@@ -166,8 +166,10 @@ int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
  * WHOLE series (n == n_max <= 4096); the other particles of the call, and any particle the structured sweep refuses (a reflection
  * coefficient of modulus >= 1: not positive definite to rounding), take the dense path, which also supplies LAPACK's info.
  * Taken when the class's share of the dense sweep would cost more than the recursion's n sequential steps (level 3 / AGP_LAG=3:
- * always).  Agreement with the dense path: <= 1e-10 of |logpdf| (tests/test_gpu_lag.py).  agp_get_toeplitz_stats counts the
- * particles scored that way. */
+ * always).  Agreement with the dense path: <= 1e-10 of |logpdf| (tests/test_gpu_lag.py) for noises the reference can produce
+ * (>= JITTER = 1e-5, src/Model.jl:22,134: <= 1e-9 in randomised runs with noises down to 1e-5); the Schur recursion is weakly stable —
+ * on matrices with conditioning beyond 1e12 (noise 1e-12) where the dense factorisation itself keeps only 2-3 digits it keeps one
+ * fewer.  agp_get_toeplitz_stats counts the particles scored that way. */
 int agp_get_toeplitz_stats(agp_ctx* ctx, int64_t* n_particles);
 
 /* Every OTHER sweep of agp_logpdf_batch{,_device,_multi} / agp_logpdf_grad_batch over (a prefix of) a regular grid of up to 4096

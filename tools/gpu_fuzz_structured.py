@@ -31,6 +31,21 @@ def predict_longdouble(tree, noise, ts, xs, tp):
     return mean.astype(np.float64), var.astype(np.float64)
 
 
+def logpdf_longdouble(tree, noise, ts, xs):
+    n = ts.shape[0]
+    A = O.compute_cov_matrix_vectorized(tree, 0.0, ts).astype(np.longdouble) + np.longdouble(noise) * np.eye(n, dtype=np.longdouble)
+    L = np.zeros_like(A)
+    for j in range(n):
+        d = A[j, j] - L[j, :j] @ L[j, :j]
+        if not d > 0: return float("nan")
+        L[j, j] = np.sqrt(d)
+        L[j + 1:, j] = (A[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+    b = xs.astype(np.longdouble).copy()
+    for j in range(n):
+        b[j] = (b[j] - L[j, :j] @ b[:j]) / L[j, j]
+    return float(-0.5 * (b @ b) - np.log(np.diag(L)).sum() - 0.5 * n * np.log(2 * np.longdouble(np.pi)))
+
+
 def run(pkg, cases=40, seed=1):
     os.environ["AGP_GRAD_FFT"] = "4"          # structured gradient sweeps whatever the population size
     eng = pkg.GPEngine(0)
@@ -38,13 +53,19 @@ def run(pkg, cases=40, seed=1):
     ref = pkg.GPEngine(0)
     for k in ("AGP_GRAD_FFT", "AGP_GRAD_LAGDOM", "AGP_LAG"): del os.environ[k]
     rng = np.random.default_rng(seed)
-    t0 = time.time(); w_val = w_grad = w_pred = w_or = 0.0; n_sv = n_sg = n_sp = 0; n_bad = 0; n_dis = 0
+    t0 = time.time(); w_val = w_grad = w_pred = w_or = 0.0; n_sv = n_sg = n_sp = 0; n_bad = 0; n_dis = 0; n_hard = n_hard_bad = 0
     for c in range(cases):
         N = int(rng.choice([256, 300, 511, 512, 640, 777, 1024, 1100, 1536, 2048, 2049, 3000, 4096], p=[.09, .09, .09, .09, .09, .09, .09, .09, .09, .09, .03, .04, .03]))
         P = int(rng.choice([33, 64, 100, 129, 256])) if N <= 1024 else int(rng.choice([33, 64, 96])) if N <= 2048 else 33
         ts, xs = pkg.prior.synthetic_series(N, seed=int(rng.integers(1 << 30)), shuffle=bool(rng.integers(2)))
         if rng.random() < 0.25: ts = ts * float(rng.choice([3.0, 0.37])) + float(rng.choice([0.5, -1.0, 2.0]))   # other origin / spacing
         nodes, noises = pkg.prior.sample_particles(rng, P, max_depth=int(rng.integers(1, 5)), max_size=31)
+        # near-singular matrices (smooth kernels, hardly any noise): refusals, retries and LAPACK's info must stay consistent between
+        # the paths; their values are only compared loosely (conditioning 1e8 and beyond)
+        if rng.random() < 0.3:
+            hj = rng.choice(P, size=max(1, P // 6), replace=False)
+            noises = np.array(noises); noises[hj] = 10.0 ** rng.uniform(-5, -4, hj.size)          # (the reference adds JITTER = 1e-5 to every noise: src/Model.jl:22,134)
+        hard = np.asarray(noises) < 1e-4
         n = N if rng.random() < 0.6 else int(rng.integers(256, N + 1))           # annealing prefix (time order: consecutive points)
         eng.set_data(ts, xs); ref.set_data(ts, xs)
         eng.set_workspace_limit(int(rng.choice([0, 0, 60e6, 200e6])))      # structured and dense sweeps in chunks of a few particles
@@ -57,7 +78,17 @@ def run(pkg, cases=40, seed=1):
         eng.set_lag_tables(1)
         ok = (i0 == 0) & (i1 == 0); n_bad += int((i0 != 0).sum())
         # (a particle that is indefinite to rounding may be rejected by one path only; values are compared where both accept)
-        assert (i0 != i1).sum() <= max(2, P // 20), ("value info", c, N, n, P, np.flatnonzero(i0 != i1))
+        assert ((i0 != 0) != (i1 != 0))[~hard].sum() <= max(2, P // 20), ("value info", c, N, n, P, np.flatnonzero(i0 != i1))
+        assert np.isfinite(lp1[i1 == 0]).all() and np.isnan(lp1[i1 > 0]).all(), ("value / info", c, N, n, P)
+        n_hard += int(hard.sum()); n_hard_bad += int((i1[hard] != 0).sum())
+        if (ok & hard).any():
+            e = np.abs(lp1 - lp0)[ok & hard] / np.maximum(1.0, np.abs(lp0[ok & hard]))
+            if e.max() > 1e-6 and n <= 1100:
+                j = int(np.flatnonzero(ok & hard)[int(np.argmax(e))])
+                ll = logpdf_longdouble(nodes[j].to_tuple(), float(noises[j]), ts[:n], xs[:n])
+                print(f"  case {c} N={N} n={n} near-singular particle {j} (noise {noises[j]:.3g}, {nodes[j]}): structured {lp1[j]:.10g} dense {lp0[j]:.10g} 80-bit {ll:.10g}", flush=True)
+                assert abs(lp1[j] - ll) <= max(1e-7 * abs(ll), 30.0 * abs(lp0[j] - ll)), ("value of a near-singular particle", c, N, n, P, j)
+        ok &= ~hard
         if ok.any():
             e = np.abs(lp1[ok] - lp0[ok]) / np.maximum(1.0, np.abs(lp0[ok])); w_val = max(w_val, e.max())
             assert e.max() <= 1e-8, ("value", c, N, n, P, int(np.argmax(e)), e.max())
@@ -69,7 +100,7 @@ def run(pkg, cases=40, seed=1):
         n_sg += eng.grad_structured_particles() - s0
         g0 = ref.logpdf_grad_batch([nodes[j] for j in sel], noises[sel], n=n, check=False)
         for q in range(len(sel)):
-            if g0[3][q] != 0 or g1[3][q] != 0: continue
+            if g0[3][q] != 0 or g1[3][q] != 0 or hard[sel[q]]: continue
             sc = max(1.0, np.abs(g0[1][q]).max() if g0[1][q].size else 0.0, abs(g0[2][q]))
             e = max(np.abs(g1[1][q] - g0[1][q]).max() if g0[1][q].size else 0.0, abs(g1[2][q] - g0[2][q])) / sc
             w_grad = max(w_grad, e)
@@ -92,7 +123,8 @@ def run(pkg, cases=40, seed=1):
             n_sp += eng.predict_structured_particles() - s0
             pm0, pv0, _, pi0 = ref.predict_batch(nodes, noises, tp, n=n, check=False)
             okp = (pi0 == 0) & (pi1 == 0)
-            assert (pi0 != pi1).sum() <= max(2, P // 20), ("predict info", c, N, n, P)
+            assert ((pi0 != 0) != (pi1 != 0))[~hard].sum() <= max(2, P // 20), ("predict info", c, N, n, P)
+            assert np.isfinite(pm1[pi1 == 0]).all() and np.isfinite(pv1[pi1 == 0]).all(), ("predict / info", c, N, n, P)
             if okp.any():
                 sc = np.maximum(1.0, np.maximum(np.abs(pm0[okp]).max(axis=1), np.abs(pv0[okp]).max(axis=1)))[:, None]
                 ep = np.maximum((np.abs(pm1 - pm0)[okp] / sc).max(axis=1), (np.abs(pv1 - pv0)[okp] / sc).max(axis=1))
@@ -106,7 +138,7 @@ def run(pkg, cases=40, seed=1):
                     ed = max(np.abs(pm0[j] - ml).max(), np.abs(pv0[j] - vl).max()) / scj
                     print(f"  case {c} particle {j} (noise {noises[j]:.3g}, {nodes[j]}): structured vs dense {e:.2e}; vs 80-bit: structured {es:.2e}, dense {ed:.2e}", flush=True)
                     n_dis += 1
-                    assert es <= max(1e-7, 4.0 * ed), ("predict", c, N, n, P, j, e, es, ed)
+                    assert es <= max(1e-7, (30.0 if hard[j] else 4.0) * ed), ("predict", c, N, n, P, j, e, es, ed)
             if c % 4 == 0 and okp.any() and n <= 1024:
                 j = int(np.flatnonzero(okp)[0])
                 mo, co = O.predict_mvn(nodes[j].to_tuple(), float(noises[j]), ts[:n], xs[:n], tp)
@@ -115,7 +147,7 @@ def run(pkg, cases=40, seed=1):
                 assert e <= 1e-7, ("predict vs oracle", c, N, n, P, j, e)
         print(f"case {c}: N={N} n={n} P={P} ok  ({time.time()-t0:.0f}s)", flush=True)
     return (f"structured fuzz ok: {cases} cases; structured particles value {n_sv} / gradient {n_sg} / predictive {n_sp}; worst rel diff vs dense "
-            f"value {w_val:.2e}, gradient {w_grad:.2e}, predictive {w_pred:.2e}; predictive vs oracle {w_or:.2e}; predictive disagreements above 1e-7 settled by 80-bit arithmetic {n_dis}; not-PD particles {n_bad}; {time.time()-t0:.0f}s")
+            f"value {w_val:.2e}, gradient {w_grad:.2e}, predictive {w_pred:.2e}; predictive vs oracle {w_or:.2e}; predictive disagreements above 1e-7 settled by 80-bit arithmetic {n_dis}; not-PD particles {n_bad}; near-singular particles {n_hard} ({n_hard_bad} refused); {time.time()-t0:.0f}s")
 
 
 if __name__ == "__main__":
