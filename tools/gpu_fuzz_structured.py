@@ -117,7 +117,7 @@ def run(pkg, cases=40, seed=1):
             order = np.argsort(ts[:n], kind="stable")
             h = (ts.max() - ts.min()) / (N - 1)
             sub = ts[:n][order][:: int(rng.integers(1, 4))]
-            tp = np.concatenate([sub, ts[:n].max() + h * np.arange(1, int(rng.integers(1, 200)))])
+            tp = np.concatenate([sub, ts[:n].max() + h * np.arange(1, int(rng.integers(1, 200) if rng.random() < 0.85 else rng.integers(200, 2300)))])      # (joint grid up to 4096 points; longer horizons take the dense pass)
             s0 = eng.predict_structured_particles()
             pm1, pv1, _, pi1 = eng.predict_batch(nodes, noises, tp, n=n, check=False)
             n_sp += eng.predict_structured_particles() - s0
