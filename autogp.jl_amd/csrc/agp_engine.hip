@@ -811,28 +811,27 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       gather(part[1], sT.oo, sT.so, sT.po, sT.sp, sT.nz);
       sT.lp.resize(part[1].size()); sT.info.assign(part[1].size(), 0);
       auto structured = [&] {
-        sT.rc = toeplitz_sweep(c, n, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(), sT.sp.data(), sT.nz.data(), sT.lp.data(),
-                               sT.info.data());
+        return toeplitz_sweep(c, n, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(), sT.sp.data(), sT.nz.data(), sT.lp.data(),
+                              sT.info.data());
       };
       // (measured: 107 recursions beside the dense kernels at n = 4096: 18.1 -> 13.8 ms; 423 of them at n = 2048 fill every SIMD
       // with their own waves and only delay the dense kernels: 8.6 -> 9.2 ms — those go first, alone)
       const bool side_by_side = part[1].size() <= 256;
-      std::thread side;
-      if (side_by_side) { try { side = std::thread(structured); } catch (const std::system_error&) { structured(); } } else structured();
+      std::unique_ptr<Beside> side;
+      if (side_by_side) side.reset(new Beside(structured)); else sT.rc = structured();
       auto dense = [&](const std::vector<int>& ix) {
         if (ix.empty()) return 0;
         gather(ix, sD.oo, sD.so, sD.po, sD.sp, sD.nz);
         sD.lp.resize(ix.size()); sD.info.assign(ix.size(), 0);
-        tl_in_toeplitz = true;
+        TlFlag nested(tl_in_toeplitz);
         const int rc0 = logpdf_batch_impl(c, n, (int)ix.size(), sD.oo.data(), sD.so.data(), sD.po.data(), sD.sp.data(), sD.nz.data(), sD.lp.data(),
                                           sD.info.data(), nullptr, nullptr, nullptr, false, nullptr, allow_lag);
-        tl_in_toeplitz = false;
         if (rc0) return rc0;
         for (size_t b2 = 0; b2 < ix.size(); ++b2) { h_out_lp[ix[b2]] = sD.lp[b2]; if (h_out_info) h_out_info[ix[b2]] = sD.info[b2]; }
         return 0;
       };
       const int rcD = dense(part[0]);
-      if (side.joinable()) side.join();
+      if (side) sT.rc = side->join();
       if (rcD) return rcD;
       if (sT.rc) return sT.rc;
       std::vector<int> refused;
@@ -943,21 +942,20 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         if (ix.empty()) return 0;
         gather(ix, sD);
         GradOut dgo{sD.grad.data(), sD.gn.data()};
-        tl_in_tgrad = true;
+        TlFlag nested(tl_in_tgrad);
         const int rc0 = logpdf_batch_impl(c, n, (int)ix.size(), sD.oo.data(), sD.so.data(), sD.po.data(), sD.sp.data(), sD.nz.data(), sD.lp.data(),
                                           sD.info.data(), nullptr, nullptr, nullptr, false, &dgo, allow_lag);
-        tl_in_tgrad = false;
         if (rc0) return rc0;
         scatter(ix, sD, nullptr);
         return 0;
       };
       gather(part[1], sT);
       Beside side([&] {
-        sT.rc = toeplitz_grad_sweep(c, n, toep_rank0, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(), sT.sp.data(), sT.nz.data(),
-                                    sT.lp.data(), sT.info.data(), sT.grad.data(), sT.gn.data());
+        return toeplitz_grad_sweep(c, n, toep_rank0, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(), sT.sp.data(), sT.nz.data(),
+                                   sT.lp.data(), sT.info.data(), sT.grad.data(), sT.gn.data());
       });
       const int rcD = dense(part[0]);
-      side.join();
+      sT.rc = side.join();
       if (lagr) { std::lock_guard<std::mutex> g(c->mu); if (!part[0].empty()) --c->n_lag_rank_sweeps; }          // (one sweep, as far as the counters go)
       if (rcD) return rcD;
       if (sT.rc) return sT.rc;
@@ -1440,10 +1438,12 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       GradOut bgo{bgrad.data(), bgn.data()};
       if (store_lk.owns_lock()) store_lk.unlock();
       sg.release();
-      tl_no_toep = true;
-      const int rc2 = logpdf_batch_impl(c, n, B, bo.data(), bops.data(), bp.data(), bprm.data(), bnoise.data(), blp.data(), binfo.data(),
-                                        nullptr, nullptr, nullptr, false, &bgo, allow_lag);
-      tl_no_toep = false;
+      int rc2;
+      {
+        TlFlag nested(tl_no_toep);
+        rc2 = logpdf_batch_impl(c, n, B, bo.data(), bops.data(), bp.data(), bprm.data(), bnoise.data(), blp.data(), binfo.data(),
+                                nullptr, nullptr, nullptr, false, &bgo, allow_lag);
+      }
       if (rc2) return rc2;
       for (int b = 0; b < B; ++b) {
         const int p = rp[b];
@@ -1497,7 +1497,11 @@ extern "C" {
 
 const char* agp_version(void) { return "autogp-hip 0.1.0 (gfx950)"; }
 
+static int init_body(agp_ctx** out, int device_id);
 int agp_init(agp_ctx** out, int device_id) {
+  return abi_guard(nullptr, [&] { return init_body(out, device_id); });
+}
+static int init_body(agp_ctx** out, int device_id) {
   if (!out) return fail(nullptr, AGP_ERR_ARG, "null out pointer");
   *out = nullptr;
   int ndev = 0;
@@ -1608,7 +1612,11 @@ int agp_get_launch_times(agp_ctx* c, int32_t which, double* out, int32_t n_out) 
   return (int)v.size();
 }
 
+static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t n_max);
 int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) {
+  return abi_guard(c, [&] { return set_data_body(c, ts, xs, n_max); });
+}
+static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   if (n_max < 0 || (n_max > 0 && (!ts || !xs))) return fail(c, AGP_ERR_ARG, "bad data arguments");
   HIPCHK(c, hipSetDevice(c->device));
@@ -1795,7 +1803,7 @@ int agp_logpdf_batch(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, co
                      const int32_t* prm_off, const double* prm, const double* noise, double* out_logpdf,
                      int32_t* out_info) {
   if (c && P > 0 && (!out_logpdf || !out_info)) return fail(c, AGP_ERR_ARG, "null output pointer");
-  return logpdf_batch_dedup(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr);
+  return abi_guard(c, [&] { return logpdf_batch_dedup(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr); });
 }
 
 int agp_get_dedup_stats(agp_ctx* c, int64_t* n_particles, int64_t* n_evaluated) {
@@ -1810,7 +1818,7 @@ int agp_logpdf_grad_batch(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_of
                           double* out_grad, double* out_grad_noise, int32_t* out_info) {
   if (c && P > 0 && (!out_logpdf || !out_info || !out_grad || !out_grad_noise)) return fail(c, AGP_ERR_ARG, "null output pointer");
   GradOut go{out_grad, out_grad_noise};
-  return logpdf_batch_dedup(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, &go);
+  return abi_guard(c, [&] { return logpdf_batch_dedup(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, &go); });
 }
 
 int agp_logpdf_batch_device(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
@@ -1822,8 +1830,10 @@ int agp_logpdf_batch_device(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_
     { std::lock_guard<std::mutex> g(c->mu); fault = c->async_fault; c->async_fault = false; }
     if (fault) return fail(c, AGP_ERR_HIP, "an earlier asynchronous sweep timed out inside a kernel waiting for a diagonal factor (its info words are < 0)");
   }
-  return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, nullptr, nullptr, d_out_logpdf,
-                           d_out_info, (hipStream_t)hip_stream, hip_stream != nullptr);
+  return abi_guard(c, [&] {
+    return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, nullptr, nullptr, d_out_logpdf, d_out_info, (hipStream_t)hip_stream,
+                             hip_stream != nullptr);
+  });
 }
 
 int agp_wait(agp_ctx* c) {
@@ -1961,7 +1971,9 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
       c->n_coalesced_batches += 1;
       lk.unlock();
       const auto t0 = std::chrono::steady_clock::now();
-      run_coalesced(c, batch);
+      // (the followers of this batch wait for `done`: whatever happens in the sweep, they get an answer)
+      try { run_coalesced(c, batch); }
+      catch (...) { for (LpRequest* r : batch) { r->rc = AGP_ERR_HOST; r->lp = std::nan(""); r->info = 0; } }
       const double sweep_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
       lk.lock();
       c->last_sweep_us = sweep_us;
@@ -1981,7 +1993,7 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
 
 int agp_logpdf(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
                double noise, double* out_logpdf, int32_t* out_info) {
-  return logpdf_one(c, n, ops, n_ops, prm, n_prm, noise, out_logpdf, nullptr, nullptr, out_info);
+  return abi_guard(c, [&] { return logpdf_one(c, n, ops, n_ops, prm, n_prm, noise, out_logpdf, nullptr, nullptr, out_info); });
 }
 
 // Value + gradient of one particle — what Gen.choice_gradients needs per trace (Gen.hmc,
@@ -1990,7 +2002,7 @@ int agp_logpdf(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const d
 int agp_logpdf_grad(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
                     double noise, double* out_logpdf, double* out_grad, double* out_grad_noise, int32_t* out_info) {
   if (c && !out_grad_noise) return fail(c, AGP_ERR_ARG, "null gradient pointer");
-  return logpdf_one(c, n, ops, n_ops, prm, n_prm, noise, out_logpdf, out_grad, out_grad_noise, out_info);
+  return abi_guard(c, [&] { return logpdf_one(c, n, ops, n_ops, prm, n_prm, noise, out_logpdf, out_grad, out_grad_noise, out_info); });
 }
 
 int agp_get_coalesce_stats(agp_ctx* c, int64_t* n_calls, int64_t* n_batches) {

@@ -17,7 +17,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
+#include <new>
+#include <exception>
 #include <string>
 #include <system_error>
 #include <thread>
@@ -379,14 +382,35 @@ struct GradOut {
   double* gnoise;    // host [P], d logpdf / d noise
 };
 
-// f on a helper thread beside the caller's own work; here and now if no thread can be had (the caller joins either way)
+// No C++ exception crosses the C boundary (the callers are ccall / ctypes / C): a failed host allocation or anything else
+// unexpected becomes AGP_ERR_HOST with the message in agp_last_error; slots, locks and helper threads unwind through their guards.
+template <class F> inline int abi_guard(agp_ctx* c, F&& f) noexcept {
+  try { return f(); }
+  catch (const std::bad_alloc&) { try { return fail(c, AGP_ERR_HOST, "host allocation failed"); } catch (...) { return AGP_ERR_HOST; } }
+  catch (const std::exception& e) { try { return fail(c, AGP_ERR_HOST, std::string("internal error: ") + e.what()); } catch (...) { return AGP_ERR_HOST; } }
+  catch (...) { return AGP_ERR_HOST; }
+}
+
+// a thread-local switch held for a scope (nested sweeps of the structured paths)
+struct TlFlag {
+  bool& f;
+  explicit TlFlag(bool& f_) : f(f_) { f = true; }
+  ~TlFlag() { f = false; }
+  TlFlag(const TlFlag&) = delete; TlFlag& operator=(const TlFlag&) = delete;
+};
+
+// f (returning an engine code) on a helper thread beside the caller's own work; here and now if no thread can be had.  The
+// caller joins (or the destructor does) and reads rc; an exception inside f ends as AGP_ERR_HOST, never in std::terminate.
 struct Beside {
   std::thread th;
+  int rc = 0;
   template <class F> explicit Beside(F&& f) {
-    try { th = std::thread(f); } catch (const std::system_error&) { f(); }
+    auto body = [this, f]() mutable noexcept { try { rc = f(); } catch (...) { rc = AGP_ERR_HOST; } };
+    try { th = std::thread(body); } catch (const std::system_error&) { body(); }
   }
-  void join() { if (th.joinable()) th.join(); }
+  int join() { if (th.joinable()) th.join(); return rc; }
   ~Beside() { join(); }
+  Beside(const Beside&) = delete; Beside& operator=(const Beside&) = delete;
 };
 
 // a sum (top-level + chain) of Linear leaves and subtrees without Linear / ChangePoint: Toeplitz + rank 2 on consecutive grid points

@@ -113,7 +113,11 @@ int agp_comm_count(agp_ctx* c, int32_t* out_n_ranks) {
   return AGP_OK;
 }
 
+static int init_multi_body(agp_ctx** out, const int32_t* device_ids, int32_t n_dev);
 int agp_init_multi(agp_ctx** out, const int32_t* device_ids, int32_t n_dev) {
+  return abi_guard(nullptr, [&] { return init_multi_body(out, device_ids, n_dev); });
+}
+static int init_multi_body(agp_ctx** out, const int32_t* device_ids, int32_t n_dev) {
   if (!out || !device_ids || n_dev < 1) return fail(nullptr, AGP_ERR_ARG, "bad arguments");
   for (int i = 0; i < n_dev; ++i) out[i] = nullptr;
   for (int i = 0; i < n_dev; ++i)
@@ -140,7 +144,11 @@ int agp_init_multi(agp_ctx** out, const int32_t* device_ids, int32_t n_dev) {
   return AGP_OK;
 }
 
+static int set_data_multi_body(agp_ctx* const* ctxs, int32_t n_dev, const double* ts, const double* xs, int64_t n_max);
 int agp_set_data_multi(agp_ctx* const* ctxs, int32_t n_dev, const double* ts, const double* xs, int64_t n_max) {
+  return abi_guard((ctxs && n_dev > 0) ? ctxs[0] : nullptr, [&] { return set_data_multi_body(ctxs, n_dev, ts, xs, n_max); });
+}
+static int set_data_multi_body(agp_ctx* const* ctxs, int32_t n_dev, const double* ts, const double* xs, int64_t n_max) {
   if (!ctxs || n_dev < 1) return fail(nullptr, AGP_ERR_ARG, "bad arguments");
   for (int i = 0; i < n_dev; ++i) {
     const int rc = agp_set_data(ctxs[i], ts, xs, n_max);
@@ -170,7 +178,11 @@ static int allgather_device_locked(agp_ctx* c, const double* d_local, int32_t P,
   return AGP_OK;
 }
 
+static int allgather_logweights_device_body(agp_ctx* c, const double* d_local, int32_t P, double* d_all, void* hip_stream);
 int agp_allgather_logweights_device(agp_ctx* c, const double* d_local, int32_t P, double* d_all, void* hip_stream) {
+  return abi_guard(c, [&] { return allgather_logweights_device_body(c, d_local, P, d_all, hip_stream); });
+}
+static int allgather_logweights_device_body(agp_ctx* c, const double* d_local, int32_t P, double* d_all, void* hip_stream) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   if (P < 0 || (P > 0 && !d_all)) return fail(c, AGP_ERR_ARG, "bad arguments");
   if (P == 0) return AGP_OK;
@@ -199,7 +211,11 @@ int agp_debug_compact_shards(agp_ctx* c, const double* padded, int32_t P, int32_
   return AGP_OK;
 }
 
+static int allgather_logweights_body(agp_ctx* c, double* inout_lw, int32_t P);
 int agp_allgather_logweights(agp_ctx* c, double* inout_lw, int32_t P) {
+  return abi_guard(c, [&] { return allgather_logweights_body(c, inout_lw, P); });
+}
+static int allgather_logweights_body(agp_ctx* c, double* inout_lw, int32_t P) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   if (P < 0 || (P > 0 && !inout_lw)) return fail(c, AGP_ERR_ARG, "bad arguments");
   if (P == 0 || c->comm_size == 1) return AGP_OK;          // a one-rank population is already complete
@@ -264,7 +280,7 @@ static int logpdf_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t 
   // callers are serialised here — the per-device worker threads hold a single job slot each.
   std::lock_guard<std::mutex> multi_lock(c0->multi_mu);
   std::vector<int> rcs((size_t)n_dev, AGP_OK);
-  auto shard = [&](int d) {
+  auto shard_body = [&](int d) {
     agp_ctx* c = ctxs[d];
     int lo, hi;
     shard_range(P, d, n_dev, &lo, &hi);
@@ -294,10 +310,17 @@ static int logpdf_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t 
                                  out_info + lo, d_loc, nullptr, nullptr, false);
     }
   };
-  // devices 1 .. n_dev-1 run on their contexts' persistent host threads (created at the first call, joined by
-  // agp_destroy), device 0's shard on the calling thread
+  // (no exception leaves a shard: the other devices' jobs refer to this frame until they are done)
+  auto shard = [&](int d) noexcept {
+    try { shard_body(d); }
+    catch (const std::bad_alloc&) { rcs[d] = AGP_ERR_HOST; }
+    catch (...) { rcs[d] = AGP_ERR_HOST; }
+  };
+  // devices 1 .. n_dev-1 run on their contexts' persistent host threads (created at the first call — all of them before the
+  // first job is posted — and joined by agp_destroy), device 0's shard on the calling thread
+  for (int d = 1; d < n_dev; ++d) (void)ensure_worker(ctxs[d]);
   for (int d = 1; d < n_dev; ++d) {
-    agp_ctx::Worker* w = ensure_worker(ctxs[d]);
+    agp_ctx::Worker* w = ctxs[d]->worker;
     { std::lock_guard<std::mutex> g(w->mu); w->job = [&shard, d]() { shard(d); }; w->has_job = true; w->done = false; }
     w->cv.notify_all();
   }
@@ -308,7 +331,7 @@ static int logpdf_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t 
     w->cv.wait(g, [&] { return w->done; });
   }
   for (int d = 0; d < n_dev; ++d)
-    if (rcs[d]) { if (d) fail(c0, rcs[d], agp_last_error(ctxs[d])); return rcs[d]; }
+    if (rcs[d]) { if (rcs[d] == AGP_ERR_HOST) return fail(c0, AGP_ERR_HOST, "host allocation failed in a device's shard"); if (d) fail(c0, rcs[d], agp_last_error(ctxs[d])); return rcs[d]; }
   if (n_dev == 1) {
     HIPCHK(c0, hipSetDevice(c0->device));
     HIPCHK(c0, hipMemcpy(out_logpdf, c0->comm_all.as<double>() + P, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost));
@@ -339,7 +362,7 @@ static int logpdf_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t 
 int agp_logpdf_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off,
                            const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
                            double* out_logpdf, int32_t* out_info) {
-  return logpdf_batch_multi_impl(ctxs, n_dev, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, false);
+  return abi_guard((ctxs && n_dev > 0) ? ctxs[0] : nullptr, [&] { return logpdf_batch_multi_impl(ctxs, n_dev, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, false); });
 }
 
 // The same with resident factors: every device runs its shard as an extension sweep (agp_logpdf_batch_extend) — the
@@ -347,7 +370,7 @@ int agp_logpdf_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32
 int agp_logpdf_batch_extend_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off,
                                   const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
                                   double* out_logpdf, int32_t* out_info) {
-  return logpdf_batch_multi_impl(ctxs, n_dev, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, true);
+  return abi_guard((ctxs && n_dev > 0) ? ctxs[0] : nullptr, [&] { return logpdf_batch_multi_impl(ctxs, n_dev, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, true); });
 }
 
 }  // extern "C"

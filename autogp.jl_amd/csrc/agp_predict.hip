@@ -614,7 +614,19 @@ thread_local bool tl_in_tpredict = false;
 
 extern "C" {
 
+static int predict_batch_body(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P,
+                      const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                      const double* noise, const double* noise_pred, const double* mean_train,
+                      const double* mean_pred, double* out_mean, double* out_var, double* out_cov,
+                      int32_t* out_info);
 int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P,
+                      const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                      const double* noise, const double* noise_pred, const double* mean_train,
+                      const double* mean_pred, double* out_mean, double* out_var, double* out_cov,
+                      int32_t* out_info) {
+  return abi_guard(c, [&] { return predict_batch_body(c, n, ts_pred, m, P, op_off, ops, prm_off, prm, noise, noise_pred, mean_train, mean_pred, out_mean, out_var, out_cov, out_info); });
+}
+static int predict_batch_body(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_t P,
                       const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
                       const double* noise, const double* noise_pred, const double* mean_train,
                       const double* mean_pred, double* out_mean, double* out_var, double* out_cov,
@@ -686,7 +698,7 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
       gather(part[1], sT.oo, sT.so, sT.po, sT.sp, sT.nz, sT.nzp);
       sT.mean.resize(part[1].size() * (size_t)m); sT.var.resize(part[1].size() * (size_t)m); sT.info.assign(part[1].size(), 0);
       Beside side([&] {
-        sT.rc = toeplitz_predict_sweep(c, n, rank0_abs, mF, plq, qkind, xq, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(),
+        return toeplitz_predict_sweep(c, n, rank0_abs, mF, plq, qkind, xq, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(),
                                        sT.sp.data(), sT.nz.data(), sT.nzp.data(), sT.mean.data(), sT.var.data(), sT.info.data(),
                                        mean_train ? xres.data() : nullptr, mean_pred);
       });
@@ -694,10 +706,9 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
         if (ix.empty()) return 0;
         gather(ix, sD.oo, sD.so, sD.po, sD.sp, sD.nz, sD.nzp);
         sD.mean.resize(ix.size() * (size_t)m); sD.var.resize(ix.size() * (size_t)m); sD.info.assign(ix.size(), 0);
-        tl_in_tpredict = true;
+        TlFlag nested(tl_in_tpredict);
         const int rc0 = agp_predict_batch(c, n, ts_pred, m, (int32_t)ix.size(), sD.oo.data(), sD.so.data(), sD.po.data(), sD.sp.data(), sD.nz.data(),
                                           sD.nzp.data(), mean_train, mean_pred, sD.mean.data(), sD.var.data(), nullptr, sD.info.data());
-        tl_in_tpredict = false;
         if (rc0) return rc0;
         for (size_t b = 0; b < ix.size(); ++b) {
           std::memcpy(out_mean + (size_t)ix[b] * m, sD.mean.data() + b * (size_t)m, sizeof(double) * (size_t)m);
@@ -707,7 +718,7 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
         return 0;
       };
       const int rcD = dense(part[0]);
-      side.join();
+      sT.rc = side.join();
       if (rcD) return rcD;
       if (sT.rc) return sT.rc;
       std::vector<int> refused;
@@ -812,7 +823,15 @@ int agp_predict_batch(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, i
 // sum_i SEL_i * K_i evaluated on coded points (SEL_i(a,b) = 1 when both points are the observable or the
 // latent of component i), so the whole computation is one pass of the predictive machinery:
 // Cholesky of Sigma_bb = S_tt + noise I (src/GP.jl:982), Schur complement (984), + JITTER I (986).
+static int infer_gp_sum_body(agp_ctx* c, int64_t n, const double* ts_pred, int64_t p, int32_t M,
+                     const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                     double noise, double noise_pred, double* out_mean, double* out_cov, int32_t* out_info);
 int agp_infer_gp_sum(agp_ctx* c, int64_t n, const double* ts_pred, int64_t p, int32_t M,
+                     const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                     double noise, double noise_pred, double* out_mean, double* out_cov, int32_t* out_info) {
+  return abi_guard(c, [&] { return infer_gp_sum_body(c, n, ts_pred, p, M, op_off, ops, prm_off, prm, noise, noise_pred, out_mean, out_cov, out_info); });
+}
+static int infer_gp_sum_body(agp_ctx* c, int64_t n, const double* ts_pred, int64_t p, int32_t M,
                      const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
                      double noise, double noise_pred, double* out_mean, double* out_cov, int32_t* out_info) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
@@ -856,7 +875,13 @@ int agp_infer_gp_sum(agp_ctx* c, int64_t n, const double* ts_pred, int64_t p, in
   return rc;
 }
 
+static int cov_matrix_body(agp_ctx* c, const double* ts, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm,
+                   int32_t n_prm, double noise, double* out_K);
 int agp_cov_matrix(agp_ctx* c, const double* ts, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm,
+                   int32_t n_prm, double noise, double* out_K) {
+  return abi_guard(c, [&] { return cov_matrix_body(c, ts, n, ops, n_ops, prm, n_prm, noise, out_K); });
+}
+static int cov_matrix_body(agp_ctx* c, const double* ts, int64_t n, const uint8_t* ops, int32_t n_ops, const double* prm,
                    int32_t n_prm, double noise, double* out_K) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   if (n < 0) return fail(c, AGP_ERR_ARG, "negative size");

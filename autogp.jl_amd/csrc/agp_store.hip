@@ -356,7 +356,7 @@ extern "C" {
 int agp_logpdf_batch_extend(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
                             const int32_t* prm_off, const double* prm, const double* noise, double* out_logpdf,
                             int32_t* out_info) {
-  return extend_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info);
+  return abi_guard(c, [&] { return extend_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info); });
 }
 
 int agp_extend_stats(agp_ctx* c, int64_t* out4) {

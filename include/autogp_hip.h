@@ -62,6 +62,7 @@ typedef struct agp_ctx agp_ctx;
 #define AGP_ERR_PROGRAM     -3   /* malformed postfix program / unsupported tree shape */
 #define AGP_ERR_NODATA      -4
 #define AGP_ERR_COMM        -5   /* RCCL unavailable / collective failed */
+#define AGP_ERR_HOST        -6   /* host allocation failure or any other C++ exception, stopped at the C boundary */
 
 #define AGP_MAX_OPS        255   /* nodes per kernel tree (depth-6 full tree = 63) */
 
