@@ -2,7 +2,7 @@
 streaming run makes (scripts/online.jl) — extension sweeps on growing prefixes, predictive passes (resident factors, resident
 L^-T, structured pass), gradient sweeps, rejuvenated / resampled particles, appended data (add_data!), store resets — and every
 result is compared with a second engine that keeps nothing (AGP_FACTOR_CACHE=0 AGP_PREDICT_REUSE=0, dense / element-wise sweeps).
-Usage: gpu_fuzz_stream.py [sequences] [seed]"""
+Usage: gpu_fuzz_stream.py [sequences] [seed] [big]   (big: series of 2500 .. 4096 points)"""
 import os, sys, time
 from pathlib import Path
 import numpy as np
@@ -11,7 +11,7 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as g
 
 
-def run(pkg, sequences=20, seed=1, steps=14):
+def run(pkg, sequences=20, seed=1, steps=14, big=False):
     eng = pkg.GPEngine(0)
     env = (("AGP_GRAD_FFT", "0"), ("AGP_GRAD_LAGDOM", "0"), ("AGP_LAG", "0"), ("AGP_LAG_RANK", "0"), ("AGP_FACTOR_CACHE", "0"), ("AGP_PREDICT_REUSE", "0"))
     for k, v in env: os.environ[k] = v
@@ -20,8 +20,8 @@ def run(pkg, sequences=20, seed=1, steps=14):
     rng = np.random.default_rng(seed)
     t0 = time.time(); w = {"value": 0.0, "predict": 0.0, "gradient": 0.0}; n_ops = {"extend": 0, "predict": 0, "gradient": 0, "append": 0, "reset": 0}
     for q in range(sequences):
-        N = int(rng.choice([300, 640, 900, 1280, 2048]))
-        P = int(rng.choice([8, 40, 64, 130])) if N <= 1280 else int(rng.choice([8, 40, 64]))
+        N = int(rng.choice([2500, 3000, 4096] if big else [300, 640, 900, 1280, 2048]))
+        P = int(rng.choice([8, 24])) if big else int(rng.choice([8, 40, 64, 130])) if N <= 1280 else int(rng.choice([8, 40, 64]))
         regular = rng.random() < 0.7
         ordered = rng.random() < 0.5
         ts, xs = pkg.prior.synthetic_series(N, seed=int(rng.integers(1 << 30)), shuffle=not ordered)
@@ -117,4 +117,4 @@ def run(pkg, sequences=20, seed=1, steps=14):
 
 if __name__ == "__main__":
     pkg_ = g.load_package()
-    print(run(pkg_, int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 1))
+    print(run(pkg_, int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 1, big=len(sys.argv) > 3 and sys.argv[3] == "big"))

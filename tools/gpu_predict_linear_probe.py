@@ -1,3 +1,6 @@
+"""Structured predictive pass on pure Linear kernels (centres inside and far outside the data, small noise): errors of the
+structured and the dense pass against an 80-bit factorisation, observed and future points apart.  The probe behind the
+future-point mean fix of round 4 (h' S U'a instead of h' C (U'a - N S U'a))."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
