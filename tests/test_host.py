@@ -67,6 +67,21 @@ def test_header_symbols_exported(pkg):
     assert b"gfx950" in lib.agp_version()
 
 
+def test_header_is_plain_c(tmp_path):
+    """include/autogp_hip.h is what a C / cgo / ccall binding includes: it must compile as C99 (no C++ in the signatures), and the
+    error codes are the documented ones."""
+    import shutil, subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "autogp_hip.h"\n'
+                   "int main(void) { return (AGP_OK == 0 && AGP_ERR_ARG == -1 && AGP_ERR_HIP == -2 && AGP_ERR_PROGRAM == -3 && AGP_ERR_NODATA == -4 &&\n"
+                   "                         AGP_ERR_COMM == -5 && AGP_ERR_HOST == -6 && AGP_COMM_ID_BYTES == 128) ? 0 : 1; }\n")
+    exe = tmp_path / "hdr"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+
+
 def test_julia_ccall_signatures(tmp_path):
     """The Julia shim has never been executed (no Julia here or on the GPU box): every ccall's type tuple, argument count
     and return type is checked statically against the prototypes of include/autogp_hip.h (tools/check_ccall_signatures.py)
