@@ -11,12 +11,7 @@ sys.path.insert(0, str(ROOT))
 import __graft_entry__ as g
 
 
-def run(pkg, sequences=20, seed=1, steps=14, big=False):
-    eng = pkg.GPEngine(0)
-    env = (("AGP_GRAD_FFT", "0"), ("AGP_GRAD_LAGDOM", "0"), ("AGP_LAG", "0"), ("AGP_LAG_RANK", "0"), ("AGP_FACTOR_CACHE", "0"), ("AGP_PREDICT_REUSE", "0"))
-    for k, v in env: os.environ[k] = v
-    ref = pkg.GPEngine(0)
-    for k, _ in env: del os.environ[k]
+def _run(pkg, eng, ref, sequences=20, seed=1, steps=14, big=False):
     rng = np.random.default_rng(seed)
     t0 = time.time(); w = {"value": 0.0, "predict": 0.0, "gradient": 0.0}; n_ops = {"extend": 0, "predict": 0, "gradient": 0, "append": 0, "reset": 0}
     for q in range(sequences):
@@ -113,6 +108,20 @@ def run(pkg, sequences=20, seed=1, steps=14, big=False):
     st = eng.extend_stats(); pr = eng.predict_reuse_stats(); gr = eng.grad_reuse_stats()
     return (f"stream fuzz ok: {sequences} sequences, calls {n_ops}; worst rel diff vs the engine that keeps nothing: {w}; "
             f"store {st}; predictive reuse {pr}; structured predictive particles {eng.predict_structured_particles()}; gradient reuse {gr}; {time.time()-t0:.0f}s")
+
+
+def run(pkg, sequences=20, seed=1, steps=14, big=False):
+    eng = pkg.GPEngine(0)
+    env = (("AGP_GRAD_FFT", "0"), ("AGP_GRAD_LAGDOM", "0"), ("AGP_LAG", "0"), ("AGP_LAG_RANK", "0"), ("AGP_FACTOR_CACHE", "0"), ("AGP_PREDICT_REUSE", "0"))
+    for k, v in env: os.environ[k] = v
+    try:
+        ref = pkg.GPEngine(0)
+    finally:
+        for k, _ in env: del os.environ[k]
+    try:
+        return _run(pkg, eng, ref, sequences, seed, steps, big)
+    finally:
+        eng.close(); ref.close()
 
 
 if __name__ == "__main__":

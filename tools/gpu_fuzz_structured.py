@@ -46,12 +46,7 @@ def logpdf_longdouble(tree, noise, ts, xs):
     return float(-0.5 * (b @ b) - np.log(np.diag(L)).sum() - 0.5 * n * np.log(2 * np.longdouble(np.pi)))
 
 
-def run(pkg, cases=40, seed=1):
-    os.environ["AGP_GRAD_FFT"] = "4"          # structured gradient sweeps whatever the population size
-    eng = pkg.GPEngine(0)
-    for k, v in (("AGP_GRAD_FFT", "0"), ("AGP_GRAD_LAGDOM", "0"), ("AGP_LAG", "0")): os.environ[k] = v
-    ref = pkg.GPEngine(0)
-    for k in ("AGP_GRAD_FFT", "AGP_GRAD_LAGDOM", "AGP_LAG"): del os.environ[k]
+def _run(pkg, eng, ref, cases=40, seed=1):
     rng = np.random.default_rng(seed)
     t0 = time.time(); w_val = w_grad = w_pred = w_or = 0.0; n_sv = n_sg = n_sp = 0; n_bad = 0; n_dis = 0; n_hard = n_hard_bad = 0
     for c in range(cases):
@@ -148,6 +143,20 @@ def run(pkg, cases=40, seed=1):
         print(f"case {c}: N={N} n={n} P={P} ok  ({time.time()-t0:.0f}s)", flush=True)
     return (f"structured fuzz ok: {cases} cases; structured particles value {n_sv} / gradient {n_sg} / predictive {n_sp}; worst rel diff vs dense "
             f"value {w_val:.2e}, gradient {w_grad:.2e}, predictive {w_pred:.2e}; predictive vs oracle {w_or:.2e}; predictive disagreements above 1e-7 settled by 80-bit arithmetic {n_dis}; not-PD particles {n_bad}; near-singular particles {n_hard} ({n_hard_bad} refused); {time.time()-t0:.0f}s")
+
+
+def run(pkg, cases=40, seed=1):
+    os.environ["AGP_GRAD_FFT"] = "4"          # structured gradient sweeps whatever the population size
+    try:
+        eng = pkg.GPEngine(0)
+        for k, v in (("AGP_GRAD_FFT", "0"), ("AGP_GRAD_LAGDOM", "0"), ("AGP_LAG", "0")): os.environ[k] = v
+        ref = pkg.GPEngine(0)
+    finally:
+        for k in ("AGP_GRAD_FFT", "AGP_GRAD_LAGDOM", "AGP_LAG"): os.environ.pop(k, None)
+    try:
+        return _run(pkg, eng, ref, cases, seed)
+    finally:
+        eng.close(); ref.close()
 
 
 if __name__ == "__main__":
