@@ -3,10 +3,12 @@
 import re, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
-src = ROOT / "autogp.jl_amd" / "csrc" / "agp_engine.hip"
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-       "-Rpass-analysis=kernel-resource-usage", "-o", "/tmp/agp_res.so", str(src), "-ldl"] + [a for a in sys.argv[2:]]
-out = subprocess.run(cmd, capture_output=True, text=True, cwd=str(src.parent)).stderr
+csrc = ROOT / "autogp.jl_amd" / "csrc"
+out = ""
+for src in sorted(csrc.glob("agp_kernels*.hip")):          # the kernel translation units (the host units hold no __global__)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Rpass-analysis=kernel-resource-usage",
+           "-c", str(src), "-o", "/tmp/agp_res.o"] + [a for a in sys.argv[2:]]
+    out += subprocess.run(cmd, capture_output=True, text=True, cwd=str(csrc)).stderr
 cur = None; rows = []
 for ln in out.splitlines():
     m = re.search(r"Function Name: (\S+)", ln)
