@@ -784,7 +784,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   // Structured value sweep (opt-in): on a regular grid, the particles whose kernel is a sum of stationary subtrees and Linear
   // leaves need no factorisation at all — Toeplitz + rank 2: Schur algorithm, O(n^2) — the others (and every particle the
   // structured sweep refuses) take the dense path below.
-  if (!go && c->toeplitz && !tl_in_toeplitz && allow_lag && c->lag_enable && c->lag_ok && n > 0 && n == c->n_max && n <= 4096 &&
+  if (!go && c->toeplitz && !tl_in_toeplitz && allow_lag && c->lag_enable && c->lag_ok && c->lag_contig && n > 0 && n == c->n_max && n <= 4096 &&
       h_out_lp && !d_user_lp && !d_user_info && !use_user_stream && !c->profiling) {
     std::vector<int> part[2];
     bool sane = true;
@@ -855,11 +855,13 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   // (the schedule is chosen per call from P and n; chunked / multi-stream sub-batches re-check with their own size)
   const bool flow_hint = n > 0 && use_flow(c, P, (int)((n + NB - 1) / NB));
   // value sweeps over the whole of a regular grid run on the sorted copy with lag tables (see agp_ctx::d_ts_s)
-  const bool lag = allow_lag && c->lag_enable && c->lag_ok && !go && n > 0 && n == c->n_max;
+  const bool lag = allow_lag && c->lag_enable && c->lag_ok && c->lag_contig && !go && n > 0 && n == c->n_max;
   // ... every other sweep over (a prefix of) a regular grid — annealing prefixes, gradient sweeps — keeps the caller's order and
   // reads the same leaves from RANK tables: |t_a - t_b| = |rank_a - rank_b| h in any order (cov_prologue)
-  const int rank_units = (int)((c->n_max + 255) / 256);
-  bool lagr = !lag && allow_lag && c->lag_rank_enable && c->lag_enable && c->lag_ok && n > 0 && c->n_max <= 4096;
+  // (a lattice with gaps — calendar-indexed series — has n_lat > n_max lags; tables of more than U_MAX_CP units never fit the fused
+  // evaluators' LDS, so those programs get their tiles from k_cov_tiles, which reads the tables in place: compile_batch)
+  const int rank_units = (int)((c->n_lat + 255) / 256);
+  bool lagr = !lag && allow_lag && c->lag_rank_enable && c->lag_enable && c->lag_ok && n > 0 && c->n_lat <= LATTICE_MAX;
   int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint, lag || lagr, lagr ? rank_units : 1, lagr);
   if (rc) return rc;
   if (lagr) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_rank_sweeps; }
@@ -871,7 +873,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   int32_t toep_rank0 = 0;
   bool any_toep_sweep = false;                 // some particle of this sweep took the Toeplitz solves
   std::vector<int32_t> toep_retry;             // ... and (caller order) whether its downdate was rejected on the device
-  if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->n_max <= LAGDOM_MAX_BINS) {
+  if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->lag_contig && c->n_max <= LAGDOM_MAX_BINS) {
     int64_t n_cov = 0, n_sum = 0;          // lag-domain particles; of which sums of stationary subtrees and Linear leaves
     // (the transform has one length, 4096: below ~1000 points the K^-1 tiles are cheaper than n/2 transforms of that length)
     const bool use_fft = c->grad_fft && c->d_fft_tw != nullptr && 2 * c->n_max <= FFT_N && n > GRAD_FFT_MIN_N;      // (n: this sweep's prefix — the number of transforms)
@@ -1118,12 +1120,12 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       // the sweep's lag tables: every stationary leaf of every particle at the 255 lags of each of the nt block diagonals
       // (sorted sweep) / at every lag 0 .. n_max-1 of the series (rank tables)
       LagArgs la = {};
-      la.tt = c->d_ts_s; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
+      la.tt = lagr ? c->d_ts_lat : c->d_ts_s; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
       la.tops = reinterpret_cast<const uint8_t*>(dstage + o_tops); la.tprm = reinterpret_cast<const double*>(dstage + o_tprm);
       la.n_tables = bt.n_lag_tables;
       if (lagr) {
         HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * rank_units * 256));
-        la.tab = s->lagtab.as<double>(); la.nt = (int)((c->n_max + NB - 1) / NB); la.full = 1; la.stride = rank_units * 256;
+        la.tab = s->lagtab.as<double>(); la.nt = (int)((c->n_lat + NB - 1) / NB); la.full = 1; la.stride = rank_units * 256;
         launch_lag_tables(st, la, rank_units, bt.n_lag_tables);
       } else {
         HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * nt * 256));
@@ -1537,6 +1539,7 @@ static int init_body(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_GE_TABLE")) c->ge_table = atoi(e) != 0;
   if (const char* e = getenv("AGP_LAG")) { c->lag_enable = atoi(e) != 0; c->toeplitz = atoi(e) >= 3 ? 2 : atoi(e) >= 2 ? 1 : 0; }
   if (const char* e = getenv("AGP_LAG_RANK")) c->lag_rank_enable = atoi(e) != 0;
+  if (const char* e = getenv("AGP_LATTICE")) c->lattice_enable = atoi(e) != 0;
   if (const char* e = getenv("AGP_GRAD_LAGDOM")) c->grad_lagdom = std::max(0, std::min(2, atoi(e)));
   if (const char* e = getenv("AGP_GRAD_FFT")) { c->grad_fft = std::max(0, std::min(2, atoi(e))); c->grad_struct = atoi(e) >= 4 ? 2 : atoi(e) >= 3 ? 1 : 0; }
   if (const char* e = getenv("AGP_RIGHT_LOOKING")) c->right_looking = atoi(e);
@@ -1572,6 +1575,7 @@ void agp_destroy(agp_ctx* c) {
   if (c->d_ts_s) (void)hipFree(c->d_ts_s);
   if (c->d_xs_s) (void)hipFree(c->d_xs_s);
   if (c->d_rank) (void)hipFree(c->d_rank);
+  if (c->d_ts_lat) (void)hipFree(c->d_ts_lat);
   if (c->d_fft_tw) (void)hipFree(c->d_fft_tw);
   if (c->d_flow_trace) (void)hipFree(c->d_flow_trace);
   delete c;
@@ -1612,6 +1616,109 @@ int agp_get_launch_times(agp_ctx* c, int32_t which, double* out, int32_t n_out) 
   return (int)v.size();
 }
 
+// Regular grid / lattice-with-gaps test of a SORTED series (agp_set_data; pure host code: agp_probe_lattice runs it without a device).
+struct LatticeFit {
+  int kind = 0;                 // 0 irregular, 1 regular grid (index i = i), 2 lattice with gaps
+  double h = 0.0, dmin = 0.0;   // lattice spacing; smallest gap of the data (the tolerance's unit)
+  int64_t n_lat = 0;            // lattice points spanned
+  std::vector<int64_t> index;   // lattice index of sorted point i
+};
+// hint_h: spacing of the lattice the previous series sat on (an append, src/api.jl:426-443, keeps the old points — the reference
+// transforms the new dates with the model's own slope and intercept — so the old spacing is tried first: the times of the
+// unoccupied lattice points, and with them the resident factors' table entries, then stay bit for bit what they were).
+static LatticeFit fit_lattice(const std::vector<double>& tss, double lag_tol_h, bool allow_gaps, double hint_h = 0.0) {
+  LatticeFit lf;
+  const int64_t n_max = (int64_t)tss.size();
+  if (n_max < 2) return lf;
+  {
+    const double t0 = tss.front(), t1 = tss.back();
+    const double h = (t1 - t0) / (double)(n_max - 1);
+    // The tolerance is a fraction of the SPACING, not of |t|: on the lag path every t_i - t_j is replaced by the table's
+    // t_sorted[g] - t_sorted[0], which differs from the element's own difference by up to ~4 position errors, i.e. by a relative
+    // 4 err / (g h) of the lag.  A point's position error is its measured deviation from t_0 + g h PLUS the quantisation of the
+    // time axis itself, one ulp of |t|max (t_0 + g h is evaluated in the same arithmetic as np.linspace / range, so for
+    // linspace(1000, 1001, n) the measured deviation is exactly 0 while the differences are only good to 1e-13 / h).
+    // linspace(0, 1, n): err / h = 7e-13 at n = 2048 (5e-12 at n = 16384), agreement with the general path 4e-13 of the log-pdf
+    // on short-lengthscale populations; the bound admits 1e-11, which keeps that agreement below 1e-11 — three digits under the
+    // 1e-8 contract.  A series with a large offset (linspace(1000, 1001, 2048): 4.6e-10) or a jitter below the former
+    // 16-ulp-of-|t| bound takes the general path.
+    const double quant = 2.220446049250313e-16 * std::max(std::fabs(t0), std::fabs(t1));
+    const double tol = lag_tol_h * h - quant;
+    bool regular = std::isfinite(h) && h > 0.0 && tol > 0.0;
+    for (int64_t i = 0; regular && i < n_max; ++i) regular = std::fabs(tss[(size_t)i] - (t0 + (double)i * h)) <= tol;
+    // Lattice with gaps.  A calendar-indexed series is never a regular grid in seconds — the reference converts dates with
+    // datetime2unix and min-max rescales them (src/api.jl:49-51,98-101): months last 28..31 days, quarters 90..92, years 365 / 366,
+    // business days skip weekends — but every such time IS an integer multiple of one day: t_i = t_0 + g_i h with integer
+    // lattice indices g_i, and |t_a - t_b| = |g_a - g_b| h for every pair, which is all the rank tables need (cov_prologue; the
+    // table of a stationary subtree then holds n_lat = g_max + 1 lags and is read in place from L2 by k_cov_tiles).  The spacing
+    // is sought as (smallest gap) / k, k = 1 .. LATTICE_MAX_DIV, refined to (t_last - t_0) / g_last; the position bound is the
+    // regular grid's, taken relative to the SMALLEST GAP of the data (the shortest lag any table entry in use represents).
+    std::vector<int64_t> lat;            // lattice index of sorted point i
+    double hl = h, dmin_lat = h; int64_t n_lat = n_max;
+    bool lattice = false;
+    if (!regular && allow_gaps && n_max >= 3 && std::isfinite(t0) && std::isfinite(t1) && t1 > t0) {
+      double dmin = t1 - t0;
+      bool distinct = true;
+      for (int64_t i = 1; i < n_max && distinct; ++i) {
+        const double d = tss[(size_t)i] - tss[(size_t)i - 1];
+        distinct = d > 0.0;
+        dmin = std::min(dmin, d);
+      }
+      const double tol_l = lag_tol_h * dmin - quant;
+      if (distinct && tol_l > 0.0) {
+        lat.resize((size_t)n_max);
+        if (hint_h > 0.0 && (t1 - t0) / hint_h <= (double)LATTICE_MAX && 8.0 * ((t1 - t0) / hint_h) <= (double)n_max * (double)n_max) {
+          bool ok = true;
+          for (int64_t i = 0; ok && i < n_max; ++i) {
+            const double g = std::nearbyint((tss[(size_t)i] - t0) / hint_h);
+            lat[(size_t)i] = (int64_t)g;
+            ok = std::fabs(tss[(size_t)i] - (t0 + g * hint_h)) <= tol_l;
+          }
+          if (ok && lat.back() > 0) { lattice = true; hl = hint_h; n_lat = lat.back() + 1; dmin_lat = dmin; }
+        }
+        for (int k = 1; k <= LATTICE_MAX_DIV && !lattice; ++k) {
+          const double h0 = dmin / (double)k;
+          // (tables of n_lat lags must stay well below the n (n + 1) / 2 elements they stand for: a yearly index of 300 points spans
+          // 109 208 days — not worth a table; such series are short and take the general path)
+          if ((t1 - t0) / h0 > (double)LATTICE_MAX || 8.0 * ((t1 - t0) / h0) > (double)n_max * (double)n_max) break;
+          bool ok = true;
+          for (int64_t i = 0; ok && i < n_max; ++i) {
+            const double q = (tss[(size_t)i] - t0) / h0, g = std::nearbyint(q);
+            ok = std::fabs(q - g) <= 1e-3;
+            lat[(size_t)i] = (int64_t)g;
+          }
+          if (!ok || lat.back() <= 0) continue;
+          const double h1 = (t1 - t0) / (double)lat.back();
+          for (int64_t i = 0; ok && i < n_max; ++i) ok = std::fabs(tss[(size_t)i] - (t0 + (double)lat[(size_t)i] * h1)) <= tol_l;
+          if (ok) { lattice = true; hl = h1; n_lat = lat.back() + 1; dmin_lat = dmin; }
+        }
+      }
+    }
+    if (regular) { lat.resize((size_t)n_max); for (int64_t i = 0; i < n_max; ++i) lat[(size_t)i] = i; }
+    lf.kind = regular ? 1 : lattice ? 2 : 0;
+    lf.h = hl; lf.dmin = regular ? h : dmin_lat; lf.n_lat = n_lat;
+    if (lf.kind) lf.index.swap(lat);
+  }
+  return lf;
+}
+
+int agp_probe_lattice(const double* ts, int64_t n, int32_t* kind, int64_t* n_lattice, double* spacing, int64_t* index_out) {
+  if (n < 0 || (n > 0 && !ts)) return AGP_ERR_ARG;
+  try {
+    std::vector<int64_t> perm((size_t)n);
+    for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return ts[a] < ts[b]; });
+    std::vector<double> tss((size_t)n);
+    for (int64_t i = 0; i < n; ++i) tss[(size_t)i] = ts[perm[(size_t)i]];
+    const LatticeFit lf = fit_lattice(tss, 1e-11, true);
+    if (kind) *kind = lf.kind;
+    if (n_lattice) *n_lattice = lf.kind ? lf.n_lat : 0;
+    if (spacing) *spacing = lf.kind ? lf.h : 0.0;
+    if (index_out) for (int64_t i = 0; i < n; ++i) index_out[perm[(size_t)i]] = lf.kind ? lf.index[(size_t)i] : -1;
+  } catch (...) { return AGP_ERR_HOST; }
+  return AGP_OK;
+}
+
 static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t n_max);
 int agp_set_data(agp_ctx* c, const double* ts, const double* xs, int64_t n_max) {
   return abi_guard(c, [&] { return set_data_body(c, ts, xs, n_max); });
@@ -1630,8 +1737,9 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
                         std::memcmp(xs, c->h_xs.data(), sizeof(double) * (size_t)c->n_max) == 0;
     if (!prefix) c->store.forget();
   }
-  const bool lag_was = c->lag_ok;
-  const std::vector<double> tss_was = c->h_ts_sorted;
+  const bool lag_was = c->lag_ok, contig_was = c->lag_contig;
+  const std::vector<double> tlat_was = c->h_ts_lat;
+  const double grid_h_was = c->grid_h;
   if (c->d_ts) { HIPCHK(c, hipFree(c->d_ts)); c->d_ts = nullptr; }
   if (c->d_xs) { HIPCHK(c, hipFree(c->d_xs)); c->d_xs = nullptr; }
   // padded to a whole tile so kernels may read (and ignore) the tail
@@ -1651,6 +1759,7 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
   // within 1e-11 spacings of its grid position (np.linspace / a min-max rescaled integer grid on [0, 1]: < 1e-12), so that the lag
   // tables' representative differences equal every element's own t_i - t_j to rounding.
   c->lag_ok = false;
+  if (c->d_ts_lat) { HIPCHK(c, hipFree(c->d_ts_lat)); c->d_ts_lat = nullptr; }
   if (c->d_ts_s) { HIPCHK(c, hipFree(c->d_ts_s)); c->d_ts_s = nullptr; }
   if (c->d_xs_s) { HIPCHK(c, hipFree(c->d_xs_s)); c->d_xs_s = nullptr; }
   if (c->d_rank) { HIPCHK(c, hipFree(c->d_rank)); c->d_rank = nullptr; }
@@ -1661,33 +1770,35 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
     std::vector<double> tss((size_t)n_max), xss((size_t)n_max);
     for (int64_t i = 0; i < n_max; ++i) { tss[(size_t)i] = ts[perm[(size_t)i]]; xss[(size_t)i] = xs[perm[(size_t)i]]; }
     const double t0 = tss.front(), t1 = tss.back();
+    LatticeFit lf = fit_lattice(tss, c->lag_tol_h, c->lattice_enable != 0,
+                                (lag_was && !contig_was && !tlat_was.empty() && tlat_was.front() == t0) ? grid_h_was : 0.0);
+    const bool regular = lf.kind == 1, lattice = lf.kind == 2;
     const double h = (t1 - t0) / (double)(n_max - 1);
-    // The tolerance is a fraction of the SPACING, not of |t|: on the lag path every t_i - t_j is replaced by the table's
-    // t_sorted[g] - t_sorted[0], which differs from the element's own difference by up to ~4 position errors, i.e. by a relative
-    // 4 err / (g h) of the lag.  A point's position error is its measured deviation from t_0 + g h PLUS the quantisation of the
-    // time axis itself, one ulp of |t|max (t_0 + g h is evaluated in the same arithmetic as np.linspace / range, so for
-    // linspace(1000, 1001, n) the measured deviation is exactly 0 while the differences are only good to 1e-13 / h).
-    // linspace(0, 1, n): err / h = 7e-13 at n = 2048 (5e-12 at n = 16384), agreement with the general path 4e-13 of the log-pdf
-    // on short-lengthscale populations; the bound admits 1e-11, which keeps that agreement below 1e-11 — three digits under the
-    // 1e-8 contract.  A series with a large offset (linspace(1000, 1001, 2048): 4.6e-10) or a jitter below the former
-    // 16-ulp-of-|t| bound takes the general path.
-    const double quant = 2.220446049250313e-16 * std::max(std::fabs(t0), std::fabs(t1));
-    const double tol = c->lag_tol_h * h - quant;
-    bool regular = std::isfinite(h) && h > 0.0 && tol > 0.0;
-    for (int64_t i = 0; regular && i < n_max; ++i) regular = std::fabs(tss[(size_t)i] - (t0 + (double)i * h)) <= tol;
-    if (regular) {
+    const double hl = lf.h, dmin_lat = lf.dmin;
+    const int64_t n_lat = lf.n_lat;
+    std::vector<int64_t>& lat = lf.index;
+    if (regular || lattice) {
       HIPCHK(c, hipMalloc((void**)&c->d_ts_s, sizeof(double) * npad));
       HIPCHK(c, hipMalloc((void**)&c->d_xs_s, sizeof(double) * npad));
       HIPCHK(c, hipMemset(c->d_ts_s, 0, sizeof(double) * npad));
       HIPCHK(c, hipMemset(c->d_xs_s, 0, sizeof(double) * npad));
       HIPCHK(c, hipMemcpy(c->d_ts_s, tss.data(), sizeof(double) * n_max, hipMemcpyHostToDevice));
       HIPCHK(c, hipMemcpy(c->d_xs_s, xss.data(), sizeof(double) * n_max, hipMemcpyHostToDevice));
+      // "rank" of a resident point = its lattice index (its position in the sorted series on a regular grid)
       std::vector<int32_t> rank((size_t)npad, 0);
-      for (int64_t i = 0; i < n_max; ++i) rank[(size_t)perm[(size_t)i]] = (int32_t)i;
+      for (int64_t i = 0; i < n_max; ++i) rank[(size_t)perm[(size_t)i]] = (int32_t)lat[(size_t)i];
       HIPCHK(c, hipMalloc((void**)&c->d_rank, sizeof(int32_t) * npad));
       HIPCHK(c, hipMemcpy(c->d_rank, rank.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice));
-      c->t_ref = 0.5 * (t0 + t1); c->grid_h = h; c->grid_mid = 0.5 * (double)(n_max - 1);
-      c->poly_mmax = std::max(0.5 * (t1 - t0) * (1.0 + 1e-9), h);
+      // times of the lattice points: the data's own values where occupied (so that a table entry's t_g - t_0 is the difference of
+      // two stored points wherever both exist, as on the regular grid), t_0 + g h elsewhere
+      const int64_t nlpad = ((n_lat + 255) / 256) * 256 + 256;
+      std::vector<double> tl((size_t)nlpad);
+      for (int64_t g = 0; g < nlpad; ++g) tl[(size_t)g] = t0 + (double)g * hl;
+      for (int64_t i = 0; i < n_max; ++i) tl[(size_t)lat[(size_t)i]] = tss[(size_t)i];
+      HIPCHK(c, hipMalloc((void**)&c->d_ts_lat, sizeof(double) * nlpad));
+      HIPCHK(c, hipMemcpy(c->d_ts_lat, tl.data(), sizeof(double) * nlpad, hipMemcpyHostToDevice));
+      c->t_ref = 0.5 * (t0 + t1); c->grid_h = hl; c->grid_mid = 0.5 * (double)(n_lat - 1);
+      c->poly_mmax = std::max(0.5 * (t1 - t0) * (1.0 + 1e-9), hl);
       if (!c->d_fft_tw) {
         // twiddle factors of the gradient sweeps' spectral lag sums (k_zspec): here, where one thread runs by contract — the sweeps
         // that read them may come from many
@@ -1702,21 +1813,27 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
         c->d_fft_tw = d_tw;
       }
       c->lag_ok = true;
+      c->lag_contig = regular;
+      c->n_lat = n_lat;
+      c->lat_tol_abs = regular ? c->lag_tol_h * h : c->lag_tol_h * dmin_lat;
       c->h_ts_sorted = tss;
       c->h_rank.assign(rank.begin(), rank.begin() + n_max);
+      c->h_ts_lat.assign(tl.begin(), tl.begin() + n_lat);
     }
   }
-  if (!c->lag_ok) { c->h_ts_sorted.clear(); c->h_rank.clear(); }
+  if (!c->lag_ok) { c->h_ts_sorted.clear(); c->h_rank.clear(); c->h_ts_lat.clear(); c->lag_contig = false; c->n_lat = 0; }
   {
     // The store's sweeps read rank tables on a regular grid and the general evaluator otherwise; an extension agrees bit for bit
     // with a from-scratch sweep of the same entry only while resident rows and new rows are evaluated the same way.  After an
     // append that holds when the mode is unchanged and, on a grid, the old sorted series is a prefix of the new one (same ranks,
     // same table entries t_sorted[g] - t_sorted[0] for the old lags); anything else drops the resident factors.
     std::lock_guard<std::mutex> g(c->store.mu);
-    bool same = lag_was == c->lag_ok;
+    // (lattice times: on a regular grid the sorted series itself; with gaps also the computed times of the unoccupied points,
+    // which move by an ulp when an append changes the refined spacing)
+    bool same = lag_was == c->lag_ok && contig_was == c->lag_contig;
     if (same && c->lag_ok)
-      same = tss_was.size() <= c->h_ts_sorted.size() &&
-             std::memcmp(tss_was.data(), c->h_ts_sorted.data(), sizeof(double) * tss_was.size()) == 0;
+      same = tlat_was.size() <= c->h_ts_lat.size() &&
+             std::memcmp(tlat_was.data(), c->h_ts_lat.data(), sizeof(double) * tlat_was.size()) == 0;
     if (!same) c->store.forget();
   }
   // log|t_i - t_j| over the resident points, shared by the GammaExp leaves of every particle (OP_GE_TAB)

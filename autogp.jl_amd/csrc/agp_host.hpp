@@ -188,7 +188,14 @@ struct agp_ctx {
   int grad_struct = 1;              // structured gradient sweeps for the Toeplitz class when no factor is resident and it pays; env AGP_GRAD_FFT=3
                                     // (2: always with a dense factor; 4: whenever the class is not empty)
   int64_t n_toep_particles = 0;      // ... of which: lag sums from the Toeplitz solves (k_toep_solve)
-  bool lag_ok = false;
+  bool lag_ok = false;            // the resident time points sit on a lattice t_0 + g h, g integer (agp_set_data): table-driven sweeps
+  bool lag_contig = false;        // ... and occupy CONSECUTIVE lattice points (a regular grid): sorted sweeps with per-tile tables, Toeplitz paths
+  double lat_tol_abs = 0.0;       // admitted deviation of a point from its lattice position (lag_tol_h x the spacing; with gaps: x the smallest gap)
+  int64_t n_lat = 0;              // lattice points the series spans: largest index + 1 (== n_max on a regular grid)
+  int lattice_enable = 1;         // admit lattices with gaps (calendar-indexed series: monthly / quarterly / yearly / business-day dates are
+                                  // integer multiples of a day after datetime2unix, src/api.jl:49-51,98-101); env AGP_LATTICE=0: regular grids only
+  std::vector<double> h_ts_lat;   // time of lattice point g: the data's own value where a point sits there, t_0 + g h elsewhere (length n_lat)
+  double* d_ts_lat = nullptr;     // ... on the device, padded to a whole 256-lag unit + one (k_lag_tables, rank tables)
   int toeplitz = 0;              // structured value sweeps (Schur algorithm) for the Toeplitz + rank-2 class; env AGP_LAG=2 / agp_set_lag_tables(ctx, 2)
                                  // (2 = whatever the class's size: AGP_LAG=3, tests)
   int64_t n_toeplitz_value = 0;  // particles scored that way so far
@@ -326,6 +333,8 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
 // 0.91 ms; lag-table sweeps price programs at ~2 us per node: dataflow 2.5 / 5 / 9 / 16 / 70 us: 3.87 / 3.83 / 3.83 / 3.86 / 4.01 ms at
 // n=2048 x 64, per-column launches 2.5 / 5 / 8 / 12 / 20 us: 25.33 / 25.40 / 25.57 / 25.58 / 25.94 ms (one-node programs only).
 constexpr double FUSE_MAX_US = 25.0, FLOW_FUSE_MAX_US = 70.0, FLOW_LAG_FUSE_MAX_US = 10.0, LAG_FUSE_MAX_US = 3.0;
+constexpr int64_t LATTICE_MAX = 131072;   // longest lattice admitted (rank tables of that many lags per stationary subtree: 1 MiB each, read from L2)
+constexpr int LATTICE_MAX_DIV = 400;      // the lattice spacing is sought as (smallest gap) / k, k <= this (a yearly index: 365 / 366 days)
 constexpr int HYBRID_BLOCKS = 512;        // medium populations: right-looking once a block column offers fewer workgroups (run_factor)
 constexpr double GRAD_TOEP_MAX_AMP = 1e4;  // ... and the largest entry of U' T^-1 U C it accepts (the downdate loses that factor times ~100 eps)
 constexpr int GRAD_TOEP_MIN_N = 256;      // Toeplitz variant of the lag sums: four solves + seven transforms per particle, whatever n

@@ -31,7 +31,7 @@ struct PredLattice {
   std::vector<int32_t> rank;      // joint padded layout [ts(1:n), pad, ts_pred, pad], shifted so that the smallest rank is 0
   std::vector<double> tl;         // time of lag g: t_sorted[g] inside the data (the store's tables), t_0 + g h beyond
 };
-constexpr int PRED_MAX_LAGS = 4096;     // (LDS capacity of the fused evaluators, as for the resident series: n_max <= 4096)
+constexpr int64_t PRED_MAX_LAGS = LATTICE_MAX;     // (tables too long for the fused evaluators' LDS are read in place by k_cov_tiles: compile_batch)
 
 void predict_lattice(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, PredLattice& pl) {
   pl.on = false;
@@ -39,12 +39,12 @@ void predict_lattice(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, Pr
   const double t0 = c->h_ts_sorted.front(), h = c->grid_h;
   const int n1_pad = round_up(n, NB), m_pad = round_up(m, NB);
   std::vector<long long> gq((size_t)m);
-  long long gmin = 0, gmax = (long long)c->n_max - 1;
+  long long gmin = 0, gmax = (long long)c->n_lat - 1;
   for (int64_t j = 0; j < m; ++j) {
     const double t = ts_pred[j];
     const double gf = std::nearbyint((t - t0) / h);
     if (!std::isfinite(gf) || std::fabs(gf) > 1e6) return;
-    const double tol = c->lag_tol_h * h - 2.220446049250313e-16 * std::max(std::fabs(t), std::max(std::fabs(t0), std::fabs(c->h_ts_sorted.back())));
+    const double tol = c->lat_tol_abs - 2.220446049250313e-16 * std::max(std::fabs(t), std::max(std::fabs(t0), std::fabs(c->h_ts_sorted.back())));
     if (!(tol > 0.0) || std::fabs(t - (t0 + gf * h)) > tol) return;
     gq[(size_t)j] = (long long)gf;
     gmin = std::min(gmin, gq[(size_t)j]); gmax = std::max(gmax, gq[(size_t)j]);
@@ -57,7 +57,7 @@ void predict_lattice(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, Pr
   for (int64_t j = 0; j < m; ++j) pl.rank[(size_t)n1_pad + j] = (int32_t)(gq[(size_t)j] - gmin);
   pl.tl.assign((size_t)pl.rank_units * 256, 0.0);
   for (long long g = 0; g < (long long)pl.tl.size(); ++g)
-    pl.tl[(size_t)g] = g < c->n_max ? c->h_ts_sorted[(size_t)g] : t0 + (double)g * h;
+    pl.tl[(size_t)g] = g < c->n_lat ? c->h_ts_lat[(size_t)g] : t0 + (double)g * h;
   pl.on = true;
 }
 
@@ -641,7 +641,7 @@ static int predict_batch_body(agp_ctx* c, int64_t n, const double* ts_pred, int6
   // Structured pass (no dense factor; toeplitz_predict_sweep): marginal predictions, the n training points
   // consecutive grid points, every query one of them or a grid point after them, nothing resident to start from — the Toeplitz +
   // rank-2 particles of the call go there, the others (and any particle the recursion refuses) through the dense path below.
-  if (!out_cov && !tl_in_tpredict && c->grad_struct && n >= 256 && n <= 2048 &&
+  if (!out_cov && !tl_in_tpredict && c->grad_struct && c->lag_contig && n >= 256 && n <= 2048 &&
       // (with factors resident, starting from them costs (n / 2048)^3 x ~14 ms of L^-T per 256 particles: the two sequential passes of
       // the structured sweep, ~3.8 us per point, are cheaper from n ~ 768 on)
       (!(c->predict_reuse && c->store.n_slots > 0) || n >= 768) && (int64_t)c->h_rank.size() >= n) {

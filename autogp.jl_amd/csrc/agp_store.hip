@@ -215,8 +215,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   Batch bt;
   // regular grid: stationary subtrees from rank lag tables, as in the caller-order sweeps of logpdf_batch_impl (the mode depends
   // on the resident series alone, so an extension and a from-scratch sweep of the same entry evaluate every tile the same way)
-  const bool lagr = c->lag_rank_enable && c->lag_enable && c->lag_ok && c->n_max <= 4096;
-  const int rank_units = (int)((c->n_max + 255) / 256);
+  const bool lagr = c->lag_rank_enable && c->lag_enable && c->lag_ok && c->n_lat <= LATTICE_MAX;
+  const int rank_units = (int)((c->n_lat + 255) / 256);
   const bool ge_tab = c->logdt_ok && !lagr;
   // (tiles are evaluated inside the factorisation kernels whatever the population size: the prebuilt-tile variants of
   // the split launches carry the most register spills, and the store never needs K itself)
@@ -283,9 +283,9 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     if (lagr && bt.n_lag_tables > 0) {
       EXTCHK(s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * rank_units * 256));
       LagArgs la = {};
-      la.tt = c->d_ts_s; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
+      la.tt = c->d_ts_lat; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
       la.tops = reinterpret_cast<const uint8_t*>(dstage + o_tops); la.tprm = reinterpret_cast<const double*>(dstage + o_tprm);
-      la.n_tables = bt.n_lag_tables; la.tab = s->lagtab.as<double>(); la.nt = (int)((c->n_max + NB - 1) / NB);
+      la.n_tables = bt.n_lag_tables; la.tab = s->lagtab.as<double>(); la.nt = (int)((c->n_lat + NB - 1) / NB);
       la.full = 1; la.stride = rank_units * 256;
       launch_lag_tables(st, la, rank_units, bt.n_lag_tables);
       EXTCHK(hipGetLastError());
@@ -383,8 +383,24 @@ int agp_grad_reuse_stats(agp_ctx* c, int64_t* out2) {
 int agp_get_lag_stats(agp_ctx* c, int32_t* regular_grid, int64_t* n_lag_sweeps) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   std::lock_guard<std::mutex> g(c->mu);
-  if (regular_grid) *regular_grid = (c->lag_enable && c->lag_ok) ? 1 : 0;
+  if (regular_grid) *regular_grid = (c->lag_enable && c->lag_ok && c->lag_contig) ? 1 : 0;
   if (n_lag_sweeps) *n_lag_sweeps = c->n_lag_sweeps;
+  return AGP_OK;
+}
+
+int agp_get_lattice_stats(agp_ctx* c, int32_t* kind, int64_t* n_lattice, double* spacing) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  std::lock_guard<std::mutex> g(c->mu);
+  const bool on = c->lag_enable && c->lag_ok;
+  if (kind) *kind = !on ? 0 : c->lag_contig ? 1 : 2;
+  if (n_lattice) *n_lattice = on ? c->n_lat : 0;
+  if (spacing) *spacing = on ? c->grid_h : 0.0;
+  return AGP_OK;
+}
+
+int agp_set_lattice(agp_ctx* c, int32_t on) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  c->lattice_enable = on != 0;
   return AGP_OK;
 }
 

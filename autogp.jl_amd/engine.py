@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi", "agp_logpdf_batch_extend_multi",
     "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
-    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_predict_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
+    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_get_lattice_stats", "agp_set_lattice", "agp_probe_lattice", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_predict_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
 ]
 COMM_ID_BYTES = 128
 
@@ -141,6 +141,9 @@ def load_library(path=None):
     lib.agp_wait.argtypes = [vp]; lib.agp_wait.restype = C.c_int
     lib.agp_get_lag_stats.argtypes = [vp, i32p, C.POINTER(C.c_int64)]; lib.agp_get_lag_stats.restype = C.c_int
     lib.agp_set_lag_tables.argtypes = [vp, C.c_int32]; lib.agp_set_lag_tables.restype = C.c_int
+    lib.agp_get_lattice_stats.argtypes = [vp, i32p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]; lib.agp_get_lattice_stats.restype = C.c_int
+    lib.agp_set_lattice.argtypes = [vp, C.c_int32]; lib.agp_set_lattice.restype = C.c_int
+    lib.agp_probe_lattice.argtypes = [dp, C.c_int64, i32p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]; lib.agp_probe_lattice.restype = C.c_int
     lib.agp_set_grad_lag_domain.argtypes = [vp, C.c_int32]; lib.agp_set_grad_lag_domain.restype = C.c_int
     lib.agp_set_lag_rank_tables.argtypes = [vp, C.c_int32]; lib.agp_set_lag_rank_tables.restype = C.c_int
     lib.agp_get_lag_rank_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_get_lag_rank_stats.restype = C.c_int
@@ -349,6 +352,17 @@ class GPEngine:
         r = C.c_int32(); k = C.c_int64()
         self._check(self._lib.agp_get_lag_stats(self._ctx, C.byref(r), C.byref(k)))
         return bool(r.value), int(k.value)
+
+    def lattice_stats(self):
+        """dict(kind, n_lattice, spacing) of the resident series: kind 0 irregular (general path), 1 regular grid, 2 lattice with
+        gaps (calendar-indexed series: table-driven sweeps over n_lattice lags)."""
+        k = C.c_int32(); g = C.c_int64(); h = C.c_double()
+        self._check(self._lib.agp_get_lattice_stats(self._ctx, C.byref(k), C.byref(g), C.byref(h)))
+        return {"kind": int(k.value), "n_lattice": int(g.value), "spacing": float(h.value)}
+
+    def set_lattice(self, on):
+        """Admit lattices with gaps at the next set_data (off: regular grids only)."""
+        self._check(self._lib.agp_set_lattice(self._ctx, 1 if on else 0))
 
     def set_lag_tables(self, on):
         """Switch the regular-grid lag-table path (takes effect at the next set_data)."""
@@ -572,6 +586,18 @@ def shard_range(P: int, rank: int, n_ranks: int):
     lo = C.c_int32(); hi = C.c_int32()
     load_library().agp_shard_range(int(P), int(rank), int(n_ranks), C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+def probe_lattice(ts):
+    """agp_probe_lattice: the admission test of agp_set_data on its own (host code, no device).  Returns
+    dict(kind, n_lattice, spacing, index): kind 0 irregular, 1 regular grid, 2 lattice with gaps; index = per-point lattice index."""
+    ts = np.ascontiguousarray(ts, dtype=np.float64)
+    k = C.c_int32(); g = C.c_int64(); h = C.c_double()
+    idx = np.empty(len(ts), dtype=np.int64)
+    rc = load_library().agp_probe_lattice(_dp(ts), len(ts), C.byref(k), C.byref(g), C.byref(h), idx.ctypes.data_as(C.POINTER(C.c_int64)))
+    if rc != 0:
+        raise AGPError(f"agp_probe_lattice failed ({rc})")
+    return {"kind": int(k.value), "n_lattice": int(g.value), "spacing": float(h.value), "index": idx}
 
 
 class GPEngineMulti:

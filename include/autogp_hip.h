@@ -158,6 +158,23 @@ int agp_set_factor_cache(agp_ctx* ctx, int32_t on);
 int agp_get_lag_stats(agp_ctx* ctx, int32_t* regular_grid, int64_t* n_lag_sweeps);
 int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
 
+/* Lattices with gaps: calendar-indexed series.  The reference turns dates into seconds (datetime2unix, src/api.jl:49-51) and
+ * min-max rescales them (src/api.jl:98-101), so monthly (28..31 days), quarterly, yearly (365 / 366) and business-day indices are
+ * never regular grids — but every such time point is t_0 + g h with an INTEGER g (h = one day after rescaling), i.e.
+ * |t_a - t_b| = |g_a - g_b| h for every pair, which is all the rank tables below need.  When the regular-grid test fails,
+ * agp_set_data looks for the largest h = (smallest gap) / k, k <= 400, that puts every sorted point within 1e-11 SMALLEST GAPS of
+ * t_0 + g h (spans of up to 131072 lattice points); the series' "ranks" are then the lattice indices g_i, a stationary subtree's
+ * table holds n_lattice lags and is read in place (L2) by the tile builder, and every value / prefix / factor-store / predictive
+ * sweep (query points on the lattice: the next month starts) takes the table-driven evaluator.  The sorted sweeps with per-tile
+ * tables, the Toeplitz paths and the lag-domain gradient need consecutive lattice points and stay with regular grids.
+ * agp_get_lattice_stats: kind = 0 (irregular: general path), 1 (regular grid), 2 (lattice with gaps); AGP_LATTICE=0 /
+ * agp_set_lattice(ctx, 0) admit regular grids only (read at the next agp_set_data). */
+int agp_get_lattice_stats(agp_ctx* ctx, int32_t* kind, int64_t* n_lattice, double* spacing);
+int agp_set_lattice(agp_ctx* ctx, int32_t on);
+/* The admission test alone, on n time points in any order (host code only: no context, no device): kind as above, the lattice's
+ * length and spacing, and per point its lattice index (index_out, nullable; -1 when kind = 0). */
+int agp_probe_lattice(const double* ts, int64_t n, int32_t* kind, int64_t* n_lattice, double* spacing, int64_t* index_out);
+
 /* OPT-IN structured value sweep (AGP_LAG=2 / agp_set_lag_tables(ctx, 2); off by default: the default path mirrors the reference's
  * dense Cholesky, src/Model.jl:134-136).  On the sorted copy of a regular grid a kernel that is a sum of stationary subtrees and
  * Linear leaves gives K = T + U C U' — T symmetric Toeplitz, U = [1, t], C 2x2 — and log N(x; 0, K) follows from log|T| and

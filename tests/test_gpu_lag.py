@@ -115,7 +115,8 @@ def test_what_must_not_take_the_lag_path(pkg):
             ref, rinfo = F.gp_logpdf_many(pkg.encode_batch(nodes[:4]), noises[:4], bad, np.cos(3 * bad))
             ok = (info == 0) & (rinfo == 0)
             assert lp_err(lp[ok], ref[ok]).max() <= LP_TOL
-        assert eng.lag_stats()[1] == 1 and eng.lag_rank_sweeps() == 2
+        # (the grid with one point missing is a lattice with a gap: not a regular grid, but its sweep reads rank tables — tests/test_gpu_calendar.py)
+        assert eng.lag_stats()[1] == 1 and eng.lag_rank_sweeps() == 3
     finally:
         eng.close()
 
@@ -218,11 +219,11 @@ def test_rank_lag_tables_prefix_sweeps(pkg, monkeypatch, n_max, n, P, depth):
         a.close(); b.close()
 
 
-@pytest.mark.parametrize("case", ["duplicates", "future", "interleaved", "backcast", "prefix", "off_grid", "too_long", "many"])
+@pytest.mark.parametrize("case", ["duplicates", "future", "interleaved", "backcast", "prefix", "off_grid", "long", "too_long", "many"])
 def test_predictive_pass_on_lattice_query_points(pkg, case):
     """agp_predict_batch with query points on the series' own lattice (scripts/online.jl:41-43: ds_query = vcat(model.ds, ds_next,
     ds_test); src/GP.jl:743) reads the stationary subtrees from rank tables: duplicates of training times, future-only points,
-    both interleaved, points before the series, a prefix n < n_max; one off-lattice point or more than 4096 lags -> general path.
+    both interleaved, points before the series, a prefix n < n_max; one off-lattice point or more than 131 072 lags -> general path.
     Mean, variance and covariance against the oracle (1e-8) and against a context without lag tables (1e-10 of the scale)."""
     from oracle import oracle as O
     G = pkg
@@ -239,7 +240,8 @@ def test_predictive_pass_on_lattice_query_points(pkg, case):
     elif case == "backcast":    tq, on = np.concatenate([grid[0] - h * np.arange(1, 30), ts[:20], fut[:5]]), True
     elif case == "prefix":      tq, on, n = np.concatenate([ts, fut]), True, 170          # (the rest of the series is "ds_next")
     elif case == "off_grid":    tq, on = np.concatenate([ts[:50], [grid[10] + 0.3 * h], fut[:5]]), False
-    elif case == "too_long":    tq, on = grid[0] + h * np.arange(0, 5000, 100), False      # ranks up to 4900 > 4096 lags
+    elif case == "long":        tq, on = grid[0] + h * np.arange(0, 5000, 100), True       # ranks up to 4900: tables too long for LDS, read in place
+    elif case == "too_long":    tq, on = grid[0] + h * np.arange(0, 200000, 4000), False   # ranks up to 196 000 > 131 072 lags
     else:                       tq, on = np.concatenate([ts, fut]), True
     ks = [G.SquaredExponential(0.1, 0.8), G.Periodic(0.7, 0.21, 1.1) * G.SquaredExponential(0.5, 0.9) + G.Linear(0.3, 0.2, 0.5),
           G.GammaExponential(0.3, 1.2, 0.7) + G.WhiteNoise(0.05), G.ChangePoint(G.Periodic(0.5, 0.1, 1.0), G.SquaredExponential(0.2, 0.6), 0.45, 0.01),

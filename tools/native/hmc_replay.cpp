@@ -13,7 +13,7 @@
 // in Julia): this is a replay of the call pattern, not a sampler.
 //
 //   build: g++ -O2 -std=c++17 -pthread -I include tools/native/hmc_replay.cpp -L autogp.jl_amd/lib -lautogp_hip
-//   run:   hmc_replay <n> <threads> <hmc_iterations> [L=10] [eps=0.02]
+//   run:   hmc_replay <n> <threads> <hmc_iterations> [L=10] [eps=0.02] [grid|monthly]
 #include "autogp_hip.h"
 
 #include <algorithm>
@@ -117,7 +117,10 @@ int main(int argc, char** argv) {
   const double eps = argc > 5 ? atof(argv[5]) : 0.02;
   // argv[6] = "grid": time points = a regular grid in shuffled order — what AutoGP hands over for a regularly sampled series
   // (min-max rescaled index, shuffle = true: src/api.jl:98-102,232); default: irregular times
+  // "monthly": n month starts from 1949-01-01 through datetime2unix and the min-max transform (src/api.jl:49-51,98-101), shuffled: a
+  // calendar-indexed series — a lattice with gaps (28..31 days), never a regular grid
   const bool grid = argc > 6 && std::string(argv[6]) == "grid";
+  const bool monthly = argc > 6 && std::string(argv[6]) == "monthly";
   agp_ctx* ctx = nullptr;
   if (agp_init(&ctx, 0) != 0) { fprintf(stderr, "agp_init: %s\n", agp_last_error(nullptr)); return 1; }
   std::mt19937_64 g(11);
@@ -129,6 +132,21 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n; ++i) perm[i] = i;
     std::shuffle(perm.begin(), perm.end(), g);
     for (int i = 0; i < n; ++i) { ts[i] = (double)perm[i] / (double)(n - 1); xs[i] = 0.5 * std::sin(12.0 * ts[i]) + 0.3 * nrm(g); }
+  }
+  if (monthly) {
+    auto days_from_civil = [](long long y, unsigned m, unsigned d) {       // days since 1970-01-01 (proleptic Gregorian)
+      y -= m <= 2;
+      const long long era = (y >= 0 ? y : y - 399) / 400;
+      const unsigned yoe = (unsigned)(y - era * 400), doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1, doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+      return era * 146097 + (long long)doe - 719468;
+    };
+    std::vector<double> ux(n);
+    for (int i = 0; i < n; ++i) ux[i] = 86400.0 * (double)days_from_civil(1949 + i / 12, 1 + i % 12, 1);
+    const double slope = 1.0 / (ux[n - 1] - ux[0]), icpt = -slope * ux[0];
+    std::vector<int> perm(n);
+    for (int i = 0; i < n; ++i) perm[i] = i;
+    std::shuffle(perm.begin(), perm.end(), g);
+    for (int i = 0; i < n; ++i) { ts[i] = slope * ux[perm[i]] + icpt; xs[i] = 0.5 * std::sin(12.0 * ts[i]) + 0.3 * nrm(g); }
   }
   if (agp_set_data(ctx, ts.data(), xs.data(), n) != 0) { fprintf(stderr, "set_data: %s\n", agp_last_error(ctx)); return 1; }
   std::vector<Particle> ps(T);
@@ -170,7 +188,7 @@ int main(int argc, char** argv) {
          "\"seconds\": %.4f, \"hmc_iterations_per_s\": %.2f, \"seconds_per_iteration_of_the_population\": %.4f, "
          "\"gradient_calls\": %lld, \"value_calls\": %lld, \"calls_per_s\": %.1f, \"coalesced_batches\": %lld, \"mean_batch\": %.1f, "
          "\"accepted_param_moves\": %lld, \"api_errors\": %lld, \"not_positive_definite\": %lld, \"non_finite\": %lld}\n",
-         grid ? "regular grid, shuffled" : "irregular", (long long)n_lagdom, (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
+         grid ? "regular grid, shuffled" : monthly ? "month starts (lattice with gaps), shuffled" : "irregular", (long long)n_lagdom, (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
          n, T, iters, L, eps, dt, it_total / dt, dt / iters, cnt.grad.load(), cnt.value.load(),
          (double)(cnt.grad.load() + cnt.value.load()) / dt, (long long)(b1 - b0),
          (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), cnt.accepted.load(), cnt.api_errors.load(), cnt.not_pd.load(), cnt.non_finite.load());
