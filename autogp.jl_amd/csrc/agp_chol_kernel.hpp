@@ -397,7 +397,7 @@ __device__ __forceinline__ bool flow_wait(const int* flag) {
 // panel solve waits for the flag of tile (tk,tk), and the finished tile raises its own flag (a.tflag, one int per
 // tile and storage index, zeroed per sweep).
 // GM: how the fused programs' stationary leaves are evaluated — 0 directly, 1 GammaExp from the data set's log|dt| table,
-// 2 every stationary leaf from the tile's lag tables (sorted regular grid; see cov_prologue)
+// 2 every stationary leaf from the tile's lag tables (sorted regular grid; see cov_prologue) or from rank tables copied to LDS
 template <bool FACTOR, int DCOV, bool INTRSM, int DM, int GM, bool FLOW>
 __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const int ps_, const int ti_, const int tk_,
                                           const int jmax_, const bool is_diag, double* sm, const int tid,

@@ -858,28 +858,37 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   const bool lag = allow_lag && c->lag_enable && c->lag_ok && c->lag_contig && !go && n > 0 && n == c->n_max;
   // ... every other sweep over (a prefix of) a regular grid — annealing prefixes, gradient sweeps — keeps the caller's order and
   // reads the same leaves from RANK tables: |t_a - t_b| = |rank_a - rank_b| h in any order (cov_prologue)
-  // (a lattice with gaps — calendar-indexed series — has n_lat > n_max lags; tables of more than U_MAX_CP units never fit the fused
-  // evaluators' LDS, so those programs get their tiles from k_cov_tiles, which reads the tables in place: compile_batch)
+  // (a lattice with gaps — a business-day index, a regular series with missing observations — has n_lat > n_max lags)
   const int rank_units = (int)((c->n_lat + 255) / 256);
-  bool lagr = !lag && allow_lag && c->lag_rank_enable && c->lag_enable && c->lag_ok && n > 0 && c->n_lat <= LATTICE_MAX;
+  // Rank tables of up to LAG_LDS_MAX_UNITS x 256 lags are copied into the evaluators' LDS, and agp_set_data admits no longer
+  // lattice.  Longer tables (2048 month starts span 62 304 days) would have to be gathered from L2, and that is slower than
+  // evaluating the leaves — measured (round 5, before the admission bound) on
+  // 2048 month starts x 512 particles: tables read in place by k_cov_tiles 31.7 ms, gathered inside the factorisation kernels 30.9 ms,
+  // the same on the sorted copy (a tile then reads a window of ~7 800 entries) 27.9 ms, general evaluator 28.1 ms: a divergent 8-byte
+  // gather costs the texture path ~64 clocks per wave instruction whatever the locality (NOTES_dead_ends.md, round 5) — so such a
+  // series keeps the general evaluator.
+  bool lagr = !lag && allow_lag && c->lag_rank_enable && c->lag_enable && c->lag_ok && n > 0 && rank_units <= LAG_LDS_MAX_UNITS;
+  const bool sorted = lag;          // the sweep runs on the sorted copy of the series (d_ts_s / d_xs_s)
   int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint, lag || lagr, lagr ? rank_units : 1, lagr);
   if (rc) return rc;
   if (lagr) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_rank_sweeps; }
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
   if (go && n > 23040) return fail(c, AGP_ERR_ARG, "gradient sweeps address a particle's packed matrix with 32-bit byte offsets: n <= 23040");
-  if (lag) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_sweeps; }
+  if (sorted) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_sweeps; }
   // Gradient sweeps on a regular grid (any order of the points): particles whose kernel is a sum of stationary subtrees and
   // Linear leaves are contracted in the lag domain (k_kinv_tiles / k_lag_grad, agp_grad_kernel.hpp)
   int32_t toep_rank0 = 0;
   bool any_toep_sweep = false;                 // some particle of this sweep took the Toeplitz solves
   std::vector<int32_t> toep_retry;             // ... and (caller order) whether its downdate was rejected on the device
-  if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->lag_contig && c->n_max <= LAGDOM_MAX_BINS) {
+  // (a lattice with gaps: the lag histograms of k_kinv_tiles over its n_lat lags; the spectral and Toeplitz sources of the lag sums
+  // need consecutive lattice points)
+  if (go && n > 0 && c->grad_lagdom && c->lag_enable && c->lag_ok && c->n_lat <= LAGDOM_MAX_BINS) {
     int64_t n_cov = 0, n_sum = 0;          // lag-domain particles; of which sums of stationary subtrees and Linear leaves
     // (the transform has one length, 4096: below ~1000 points the K^-1 tiles are cheaper than n/2 transforms of that length)
-    const bool use_fft = c->grad_fft && c->d_fft_tw != nullptr && 2 * c->n_max <= FFT_N && n > GRAD_FFT_MIN_N;      // (n: this sweep's prefix — the number of transforms)
+    const bool use_fft = c->lag_contig && c->grad_fft && c->d_fft_tw != nullptr && 2 * c->n_max <= FFT_N && n > GRAD_FFT_MIN_N;      // (n: this sweep's prefix — the number of transforms)
     // the sweep's points are n consecutive grid points (the whole series; a prefix of a series in time order): K is Toeplitz
     // plus the Linear leaves' rank-2 term in sorted order — lag sums of K^-1 from four solves (k_toep_solve)
-    bool use_toep = !tl_no_toep && c->grad_fft >= 2 && c->d_fft_tw != nullptr && 2 * c->n_max <= FFT_N && n >= GRAD_TOEP_MIN_N && (int64_t)c->h_rank.size() >= n;
+    bool use_toep = c->lag_contig && !tl_no_toep && c->grad_fft >= 2 && c->d_fft_tw != nullptr && 2 * c->n_max <= FFT_N && n >= GRAD_TOEP_MIN_N && (int64_t)c->h_rank.size() >= n;
     if (use_toep) {
       int32_t lo = c->h_rank[0], hi = c->h_rank[0];
       for (int64_t i = 1; i < n; ++i) { lo = std::min(lo, c->h_rank[(size_t)i]); hi = std::max(hi, c->h_rank[(size_t)i]); }
@@ -904,7 +913,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       }
       if (g.n_ops > 0 && cov[g.n_ops - 1]) { g.flags |= GFLAG_LAGDOM | (use_toep ? GFLAG_LAGTOEP : use_fft ? GFLAG_LAGFFT : 0); ++n_cov; ++n_sum; }
       else if (g.n_ops > 0 && c->grad_lagdom >= 2 && deg[g.n_ops - 1] >= 1 && deg[g.n_ops - 1] <= 3 &&
-               (2 * deg[g.n_ops - 1] + 1) * c->n_max + 8 <= NB2) {
+               (2 * deg[g.n_ops - 1] + 1) * c->n_lat + 8 <= NB2) {
         // Linear leaves inside products: moment histograms of G over the lags (k_kinv_tiles), (2d+1) n virtual elements (k_lag_grad)
         g.flags |= GFLAG_LAGPOLY | ((int)deg[g.n_ops - 1] << GFLAG_POLY_DEG_SHIFT); ++n_cov;
       }
@@ -1143,9 +1152,9 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         // (one group per chunk; sub-batches on several streams were measured: no gain, removed)
         const int g0 = 0, Pg = Pc;
         hipStream_t q = st;
-        launch_init_vec(q, n_pad, Pg, s->vec.as<double>() + (size_t)g0 * n_pad, lag ? c->d_xs_s : c->d_xs, (const double*)nullptr, (int)n, s->info.as<int>() + g0, s->ready.as<int>() + g0);
+        launch_init_vec(q, n_pad, Pg, s->vec.as<double>() + (size_t)g0 * n_pad, sorted ? c->d_xs_s : c->d_xs, (const double*)nullptr, (int)n, s->info.as<int>() + g0, s->ready.as<int>() + g0);
         CovArgs cv = {};
-        cv.tt = lag ? c->d_ts_s : c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
+        cv.tt = sorted ? c->d_ts_s : c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
         cv.hdr = d_hdr + p0 + g0; cv.ops = d_ops; cv.prm = d_prm;
         cv.noise = d_noise + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
         cv.strideA = strideA; cv.P = Pg; cv.logdt = (ge_tab && !lag && !lagr) ? c->d_logdt : nullptr;
@@ -1231,7 +1240,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           ga.tt = c->d_ts; ga.logdt = c->logdt_ok ? c->d_logdt : nullptr; ga.gpart = s->gpart.as<double>() + (size_t)g0 * ntiles * gstride; ga.gstride = gstride;
           ga.gmap = s->gmap.as<int32_t>(); ga.out_off = s->goff.as<int32_t>() + p0 + g0;
           ga.pmap = d_map + p0 + g0; ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
-          ga.rank = c->d_rank; ga.tts = c->d_ts_s; ga.nbins = (int)c->n_max; ga.tref = c->t_ref; ga.tw = c->d_fft_tw; ga.grid_h = c->grid_h; ga.grid_mid = c->grid_mid;
+          // (lag histograms: one bin per lattice lag, lag g at time t_lat[g] - t_lat[0]; on a regular grid d_ts_lat holds the sorted series)
+          ga.rank = c->d_rank; ga.tts = c->d_ts_lat; ga.nbins = (int)c->n_lat; ga.tref = c->t_ref; ga.tw = c->d_fft_tw; ga.grid_h = c->grid_h; ga.grid_mid = c->grid_mid;
           if (n_hit > 0) {
             ga.lslot = d_src + p0 + g0; ga.Lsrc = c->store.A.as<double>(); ga.Lstride = c->store.strideA;
             ga.Wsrc = c->store.W.as<double>(); ga.Wnt = c->store.nt_cap;
@@ -1342,13 +1352,13 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
               // (2 d + 1 moment histograms of n_max lags for the class's largest degree d: admission keeps them within one tile of LDS)
               int dmax = 1;
               for (int r = Pe; r < Pn; ++r) dmax = std::max(dmax, (bt.ghdr[p0 + g0 + pl[r]].flags >> GFLAG_POLY_DEG_SHIFT) & 3);
-              const size_t ldsp = sizeof(double) * ((size_t)(2 * dmax + 1) * c->n_max + 40 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
+              const size_t ldsp = sizeof(double) * ((size_t)(2 * dmax + 1) * c->n_lat + 40 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
               launch_lag_grad(qs[3], Pn - Pe, ldsp, gp);
               HIPCHK(c, hipGetLastError());
             }
             if (Pn < Pg) {
               gs.plist = d_pl + Pn;
-              const size_t lds4 = sizeof(double) * (((any_fft || any_toep) ? 2 * (size_t)FFT_BUF : 0) + (size_t)c->n_max + 40 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
+              const size_t lds4 = sizeof(double) * (((any_fft || any_toep) ? 2 * (size_t)FFT_BUF : 0) + (size_t)c->n_lat + 40 + bt.g_max_prm + 3 + bt.g_max_nodes + 26 + bt.g_max_prm);
               launch_lag_grad(qs[3], Pg - Pn, lds4, gs);
               HIPCHK(c, hipGetLastError());
             }
@@ -1457,7 +1467,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       c->n_lagdom_particles -= B;          // (the nested sweep counted them again)
     }
   }
-  if (lag && h_out_info) {
+  if (sorted && h_out_info) {
     // LAPACK's info names the first non-positive leading minor IN THE CALLER'S ORDER of the observations
     // (LinearAlgebra.PosDefException(info) in the reference); the sorted sweep found the matrix not positive definite
     // at some minor of the sorted order.  The (rare) rejected particles are factored once more in the caller's order.
@@ -1650,7 +1660,8 @@ static LatticeFit fit_lattice(const std::vector<double>& tss, double lag_tol_h, 
     // datetime2unix and min-max rescales them (src/api.jl:49-51,98-101): months last 28..31 days, quarters 90..92, years 365 / 366,
     // business days skip weekends — but every such time IS an integer multiple of one day: t_i = t_0 + g_i h with integer
     // lattice indices g_i, and |t_a - t_b| = |g_a - g_b| h for every pair, which is all the rank tables need (cov_prologue; the
-    // table of a stationary subtree then holds n_lat = g_max + 1 lags and is read in place from L2 by k_cov_tiles).  The spacing
+    // table of a stationary subtree then holds n_lat = g_max + 1 <= 4096 lags, the LDS budget of the evaluators: business-day
+    // indices of up to ~2 900 points, month starts of up to 134, any regular series with missing observations).  The spacing
     // is sought as (smallest gap) / k, k = 1 .. LATTICE_MAX_DIV, refined to (t_last - t_0) / g_last; the position bound is the
     // regular grid's, taken relative to the SMALLEST GAP of the data (the shortest lag any table entry in use represents).
     std::vector<int64_t> lat;            // lattice index of sorted point i
@@ -1667,7 +1678,7 @@ static LatticeFit fit_lattice(const std::vector<double>& tss, double lag_tol_h, 
       const double tol_l = lag_tol_h * dmin - quant;
       if (distinct && tol_l > 0.0) {
         lat.resize((size_t)n_max);
-        if (hint_h > 0.0 && (t1 - t0) / hint_h <= (double)LATTICE_MAX && 8.0 * ((t1 - t0) / hint_h) <= (double)n_max * (double)n_max) {
+        if (hint_h > 0.0 && (t1 - t0) / hint_h <= (double)(LATTICE_MAX - 1) && 2.0 * ((t1 - t0) / hint_h) <= (double)n_max * (double)n_max) {
           bool ok = true;
           for (int64_t i = 0; ok && i < n_max; ++i) {
             const double g = std::nearbyint((tss[(size_t)i] - t0) / hint_h);
@@ -1678,9 +1689,8 @@ static LatticeFit fit_lattice(const std::vector<double>& tss, double lag_tol_h, 
         }
         for (int k = 1; k <= LATTICE_MAX_DIV && !lattice; ++k) {
           const double h0 = dmin / (double)k;
-          // (tables of n_lat lags must stay well below the n (n + 1) / 2 elements they stand for: a yearly index of 300 points spans
-          // 109 208 days — not worth a table; such series are short and take the general path)
-          if ((t1 - t0) / h0 > (double)LATTICE_MAX || 8.0 * ((t1 - t0) / h0) > (double)n_max * (double)n_max) break;
+          // (a table of n_lat lags must stay below the n (n + 1) / 2 elements it stands for)
+          if ((t1 - t0) / h0 > (double)(LATTICE_MAX - 1) || 2.0 * ((t1 - t0) / h0) > (double)n_max * (double)n_max) break;
           bool ok = true;
           for (int64_t i = 0; ok && i < n_max; ++i) {
             const double q = (tss[(size_t)i] - t0) / h0, g = std::nearbyint(q);
@@ -1789,6 +1799,7 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
       for (int64_t i = 0; i < n_max; ++i) rank[(size_t)perm[(size_t)i]] = (int32_t)lat[(size_t)i];
       HIPCHK(c, hipMalloc((void**)&c->d_rank, sizeof(int32_t) * npad));
       HIPCHK(c, hipMemcpy(c->d_rank, rank.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice));
+
       // times of the lattice points: the data's own values where occupied (so that a table entry's t_g - t_0 is the difference of
       // two stored points wherever both exist, as on the regular grid), t_0 + g h elsewhere
       const int64_t nlpad = ((n_lat + 255) / 256) * 256 + 256;

@@ -333,7 +333,9 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
 // 0.91 ms; lag-table sweeps price programs at ~2 us per node: dataflow 2.5 / 5 / 9 / 16 / 70 us: 3.87 / 3.83 / 3.83 / 3.86 / 4.01 ms at
 // n=2048 x 64, per-column launches 2.5 / 5 / 8 / 12 / 20 us: 25.33 / 25.40 / 25.57 / 25.58 / 25.94 ms (one-node programs only).
 constexpr double FUSE_MAX_US = 25.0, FLOW_FUSE_MAX_US = 70.0, FLOW_LAG_FUSE_MAX_US = 10.0, LAG_FUSE_MAX_US = 3.0;
-constexpr int64_t LATTICE_MAX = 131072;   // longest lattice admitted (rank tables of that many lags per stationary subtree: 1 MiB each, read from L2)
+constexpr int LAG_LDS_MAX_UNITS = 16;     // rank tables of up to 16 x 256 lags are copied into the evaluators' LDS
+constexpr int64_t LATTICE_MAX = LAG_LDS_MAX_UNITS * 256;   // longest lattice admitted: its rank tables must fit that LDS budget (longer tables would be
+                                          // gathered from L2, which is slower than evaluating the leaves: logpdf_batch_impl, NOTES_dead_ends.md round 5)
 constexpr int LATTICE_MAX_DIV = 400;      // the lattice spacing is sought as (smallest gap) / k, k <= this (a yearly index: 365 / 366 days)
 constexpr int HYBRID_BLOCKS = 512;        // medium populations: right-looking once a block column offers fewer workgroups (run_factor)
 constexpr double GRAD_TOEP_MAX_AMP = 1e4;  // ... and the largest entry of U' T^-1 U C it accepts (the downdate loses that factor times ~100 eps)

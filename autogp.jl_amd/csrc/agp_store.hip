@@ -215,8 +215,9 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   Batch bt;
   // regular grid: stationary subtrees from rank lag tables, as in the caller-order sweeps of logpdf_batch_impl (the mode depends
   // on the resident series alone, so an extension and a from-scratch sweep of the same entry evaluate every tile the same way)
-  const bool lagr = c->lag_rank_enable && c->lag_enable && c->lag_ok && c->n_lat <= LATTICE_MAX;
+  // (rank tables too long for LDS — a lattice with gaps — do not pay in the caller's order: see logpdf_batch_impl)
   const int rank_units = (int)((c->n_lat + 255) / 256);
+  const bool lagr = c->lag_rank_enable && c->lag_enable && c->lag_ok && rank_units <= LAG_LDS_MAX_UNITS;
   const bool ge_tab = c->logdt_ok && !lagr;
   // (tiles are evaluated inside the factorisation kernels whatever the population size: the prebuilt-tile variants of
   // the split launches carry the most register spills, and the store never needs K itself)

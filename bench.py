@@ -321,85 +321,92 @@ def extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, device):
 
 
 def calendar_leg(pkg, programs, nodes, noises, n, device):
-    """The same population on a calendar-indexed series: n month starts from 1949-01-01 through the reference's own date ingestion
-    (datetime2unix + min-max LinearTransform, src/api.jl:49-51,98-101) — 28..31-day spacings: NOT a regular grid, but a lattice
-    with gaps (the day), so the sweeps read their stationary subtrees from rank tables over the lattice's lags; none of the
-    Toeplitz / lag-domain machinery of regular grids applies (dense factor, L^-T, K^-1 for every particle)."""
+    """The same population on two calendar-indexed series, through the reference's own date ingestion (datetime2unix + min-max
+    LinearTransform, src/api.jl:49-51,98-101), shuffled as fit_smc! does (src/api.jl:232):
+      * `calendar_business_days`: n business days from 1949-01-03 — gaps of 1 and 3 days, NOT a regular grid, but a lattice with gaps of
+        n_lattice <= 4096 days: every caller-order sweep reads its stationary subtrees from rank tables in LDS, the gradient's
+        contraction runs over the lattice's lags (K^-1 tiles' lag histograms); no Toeplitz path (the points are not consecutive);
+      * `calendar_monthly`: n month starts from 1949-01-01 (28..31-day spacings; 62 304 days at n = 2048): too long a lattice for
+        LDS tables (gathering them from L2 was measured slower than evaluating the leaves: NOTES_dead_ends.md, round 5): general
+        evaluator, dense factor + L^-T + K^-1 + element-wise contraction for every particle."""
     import torch
-    out = {}
+    res = {}
     P = len(noises)
     stream = torch.cuda.current_stream().cuda_stream
-    ts, xs = pkg.prior.calendar_series(n, "M", seed=161, shuffle=True)
-    eng = pkg.GPEngine(device)
-    gen = pkg.GPEngine(device)
-    try:
-        gen.set_lattice(False)
-        eng.set_data(ts, xs); gen.set_data(ts, xs)
-        st = eng.lattice_stats()
-        d_lp = torch.zeros(P, dtype=torch.float64, device=f"cuda:{device}"); d_info = torch.zeros(P, dtype=torch.int32, device=f"cuda:{device}")
+    for name, freq in (("calendar_business_days", "B"), ("calendar_monthly", "M")):
+        out = {}
+        eng = pkg.GPEngine(device)
+        gen = pkg.GPEngine(device)
+        try:
+            ts, xs = pkg.prior.calendar_series(n, freq, seed=161, shuffle=True)
+            gen.set_lattice(False)
+            eng.set_data(ts, xs); gen.set_data(ts, xs)
+            st = eng.lattice_stats()
+            tables = st["kind"] == 2
+            d_lp = torch.zeros(P, dtype=torch.float64, device=f"cuda:{device}"); d_info = torch.zeros(P, dtype=torch.int32, device=f"cuda:{device}")
 
-        def value(e, reps=20):
-            for _ in range(3):
-                e.logpdf_batch_device(programs, noises, n, d_lp.data_ptr(), d_info.data_ptr(), stream); torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                e.logpdf_batch_device(programs, noises, n, d_lp.data_ptr(), d_info.data_ptr(), stream)
-                torch.cuda.current_stream().synchronize()
-            return (time.perf_counter() - t0) / reps, d_lp.cpu().numpy(), d_info.cpu().numpy()
-        dt, lp, info = value(eng)
-        dt_g, lp_g, info_g = value(gen, 10)
-        ok = (info == 0) & (info_g == 0)
-        out = {"what": f"n={n} month starts 1949-01-01.. (datetime2unix + min-max rescaling, shuffled), the same {P} particles",
-               "lattice": st, "evals_per_s": P / dt, "ms_per_step": dt * 1e3,
-               "general_evaluator": {"what": "the same series with agp_set_lattice(0): every element from its own t_i - t_j",
-                                     "evals_per_s": P / dt_g, "ms_per_step": dt_g * 1e3},
-               "max_rel_diff_vs_general_evaluator": float(np.max(np.abs(lp[ok] - lp_g[ok]) / np.maximum(1.0, np.abs(lp_g[ok])))) if ok.any() else None,
-               "info_equal": bool(np.array_equal(info, info_g))}
+            def value(e, reps=20):
+                for _ in range(3):
+                    e.logpdf_batch_device(programs, noises, n, d_lp.data_ptr(), d_info.data_ptr(), stream); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    e.logpdf_batch_device(programs, noises, n, d_lp.data_ptr(), d_info.data_ptr(), stream)
+                    torch.cuda.current_stream().synchronize()
+                return (time.perf_counter() - t0) / reps, d_lp.cpu().numpy(), d_info.cpu().numpy()
+            dt, lp, info = value(eng)
+            out = {"what": f"n={n} {'business days from 1949-01-03' if freq == 'B' else 'month starts from 1949-01-01'} (datetime2unix + min-max rescaling, shuffled), the same {P} particles",
+                   "lattice": st, "rank_tables": tables, "evals_per_s": P / dt, "ms_per_step": dt * 1e3}
+            if tables:
+                dt_g, lp_g, info_g = value(gen, 10)
+                ok = (info == 0) & (info_g == 0)
+                out["general_evaluator"] = {"what": "the same series with agp_set_lattice(0): every element from its own t_i - t_j",
+                                            "evals_per_s": P / dt_g, "ms_per_step": dt_g * 1e3}
+                out["max_rel_diff_vs_general_evaluator"] = float(np.max(np.abs(lp[ok] - lp_g[ok]) / np.maximum(1.0, np.abs(lp_g[ok])))) if ok.any() else None
+                out["info_equal"] = bool(np.array_equal(info, info_g))
 
-        def grad(e):
-            e.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                r = e.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
-            return (time.perf_counter() - t0) / 3, r
-        dg, (glp, gg, ggn, ginfo) = grad(eng)
-        dg_g, (glp2, gg2, ggn2, ginfo2) = grad(gen)
-        worst = 0.0
-        for a_, b_, i_ in zip(gg, gg2, ginfo):
-            if i_ == 0 and len(a_):
-                worst = max(worst, float(np.max(np.abs(a_ - b_)) / max(1.0, float(np.max(np.abs(b_))))))
-        out["grad"] = {"ms_per_sweep": dg * 1e3, "general_evaluator_ms_per_sweep": dg_g * 1e3, "max_diff_vs_general_evaluator_of_gradient_scale": worst,
-                       "flop_floor": "n^3 per particle (factor n^3/3 + L^-T n^3/3 + K^-1 n^3/3): "
-                                     f"{P * float(n) ** 3 / PEAK_FP64_MFMA_TFLOPS / 1e9:.1f} ms at the fp64 MFMA peak",
-                       "tflops_on_n3": P * float(n) ** 3 / dg / 1e12}
-        # predictive pass: the observed months + as many future month starts (lattice points), first 128 particles
-        Pp = min(P, 128)
-        x = pkg.prior.datetime2unix(pkg.prior.calendar_dates(2 * n, "M"))
-        slope, icpt = pkg.prior.linear_transform_minmax(x[:n])
-        tq = np.concatenate([ts, (slope * x + icpt)[n:]])
+            def grad(e):
+                e.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    r = e.logpdf_grad_batch(None, noises, n=n, check=False, programs=programs)
+                return (time.perf_counter() - t0) / 3, r
+            k0 = eng.grad_lag_domain_particles()
+            dg, (glp, gg, ggn, ginfo) = grad(eng)
+            n_lagdom = (eng.grad_lag_domain_particles() - k0) // 4
+            out["grad"] = {"ms_per_sweep": dg * 1e3, "lag_domain_particles": int(n_lagdom), "tflops_on_n3": P * float(n) ** 3 / dg / 1e12,
+                           "flop_floor": "dense pipeline, n^3 per particle (factor n^3/3 + L^-T n^3/3 + K^-1 n^3/3): "
+                                         f"{P * float(n) ** 3 / PEAK_FP64_MFMA_TFLOPS / 1e9:.1f} ms at the fp64 MFMA peak"}
+            if tables:
+                dg_g, (glp2, gg2, ggn2, ginfo2) = grad(gen)
+                worst = 0.0
+                for a_, b_, i_ in zip(gg, gg2, ginfo):
+                    if i_ == 0 and len(a_):
+                        worst = max(worst, float(np.max(np.abs(a_ - b_)) / max(1.0, float(np.max(np.abs(b_))))))
+                out["grad"].update({"general_evaluator_ms_per_sweep": dg_g * 1e3, "max_diff_vs_general_evaluator_of_gradient_scale": worst})
+            # predictive pass: the observed dates + as many future dates at the index's cadence (lattice points), first 128 particles
+            Pp = min(P, 128)
+            x = pkg.prior.datetime2unix(pkg.prior.calendar_dates(2 * n, freq))
+            slope, icpt = pkg.prior.linear_transform_minmax(x[:n])
+            tq = np.concatenate([ts, (slope * x + icpt)[n:]])
 
-        def pred(e):
-            for _ in range(2):
-                e.predict_batch(nodes[:Pp], noises[:Pp], tq, n=n, check=False)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                r = e.predict_batch(nodes[:Pp], noises[:Pp], tq, n=n, check=False)
-            return (time.perf_counter() - t0) / 3, r
-        k0 = eng.lag_predict_passes()
-        dp, (pm, pv, _, pinfo) = pred(eng)
-        on_lat = eng.lag_predict_passes() > k0
-        dp_g, (pm2, pv2, _, pinfo2) = pred(gen)
-        okp = (pinfo == 0) & (pinfo2 == 0)
-        fl_done = Pp * (2.0 * cholesky_flops(n) + float(n) * n * n)
-        out["predict"] = {"ms": dp * 1e3, "general_evaluator_ms": dp_g * 1e3, "particles": Pp, "m": 2 * n, "rank_tables": bool(on_lat),
-                          "executed_flops": fl_done, "frac_of_fp64_mfma_peak": fl_done / dp / 1e12 / PEAK_FP64_MFMA_TFLOPS,
-                          "max_diff_mean_vs_general_evaluator": float(np.max(np.abs(pm[okp] - pm2[okp])) / max(1.0, float(np.max(np.abs(pm2[okp]))))) if okp.any() else None,
-                          "max_diff_var_vs_general_evaluator": float(np.max(np.abs(pv[okp] - pv2[okp])) / max(1.0, float(np.max(np.abs(pv2[okp]))))) if okp.any() else None}
-    except Exception as e:      # noqa: BLE001
-        out["error"] = str(e)[:300]
-    finally:
-        eng.close(); gen.close()
-    return {"calendar_monthly": out}
+            def pred(e):
+                for _ in range(2):
+                    e.predict_batch(nodes[:Pp], noises[:Pp], tq, n=n, check=False)
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    r = e.predict_batch(nodes[:Pp], noises[:Pp], tq, n=n, check=False)
+                return (time.perf_counter() - t0) / 3, r
+            k0 = eng.lag_predict_passes()
+            dp, (pm, pv, _, pinfo) = pred(eng)
+            fl_done = Pp * (2.0 * cholesky_flops(n) + float(n) * n * n)
+            out["predict"] = {"ms": dp * 1e3, "particles": Pp, "m": 2 * n, "rank_tables": bool(eng.lag_predict_passes() > k0),
+                              "executed_flops": fl_done, "frac_of_fp64_mfma_peak": fl_done / dp / 1e12 / PEAK_FP64_MFMA_TFLOPS}
+        except Exception as e:      # noqa: BLE001
+            out["error"] = str(e)[:300]
+        finally:
+            eng.close(); gen.close()
+        res[name] = out
+    return res
 
 
 def free_port():

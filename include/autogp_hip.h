@@ -158,16 +158,18 @@ int agp_set_factor_cache(agp_ctx* ctx, int32_t on);
 int agp_get_lag_stats(agp_ctx* ctx, int32_t* regular_grid, int64_t* n_lag_sweeps);
 int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
 
-/* Lattices with gaps: calendar-indexed series.  The reference turns dates into seconds (datetime2unix, src/api.jl:49-51) and
- * min-max rescales them (src/api.jl:98-101), so monthly (28..31 days), quarterly, yearly (365 / 366) and business-day indices are
- * never regular grids — but every such time point is t_0 + g h with an INTEGER g (h = one day after rescaling), i.e.
- * |t_a - t_b| = |g_a - g_b| h for every pair, which is all the rank tables below need.  When the regular-grid test fails,
- * agp_set_data looks for the largest h = (smallest gap) / k, k <= 400, that puts every sorted point within 1e-11 SMALLEST GAPS of
- * t_0 + g h (spans of up to 131072 lattice points); the series' "ranks" are then the lattice indices g_i, a stationary subtree's
- * table holds n_lattice lags and is read in place (L2) by the tile builder, and every value / prefix / factor-store / predictive
- * sweep (query points on the lattice: the next month starts) takes the table-driven evaluator.  The sorted sweeps with per-tile
- * tables, the Toeplitz paths and the lag-domain gradient need consecutive lattice points and stay with regular grids.
- * agp_get_lattice_stats: kind = 0 (irregular: general path), 1 (regular grid), 2 (lattice with gaps); AGP_LATTICE=0 /
+/* Lattices with gaps: business-day indices, short calendar indices, regular series with missing observations.  The reference turns
+ * dates into seconds (datetime2unix, src/api.jl:49-51) and min-max rescales them (src/api.jl:98-101); a business-day index (gaps of
+ * 1 and 3 days), month starts (28..31 days) or a daily / hourly series with missing observations are not regular grids, but every
+ * such time point is t_0 + g h with an INTEGER g, i.e. |t_a - t_b| = |g_a - g_b| h for every pair, which is all the rank tables
+ * below need.  When the regular-grid test fails, agp_set_data looks for the largest h = (smallest gap) / k, k <= 400, that puts every
+ * sorted point within 1e-11 SMALLEST GAPS of t_0 + g h, for spans of up to 4096 lattice points (the LDS budget of a rank table;
+ * n_lattice <= n^2 / 2): the series' "ranks" are then the lattice indices g_i, a stationary subtree's table holds n_lattice lags, and
+ * every caller-order sweep — value, prefix, factor store, gradient factorisation, predictive passes on lattice query points — takes
+ * the table-driven evaluator.  The sorted sweeps with per-tile tables, the Toeplitz paths and the lag-domain gradient need
+ * CONSECUTIVE lattice points and stay with regular grids.  Longer lattices (2048 month starts span 62 304 days) keep the general
+ * evaluator: their tables would be gathered from L2, which was measured slower than evaluating the leaves (NOTES_dead_ends.md,
+ * round 5).  agp_get_lattice_stats: kind = 0 (general path), 1 (regular grid), 2 (lattice with gaps); AGP_LATTICE=0 /
  * agp_set_lattice(ctx, 0) admit regular grids only (read at the next agp_set_data). */
 int agp_get_lattice_stats(agp_ctx* ctx, int32_t* kind, int64_t* n_lattice, double* spacing);
 int agp_set_lattice(agp_ctx* ctx, int32_t on);

@@ -159,15 +159,16 @@ def test_documented_build_recipes_produce_the_full_library(pkg, tmp_path):
 
 def test_lattice_admission_of_calendar_indices(pkg):
     """agp_probe_lattice = the admission test of agp_set_data on its own (host code): date indices as GPModel ingests them
-    (datetime2unix + min-max LinearTransform, src/api.jl:49-51,98-101) are lattices with gaps, with the day as spacing."""
+    (datetime2unix + min-max LinearTransform, src/api.jl:49-51,98-101) are lattices with gaps, with the day as spacing — admitted
+    up to 4096 lattice points (the LDS budget of a rank table)."""
     pr = pkg.prior
-    for freq, n, gaps in (("M", 2048, {28, 29, 30, 31}), ("M", 512, {28, 29, 30, 31}), ("B", 2048, {1, 3}), ("Q", 800, {90, 91, 92})):
+    for freq, n, gaps in (("B", 2048, {1, 3}), ("B", 2900, {1, 3}), ("M", 134, {28, 29, 30, 31}), ("M", 64, {28, 29, 30, 31})):
         for shuffle in (False, True):
             ts, _ = pr.calendar_series(n, freq, seed=1, shuffle=shuffle)
             r = pkg.probe_lattice(ts)
             assert r["kind"] == 2, (freq, n)
             g = np.sort(r["index"])
-            assert g[0] == 0 and r["n_lattice"] == g[-1] + 1 and set(np.diff(g)) == gaps
+            assert g[0] == 0 and r["n_lattice"] == g[-1] + 1 <= 4096 and set(np.diff(g)) == gaps
             days = (pr.datetime2unix(pr.calendar_dates(n, freq)) / 86400.0)
             assert np.array_equal(g, np.sort(days - days.min()).astype(np.int64))           # the lattice index IS the day number
             # |t_a - t_b| = |g_a - g_b| h to the admitted 1e-11 of the smallest gap
@@ -176,19 +177,20 @@ def test_lattice_admission_of_calendar_indices(pkg):
     assert pkg.probe_lattice(pr.calendar_series(2048, "D")[0])["kind"] == 1              # calendar days: a regular grid
     assert pkg.probe_lattice(np.linspace(0.0, 1.0, 777))["kind"] == 1
     # raw unix seconds, unscaled (test/test_GP.jl:35-68 style raw-space calls)
-    r = pkg.probe_lattice(pr.datetime2unix(pr.calendar_dates(500, "M", "1990-01-01")))
+    r = pkg.probe_lattice(pr.datetime2unix(pr.calendar_dates(120, "M", "1990-01-01")))
     assert r["kind"] == 2 and r["spacing"] == 86400.0
-    # refused: irregular times; an offset grid (ulp(1000) / h = 4.6e-10); a monthly index with one date moved by 1e-9 gaps; duplicates;
-    # lattices whose tables would cost more than the elements they stand for (n_lattice > n^2 / 8: a yearly index, tsdl.161's 144 months)
+    # a regular grid with missing observations is a lattice with gaps
+    r = pkg.probe_lattice(np.delete(np.linspace(0.0, 1.0, 400), [17, 18, 200, 333]))
+    assert r["kind"] == 2 and r["n_lattice"] == 400
+    # refused: irregular times; an offset grid (ulp(1000) / h = 4.6e-10); a business-day index with one date moved by 1e-9 gaps;
+    # duplicates; lattices beyond 4096 points (2048 month starts: 62 304 days; 3000 business days) or with more lags than
+    # elements (n_lattice > n^2 / 2: 40 month starts)
     rng = np.random.default_rng(0)
-    ts, _ = pr.calendar_series(512, "M")
+    ts, _ = pr.calendar_series(512, "B")
     moved = ts.copy(); moved[100] += 1e-9 * np.diff(ts).min()
     for bad in (np.sort(rng.random(500)), np.linspace(1000.0, 1001.0, 2048), moved, np.concatenate([ts, ts[5:6]]),
-                pr.calendar_series(300, "Y")[0], pr.calendar_series(144, "M")[0]):
+                pr.calendar_series(2048, "M")[0], pr.calendar_series(3000, "B")[0], pr.calendar_series(300, "Y")[0], pr.calendar_series(40, "M")[0]):
         assert pkg.probe_lattice(bad)["kind"] == 0
-    # a regular grid with one point missing is a lattice with one gap
-    r = pkg.probe_lattice(np.delete(np.linspace(0.0, 1.0, 400), 17))
-    assert r["kind"] == 2 and r["n_lattice"] == 400
 
 
 def test_no_cpu_fallback(pkg):
