@@ -11,6 +11,21 @@ int fail(agp_ctx* c, int code, const std::string& msg) {
   return code;
 }
 
+// Reference arithmetic: every structure-exploiting or state-dependent path off, ONE schedule.  A particle's results then depend on
+// (program, parameters, noise, data, n) alone — not on the batch it travels in, on what the factor store holds, on the order of
+// the calls or on the other switches: prebuilt tiles from k_cov_tiles (each element from its own t_i - t_j, GammaExp by pow as the
+// reference's (abs(dt) / l)^gamma, src/GP.jl:285-289), left-looking per-column launches with the diagonal tiles in their own
+// launch whatever the population, the dense joint predictive pass (V = L^-1 K12 for every query point, src/GP.jl:743-757),
+// L^-T + K^-1 + element-wise contraction for every gradient, nothing resident.  Slower (the price of the general path); meant for
+// reproducible runs and for arbitrating differences between the fast paths.  Read at agp_init (env) and at the next agp_set_data.
+void apply_reference_arithmetic(agp_ctx* c) {
+  c->ref_arith = 1;
+  c->lag_enable = 0; c->lag_rank_enable = 0; c->lattice_enable = 0; c->toeplitz = 0;
+  c->grad_lagdom = 0; c->grad_fft = 0; c->grad_struct = 0;
+  c->factor_cache = 0; c->predict_reuse = 0;
+  c->flow = 0; c->right_looking = 0; c->split_diag = 1; c->fuse_mode = 0; c->ge_table = 0; c->logdt_ok = false;
+}
+
 // (c->mu held) an asynchronously handed-back slot whose event has completed: look at the info words it left behind
 void latch_async_info(agp_ctx* c, Slot* s) {
   const int32_t* hi = static_cast<const int32_t*>(s->h_async_info.p);
@@ -1559,6 +1574,7 @@ static int init_body(agp_ctx** out, int device_id) {
   if (const char* e = getenv("AGP_COALESCE_US")) c->coalesce_us = std::max(0, atoi(e));
   if (const char* e = getenv("AGP_FLOW")) c->flow = atoi(e);
   if (const char* e = getenv("AGP_EXTEND_FRAC")) c->store.max_frac = std::max(0.0, std::min(0.8, atof(e)));
+  if (const char* e = getenv("AGP_REFERENCE_ARITHMETIC")) { if (atoi(e) != 0) apply_reference_arithmetic(c); }      // (overrides the switches above)
   *out = c;
   return AGP_OK;
 }

@@ -192,6 +192,8 @@ struct agp_ctx {
   bool lag_contig = false;        // ... and occupy CONSECUTIVE lattice points (a regular grid): sorted sweeps with per-tile tables, Toeplitz paths
   double lat_tol_abs = 0.0;       // admitted deviation of a point from its lattice position (lag_tol_h x the spacing; with gaps: x the smallest gap)
   int64_t n_lat = 0;              // lattice points the series spans: largest index + 1 (== n_max on a regular grid)
+  int ref_arith = 0;              // AGP_REFERENCE_ARITHMETIC=1 / agp_set_reference_arithmetic: ONE arithmetic whatever the call order — dense Cholesky
+                                  // on one fixed schedule, every element from its own t_i - t_j, dense predictive pass, element-wise gradient, no store
   int lattice_enable = 1;         // admit lattices with gaps (calendar-indexed series: monthly / quarterly / yearly / business-day dates are
                                   // integer multiples of a day after datetime2unix, src/api.jl:49-51,98-101); env AGP_LATTICE=0: regular grids only
   std::vector<double> h_ts_lat;   // time of lattice point g: the data's own value where a point sits there, t_0 + g h elsewhere (length n_lat)
@@ -401,6 +403,8 @@ template <class F> inline int abi_guard(agp_ctx* c, F&& f) noexcept {
   catch (const std::exception& e) { try { return fail(c, AGP_ERR_HOST, std::string("internal error: ") + e.what()); } catch (...) { return AGP_ERR_HOST; } }
   catch (...) { return AGP_ERR_HOST; }
 }
+
+void apply_reference_arithmetic(agp_ctx* c);      // agp_engine.hip
 
 // a thread-local switch held for a scope (nested sweeps of the structured paths)
 struct TlFlag {

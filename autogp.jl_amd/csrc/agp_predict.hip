@@ -97,7 +97,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
   // joint path spends n^2 flops PER SUCH POINT on V = L^-1 K12 (the reference's query set is train + test + future,
   // scripts/online.jl:41-43: n of its points are of this kind).  The other query points take the joint path below.
   std::vector<int32_t> dq, di, fq;      // duplicates: position in ts_pred, training index; the remaining queries
-  split_queries(c, n, ts_pred, m, !out_cov && !pred_code, dq, di, fq);
+  split_queries(c, n, ts_pred, m, !out_cov && !pred_code && !c->ref_arith, dq, di, fq);
   const bool diag_path = !dq.empty();
   const int64_t mJ = diag_path ? (int64_t)fq.size() : m;      // query points of the joint matrix
   std::vector<double> tsF, meanF, daddF;
@@ -768,7 +768,7 @@ static int predict_batch_body(agp_ctx* c, int64_t n, const double* ts_pred, int6
   int64_t m_joint = m;       // query points predict_core keeps in the joint matrix (it makes the same split)
   {
     std::vector<int32_t> dq, di, fq;
-    split_queries(c, n, ts_pred, m, !out_cov, dq, di, fq);
+    split_queries(c, n, ts_pred, m, !out_cov && !c->ref_arith, dq, di, fq);
     if (!dq.empty()) m_joint = (int64_t)fq.size();
   }
   if (U == 0 || U == P) {

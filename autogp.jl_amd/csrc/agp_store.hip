@@ -357,7 +357,20 @@ extern "C" {
 int agp_logpdf_batch_extend(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
                             const int32_t* prm_off, const double* prm, const double* noise, double* out_logpdf,
                             int32_t* out_info) {
+  // (reference arithmetic keeps nothing resident: the same call is a plain sweep)
+  if (c && c->ref_arith) return agp_logpdf_batch(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info);
   return abi_guard(c, [&] { return extend_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info); });
+}
+
+int agp_set_reference_arithmetic(agp_ctx* c, int32_t on) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (on) {
+    std::lock_guard<std::mutex> g(c->store.mu);
+    apply_reference_arithmetic(c);
+    c->store.forget();
+    return AGP_OK;
+  }
+  return fail(c, AGP_ERR_ARG, "reference arithmetic cannot be switched off on a live context (create a new one)");
 }
 
 int agp_extend_stats(agp_ctx* c, int64_t* out4) {

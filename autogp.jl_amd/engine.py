@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi", "agp_logpdf_batch_extend_multi",
     "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
-    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_get_lattice_stats", "agp_set_lattice", "agp_probe_lattice", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_predict_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
+    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_get_lattice_stats", "agp_set_lattice", "agp_probe_lattice", "agp_set_reference_arithmetic", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_predict_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
 ]
 COMM_ID_BYTES = 128
 
@@ -143,6 +143,7 @@ def load_library(path=None):
     lib.agp_set_lag_tables.argtypes = [vp, C.c_int32]; lib.agp_set_lag_tables.restype = C.c_int
     lib.agp_get_lattice_stats.argtypes = [vp, i32p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]; lib.agp_get_lattice_stats.restype = C.c_int
     lib.agp_set_lattice.argtypes = [vp, C.c_int32]; lib.agp_set_lattice.restype = C.c_int
+    lib.agp_set_reference_arithmetic.argtypes = [vp, C.c_int32]; lib.agp_set_reference_arithmetic.restype = C.c_int
     lib.agp_probe_lattice.argtypes = [dp, C.c_int64, i32p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]; lib.agp_probe_lattice.restype = C.c_int
     lib.agp_set_grad_lag_domain.argtypes = [vp, C.c_int32]; lib.agp_set_grad_lag_domain.restype = C.c_int
     lib.agp_set_lag_rank_tables.argtypes = [vp, C.c_int32]; lib.agp_set_lag_rank_tables.restype = C.c_int
@@ -363,6 +364,10 @@ class GPEngine:
     def set_lattice(self, on):
         """Admit lattices with gaps at the next set_data (off: regular grids only)."""
         self._check(self._lib.agp_set_lattice(self._ctx, 1 if on else 0))
+
+    def set_reference_arithmetic(self):
+        """ONE arithmetic whatever the call order / batch / store state (agp_set_reference_arithmetic); call before set_data."""
+        self._check(self._lib.agp_set_reference_arithmetic(self._ctx, 1))
 
     def set_lag_tables(self, on):
         """Switch the regular-grid lag-table path (takes effect at the next set_data)."""

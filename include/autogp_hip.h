@@ -177,6 +177,19 @@ int agp_set_lattice(agp_ctx* ctx, int32_t on);
  * length and spacing, and per point its lattice index (index_out, nullable; -1 when kind = 0). */
 int agp_probe_lattice(const double* ts, int64_t n, int32_t* kind, int64_t* n_lattice, double* spacing, int64_t* index_out);
 
+/* Reference arithmetic (AGP_REFERENCE_ARITHMETIC=1 at agp_init, or agp_set_reference_arithmetic(ctx, 1) right after it, before
+ * agp_set_data).  The default engine picks, per call, among evaluators (direct, lag / rank tables), schedules (per-column,
+ * dataflow, right-looking), structured sweeps (Toeplitz class), gradient contractions (lag domain, element-wise) and whatever the
+ * factor store holds: all within the stated tolerances of one another, but a particle's low-order bits then depend on the batch it
+ * travels in and on the order of the calls.  This switch selects ONE arithmetic whatever the state: every covariance element from
+ * its own t_i - t_j (GammaExp by pow, src/GP.jl:285-289), tiles prebuilt, the left-looking Cholesky on one fixed schedule, the
+ * dense joint predictive pass (V = L^-1 K12 for every query point, src/GP.jl:743-757), L^-T + K^-1 + the element-wise contraction
+ * for every gradient, nothing resident (agp_logpdf_batch_extend = agp_logpdf_batch).  Results are then bit-identical across batch
+ * sizes, call orders and single / batched / coalesced entries (tests/test_gpu_parity.py::test_reference_arithmetic_is_call_order_stable).
+ * It overrides AGP_LAG / AGP_LAG_RANK / AGP_LATTICE / AGP_GRAD_LAGDOM / AGP_GRAD_FFT / AGP_FLOW / AGP_RIGHT_LOOKING /
+ * AGP_SPLIT_DIAG / AGP_FUSE / AGP_GE_TABLE / AGP_FACTOR_CACHE / AGP_PREDICT_REUSE and cannot be switched off on a live context. */
+int agp_set_reference_arithmetic(agp_ctx* ctx, int32_t on);
+
 /* OPT-IN structured value sweep (AGP_LAG=2 / agp_set_lag_tables(ctx, 2); off by default: the default path mirrors the reference's
  * dense Cholesky, src/Model.jl:134-136).  On the sorted copy of a regular grid a kernel that is a sum of stationary subtrees and
  * Linear leaves gives K = T + U C U' — T symmetric Toeplitz, U = [1, t], C 2x2 — and log N(x; 0, K) follows from log|T| and

@@ -851,3 +851,56 @@ def test_engine_against_scikit_learn(pkg, engine):
         assert abs(lpg - ref) <= LP_TOL * max(1.0, abs(ref))
         for nm, want in zip(names, gsk):
             assert abs(mine[nm] - want) <= 1e-7 * max(1.0, abs(want)), (nm, mine[nm], want)
+
+
+def test_reference_arithmetic_is_call_order_stable(pkg):
+    """agp_set_reference_arithmetic: a particle's results depend on (program, parameters, noise, data, n) alone — the same BITS from a
+    batch of 1, of 6 and of 300, from the single-particle entry (coalesced), from the extension entry, from the value part of a
+    gradient call, before and after other calls left state behind, on a regular grid (where the default engine would pick among
+    lag tables, Toeplitz sweeps and lag-domain contractions) — and they meet the oracle at the stated tolerances."""
+    n = 600
+    ts, xs = pkg.prior.synthetic_series(n, seed=8, shuffle=True)          # a regular grid: every structured path would apply
+    G = pkg
+    mine = [G.SquaredExponential(0.2, 0.8) + G.Linear(0.3, 0.2, 0.5), G.Periodic(0.7, 0.21, 1.1) * G.SquaredExponential(0.5, 0.9),
+            G.GammaExponential(0.3, 1.2, 0.7) + G.WhiteNoise(0.05), G.ChangePoint(G.Periodic(0.5, 0.1, 1.0), G.SquaredExponential(0.2, 0.6), 0.45, 0.01),
+            G.Linear(0.1, 0.3, 0.7), G.Linear(0.2, 0.1, 0.6) * G.Periodic(1.0, 0.3, 0.8) + G.Constant(0.3)]
+    nz = np.linspace(0.05, 0.2, len(mine))
+    others, onz = pkg.prior.sample_particles(np.random.default_rng(4), 294, max_depth=3)
+    tq = np.concatenate([ts[:50], np.linspace(1.0, 1.2, 30)])
+    eng = pkg.GPEngine(0)
+    try:
+        eng.set_reference_arithmetic()
+        eng.set_data(ts, xs)
+        assert eng.lag_stats() == (False, 0) and eng.lattice_stats()["kind"] == 0
+        lp6, i6 = eng.logpdf_batch(mine, nz, check=False)
+        assert (i6 == 0).all()
+        lp1 = np.array([eng.logpdf_batch([k], [z], check=False)[0][0] for k, z in zip(mine, nz)])
+        lps = np.array([eng.logpdf(k, float(z)) for k, z in zip(mine, nz)])          # agp_logpdf (coalescing queue)
+        big, _ = eng.logpdf_batch(list(others[:150]) + mine + list(others[150:]), np.concatenate([onz[:150], nz, onz[150:]]), check=False)
+        ext, _ = eng.logpdf_batch_extend(mine, nz, check=False)
+        ext_prefix, _ = eng.logpdf_batch_extend(mine, nz, n=300, check=False)
+        ext2, _ = eng.logpdf_batch_extend(mine, nz, check=False)                      # (would be an extension sweep by default)
+        glp, grads, gn, gi = eng.logpdf_grad_batch(mine, nz, check=False)
+        glp_big, grads_big, gn_big, _ = eng.logpdf_grad_batch(list(others[:280]) + mine, np.concatenate([onz[:280], nz]), check=False)
+        for other in (lp1, lps, big[150:156], ext, ext2, glp, glp_big[280:]):
+            assert np.array_equal(lp6, other)
+        for a_, b_ in zip(grads, grads_big[280:]):
+            assert np.array_equal(a_, b_)
+        assert np.array_equal(gn, gn_big[280:])
+        assert eng.extend_stats()["tile_rows_reused"] == 0 and eng.grad_lag_domain_particles() == 0 and eng.grad_structured_particles() == 0
+        m6, v6, _, _ = eng.predict_batch(mine, nz, tq, check=False)
+        m1 = np.array([eng.predict_batch([k], [z], tq, check=False)[0][0] for k, z in zip(mine, nz)])
+        mb, vb, _, _ = eng.predict_batch(list(others[:60]) + mine, np.concatenate([onz[:60], nz]), tq, check=False)
+        assert np.array_equal(m6, m1) and np.array_equal(m6, mb[60:]) and np.array_equal(v6, vb[60:])
+        assert eng.predict_structured_particles() == 0 and eng.lag_predict_passes() == 0
+        for i, (k, z) in enumerate(zip(mine, nz)):
+            lpo, go, gno = O.gp_logpdf_grad(k.to_tuple(), float(z), ts, xs)
+            sc = max(1.0, np.abs(go).max(), abs(gno))
+            assert abs(lp6[i] - lpo) <= LP_TOL * max(1.0, abs(lpo))
+            assert np.abs(grads[i] - go).max() <= GRAD_TOL * sc and abs(gn[i] - gno) <= GRAD_TOL * sc
+            mu, cv = O.predict_mvn(k.to_tuple(), float(z), ts, xs, tq)
+            assert np.abs(m6[i] - mu).max() <= 1e-8 * max(1.0, np.abs(mu).max())
+            assert np.abs(v6[i] - np.diag(cv)).max() <= 1e-8 * max(1.0, np.abs(cv).max())
+        assert np.abs(ext_prefix - eng.logpdf_batch(mine, nz, n=300, check=False)[0]).max() == 0.0
+    finally:
+        eng.close()
