@@ -43,6 +43,33 @@ def allgather_logweights(local, P: int, group=None):
     return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
 
 
+def plan_indices(owner, rank: int):
+    """Particles of `rank` under a shard plan (agp_shard_plan's owner array), in ascending population order."""
+    return np.flatnonzero(np.asarray(owner) == rank)
+
+
+def allgather_planned(local, owner, group=None):
+    """All-gather for a cost-aware plan: rank r holds the log-weights of plan_indices(owner, r) in that order; the result is the
+    full vector in population order (every rank knows the plan, so un-permuting needs no communication)."""
+    import torch
+    import torch.distributed as dist
+    owner = np.asarray(owner)
+    world = dist.get_world_size(group)
+    counts = [int(np.sum(owner == r)) for r in range(world)]
+    if local.numel() != counts[dist.get_rank(group)]:
+        raise ValueError("local shard has the wrong length for this plan")
+    mx = max(counts + [1])
+    pad = torch.zeros(mx, dtype=local.dtype, device=local.device)
+    pad[: local.numel()] = local
+    gathered = torch.empty(world * mx, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, pad, group=group)
+    out = torch.empty(owner.shape[0], dtype=local.dtype, device=local.device)
+    for r in range(world):
+        idx = torch.as_tensor(plan_indices(owner, r), dtype=torch.long, device=local.device)
+        out[idx] = gathered[r * mx: r * mx + counts[r]]
+    return out
+
+
 # ---- consumers of the gathered vector (host side, identical on every rank) -------------------
 def normalize_weights(log_weights):
     """Gen.normalize_weights: (log_total_weight, log_normalized_weights)."""

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi", "agp_logpdf_batch_extend_multi",
     "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
-    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_get_lattice_stats", "agp_set_lattice", "agp_probe_lattice", "agp_set_reference_arithmetic", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_predict_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
+    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_get_lattice_stats", "agp_set_lattice", "agp_probe_lattice", "agp_set_reference_arithmetic", "agp_shard_plan", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_predict_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
 ]
 COMM_ID_BYTES = 128
 
@@ -136,6 +136,8 @@ def load_library(path=None):
     lib.agp_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, i32p, i32p]; lib.agp_shard_range.restype = None
     lib.agp_comm_get_unique_id.argtypes = [vp]; lib.agp_comm_get_unique_id.restype = C.c_int
     lib.agp_comm_init_rank.argtypes = [vp, vp, C.c_int32, C.c_int32]; lib.agp_comm_init_rank.restype = C.c_int
+    lib.agp_shard_plan.argtypes = [C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, C.c_int32, C.c_int32, C.c_int64, C.c_int32, i32p, dp, dp]
+    lib.agp_shard_plan.restype = C.c_int
     lib.agp_comm_info.argtypes = [vp, i32p, i32p]; lib.agp_comm_info.restype = C.c_int
     lib.agp_comm_count.argtypes = [vp, i32p]; lib.agp_comm_count.restype = C.c_int
     lib.agp_wait.argtypes = [vp]; lib.agp_wait.restype = C.c_int
@@ -591,6 +593,20 @@ def shard_range(P: int, rank: int, n_ranks: int):
     lo = C.c_int32(); hi = C.c_int32()
     load_library().agp_shard_range(int(P), int(rank), int(n_ranks), C.byref(lo), C.byref(hi))
     return lo.value, hi.value
+
+
+def shard_plan(programs, noises, n, n_ranks, sweep=1, regular_grid=True, m_future=0):
+    """agp_shard_plan: (owner[P], cost[P], rank_cost[n_ranks]) — cost-aware, duplicate-aware assignment of particles to ranks."""
+    op_off, ops, prm_off, prm = programs
+    P = op_off.shape[0] - 1
+    noises = _f64(noises)
+    owner = np.zeros(max(P, 1), dtype=np.int32); cost = np.zeros(max(P, 1)); rc = np.zeros(n_ranks)
+    r = load_library().agp_shard_plan(int(n), P, _ip(op_off), _u8(ops), _ip(prm_off), _dp(prm if prm.size else np.zeros(1)), _dp(noises),
+                                      int(sweep), 1 if regular_grid else 0, int(m_future), int(n_ranks),
+                                      owner.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cost), _dp(rc))
+    if r != 0:
+        raise AGPError(f"agp_shard_plan failed ({r})")
+    return owner[:P], cost[:P], rc
 
 
 def probe_lattice(ts):

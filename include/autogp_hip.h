@@ -348,6 +348,19 @@ int agp_cov_matrix(agp_ctx* ctx, const double* ts, int64_t n,
 
 /* first P % R ranks hold one particle more; identical on every rank */
 void agp_shard_range(int32_t P, int32_t rank, int32_t n_ranks, int32_t* lo, int32_t* hi);
+/* Cost-aware, duplicate-aware alternative for sweeps whose per-particle cost is NOT uniform (host code only; every rank derives
+ * the same plan from the same population): sweep = 0 dense value sweep (uniform: use agp_shard_range), 1 gradient sweep,
+ * 2 marginal predictive pass with m_future query points beyond the training points, 3 opt-in structured value sweep;
+ * regular_grid = the resident series' kind (agp_get_lag_stats): on a regular grid the particles whose kernel is a sum of
+ * stationary subtrees and Linear leaves cost O(n^2) in sweeps 1-3, the others ~n^3; copies of an earlier particle (resampled
+ * populations, src/inference_smc_anneal_data.jl:198-204) cost nothing and follow their representative.  Longest-processing-time
+ * greedy over the distinct particles.  owner_out[p] = rank of particle p; cost_out[p] (nullable) = its modelled cost in units of one
+ * dense factorisation (n^3/3 flops); rank_cost_out[r] (nullable) = the ranks' totals.  A rank evaluates its particles in ascending
+ * index order; the all-gathered log-weights are put back in population order with the same owner_out (autogp.jl_amd/dist.py:
+ * plan_shards / allgather_planned; the Julia shim's equivalent is a scatter by owner). */
+int agp_shard_plan(int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                   const double* noise, int32_t sweep, int32_t regular_grid, int64_t m_future, int32_t n_ranks,
+                   int32_t* owner_out, double* cost_out, double* rank_cost_out);
 
 /* One process (or thread) per GPU: rank 0 creates the id, hands the 128 bytes to the other ranks over any host
  * channel (MPI, a file, Julia's Distributed, torch.distributed), every rank then joins with its own context. */

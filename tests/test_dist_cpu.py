@@ -101,3 +101,59 @@ def test_rejuvenation_without_object_channel_is_refused(pkg):
                                  rank=0, world=2, allgather=lambda full: full, seed=1)
     with pytest.raises(RuntimeError, match="allgather_objects"):
         st.step(5, rejuvenate=lambda nb, zb, n: (nb, zb, np.zeros(len(nb))))
+
+
+def test_shard_plan_properties(pkg):
+    """agp_shard_plan (host code): copies follow their representative and cost nothing, the Toeplitz class is cheap only where the
+    structured sweeps run (regular grid, gradient / predictive), uniform costs give an even count split, the plan is deterministic."""
+    import numpy as np
+    sys.path.insert(0, str(ROOT / "tests"))
+    import _plan_worker as W
+    P, n = 96, 2048
+    nodes, noises = W.skewed_population(pkg, P, seed=9)
+    programs = pkg.encode_batch(nodes)
+    for world in (2, 4, 8):
+        owner, cost, rc = pkg.shard_plan(programs, noises, n, world, sweep=1, regular_grid=True)
+        owner2, _, _ = pkg.shard_plan(programs, noises, n, world, sweep=1, regular_grid=True)
+        assert np.array_equal(owner, owner2) and owner.min() >= 0 and owner.max() < world
+        # copies: zero cost, same rank as the original
+        keys = {}
+        for p, (nd, nz) in enumerate(zip(nodes, noises)):
+            k = (repr(nd.to_tuple()), float(nz))
+            if k in keys:
+                assert cost[p] == 0.0 and owner[p] == owner[keys[k]]
+            else:
+                keys[k] = p; assert cost[p] > 0.0
+        assert np.isclose(rc.sum(), cost.sum()) and np.allclose(rc, [cost[owner == r].sum() for r in range(world)])
+        assert rc.max() <= 1.05 * rc.mean(), (world, rc)                      # imbalance <= 5 % by the cost model
+        block = np.array([cost[slice(*pkg.dist.shard_range(P, r, world))].sum() for r in range(world)])
+        assert block.max() >= 1.5 * block.mean()                               # ... where contiguous blocks are off by > 50 %
+    # the class is only cheap on a regular grid, in the sweeps that have a structured path
+    _, c_irr, _ = pkg.shard_plan(programs, noises, n, 2, sweep=1, regular_grid=False)
+    assert set(np.unique(c_irr)) == {0.0, 3.4}
+    _, c_val, rcv = pkg.shard_plan(programs, noises, n, 4, sweep=0, regular_grid=True)
+    assert set(np.unique(c_val)) == {0.0, 1.0}
+    n_distinct = int((c_val > 0).sum())
+    assert rcv.max() - rcv.min() <= 1.0 and rcv.sum() == n_distinct               # uniform cost: an even split of the DISTINCT particles
+    with pytest.raises(pkg.AGPError):
+        pkg.shard_plan(programs, noises, n, 0)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cost_aware_plan_allgather(tmp_path, world):
+    """gloo ranks evaluate the particles a cost-aware plan gives them (non-contiguous index sets, uneven counts, copies following
+    their representatives); the planned all-gather returns the population-order vector on every rank."""
+    P = 48
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    port = 30700 + (os.getpid() % 300) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "tests" / "_plan_worker.py"), str(tmp_path), str(P)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = [json.loads((tmp_path / f"plan_rank{k}.json").read_text()) for k in range(world)]
+    assert all(x["match"] for x in res), "planned all-gather differs from the unsharded evaluation"
+    assert all(x["owner"] == res[0]["owner"] for x in res)
+    rc = res[0]["rank_cost"]
+    assert max(rc) <= 1.05 * (sum(rc) / world), rc
+    assert max(res[0]["block_cost"]) > 1.2 * (sum(rc) / world)          # (contiguous blocks: the dense class sits at the front)
+    assert sum(x["n_mine"] for x in res) == P

@@ -41,3 +41,38 @@ def test_sizes_and_schedules_randomised(pkg):
     finally:
         eng.close()
     assert msg.startswith("fuzz ok"), msg
+
+
+def _native(name, *args):
+    """Run a native driver of the C ABI (tools/native/*.cpp, built by __graft_entry__.build()) and parse its JSON line."""
+    import json, os, subprocess
+    exe = ROOT / "tools" / "native" / name
+    assert exe.exists(), f"{exe} missing: __graft_entry__.build() compiles the native drivers"
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = str(ROOT / "autogp.jl_amd" / "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
+    pr = subprocess.run([str(exe)] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert pr.returncode == 0 and lines, (pr.returncode, pr.stdout[-500:], pr.stderr[-500:])
+    return json.loads(lines[-1])
+
+
+@pytest.mark.parametrize("entry", ["value", "grad"])
+def test_native_threads_driver(entry):
+    """The only non-Python users of the ABI: C++ threads calling agp_logpdf / agp_logpdf_grad one particle at a time, as
+    Threads.@threads does in the reference (src/inference_smc_anneal_data.jl:133,240) — SURVEY section 8(b) "Threading".  Pass: no API
+    error, and the coalesced single-particle results equal the batch entry's."""
+    r = _native("threads_bench", 640, 96, 3, *( ["g"] if entry == "grad" else []))
+    assert r["api_errors"] == 0 and r["calls"] == 96 * 3 and r["batches"] >= 1
+    assert r["max_rel_diff_vs_batch_entry"] <= 1e-10, r
+
+
+@pytest.mark.parametrize("points", ["irregular", "grid", "monthly"])
+def test_native_hmc_replay(points):
+    """Gen.hmc's call pattern (update -> choice_gradients pairs at new parameters, src/inference_smc_anneal_data.jl:63-67) from 64 C++
+    threads on irregular times, a shuffled regular grid and a shuffled monthly index.  Pass: no API error, no non-finite value at an
+    accepted (info == 0) evaluation, gradient calls start from the resident factor of the value call before them."""
+    r = _native("hmc_replay", 512, 64, 1, 10, 0.02, *([] if points == "irregular" else [points]))
+    assert r["api_errors"] == 0 and r["non_finite"] == 0, r
+    assert r["gradient_calls"] >= 64 * 2 and r["value_calls"] >= 64
+    assert r["gradient_particles_from_resident_factor"] >= 0.5 * r["value_calls"], r
+    assert (r["gradient_particles_in_lag_domain"] > 0) == (points == "grid"), r

@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
   std::vector<Particle> ps(T);
   for (auto& p : ps) { gen_tree(g, 2, p); p.noise = 0.05 + 0.3 * u(g); }
   std::vector<double> lp(T, 0.0);
-  std::atomic<int> bad{0};
+  std::atomic<int> bad{0}, api_errors{0};
   auto sweep = [&](int reps) {
     std::vector<std::thread> th;
     th.reserve(T);
@@ -65,6 +65,7 @@ int main(int argc, char** argv) {
                                                 p.noise, &lp[t], g, &gn, &info)
                               : agp_logpdf(ctx, n, p.ops.data(), (int32_t)p.ops.size(), p.prm.data(), (int32_t)p.prm.size(),
                                            p.noise, &lp[t], &info);
+          if (rc != 0) api_errors.fetch_add(1);
           if (rc != 0 || info != 0) bad.fetch_add(1);
         }
       });
@@ -88,9 +89,9 @@ int main(int argc, char** argv) {
   double maxd = 0.0;
   for (int t = 0; t < T; ++t) if (info[t] == 0) maxd = std::fmax(maxd, std::fabs(ref[t] - lp[t]) / std::fmax(1.0, std::fabs(ref[t])));
   printf("{\"entry\": \"%s\", \"n\": %d, \"threads\": %d, \"calls\": %lld, \"seconds\": %.4f, \"evals_per_s\": %.1f, \"batches\": %lld, "
-         "\"mean_batch\": %.1f, \"not_pd_or_failed\": %d, \"max_rel_diff_vs_batch_entry\": %.3g}\n",
+         "\"mean_batch\": %.1f, \"api_errors\": %d, \"not_pd_or_failed\": %d, \"max_rel_diff_vs_batch_entry\": %.3g}\n",
          grad ? "agp_logpdf_grad" : "agp_logpdf", n, T, (long long)(c1 - c0), dt, (double)T * iters / dt, (long long)(b1 - b0),
-         (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), bad.load(), maxd);
+         (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), api_errors.load(), bad.load(), maxd);
   agp_destroy(ctx);
-  return 0;
+  return api_errors.load() != 0 ? 2 : 0;
 }
