@@ -727,6 +727,7 @@ static int toeplitz_grad_sweep(agp_ctx* c, int64_t n, int32_t rank0, int P, cons
   HIPCHK(c, up.flush(s->h_stage, st));
   HIPCHK(c, hipMemsetAsync(s->dgrad.p, 0, sizeof(double) * (size_t)std::max(1, n_prm_total), st));
   HIPCHK(c, hipMemsetAsync(s->dgnoise.p, 0, sizeof(double) * (size_t)P, st));
+  HIPCHK(c, hipMemsetAsync(s->tretry.p, 0, sizeof(int32_t) * (size_t)P, st));      // (k_lag_grad receives it; the TSOL branch never writes it)
   const int stride = rank_units * 256;
   if (bt.n_lag_tables > 0) {
     HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * stride));
@@ -765,17 +766,24 @@ static int toeplitz_grad_sweep(agp_ctx* c, int64_t n, int32_t rank0, int P, cons
     launch_lag_grad(st, Pc, lds4, ga);
     HIPCHK(c, hipGetLastError());
   }
-  const size_t out_bytes = sizeof(double) * (size_t)P + sizeof(int32_t) * (size_t)P;
+  // every result lands in the slot's pinned zone [logpdf | noise gradients | parameter gradients | info] (an early return on a
+  // failed call never leaves a copy in flight towards a local or the caller's storage)
+  const size_t o_gn = sizeof(double) * (size_t)P, o_gr = o_gn + sizeof(double) * (size_t)P;
+  const size_t o_info = o_gr + sizeof(double) * (size_t)std::max(1, n_prm_total);
+  const size_t out_bytes = o_info + sizeof(int32_t) * (size_t)P;
   HIPCHK(c, s->h_out.ensure(out_bytes));
-  HIPCHK(c, hipMemcpyAsync(s->h_out.p, s->out_lp.p, out_bytes, hipMemcpyDeviceToHost, st));
-  if (n_prm_total > 0) HIPCHK(c, hipMemcpyAsync(out_grad, s->dgrad.p, sizeof(double) * (size_t)n_prm_total, hipMemcpyDeviceToHost, st));
-  std::vector<double> gn((size_t)P);
-  HIPCHK(c, hipMemcpyAsync(gn.data(), s->dgnoise.p, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, st));
+  char* ho = static_cast<char*>(s->h_out.p);
+  HIPCHK(c, hipMemcpyAsync(ho, s->out_lp.p, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(ho + o_info, s->out_lp.as<double>() + P, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(ho + o_gn, s->dgnoise.p, sizeof(double) * (size_t)P, hipMemcpyDeviceToHost, st));
+  if (n_prm_total > 0) HIPCHK(c, hipMemcpyAsync(ho + o_gr, s->dgrad.p, sizeof(double) * (size_t)n_prm_total, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
-  const double* hl = static_cast<const double*>(s->h_out.p);
-  const int32_t* hi = reinterpret_cast<const int32_t*>(hl + P);
+  const double* hl = reinterpret_cast<const double*>(ho);
+  const double* hgn = reinterpret_cast<const double*>(ho + o_gn);
+  const int32_t* hi = reinterpret_cast<const int32_t*>(ho + o_info);
   for (int q = 0; q < P; ++q) { out_lp[bt.order[q]] = hl[q]; out_info[bt.order[q]] = hi[q]; }
-  for (int b = 0; b < P; ++b) out_gnoise[b] = gn[(size_t)b];          // (k_lag_grad writes out_gnoise[pmap[p]]: the sub-batch's order)
+  for (int b = 0; b < P; ++b) out_gnoise[b] = hgn[b];          // (k_lag_grad writes out_gnoise[pmap[p]]: the sub-batch's order)
+  if (n_prm_total > 0) std::memcpy(out_grad, ho + o_gr, sizeof(double) * (size_t)n_prm_total);
   return AGP_OK;
 }
 
@@ -803,7 +811,9 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       h_out_lp && !d_user_lp && !d_user_info && !use_user_stream && !c->profiling) {
     std::vector<int> part[2];
     bool sane = true;
-    for (int p = 0; p < P && sane; ++p) sane = op_off[p + 1] >= op_off[p] && op_off[p + 1] - op_off[p] <= AGP_MAX_OPS_DEV;
+    // (malformed offsets are left to compile_batch's diagnosis on the plain path: the split below indexes with them)
+    for (int p = 0; p < P && sane; ++p)
+      sane = op_off[p] >= 0 && prm_off[p] >= 0 && op_off[p + 1] >= op_off[p] && prm_off[p + 1] >= prm_off[p] && op_off[p + 1] - op_off[p] <= AGP_MAX_OPS_DEV;
     if (sane)
       for (int p = 0; p < P; ++p) part[toeplitz_class(ops + op_off[p], op_off[p + 1] - op_off[p]) ? 1 : 0].push_back(p);
     // (worth it when the class's share of a dense sweep costs more than the n sequential steps of the recursion:

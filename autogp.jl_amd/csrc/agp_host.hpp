@@ -233,7 +233,7 @@ struct agp_ctx {
   struct FactorStore {
     std::mutex mu;                      // one extension sweep at a time
     int nt_cap = 0;                     // tile rows a slot can hold
-    int n_slots = 0;
+    std::atomic<int> n_slots{0};        // (read without the lock by the gates of the structured sweeps)
     long long strideA = 0;              // doubles per slot
     DevBuf A, W, vec, partial, info, ready, tflag, flowq;
     // L^-T of the resident factors, kept by the predictive passes that start from them (allocated on their first use): Z in A's layout,

@@ -195,6 +195,11 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
   // the store beside L (same layout) with the rows' running sums — the next pass on a longer prefix (the per-step callback of a
   // stream, scripts/online.jl:43) forms the new tile columns of Z only: nt^2/2 tile products instead of nt^3/6.
   bool zstore = false;
+  // (declared after store_lk: runs first, while the store's lock is still held)
+  struct ZGuard {
+    agp_ctx* c; const std::vector<int32_t>* slots; bool armed = false;
+    ~ZGuard() { if (armed) for (int32_t sl : *slots) if (sl >= 0 && (size_t)sl < c->store.zrows.size()) c->store.zrows[(size_t)sl] = 0; }
+  } zguard{c, &src_slot};
   std::vector<int32_t> zi0v;
   const int32_t* d_zi0 = nullptr;
   if (n_hit > 0 && diag_path) {
@@ -351,12 +356,16 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
         ga.zalpha = fs.zalpha.as<double>(); ga.zdinv = fs.zdinv.as<double>(); ga.zld = (long long)fs.nt_cap * NB;
         ga.zfull = (int)(n / NB);
       }
+      // (the kernel advances the slots' running sums on the device; their column counts are committed on the host only after the
+      // LAST chunk: any return in between must not leave sums that already include columns the host does not know of)
+      if (zstore) zguard.armed = true;
       launch_trtri_chain(st, 8 * ((Pc + 7) / 8) * nt1, ga);
       if (zstore && p0 + chunk >= P) {
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipStreamSynchronize(st));
         // (complete tile columns only: the column of a partly filled last tile is formed again on a longer prefix)
         for (int q = 0; q < P; ++q) if (src_slot[(size_t)q] >= 0) c->store.zrows[(size_t)src_slot[(size_t)q]] = (int32_t)(n / NB);
+        zguard.armed = false;
         store_lk.unlock();
       }
       HIPCHK(c, hipGetLastError());
@@ -424,8 +433,8 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
   {
     // always inspected: a caller that passes out_info = NULL must still never receive unmarked garbage
     std::vector<int32_t> info_sorted(P);
-    HIPCHK(c, hipMemcpyAsync(info_sorted.data(), s->info.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipMemcpy(info_sorted.data(), s->info.p, sizeof(int32_t) * P, hipMemcpyDeviceToHost));      // (blocking: nothing in flight towards the local on an error return)
     for (int q = 0; q < P; ++q) {
       if (info_sorted[q] < 0) return fail(c, AGP_ERR_HIP, "in-kernel panel solve timed out waiting for its diagonal factor");
       const int p = bt.order[q];
@@ -666,6 +675,9 @@ static int predict_batch_body(agp_ctx* c, int64_t n, const double* ts_pred, int6
       for (int64_t j = 0; j < m && ok; ++j) {
         const int32_t r = plq.rank[(size_t)n1_pad + j];
         if (r < lo) { ok = false; break; }          // (a point before the series: the dense path)
+        // (observed = the SAME time value, as the reference's WhiteNoise t1 == t2, src/GP.jl:135, and the dense path's split_queries: a
+        // query a few ulp off a training time is a lattice point by the tolerance but not that observation -> dense path)
+        if (r <= hi && ts_pred[j] != c->h_ts[(size_t)at[(size_t)(r - lo)]]) { ok = false; break; }
         if (r <= hi) { const int32_t i = at[(size_t)(r - lo)]; qkind[(size_t)j] = r - lo; xq[(size_t)j] = c->h_xs[(size_t)i] - (mean_train ? mean_train[i] : 0.0); }
         else { const int f = r - hi - 1; qkind[(size_t)j] = -1 - f; mF = std::max(mF, f + 1); }
       }

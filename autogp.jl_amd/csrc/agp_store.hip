@@ -49,7 +49,7 @@ int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
   STORECHK(info.ensure(sizeof(int) * (size_t)n_slots));
   STORECHK(ready.ensure(sizeof(int) * (size_t)n_slots));
   STORECHK(hipMemset(info.p, 0, sizeof(int) * (size_t)n_slots));
-  const int keep = std::min(n_slots, fs.n_slots), nto = std::min(nt_cap, fs.nt_cap);
+  const int keep = std::min(n_slots, fs.n_slots.load()), nto = std::min(nt_cap, fs.nt_cap);
   if (keep > 0 && nto > 0) {
     // strided copy by a small kernel (row = slot): the per-slot stride is ~1 GiB at n = 16k and passes 2 GiB from n ~ 23k —
     // pitches hipMemcpy2D may refuse
@@ -158,7 +158,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     // capacity: slots sized for the resident data, at least as many as this population (twice, so that a population
     // mid-rejuvenation keeps its previous states), within the store's share of device memory
     const int want_nt = std::max(fs.nt_cap, std::max(nt, round_up(c->n_max, NB) / NB));
-    int want_slots = std::max(fs.n_slots, std::max(2 * U, 32));
+    int want_slots = std::max(fs.n_slots.load(), std::max(2 * U, 32));
     if (want_slots > fs.n_slots && fs.n_slots > 0) want_slots = std::max(want_slots, fs.n_slots + fs.n_slots / 2);   // (growth copies the store: few, larger steps)
     const size_t budget = (size_t)(fs.max_frac * (double)c->total_mem);
     const size_t per = store_bytes_per_slot(want_nt);
@@ -507,7 +507,7 @@ int agp_extend_reserve(agp_ctx* c, int64_t n_cap, int32_t n_slots) {
   HIPCHK(c, hipSetDevice(c->device));
   std::lock_guard<std::mutex> g(c->store.mu);
   const int nt_cap = std::max(c->store.nt_cap, round_up(std::max<int64_t>(n_cap, 1), NB) / NB);
-  const int slots = std::max(c->store.n_slots, (int)n_slots);
+  const int slots = std::max(c->store.n_slots.load(), (int)n_slots);
   if ((size_t)slots * store_bytes_per_slot(nt_cap) > (size_t)(c->store.max_frac * (double)c->total_mem))
     return fail(c, AGP_ERR_ARG, "reservation exceeds the store's share of device memory");
   HIPCHK(c, hipDeviceSynchronize());

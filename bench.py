@@ -836,6 +836,20 @@ def main():
         }
         if diag_block:
             out["roofline_diag_kernel"] = diag_block
+        try:
+            # per-rank cost (units of one dense factorisation, agp_shard_plan's model): the timed value sweep is uniform per distinct
+            # particle, so it keeps the contiguous blocks; a gradient sweep of the same population would not be
+            prog_all = pkg.encode_batch(nodes_all)
+            _, c_val, _ = pkg.shard_plan(prog_all, noises_all, n, world, sweep=0, regular_grid=True)
+            _, c_grad, rc_grad = pkg.shard_plan(prog_all, noises_all, n, world, sweep=1, regular_grid=True)
+            blocks = [pkg.shard_range(P_total, r, world) for r in range(world)]
+            out["config"]["per_rank_cost_model"] = {
+                "unit": "dense factorisations (n^3/3 flops)",
+                "value_sweep_block_split": [float(c_val[a:b].sum()) for a, b in blocks],
+                "gradient_sweep_block_split": [float(c_grad[a:b].sum()) for a, b in blocks],
+                "gradient_sweep_cost_aware_plan": [float(x) for x in rc_grad]}
+        except Exception as e:      # noqa: BLE001
+            out["config"]["per_rank_cost_model"] = {"error": str(e)[:200]}
         out["config"]["regular_grid_lag_tables"] = eng.lag_stats()[0] and eng.lag_stats()[1] > 0
         if world == 1 and not args.no_extra_legs:
             out.update(extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, local_rank))

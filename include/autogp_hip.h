@@ -153,8 +153,9 @@ int agp_set_factor_cache(agp_ctx* ctx, int32_t on);
  * evaluated inside the factorisation kernels whatever the kernel tree's size.  Results agree with the general path to
  * rounding (the table's representative t_i - t_j differs from an element's own by a few ulp of t).  Prefix sweeps
  * (n < n_max: a subset of a shuffled grid is not a grid), gradient sweeps and the factor store's sweeps use rank tables instead
- * (below), predictive passes on lattice query points too; irregular series take the general path.  AGP_LAG=0 / agp_set_lag_tables(ctx, 0) disable it (the switch is read at
- * the next agp_set_data).  agp_get_lag_stats: whether the resident series qualifies, and how many sweeps took the path. */
+ * (below), predictive passes on lattice query points too; irregular series take the general path.  AGP_LAG=0 / agp_set_lag_tables(ctx, 0) disable it.  Of
+ * agp_set_lag_tables, the admission part (0 / non-zero) is read at the next agp_set_data; the sweeps also test the switch, so 0
+ * takes effect at once, and the levels 2 / 3 (structured value sweep, below) apply from the next sweep.  agp_get_lag_stats: whether the resident series qualifies, and how many sweeps took the path. */
 int agp_get_lag_stats(agp_ctx* ctx, int32_t* regular_grid, int64_t* n_lag_sweeps);
 int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
 
@@ -225,8 +226,9 @@ int agp_get_lag_rank_stats(agp_ctx* ctx, int64_t* n_sweeps);
  * the calls that took it. */
 int agp_get_lag_predict_stats(agp_ctx* ctx, int64_t* n_passes);
 /* ... and where, in addition, the n training points are consecutive grid points (256 <= n <= 2048), every query point is one of them
- * or a grid point after them (n + future points <= 4096), no covariance is requested and nothing is resident in
- * the factor store, the particles whose kernel is a sum of stationary subtrees and Linear leaves (at least 32 of them) need no dense
+ * or a grid point after them (n + future points <= 4096), no covariance is requested and either nothing is resident in the
+ * factor store or n >= 768 (from there on the two sequential passes of the recursion are cheaper than starting from resident
+ * factors), the particles whose kernel is a sum of stationary subtrees and Linear leaves (at least 32 of them) need no dense
  * factor: one Schur recursion over the JOINT grid leaves L21 L11^-1 [x, 1, t] and the diagonal of T22 - T21 T11^-1 T12 per future
  * point, a backward substitution T11^-1 [x, e_first, 1, t]; predictions at training points come from alpha and diag(K11^-1)
  * (Gohberg-Semencul), the Linear leaves enter as a Bayesian linear model in [1, t] (Woodbury, update direction).  The other
