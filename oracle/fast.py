@@ -221,3 +221,79 @@ def gp_logpdf_many(programs, noises, ts, xs, threads=None, indices=None):
         return np.array([r[0] for r in res]), np.array([r[1] for r in res], dtype=np.int32)
     with OraclePool(programs, noises, ts, xs, workers) as pool:
         return pool.evaluate(idx)
+
+
+# ---- marginal predictive distribution at full size (src/GP.jl:739-757 restated for one particle: joint kernel matrix on
+# [ts; ts_pred] with zero noise, K11 + noise I, mean = K21 K11^-1 x, var_j = K22_jj - k_j' K11^-1 k_j + noise_pred).  The C assembly
+# fills the joint lower triangle; K11^-1 is applied through LAPACK's Cholesky factor (the reference's `K11 \ .` is an LU solve:
+# oracle.predict_mvn keeps that form for the small cases and pins this one in tests/test_oracle.py) ----
+def predict_marginal_program(ops, prm, noise, ts, xs, ts_pred, noise_pred=None):
+    """(mean[m], var[m], info) of one particle; info = dpotrf's on K11."""
+    ops = np.ascontiguousarray(ops, dtype=np.uint8)
+    prm = np.ascontiguousarray(prm if len(prm) else [0.0], dtype=np.float64)
+    tj = np.ascontiguousarray(np.concatenate([ts, ts_pred]), dtype=np.float64)
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    n, m = len(ts), len(ts_pred)
+    K = np.empty((n + m, n + m), dtype=np.float64, order="F")
+    _lib().agp_oracle_cov_lower(ops.ctypes.data, int(ops.shape[0]), prm.ctypes.data, 0.0, tj.ctypes.data, n + m, K.ctypes.data)
+    K11 = np.asfortranarray(K[:n, :n])
+    K11[np.diag_indices(n)] += float(noise)
+    k22 = np.diagonal(K)[n:].copy()
+    K12 = np.asfortranarray(K[n:, :n].T)                      # (the joint lower triangle holds K21)
+    L, info = lapack.dpotrf(K11, lower=1, clean=0, overwrite_a=1)
+    if info != 0:
+        return np.full(m, np.nan), np.full(m, np.nan), int(info)
+    beta, _ = lapack.dtrtrs(L, xs, lower=1, trans=0, unitdiag=0)
+    V, _ = lapack.dtrtrs(L, K12, lower=1, trans=0, unitdiag=0, overwrite_b=1)
+    mean = V.T @ beta
+    var = k22 - np.einsum("ij,ij->j", V, V) + float(noise if noise_pred is None else noise_pred)
+    return mean, var, 0
+
+
+def _predict_worker(npz_in, npz_out):
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(1)
+    except Exception:
+        pass
+    z = np.load(npz_in)
+    op_off, ops, prm_off, prm = z["op_off"], z["ops"], z["prm_off"], z["prm"]
+    idx = z["indices"]
+    m = len(z["tq"])
+    mean = np.empty((len(idx), m)); var = np.empty((len(idx), m)); info = np.zeros(len(idx), dtype=np.int32)
+    for k, i in enumerate(idx):
+        mean[k], var[k], info[k] = predict_marginal_program(ops[op_off[i]:op_off[i + 1]], prm[prm_off[i]:prm_off[i + 1]], float(z["noises"][i]),
+                                                            z["ts"], z["xs"], z["tq"])
+    np.savez(npz_out, mean=mean, var=var, info=info)
+
+
+def predict_marginal_many(programs, noises, ts, xs, ts_pred, indices, workers=None):
+    """(mean[k, m], var[k, m], info[k]) for the particles `indices`, one subprocess per slice of them (single-threaded BLAS each)."""
+    import subprocess
+    import sys
+    import tempfile
+    indices = np.asarray(list(indices), dtype=np.int64)
+    _lib()
+    W = max(1, min(len(indices), workers or host_cores()))
+    op_off, ops, prm_off, prm = programs
+    tmp = tempfile.mkdtemp(prefix="agp_oracle_pred_")
+    procs = []
+    for w in range(W):
+        sl = indices[w::W]
+        fin, fout = os.path.join(tmp, f"in{w}.npz"), os.path.join(tmp, f"out{w}.npz")
+        np.savez(fin, op_off=op_off, ops=ops, prm_off=prm_off, prm=prm if len(prm) else np.zeros(1), noises=np.asarray(noises, dtype=np.float64),
+                 ts=ts, xs=xs, tq=ts_pred, indices=sl)
+        code = f"import sys; sys.path.insert(0, {str(_HERE.parent)!r}); from oracle import fast; fast._predict_worker({fin!r}, {fout!r})"
+        procs.append((sl, fout, subprocess.Popen([sys.executable, "-c", code])))
+    m = len(ts_pred)
+    mean = np.empty((len(indices), m)); var = np.empty((len(indices), m)); info = np.zeros(len(indices), dtype=np.int32)
+    pos = {int(i): k for k, i in enumerate(indices)}
+    for sl, fout, pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError("oracle predictive worker failed")
+        z = np.load(fout)
+        for k, i in enumerate(sl):
+            mean[pos[int(i)]] = z["mean"][k]; var[pos[int(i)]] = z["var"][k]; info[pos[int(i)]] = z["info"][k]
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return mean, var, info

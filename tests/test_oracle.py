@@ -321,3 +321,18 @@ def test_oracle_against_scikit_learn():
     gpr = GaussianProcessRegressor(kernel=kern, alpha=0.0, optimizer=None).fit((ts - c)[:, None], xs)
     ref = O.gp_logpdf(tree, noise, ts, xs)
     assert abs(gpr.log_marginal_likelihood() - ref) <= 1e-9 * max(1.0, abs(ref))
+
+
+def test_fast_predictive_restatement_matches_oracle(pkg):
+    """oracle/fast.py: predict_marginal_many (C assembly of the joint matrix + LAPACK Cholesky on worker processes: the full-size
+    predictive checks of the GPU suite) against oracle.predict_mvn (the LU form of src/GP.jl:753-754) on small cases."""
+    from oracle import fast as F
+    ts, xs = pkg.prior.synthetic_series(150, seed=3, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(1), 6, max_depth=3)
+    tq = np.concatenate([ts[:40], np.linspace(1.0, 1.3, 30), [ts[7] + 1e-9]])
+    m, v, info = F.predict_marginal_many(pkg.encode_batch(nodes), noises, ts, xs, tq, range(6), workers=3)
+    for k in range(6):
+        mu, cv = O.predict_mvn(nodes[k].to_tuple(), float(noises[k]), ts, xs, tq)
+        assert info[k] == 0
+        assert np.abs(m[k] - mu).max() <= 1e-12 * max(1.0, np.abs(mu).max())
+        assert np.abs(v[k] - np.diag(cv)).max() <= 1e-12 * max(1.0, np.abs(cv).max())

@@ -106,7 +106,11 @@ def _run(pkg, eng, ref, cases=40, seed=1):
                 ed = max(np.abs(g0[1][q] - go).max() if go.size else 0.0, abs(g0[2][q] - gno)) / sc
                 print(f"  case {c} N={N} n={n} particle {j} (noise {noises[j]:.3g}, {nodes[j]}): gradient structured vs element-wise {e:.2e}; vs oracle: structured {es:.2e}, element-wise {ed:.2e}; scale {sc:.3g}", flush=True)
             assert abs(g1[0][q] - g0[0][q]) <= 1e-8 * max(1.0, abs(g0[0][q])), ("gradient value", c, N, n, P, q)
-            assert e <= 2e-6, ("gradient", c, N, n, P, q, e)
+            # north_star's gradient bound: 1e-7 of the gradient's scale.  Above it the oracle arbitrates: the structured sweep may be
+            # no further from it than 1e-7, or than 4x the element-wise sweep's own distance (Periodic kernels with periods near 0.02 —
+            # hundreds of oscillations over the series, gradient scales of 1e4 — where both sweeps and the oracle keep 1e-6: DESIGN.md section 6)
+            if e > 1e-7:
+                assert es <= max(1e-7, 4.0 * ed), ("gradient", c, N, n, P, q, e, es, ed)
         # ---- predictive pass: training points and the grid's continuation ----
         if n <= 2048:
             order = np.argsort(ts[:n], kind="stable")
@@ -124,8 +128,8 @@ def _run(pkg, eng, ref, cases=40, seed=1):
                 sc = np.maximum(1.0, np.maximum(np.abs(pm0[okp]).max(axis=1), np.abs(pv0[okp]).max(axis=1)))[:, None]
                 ep = np.maximum((np.abs(pm1 - pm0)[okp] / sc).max(axis=1), (np.abs(pv1 - pv0)[okp] / sc).max(axis=1))
                 e = ep.max(); w_pred = max(w_pred, e)
-                if e > 1e-7:
-                    # the two double-precision passes disagree: an 80-bit factorisation says which one lost the digits
+                if e > 1e-8:
+                    # the two double-precision passes disagree beyond north_star's 1e-8: an 80-bit factorisation says which one lost the digits
                     j = int(np.flatnonzero(okp)[int(np.argmax(ep))])
                     ml, vl = predict_longdouble(nodes[j].to_tuple(), float(noises[j]), ts[:n], xs[:n], tp)
                     scj = max(1.0, np.abs(ml).max(), np.abs(vl).max())
@@ -133,16 +137,16 @@ def _run(pkg, eng, ref, cases=40, seed=1):
                     ed = max(np.abs(pm0[j] - ml).max(), np.abs(pv0[j] - vl).max()) / scj
                     print(f"  case {c} particle {j} (noise {noises[j]:.3g}, {nodes[j]}): structured vs dense {e:.2e}; vs 80-bit: structured {es:.2e}, dense {ed:.2e}", flush=True)
                     n_dis += 1
-                    assert es <= max(1e-7, (30.0 if hard[j] else 4.0) * ed), ("predict", c, N, n, P, j, e, es, ed)
+                    assert es <= max(1e-7 if hard[j] else 1e-8, (30.0 if hard[j] else 4.0) * ed), ("predict", c, N, n, P, j, e, es, ed)
             if c % 4 == 0 and okp.any() and n <= 1024:
                 j = int(np.flatnonzero(okp)[0])
                 mo, co = O.predict_mvn(nodes[j].to_tuple(), float(noises[j]), ts[:n], xs[:n], tp)
                 sc = max(1.0, np.abs(mo).max(), np.abs(np.diag(co)).max())
                 e = max(np.abs(pm1[j] - mo).max(), np.abs(pv1[j] - np.diag(co)).max()) / sc; w_or = max(w_or, e)
-                assert e <= 1e-7, ("predict vs oracle", c, N, n, P, j, e)
+                assert e <= (1e-7 if hard[j] else 1e-8), ("predict vs oracle", c, N, n, P, j, e)
         print(f"case {c}: N={N} n={n} P={P} ok  ({time.time()-t0:.0f}s)", flush=True)
     return (f"structured fuzz ok: {cases} cases; structured particles value {n_sv} / gradient {n_sg} / predictive {n_sp}; worst rel diff vs dense "
-            f"value {w_val:.2e}, gradient {w_grad:.2e}, predictive {w_pred:.2e}; predictive vs oracle {w_or:.2e}; predictive disagreements above 1e-7 settled by 80-bit arithmetic {n_dis}; not-PD particles {n_bad}; near-singular particles {n_hard} ({n_hard_bad} refused); {time.time()-t0:.0f}s")
+            f"value {w_val:.2e}, gradient {w_grad:.2e}, predictive {w_pred:.2e}; predictive vs oracle {w_or:.2e}; predictive disagreements above 1e-8 settled by 80-bit arithmetic {n_dis}; not-PD particles {n_bad}; near-singular particles {n_hard} ({n_hard_bad} refused); {time.time()-t0:.0f}s")
 
 
 def run(pkg, cases=40, seed=1):
