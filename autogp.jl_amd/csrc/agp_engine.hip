@@ -789,6 +789,17 @@ static int toeplitz_grad_sweep(agp_ctx* c, int64_t n, int32_t rank0, int P, cons
 
 static thread_local bool tl_in_toeplitz = false;
 static thread_local bool tl_in_tgrad = false;
+// Class-aware value sweeps of the coalesced single-particle entry (run_coalesced, opt-in level AGP_LAG >= 2): the dense part of the
+// batch goes through the factor store (extend_impl) instead of a plain sweep, so that the gradient call that follows at the same
+// parameters — Gen.hmc's update -> choice_gradients pair, src/inference_smc_anneal_data.jl:63-67 — finds those factors resident,
+// while the Toeplitz class never enters the store (value from the Schur recursion, gradient from the structured sweep).
+static thread_local bool tl_dense_via_store = false;
+struct TlClear {          // a thread-local switch cleared for a scope (the store's own fallbacks must run plain sweeps)
+  bool& f; bool was;
+  explicit TlClear(bool& f_) : f(f_), was(f_) { f = false; }
+  ~TlClear() { f = was; }
+  TlClear(const TlClear&) = delete; TlClear& operator=(const TlClear&) = delete;
+};
 
 // (set around the repeat of particles whose Toeplitz downdate was rejected: the nested sweep takes L^-T for them)
 static thread_local bool tl_no_toep = false;
@@ -819,7 +830,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     // (worth it when the class's share of a dense sweep costs more than the n sequential steps of the recursion:
     // ~50 us per particle at n = 2048 against ~0.7 us per step + ~0.4 ms of sub-batch overheads; level 3 forces it)
     const double dense_us = 50.0 * (double)part[1].size() * std::pow((double)n / 2048.0, 3.0), schur_us = 0.7 * (double)n + 400.0;
-    if (sane && !part[1].empty() && (c->toeplitz >= 2 || dense_us > 1.5 * schur_us)) {
+    // (the coalesced entry's class-aware mode: a class particle scored here stays out of the store, so the gradient call that follows
+    // must take the structured sweep too — the same test as there, or the class would be factored densely by the gradient sweep:
+    // measured with 128 threads, 106 class particles: 294 -> 262 HMC iterations/s with the value sweep's own, lower threshold)
+    const bool pays = tl_dense_via_store ? dense_us > 1.5 * 2.2 * (double)n : dense_us > 1.5 * schur_us;
+    if (sane && !part[1].empty() && (c->toeplitz >= 2 || pays)) {
       auto gather = [&](const std::vector<int>& ix, std::vector<int32_t>& oo, std::vector<uint8_t>& so, std::vector<int32_t>& po,
                         std::vector<double>& sp, std::vector<double>& nz) {
         oo.assign(ix.size() + 1, 0); po.assign(ix.size() + 1, 0); nz.resize(ix.size()); so.clear(); sp.clear();
@@ -832,6 +847,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         if (sp.empty()) sp.push_back(0.0);
       };
       // the two sub-sweeps (own slots and streams)
+      const bool via_store = tl_dense_via_store;          // (read here: the structured half may run on a helper thread)
       struct Sub { std::vector<int32_t> oo, po, info; std::vector<uint8_t> so; std::vector<double> sp, nz, lp; int rc = 0; } sT, sD;
       gather(part[1], sT.oo, sT.so, sT.po, sT.sp, sT.nz);
       sT.lp.resize(part[1].size()); sT.info.assign(part[1].size(), 0);
@@ -849,8 +865,14 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         gather(ix, sD.oo, sD.so, sD.po, sD.sp, sD.nz);
         sD.lp.resize(ix.size()); sD.info.assign(ix.size(), 0);
         TlFlag nested(tl_in_toeplitz);
-        const int rc0 = logpdf_batch_impl(c, n, (int)ix.size(), sD.oo.data(), sD.so.data(), sD.po.data(), sD.sp.data(), sD.nz.data(), sD.lp.data(),
-                                          sD.info.data(), nullptr, nullptr, nullptr, false, nullptr, allow_lag);
+        int rc0;
+        if (via_store) {
+          TlClear plain(tl_dense_via_store);
+          rc0 = extend_impl(c, n, (int)ix.size(), sD.oo.data(), sD.so.data(), sD.po.data(), sD.sp.data(), sD.nz.data(), sD.lp.data(), sD.info.data());
+        } else {
+          rc0 = logpdf_batch_impl(c, n, (int)ix.size(), sD.oo.data(), sD.so.data(), sD.po.data(), sD.sp.data(), sD.nz.data(), sD.lp.data(),
+                                  sD.info.data(), nullptr, nullptr, nullptr, false, nullptr, allow_lag);
+        }
         if (rc0) return rc0;
         for (size_t b2 = 0; b2 < ix.size(); ++b2) { h_out_lp[ix[b2]] = sD.lp[b2]; if (h_out_info) h_out_info[ix[b2]] = sD.info[b2]; }
         return 0;
@@ -872,6 +894,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     }
   }
 
+  if (tl_dense_via_store && !go && h_out_lp && h_out_info) {
+    // (no structured split for this batch: the whole of it goes through the store, as the coalesced entry does by default)
+    TlClear plain(tl_dense_via_store);
+    return extend_impl(c, n, P, op_off, ops, prm_off, prm, noise, h_out_lp, h_out_info);
+  }
   Batch bt;
   std::vector<std::vector<int32_t>> pls;     // per-group particle orders of the gradient contraction
   pls.reserve(64);
@@ -946,11 +973,28 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     // Structured gradient sweep: with no factor resident anywhere, the Toeplitz class needs no dense factorisation at all
     // (toeplitz_grad_sweep: Schur recursion + backward substitution + k_lag_grad); it runs beside the dense sweep of the others.
     // (it pays when the class's share of the dense factorisation costs more than the ~2.2 us per point of the two sequential passes)
-    const bool struct_pays = c->grad_struct >= 2 || 50.0 * (double)n_sum * std::pow((double)n / 2048.0, 3.0) > 1.5 * 2.2 * (double)n;
-    if (use_toep && n_sum > 0 && struct_pays && n <= 2048 && !tl_in_tgrad && !tl_no_toep && !c->profiling && c->grad_struct &&
-        h_out_lp && !d_user_lp && !d_user_info && !use_user_stream && !(c->factor_cache && c->store.n_slots > 0)) {
+    // With factors resident the sweep normally starts from them (Gen.hmc's update -> choice_gradients pair).  At the opt-in level
+    // AGP_LAG >= 2 the coalesced value calls keep the Toeplitz class OUT of the store (run_coalesced: Schur recursion), so here the
+    // class particles that are not resident take the structured sweep and only the others start from their resident factors:
+    // per leapfrog no particle is factored twice, and the class is never factored densely at all.
+    const bool store_live = c->factor_cache && c->store.n_slots > 0;
+    std::vector<char> resident((size_t)P, 0);          // (sorted position) the store holds this particle's factor for exactly this prefix
+    int64_t n_struct = n_sum;
+    if (store_live && c->toeplitz && use_toep && n_sum > 0) {
+      std::lock_guard<std::mutex> g(c->store.mu);
+      agp_ctx::FactorStore& fs = c->store;
+      for (int q = 0; q < P; ++q) {
+        if (!(bt.ghdr[q].flags & GFLAG_LAGTOEP)) continue;
+        const int p = bt.order[q];
+        auto it = fs.index.find(particle_key(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p], prm_off[p + 1] - prm_off[p], noise[p]));
+        if (it != fs.index.end() && fs.n_cached[(size_t)it->second] == n && fs.info_h[(size_t)it->second] == 0) { resident[(size_t)q] = 1; --n_struct; }
+      }
+    }
+    const bool struct_pays = c->grad_struct >= 2 || 50.0 * (double)n_struct * std::pow((double)n / 2048.0, 3.0) > 1.5 * 2.2 * (double)n;
+    if (use_toep && n_struct > 0 && struct_pays && n <= 2048 && !tl_in_tgrad && !tl_no_toep && !c->profiling && c->grad_struct &&
+        h_out_lp && !d_user_lp && !d_user_info && !use_user_stream && (!store_live || c->toeplitz)) {
       std::vector<int> part[2];
-      for (int q = 0; q < P; ++q) part[(bt.ghdr[q].flags & GFLAG_LAGTOEP) ? 1 : 0].push_back(bt.order[q]);
+      for (int q = 0; q < P; ++q) part[((bt.ghdr[q].flags & GFLAG_LAGTOEP) && !resident[(size_t)q]) ? 1 : 0].push_back(bt.order[q]);
       struct Sub { std::vector<int32_t> oo, po, info; std::vector<uint8_t> so; std::vector<double> sp, nz, lp, grad, gn; int rc = 0; } sT, sD;
       auto gather = [&](const std::vector<int>& ix, Sub& S) {
         S.oo.assign(ix.size() + 1, 0); S.po.assign(ix.size() + 1, 0); S.nz.resize(ix.size()); S.so.clear(); S.sp.clear();
@@ -2037,6 +2081,13 @@ static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
     if (want_grad) return agp_logpdf_grad_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_g, out_gn, out_info);
     // value calls go through the factor store: the reweight on a longer prefix becomes an extension sweep, the gradient
     // call that follows at the same parameters (HMC leapfrog) and a predictive call find the factor resident
+    if (c->factor_cache && c->toeplitz && c->lag_enable && c->lag_ok && c->lag_contig && n == c->n_max && n <= 4096) {
+      // opt-in (AGP_LAG >= 2): class-aware value sweep — Toeplitz-class particles from the Schur recursion, the others through the store
+      return abi_guard(c, [&] {
+        TlFlag via_store(tl_dense_via_store);
+        return logpdf_batch_impl(c, n, Pn, oo, o, po, q, nz, out_lp, out_info, nullptr, nullptr, nullptr, false);
+      });
+    }
     return c->factor_cache ? extend_impl(c, n, Pn, oo, o, po, q, nz, out_lp, out_info)
                                           : agp_logpdf_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_info);
   };

@@ -190,6 +190,19 @@ end
 set_factor_cache!(eng::Engine, on::Bool) =
     check(eng, ccall((:agp_set_factor_cache, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
 
+"Pre-size the factor store for `n_particles` particles of series of up to `n_cap` points (twice the population: a particle
+mid-rejuvenation keeps its previous state).  Call once per fit, after `set_data!`: the single-particle entries are coalesced into
+batches of whatever size the threads' arrival times give, and a store sized for those batches alone would evict a large
+population's factors between Gen.hmc's `update` and `choice_gradients` (src/inference_smc_anneal_data.jl:63-67)."
+reserve_store!(eng::Engine, n_cap::Integer, n_particles::Integer) =
+    check(eng, ccall((:agp_extend_reserve, LIB), Cint, (Ptr{Cvoid}, Int64, Int32), eng.ptr, n_cap, 2 * n_particles))
+
+"Opt-in structured arithmetic on regular time grids (`agp_set_lag_tables` level 2): particles whose kernel is a sum of stationary
+subtrees and Linear leaves are scored by the Schur recursion and differentiated by the structured sweep — also through the
+single-particle entries that Gen drives — instead of the dense Cholesky; the others keep the dense path and the factor store."
+set_structured_sweeps!(eng::Engine, on::Bool) =
+    check(eng, ccall((:agp_set_lag_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 2 : 1))
+
 "The whole population over every GPU of the pool: shards by agp_shard_range, one sweep per device, log-weights
 all-gathered over RCCL inside the library (agp_logpdf_batch_multi)."
 function logpdf_batch(pool::EnginePool, nodes::Vector{<:GP.Node}, noises::Vector{Float64}, n::Integer=pool.engines[1].n_max; extend::Bool=false)

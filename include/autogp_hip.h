@@ -117,8 +117,10 @@ int agp_logpdf_batch_extend(agp_ctx* ctx, int64_t n, int32_t P,
 int agp_extend_stats(agp_ctx* ctx, int64_t* out4);
 /* forget every resident factor (release_memory != 0 also frees the store) */
 int agp_extend_reset(agp_ctx* ctx, int release_memory);
-/* pre-size the store for series of up to n_cap observations and n_slots particles (optional: it grows on demand,
- * keeping its contents) */
+/* pre-size the store for series of up to n_cap observations and n_slots particles.  Optional for batch callers (the store grows
+ * on demand to twice the largest batch, keeping its contents).  RECOMMENDED for the single-particle entries: agp_logpdf calls are
+ * coalesced into batches of whatever size the callers' arrival times give, so a population larger than twice those batches would
+ * evict its own factors between the value and the gradient call — reserve 2 x num_particles slots (the shim does). */
 int agp_extend_reserve(agp_ctx* ctx, int64_t n_cap, int32_t n_slots);
 /* The predictive entries consult the same store: a particle whose factor of exactly the prefix n is resident (the
  * per-step callback of the streaming workload predicts right after the reweight: scripts/online.jl:43,59 ->
@@ -203,7 +205,16 @@ int agp_set_reference_arithmetic(agp_ctx* ctx, int32_t on);
  * always).  Agreement with the dense path: <= 1e-10 of |logpdf| (tests/test_gpu_lag.py) for noises the reference can produce
  * (>= JITTER = 1e-5, src/Model.jl:22,134: <= 1e-9 in randomised runs with noises down to 1e-5); the Schur recursion is weakly stable —
  * on matrices with conditioning beyond 1e12 (noise 1e-12) where the dense factorisation itself keeps only 2-3 digits it keeps one
- * fewer.  agp_get_toeplitz_stats counts the particles scored that way. */
+ * fewer.  agp_get_toeplitz_stats counts the particles scored that way.
+ * The same level also makes the COALESCED single-particle entries class-aware (what Gen drives: every leapfrog step of Gen.hmc is
+ * `update`, a value call, then `choice_gradients` at the same parameters, src/inference_smc_anneal_data.jl:63-67).  A coalesced
+ * batch of agp_logpdf calls over the whole series scores its Toeplitz-class particles by the recursion and keeps them OUT of the
+ * factor store; the others go through the store as before.  The agp_logpdf_grad batch that follows differentiates the class
+ * particles that are not resident by the structured gradient sweep (Schur recursion + backward substitution, no dense factor) and
+ * the others from their resident factors: per leapfrog no particle is factored twice, and the class never densely.  Both calls
+ * apply the same size test (the class's share of the dense work against the two sequential passes of the structured gradient),
+ * so a class too small to pay stays on the dense + store route in both.  Measured (tools/native/hmc_replay, n = 2048, regular
+ * grid): 512 threads 402 -> 535 HMC iterations/s, 192 threads 343 -> 402, 64 / 128 threads unchanged (class below the size test). */
 int agp_get_toeplitz_stats(agp_ctx* ctx, int64_t* n_particles);
 
 /* Every OTHER sweep of agp_logpdf_batch{,_device,_multi} / agp_logpdf_grad_batch over (a prefix of) a regular grid of up to 4096

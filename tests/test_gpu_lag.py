@@ -803,3 +803,67 @@ def test_gradient_polynomial_class_above_2048_points(pkg, n_max):
             assert np.abs(g[i] - g2[i]).max() <= 1e-7 * sc and abs(gn[i] - gn2[i]) <= 1e-7 * sc, (n_max, i)
     finally:
         a.close(); b.close()
+
+
+def test_class_aware_leapfrog_pairs(pkg, monkeypatch):
+    """Opt-in level AGP_LAG = 2 on the coalesced single-particle entries (Gen.hmc's update -> choice_gradients pairs,
+    src/inference_smc_anneal_data.jl:63-67): value calls score the Toeplitz class by the Schur recursion and keep it OUT of the factor
+    store, the others go through the store; the gradient calls that follow differentiate the class by the structured sweep and the
+    others from their resident factors — no particle is factored twice, none of the class densely.  Results against the default
+    engine (value 1e-10 of |logpdf|, gradient 1e-7 of its scale) and the oracle."""
+    import threading
+    from oracle import oracle as O
+    n, T = 512, 160
+    ts, xs = pkg.prior.synthetic_series(n, seed=77, shuffle=True)
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(12), T, max_depth=3, max_size=15)
+    cls = np.array([pkg.shard_plan(pkg.encode_batch([nd]), [z], n, 1, sweep=1, regular_grid=True)[1][0] < 3.0 for nd, z in zip(nodes, noises)])
+    assert 0.5 * T <= cls.sum() < T
+    ref = pkg.GPEngine(0)
+    monkeypatch.setenv("AGP_GRAD_FFT", "4")      # structured gradient sweeps whatever the class's size ...
+    eng = pkg.GPEngine(0)
+    monkeypatch.delenv("AGP_GRAD_FFT")
+    try:
+        ref.set_data(ts, xs)
+        r_lp, r_g, r_gn, r_info = ref.logpdf_grad_batch(nodes, noises, check=False)
+        eng.set_lag_tables(3)                    # ... and level 3 = level 2 whatever it is: the size heuristics are not under test
+        eng.set_data(ts, xs)
+        eng.extend_reserve(n, 2 * T)             # (Python threads arrive slowly: many small coalesced batches, the store must hold the population)
+
+        def phase(fn):
+            out = [None] * T
+            def work(i):
+                out[i] = fn(nodes[i], float(noises[i]), check=False)
+            th = [threading.Thread(target=work, args=(i,)) for i in range(T)]
+            for t in th: t.start()
+            for t in th: t.join()
+            return out
+        for rep in range(2):                     # two leapfrog steps (the second at the same parameters: value calls hit the store / recompute the class)
+            k_t0, k_s0, g0 = eng.toeplitz_particles(), eng.grad_structured_particles(), eng.grad_reuse_stats()
+            vals = phase(eng.logpdf)
+            k_t1 = eng.toeplitz_particles()
+            grads = phase(eng.logpdf_grad)
+            k_s1, g1 = eng.grad_structured_particles(), eng.grad_reuse_stats()
+            ok = r_info == 0
+            n_cls_ok = int((cls & ok).sum())
+            # every accepted class particle: value from the recursion, gradient from the structured sweep
+            assert k_t1 - k_t0 >= n_cls_ok - 2, (k_t1 - k_t0, n_cls_ok)
+            assert k_s1 - k_s0 >= n_cls_ok - 2, (k_s1 - k_s0, n_cls_ok)
+            # the others: gradient from the resident factor of the value call, nothing factored by a gradient sweep
+            assert g1["reused"] - g0["reused"] >= int((~cls & ok).sum()) and g1["factored"] - g0["factored"] <= 2, (g0, g1)
+            for i in range(T):
+                if not ok[i]:
+                    continue
+                lp, g, gn = grads[i]
+                sc = max(1.0, np.abs(r_g[i]).max() if len(r_g[i]) else 0.0, abs(r_gn[i]))
+                assert abs(vals[i] - r_lp[i]) <= 1e-10 * max(1.0, abs(r_lp[i])), i
+                assert abs(lp - r_lp[i]) <= 1e-10 * max(1.0, abs(r_lp[i])), i
+                assert (np.abs(g - r_g[i]).max() if len(g) else 0.0) <= 1e-7 * sc and abs(gn - r_gn[i]) <= 1e-7 * sc, i
+        for i in range(0, T, 23):
+            if r_info[i] != 0:
+                continue
+            lpo, go, gno = O.gp_logpdf_grad(nodes[i].to_tuple(), float(noises[i]), ts, xs)
+            sc = max(1.0, np.abs(go).max() if len(go) else 0.0, abs(gno))
+            assert abs(grads[i][0] - lpo) <= LP_TOL * max(1.0, abs(lpo))
+            assert (np.abs(grads[i][1] - go).max() if len(go) else 0.0) <= 1e-7 * sc and abs(grads[i][2] - gno) <= 1e-7 * sc
+    finally:
+        ref.close(); eng.close()

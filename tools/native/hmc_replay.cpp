@@ -181,14 +181,16 @@ int main(int argc, char** argv) {
   int64_t gr[2] = {0, 0};
   agp_grad_reuse_stats(ctx, gr);      // gradient calls that started from the factor of the value call before them
   const char* fc = getenv("AGP_FACTOR_CACHE");
-  int64_t n_lagdom = 0;
+  int64_t n_lagdom = 0, n_schur = 0, n_sgrad = 0;
   agp_get_grad_lag_domain_stats(ctx, &n_lagdom);
-  printf("{\"tool\": \"hmc_replay\", \"time_points\": \"%s\", \"gradient_particles_in_lag_domain\": %lld, \"factor_cache\": %s, \"gradient_particles_from_resident_factor\": %lld, \"gradient_particles_factored\": %lld, "
+  agp_get_toeplitz_stats(ctx, &n_schur);          // value calls scored by the Schur recursion (opt-in level AGP_LAG >= 2)
+  agp_get_grad_structured_stats(ctx, &n_sgrad);   // gradient particles differentiated without any dense factor
+  printf("{\"tool\": \"hmc_replay\", \"time_points\": \"%s\", \"gradient_particles_in_lag_domain\": %lld, \"value_particles_by_schur_recursion\": %lld, \"gradient_particles_without_dense_factor\": %lld, \"factor_cache\": %s, \"gradient_particles_from_resident_factor\": %lld, \"gradient_particles_factored\": %lld, "
          "\"n\": %d, \"threads\": %d, \"hmc_iterations_per_particle\": %d, \"L\": %d, \"eps\": %g, "
          "\"seconds\": %.4f, \"hmc_iterations_per_s\": %.2f, \"seconds_per_iteration_of_the_population\": %.4f, "
          "\"gradient_calls\": %lld, \"value_calls\": %lld, \"calls_per_s\": %.1f, \"coalesced_batches\": %lld, \"mean_batch\": %.1f, "
          "\"accepted_param_moves\": %lld, \"api_errors\": %lld, \"not_positive_definite\": %lld, \"non_finite\": %lld}\n",
-         grid ? "regular grid, shuffled" : monthly ? "month starts (lattice with gaps), shuffled" : "irregular", (long long)n_lagdom, (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
+         grid ? "regular grid, shuffled" : monthly ? "month starts (lattice with gaps), shuffled" : "irregular", (long long)n_lagdom, (long long)n_schur, (long long)n_sgrad, (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
          n, T, iters, L, eps, dt, it_total / dt, dt / iters, cnt.grad.load(), cnt.value.load(),
          (double)(cnt.grad.load() + cnt.value.load()) / dt, (long long)(b1 - b0),
          (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), cnt.accepted.load(), cnt.api_errors.load(), cnt.not_pd.load(), cnt.non_finite.load());
