@@ -2142,10 +2142,23 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
   c->queue.push_back(&req);
   ++c->arrivals;
   if (c->leader_gathering) c->qcv_leader.notify_one();      // only the gathering leader cares about arrivals
-  while (!req.done) {
-    if (!c->leader_active) {
-      // ---- become the leader ----
-      c->leader_active = true;
+  bool lead = !c->leader_active;
+  if (lead) c->leader_active = true;
+  for (;;) {
+    if (!lead) {
+      // ---- follower: sleep on this request's own condition variable until its results are in or it is promoted ----
+      lk.unlock();
+      {
+        std::unique_lock<std::mutex> l(req.m);
+        req.cv.wait(l, [&] { return req.done || req.lead; });
+        if (req.done) break;
+        req.lead = false;
+      }
+      lk.lock();
+      lead = true;                       // (leader_active stayed true: the finishing leader handed the role over)
+    }
+    {
+      // ---- leader ----
       // Gather.  With callers alternating between "in a sweep" and "queued" the population is up to the last TWO
       // batches together; wait for that many, or until arrivals have stopped for one quiet slice with at least the
       // last batch's size queued, or until the budget is spent: min(window, a quarter of the last sweep), so
@@ -2180,16 +2193,29 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
       try { run_coalesced(c, batch); }
       catch (...) { for (LpRequest* r : batch) { r->rc = AGP_ERR_HOST; r->lp = std::nan(""); r->info = 0; } }
       const double sweep_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      // hand the results back: each follower is woken on its own condition variable (notified under its lock: the request lives on
+      // the follower's stack and may be gone the moment the lock is released)
+      for (LpRequest* r : batch) {
+        if (r == &req) continue;
+        std::lock_guard<std::mutex> l(r->m);
+        r->done = true;
+        r->cv.notify_one();
+      }
       lk.lock();
       c->last_sweep_us = sweep_us;
-      for (LpRequest* r : batch) r->done = true;
-      c->leader_active = false;
-      c->qcv.notify_all();               // finished followers return; one of the queued callers leads the next batch
-    } else {
-      c->qcv.wait(lk);
+      // one of the callers queued meanwhile leads the next batch; with nobody queued the next arrival will
+      if (!c->queue.empty()) {
+        LpRequest* nx = c->queue.front();
+        std::lock_guard<std::mutex> l(nx->m);
+        nx->lead = true;
+        nx->cv.notify_one();
+      } else {
+        c->leader_active = false;
+      }
+      lk.unlock();
+      break;
     }
   }
-  lk.unlock();
   *out_logpdf = req.lp;
   *out_info = req.info;
   if (want_grad) *out_grad_noise = req.gnoise;

@@ -134,7 +134,13 @@ struct LpRequest {
   double* grad = nullptr;        // value + gradient request: d logpdf / d prm[0..n_prm), caller's storage
   double gnoise = 0.0;
   double lp = 0.0; int32_t info = 0; int rc = 0;
-  bool done = false;
+  // hand-back: every waiting caller sleeps on its OWN condition variable (a shared one made all followers of a finished batch —
+  // hundreds of threads — re-acquire the queue mutex one after the other before they could return, while the next leader needed
+  // the same mutex to gather them again: the batches of a 512-thread population came out at ~410 + ~100)
+  std::mutex m;
+  std::condition_variable cv;
+  bool done = false;             // (under m) results are in
+  bool lead = false;             // (under m) promoted: this caller runs the next batch
 };
 
 struct agp_ctx {
@@ -216,7 +222,6 @@ struct agp_ctx {
   std::vector<double> upd_ms, trsm_ms;   // per-launch durations of the last profiled call
   // ---- coalescing of concurrent single-particle callers (agp_logpdf) ----
   std::mutex qmu;
-  std::condition_variable qcv;          // followers: a batch finished (results ready / a new leader is needed)
   std::condition_variable qcv_leader;   // the gathering leader: a request arrived
   bool leader_gathering = false;
   long long arrivals = 0;              // requests ever queued
