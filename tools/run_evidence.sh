@@ -1,7 +1,7 @@
 #!/bin/bash
 # evidence pass: gpu tests, smoke, bench (with cpu baseline), rocprofv3 kernel stats, PMC passes, configs, schedules
 # usage (on the GPU box, from the repo root): bash tools/run_evidence.sh <tag>      -> gpurun_out/<tag>_*
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R; mkdir -p gpurun_out
 (time python -m pytest tests -m gpu -q) > gpurun_out/${TAG}_pytest_gpu.log 2>&1; grep -E "passed|failed" gpurun_out/${TAG}_pytest_gpu.log
@@ -21,7 +21,8 @@ python tools/gpu_grad_lagdom_check.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_
 (python tools/gpu_grad_toeplitz_check.py; python tools/gpu_grad_phases.py) 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_grad_toeplitz_check.txt; cat gpurun_out/${TAG}_grad_toeplitz_check.txt
 (python tools/run_stream.py --rejuvenate; python tools/run_stream.py --rejuvenate --no-extend; python tools/run_stream.py --rejuvenate --predict; AGP_PREDICT_REUSE=0 python tools/run_stream.py --rejuvenate --predict; python tools/run_stream.py --rejuvenate --predict --time-order) 2>&1 | grep -v amdgpu | grep "^{" > gpurun_out/${TAG}_stream.jsonl; cut -c1-200 gpurun_out/${TAG}_stream.jsonl
 python tools/gpu_scratch_via_store.py 2>&1 | grep "^n=" > gpurun_out/${TAG}_store_scratch.txt; cat gpurun_out/${TAG}_store_scratch.txt
-(for T in 64 512; do tools/native/hmc_replay 2048 $T 2; tools/native/hmc_replay 2048 $T 2 10 0.02 grid; AGP_FACTOR_CACHE=0 tools/native/hmc_replay 2048 $T 2; done; tools/native/hmc_replay 512 256 4; tools/native/threads_bench 2048 512 8; tools/native/threads_bench 2048 64 8; tools/native/threads_bench 2048 512 4 grad) 2>&1 | grep "^{" > gpurun_out/${TAG}_native.jsonl; cut -c1-220 gpurun_out/${TAG}_native.jsonl
+python tools/gpu_calendar_bench.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_calendar.json; cut -c1-300 gpurun_out/${TAG}_calendar.json
+(for T in 64 512; do tools/native/hmc_replay 2048 $T 2; tools/native/hmc_replay 2048 $T 2 10 0.02 grid; AGP_LAG=2 tools/native/hmc_replay 2048 $T 2 10 0.02 grid; tools/native/hmc_replay 2048 $T 2 10 0.02 monthly; AGP_FACTOR_CACHE=0 tools/native/hmc_replay 2048 $T 2; done; tools/native/hmc_replay 2048 192 2 10 0.02 grid; AGP_LAG=2 tools/native/hmc_replay 2048 192 2 10 0.02 grid; tools/native/hmc_replay 512 256 4; tools/native/threads_bench 2048 512 8; tools/native/threads_bench 2048 64 8; tools/native/threads_bench 2048 512 4 grad) 2>&1 | grep "^{" > gpurun_out/${TAG}_native.jsonl; cut -c1-220 gpurun_out/${TAG}_native.jsonl
 # stand-alone diagonal-tile harness (per-phase clocks), predictive passes, extension sweeps alone, dataflow traces (measurement library)
 (tools/native/diag_bench 8 0 20; tools/native/diag_bench 512 0 20; tools/native/diag_bench 512 8 20; tools/native/diag_bench 64 8 20) > gpurun_out/${TAG}_diag_bench.txt 2>&1; tail -1 gpurun_out/${TAG}_diag_bench.txt | cut -c1-160
 (python tools/gpu_predict_perf.py; python tools/gpu_predict_perf.py 2048:2048:128 --off-lattice) 2>&1 | grep "^predict" > gpurun_out/${TAG}_predict_perf.txt; tail -2 gpurun_out/${TAG}_predict_perf.txt
