@@ -12,15 +12,31 @@ from oracle import oracle as O
 
 def run(pkg, eng, cases=60, seed=1, big=False):
     rng = np.random.default_rng(seed)
-    worst = 0.0; worst_g = 0.0; t0 = time.time(); nbad = 0; nstore = 0
+    worst = 0.0; worst_g = 0.0; t0 = time.time(); nbad = 0; nstore = 0; nlat = 0
     for c in range(cases):
         n = int(rng.choice([1, 2, 63, 127, 128, 129, 255, 256, 257, 383, 385, 500, 640, 777, 900] + ([1025, 1100, 1536, 2048] if big else [])))      # (big: the spectral lag sums of gradient sweeps start above 1024 points)
         P = int(rng.choice([1, 2, 7, 8, 9, 47, 48, 49, 63, 100, 129, 255, 256, 257, 300, 513]))
         if n * n * P > 640 * 640 * 300: P = max(1, (640 * 640 * 300) // (n * n))
         depth = int(rng.integers(1, 5))
-        ts, xs = pkg.prior.synthetic_series(max(n, 2), seed=int(rng.integers(1 << 30)), shuffle=bool(rng.integers(2)))
-        ts, xs = ts[:n], xs[:n]
-        if n > 4 and rng.random() < 0.3: ts[n // 2] = ts[n // 2 - 1]          # duplicate time point
+        # the time axis: a regular grid (sometimes with a duplicate point), or a calendar index through the reference's date ingestion —
+        # business days, month starts, a daily index with missing observations: lattices with gaps where they span <= 4096 points
+        kind = str(rng.choice(["grid", "grid", "business", "missing", "months"])) if n >= 8 else "grid"
+        sd, shuf = int(rng.integers(1 << 30)), bool(rng.integers(2))
+        if kind == "grid":
+            ts, xs = pkg.prior.synthetic_series(max(n, 2), seed=sd, shuffle=shuf)
+            ts, xs = ts[:n], xs[:n]
+            if n > 4 and rng.random() < 0.3: ts[n // 2] = ts[n // 2 - 1]          # duplicate time point
+        elif kind == "missing":
+            tf, xf = pkg.prior.calendar_series(n + max(1, n // 10), "D", seed=sd)
+            keep = np.sort(rng.permutation(len(tf))[:n]); keep[0], keep[-1] = 0, len(tf) - 1
+            ts, xs = tf[keep], xf[keep]
+            if shuf:
+                perm = rng.permutation(n); ts, xs = ts[perm], xs[perm]
+            ts, xs = np.ascontiguousarray(ts), np.ascontiguousarray(xs)
+        else:
+            ts, xs = pkg.prior.calendar_series(n, "B" if kind == "business" else "M", seed=sd, shuffle=shuf)
+        lat = pkg.probe_lattice(ts)
+        nlat += lat["kind"] == 2
         nodes, noises = pkg.prior.sample_particles(rng, P, max_depth=depth, max_size=31)
         eng.set_data(ts, xs)
         lp, info = eng.logpdf_batch(nodes, noises, check=False)
@@ -52,6 +68,8 @@ def run(pkg, eng, cases=60, seed=1, big=False):
             # factors — against the sweeps that factor themselves (computed with an empty store)
             m = min(P, 24)
             tp = np.concatenate([ts[: max(1, n // 3)], np.linspace(1.0, 1.2, 5)])
+            if lat["kind"] >= 1 and rng.random() < 0.6:          # the reference's query set: observed points + the next points of the index (lattice points)
+                tp = np.concatenate([ts[: max(1, n // 3)], ts.max() + lat["spacing"] * np.arange(1, 8)])
             eng.extend_reset()
             pm0, pv0, _, pi0 = eng.predict_batch(nodes[:m], noises[:m], tp, check=False)
             sel = [j for j in range(m) if nodes[j].size() <= 63]
@@ -79,7 +97,7 @@ def run(pkg, eng, cases=60, seed=1, big=False):
                     assert abs(g1[0][q] - g0[0][q]) <= 1e-10 * max(1.0, abs(g0[0][q])), ("gradient reuse value", n, P, q)
                     assert (np.abs(g1[1][q] - g0[1][q]).max() if g0[1][q].size else 0.0) <= 1e-8 * scg and abs(g1[2][q] - g0[2][q]) <= 1e-8 * scg, ("gradient reuse", n, P, q)
             nstore += 1
-    msg = f"fuzz ok: {cases} cases ({nstore} with factor-store sweeps), worst logpdf rel err {worst:.2e}, worst gradient rel err {worst_g:.2e}, not-PD particles skipped {nbad}, {time.time()-t0:.0f}s"
+    msg = f"fuzz ok: {cases} cases ({nstore} with factor-store sweeps, {nlat} on lattices with gaps), worst logpdf rel err {worst:.2e}, worst gradient rel err {worst_g:.2e}, not-PD particles skipped {nbad}, {time.time()-t0:.0f}s"
     return msg
 
 

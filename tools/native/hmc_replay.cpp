@@ -190,7 +190,7 @@ int main(int argc, char** argv) {
          "\"seconds\": %.4f, \"hmc_iterations_per_s\": %.2f, \"seconds_per_iteration_of_the_population\": %.4f, "
          "\"gradient_calls\": %lld, \"value_calls\": %lld, \"calls_per_s\": %.1f, \"coalesced_batches\": %lld, \"mean_batch\": %.1f, "
          "\"accepted_param_moves\": %lld, \"api_errors\": %lld, \"not_positive_definite\": %lld, \"non_finite\": %lld}\n",
-         grid ? "regular grid, shuffled" : monthly ? "month starts (lattice with gaps), shuffled" : "irregular", (long long)n_lagdom, (long long)n_schur, (long long)n_sgrad, (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
+         grid ? "regular grid, shuffled" : monthly ? "month starts (calendar index), shuffled" : "irregular", (long long)n_lagdom, (long long)n_schur, (long long)n_sgrad, (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
          n, T, iters, L, eps, dt, it_total / dt, dt / iters, cnt.grad.load(), cnt.value.load(),
          (double)(cnt.grad.load() + cnt.value.load()) / dt, (long long)(b1 - b0),
          (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), cnt.accepted.load(), cnt.api_errors.load(), cnt.not_pd.load(), cnt.non_finite.load());
