@@ -1784,6 +1784,14 @@ static LatticeFit fit_lattice(const std::vector<double>& tss, double lag_tol_h, 
 
 int agp_probe_lattice(const double* ts, int64_t n, int32_t* kind, int64_t* n_lattice, double* spacing, int64_t* index_out) {
   if (n < 0 || (n > 0 && !ts)) return AGP_ERR_ARG;
+  for (int64_t i = 0; i < n; ++i)
+    if (!std::isfinite(ts[i])) {      // (as agp_set_data: general path)
+      if (kind) *kind = 0;
+      if (n_lattice) *n_lattice = 0;
+      if (spacing) *spacing = 0.0;
+      if (index_out) for (int64_t j = 0; j < n; ++j) index_out[j] = -1;
+      return AGP_OK;
+    }
   try {
     std::vector<int64_t> perm((size_t)n);
     for (int64_t i = 0; i < n; ++i) perm[(size_t)i] = i;
@@ -1843,7 +1851,9 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
   if (c->d_ts_s) { HIPCHK(c, hipFree(c->d_ts_s)); c->d_ts_s = nullptr; }
   if (c->d_xs_s) { HIPCHK(c, hipFree(c->d_xs_s)); c->d_xs_s = nullptr; }
   if (c->d_rank) { HIPCHK(c, hipFree(c->d_rank)); c->d_rank = nullptr; }
-  if (c->lag_enable && n_max >= 2) {
+  bool finite_ts = true;      // (a NaN among the time points would break the sort's ordering; such a series takes the general path)
+  for (int64_t i = 0; i < n_max && finite_ts; ++i) finite_ts = std::isfinite(ts[i]);
+  if (c->lag_enable && n_max >= 2 && finite_ts) {
     std::vector<int64_t> perm((size_t)n_max);
     for (int64_t i = 0; i < n_max; ++i) perm[(size_t)i] = i;
     std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return ts[a] < ts[b]; });
