@@ -857,6 +857,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       };
       // (measured: 107 recursions beside the dense kernels at n = 4096: 18.1 -> 13.8 ms; 423 of them at n = 2048 fill every SIMD
       // with their own waves and only delay the dense kernels: 8.6 -> 9.2 ms — those go first, alone)
+      // (the same in the coalesced entry's class-aware mode: value sweeps of the HMC replay 11.9 ms either way)
       const bool side_by_side = part[1].size() <= 256;
       std::unique_ptr<Beside> side;
       if (side_by_side) side.reset(new Beside(structured)); else sT.rc = structured();
@@ -2189,6 +2190,7 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
           if (c->arrivals == seen && c->queue.size() >= (size_t)std::max(1, c->batch_hint)) break;
         }
         c->leader_gathering = false;
+        c->co_wait_us += std::chrono::duration<double, std::micro>(clk::now() - t_start).count();
       }
       std::vector<LpRequest*> batch, rest;
       for (LpRequest* r : c->queue) ((r->n == req.n && (r->grad != nullptr) == want_grad) ? batch : rest).push_back(r);
@@ -2211,8 +2213,11 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
         r->done = true;
         r->cv.notify_one();
       }
+      const double hand_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() - sweep_us;
       lk.lock();
       c->last_sweep_us = sweep_us;
+      (want_grad ? c->co_grad_us : c->co_value_us) += sweep_us;
+      c->co_handback_us += hand_us;
       // one of the callers queued meanwhile leads the next batch; with nobody queued the next arrival will
       if (!c->queue.empty()) {
         LpRequest* nx = c->queue.front();
@@ -2244,6 +2249,13 @@ int agp_logpdf_grad(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, co
                     double noise, double* out_logpdf, double* out_grad, double* out_grad_noise, int32_t* out_info) {
   if (c && !out_grad_noise) return fail(c, AGP_ERR_ARG, "null gradient pointer");
   return abi_guard(c, [&] { return logpdf_one(c, n, ops, n_ops, prm, n_prm, noise, out_logpdf, out_grad, out_grad_noise, out_info); });
+}
+
+int agp_get_coalesce_timing(agp_ctx* c, double* out4) {
+  if (!c || !out4) return fail(c, AGP_ERR_ARG, "null pointer");
+  std::lock_guard<std::mutex> g(c->qmu);
+  out4[0] = c->co_wait_us; out4[1] = c->co_value_us; out4[2] = c->co_grad_us; out4[3] = c->co_handback_us;
+  return AGP_OK;
 }
 
 int agp_get_coalesce_stats(agp_ctx* c, int64_t* n_calls, int64_t* n_batches) {

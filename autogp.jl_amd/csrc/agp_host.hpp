@@ -233,6 +233,7 @@ struct agp_ctx {
                              // last sweep's duration); 0 = every call runs alone (env AGP_COALESCE_US)
   int batch_hint = 1;        // size of the last coalesced batch
   long long n_coalesced_calls = 0, n_coalesced_batches = 0;
+  double co_wait_us = 0.0, co_value_us = 0.0, co_grad_us = 0.0, co_handback_us = 0.0;   // leaders' gather waits, value / gradient sweeps, hand-back (agp_get_coalesce_timing)
   // ---- resident factor store of the block-extension sweeps (agp_logpdf_batch_extend) ----
   std::vector<double> h_xs;             // host copy of the observations (prefix test of agp_set_data)
   struct FactorStore {

@@ -449,6 +449,9 @@ int agp_get_launch_times(agp_ctx* ctx, int32_t which, double* out, int32_t n_out
 /* Coalescing of concurrent agp_logpdf callers: window in microseconds (0 = off) and counters. */
 int agp_set_coalesce_window(agp_ctx* ctx, int32_t microseconds);
 int agp_get_coalesce_stats(agp_ctx* ctx, int64_t* n_calls, int64_t* n_batches);
+/* where the coalesced entries' wall time went since agp_init, microseconds: out4 = { leaders waiting for followers, value sweeps,
+ * value + gradient sweeps (host side included), handing results back } */
+int agp_get_coalesce_timing(agp_ctx* ctx, double* out4);
 
 /* agp_logpdf_batch / agp_logpdf_grad_batch evaluate each distinct (program, parameters, noise) once and copy
  * the result to its duplicates (a resampled SMC population, src/inference_smc_anneal_data.jl:198-204, holds

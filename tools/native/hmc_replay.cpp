@@ -177,6 +177,8 @@ int main(int argc, char** argv) {
   run(iters, cnt);
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   agp_get_coalesce_stats(ctx, &c1, &b1);
+  double cot[4] = {0, 0, 0, 0};
+  agp_get_coalesce_timing(ctx, cot);          // (since agp_init: the warm-up iteration included)
   const double it_total = (double)T * iters;
   int64_t gr[2] = {0, 0};
   agp_grad_reuse_stats(ctx, gr);      // gradient calls that started from the factor of the value call before them
@@ -189,11 +191,11 @@ int main(int argc, char** argv) {
          "\"n\": %d, \"threads\": %d, \"hmc_iterations_per_particle\": %d, \"L\": %d, \"eps\": %g, "
          "\"seconds\": %.4f, \"hmc_iterations_per_s\": %.2f, \"seconds_per_iteration_of_the_population\": %.4f, "
          "\"gradient_calls\": %lld, \"value_calls\": %lld, \"calls_per_s\": %.1f, \"coalesced_batches\": %lld, \"mean_batch\": %.1f, "
-         "\"accepted_param_moves\": %lld, \"api_errors\": %lld, \"not_positive_definite\": %lld, \"non_finite\": %lld}\n",
+         "\"leader_wait_ms\": %.1f, \"value_sweeps_ms\": %.1f, \"gradient_sweeps_ms\": %.1f, \"handback_ms\": %.1f, \"accepted_param_moves\": %lld, \"api_errors\": %lld, \"not_positive_definite\": %lld, \"non_finite\": %lld}\n",
          grid ? "regular grid, shuffled" : monthly ? "month starts (calendar index), shuffled" : "irregular", (long long)n_lagdom, (long long)n_schur, (long long)n_sgrad, (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
          n, T, iters, L, eps, dt, it_total / dt, dt / iters, cnt.grad.load(), cnt.value.load(),
          (double)(cnt.grad.load() + cnt.value.load()) / dt, (long long)(b1 - b0),
-         (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), cnt.accepted.load(), cnt.api_errors.load(), cnt.not_pd.load(), cnt.non_finite.load());
+         (double)(c1 - c0) / (double)std::max<int64_t>(1, b1 - b0), cot[0] / 1e3, cot[1] / 1e3, cot[2] / 1e3, cot[3] / 1e3, cnt.accepted.load(), cnt.api_errors.load(), cnt.not_pd.load(), cnt.non_finite.load());
   agp_destroy(ctx);
   return cnt.api_errors.load() != 0 ? 2 : 0;
 }
