@@ -263,7 +263,7 @@ def test_gamma_exponential_table_path(pkg, engine, monkeypatch):
                                  {"AGP_SPLIT_DIAG": "0", "AGP_RIGHT_LOOKING": "0"}, {"AGP_FLOW": "0"}, {"AGP_FLOW": "1"},
                                  {"AGP_FLOW": "1", "AGP_FUSE": "0"}, {"AGP_FLOW": "0", "AGP_RIGHT_LOOKING": "0"},
                                  {"AGP_GRAD_FFT": "0"}, {"AGP_GRAD_FFT": "1"}, {"AGP_GRAD_LAGDOM": "0"}, {"AGP_GRAD_LAGDOM": "1"}, {"AGP_LAG_RANK": "0"},
-                                 {"AGP_LAG": "0"}, {"AGP_LAG": "3"}])
+                                 {"AGP_LAG": "0"}, {"AGP_LAG": "3"}, {"AGP_LATTICE": "0"}, {"AGP_REFERENCE_ARITHMETIC": "1"}])
 def test_runtime_switches_agree_with_default(pkg, engine, monkeypatch, env):
     """Every documented schedule / path switch selects different kernels for the same arithmetic: value,
     info and gradient agree with the default engine to rounding, on a 260-particle population (in-kernel evaluation, split
