@@ -1051,6 +1051,19 @@ int agp_debug_gemm_variant(agp_ctx* c, int32_t P, int32_t nt, int32_t k, int32_t
         hipLaunchKernelGGL((k_gemm_nolds<true>), dim3(blocks), dim3(256), 0, st, ca);
         break;
       }
+      case 4000: case 4032: {   // 256 x 128 macro-items (two row tiles per workgroup, one workgroup per CU), every block column in one launch
+        int blocks = 0;
+        for (int kk = 1; kk < nt - 1; ++kk) blocks += Pg8 * ((nt - kk) / 2);
+        if (variant == 4000) hipLaunchKernelGGL((k_gemm_macro<true, 16>), dim3(blocks), dim3(256), 0, st, ca);
+        else hipLaunchKernelGGL((k_gemm_macro<true, 32>), dim3(blocks), dim3(256), 0, st, ca);
+        break;
+      }
+      case 4100: {   // 256 x 128 macro-items, eight waves (two row tiles per workgroup share the column slab in LDS), one launch
+        int blocks = 0;
+        for (int kk = 1; kk < nt - 1; ++kk) blocks += Pg8 * ((nt - kk) / 2);
+        hipLaunchKernelGGL((k_gemm_pair8<true>), dim3(blocks), dim3(512), 0, st, ca);
+        break;
+      }
       case 3000: {   // every block column in one launch, EIGHT waves per workgroup (column halves)
         int blocks = 0;
         for (int kk = 1; kk < nt - 1; ++kk) blocks += Pg8 * (nt - kk - 1);

@@ -487,6 +487,223 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nolds(CholArgs a) {
     }
 }
 
+// Variant: 256 x 128 MACRO-ITEMS.  One workgroup (4 waves, ONE per SIMD: up to 512 unified registers per lane) multiplies TWO row
+// tiles (ti, ti + 1) of block column k against the same column operand: the slab of L(k, j) is staged in LDS once for both, every LDS
+// fragment read feeds 4 MFMAs instead of 2, one barrier per 2 x 16 columns of work, and the column operand's HBM / L2 traffic per
+// flop halves.  Wave w owns rows [32w, 32w + 32) of BOTH tiles: 32 accumulator blocks (256 registers).  ALL as in k_gemm_strip; a
+// block column with an odd number of tiles ends on a single-tile item.  Timing only (no dependencies honoured).
+template <bool ALL, int KBX = 16>
+__global__ __launch_bounds__(256, 1) void k_gemm_macro(CholArgs a) {
+  __shared__ __attribute__((aligned(16))) double sm[2 * KBX * LDS_STRIDE];
+  constexpr int SLAB = KBX * LDS_STRIDE;
+  int b = blockIdx.x;
+  int kcol = a.k, T = a.tiles;
+  const int npl8 = 8 * ((a.P + 7) / 8);
+  if (ALL) {
+    kcol = 1;
+    while (kcol < a.nt - 1 && b >= npl8 * ((a.nt - kcol) / 2)) { b -= npl8 * ((a.nt - kcol) / 2); ++kcol; }
+    T = a.nt - kcol - 1;
+  }
+  const int TP = (T + 1) / 2;                    // items per particle in this block column
+  const int xcd = b & 7, qq = b >> 3;
+  const int pl = qq / TP, tl = qq - pl * TP;
+  const int tk = kcol, ti0 = kcol + 1 + 2 * tl, jmax = kcol;
+  const bool two = __builtin_amdgcn_readfirstlane((int)(ti0 + 1 < a.nt)) != 0;
+  const int ti1 = two ? ti0 + 1 : ti0;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, l15 = l & 15, lq = l >> 4;
+  const int row0 = 32 * w + 2 * l15;
+  double* __restrict__ Ap = a.A + (long long)p * a.strideA;
+  d4 acc0[NSB][2], acc1[NSB][2];
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb) {
+    acc0[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc0[cb][1] = d4{0.0, 0.0, 0.0, 0.0};
+    acc1[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc1[cb][1] = d4{0.0, 0.0, 0.0, 0.0};
+  }
+  constexpr int NU = KBX / 4;
+  const int nslab = jmax * (NB / KBX);
+  const int scol0 = tid >> 6, srow = 2 * (tid & 63);
+  d2 ra0[NU], ra1[NU], rb[NU], f0[NU], f1[NU];
+  auto gload = [&](int s) {
+    const int per = NB / KBX;
+    const int j = s / per, cs = (s % per) * KBX;
+    const double* __restrict__ srcA0 = Ap + tile_off(ti0, j) + (long long)cs * NB;
+    const double* __restrict__ srcA1 = Ap + tile_off(ti1, j) + (long long)cs * NB;
+    const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      ra0[u] = *reinterpret_cast<const d2*>(srcA0 + (4 * u + lq) * NB + row0);
+      if (two) ra1[u] = *reinterpret_cast<const d2*>(srcA1 + (4 * u + lq) * NB + row0);
+      rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 4 * u) * NB + srow);
+    }
+  };
+  auto lstore = [&](int buf) {
+    double* Bs = sm + buf * SLAB;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 4 * u) * LDS_STRIDE + srow) = rb[u];
+  };
+  gload(0); lstore(0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) { f0[u] = ra0[u]; f1[u] = ra1[u]; }
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) gload(s + 1);
+    const double* Bs = sm + buf * SLAB;
+    __builtin_amdgcn_s_setprio(1);
+    if (two) {
+#pragma unroll
+      for (int kk = 0; kk < KBX / 4; ++kk) {
+        const int krow = (kk * 4 + lq) * LDS_STRIDE;
+        double fa[NSB];
+#pragma unroll
+        for (int cb = 0; cb < NSB; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];
+#pragma unroll
+        for (int cb = 0; cb < NSB; ++cb) {
+          acc0[cb][0] = mfma(fa[cb], f0[kk].x, acc0[cb][0]);
+          acc0[cb][1] = mfma(fa[cb], f0[kk].y, acc0[cb][1]);
+          acc1[cb][0] = mfma(fa[cb], f1[kk].x, acc1[cb][0]);
+          acc1[cb][1] = mfma(fa[cb], f1[kk].y, acc1[cb][1]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < KBX / 4; ++kk) {
+        const int krow = (kk * 4 + lq) * LDS_STRIDE;
+        double fa[NSB];
+#pragma unroll
+        for (int cb = 0; cb < NSB; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];
+#pragma unroll
+        for (int cb = 0; cb < NSB; ++cb) {
+          acc0[cb][0] = mfma(fa[cb], f0[kk].x, acc0[cb][0]);
+          acc0[cb][1] = mfma(fa[cb], f0[kk].y, acc0[cb][1]);
+        }
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (s + 1 < nslab) {
+      lstore(buf ^ 1);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) { f0[u] = ra0[u]; f1[u] = ra1[u]; }
+    }
+    __syncthreads();
+  }
+  double* __restrict__ T0 = Ap + tile_off(ti0, tk);
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d2 o2; o2.x = -acc0[cb][0][r]; o2.y = -acc0[cb][1][r];
+      *reinterpret_cast<d2*>(T0 + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
+    }
+  if (two) {
+    double* __restrict__ T1 = Ap + tile_off(ti1, tk);
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d2 o2; o2.x = -acc1[cb][0][r]; o2.y = -acc1[cb][1][r];
+        *reinterpret_cast<d2*>(T1 + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
+      }
+  }
+}
+
+// Variant: 256 x 128 macro-items with EIGHT waves (512 threads, one workgroup per CU = two waves per SIMD, the production loop's
+// register budget).  Waves 0-3 own the four 32-row strips of tile ti, waves 4-7 those of tile ti + 1; the column operand's slab is
+// staged in LDS ONCE for all eight (half the LDS stores, barriers and column-operand fetches per MFMA of the production loop; the
+// fragment reads per MFMA stay).  ALL as in k_gemm_strip; a block column with an odd number of tiles ends on an item whose second
+// half idles.  Timing only.
+template <bool ALL>
+__global__ __launch_bounds__(512, 1) void k_gemm_pair8(CholArgs a) {
+  __shared__ __attribute__((aligned(16))) double sm[2 * KB * LDS_STRIDE];
+  constexpr int SLAB = KB * LDS_STRIDE;
+  int b = blockIdx.x;
+  int kcol = a.k, T = a.tiles;
+  const int npl8 = 8 * ((a.P + 7) / 8);
+  if (ALL) {
+    kcol = 1;
+    while (kcol < a.nt - 1 && b >= npl8 * ((a.nt - kcol) / 2)) { b -= npl8 * ((a.nt - kcol) / 2); ++kcol; }
+    T = a.nt - kcol - 1;
+  }
+  const int TP = (T + 1) / 2;
+  const int xcd = b & 7, qq = b >> 3;
+  const int pl = qq / TP, tl = qq - pl * TP;
+  const int tid = threadIdx.x, l = tid & 63, w8 = tid >> 6, w = w8 & 3, half = w8 >> 2, l15 = l & 15, lq = l >> 4;
+  const int tk = kcol, jmax = kcol;
+  const int ti = kcol + 1 + 2 * tl + half;
+  const bool live = __builtin_amdgcn_readfirstlane((int)(ti < a.nt)) != 0;     // (wave-uniform)
+  const int tir = live ? ti : ti - 1;
+  const int p = pl * 8 + xcd;
+  if (p >= a.P) return;
+  const int row0 = 32 * w + 2 * l15;
+  double* __restrict__ Ap = a.A + (long long)p * a.strideA;
+  d4 acc[NSB][2];
+#pragma unroll
+  for (int cb = 0; cb < NSB; ++cb) { acc[cb][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[cb][1] = d4{0.0, 0.0, 0.0, 0.0}; }
+  constexpr int NU = KB / 4;                   // row-operand loads per thread and slab
+  const int nslab = jmax * (NB / KB);
+  // column slab: 16 columns x 128 rows = 1024 d2, two per thread: thread t -> column (t >> 6) + 8 u, rows 2 (t & 63)
+  const int scol0 = tid >> 6, srow = 2 * (tid & 63);
+  d2 ra[NU], rb[2], fr[NU];
+  auto gload = [&](int s) {
+    const int per = NB / KB;
+    const int j = s / per, cs = (s % per) * KB;
+    const double* __restrict__ srcA = Ap + tile_off(tir, j) + (long long)cs * NB;
+    const double* __restrict__ srcB = Ap + tile_off(tk, j) + (long long)cs * NB;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) ra[u] = *reinterpret_cast<const d2*>(srcA + (4 * u + lq) * NB + row0);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) rb[u] = *reinterpret_cast<const d2*>(srcB + (scol0 + 8 * u) * NB + srow);
+  };
+  auto lstore = [&](int buf) {
+    double* Bs = sm + buf * SLAB;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) *reinterpret_cast<d2*>(Bs + (scol0 + 8 * u) * LDS_STRIDE + srow) = rb[u];
+  };
+  gload(0); lstore(0);
+#pragma unroll
+  for (int u = 0; u < NU; ++u) fr[u] = ra[u];
+  __syncthreads();
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) gload(s + 1);
+    const double* Bs = sm + buf * SLAB;
+    if (live) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < KB / 4; ++kk) {
+        const int krow = (kk * 4 + lq) * LDS_STRIDE;
+        double fa[NSB];
+#pragma unroll
+        for (int cb = 0; cb < NSB; ++cb) fa[cb] = Bs[krow + cb * 16 + l15];
+#pragma unroll
+        for (int cb = 0; cb < NSB; ++cb) {
+          acc[cb][0] = mfma(fa[cb], fr[kk].x, acc[cb][0]);
+          acc[cb][1] = mfma(fa[cb], fr[kk].y, acc[cb][1]);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+    }
+    if (s + 1 < nslab) {
+      lstore(buf ^ 1);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) fr[u] = ra[u];
+    }
+    __syncthreads();
+  }
+  if (live) {
+    double* __restrict__ Tt = Ap + tile_off(ti, tk);
+#pragma unroll
+    for (int cb = 0; cb < NSB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d2 o2; o2.x = -acc[cb][0][r]; o2.y = -acc[cb][1][r];
+        *reinterpret_cast<d2*>(Tt + (cb * 16 + 4 * r + lq) * NB + row0) = o2;
+      }
+  }
+}
+
 __global__ void k_fill_pseudo(double* A, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
