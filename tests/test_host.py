@@ -193,6 +193,33 @@ def test_lattice_admission_of_calendar_indices(pkg):
         assert pkg.probe_lattice(bad)["kind"] == 0
 
 
+def test_julia_block_structure(tmp_path):
+    """The Julia sources (shim, its tests, deps/build.jl, the golden-vector script) have never met a Julia parser: a tokenizer
+    checks that strings, comments and brackets balance and that every block opener has its `end` (tools/check_julia_blocks.py) —
+    and that the checker notices when they do not."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    import check_julia_blocks as CB
+    assert len(CB.FILES) >= 4
+    assert CB.main() == []
+    src = (ROOT / "autogp.jl_amd" / "julia" / "src" / "AutoGPHIP.jl").read_text()
+    broken = {
+        "missing_end": src.replace("\nend\n", "\n", 1),
+        "stray_end": src.replace("function check(", "end\nfunction check(", 1),
+        "open_paren": src.replace("check(eng, ccall((:agp_set_data, LIB), Cint,", "check(eng, ccall(((:agp_set_data, LIB), Cint,", 1),
+        "open_string": src.replace('"Pre-size the factor store', 'Pre-size the factor store', 1),
+    }
+    for name, text in broken.items():
+        assert text != src, name
+        f = tmp_path / f"{name}.jl"
+        f.write_text(text)
+        assert CB.main([f]) != [], name
+    # constructs the tokenizer must NOT trip over: indexing with end, comprehensions, one-line definitions, symbols, adjoints
+    ok = tmp_path / "ok.jl"
+    ok.write_text("module M\nf(x) = x[end] + sum(y for y in x if y > 0)\ng = [i for i in 1:3]\nh(a) = a' * a\ns = :end\n"
+                  "function k(v)\n  if v > 0 v else -v end\nend\nz = \"a $(f([1])) end\"\nstruct P\n  x::Int\nend\nend\n")
+    assert CB.main([ok]) == []
+
+
 def test_no_cpu_fallback(pkg):
     """Without a GPU the product path must fail loudly, never fall back to a CPU implementation."""
     with pytest.raises(pkg.AGPError, match="no CPU fallback"):
