@@ -586,7 +586,7 @@ bool toeplitz_class(const uint8_t* ops, int n_ops) {
 
 // The class's particles of one value sweep over the whole (regular, sorted) series: rank-layout lag tables, then one workgroup
 // per particle.  Outputs in the sub-batch's order; info 1 = refused (not positive definite to rounding).
-static int toeplitz_sweep(agp_ctx* c, int64_t n, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
+static int toeplitz_sweep(agp_ctx* c, int64_t n, int32_t rank0, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                           const double* prm, const double* noise, double* out_lp, int32_t* out_info) {
   HIPCHK(c, hipSetDevice(c->device));          // (may run on a helper thread: the device is per thread)
   Batch bt;
@@ -637,7 +637,8 @@ static int toeplitz_sweep(agp_ctx* c, int64_t n, int P, const int32_t* op_off, c
     HIPCHK(c, s->lagtab.ensure(sizeof(double) * 16));
   }
   ToepArgs ta = {};
-  ta.xs = c->d_xs_s; ta.n = (int)n; ta.P = P;
+  // (the sweep's points: the n consecutive grid points rank0 .. rank0 + n - 1 — the whole series, or a prefix of a series in time order)
+  ta.xs = c->d_xs_s + rank0; ta.n = (int)n; ta.P = P; ta.rank0 = rank0;
   ta.hdr = s->hdr.as<ProgHdr>(); ta.ops = s->ops.as<uint8_t>(); ta.prm = s->prm.as<double>(); ta.noise = s->noise.as<double>();
   ta.lagtab = s->lagtab.as<double>(); ta.lag_stride = stride;
   ta.grid_h = c->grid_h; ta.grid_mid = c->grid_mid; ta.tref = c->t_ref;
@@ -818,7 +819,18 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   // Structured value sweep (opt-in): on a regular grid, the particles whose kernel is a sum of stationary subtrees and Linear
   // leaves need no factorisation at all — Toeplitz + rank 2: Schur algorithm, O(n^2) — the others (and every particle the
   // structured sweep refuses) take the dense path below.
-  if (!go && c->toeplitz && !tl_in_toeplitz && allow_lag && c->lag_enable && c->lag_ok && c->lag_contig && n > 0 && n == c->n_max && n <= 4096 &&
+  // The sweep's points must be n CONSECUTIVE grid points: the whole series (any order), or a prefix of a series in time order
+  // (scripts/online.jl feeds the observations that way; fit_smc!(shuffle = false)) — a prefix of a shuffled grid is not.
+  int32_t value_rank0 = 0;
+  bool value_consecutive = n == c->n_max;
+  if (!go && c->toeplitz && !tl_in_toeplitz && allow_lag && c->lag_enable && c->lag_ok && c->lag_contig && n > 1 && n < c->n_max &&
+      (int64_t)c->h_rank.size() >= n) {
+    int32_t lo = c->h_rank[0], hi = c->h_rank[0];
+    for (int64_t i = 1; i < n; ++i) { lo = std::min(lo, c->h_rank[(size_t)i]); hi = std::max(hi, c->h_rank[(size_t)i]); }
+    value_consecutive = (int64_t)hi - lo + 1 == n;
+    value_rank0 = lo;
+  }
+  if (!go && c->toeplitz && !tl_in_toeplitz && allow_lag && c->lag_enable && c->lag_ok && c->lag_contig && n > 0 && value_consecutive && c->n_max <= 4096 &&
       h_out_lp && !d_user_lp && !d_user_info && !use_user_stream && !c->profiling) {
     std::vector<int> part[2];
     bool sane = true;
@@ -852,7 +864,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       gather(part[1], sT.oo, sT.so, sT.po, sT.sp, sT.nz);
       sT.lp.resize(part[1].size()); sT.info.assign(part[1].size(), 0);
       auto structured = [&] {
-        return toeplitz_sweep(c, n, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(), sT.sp.data(), sT.nz.data(), sT.lp.data(),
+        return toeplitz_sweep(c, n, value_rank0, (int)part[1].size(), sT.oo.data(), sT.so.data(), sT.po.data(), sT.sp.data(), sT.nz.data(), sT.lp.data(),
                               sT.info.data());
       };
       // (measured: 107 recursions beside the dense kernels at n = 4096: 18.1 -> 13.8 ms; 423 of them at n = 2048 fill every SIMD
@@ -2092,7 +2104,7 @@ static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
     if (want_grad) return agp_logpdf_grad_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_g, out_gn, out_info);
     // value calls go through the factor store: the reweight on a longer prefix becomes an extension sweep, the gradient
     // call that follows at the same parameters (HMC leapfrog) and a predictive call find the factor resident
-    if (c->factor_cache && c->toeplitz && c->lag_enable && c->lag_ok && c->lag_contig && n == c->n_max && n <= 4096) {
+    if (c->factor_cache && c->toeplitz && c->lag_enable && c->lag_ok && c->lag_contig && n > 1 && c->n_max <= 4096) {
       // opt-in (AGP_LAG >= 2): class-aware value sweep — Toeplitz-class particles from the Schur recursion, the others through the store
       return abi_guard(c, [&] {
         TlFlag via_store(tl_dense_via_store);

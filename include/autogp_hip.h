@@ -198,8 +198,9 @@ int agp_set_reference_arithmetic(agp_ctx* ctx, int32_t on);
  * Linear leaves gives K = T + U C U' — T symmetric Toeplitz, U = [1, t], C 2x2 — and log N(x; 0, K) follows from log|T| and
  * L^-1 [x, 1, t] (T = L L') by the matrix determinant lemma and Woodbury's identity.  The Schur algorithm generates L column by
  * column from the generators of T's displacement (a hyperbolic rotation and a shift per column) without ever storing it: O(n^2)
- * flops per particle instead of n^3/3, stable for positive definite T.  Applies to agp_logpdf_batch with host outputs over the
- * WHOLE series (n == n_max <= 4096); the other particles of the call, and any particle the structured sweep refuses (a reflection
+ * flops per particle instead of n^3/3, stable for positive definite T.  Applies to agp_logpdf_batch with host outputs over n
+ * CONSECUTIVE grid points of a series of n_max <= 4096 points: the whole series in any order, or a prefix of a series held in time
+ * order (scripts/online.jl; fit_smc!(shuffle = false)) — a prefix of a shuffled grid is not; the other particles of the call, and any particle the structured sweep refuses (a reflection
  * coefficient of modulus >= 1: not positive definite to rounding), take the dense path, which also supplies LAPACK's info.
  * Taken when the class's share of the dense sweep would cost more than the recursion's n sequential steps (level 3 / AGP_LAG=3:
  * always).  Agreement with the dense path: <= 1e-10 of |logpdf| (tests/test_gpu_lag.py) for noises the reference can produce

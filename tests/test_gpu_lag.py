@@ -473,7 +473,7 @@ def test_predictive_lattice_pass_reuses_resident_factors(pkg):
         a.close(); b.close()
 
 
-@pytest.mark.parametrize("case", ["population_2048", "shapes_300", "n4096", "refused", "irregular", "prefix"])
+@pytest.mark.parametrize("case", ["population_2048", "shapes_300", "n4096", "refused", "irregular", "prefix", "prefix_in_time_order", "window_in_time_order"])
 def test_structured_value_sweep(pkg, case):
     """Opt-in structured value sweep (agp_set_lag_tables(ctx, 2) / AGP_LAG=2; csrc/agp_toep_kernel.hpp): on a regular grid the
     particles whose kernel is a sum of stationary subtrees and Linear leaves are scored by the Schur algorithm on T + U C U'
@@ -503,6 +503,10 @@ def test_structured_value_sweep(pkg, case):
             ts = ts.copy(); ts[7] += 3e-4
         elif case == "prefix":
             n = 250
+        elif case == "prefix_in_time_order":         # (scripts/online.jl, fit_smc!(shuffle = false): the first n points ARE consecutive grid points)
+            order = np.argsort(ts); ts, xs = ts[order], xs[order]; n = 250
+        elif case == "window_in_time_order":         # ... consecutive, but not starting at the series' first point
+            order = np.argsort(ts); order = np.concatenate([order[40:], order[:40]]); ts, xs = ts[order], xs[order]; n = 260
     a = G.GPEngine(0); b = G.GPEngine(0)
     try:
         a.set_lag_tables(level)
@@ -515,7 +519,7 @@ def test_structured_value_sweep(pkg, case):
             assert k == 0
         elif case == "refused":
             assert k == 2 and ia[0] > 0 and np.isnan(la[0])          # (particle 0 went to the dense path)
-        elif case == "shapes_300":
+        elif case in ("shapes_300", "prefix_in_time_order", "window_in_time_order"):
             assert k == len(covered) - n_poly
         else:
             assert k >= len(nodes) // 2
