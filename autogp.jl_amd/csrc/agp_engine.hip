@@ -5,6 +5,26 @@
 
 thread_local std::string g_err_noctx;
 
+std::atomic<long long> HostProf::ns[HostProf::N];
+std::atomic<long long> HostProf::cnt[HostProf::N];
+const char* HostProf::names[HostProf::N] = {"coalesce: assemble", "dedup keys", "compile_batch", "grad classify + residency", "store lookup (grad)",
+    "slot + buffers + staging", "launches (value)", "launches (grad)", "wait + copy back", "scatter results", "extend: keys + dedup",
+    "extend: capacity + slots", "extend: compile", "extend: staging + launches", "extend: wait + register", "coalesce: hand back",
+    "structured split (value)", "toeplitz_sweep host", "toeplitz_grad_sweep host", "predict host", "", "", "", ""};
+int HostProf::enabled() {
+  static int e = -1;
+  if (e < 0) { const char* v = getenv("AGP_HOST_PROF"); e = (v && atoi(v) != 0) ? 1 : 0; }
+  return e;
+}
+void HostProf::report() {
+  if (enabled() <= 0) return;
+  fprintf(stderr, "[AGP_HOST_PROF] stage                              calls     total ms    us / call\n");
+  for (int i = 0; i < N; ++i) {
+    const long long k = cnt[i].load(), t = ns[i].load();
+    if (k > 0) fprintf(stderr, "[AGP_HOST_PROF] %-32s %8lld %12.2f %12.1f\n", names[i], k, (double)t / 1e6, (double)t / 1e3 / (double)k);
+  }
+}
+
 int fail(agp_ctx* c, int code, const std::string& msg) {
   if (c) { std::lock_guard<std::mutex> g(c->mu); c->err = msg; }
   else g_err_noctx = msg;
@@ -934,8 +954,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   // series keeps the general evaluator.
   bool lagr = !lag && allow_lag && c->lag_rank_enable && c->lag_enable && c->lag_ok && n > 0 && rank_units <= LAG_LDS_MAX_UNITS;
   const bool sorted = lag;          // the sweep runs on the sorted copy of the series (d_ts_s / d_xs_s)
+  HostProf hp_cb(2);
   int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint, lag || lagr, lagr ? rank_units : 1, lagr);
+  hp_cb.stop();
   if (rc) return rc;
+  HostProf hp_cls(3);
   if (lagr) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_rank_sweeps; }
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
   if (go && n > 23040) return fail(c, AGP_ERR_ARG, "gradient sweeps address a particle's packed matrix with 32-bit byte offsets: n <= 23040");
@@ -1066,6 +1089,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     if (use_toep) c->n_toep_particles += n_sum;
     any_toep_sweep = use_toep && n_sum > 0;
   }
+  hp_cls.stop();
   const int n_prm_total = prm_off[P];
   if (go && n == 0) {
     for (int i = 0; i < n_prm_total; ++i) go->grad[i] = 0.0;
@@ -1078,6 +1102,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   std::vector<int32_t> src_slot, i0v;
   int n_hit = 0;
   std::unique_lock<std::mutex> store_lk;       // held to the end of the sweep when anything is resident
+  HostProf hp_sl(4);
   if (go && n > 0 && c->factor_cache && c->store.n_slots > 0) {
     std::vector<std::string> keys((size_t)P);
     for (int p = 0; p < P; ++p)
@@ -1087,6 +1112,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     c->grad_reused += n_hit; c->grad_factored += P - n_hit;
   }
 
+  hp_sl.stop();
+  HostProf hp_buf(5);
   SlotGuard sg(c);
   Slot* s = sg.s;
   if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -1188,6 +1215,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     const int32_t* d_src = n_hit > 0 ? reinterpret_cast<const int32_t*>(dstage + o_src) : nullptr;
     const int32_t* d_i0 = n_hit > 0 ? reinterpret_cast<const int32_t*>(dstage + o_i0) : nullptr;
 
+    hp_buf.stop();
+    HostProf hp_launch(go ? 7 : 6);
     Prof pf{c, s, st, c->profiling};
     double tacc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     size_t ev_begin = pf.mark();
@@ -1481,6 +1510,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     sg.async_done = true;
     return AGP_OK;
   }
+  HostProf hp_wait(8);
   const size_t out_bytes = sizeof(double) * P + sizeof(int32_t) * P;
   if (own_out) {
     HIPCHK(c, s->h_out.ensure(out_bytes));
@@ -1648,6 +1678,7 @@ static int init_body(agp_ctx** out, int device_id) {
 
 void agp_destroy(agp_ctx* c) {
   if (!c) return;
+  HostProf::report();
   if (c->worker) {
     { std::lock_guard<std::mutex> g(c->worker->mu); c->worker->stop = true; }
     c->worker->cv.notify_all();
@@ -1974,6 +2005,7 @@ static int logpdf_batch_dedup(agp_ctx* c, int64_t n, int32_t P, const int32_t* o
     if (op_off[p + 1] < op_off[p] || prm_off[p + 1] < prm_off[p] || op_off[p] < 0 || prm_off[p] < 0)
       return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr, nullptr,
                                nullptr, false, go);
+  HostProf hp_dd(1);
   std::unordered_map<std::string, int> seen;
   seen.reserve((size_t)P * 2);
   std::vector<int> rep(P), uniq;
@@ -1991,6 +2023,7 @@ static int logpdf_batch_dedup(agp_ctx* c, int64_t n, int32_t P, const int32_t* o
   }
   const int U = (int)uniq.size();
   { std::lock_guard<std::mutex> g(c->mu); c->n_particles_seen += P; c->n_particles_run += U; }
+  hp_dd.stop();
   if (U == P)
     return logpdf_batch_impl(c, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_info, nullptr, nullptr,
                              nullptr, false, go);
@@ -2087,6 +2120,7 @@ int agp_wait(agp_ctx* c) {
 static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
   const int P = (int)batch.size();
   const bool want_grad = batch[0]->grad != nullptr;
+  HostProf hp_asm(0);
   std::vector<int32_t> op_off(P + 1, 0), prm_off(P + 1, 0);
   std::vector<uint8_t> ops; std::vector<double> prm, noise(P), lp(P), gn(want_grad ? P : 0);
   std::vector<int32_t> info(P);
@@ -2099,6 +2133,7 @@ static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
   }
   std::vector<double> grad(want_grad ? std::max<size_t>(1, prm.size()) : 0);
   if (prm.empty()) prm.push_back(0.0);
+  hp_asm.stop();
   auto sweep = [&](int64_t n, int32_t Pn, const int32_t* oo, const uint8_t* o, const int32_t* po, const double* q,
                    const double* nz, double* out_lp, double* out_g, double* out_gn, int32_t* out_info) {
     if (want_grad) return agp_logpdf_grad_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_g, out_gn, out_info);
@@ -2219,13 +2254,18 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
       const double sweep_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
       // hand the results back: each follower is woken on its own condition variable (notified under its lock: the request lives on
       // the follower's stack and may be gone the moment the lock is released)
-      for (LpRequest* r : batch) {
-        if (r == &req) continue;
-        std::lock_guard<std::mutex> l(r->m);
-        r->done = true;
-        r->cv.notify_one();
+      {
+        // (measured alternatives, NOTES round 5: promoting the next leader before this loop, and waking through group heads — 16 / 64
+        // followers each — both make the batches of a 256-thread population smaller and the whole slower: 3 170 -> 2 520 / 2 230 HMC
+        // iterations/s at n = 512; the one-by-one wake-up paces the arrivals the next leader gathers)
+        HostProf hp_hb(15);
+        for (LpRequest* r : batch) {
+          if (r == &req) continue;
+          std::lock_guard<std::mutex> l(r->m);
+          r->done = true;
+          r->cv.notify_one();
+        }
       }
-      const double hand_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() - sweep_us;
       lk.lock();
       c->last_sweep_us = sweep_us;
       (want_grad ? c->co_grad_us : c->co_value_us) += sweep_us;

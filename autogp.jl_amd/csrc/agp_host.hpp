@@ -412,6 +412,21 @@ template <class F> inline int abi_guard(agp_ctx* c, F&& f) noexcept {
 
 void apply_reference_arithmetic(agp_ctx* c);      // agp_engine.hip
 
+// Host-side stage timer (AGP_HOST_PROF=1; printed by agp_destroy): where the host code of a sweep spends its time when the kernels
+// are short (n of a few hundred: half of a coalesced batch's wall time is host code).  Costs two clock reads per scope when on.
+struct HostProf {
+  static constexpr int N = 24;
+  static std::atomic<long long> ns[N];
+  static std::atomic<long long> cnt[N];
+  static const char* names[N];
+  static int enabled();      // (-1 unknown, 0 / 1) from the environment
+  int id; std::chrono::steady_clock::time_point t0; bool on;
+  explicit HostProf(int id_) : id(id_), on(enabled() > 0) { if (on) t0 = std::chrono::steady_clock::now(); }
+  void stop() { if (on) { ns[id] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); cnt[id] += 1; on = false; } }
+  ~HostProf() { stop(); }
+  static void report();
+};
+
 // a thread-local switch held for a scope (nested sweeps of the structured paths)
 struct TlFlag {
   bool& f;

@@ -129,6 +129,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   HIPCHK(c, hipSetDevice(c->device));
 
   // distinct particles (a resampled population holds copies)
+  HostProf hp_k(10);
   std::unordered_map<std::string, int> seen;
   seen.reserve((size_t)P * 2);
   std::vector<int> rep(P), uniq;
@@ -153,6 +154,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
 
   const int n_pad = round_up(n, NB), nt = n_pad / NB;
   agp_ctx::FactorStore& fs = c->store;
+  hp_k.stop();
+  HostProf hp_cap(11);
   std::unique_lock<std::mutex> lk(fs.mu);
   {
     // capacity: slots sized for the resident data, at least as many as this population (twice, so that a population
@@ -212,6 +215,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     if (!fs.key[sl].empty()) { fs.index.erase(fs.key[sl]); fs.key[sl].clear(); }
   }
 
+  hp_cap.stop();
+  HostProf hp_cmp(12);
   Batch bt;
   // regular grid: stationary subtrees from rank lag tables, as in the caller-order sweeps of logpdf_batch_impl (the mode depends
   // on the resident series alone, so an extension and a from-scratch sweep of the same entry evaluate every tile the same way)
@@ -227,6 +232,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   int i0min = nt;
   for (int u = 0; u < U; ++u) i0min = std::min(i0min, (int)i0[u]);
 
+  hp_cmp.stop();
+  HostProf hp_st(13);
   SlotGuard sg(c);
   Slot* s = sg.s;
   if (!s->stream) HIPCHK(c, hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
@@ -333,6 +340,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     EXTCHK(hipGetLastError());
   }
   EXTCHK(hipMemcpyAsync(s->h_out.p, d_lp, sizeof(double) * U + sizeof(int32_t) * U, hipMemcpyDeviceToHost, st));
+  hp_st.stop();
+  HostProf hp_w(14);
   EXTCHK(hipStreamSynchronize(st));
   if (d_out_caller && wrote_device) *wrote_device = true;
 #undef EXTCHK
