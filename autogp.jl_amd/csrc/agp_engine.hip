@@ -2266,6 +2266,7 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
           r->cv.notify_one();
         }
       }
+      const double hand_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() - sweep_us;
       lk.lock();
       c->last_sweep_us = sweep_us;
       (want_grad ? c->co_grad_us : c->co_value_us) += sweep_us;
