@@ -10,7 +10,7 @@ std::atomic<long long> HostProf::cnt[HostProf::N];
 const char* HostProf::names[HostProf::N] = {"coalesce: assemble", "dedup keys", "compile_batch", "grad classify + residency", "store lookup (grad)",
     "slot + buffers + staging", "launches (value)", "launches (grad)", "wait + copy back", "scatter results", "extend: keys + dedup",
     "extend: capacity + slots", "extend: compile", "extend: staging + launches", "extend: wait + register", "coalesce: hand back",
-    "structured split (value)", "toeplitz_sweep host", "toeplitz_grad_sweep host", "predict host", "", "", "", ""};
+    "  of which: factor part", "  of which: gradient launches", "", "", "", "", "", ""};
 int HostProf::enabled() {
   static int e = -1;
   if (e < 0) { const char* v = getenv("AGP_HOST_PROF"); e = (v && atoi(v) != 0) ? 1 : 0; }
@@ -1255,6 +1255,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       HIPCHK(c, hipGetLastError());
     }
     size_t ev_h2d = pf.mark();
+    HostProf hp_fac(16);
     pf.span(7, ev_begin, ev_h2d);
 
     for (int p0 = 0; p0 < P; p0 += chunk) {
@@ -1341,6 +1342,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         pf.span(4, e2, e3);
         HIPCHK(c, hipGetLastError());
         if (go) {
+          hp_fac.stop();
+          HostProf hp_gl(17);
           // ---- gradient: Z = L^-T, alpha = Z beta, per-tile contraction, fixed-order reduction ----
           GradArgs ga = {};
           ga.A = cv.A; ga.Z = s->Z.as<double>() + (size_t)g0 * strideA; ga.strideA = strideA; ga.W = ca.W;
