@@ -401,6 +401,14 @@ def calendar_leg(pkg, programs, nodes, noises, n, device):
             fl_done = Pp * (2.0 * cholesky_flops(n) + float(n) * n * n)
             out["predict"] = {"ms": dp * 1e3, "particles": Pp, "m": 2 * n, "rank_tables": bool(eng.lag_predict_passes() > k0),
                               "executed_flops": fl_done, "frac_of_fp64_mfma_peak": fl_done / dp / 1e12 / PEAK_FP64_MFMA_TFLOPS}
+            # ... and with a forecasting horizon of n / 8 dates (on a business-day index the joint lattice then stays within the table budget)
+            mh = n // 8
+            tq = np.concatenate([ts, (slope * x + icpt)[n:n + mh]])
+            k0 = eng.lag_predict_passes()
+            dph, _ = pred(eng)
+            fl_h = Pp * (2.0 * cholesky_flops(n) + float(n) * n * mh)
+            out["predict_short_horizon"] = {"ms": dph * 1e3, "m": n + mh, "rank_tables": bool(eng.lag_predict_passes() > k0),
+                                            "frac_of_fp64_mfma_peak": fl_h / dph / 1e12 / PEAK_FP64_MFMA_TFLOPS}
         except Exception as e:      # noqa: BLE001
             out["error"] = str(e)[:300]
         finally:
