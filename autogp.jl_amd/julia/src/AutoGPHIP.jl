@@ -362,6 +362,23 @@ function shard_range(P::Integer, rank::Integer, n_ranks::Integer)
     return (lo[] + 1):hi[]
 end
 """
+Cost-aware, duplicate-aware assignment of a population to ranks (`agp_shard_plan`; host code, identical on every rank): `sweep` 0 value,
+1 gradient, 2 marginal prediction with `m_future` query points beyond the data, 3 opt-in structured value sweep.  Returns the 0-based
+owner rank of every particle and the ranks' modelled costs; a rank evaluates `findall(==(rank), owner)` and the gathered log-weights
+are scattered back by the same vector.
+"""
+function shard_plan(nodes::Vector{<:GP.Node}, noises::Vector{Float64}, n::Integer, n_ranks::Integer;
+                    sweep::Integer=1, regular_grid::Bool=true, m_future::Integer=0)
+    P = length(nodes)
+    op_off, ops, prm_off, prm = encode_batch(nodes)
+    owner = Vector{Int32}(undef, max(P, 1)); cost = Vector{Float64}(undef, max(P, 1)); rank_cost = Vector{Float64}(undef, n_ranks)
+    rc = GC.@preserve op_off ops prm_off prm noises owner cost rank_cost ccall((:agp_shard_plan, LIB), Cint,
+        (Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Int64, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
+        n, P, op_off, ops, prm_off, prm, noises, sweep, regular_grid ? 1 : 0, m_future, n_ranks, owner, cost, rank_cost)
+    rc == 0 || error("agp_shard_plan failed ($rc)")
+    return owner[1:P], rank_cost
+end
+"""
 `lw` has one entry per particle of the WHOLE population with this rank's block filled; on return every rank holds
 the complete vector — the input of compute_particle_weights / effective_sample_size / Gen.maybe_resample!
 (src/inference_smc_anneal_data.jl:22-31,232).

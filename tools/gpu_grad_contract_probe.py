@@ -10,6 +10,7 @@ pkg = g.load_package(); G = pkg
 eng = pkg.GPEngine(0)
 n, P = 2048, 512
 ts, xs = pkg.prior.synthetic_series(n, seed=n, shuffle=True); eng.set_data(ts, xs)
+if len(sys.argv) > 1 and sys.argv[1] == "elementwise": eng.set_grad_lag_domain(False)      # (what an irregular series pays)
 rng = np.random.default_rng(0)
 def u(): return float(np.exp(-1.5 + 0.3 * rng.standard_normal()))
 pops = {
