@@ -1875,6 +1875,7 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
   const bool lag_was = c->lag_ok, contig_was = c->lag_contig;
   const std::vector<double> tlat_was = c->h_ts_lat;
   const double grid_h_was = c->grid_h;
+  const double t0_was = c->h_ts_sorted.empty() ? std::nan("") : c->h_ts_sorted.front();
   if (c->d_ts) { HIPCHK(c, hipFree(c->d_ts)); c->d_ts = nullptr; }
   if (c->d_xs) { HIPCHK(c, hipFree(c->d_xs)); c->d_xs = nullptr; }
   // padded to a whole tile so kernels may read (and ignore) the tail
@@ -1908,7 +1909,7 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
     for (int64_t i = 0; i < n_max; ++i) { tss[(size_t)i] = ts[perm[(size_t)i]]; xss[(size_t)i] = xs[perm[(size_t)i]]; }
     const double t0 = tss.front(), t1 = tss.back();
     LatticeFit lf = fit_lattice(tss, c->lag_tol_h, c->lattice_enable != 0,
-                                (lag_was && !contig_was && !tlat_was.empty() && tlat_was.front() == t0) ? grid_h_was : 0.0);
+                                (lag_was && !contig_was && !tlat_was.empty() && t0_was == t0) ? grid_h_was : 0.0);
     const bool regular = lf.kind == 1, lattice = lf.kind == 2;
     const double h = (t1 - t0) / (double)(n_max - 1);
     const double hl = lf.h, dmin_lat = lf.dmin;
@@ -1927,12 +1928,20 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
       HIPCHK(c, hipMalloc((void**)&c->d_rank, sizeof(int32_t) * npad));
       HIPCHK(c, hipMemcpy(c->d_rank, rank.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice));
 
-      // times of the lattice points: the data's own values where occupied (so that a table entry's t_g - t_0 is the difference of
-      // two stored points wherever both exist, as on the regular grid), t_0 + g h elsewhere
+      // "Times" of the lattice points, of which only the differences t_g - t_0 are ever used (lag g of a rank table, of the lag
+      // histograms, of a lattice query).  Regular grid: the sorted series itself (a table entry is the difference of two stored
+      // points).  Lattice with gaps: g h EXACTLY as a product (t_0 taken as 0): a lag's time then carries a relative error of
+      // 1e-16 instead of the ~1.5 ulp(|t|max) of two rescaled dates — a table applies ONE representative to all ~n pairs of a
+      // lag, so its error adds up coherently: with data-derived times a particle of a randomised run (a large Linear term, noise
+      // 0.011) sat 2.3e-9 from the oracle, 4x the oracle's own sensitivity to +-1 ulp in ts; with exact lags 1e-10 (NOTES round 5).
       const int64_t nlpad = ((n_lat + 255) / 256) * 256 + 256;
       std::vector<double> tl((size_t)nlpad);
-      for (int64_t g = 0; g < nlpad; ++g) tl[(size_t)g] = t0 + (double)g * hl;
-      for (int64_t i = 0; i < n_max; ++i) tl[(size_t)lat[(size_t)i]] = tss[(size_t)i];
+      if (regular) {
+        for (int64_t g = 0; g < nlpad; ++g) tl[(size_t)g] = t0 + (double)g * hl;
+        for (int64_t i = 0; i < n_max; ++i) tl[(size_t)lat[(size_t)i]] = tss[(size_t)i];
+      } else {
+        for (int64_t g = 0; g < nlpad; ++g) tl[(size_t)g] = (double)g * hl;
+      }
       HIPCHK(c, hipMalloc((void**)&c->d_ts_lat, sizeof(double) * nlpad));
       HIPCHK(c, hipMemcpy(c->d_ts_lat, tl.data(), sizeof(double) * nlpad, hipMemcpyHostToDevice));
       c->t_ref = 0.5 * (t0 + t1); c->grid_h = hl; c->grid_mid = 0.5 * (double)(n_lat - 1);

