@@ -76,3 +76,10 @@ def test_native_hmc_replay(points):
     assert r["gradient_calls"] >= 64 * 2 and r["value_calls"] >= 64
     assert r["gradient_particles_from_resident_factor"] >= 0.5 * r["value_calls"], r
     assert (r["gradient_particles_in_lag_domain"] > 0) == (points == "grid"), r
+
+
+def test_class_aware_pairs_randomised(pkg):
+    """Gen.hmc's update -> choice_gradients pairs at the opt-in level AGP_LAG >= 2 from Python threads: random sizes, orders, prefixes,
+    forced / heuristic size tests, reserved / unreserved stores, three leapfrog steps each — against the default engine's batch entry."""
+    msg = _tool("gpu_fuzz_pairs").run(pkg, cases=25, seed=2024)
+    assert msg.startswith("pairs fuzz ok"), msg

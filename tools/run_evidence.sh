@@ -31,7 +31,7 @@ if [ -f autogp.jl_amd/lib/libautogp_hip_exp.so ]; then
   python tools/gpu_flow_trace.py 1024 64 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_flow_trace_config2.txt; python tools/gpu_flow_trace.py 2048 64 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_flow_trace_P64.txt; grep "^diag items\|^sub items" gpurun_out/${TAG}_flow_trace_config2.txt
 fi
 # randomised soak runs (short versions): sizes x schedules x store; structured sweeps forced against dense / element-wise engines; the factor store's life cycle; 32 host threads
-(python tools/gpu_fuzz.py 100 1 big; python tools/gpu_fuzz_structured.py 300 1; python tools/gpu_fuzz_stream.py 150 1; python tools/gpu_stress_threads.py 10) 2>&1 | grep -E "fuzz ok|^stress|Error|assert" | cut -c1-900 > gpurun_out/${TAG}_soak.txt; cut -c1-200 gpurun_out/${TAG}_soak.txt
+(python tools/gpu_fuzz.py 100 1 big; python tools/gpu_fuzz_structured.py 300 1; python tools/gpu_fuzz_stream.py 150 1; python tools/gpu_fuzz_pairs.py 100 1; python tools/gpu_stress_threads.py 10) 2>&1 | grep -E "fuzz ok|^stress|Error|assert" | cut -c1-900 > gpurun_out/${TAG}_soak.txt; cut -c1-200 gpurun_out/${TAG}_soak.txt
 bash tools/run_profiles_extra.sh ${TAG} 2>&1 | grep -E "k_chol|k_trtri|k_zspec|k_grad" | head -12
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra-legs > $R/gpurun_out/prof.log 2>&1
