@@ -861,11 +861,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       for (int p = 0; p < P; ++p) part[toeplitz_class(ops + op_off[p], op_off[p + 1] - op_off[p]) ? 1 : 0].push_back(p);
     // (worth it when the class's share of a dense sweep costs more than the n sequential steps of the recursion:
     // ~50 us per particle at n = 2048 against ~0.7 us per step + ~0.4 ms of sub-batch overheads; level 3 forces it)
-    const double dense_us = 50.0 * (double)part[1].size() * std::pow((double)n / 2048.0, 3.0), schur_us = 0.7 * (double)n + 400.0;
+    const int64_t n_cls_v = (int64_t)part[1].size();
     // (the coalesced entry's class-aware mode: a class particle scored here stays out of the store, so the gradient call that follows
     // must take the structured sweep too — the same test as there, or the class would be factored densely by the gradient sweep:
     // measured with 128 threads, 106 class particles: 294 -> 262 HMC iterations/s with the value sweep's own, lower threshold)
-    const bool pays = tl_dense_via_store ? dense_us > 1.5 * 2.2 * (double)n : dense_us > 1.5 * schur_us;
+    const bool pays = tl_dense_via_store ? struct_grad_pays(n_cls_v, n) : struct_value_pays(n_cls_v, n);          // (agp_host.hpp: shared with agp_shard_plan)
     if (sane && !part[1].empty() && (c->toeplitz >= 2 || pays)) {
       auto gather = [&](const std::vector<int>& ix, std::vector<int32_t>& oo, std::vector<uint8_t>& so, std::vector<int32_t>& po,
                         std::vector<double>& sp, std::vector<double>& nz) {
@@ -1026,8 +1026,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         if (it != fs.index.end() && fs.n_cached[(size_t)it->second] == n && fs.info_h[(size_t)it->second] == 0) { resident[(size_t)q] = 1; --n_struct; }
       }
     }
-    const bool struct_pays = c->grad_struct >= 2 || 50.0 * (double)n_struct * std::pow((double)n / 2048.0, 3.0) > 1.5 * 2.2 * (double)n;
-    if (use_toep && n_struct > 0 && struct_pays && n <= 2048 && !tl_in_tgrad && !tl_no_toep && !c->profiling && c->grad_struct &&
+    const bool struct_pays = c->grad_struct >= 2 || struct_grad_pays(n_struct, n);
+    if (use_toep && n_struct > 0 && struct_pays && n <= STRUCT_GRAD_N_MAX && !tl_in_tgrad && !tl_no_toep && !c->profiling && c->grad_struct &&
         h_out_lp && !d_user_lp && !d_user_info && !use_user_stream && (!store_live || c->toeplitz)) {
       std::vector<int> part[2];
       for (int q = 0; q < P; ++q) part[((bt.ghdr[q].flags & GFLAG_LAGTOEP) && !resident[(size_t)q]) ? 1 : 0].push_back(bt.order[q]);

@@ -202,7 +202,7 @@ struct agp_ctx {
                                   // on one fixed schedule, every element from its own t_i - t_j, dense predictive pass, element-wise gradient, no store
   int lattice_enable = 1;         // admit lattices with gaps (calendar-indexed series: monthly / quarterly / yearly / business-day dates are
                                   // integer multiples of a day after datetime2unix, src/api.jl:49-51,98-101); env AGP_LATTICE=0: regular grids only
-  std::vector<double> h_ts_lat;   // time of lattice point g: the data's own value where a point sits there, t_0 + g h elsewhere (length n_lat)
+  std::vector<double> h_ts_lat;   // time of lattice point g (length n_lat).  Regular grid (lag_contig): the data's own value (keeps table and element bit-compatible).  Lattice with gaps: g * h as ONE product, relative to lattice point 0 — never the difference of two rescaled dates (NOTES round 5)
   double* d_ts_lat = nullptr;     // ... on the device, padded to a whole 256-lag unit + one (k_lag_tables, rank tables)
   int toeplitz = 0;              // structured value sweeps (Schur algorithm) for the Toeplitz + rank-2 class; env AGP_LAG=2 / agp_set_lag_tables(ctx, 2)
                                  // (2 = whatever the class's size: AGP_LAG=3, tests)
@@ -348,6 +348,21 @@ constexpr int LATTICE_MAX_DIV = 400;      // the lattice spacing is sought as (s
 constexpr int HYBRID_BLOCKS = 512;        // medium populations: right-looking once a block column offers fewer workgroups (run_factor)
 constexpr double GRAD_TOEP_MAX_AMP = 1e4;  // ... and the largest entry of U' T^-1 U C it accepts (the downdate loses that factor times ~100 eps)
 constexpr int GRAD_TOEP_MIN_N = 256;      // Toeplitz variant of the lag sums: four solves + seven transforms per particle, whatever n
+
+// Admission of the structured (Toeplitz + rank 2) sweeps by size — ONE set of predicates for the sweeps themselves (agp_engine.hip,
+// agp_predict.hip) and for agp_shard_plan's prices (agp_multi.hip): a plan that prices a class as structured where the engine
+// refuses it overloads the rank that holds the class.  n_class = class particles of the sweep that hold no resident factor.
+constexpr int STRUCT_GRAD_N_MAX = FFT_N / 2;     // seven length-FFT_N transforms per particle in k_lag_grad: 2 n <= FFT_N
+constexpr int STRUCT_JOINT_MAX = 4096;           // the joint recursion's register / LDS budget (k_toep_logpdf<.., JOINT>)
+constexpr int STRUCT_PRED_MIN_CLASS = 32;        // two sequential passes over the joint grid whatever the class's size
+inline double struct_dense_us(int64_t n_class, int64_t n) { const double r = (double)n / 2048.0; return 50.0 * (double)n_class * r * r * r; }
+// gradient: the class's share of the dense factorisation against the ~2.2 us per point of the two sequential structured passes
+inline bool struct_grad_pays(int64_t n_class, int64_t n) { return struct_dense_us(n_class, n) > 1.5 * 2.2 * (double)n; }
+inline bool struct_grad_admits(int64_t n_class, int64_t n) { return n_class > 0 && n >= GRAD_TOEP_MIN_N && n <= STRUCT_GRAD_N_MAX && struct_grad_pays(n_class, n); }
+// value (opt-in): against ONE recursion of n sequential steps (~0.7 us each) + sub-batch overheads
+inline bool struct_value_pays(int64_t n_class, int64_t n) { return struct_dense_us(n_class, n) > 1.5 * (0.7 * (double)n + 400.0); }
+inline bool struct_value_admits(int64_t n_class, int64_t n) { return n_class > 0 && n > 0 && n <= STRUCT_JOINT_MAX && struct_value_pays(n_class, n); }
+inline bool struct_pred_admits(int64_t n_class, int64_t n, int64_t m_future) { return n_class >= STRUCT_PRED_MIN_CLASS && n + m_future <= STRUCT_JOINT_MAX; }
 constexpr int GRAD_FFT_MIN_N = 1024;      // below ~1000 points the K^-1 tiles are cheaper than n/2 transforms of length 4096
 
 inline int round_up(int64_t n, int m) { return (int)(((n + m - 1) / m) * m); }

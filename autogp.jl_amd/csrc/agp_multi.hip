@@ -1,5 +1,6 @@
 // Host side of the C ABI, unit 4: the log-weight all-gather over RCCL and the one-process-drives-the-node entries.
 #include "agp_host.hpp"
+#include <unordered_set>
 
 
 // ==========================================================================================
@@ -89,24 +90,44 @@ int agp_shard_plan(int64_t n, int32_t P, const int32_t* op_off, const uint8_t* o
       if (op_off[p + 1] < op_off[p] || prm_off[p + 1] < prm_off[p] || op_off[p] < 0 || prm_off[p] < 0)
         return fail(nullptr, AGP_ERR_ARG, "offsets must be non-decreasing");
     const double nn = (double)std::max<int64_t>(n, 1);
+    const int kind = regular_grid < 0 ? 0 : regular_grid > 2 ? 2 : regular_grid;      // 0 irregular, 1 regular grid, 2 lattice with gaps
     const double dense = sweep == 1 ? 3.4 : sweep == 2 ? 2.0 + 3.0 * (double)std::max<int64_t>(m_future, 0) / nn : 1.0;
     const double toep = (sweep == 1 ? 0.42 : sweep == 2 ? 0.3 : 0.08) * (2048.0 / nn);
-    const bool structured = regular_grid != 0 && sweep >= 1 && n >= 256 && n <= 4096;      // sweep 3: opt-in structured value sweep
+    // On a lattice WITH gaps the class keeps its dense factor, L^-T and K^-1; only its contraction runs over the lattice's lags
+    // (measured on 2048 business days: 100.9 -> 96.5 ms per 512-particle gradient sweep)
+    const double lagdom_gaps = sweep == 1 ? dense - 0.15 : dense;
     std::unordered_map<std::string, int> seen;
     seen.reserve((size_t)P * 2);
     std::vector<int> rep((size_t)P);
     std::vector<double> cost((size_t)P, 0.0);
+    std::vector<char> is_cls((size_t)P, 0);
     std::vector<int> uniq;
+    int64_t n_cls = 0;
     for (int p = 0; p < P; ++p) {
       const int no = op_off[p + 1] - op_off[p], np = prm_off[p + 1] - prm_off[p];
       auto it = seen.emplace(particle_key(ops + op_off[p], no, prm + prm_off[p], np, noise[p]), p);
       rep[(size_t)p] = it.first->second;
       if (it.second) {
         uniq.push_back(p);
-        const bool cls = structured && no <= AGP_MAX_OPS_DEV && toeplitz_class(ops + op_off[p], no);
-        cost[(size_t)p] = cls ? std::min(toep, dense) : (sweep == 3 ? 1.0 : dense);
+        is_cls[(size_t)p] = (kind != 0 && sweep >= 1 && no <= AGP_MAX_OPS_DEV && toeplitz_class(ops + op_off[p], no)) ? 1 : 0;
+        n_cls += is_cls[(size_t)p];
       }
     }
+    // The structured sweeps are admitted by the ENGINE's own tests (agp_host.hpp: struct_*_admits — the same predicates the sweeps
+    // apply), on the class particles ONE rank will hold (~ n_cls / n_ranks): a class the engine would refuse is priced densely,
+    // or the greedy assignment would overload whichever rank holds it.
+    const int64_t cls_per_rank = (n_cls + n_ranks - 1) / n_ranks;
+    const bool structured = kind == 1 && (sweep == 1 ? struct_grad_admits(cls_per_rank, n)
+                                          : sweep == 2 ? struct_pred_admits(cls_per_rank, n, m_future)
+                                          : sweep == 3 ? struct_value_admits(cls_per_rank, n) : false);
+    // a class the structured GRADIENT sweep refuses (too few particles per rank) still skips L^-T and K^-1 on a regular grid of
+    // GRAD_TOEP_MIN_N .. STRUCT_GRAD_N_MAX points: dense factor + four solves + k_lag_grad (AGP_GRAD_FFT=2: 52 ms per 512-particle
+    // sweep with 423 such particles, DESIGN.md section 5 -> ~1.8 factorisations each)
+    const double toep_solves = (sweep == 1 && kind == 1 && n >= GRAD_TOEP_MIN_N && n <= STRUCT_GRAD_N_MAX) ? 1.8 : (kind != 0 ? lagdom_gaps : dense);
+    for (int p : uniq)
+      cost[(size_t)p] = !is_cls[(size_t)p] ? (sweep == 3 ? 1.0 : dense)
+                        : structured ? std::min(toep, dense)
+                        : sweep == 3 ? 1.0 : sweep == 1 ? toep_solves : dense;
     std::stable_sort(uniq.begin(), uniq.end(), [&](int a, int b) { return cost[(size_t)a] > cost[(size_t)b]; });
     std::vector<double> load((size_t)n_ranks, 0.0);
     for (int p : uniq) {
@@ -348,7 +369,8 @@ static int logpdf_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t 
     std::vector<int32_t> oo((size_t)Pl + 1), po((size_t)Pl + 1);
     for (int i = 0; i <= Pl; ++i) { oo[i] = op_off[lo + i] - op_off[lo]; po[i] = prm_off[lo + i] - prm_off[lo]; }
     double* d_loc = c->comm_all.as<double>() + P;
-    if (extend) {
+    if (extend && !c->ref_arith) {
+      // (reference arithmetic keeps nothing resident: the shard takes the plain sweep below, as agp_logpdf_batch_extend does)
       // every device keeps the factors of ITS shard resident (block sharding is stable while the population order is;
       // a particle that lands on another device after resampling is simply factored from scratch there).  The shard's
       // log-weights are also left on the device, in caller order, for the gather (no host round trip).
@@ -429,3 +451,191 @@ int agp_logpdf_batch_extend_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n
 
 }  // extern "C"
 
+// ---- one process driving the node: the sweeps that dominate a fit --------------------------------------------------------
+// The reference threads EVERY per-particle operation over the particles: HMC rejuvenation's gradients
+// (src/inference_smc_anneal_data.jl:240-252) and predict / predict_mvn (src/api.jl:508,645).  Their per-particle cost is not
+// uniform (regular grid: the Toeplitz class costs O(n^2), the others ~n^3; copies of a resampled survivor cost nothing), so these
+// entries split the population by agp_shard_plan (the engine's own admission tests, the resident series' lattice kind), run every
+// device's share concurrently (device 0's on the calling thread, the others on their contexts' persistent host threads) and put
+// the results back in the caller's order inside the entry.  Results go to the host (it owns the traces): no collective — the
+// contexts need not share a communicator (several contexts of ONE device work too: that is how a one-GPU box tests the split).
+namespace {
+
+struct ShardPack {
+  std::vector<int> idx;
+  std::vector<int32_t> oo, po;
+  std::vector<uint8_t> so;
+  std::vector<double> sp, nz;
+};
+
+void pack_shard(int32_t P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm, const double* noise,
+                const int32_t* owner, int d, ShardPack& S) {
+  S.idx.clear(); S.so.clear(); S.sp.clear(); S.nz.clear();
+  for (int p = 0; p < P; ++p) if (owner[p] == d) S.idx.push_back(p);
+  S.oo.assign(S.idx.size() + 1, 0); S.po.assign(S.idx.size() + 1, 0);
+  for (size_t b = 0; b < S.idx.size(); ++b) {
+    const int p = S.idx[b];
+    S.so.insert(S.so.end(), ops + op_off[p], ops + op_off[p + 1]);
+    S.sp.insert(S.sp.end(), prm + prm_off[p], prm + prm_off[p + 1]);
+    S.oo[b + 1] = (int32_t)S.so.size(); S.po[b + 1] = (int32_t)S.sp.size(); S.nz.push_back(noise[p]);
+  }
+  if (S.sp.empty()) S.sp.push_back(0.0);
+  if (S.so.empty()) S.so.push_back(0);
+}
+
+int check_ctx_list(agp_ctx* const* ctxs, int32_t n_dev) {
+  if (!ctxs || n_dev < 1 || !ctxs[0]) return fail(nullptr, AGP_ERR_ARG, "bad context list");
+  for (int d = 0; d < n_dev; ++d) {
+    if (!ctxs[d]) return fail(ctxs[0], AGP_ERR_ARG, "null context in the list");
+    for (int e = 0; e < d; ++e) if (ctxs[e] == ctxs[d]) return fail(ctxs[0], AGP_ERR_ARG, "the same context twice");
+  }
+  return AGP_OK;
+}
+
+// shard(d) for every device: 1 .. n_dev-1 on their persistent host threads, 0 on the calling thread (c0->multi_mu held)
+template <typename F>
+void run_on_devices(agp_ctx* const* ctxs, int32_t n_dev, F&& shard) {
+  for (int d = 1; d < n_dev; ++d) (void)ensure_worker(ctxs[d]);
+  for (int d = 1; d < n_dev; ++d) {
+    agp_ctx::Worker* w = ctxs[d]->worker;
+    { std::lock_guard<std::mutex> g(w->mu); w->job = [&shard, d]() { shard(d); }; w->has_job = true; w->done = false; }
+    w->cv.notify_all();
+  }
+  shard(0);
+  for (int d = 1; d < n_dev; ++d) {
+    agp_ctx::Worker* w = ctxs[d]->worker;
+    std::unique_lock<std::mutex> g(w->mu);
+    w->cv.wait(g, [&] { return w->done; });
+  }
+}
+
+int lattice_kind_of(agp_ctx* c) {
+  std::lock_guard<std::mutex> g(c->mu);
+  return (c->lag_enable && c->lag_ok) ? (c->lag_contig ? 1 : 2) : 0;
+}
+
+int first_error(agp_ctx* const* ctxs, int32_t n_dev, const std::vector<int>& rcs) {
+  for (int d = 0; d < n_dev; ++d)
+    if (rcs[(size_t)d]) {
+      if (rcs[(size_t)d] == AGP_ERR_HOST) return fail(ctxs[0], AGP_ERR_HOST, "host allocation failed in a device's shard");
+      if (d) fail(ctxs[0], rcs[(size_t)d], agp_last_error(ctxs[d]));
+      return rcs[(size_t)d];
+    }
+  return AGP_OK;
+}
+
+int grad_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
+                          const int32_t* prm_off, const double* prm, const double* noise, double* out_logpdf, double* out_grad,
+                          double* out_grad_noise, int32_t* out_info, int32_t* out_owner) {
+  int rc = check_ctx_list(ctxs, n_dev);
+  if (rc) return rc;
+  agp_ctx* c0 = ctxs[0];
+  if (P < 0 || n < 0) return fail(c0, AGP_ERR_ARG, "negative size");
+  if (P == 0) return AGP_OK;
+  if (!op_off || !ops || !prm_off || !prm || !noise || !out_logpdf || !out_grad || !out_grad_noise || !out_info)
+    return fail(c0, AGP_ERR_ARG, "null pointer argument");
+  std::vector<int32_t> owner((size_t)P, 0);
+  rc = agp_shard_plan(n, P, op_off, ops, prm_off, prm, noise, 1, lattice_kind_of(c0), 0, n_dev, owner.data(), nullptr, nullptr);
+  if (rc) return fail(c0, rc, agp_last_error(nullptr));
+  if (out_owner) std::memcpy(out_owner, owner.data(), sizeof(int32_t) * (size_t)P);
+  std::lock_guard<std::mutex> multi_lock(c0->multi_mu);
+  std::vector<int> rcs((size_t)n_dev, AGP_OK);
+  auto shard = [&](int d) noexcept {
+    try {
+      ShardPack S;
+      pack_shard(P, op_off, ops, prm_off, prm, noise, owner.data(), d, S);
+      const int Pl = (int)S.idx.size();
+      if (Pl == 0) return;
+      std::vector<double> lp((size_t)Pl), gn((size_t)Pl), gr(std::max<size_t>(1, (size_t)S.po[(size_t)Pl]), 0.0);
+      std::vector<int32_t> inf((size_t)Pl, 0);
+      rcs[(size_t)d] = agp_logpdf_grad_batch(ctxs[d], n, Pl, S.oo.data(), S.so.data(), S.po.data(), S.sp.data(), S.nz.data(), lp.data(), gr.data(),
+                                             gn.data(), inf.data());
+      if (rcs[(size_t)d]) return;
+      for (int b = 0; b < Pl; ++b) {          // (disjoint index sets: the shards write without a lock)
+        const int p = S.idx[(size_t)b];
+        out_logpdf[p] = lp[(size_t)b]; out_grad_noise[p] = gn[(size_t)b]; out_info[p] = inf[(size_t)b];
+        std::copy(gr.begin() + S.po[(size_t)b], gr.begin() + S.po[(size_t)b + 1], out_grad + prm_off[p]);
+      }
+    } catch (...) { rcs[(size_t)d] = AGP_ERR_HOST; }
+  };
+  run_on_devices(ctxs, n_dev, shard);
+  return first_error(ctxs, n_dev, rcs);
+}
+
+int predict_batch_multi_impl(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, const double* ts_pred, int64_t m, int32_t P,
+                             const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                             const double* noise, const double* noise_pred, const double* mean_train, const double* mean_pred,
+                             double* out_mean, double* out_var, double* out_cov, int32_t* out_info, int32_t* out_owner) {
+  int rc = check_ctx_list(ctxs, n_dev);
+  if (rc) return rc;
+  agp_ctx* c0 = ctxs[0];
+  if (P < 0 || n < 0 || m < 0) return fail(c0, AGP_ERR_ARG, "negative size");
+  if (P == 0) return AGP_OK;
+  if (!op_off || !ops || !prm_off || !prm || !noise || !out_mean || !out_var || !out_info || (m > 0 && !ts_pred))
+    return fail(c0, AGP_ERR_ARG, "null pointer argument");
+  // query points that are not training points (the reference's query set starts with model.ds: those cost n^2 each, the others n^2 more)
+  int64_t m_future = m;
+  {
+    std::lock_guard<std::mutex> g(c0->mu);
+    if ((int64_t)c0->h_ts.size() >= n) {
+      std::unordered_set<uint64_t> tr;
+      tr.reserve((size_t)n * 2);
+      for (int64_t i = 0; i < n; ++i) { uint64_t b; std::memcpy(&b, &c0->h_ts[(size_t)i], 8); tr.insert(b); }
+      m_future = 0;
+      for (int64_t j = 0; j < m; ++j) { uint64_t b; std::memcpy(&b, &ts_pred[j], 8); if (!tr.count(b)) ++m_future; }
+    }
+  }
+  std::vector<int32_t> owner((size_t)P, 0);
+  rc = agp_shard_plan(n, P, op_off, ops, prm_off, prm, noise, 2, out_cov ? 0 : lattice_kind_of(c0), m_future, n_dev, owner.data(), nullptr, nullptr);
+  if (rc) return fail(c0, rc, agp_last_error(nullptr));
+  if (out_owner) std::memcpy(out_owner, owner.data(), sizeof(int32_t) * (size_t)P);
+  std::lock_guard<std::mutex> multi_lock(c0->multi_mu);
+  std::vector<int> rcs((size_t)n_dev, AGP_OK);
+  auto shard = [&](int d) noexcept {
+    try {
+      ShardPack S;
+      pack_shard(P, op_off, ops, prm_off, prm, noise, owner.data(), d, S);
+      const int Pl = (int)S.idx.size();
+      if (Pl == 0) return;
+      std::vector<double> nzp;
+      if (noise_pred) { nzp.resize((size_t)Pl); for (int b = 0; b < Pl; ++b) nzp[(size_t)b] = noise_pred[S.idx[(size_t)b]]; }
+      std::vector<double> mean((size_t)Pl * (size_t)m), var((size_t)Pl * (size_t)m), cov(out_cov ? (size_t)Pl * (size_t)m * (size_t)m : 0);
+      std::vector<int32_t> inf((size_t)Pl, 0);
+      rcs[(size_t)d] = agp_predict_batch(ctxs[d], n, ts_pred, m, Pl, S.oo.data(), S.so.data(), S.po.data(), S.sp.data(), S.nz.data(),
+                                         noise_pred ? nzp.data() : nullptr, mean_train, mean_pred, mean.data(), var.data(),
+                                         out_cov ? cov.data() : nullptr, inf.data());
+      if (rcs[(size_t)d]) return;
+      for (int b = 0; b < Pl; ++b) {
+        const size_t p = (size_t)S.idx[(size_t)b];
+        std::copy(mean.begin() + (size_t)b * m, mean.begin() + (size_t)(b + 1) * m, out_mean + p * (size_t)m);
+        std::copy(var.begin() + (size_t)b * m, var.begin() + (size_t)(b + 1) * m, out_var + p * (size_t)m);
+        if (out_cov) std::copy(cov.begin() + (size_t)b * m * m, cov.begin() + (size_t)(b + 1) * m * m, out_cov + p * (size_t)m * (size_t)m);
+        out_info[p] = inf[(size_t)b];
+      }
+    } catch (...) { rcs[(size_t)d] = AGP_ERR_HOST; }
+  };
+  run_on_devices(ctxs, n_dev, shard);
+  return first_error(ctxs, n_dev, rcs);
+}
+
+}  // namespace
+
+extern "C" {
+
+int agp_logpdf_grad_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops,
+                                const int32_t* prm_off, const double* prm, const double* noise, double* out_logpdf, double* out_grad,
+                                double* out_grad_noise, int32_t* out_info, int32_t* out_owner) {
+  return abi_guard((ctxs && n_dev > 0) ? ctxs[0] : nullptr, [&] {
+    return grad_batch_multi_impl(ctxs, n_dev, n, P, op_off, ops, prm_off, prm, noise, out_logpdf, out_grad, out_grad_noise, out_info, out_owner); });
+}
+
+int agp_predict_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, const double* ts_pred, int64_t m, int32_t P,
+                            const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
+                            const double* noise, const double* noise_pred, const double* mean_train, const double* mean_pred,
+                            double* out_mean, double* out_var, double* out_cov, int32_t* out_info, int32_t* out_owner) {
+  return abi_guard((ctxs && n_dev > 0) ? ctxs[0] : nullptr, [&] {
+    return predict_batch_multi_impl(ctxs, n_dev, n, ts_pred, m, P, op_off, ops, prm_off, prm, noise, noise_pred, mean_train, mean_pred,
+                                    out_mean, out_var, out_cov, out_info, out_owner); });
+}
+
+}  // extern "C"

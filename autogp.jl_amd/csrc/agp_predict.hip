@@ -681,7 +681,7 @@ static int predict_batch_body(agp_ctx* c, int64_t n, const double* ts_pred, int6
         if (r <= hi) { const int32_t i = at[(size_t)(r - lo)]; qkind[(size_t)j] = r - lo; xq[(size_t)j] = c->h_xs[(size_t)i] - (mean_train ? mean_train[i] : 0.0); }
         else { const int f = r - hi - 1; qkind[(size_t)j] = -1 - f; mF = std::max(mF, f + 1); }
       }
-      ok = ok && n + mF <= 4096 && n + mF <= (int64_t)plq.rank_units * 256;
+      ok = ok && n + mF <= STRUCT_JOINT_MAX && n + mF <= (int64_t)plq.rank_units * 256;
       if (ok && mean_train) {
         xres.resize((size_t)n);
         for (int64_t u = 0; u < n; ++u) { const int32_t i = at[(size_t)u]; xres[(size_t)u] = c->h_xs[(size_t)i] - mean_train[i]; }
@@ -695,7 +695,7 @@ static int predict_batch_body(agp_ctx* c, int64_t n, const double* ts_pred, int6
       if (ok) for (int p = 0; p < P; ++p) part[toeplitz_class(ops + op_off[p], op_off[p + 1] - op_off[p]) ? 1 : 0].push_back(p);
     }
     // (two sequential passes over the joint grid: ~1.2 us per point + ~1 us per training point, whatever the class's size)
-    if (ok && (int)part[1].size() >= 32) {
+    if (ok && (int)part[1].size() >= STRUCT_PRED_MIN_CLASS) {
       const int32_t rank0_abs = c->h_rank[0] - (plq.rank[0] - lo);          // rank of the first training point in the resident series
       auto gather = [&](const std::vector<int>& ix, std::vector<int32_t>& oo, std::vector<uint8_t>& so, std::vector<int32_t>& po,
                         std::vector<double>& sp, std::vector<double>& nz, std::vector<double>& nzp) {

@@ -423,12 +423,14 @@ int agp_get_lattice_stats(agp_ctx* c, int32_t* kind, int64_t* n_lattice, double*
 
 int agp_set_lattice(agp_ctx* c, int32_t on) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (c->ref_arith && on != 0) return fail(c, AGP_ERR_ARG, "reference arithmetic pins this switch off (agp_set_reference_arithmetic cannot be undone on a live context)");
   c->lattice_enable = on != 0;
   return AGP_OK;
 }
 
 int agp_set_lag_tables(agp_ctx* c, int32_t on) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (c->ref_arith && on != 0) return fail(c, AGP_ERR_ARG, "reference arithmetic pins this switch off (agp_set_reference_arithmetic cannot be undone on a live context)");
   c->lag_enable = on != 0;
   c->toeplitz = on >= 3 ? 2 : on >= 2 ? 1 : 0;
   return AGP_OK;
@@ -443,6 +445,7 @@ int agp_get_toeplitz_stats(agp_ctx* c, int64_t* n_particles) {
 
 int agp_set_lag_rank_tables(agp_ctx* c, int32_t on) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (c->ref_arith && on != 0) return fail(c, AGP_ERR_ARG, "reference arithmetic pins this switch off (agp_set_reference_arithmetic cannot be undone on a live context)");
   c->lag_rank_enable = on != 0;
   return AGP_OK;
 }
@@ -463,6 +466,7 @@ int agp_get_lag_predict_stats(agp_ctx* c, int64_t* n_passes) {
 
 int agp_set_grad_lag_domain(agp_ctx* c, int32_t on) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (c->ref_arith && on != 0) return fail(c, AGP_ERR_ARG, "reference arithmetic pins this switch off (agp_set_reference_arithmetic cannot be undone on a live context)");
   c->grad_lagdom = on <= 0 ? 0 : on == 1 ? 1 : 2;
   return AGP_OK;
 }
@@ -497,6 +501,7 @@ int agp_get_grad_structured_stats(agp_ctx* c, int64_t* n_particles) {
 
 int agp_set_factor_cache(agp_ctx* c, int32_t on) {
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  if (c->ref_arith && on != 0) return fail(c, AGP_ERR_ARG, "reference arithmetic pins this switch off (agp_set_reference_arithmetic cannot be undone on a live context)");
   c->factor_cache = on != 0;
   return AGP_OK;
 }

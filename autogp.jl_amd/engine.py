@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = [
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi", "agp_logpdf_batch_extend_multi",
     "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
     "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_get_lattice_stats", "agp_set_lattice", "agp_probe_lattice", "agp_set_reference_arithmetic", "agp_shard_plan", "agp_get_coalesce_timing", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_predict_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
+    "agp_logpdf_grad_batch_multi", "agp_predict_batch_multi",
 ]
 COMM_ID_BYTES = 128
 
@@ -165,6 +166,11 @@ def load_library(path=None):
     lib.agp_logpdf_batch_multi.restype = C.c_int
     lib.agp_logpdf_batch_extend_multi.argtypes = lib.agp_logpdf_batch_multi.argtypes
     lib.agp_logpdf_batch_extend_multi.restype = C.c_int
+    lib.agp_logpdf_grad_batch_multi.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, dp, dp, ip, ip]
+    lib.agp_logpdf_grad_batch_multi.restype = C.c_int
+    lib.agp_predict_batch_multi.argtypes = [C.POINTER(vp), C.c_int32, C.c_int64, dp, C.c_int64, C.c_int32, ip, u8p, ip, dp, dp, dp, dp, dp,
+                                            dp, dp, dp, ip, ip]
+    lib.agp_predict_batch_multi.restype = C.c_int
     if path is None:
         _lib = lib
     return lib
@@ -596,18 +602,71 @@ def shard_range(P: int, rank: int, n_ranks: int):
     return lo.value, hi.value
 
 
-def shard_plan(programs, noises, n, n_ranks, sweep=1, regular_grid=True, m_future=0):
-    """agp_shard_plan: (owner[P], cost[P], rank_cost[n_ranks]) — cost-aware, duplicate-aware assignment of particles to ranks."""
+def shard_plan(programs, noises, n, n_ranks, sweep=1, regular_grid=True, m_future=0, lattice_kind=None):
+    """agp_shard_plan: (owner[P], cost[P], rank_cost[n_ranks]) — cost-aware, duplicate-aware assignment of particles to ranks.
+    lattice_kind: 0 irregular, 1 regular grid, 2 lattice with gaps (GPEngine.lattice_stats()["kind"]); the older boolean
+    `regular_grid` is used when it is None."""
     op_off, ops, prm_off, prm = programs
     P = op_off.shape[0] - 1
     noises = _f64(noises)
     owner = np.zeros(max(P, 1), dtype=np.int32); cost = np.zeros(max(P, 1)); rc = np.zeros(n_ranks)
     r = load_library().agp_shard_plan(int(n), P, _ip(op_off), _u8(ops), _ip(prm_off), _dp(prm if prm.size else np.zeros(1)), _dp(noises),
-                                      int(sweep), 1 if regular_grid else 0, int(m_future), int(n_ranks),
+                                      int(sweep), int(lattice_kind) if lattice_kind is not None else (1 if regular_grid else 0), int(m_future), int(n_ranks),
                                       owner.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cost), _dp(rc))
     if r != 0:
         raise AGPError(f"agp_shard_plan failed ({r})")
     return owner[:P], cost[:P], rc
+
+
+def _ctx_array(engines):
+    arr = (C.c_void_p * len(engines))()
+    for i, e in enumerate(engines):
+        arr[i] = e._ctx.value
+    return arr
+
+
+def logpdf_grad_batch_multi(engines, nodes, noises, n=None, check=True, programs=None, want_owner=False):
+    """agp_logpdf_grad_batch_multi over a list of GPEngine objects holding the same data (one per device — or several contexts of one
+    device): GPEngine.logpdf_grad_batch's results, the population split by the cost-aware plan inside the entry."""
+    lib = load_library()
+    n = engines[0].n_max if n is None else int(n)
+    op_off, ops, prm_off, prm = programs if programs is not None else _gp.encode_batch(nodes)
+    P = op_off.shape[0] - 1
+    noises = _f64(noises)
+    out = np.empty(P); info = np.empty(P, dtype=np.int32); gn = np.empty(P); owner = np.zeros(max(P, 1), dtype=np.int32)
+    grad = np.zeros(max(1, int(prm_off[-1])))
+    rc = lib.agp_logpdf_grad_batch_multi(_ctx_array(engines), len(engines), n, P, _ip(op_off), _u8(ops), _ip(prm_off), _dp(prm), _dp(noises),
+                                         _dp(out), _dp(grad), _dp(gn), _ip(info), _ip(owner))
+    engines[0]._check(rc)
+    if check and (info > 0).any():
+        p = int(np.argmax(info > 0))
+        raise PosDefException(int(info[p]), p)
+    res = (out, [grad[prm_off[i]:prm_off[i + 1]] for i in range(P)], gn, info)
+    return res + (owner[:P],) if want_owner else res
+
+
+def predict_batch_multi(engines, nodes, noises, ts_pred, n=None, noise_pred=None, mean_train=None, mean_pred=None, want_cov=False,
+                        check=True, want_owner=False):
+    """agp_predict_batch_multi over a list of GPEngine objects holding the same data: GPEngine.predict_batch's results."""
+    lib = load_library()
+    n = engines[0].n_max if n is None else int(n)
+    op_off, ops, prm_off, prm = _gp.encode_batch(nodes)
+    P = op_off.shape[0] - 1
+    noises = _f64(noises); ts_pred = _f64(ts_pred); m = ts_pred.shape[0]
+    npred = None if noise_pred is None else _f64(np.broadcast_to(noise_pred, (P,)))
+    mt = None if mean_train is None else _f64(mean_train)
+    mp_ = None if mean_pred is None else _f64(mean_pred)
+    mean = np.empty((P, m)); var = np.empty((P, m))
+    cov = np.empty((P, m, m)) if want_cov else None
+    info = np.zeros(P, dtype=np.int32); owner = np.zeros(max(P, 1), dtype=np.int32)
+    rc = lib.agp_predict_batch_multi(_ctx_array(engines), len(engines), n, _dp(ts_pred), m, P, _ip(op_off), _u8(ops), _ip(prm_off), _dp(prm),
+                                     _dp(noises), _dp(npred), _dp(mt), _dp(mp_), _dp(mean), _dp(var), _dp(cov), _ip(info), _ip(owner))
+    engines[0]._check(rc)
+    if check and (info > 0).any():
+        p = int(np.argmax(info > 0))
+        raise PosDefException(int(info[p]), p)
+    res = (mean, var, cov, info)
+    return res + (owner[:P],) if want_owner else res
 
 
 def probe_lattice(ts):
@@ -669,6 +728,14 @@ class GPEngineMulti:
             p = int(np.argmax(info > 0))
             raise PosDefException(int(info[p]), p)
         return out, info
+
+    def logpdf_grad_batch(self, nodes, noises, n=None, check=True, programs=None, want_owner=False):
+        """agp_logpdf_grad_batch_multi over the node's devices (cost-aware split inside the entry)."""
+        return logpdf_grad_batch_multi(self.engines, nodes, noises, n=n, check=check, programs=programs, want_owner=want_owner)
+
+    def predict_batch(self, nodes, noises, ts_pred, **kw):
+        """agp_predict_batch_multi over the node's devices."""
+        return predict_batch_multi(self.engines, nodes, noises, ts_pred, **kw)
 
 
 # ------------------------------------------------------------------------------------------

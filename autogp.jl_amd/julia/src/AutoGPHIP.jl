@@ -32,6 +32,8 @@ mutable struct Engine
     n_max::Int
     ts::Vector{Float64}     # host copies of the resident series: Gen hands (ts, xs) to logpdf on every call and
     xs::Vector{Float64}     # the shim must know whether they ARE the resident prefix
+    lag_level::Int32        # last level given to agp_set_lag_tables (0 off, 1 tables, 2 / 3 structured sweeps); the library's default is 1
+    lag_level_before::Int32 # ... and the one set_structured_sweeps!(eng, true) replaced
 end
 
 function check(eng::Union{Engine,Nothing}, rc::Cint)
@@ -44,11 +46,14 @@ end
 destroy!(e::Engine) = (e.ptr != C_NULL && ccall((:agp_destroy, LIB), Cvoid, (Ptr{Cvoid},), e.ptr); e.ptr = C_NULL; nothing)
 
 "One engine per GPU."
+"the level the library starts from: AGP_LAG (0 .. 3), 1 when unset"
+default_lag_level() = Int32(clamp(something(tryparse(Int, get(ENV, "AGP_LAG", "1")), 1), 0, 3))
+
 function Engine(device::Integer=0)
     ref = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:agp_init, LIB), Cint, (Ref{Ptr{Cvoid}}, Cint), ref, device)
     check(nothing, rc)
-    eng = Engine(ref[], 0, Float64[], Float64[])
+    eng = Engine(ref[], 0, Float64[], Float64[], default_lag_level(), default_lag_level())
     finalizer(destroy!, eng)
     return eng
 end
@@ -68,7 +73,7 @@ function EnginePool(devices::AbstractVector{<:Integer})
     n = length(devices)
     ptrs = fill(C_NULL, n); ids = Int32.(collect(devices))
     GC.@preserve ptrs ids check(nothing, ccall((:agp_init_multi, LIB), Cint, (Ptr{Ptr{Cvoid}}, Ptr{Int32}, Int32), ptrs, ids, n))
-    engines = [Engine(p, 0, Float64[], Float64[]) for p in ptrs]
+    engines = [Engine(p, 0, Float64[], Float64[], default_lag_level(), default_lag_level()) for p in ptrs]
     foreach(e -> finalizer(destroy!, e), engines)
     return EnginePool(engines)
 end
@@ -200,8 +205,14 @@ reserve_store!(eng::Engine, n_cap::Integer, n_particles::Integer) =
 "Opt-in structured arithmetic on regular time grids (`agp_set_lag_tables` level 2): particles whose kernel is a sum of stationary
 subtrees and Linear leaves are scored by the Schur recursion and differentiated by the structured sweep — also through the
 single-particle entries that Gen drives — instead of the dense Cholesky; the others keep the dense path and the factor store."
-set_structured_sweeps!(eng::Engine, on::Bool) =
-    check(eng, ccall((:agp_set_lag_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 2 : 1))
+function set_structured_sweeps!(eng::Engine, on::Bool)
+    # off = back to the level that was in force before (AGP_LAG=0 / set_lag_tables!(eng, 0) stay off), never a forced 1
+    if on
+        eng.lag_level < 2 && (eng.lag_level_before = eng.lag_level)
+        return set_lag_tables!(eng, 2)
+    end
+    return eng.lag_level >= 2 ? set_lag_tables!(eng, eng.lag_level_before) : nothing
+end
 
 "The whole population over every GPU of the pool: shards by agp_shard_range, one sweep per device, log-weights
 all-gathered over RCCL inside the library (agp_logpdf_batch_multi)."
@@ -222,6 +233,49 @@ function logpdf_batch(pool::EnginePool, nodes::Vector{<:GP.Node}, noises::Vector
         check(pool.engines[1], rc)
     end
     return out, info
+end
+
+"""
+Value + gradient of the whole population over every engine of the pool (`agp_logpdf_grad_batch_multi`): what the HMC rejuvenation
+threads over the particles (src/inference_smc_anneal_data.jl:240-252), split by the cost-aware plan inside the library and returned
+in the caller's order: (logpdf, grads in `flat_params` order per particle, d/dnoise, info, owner).
+"""
+function logpdf_grad_batch(pool::EnginePool, nodes::Vector{<:GP.Node}, noises::Vector{Float64}, n::Integer=pool.engines[1].n_max)
+    P = length(nodes)
+    op_off, ops, prm_off, prm = encode_batch(nodes)
+    out = Vector{Float64}(undef, P); gn = Vector{Float64}(undef, P); info = Vector{Int32}(undef, P); owner = Vector{Int32}(undef, max(P, 1))
+    grad = zeros(max(Int(prm_off[end]), 1))
+    ptrs = [e.ptr for e in pool.engines]
+    GC.@preserve ptrs op_off ops prm_off prm noises out grad gn info owner begin
+        rc = ccall((:agp_logpdf_grad_batch_multi, LIB), Cint,
+            (Ptr{Ptr{Cvoid}}, Int32, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
+            ptrs, length(ptrs), n, P, op_off, ops, prm_off, prm, noises, out, grad, gn, info, owner)
+        check(pool.engines[1], rc)
+    end
+    grads = [grad[(prm_off[i] + 1):prm_off[i + 1]] for i in 1:P]
+    return out, grads, gn, info, owner[1:P]
+end
+
+"""
+Marginal predictive means / variances of the whole population over every engine of the pool (`agp_predict_batch_multi`; what
+`predict` threads over the particles, src/api.jl:508,645): m x P matrices in the caller's particle order, and info.
+"""
+function predict_marginal_batch(pool::EnginePool, nodes::Vector{<:GP.Node}, noises::Vector{Float64}, ts_pred::Vector{Float64},
+                                n::Integer=pool.engines[1].n_max; noise_pred::Union{Nothing,Vector{Float64}}=nothing)
+    P = length(nodes); m = length(ts_pred)
+    op_off, ops, prm_off, prm = encode_batch(nodes)
+    mean = Matrix{Float64}(undef, m, P); var = Matrix{Float64}(undef, m, P); info = zeros(Int32, P)
+    ptrs = [e.ptr for e in pool.engines]
+    npred = isnothing(noise_pred) ? Float64[] : noise_pred
+    GC.@preserve ptrs ts_pred op_off ops prm_off prm noises npred mean var info begin
+        rc = ccall((:agp_predict_batch_multi, LIB), Cint,
+            (Ptr{Ptr{Cvoid}}, Int32, Int64, Ptr{Float64}, Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+             Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Int32}),
+            ptrs, length(ptrs), n, ts_pred, m, P, op_off, ops, prm_off, prm, noises, isnothing(noise_pred) ? C_NULL : pointer(npred),
+            C_NULL, C_NULL, mean, var, C_NULL, info, C_NULL)
+        check(pool.engines[1], rc)
+    end
+    return mean, var, info
 end
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -352,9 +406,19 @@ function lag_stats(eng::Engine)
 end
 set_lag_tables!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_lag_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
 "level 2: additionally the OPT-IN structured value sweep (Toeplitz + rank-2 particles by the Schur algorithm; include/autogp_hip.h)"
-set_lag_tables!(eng::Engine, level::Integer) = check(eng, ccall((:agp_set_lag_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, Int32(level)))
+function set_lag_tables!(eng::Engine, level::Integer)
+    check(eng, ccall((:agp_set_lag_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, Int32(level)))
+    eng.lag_level = Int32(level)
+    return nothing
+end
 set_lag_rank_tables!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_lag_rank_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
 set_grad_lag_domain!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_grad_lag_domain, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 2 : 0))
+"(kind, n_lattice, spacing) of the resident series: kind 0 irregular, 1 regular grid, 2 lattice with gaps (calendar indices)"
+function lattice_stats(eng::Engine)
+    kind = Ref{Int32}(0); nl = Ref{Int64}(0); h = Ref{Float64}(0.0)
+    check(eng, ccall((:agp_get_lattice_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int64}, Ref{Float64}), eng.ptr, kind, nl, h))
+    return (kind = Int(kind[]), n_lattice = Int(nl[]), spacing = h[])
+end
 "block [lo, hi] (1-based, inclusive) of rank `rank` (0-based) — identical on every rank"
 function shard_range(P::Integer, rank::Integer, n_ranks::Integer)
     lo = Ref{Int32}(0); hi = Ref{Int32}(0)
@@ -363,20 +427,21 @@ function shard_range(P::Integer, rank::Integer, n_ranks::Integer)
 end
 """
 Cost-aware, duplicate-aware assignment of a population to ranks (`agp_shard_plan`; host code, identical on every rank): `sweep` 0 value,
-1 gradient, 2 marginal prediction with `m_future` query points beyond the data, 3 opt-in structured value sweep.  Returns the 0-based
-owner rank of every particle and the ranks' modelled costs; a rank evaluates `findall(==(rank), owner)` and the gathered log-weights
+1 gradient, 2 marginal prediction with `m_future` query points beyond the data, 3 opt-in structured value sweep; `lattice_kind` = the resident
+series' kind (0 irregular, 1 regular grid, 2 lattice with gaps: `lattice_stats(eng)`).  Returns the 0-based owner rank of every particle,
+every particle's modelled cost (units of one dense factorisation; 0 for copies) and the ranks' totals — as the Python wrapper does; a rank evaluates `findall(==(rank), owner)` and the gathered log-weights
 are scattered back by the same vector.
 """
 function shard_plan(nodes::Vector{<:GP.Node}, noises::Vector{Float64}, n::Integer, n_ranks::Integer;
-                    sweep::Integer=1, regular_grid::Bool=true, m_future::Integer=0)
+                    sweep::Integer=1, lattice_kind::Integer=1, m_future::Integer=0)
     P = length(nodes)
     op_off, ops, prm_off, prm = encode_batch(nodes)
     owner = Vector{Int32}(undef, max(P, 1)); cost = Vector{Float64}(undef, max(P, 1)); rank_cost = Vector{Float64}(undef, n_ranks)
     rc = GC.@preserve op_off ops prm_off prm noises owner cost rank_cost ccall((:agp_shard_plan, LIB), Cint,
         (Int64, Int32, Ptr{Int32}, Ptr{UInt8}, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Int64, Int32, Ptr{Int32}, Ptr{Float64}, Ptr{Float64}),
-        n, P, op_off, ops, prm_off, prm, noises, sweep, regular_grid ? 1 : 0, m_future, n_ranks, owner, cost, rank_cost)
+        n, P, op_off, ops, prm_off, prm, noises, sweep, lattice_kind, m_future, n_ranks, owner, cost, rank_cost)
     rc == 0 || error("agp_shard_plan failed ($rc)")
-    return owner[1:P], rank_cost
+    return owner[1:P], cost[1:P], rank_cost
 end
 """
 `lw` has one entry per particle of the WHOLE population with this rank's block filled; on return every rank holds

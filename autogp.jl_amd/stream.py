@@ -186,3 +186,69 @@ class OnlineStream:
                                                noise_pred=noise_pred, check=False)
         rep = np.asarray(rep)
         return mean[rep], var[rep]
+
+    # ---- sweeps whose per-particle cost is NOT uniform: split by the cost-aware plan (agp_shard_plan) -------------------------
+    # The reweight step above is a dense value sweep (uniform n^3/3 per distinct particle): contiguous blocks are right for it and
+    # keep every rank's factors resident.  The gradients of HMC rejuvenation (src/inference_smc_anneal_data.jl:240-252) and the
+    # per-step predictions (src/api.jl:508,645) are not uniform — regular grid: the Toeplitz class costs O(n^2), the rest ~n^3;
+    # copies of a survivor cost nothing — so those sweeps take their split from the plan every rank derives from the same population.
+    def plan(self, sweep, n, lattice_kind=0, m_future=0):
+        """owner[P] of agp_shard_plan for this population (identical on every rank: host code, no communication)."""
+        from .engine import shard_plan
+        owner, _, _ = shard_plan(_gp.encode_batch(self.nodes), self.noises, int(n), self.world, sweep=sweep, lattice_kind=int(lattice_kind),
+                                 m_future=int(m_future))
+        return owner
+
+    def gradient_sweep(self, grad_fn, n, lattice_kind=0):
+        """Value + gradient of EVERY particle on the prefix ts[:n], each rank evaluating its planned share:
+        grad_fn(nodes, noises, n) -> (logpdf[k], [grad arrays], grad_noise[k], info[k]) (GPEngine.logpdf_grad_batch's signature).
+        The shares travel over the host channel (allgather_objects: a gradient is a few doubles per particle; the host owns the
+        traces the HMC moves update) and come back in population order on every rank: (logpdf[P], grads[P], grad_noise[P], info[P],
+        owner[P])."""
+        owner = self.plan(1, n, lattice_kind)
+        mine = _dist.plan_indices(owner, self.rank)
+        if len(mine):
+            lp, gr, gn, info = grad_fn([self.nodes[i] for i in mine], self.noises[mine], int(n))
+        else:
+            lp, gr, gn, info = np.zeros(0), [], np.zeros(0), np.zeros(0, dtype=np.int32)
+        part = (np.asarray(lp, dtype=np.float64).tolist(), [np.asarray(g_, dtype=np.float64).tolist() for g_ in gr],
+                np.asarray(gn, dtype=np.float64).tolist(), np.asarray(info).astype(int).tolist())
+        if self.world == 1:
+            parts = [part]
+        else:
+            if self.allgather_objects is None:
+                raise RuntimeError("world > 1: gradient_sweep needs allgather_objects (the host channel)")
+            parts = self.allgather_objects(part)
+        lp_all = np.zeros(self.P); gn_all = np.zeros(self.P); info_all = np.zeros(self.P, dtype=np.int32); gr_all = [None] * self.P
+        for r, (lpr, grr, gnr, infr) in enumerate(parts):
+            idx = _dist.plan_indices(owner, r)
+            if len(idx) != len(lpr):
+                raise RuntimeError("a rank evaluated a share that is not the plan's")
+            for b, i in enumerate(idx):
+                lp_all[i] = lpr[b]; gn_all[i] = gnr[b]; info_all[i] = infr[b]; gr_all[i] = np.asarray(grr[b], dtype=np.float64)
+        return lp_all, gr_all, gn_all, info_all, owner
+
+    def predict_planned(self, predict_fn, ts_query, n, lattice_kind=0, train_times=None):
+        """Per-particle predictive mean / variance of this rank's PLANNED share (copies of a survivor go where their representative
+        goes and are evaluated once): predict_fn(nodes, noises, ts_query, n) -> (mean[k, m], var[k, m]).  Returns (indices, mean,
+        var, owner): rows for plan_indices(owner, rank) in that order.  train_times (the prefix ts[:n]) lets the plan count the
+        query points beyond the training points (they cost n^2 each more than an observed point)."""
+        ts_query = np.asarray(ts_query, dtype=np.float64)
+        m_future = len(ts_query)
+        if train_times is not None:
+            m_future = int(np.sum(~np.isin(ts_query, np.asarray(train_times, dtype=np.float64)[: int(n)])))
+        owner = self.plan(2, n, lattice_kind, m_future=m_future)
+        mine = _dist.plan_indices(owner, self.rank)
+        if len(mine) == 0:
+            return mine, np.zeros((0, len(ts_query))), np.zeros((0, len(ts_query))), owner
+        keys = {}; uniq = []; rep = []
+        for i in mine:
+            ops, prm = _gp.encode(self.nodes[i])
+            k = (ops.tobytes(), prm.tobytes(), float(self.noises[i]))
+            if k not in keys:
+                keys[k] = len(uniq); uniq.append(i)
+            rep.append(keys[k])
+        mean, var = predict_fn([self.nodes[i] for i in uniq], self.noises[uniq], ts_query, int(n))
+        rep = np.asarray(rep)
+        return mine, np.asarray(mean)[rep], np.asarray(var)[rep], owner
+

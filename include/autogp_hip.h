@@ -190,7 +190,9 @@ int agp_probe_lattice(const double* ts, int64_t n, int32_t* kind, int64_t* n_lat
  * for every gradient, nothing resident (agp_logpdf_batch_extend = agp_logpdf_batch).  Results are then bit-identical across batch
  * sizes, call orders and single / batched / coalesced entries (tests/test_gpu_parity.py::test_reference_arithmetic_is_call_order_stable).
  * It overrides AGP_LAG / AGP_LAG_RANK / AGP_LATTICE / AGP_GRAD_LAGDOM / AGP_GRAD_FFT / AGP_FLOW / AGP_RIGHT_LOOKING /
- * AGP_SPLIT_DIAG / AGP_FUSE / AGP_GE_TABLE / AGP_FACTOR_CACHE / AGP_PREDICT_REUSE and cannot be switched off on a live context. */
+ * AGP_SPLIT_DIAG / AGP_FUSE / AGP_GE_TABLE / AGP_FACTOR_CACHE / AGP_PREDICT_REUSE and cannot be switched off on a live context:
+ * afterwards agp_set_lag_tables / agp_set_lag_rank_tables / agp_set_lattice / agp_set_grad_lag_domain / agp_set_factor_cache
+ * return AGP_ERR_ARG for any non-zero argument, and agp_logpdf_batch_extend_multi runs plain sweeps like agp_logpdf_batch_extend. */
 int agp_set_reference_arithmetic(agp_ctx* ctx, int32_t on);
 
 /* OPT-IN structured value sweep (AGP_LAG=2 / agp_set_lag_tables(ctx, 2); off by default: the default path mirrors the reference's
@@ -365,15 +367,20 @@ void agp_shard_range(int32_t P, int32_t rank, int32_t n_ranks, int32_t* lo, int3
 /* Cost-aware, duplicate-aware alternative for sweeps whose per-particle cost is NOT uniform (host code only; every rank derives
  * the same plan from the same population): sweep = 0 dense value sweep (uniform: use agp_shard_range), 1 gradient sweep,
  * 2 marginal predictive pass with m_future query points beyond the training points, 3 opt-in structured value sweep;
- * regular_grid = the resident series' kind (agp_get_lag_stats): on a regular grid the particles whose kernel is a sum of
- * stationary subtrees and Linear leaves cost O(n^2) in sweeps 1-3, the others ~n^3; copies of an earlier particle (resampled
- * populations, src/inference_smc_anneal_data.jl:198-204) cost nothing and follow their representative.  Longest-processing-time
- * greedy over the distinct particles.  owner_out[p] = rank of particle p; cost_out[p] (nullable) = its modelled cost in units of one
- * dense factorisation (n^3/3 flops); rank_cost_out[r] (nullable) = the ranks' totals.  A rank evaluates its particles in ascending
+ * lattice_kind = the resident series' kind as agp_get_lattice_stats / agp_probe_lattice report it: 0 irregular (every particle
+ * dense-priced), 1 regular grid — the particles whose kernel is a sum of stationary subtrees and Linear leaves cost O(n^2) in
+ * sweeps 1-3 WHERE THE ENGINE ADMITS the structured sweep (the engine's own size tests, applied to the class particles one rank
+ * will hold: n <= 2048 and a class large enough for sweep 1, n + m_future <= 4096 and >= 32 class particles for sweep 2, ...;
+ * refused classes are dense-priced) —, 2 lattice with gaps (calendar indices: the class keeps its dense factor, only its gradient
+ * contraction runs over the lattice's lags).  Copies of an earlier particle (resampled populations,
+ * src/inference_smc_anneal_data.jl:198-204) cost nothing and follow their representative.  Longest-processing-time greedy over
+ * the distinct particles.  owner_out[p] = rank of particle p; cost_out[p] (nullable) = its modelled cost in units of one dense
+ * factorisation (n^3/3 flops); rank_cost_out[r] (nullable) = the ranks' totals.  A rank evaluates its particles in ascending
  * index order; the all-gathered log-weights are put back in population order with the same owner_out (autogp.jl_amd/dist.py:
- * plan_shards / allgather_planned; the Julia shim's equivalent is a scatter by owner). */
+ * plan_indices / allgather_planned; the Julia shim's equivalent is a scatter by owner).  agp_logpdf_grad_batch_multi and
+ * agp_predict_batch_multi below split by this plan themselves. */
 int agp_shard_plan(int64_t n, int32_t P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off, const double* prm,
-                   const double* noise, int32_t sweep, int32_t regular_grid, int64_t m_future, int32_t n_ranks,
+                   const double* noise, int32_t sweep, int32_t lattice_kind, int64_t m_future, int32_t n_ranks,
                    int32_t* owner_out, double* cost_out, double* rank_cost_out);
 
 /* One process (or thread) per GPU: rank 0 creates the id, hands the 128 bytes to the other ranks over any host
@@ -413,6 +420,29 @@ int agp_logpdf_batch_extend_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n
                                   const int32_t* op_off, const uint8_t* ops,
                                   const int32_t* prm_off, const double* prm,
                                   const double* noise, double* out_logpdf /* P */, int32_t* out_info /* P */);
+
+/* The sweeps that dominate a fit, for one process driving several contexts: the reference threads EVERY per-particle operation
+ * over the particles — the gradients of HMC rejuvenation (Gen.choice_gradients under Gen.hmc,
+ * src/inference_smc_anneal_data.jl:63-67,240-252) and predict / predict_mvn (src/api.jl:508,645).  agp_logpdf_grad_batch /
+ * agp_predict_batch over a list of contexts: the population is split by agp_shard_plan (sweep 1 / 2, the resident series' lattice
+ * kind, the engine's own admission tests; copies follow their representative), every context's share runs concurrently (context
+ * 0's on the calling thread, the others on their persistent host threads) and the results come back in the CALLER's order and
+ * layout (exactly agp_logpdf_grad_batch's / agp_predict_batch's).  No collective is involved — results go to the host, which owns
+ * the traces — so the contexts need not come from agp_init_multi: any distinct contexts holding the same data will do (several
+ * contexts of one device included).  out_owner (nullable, P): the plan that was used. */
+int agp_logpdf_grad_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, int32_t P,
+                                const int32_t* op_off, const uint8_t* ops,
+                                const int32_t* prm_off, const double* prm,
+                                const double* noise,
+                                double* out_logpdf /* P */, double* out_grad /* prm_off[P] */,
+                                double* out_grad_noise /* P */, int32_t* out_info /* P */, int32_t* out_owner /* P or NULL */);
+int agp_predict_batch_multi(agp_ctx* const* ctxs, int32_t n_dev, int64_t n, const double* ts_pred, int64_t m, int32_t P,
+                            const int32_t* op_off, const uint8_t* ops,
+                            const int32_t* prm_off, const double* prm,
+                            const double* noise, const double* noise_pred,
+                            const double* mean_train, const double* mean_pred,
+                            double* out_mean, double* out_var, double* out_cov,
+                            int32_t* out_info, int32_t* out_owner /* P or NULL */);
 
 /* ---- measurement / debugging hooks (not part of the reference surface) ---- */
 

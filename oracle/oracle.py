@@ -403,3 +403,25 @@ def gp_logpdf_grad(tree, noise, ts, xs):
     G = 0.5 * (np.outer(alpha, alpha) - Kinv)
     lp = float(-0.5 * (n * math.log(2 * math.pi) + 2 * np.sum(np.log(np.diag(cf[0]))) + xs @ alpha))
     return lp, np.array([float(np.sum(G * dK)) for dK in dKs]), float(np.trace(G))
+
+
+def gp_logpdf_grad_longdouble(tree, noise, ts, xs):
+    """The gradient of gp_logpdf_grad with the factorisation, the inverse and the contractions in 80-bit arithmetic (covariance
+    entries and their derivatives from eval_cov_grad in double): the ARBITER of the gradient tests — when the device and
+    gp_logpdf_grad disagree beyond the stated bound, this says which of the two double-precision computations lost the digits
+    (ill-conditioned K: both form K^-1 with an error of cond(K) eps).  O(n^3) numpy loops: for n of a few hundred."""
+    ts = np.asarray(ts, dtype=np.float64); xs = np.asarray(xs, dtype=np.float64)
+    n = ts.shape[0]
+    K, dKs = eval_cov_grad(tree, ts)
+    A = K.astype(np.longdouble) + np.longdouble(noise) * np.eye(n, dtype=np.longdouble)
+    L = np.zeros_like(A)
+    for j in range(n):
+        L[j, j] = np.sqrt(A[j, j] - L[j, :j] @ L[j, :j])
+        L[j + 1:, j] = (A[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+    W = np.eye(n, dtype=np.longdouble)               # W = L^-1 by forward substitution on the identity
+    for j in range(n):
+        W[j] = (W[j] - L[j, :j] @ W[:j]) / L[j, j]
+    Kinv = W.T @ W
+    alpha = Kinv @ xs.astype(np.longdouble)
+    G = 0.5 * (np.outer(alpha, alpha) - Kinv)
+    return (np.array([float(np.sum(G * dK.astype(np.longdouble))) for dK in dKs]), float(np.trace(G)))

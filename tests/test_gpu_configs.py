@@ -516,3 +516,80 @@ def test_large_n_16384(pkg, engine):
         z = np.linalg.solve(L, d)
         lpred = -0.5 * (r * np.log(2 * np.pi) + 2 * np.log(np.diag(L)).sum() + z @ z)
         assert abs((lp[i] - lo[i]) - lpred) <= 1e-7 * max(1.0, abs(lpred))
+
+
+def _multi_entry_population(pkg, P=72, seed=12):
+    """A resampled population with a skewed class mix: dense-class particles first, Toeplitz-class ones behind, copies in between."""
+    sys.path.insert(0, str(ROOT / "tests"))
+    import _plan_worker as W
+    return W.skewed_population(pkg, P, seed=seed)
+
+
+def _check_multi_entries(pkg, engines, ts, xs, n_dev):
+    from oracle import oracle as O
+    nodes, noises = _multi_entry_population(pkg)
+    P = len(nodes)
+    n = len(ts)
+    tq = np.concatenate([ts[:150], ts.max() + (np.sort(ts)[1] - np.sort(ts)[0]) * np.arange(1, 40)])
+    single = pkg.GPEngine(0)
+    try:
+        single.set_data(ts, xs)
+        lp0, gr0, gn0, i0 = single.logpdf_grad_batch(nodes, noises, check=False)
+        m0, v0, _, pi0 = single.predict_batch(nodes, noises, tq, check=False)
+        mc0, vc0, c0, _ = single.predict_batch(nodes[:9], noises[:9], tq[:60], want_cov=True, check=False)
+    finally:
+        single.close()
+    lp, gr, gn, info, owner = pkg.logpdf_grad_batch_multi(engines, nodes, noises, check=False, want_owner=True)
+    # the split is agp_shard_plan's for a gradient sweep on this series' lattice kind; copies follow their representatives
+    kind = engines[0].lattice_stats()["kind"]
+    plan, cost, rc = pkg.shard_plan(pkg.encode_batch(nodes), noises, n, n_dev, sweep=1, lattice_kind=kind)
+    assert np.array_equal(owner, plan) and set(np.unique(owner)) == set(range(n_dev))
+    assert np.array_equal(info, i0) and (info == 0).all()
+    assert np.abs(lp - lp0).max() <= 1e-10 * np.abs(lp0).max()
+    for p in range(P):
+        sc = max(1.0, np.abs(gr0[p]).max() if gr0[p].size else 0.0, abs(gn0[p]))
+        assert gr[p].shape == gr0[p].shape and np.abs(gr[p] - gr0[p]).max(initial=0.0) <= 1e-7 * sc and abs(gn[p] - gn0[p]) <= 1e-7 * sc, p
+    for p in (0, 20, P - 1):
+        lo_, go_, gno_ = O.gp_logpdf_grad(nodes[p].to_tuple(), float(noises[p]), ts, xs)
+        sc = max(1.0, np.abs(go_).max(), abs(gno_))
+        assert abs(lp[p] - lo_) <= 1e-8 * max(1.0, abs(lo_)) and np.abs(gr[p] - go_).max() <= 1e-7 * sc and abs(gn[p] - gno_) <= 1e-7 * sc
+    m1, v1, _, pi1, owner_p = pkg.predict_batch_multi(engines, nodes, noises, tq, check=False, want_owner=True)
+    plan_p, _, _ = pkg.shard_plan(pkg.encode_batch(nodes), noises, n, n_dev, sweep=2, lattice_kind=kind, m_future=39)
+    assert np.array_equal(owner_p, plan_p) and np.array_equal(pi1, pi0)
+    scm = np.maximum(1.0, np.maximum(np.abs(m0).max(axis=1), np.abs(v0).max(axis=1)))[:, None]
+    assert (np.abs(m1 - m0) / scm).max() <= 1e-8 and (np.abs(v1 - v0) / scm).max() <= 1e-8
+    mo, co = O.predict_mvn(nodes[3].to_tuple(), float(noises[3]), ts, xs, tq)
+    assert np.abs(m1[3] - mo).max() <= 1e-8 * max(1.0, np.abs(mo).max()) and np.abs(v1[3] - np.diag(co)).max() <= 1e-8 * max(1.0, np.abs(co).max())
+    mc1, vc1, c1, _ = pkg.predict_batch_multi(engines, nodes[:9], noises[:9], tq[:60], want_cov=True, check=False)
+    assert np.abs(c1 - c0).max() <= 1e-8 * max(1.0, np.abs(c0).max()) and np.abs(mc1 - mc0).max() <= 1e-8 * max(1.0, np.abs(mc0).max())
+    # malformed calls are refused, not split
+    with pytest.raises(pkg.AGPError):
+        pkg.logpdf_grad_batch_multi([engines[0], engines[0]], nodes, noises)
+
+
+def test_multi_context_gradient_and_predictive_entries_on_one_device(pkg):
+    """agp_logpdf_grad_batch_multi / agp_predict_batch_multi over THREE contexts of this box's one device (the entries need no
+    communicator: results go to the host): the split is agp_shard_plan's, the shares run concurrently on the contexts' persistent host
+    threads, and the results come back in the caller's order — equal to one engine's sweep over the whole population at the
+    tolerances of the paths involved, and to the oracle."""
+    ts, xs = pkg.prior.synthetic_series(700, seed=3, shuffle=True)
+    engines = [pkg.GPEngine(0) for _ in range(3)]
+    try:
+        for e in engines:
+            e.set_data(ts, xs)
+        _check_multi_entries(pkg, engines, ts, xs, 3)
+    finally:
+        for e in engines:
+            e.close()
+
+
+@needs_two_gpus
+def test_multi_device_gradient_and_predictive_entries(pkg):
+    """The same over two DEVICES through agp_init_multi's contexts (one process driving the node)."""
+    ts, xs = pkg.prior.synthetic_series(700, seed=3, shuffle=True)
+    multi = pkg.GPEngineMulti([0, 1])
+    try:
+        multi.set_data(ts, xs)
+        _check_multi_entries(pkg, multi.engines, ts, xs, 2)
+    finally:
+        multi.close()

@@ -21,7 +21,8 @@ def _tool(name):
 
 def test_factor_store_life_cycle_randomised(pkg):
     """Growing prefixes, rejuvenated and copied particles, appended data, resets, chunked workspaces, predictive and gradient calls in
-    between — every result against an engine that keeps nothing (value 1e-9, predictive 1e-7, gradient 2e-6 of the scale)."""
+    between — every result against an engine that keeps nothing (value 1e-9, predictive 1e-8, gradient 1e-7 of the scale; above those the
+    oracle arbitrates: the store-based engine may be no further from it than the bound or 4x the other engine's distance)."""
     msg = _tool("gpu_fuzz_stream").run(pkg, sequences=40, seed=2024)
     assert msg.startswith("stream fuzz ok"), msg
 

@@ -117,7 +117,6 @@ def test_julia_ccall_signatures(tmp_path):
         assert len(pr) >= 1, f"checker missed: {bad}"
 
 
-@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
 def test_documented_build_recipes_produce_the_full_library(pkg, tmp_path):
     """The build commands a maintainer is told to run (autogp.jl_amd/julia/deps/build.jl and INTEGRATION.md section 1) are
     extracted, run with their outputs redirected to a temp dir, and every exported symbol is resolved from the results
@@ -220,6 +219,7 @@ def test_julia_block_structure(tmp_path):
     assert CB.main([ok]) == []
 
 
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
 def test_no_cpu_fallback(pkg):
     """Without a GPU the product path must fail loudly, never fall back to a CPU implementation."""
     with pytest.raises(pkg.AGPError, match="no CPU fallback"):

@@ -62,7 +62,17 @@ def run(pkg, eng, cases=60, seed=1, big=False):
                 lo, go, gno = O.gp_logpdf_grad(nodes[sel[0]].to_tuple(), float(noises[sel[0]]), ts, xs)
                 sc = max(1.0, np.abs(go).max(), abs(gno))
                 eg = max(np.abs(gr[0] - go).max() if go.size else 0.0, abs(gn[0] - gno)) / sc; worst_g = max(worst_g, eg)
-                assert eg <= 1e-6, ("gradient", n, P, eg)
+                if eg > 1e-7 and n <= 1200:
+                    # north_star's bound is 1e-7 of the gradient's scale; above it the 80-bit arbiter decides (device no further from
+                    # it than 1e-7 or 4x the double-precision oracle's own distance)
+                    gl, gnl = O.gp_logpdf_grad_longdouble(nodes[sel[0]].to_tuple(), float(noises[sel[0]]), ts, xs)
+                    ed = max(np.abs(gr[0] - gl).max() if gl.size else 0.0, abs(gn[0] - gnl)) / sc
+                    eo = max(np.abs(go - gl).max() if gl.size else 0.0, abs(gno - gnl)) / sc
+                    assert ed <= max(1e-7, 4.0 * eo), ("gradient", n, P, eg, ed, eo)
+                else:
+                    # (longer series: the arbiter's O(n^3) loops in 80-bit arithmetic take minutes; there the bound is 3e-7, the distance the
+                    # double-precision oracle itself shows from the arbiter on Periodic kernels with hundreds of oscillations)
+                    assert eg <= (1e-7 if n <= 1200 else 3e-7), ("gradient", n, P, eg)
         if n >= 2 and c % 2 == 1:
             # factor store: extension at a random split point, then gradient and predictive sweeps from the resident
             # factors — against the sweeps that factor themselves (computed with an empty store)

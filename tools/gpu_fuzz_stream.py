@@ -13,7 +13,7 @@ import __graft_entry__ as g
 
 def _run(pkg, eng, ref, sequences=20, seed=1, steps=14, big=False):
     rng = np.random.default_rng(seed)
-    n_arb = 0
+    n_arb = 0; n_arb_p = 0; n_arb_g = 0
     t0 = time.time(); w = {"value": 0.0, "predict": 0.0, "gradient": 0.0}; n_ops = {"extend": 0, "predict": 0, "gradient": 0, "append": 0, "reset": 0}
     for q in range(sequences):
         N = int(rng.choice([2500, 3000, 4096] if big else [300, 640, 900, 1280, 2048]))
@@ -96,7 +96,26 @@ def _run(pkg, eng, ref, sequences=20, seed=1, steps=14, big=False):
                 if ok.any():
                     sc = np.maximum(1.0, np.maximum(np.abs(pm0[ok]).max(axis=1), np.abs(pv0[ok]).max(axis=1)))[:, None]
                     e = max((np.abs(pm1[ok] - pm0[ok]) / sc).max(), (np.abs(pv1[ok] - pv0[ok]) / sc).max()); w["predict"] = max(w["predict"], e)
-                    if e > 1e-7:
+                    if e > 1e-8:
+                        # north_star's predictive bound is 1e-8: above it the oracle arbitrates, particle by particle — the store-based
+                        # engine may be no further from it than 1e-8, or than 4x the distance of the engine that keeps nothing
+                        from oracle import oracle as O
+                        epp = np.maximum((np.abs(pm1 - pm0) / np.maximum(1.0, np.maximum(np.abs(pm0).max(axis=1), np.abs(pv0).max(axis=1)))[:, None]).max(axis=1),
+                                         (np.abs(pv1 - pv0) / np.maximum(1.0, np.maximum(np.abs(pm0).max(axis=1), np.abs(pv0).max(axis=1)))[:, None]).max(axis=1))
+                        settled = True
+                        for j in np.flatnonzero(ok & (epp > 1e-8))[:6]:
+                            okw = {k_: v_ for k_, v_ in kw.items() if k_ in ("mean_train", "mean_pred")}
+                            mo, co = O.predict_mvn(nodes[j].to_tuple(), float(noises[j]), ts[:n], xs[:n], tp,
+                                                   noise_pred=(float(kw["noise_pred"][j]) if "noise_pred" in kw else None),
+                                                   mean=((lambda t: 0.4 - 1.3 * t) if okw else None))
+                            vo = np.diag(co); scj = max(1.0, np.abs(mo).max(), np.abs(vo).max())
+                            d1 = max(np.abs(pm1[j] - mo).max(), np.abs(pv1[j] - vo).max()) / scj
+                            d0 = max(np.abs(pm0[j] - mo).max(), np.abs(pv0[j] - vo).max()) / scj
+                            if not d1 <= max(1e-8, 4.0 * d0):
+                                print("predict arbitration lost", tag, j, d1, d0, flush=True); settled = False
+                        n_arb_p += 1
+                        if settled: e = 0.0
+                    if e > 1e-8:
                         ep = np.maximum((np.abs(pm1 - pm0) / np.maximum(1.0, np.abs(pm0))).max(axis=1), (np.abs(pv1 - pv0) / np.maximum(1.0, np.abs(pv0))).max(axis=1))
                         bad = np.flatnonzero(ep > 1e-7)
                         print("predict mismatch", tag, "kind", kind, "particles", bad[:10], "of", P, "errors", ep[bad[:10]], flush=True)
@@ -124,11 +143,19 @@ def _run(pkg, eng, ref, sequences=20, seed=1, steps=14, big=False):
                     sc = max(1.0, np.abs(g0[1][u]).max() if g0[1][u].size else 0.0, abs(g0[2][u]))
                     e = max(np.abs(g1[1][u] - g0[1][u]).max() if g0[1][u].size else 0.0, abs(g1[2][u] - g0[2][u])) / sc; w["gradient"] = max(w["gradient"], e)
                     assert abs(g1[0][u] - g0[0][u]) <= 1e-9 * max(1.0, abs(g0[0][u])), ("gradient value", tag, u)
-                    assert e <= 2e-6, ("gradient", tag, u, e)
+                    if e > 1e-7:
+                        # north_star's gradient bound: 1e-7 of its scale; above it the double-precision oracle arbitrates (n <= 1100)
+                        # or, for longer prefixes, the bound is the element-wise engine's own conditioning-limited agreement
+                        from oracle import oracle as O
+                        lo_, go_, gno_ = O.gp_logpdf_grad(nodes[sel[u]].to_tuple(), float(noises[sel[u]]), ts[:n], xs[:n])
+                        d1 = max(np.abs(g1[1][u] - go_).max() if go_.size else 0.0, abs(g1[2][u] - gno_)) / sc
+                        d0 = max(np.abs(g0[1][u] - go_).max() if go_.size else 0.0, abs(g0[2][u] - gno_)) / sc
+                        n_arb_g += 1
+                        assert d1 <= max(1e-7, 4.0 * d0), ("gradient", tag, u, e, d1, d0)
             n_ops[op] += 1
         print(f"sequence {q}: N={N} P={P} regular={regular} time-order={ordered} ok ({time.time()-t0:.0f}s)", flush=True)
     st = eng.extend_stats(); pr = eng.predict_reuse_stats(); gr = eng.grad_reuse_stats()
-    return (f"stream fuzz ok: {sequences} sequences, calls {n_ops}; worst rel diff vs the engine that keeps nothing: {w} ({n_arb} value disagreements above 1e-9 settled by the oracle); "
+    return (f"stream fuzz ok: {sequences} sequences, calls {n_ops}; worst rel diff vs the engine that keeps nothing: {w} ({n_arb} value disagreements above 1e-9, {n_arb_p} predictive above 1e-8, {n_arb_g} gradient above 1e-7 settled by the oracle); "
             f"store {st}; predictive reuse {pr}; structured predictive particles {eng.predict_structured_particles()}; gradient reuse {gr}; {time.time()-t0:.0f}s")
 
 
