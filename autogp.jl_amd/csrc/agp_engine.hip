@@ -550,7 +550,7 @@ int store_lookup(agp_ctx* c, const std::vector<std::string>& keys, const std::ve
       if (it == fs.index.end()) continue;
       const int sl = it->second;
       if (fs.n_cached[sl] != n || fs.info_h[sl] != 0) continue;
-      src_slot[q] = sl; i0v[q] = nt; fs.stamp[sl] = call; ++n_hit;
+      src_slot[q] = sl; i0v[q] = nt; fs.stamp[sl] = call; fs.used[(size_t)sl] = 1; ++n_hit;
     }
   }
   if (n_hit == 0) lk.unlock();
@@ -1870,7 +1870,11 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
     const bool prefix = c->n_max > 0 && n_max >= c->n_max &&
                         std::memcmp(ts, c->h_ts.data(), sizeof(double) * (size_t)c->n_max) == 0 &&
                         std::memcmp(xs, c->h_xs.data(), sizeof(double) * (size_t)c->n_max) == 0;
-    if (!prefix) c->store.forget();
+    if (!prefix) {
+      c->store.forget(); c->store.evicted_before_reuse = 0;
+      std::lock_guard<std::mutex> q(c->qmu);          // (another series: another population of callers)
+      c->caller_ids.clear(); c->n_callers = 0;
+    }
   }
   const bool lag_was = c->lag_ok, contig_was = c->lag_contig;
   const std::vector<double> tlat_was = c->h_ts_lat;
@@ -2211,6 +2215,7 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
   std::unique_lock<std::mutex> lk(c->qmu);
   c->queue.push_back(&req);
   ++c->arrivals;
+  if (c->caller_ids.size() < 65536 && c->caller_ids.insert(std::this_thread::get_id()).second) c->n_callers = (int)c->caller_ids.size();
   if (c->leader_gathering) c->qcv_leader.notify_one();      // only the gathering leader cares about arrivals
   bool lead = !c->leader_active;
   if (lead) c->leader_active = true;

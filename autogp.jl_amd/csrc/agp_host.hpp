@@ -25,6 +25,7 @@
 #include <system_error>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 using namespace agp;
@@ -228,6 +229,12 @@ struct agp_ctx {
   int batch_prev = 0;                  // size of the batch before the last one
   double last_sweep_us = 0.0;          // duration of the last coalesced sweep
   std::vector<LpRequest*> queue;
+  // distinct threads that have called the single-particle entries since the last agp_set_data / agp_extend_reset (qmu): the
+  // reference runs ONE particle per thread at a time (Threads.@threads, src/inference_smc_anneal_data.jl:133,240), each through
+  // update -> choice_gradients at the same parameters — so this many factors are waiting for their gradient call at any time,
+  // however small the coalesced batches are.  The factor store sizes itself by it (extend_impl).
+  std::unordered_set<std::thread::id> caller_ids;
+  std::atomic<int> n_callers{0};
   bool leader_active = false;
   int coalesce_us = 2000;    // upper bound of a leader's wait for followers (it also never exceeds a quarter of the
                              // last sweep's duration); 0 = every call runs alone (env AGP_COALESCE_US)
@@ -251,14 +258,16 @@ struct agp_ctx {
     std::vector<int64_t> n_cached;      // observations the slot's factor covers
     std::vector<uint64_t> stamp;        // last use (LRU)
     std::vector<int32_t> info_h;        // host copy of the slot's LAPACK info (a predictive pass only reuses info == 0)
+    std::vector<uint8_t> used;          // the slot's factor has been STARTED FROM since it was stored (extension, gradient or predictive sweep)
+    int64_t evicted_before_reuse = 0;   // factors dropped for room that nothing ever started from (see agp_extend_stats2)
     std::unordered_map<std::string, int> index;
     uint64_t clock = 0;
     int64_t hits = 0, misses = 0, tile_rows_reused = 0, tile_rows_total = 0;
     double max_frac = 0.45;             // share of the device memory the store may take
     std::atomic<size_t> footprint{0};   // bytes the store holds right now (read by ws_limit_bytes without the lock)
     size_t failed_bytes = 0;            // size of the last (re)allocation that failed: not retried at that size or above
-    void forget() { failed_bytes = 0; index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); std::fill(zrows.begin(), zrows.end(), 0); }
-    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); z_release(); zrows.clear(); n_slots = 0; nt_cap = 0; footprint = 0; failed_bytes = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); }
+    void forget() { failed_bytes = 0; index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); std::fill(zrows.begin(), zrows.end(), 0); std::fill(used.begin(), used.end(), 0); }
+    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); z_release(); zrows.clear(); n_slots = 0; nt_cap = 0; footprint = 0; failed_bytes = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); used.clear(); }
   } store;
   // ---- RCCL communicator of the particle-sharded deployment (agp_comm_init_rank / agp_init_multi) ----
   ncclComm_t comm = nullptr;

@@ -75,7 +75,7 @@ int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
     if (!fs.key[sl].empty()) fs.index.erase(fs.key[sl]);
   fs.key.resize((size_t)n_slots); fs.n_cached.resize((size_t)n_slots, 0); fs.stamp.resize((size_t)n_slots, 0);
   fs.z_release(); fs.zrows.assign((size_t)n_slots, 0);          // (the resident L^-T does not survive a resize: rare, rebuilt on demand)
-  fs.info_h.resize((size_t)n_slots, 0);
+  fs.info_h.resize((size_t)n_slots, 0); fs.used.resize((size_t)n_slots, 0);
   fs.nt_cap = nt_cap; fs.n_slots = n_slots; fs.strideA = strideA;
   fs.footprint = A.cap + W.cap + vec.cap + partial.cap + info.cap + ready.cap + fs.tflag.cap + fs.flowq.cap;
   return AGP_OK;
@@ -160,8 +160,11 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   {
     // capacity: slots sized for the resident data, at least as many as this population (twice, so that a population
     // mid-rejuvenation keeps its previous states), within the store's share of device memory
+    // ... and at least twice the number of threads that drive the single-particle entries: their calls are coalesced into batches
+    // of whatever size the arrival times give, while EVERY thread's value factor waits for its gradient call (HMC leapfrog) — a
+    // store sized by the batch alone evicted a population's factors between update and choice_gradients (NOTES round 5)
     const int want_nt = std::max(fs.nt_cap, std::max(nt, round_up(c->n_max, NB) / NB));
-    int want_slots = std::max(fs.n_slots.load(), std::max(2 * U, 32));
+    int want_slots = std::max(fs.n_slots.load(), std::max(std::max(2 * U, 2 * c->n_callers.load()), 32));
     if (want_slots > fs.n_slots && fs.n_slots > 0) want_slots = std::max(want_slots, fs.n_slots + fs.n_slots / 2);   // (growth copies the store: few, larger steps)
     const size_t budget = (size_t)(fs.max_frac * (double)c->total_mem);
     const size_t per = store_bytes_per_slot(want_nt);
@@ -180,6 +183,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     slot[u] = sl; fs.stamp[sl] = call;
     const int64_t nc = fs.n_cached[sl];
     i0[u] = nc == n ? nt : (nc < n ? (int32_t)(nc / NB) : 0);     // a factor of a LONGER prefix is redone
+    if (i0[u] > 0) fs.used[(size_t)sl] = 1;
     rows_reused += i0[u];
   }
   {
@@ -194,8 +198,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     for (int u = 0; u < U; ++u) {
       if (slot[u] >= 0) continue;
       const int sl = cand[ci++];                  // ci < cand.size(): n_slots >= U
-      if (!fs.key[sl].empty()) fs.index.erase(fs.key[sl]);
-      fs.key[sl].clear(); fs.n_cached[sl] = 0; fs.stamp[sl] = call;
+      if (!fs.key[sl].empty()) { fs.index.erase(fs.key[sl]); if (!fs.used[(size_t)sl]) ++fs.evicted_before_reuse; }
+      fs.key[sl].clear(); fs.n_cached[sl] = 0; fs.stamp[sl] = call; fs.used[(size_t)sl] = 0;
       slot[u] = sl; i0[u] = 0;
     }
   }
@@ -352,6 +356,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   for (int u = 0; u < U; ++u) {
     const int sl = slot[u];
     fs.key[sl] = keys[u]; fs.index[keys[u]] = sl; fs.n_cached[sl] = n; fs.info_h[sl] = hinfo[u];
+    if (i0[u] == 0) fs.used[(size_t)sl] = 0;          // a fresh factor: nothing has started from it yet
     if (i0[u] > 0) ++fs.hits; else ++fs.misses;
   }
   fs.tile_rows_reused += rows_reused; fs.tile_rows_total += (int64_t)U * nt;
@@ -386,6 +391,20 @@ int agp_extend_stats(agp_ctx* c, int64_t* out4) {
   if (!c || !out4) return fail(c, AGP_ERR_ARG, "null pointer");
   std::lock_guard<std::mutex> g(c->store.mu);
   out4[0] = c->store.hits; out4[1] = c->store.misses; out4[2] = c->store.tile_rows_reused; out4[3] = c->store.tile_rows_total;
+  return AGP_OK;
+}
+
+int agp_extend_stats2(agp_ctx* c, int64_t* out, int32_t n_out) {
+  if (!c || !out || n_out < 0) return fail(c, AGP_ERR_ARG, "null pointer");
+  int64_t v[8];
+  {
+    std::lock_guard<std::mutex> g(c->store.mu);
+    v[0] = c->store.hits; v[1] = c->store.misses; v[2] = c->store.tile_rows_reused; v[3] = c->store.tile_rows_total;
+    v[4] = c->store.evicted_before_reuse; v[5] = c->store.n_slots.load(); v[6] = c->n_callers.load();
+    v[7] = 0;
+    for (const std::string& k : c->store.key) v[7] += k.empty() ? 0 : 1;
+  }
+  for (int i = 0; i < n_out && i < 8; ++i) out[i] = v[i];
   return AGP_OK;
 }
 
@@ -512,6 +531,8 @@ int agp_extend_reset(agp_ctx* c, int release_memory) {
   std::lock_guard<std::mutex> g(c->store.mu);
   if (release_memory) { HIPCHK(c, hipDeviceSynchronize()); c->store.release(); }
   else c->store.forget();
+  c->store.evicted_before_reuse = 0;
+  { std::lock_guard<std::mutex> q(c->qmu); c->caller_ids.clear(); c->n_callers = 0; }
   return AGP_OK;
 }
 

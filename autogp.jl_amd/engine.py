@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = [
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi", "agp_logpdf_batch_extend_multi",
     "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
     "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_get_lattice_stats", "agp_set_lattice", "agp_probe_lattice", "agp_set_reference_arithmetic", "agp_shard_plan", "agp_get_coalesce_timing", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_predict_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
-    "agp_logpdf_grad_batch_multi", "agp_predict_batch_multi",
+    "agp_logpdf_grad_batch_multi", "agp_predict_batch_multi", "agp_extend_stats2",
 ]
 COMM_ID_BYTES = 128
 
@@ -130,6 +130,7 @@ def load_library(path=None):
     lib.agp_debug_compact_shards.argtypes = [vp, dp, C.c_int32, C.c_int32, dp]; lib.agp_debug_compact_shards.restype = C.c_int
     lib.agp_extend_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_extend_stats.restype = C.c_int
     lib.agp_extend_reset.argtypes = [vp, C.c_int]; lib.agp_extend_reset.restype = C.c_int
+    lib.agp_extend_stats2.argtypes = [vp, C.POINTER(C.c_int64), C.c_int32]; lib.agp_extend_stats2.restype = C.c_int
     lib.agp_predict_reuse_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_predict_reuse_stats.restype = C.c_int
     lib.agp_grad_reuse_stats.argtypes = [vp, C.POINTER(C.c_int64)]; lib.agp_grad_reuse_stats.restype = C.c_int
     lib.agp_set_factor_cache.argtypes = [vp, C.c_int32]; lib.agp_set_factor_cache.restype = C.c_int
@@ -340,10 +341,12 @@ class GPEngine:
         return out, info
 
     def extend_stats(self):
-        """dict(extended, from_scratch, tile_rows_reused, tile_rows_total)."""
-        out = (C.c_int64 * 4)()
-        self._check(self._lib.agp_extend_stats(self._ctx, out))
-        return dict(zip(("extended", "from_scratch", "tile_rows_reused", "tile_rows_total"), [int(v) for v in out]))
+        """dict(extended, from_scratch, tile_rows_reused, tile_rows_total, evicted_before_reuse, slots, callers, occupied)
+        (agp_extend_stats2)."""
+        out = (C.c_int64 * 8)()
+        self._check(self._lib.agp_extend_stats2(self._ctx, out, 8))
+        return dict(zip(("extended", "from_scratch", "tile_rows_reused", "tile_rows_total", "evicted_before_reuse", "slots", "callers", "occupied"),
+                        [int(v) for v in out]))
 
     def predict_reuse_stats(self):
         """dict(reused, factored): particles a predictive pass served from a resident factor / factored itself."""

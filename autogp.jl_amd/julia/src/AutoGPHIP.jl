@@ -176,6 +176,14 @@ end
 
 "(particles a predictive call served from a resident factor, particles whose K11 it factored itself): after
 `logpdf_batch(...; extend=true)` on a prefix, `predict_marginal` / `predict_mvn` on the same prefix reuse L11 and alpha."
+"(extended, from_scratch, tile_rows_reused, tile_rows_total, evicted_before_reuse, slots, callers, occupied) of the factor store"
+function extend_stats(eng::Engine)
+    out = zeros(Int64, 8)
+    GC.@preserve out check(eng, ccall((:agp_extend_stats2, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}, Int32), eng.ptr, out, 8))
+    return (extended = out[1], from_scratch = out[2], tile_rows_reused = out[3], tile_rows_total = out[4],
+            evicted_before_reuse = out[5], slots = out[6], callers = out[7], occupied = out[8])
+end
+
 function predict_reuse_stats(eng::Engine)
     out = Vector{Int64}(undef, 2)
     GC.@preserve out check(eng, ccall((:agp_predict_reuse_stats, LIB), Cint, (Ptr{Cvoid}, Ptr{Int64}), eng.ptr, out))

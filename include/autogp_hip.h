@@ -115,12 +115,21 @@ int agp_logpdf_batch_extend(agp_ctx* ctx, int64_t n, int32_t P,
 /* out4 = { particles extended from a resident factor, particles factored from scratch,
  *          tile rows reused, tile rows a from-scratch sweep would have computed } since agp_init / the last reset */
 int agp_extend_stats(agp_ctx* ctx, int64_t* out4);
+/* The same and more, up to n_out <= 8 values: out[0..3] as agp_extend_stats; out[4] = evicted_before_reuse — factors dropped for room
+ * that no sweep ever started from (no extension, gradient or predictive call found them first): 0 in a healthy run of
+ * update -> choice_gradients pairs; a growing count beside gradient sweeps that factor from scratch (agp_grad_reuse_stats) says the
+ * store is too small for the population (factors of REJECTED moves, which nothing comes back for, count too); out[5] = slots the store
+ * holds; out[6] = distinct threads seen by the single-particle entries since the last agp_set_data of another series /
+ * agp_extend_reset; out[7] = occupied slots. */
+int agp_extend_stats2(agp_ctx* ctx, int64_t* out, int32_t n_out);
 /* forget every resident factor (release_memory != 0 also frees the store) */
 int agp_extend_reset(agp_ctx* ctx, int release_memory);
-/* pre-size the store for series of up to n_cap observations and n_slots particles.  Optional for batch callers (the store grows
- * on demand to twice the largest batch, keeping its contents).  RECOMMENDED for the single-particle entries: agp_logpdf calls are
- * coalesced into batches of whatever size the callers' arrival times give, so a population larger than twice those batches would
- * evict its own factors between the value and the gradient call — reserve 2 x num_particles slots (the shim does). */
+/* pre-size the store for series of up to n_cap observations and n_slots particles.  OPTIONAL: the store sizes itself — it grows on
+ * demand (keeping its contents, within its 45 % share of device memory) to twice the largest batch AND to twice the number of
+ * distinct threads that have called the single-particle entries (agp_logpdf / agp_logpdf_grad are coalesced into batches of
+ * whatever size the callers' arrival times give, while every thread's value factor waits for its gradient call: sized by the batch
+ * alone, a population arriving in small batches evicted its own factors between update and choice_gradients).  Reserving up front
+ * only saves the growth copies of the first sweeps.  agp_extend_stats2 shows the outcome (evicted_before_reuse, slots, callers). */
 int agp_extend_reserve(agp_ctx* ctx, int64_t n_cap, int32_t n_slots);
 /* The predictive entries consult the same store: a particle whose factor of exactly the prefix n is resident (the
  * per-step callback of the streaming workload predicts right after the reweight: scripts/online.jl:43,59 ->

@@ -44,12 +44,13 @@ def test_sizes_and_schedules_randomised(pkg):
     assert msg.startswith("fuzz ok"), msg
 
 
-def _native(name, *args):
+def _native(name, *args, env_extra=None):
     """Run a native driver of the C ABI (tools/native/*.cpp, built by __graft_entry__.build()) and parse its JSON line."""
     import json, os, subprocess
     exe = ROOT / "tools" / "native" / name
     assert exe.exists(), f"{exe} missing: __graft_entry__.build() compiles the native drivers"
     env = dict(os.environ)
+    env.update(env_extra or {})
     env["LD_LIBRARY_PATH"] = str(ROOT / "autogp.jl_amd" / "lib") + ":" + env.get("LD_LIBRARY_PATH", "")
     pr = subprocess.run([str(exe)] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
     lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
@@ -84,3 +85,19 @@ def test_class_aware_pairs_randomised(pkg):
     forced / heuristic size tests, reserved / unreserved stores, three leapfrog steps each — against the default engine's batch entry."""
     msg = _tool("gpu_fuzz_pairs").run(pkg, cases=25, seed=2024)
     assert msg.startswith("pairs fuzz ok"), msg
+
+
+def test_factor_store_sizes_itself_for_small_batches():
+    """A population of 256 threads whose single-particle calls are coalesced into SMALL batches (20 us window) and that never
+    announces itself (no agp_extend_reserve): the store must size itself by the distinct callers — no factor may be dropped before
+    the gradient call of its own leapfrog step came for it (agp_extend_stats2: evicted_before_reuse == 0), and the gradient sweeps
+    start from resident factors as in the reserved run."""
+    r = _native("hmc_replay", 512, 256, 2, 10, 0.02, env_extra={"HMC_WINDOW_US": "20"})
+    assert r["api_errors"] == 0 and r["store_reserved"] is False
+    assert r["store_callers_seen"] == 256 and r["store_slots"] >= 2 * 256, r
+    assert r["evicted_before_reuse"] == 0, r
+    assert r["mean_batch"] < 200, r                       # (the premise: batches well below the population)
+    assert r["gradient_particles_from_resident_factor"] >= 0.9 * r["value_calls"], r
+    rr = _native("hmc_replay", 512, 256, 2, 10, 0.02, env_extra={"HMC_WINDOW_US": "20", "HMC_RESERVE": "1"})
+    assert rr["evicted_before_reuse"] == 0 and rr["store_reserved"] is True
+    assert r["gradient_particles_factored"] <= rr["gradient_particles_factored"] + 0.02 * r["value_calls"], (r, rr)

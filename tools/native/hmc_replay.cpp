@@ -149,6 +149,12 @@ int main(int argc, char** argv) {
     for (int i = 0; i < n; ++i) { ts[i] = slope * ux[perm[i]] + icpt; xs[i] = 0.5 * std::sin(12.0 * ts[i]) + 0.3 * nrm(g); }
   }
   if (agp_set_data(ctx, ts.data(), xs.data(), n) != 0) { fprintf(stderr, "set_data: %s\n", agp_last_error(ctx)); return 1; }
+  // HMC_WINDOW_US: the coalescing window (small windows -> many small batches: what a population of slow host threads produces);
+  // HMC_RESERVE=1: announce the population to the factor store up front (agp_extend_reserve(n, 2 T)) — optional since round 6,
+  // the store sizes itself by the distinct calling threads; the pair is how the self-sizing is measured
+  if (const char* w = getenv("HMC_WINDOW_US")) agp_set_coalesce_window(ctx, atoi(w));
+  const char* rsv = getenv("HMC_RESERVE");
+  if (rsv && atoi(rsv) != 0 && agp_extend_reserve(ctx, n, 2 * T) != 0) { fprintf(stderr, "reserve: %s\n", agp_last_error(ctx)); return 1; }
   std::vector<Particle> ps(T);
   for (auto& p : ps) { gen_tree(g, 2, p); p.noise = 0.05 + 0.3 * u(g); }
   Counters cnt;
@@ -187,11 +193,14 @@ int main(int argc, char** argv) {
   agp_get_grad_lag_domain_stats(ctx, &n_lagdom);
   agp_get_toeplitz_stats(ctx, &n_schur);          // value calls scored by the Schur recursion (opt-in level AGP_LAG >= 2)
   agp_get_grad_structured_stats(ctx, &n_sgrad);   // gradient particles differentiated without any dense factor
-  printf("{\"tool\": \"hmc_replay\", \"time_points\": \"%s\", \"gradient_particles_in_lag_domain\": %lld, \"value_particles_by_schur_recursion\": %lld, \"gradient_particles_without_dense_factor\": %lld, \"factor_cache\": %s, \"gradient_particles_from_resident_factor\": %lld, \"gradient_particles_factored\": %lld, "
+  int64_t st8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  agp_extend_stats2(ctx, st8, 8);
+  printf("{\"tool\": \"hmc_replay\", \"store_reserved\": %s, \"store_slots\": %lld, \"store_callers_seen\": %lld, \"evicted_before_reuse\": %lld, \"time_points\": \"%s\", \"gradient_particles_in_lag_domain\": %lld, \"value_particles_by_schur_recursion\": %lld, \"gradient_particles_without_dense_factor\": %lld, \"factor_cache\": %s, \"gradient_particles_from_resident_factor\": %lld, \"gradient_particles_factored\": %lld, "
          "\"n\": %d, \"threads\": %d, \"hmc_iterations_per_particle\": %d, \"L\": %d, \"eps\": %g, "
          "\"seconds\": %.4f, \"hmc_iterations_per_s\": %.2f, \"seconds_per_iteration_of_the_population\": %.4f, "
          "\"gradient_calls\": %lld, \"value_calls\": %lld, \"calls_per_s\": %.1f, \"coalesced_batches\": %lld, \"mean_batch\": %.1f, "
          "\"leader_wait_ms\": %.1f, \"value_sweeps_ms\": %.1f, \"gradient_sweeps_ms\": %.1f, \"handback_ms\": %.1f, \"accepted_param_moves\": %lld, \"api_errors\": %lld, \"not_positive_definite\": %lld, \"non_finite\": %lld}\n",
+         (rsv && atoi(rsv) != 0) ? "true" : "false", (long long)st8[5], (long long)st8[6], (long long)st8[4],
          grid ? "regular grid, shuffled" : monthly ? "month starts (calendar index), shuffled" : "irregular", (long long)n_lagdom, (long long)n_schur, (long long)n_sgrad, (fc && atoi(fc) == 0) ? "false" : "true", (long long)gr[0], (long long)gr[1],
          n, T, iters, L, eps, dt, it_total / dt, dt / iters, cnt.grad.load(), cnt.value.load(),
          (double)(cnt.grad.load() + cnt.value.load()) / dt, (long long)(b1 - b0),
