@@ -547,7 +547,7 @@ int store_lookup(agp_ctx* c, const std::vector<std::string>& keys, const std::ve
     const uint64_t call = ++fs.clock;
     for (int q = 0; q < P; ++q) {
       auto it = fs.index.find(keys[(size_t)order[q]]);
-      if (it == fs.index.end()) continue;
+      if (it == fs.index.end()) { fs.ghost_probe(keys[(size_t)order[q]]); continue; }
       const int sl = it->second;
       if (fs.n_cached[sl] != n || fs.info_h[sl] != 0) continue;
       src_slot[q] = sl; i0v[q] = nt; fs.stamp[sl] = call; fs.used[(size_t)sl] = 1; ++n_hit;
@@ -1871,7 +1871,7 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
                         std::memcmp(ts, c->h_ts.data(), sizeof(double) * (size_t)c->n_max) == 0 &&
                         std::memcmp(xs, c->h_xs.data(), sizeof(double) * (size_t)c->n_max) == 0;
     if (!prefix) {
-      c->store.forget(); c->store.evicted_before_reuse = 0;
+      c->store.forget(); c->store.ghost_clear();
       std::lock_guard<std::mutex> q(c->qmu);          // (another series: another population of callers)
       c->caller_ids.clear(); c->n_callers = 0;
     }

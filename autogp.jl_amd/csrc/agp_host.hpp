@@ -24,6 +24,7 @@
 #include <string>
 #include <system_error>
 #include <thread>
+#include <deque>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -259,7 +260,19 @@ struct agp_ctx {
     std::vector<uint64_t> stamp;        // last use (LRU)
     std::vector<int32_t> info_h;        // host copy of the slot's LAPACK info (a predictive pass only reuses info == 0)
     std::vector<uint8_t> used;          // the slot's factor has been STARTED FROM since it was stored (extension, gradient or predictive sweep)
-    int64_t evicted_before_reuse = 0;   // factors dropped for room that nothing ever started from (see agp_extend_stats2)
+    // Factors dropped for room that nothing had started from, remembered by key (bounded FIFO): a later lookup that finds its key
+    // HERE is the cliff a too-small store falls off — the gradient call of a leapfrog step refactoring what the value call before it
+    // had just computed.  evicted_before_reuse counts those lookups (agp_extend_stats2); factors nobody comes back for (the end of a
+    // move, rejected proposals) leave the list silently.
+    std::unordered_set<std::string> ghost;
+    std::deque<std::string> ghost_fifo;
+    int64_t evicted_before_reuse = 0;
+    void ghost_add(const std::string& k) {
+      if (ghost.insert(k).second) ghost_fifo.push_back(k);
+      while (ghost_fifo.size() > 8192) { ghost.erase(ghost_fifo.front()); ghost_fifo.pop_front(); }
+    }
+    void ghost_probe(const std::string& k) { if (!ghost.empty() && ghost.erase(k)) ++evicted_before_reuse; }
+    void ghost_clear() { ghost.clear(); ghost_fifo.clear(); evicted_before_reuse = 0; }
     std::unordered_map<std::string, int> index;
     uint64_t clock = 0;
     int64_t hits = 0, misses = 0, tile_rows_reused = 0, tile_rows_total = 0;

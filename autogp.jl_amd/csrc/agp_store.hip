@@ -164,7 +164,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     // of whatever size the arrival times give, while EVERY thread's value factor waits for its gradient call (HMC leapfrog) — a
     // store sized by the batch alone evicted a population's factors between update and choice_gradients (NOTES round 5)
     const int want_nt = std::max(fs.nt_cap, std::max(nt, round_up(c->n_max, NB) / NB));
-    int want_slots = std::max(fs.n_slots.load(), std::max(std::max(2 * U, 2 * c->n_callers.load()), 32));
+    static const bool self_size = [] { const char* e = getenv("AGP_STORE_SELF_SIZE"); return !(e && atoi(e) == 0); }();      // (0: round 5's rule, for A/B runs)
+    int want_slots = std::max(fs.n_slots.load(), std::max(std::max(2 * U, self_size ? 2 * c->n_callers.load() : 0), 32));
     if (want_slots > fs.n_slots && fs.n_slots > 0) want_slots = std::max(want_slots, fs.n_slots + fs.n_slots / 2);   // (growth copies the store: few, larger steps)
     const size_t budget = (size_t)(fs.max_frac * (double)c->total_mem);
     const size_t per = store_bytes_per_slot(want_nt);
@@ -178,7 +179,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   int64_t rows_reused = 0;
   for (int u = 0; u < U; ++u) {
     auto it = fs.index.find(keys[u]);
-    if (it == fs.index.end()) continue;
+    if (it == fs.index.end()) { fs.ghost_probe(keys[u]); continue; }
     const int sl = it->second;
     slot[u] = sl; fs.stamp[sl] = call;
     const int64_t nc = fs.n_cached[sl];
@@ -198,7 +199,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     for (int u = 0; u < U; ++u) {
       if (slot[u] >= 0) continue;
       const int sl = cand[ci++];                  // ci < cand.size(): n_slots >= U
-      if (!fs.key[sl].empty()) { fs.index.erase(fs.key[sl]); if (!fs.used[(size_t)sl]) ++fs.evicted_before_reuse; }
+      if (!fs.key[sl].empty()) { fs.index.erase(fs.key[sl]); if (!fs.used[(size_t)sl]) fs.ghost_add(fs.key[sl]); }
       fs.key[sl].clear(); fs.n_cached[sl] = 0; fs.stamp[sl] = call; fs.used[(size_t)sl] = 0;
       slot[u] = sl; i0[u] = 0;
     }
@@ -531,7 +532,7 @@ int agp_extend_reset(agp_ctx* c, int release_memory) {
   std::lock_guard<std::mutex> g(c->store.mu);
   if (release_memory) { HIPCHK(c, hipDeviceSynchronize()); c->store.release(); }
   else c->store.forget();
-  c->store.evicted_before_reuse = 0;
+  c->store.ghost_clear();
   { std::lock_guard<std::mutex> q(c->qmu); c->caller_ids.clear(); c->n_callers = 0; }
   return AGP_OK;
 }

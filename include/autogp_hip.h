@@ -115,12 +115,12 @@ int agp_logpdf_batch_extend(agp_ctx* ctx, int64_t n, int32_t P,
 /* out4 = { particles extended from a resident factor, particles factored from scratch,
  *          tile rows reused, tile rows a from-scratch sweep would have computed } since agp_init / the last reset */
 int agp_extend_stats(agp_ctx* ctx, int64_t* out4);
-/* The same and more, up to n_out <= 8 values: out[0..3] as agp_extend_stats; out[4] = evicted_before_reuse — factors dropped for room
- * that no sweep ever started from (no extension, gradient or predictive call found them first): 0 in a healthy run of
- * update -> choice_gradients pairs; a growing count beside gradient sweeps that factor from scratch (agp_grad_reuse_stats) says the
- * store is too small for the population (factors of REJECTED moves, which nothing comes back for, count too); out[5] = slots the store
- * holds; out[6] = distinct threads seen by the single-particle entries since the last agp_set_data of another series /
- * agp_extend_reset; out[7] = occupied slots. */
+/* The same and more, up to n_out <= 8 values: out[0..3] as agp_extend_stats; out[4] = evicted_before_reuse — lookups (extension,
+ * gradient or predictive sweeps) whose factor HAD been resident and was dropped for room before anything started from it: the cliff
+ * of a store too small for its population (the gradient call of a leapfrog step refactoring what the value call before it had just
+ * computed).  0 in a healthy run; factors nobody comes back for (the last state of a move, rejected proposals) are not counted.  The
+ * library remembers the last 8192 such keys.  out[5] = slots the store holds; out[6] = distinct threads seen by the single-particle
+ * entries since the last agp_set_data of another series / agp_extend_reset; out[7] = occupied slots. */
 int agp_extend_stats2(agp_ctx* ctx, int64_t* out, int32_t n_out);
 /* forget every resident factor (release_memory != 0 also frees the store) */
 int agp_extend_reset(agp_ctx* ctx, int release_memory);

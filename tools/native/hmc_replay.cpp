@@ -57,6 +57,15 @@ struct Counters {
   }
 };
 
+// HMC_JITTER_US: every call is preceded by a random host-side pause of up to that many microseconds — the arrival pattern of slow
+// host threads (Julia tasks doing trace bookkeeping, Python threads under the GIL): the coalescer then forms many SMALL batches
+static int g_jitter_us = 0;
+static void host_pause() {
+  if (g_jitter_us <= 0) return;
+  thread_local std::mt19937 r((unsigned)std::hash<std::thread::id>()(std::this_thread::get_id()));
+  std::this_thread::sleep_for(std::chrono::microseconds(r() % (unsigned)g_jitter_us));
+}
+
 // value + gradient w.r.t. q = log(theta) (and log noise)
 static bool eval_grad(agp_ctx* ctx, int n, const Particle& p, const std::vector<double>& q, double qn, double* lp,
                       std::vector<double>& gq, double* gqn, Counters& c) {
@@ -65,6 +74,7 @@ static bool eval_grad(agp_ctx* ctx, int n, const Particle& p, const std::vector<
   const double nz = std::exp(qn);
   std::vector<double> g(q.size() + 1, 0.0);
   double gn = 0.0; int32_t info = 0;
+  host_pause();
   const int rc = agp_logpdf_grad(ctx, n, p.ops.data(), (int32_t)p.ops.size(), th.data(), (int32_t)th.size(), nz, lp, g.data(), &gn, &info);
   c.grad.fetch_add(1);
   if (!c.classify(rc, info, *lp)) return false;
@@ -76,6 +86,7 @@ static bool eval_value(agp_ctx* ctx, int n, const Particle& p, const std::vector
   std::vector<double> th(q.size());
   for (size_t i = 0; i < q.size(); ++i) th[i] = std::exp(q[i]);
   int32_t info = 0;
+  host_pause();
   const int rc = agp_logpdf(ctx, n, p.ops.data(), (int32_t)p.ops.size(), th.data(), (int32_t)th.size(), std::exp(qn), lp, &info);
   c.value.fetch_add(1);
   return c.classify(rc, info, *lp);
@@ -153,6 +164,7 @@ int main(int argc, char** argv) {
   // HMC_RESERVE=1: announce the population to the factor store up front (agp_extend_reserve(n, 2 T)) — optional since round 6,
   // the store sizes itself by the distinct calling threads; the pair is how the self-sizing is measured
   if (const char* w = getenv("HMC_WINDOW_US")) agp_set_coalesce_window(ctx, atoi(w));
+  if (const char* j = getenv("HMC_JITTER_US")) g_jitter_us = atoi(j);
   const char* rsv = getenv("HMC_RESERVE");
   if (rsv && atoi(rsv) != 0 && agp_extend_reserve(ctx, n, 2 * T) != 0) { fprintf(stderr, "reserve: %s\n", agp_last_error(ctx)); return 1; }
   std::vector<Particle> ps(T);
