@@ -260,6 +260,7 @@ struct agp_ctx {
     std::vector<uint64_t> stamp;        // last use (LRU)
     std::vector<int32_t> info_h;        // host copy of the slot's LAPACK info (a predictive pass only reuses info == 0)
     std::vector<uint8_t> used;          // the slot's factor has been STARTED FROM since it was stored (extension, gradient or predictive sweep)
+    std::vector<uint64_t> born;         // clock of the sweep that stored the slot's factor from scratch
     // Factors dropped for room that nothing had started from, remembered by key (bounded FIFO): a later lookup that finds its key
     // HERE is the cliff a too-small store falls off — the gradient call of a leapfrog step refactoring what the value call before it
     // had just computed.  evicted_before_reuse counts those lookups (agp_extend_stats2); factors nobody comes back for (the end of a
@@ -279,8 +280,8 @@ struct agp_ctx {
     double max_frac = 0.45;             // share of the device memory the store may take
     std::atomic<size_t> footprint{0};   // bytes the store holds right now (read by ws_limit_bytes without the lock)
     size_t failed_bytes = 0;            // size of the last (re)allocation that failed: not retried at that size or above
-    void forget() { failed_bytes = 0; index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); std::fill(zrows.begin(), zrows.end(), 0); std::fill(used.begin(), used.end(), 0); }
-    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); z_release(); zrows.clear(); n_slots = 0; nt_cap = 0; footprint = 0; failed_bytes = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); used.clear(); }
+    void forget() { failed_bytes = 0; index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); std::fill(zrows.begin(), zrows.end(), 0); std::fill(used.begin(), used.end(), 0); std::fill(born.begin(), born.end(), 0); }
+    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); z_release(); zrows.clear(); n_slots = 0; nt_cap = 0; footprint = 0; failed_bytes = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); used.clear(); born.clear(); }
   } store;
   // ---- RCCL communicator of the particle-sharded deployment (agp_comm_init_rank / agp_init_multi) ----
   ncclComm_t comm = nullptr;

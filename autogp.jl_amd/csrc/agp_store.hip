@@ -17,6 +17,7 @@
 // ==========================================================================================
 
 
+constexpr uint64_t STORE_YOUNG_CALLS = 64;      // sweeps (store clock ticks) a never-used factor stays protected from eviction
 inline size_t store_bytes_per_slot(int nt_cap) {
   const size_t tiles = (size_t)nt_cap * (nt_cap + 1) / 2;
   return tiles * NB2 * 8 + (size_t)nt_cap * NSB * 256 * 8 + (size_t)nt_cap * NB * 8 + (size_t)nt_cap * 2 * 8 + 8;
@@ -75,7 +76,7 @@ int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
     if (!fs.key[sl].empty()) fs.index.erase(fs.key[sl]);
   fs.key.resize((size_t)n_slots); fs.n_cached.resize((size_t)n_slots, 0); fs.stamp.resize((size_t)n_slots, 0);
   fs.z_release(); fs.zrows.assign((size_t)n_slots, 0);          // (the resident L^-T does not survive a resize: rare, rebuilt on demand)
-  fs.info_h.resize((size_t)n_slots, 0); fs.used.resize((size_t)n_slots, 0);
+  fs.info_h.resize((size_t)n_slots, 0); fs.used.resize((size_t)n_slots, 0); fs.born.resize((size_t)n_slots, 0);
   fs.nt_cap = nt_cap; fs.n_slots = n_slots; fs.strideA = strideA;
   fs.footprint = A.cap + W.cap + vec.cap + partial.cap + info.cap + ready.cap + fs.tflag.cap + fs.flowq.cap;
   return AGP_OK;
@@ -190,16 +191,27 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   {
     std::vector<int> cand;
     for (int sl = 0; sl < fs.n_slots; ++sl) if (fs.stamp[sl] != call) cand.push_back(sl);
+    // Free slots first; then least recently used — EXCEPT that a factor nothing has started from yet, stored within the last
+    // STORE_YOUNG_CALLS sweeps, goes last: it is some thread's value factor waiting for its gradient call (Gen.hmc's update ->
+    // choice_gradients), while a factor that HAS been started from carries the newer stamp of that use and is most likely dead
+    // (the leapfrog moved on).  Plain LRU dropped the slow threads' waiting factors before the fast threads' dead ones (HMC
+    // replay with ragged arrivals: ~100 refactorisations per 30 000 gradient calls with 2 x population slots).  Old unused factors —
+    // rejected proposals nobody comes back for — age out of the protection and go by their stamp like the rest.
+    static const bool protect_young = [] { const char* e = getenv("AGP_STORE_SELF_SIZE"); return !(e && atoi(e) == 0); }();      // (0: round 5's plain LRU, for A/B runs)
+    auto young_unused = [&](int sl) { return protect_young && !fs.used[(size_t)sl] && call - fs.born[(size_t)sl] <= STORE_YOUNG_CALLS; };
     std::sort(cand.begin(), cand.end(), [&](int a, int b) {
       const bool ea = fs.key[a].empty(), eb = fs.key[b].empty();
-      if (ea != eb) return ea;                    // free slots first, then least recently used
+      if (ea != eb) return ea;
+      if (ea) return a < b;
+      const bool ya = young_unused(a), yb = young_unused(b);
+      if (ya != yb) return yb;
       return fs.stamp[a] < fs.stamp[b];
     });
     size_t ci = 0;
     for (int u = 0; u < U; ++u) {
       if (slot[u] >= 0) continue;
       const int sl = cand[ci++];                  // ci < cand.size(): n_slots >= U
-      if (!fs.key[sl].empty()) { fs.index.erase(fs.key[sl]); if (!fs.used[(size_t)sl]) fs.ghost_add(fs.key[sl]); }
+      if (!fs.key[sl].empty()) { fs.index.erase(fs.key[sl]); if (!fs.used[(size_t)sl] && fs.info_h[(size_t)sl] == 0) fs.ghost_add(fs.key[sl]); }          // (nothing can start from a factor that is not positive definite)
       fs.key[sl].clear(); fs.n_cached[sl] = 0; fs.stamp[sl] = call; fs.used[(size_t)sl] = 0;
       slot[u] = sl; i0[u] = 0;
     }
@@ -357,7 +369,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   for (int u = 0; u < U; ++u) {
     const int sl = slot[u];
     fs.key[sl] = keys[u]; fs.index[keys[u]] = sl; fs.n_cached[sl] = n; fs.info_h[sl] = hinfo[u];
-    if (i0[u] == 0) fs.used[(size_t)sl] = 0;          // a fresh factor: nothing has started from it yet
+    if (i0[u] == 0) { fs.used[(size_t)sl] = 0; fs.born[(size_t)sl] = call; }          // a fresh factor: nothing has started from it yet
     if (i0[u] > 0) ++fs.hits; else ++fs.misses;
   }
   fs.tile_rows_reused += rows_reused; fs.tile_rows_total += (int64_t)U * nt;
