@@ -814,6 +814,39 @@ def main():
             rs = torch.tensor([ranks_seen], dtype=torch.int64)
             dist.all_reduce(rs, op=dist.ReduceOp.MIN)
             ranks_seen = int(rs.item())
+    # ---- multi-rank only: ONE gradient sweep of the whole population, split twice — by contiguous blocks and by the cost-aware plan
+    # (agp_shard_plan, sweep 1, the resident series' lattice kind) — every rank timing its own share: the first real multi-GPU run
+    # validates or falsifies the plan's constants (modelled cost per rank beside measured ms per rank).  Untimed for the headline.
+    grad_split = None
+    if world > 1 and not args.no_extra_legs:
+        try:
+            prog_all = pkg.encode_batch(nodes_all)
+            kind = eng.lattice_stats()["kind"]
+            owner, c_grad, rc_grad = pkg.shard_plan(prog_all, noises_all, n, world, sweep=1, lattice_kind=kind)
+
+            def timed_share(idx):
+                if len(idx) == 0:
+                    return 0.0
+                sub = [nodes_all[i] for i in idx]; nz = noises_all[idx]
+                eng.logpdf_grad_batch(sub, nz, n=n, check=False)
+                torch.cuda.synchronize(); t_ = time.perf_counter()
+                for _ in range(2):
+                    eng.logpdf_grad_batch(sub, nz, n=n, check=False)
+                return (time.perf_counter() - t_) / 2 * 1e3
+            ms_block = timed_share(np.arange(lo, hi))
+            dist.barrier()
+            ms_plan = timed_share(pkg.dist.plan_indices(owner, rank))
+            both = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(both, torch.tensor([ms_block, ms_plan], dtype=torch.float64))
+            blocks = [pkg.shard_range(P_total, r, world) for r in range(world)]
+            grad_split = {"what": "one value + gradient sweep of the whole population per split; every rank times its own share (ms)",
+                          "lattice_kind": int(kind), "unit_of_the_model": "dense factorisations (n^3/3 flops)",
+                          "block_split": {"modelled_cost_per_rank": [float(c_grad[a:b].sum()) for a, b in blocks],
+                                          "measured_ms_per_rank": [float(x[0]) for x in both]},
+                          "cost_aware_plan": {"modelled_cost_per_rank": [float(x) for x in rc_grad],
+                                              "measured_ms_per_rank": [float(x[1]) for x in both]}}
+        except Exception as e:      # noqa: BLE001
+            grad_split = {"error": str(e)[:300]}
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         evals_s = P_total * args.steps / dt
@@ -823,7 +856,8 @@ def main():
             "metric": "particle_logpdf_evals_per_sec", "value": evals_s, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": n_prewarm, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak" if args.weak else "strong", "vs_baseline": None,
-            "dtype": "f64", "data": ("synthetic: one draw from SURVEY 8(d)'s ground-truth GP (Linear + Periodic x SquaredExponential, noise 0.05) on a shuffled regular grid"
+            "dtype": "f64", "series_version": (2 if n <= 8192 else 1),      # 1: trend + seasonal + AR(1) stand-in (rounds 1-4, and n > 8192); 2: SURVEY 8(d)'s ground-truth GP draw
+            "data": ("synthetic: one draw from SURVEY 8(d)'s ground-truth GP (Linear + Periodic x SquaredExponential, noise 0.05) on a shuffled regular grid"
                                     if n <= 8192 else "synthetic: trend + seasonal + AR(1) on a shuffled regular grid (n > 8192: no host-side GP draw)"),
             "config": {"workload": f"AutoGP config-3 final annealing step: n={n} observations, population of {P_total} particles "
                                    f"({P} on rank 0), kernel trees sampled from the restated AutoGP prior, one logpdf sweep "
@@ -848,8 +882,9 @@ def main():
             # per-rank cost (units of one dense factorisation, agp_shard_plan's model): the timed value sweep is uniform per distinct
             # particle, so it keeps the contiguous blocks; a gradient sweep of the same population would not be
             prog_all = pkg.encode_batch(nodes_all)
-            _, c_val, _ = pkg.shard_plan(prog_all, noises_all, n, world, sweep=0, regular_grid=True)
-            _, c_grad, rc_grad = pkg.shard_plan(prog_all, noises_all, n, world, sweep=1, regular_grid=True)
+            kind_ = eng.lattice_stats()["kind"]
+            _, c_val, _ = pkg.shard_plan(prog_all, noises_all, n, world, sweep=0, lattice_kind=kind_)
+            _, c_grad, rc_grad = pkg.shard_plan(prog_all, noises_all, n, world, sweep=1, lattice_kind=kind_)
             blocks = [pkg.shard_range(P_total, r, world) for r in range(world)]
             out["config"]["per_rank_cost_model"] = {
                 "unit": "dense factorisations (n^3/3 flops)",
@@ -858,6 +893,8 @@ def main():
                 "gradient_sweep_cost_aware_plan": [float(x) for x in rc_grad]}
         except Exception as e:      # noqa: BLE001
             out["config"]["per_rank_cost_model"] = {"error": str(e)[:200]}
+        if grad_split is not None:
+            out["config"]["gradient_sweep_split"] = grad_split
         out["config"]["regular_grid_lag_tables"] = eng.lag_stats()[0] and eng.lag_stats()[1] > 0
         if world == 1 and not args.no_extra_legs:
             out.update(extra_legs(pkg, eng, programs, nodes, noises, ts, xs, n, local_rank))
@@ -869,6 +906,12 @@ def main():
                 gp_["max_rel_diff_vs_lag_path"] = float(np.max(np.abs(lg[okb] - lp[okb]) / np.maximum(1.0, np.abs(lp[okb])))) if okb.any() else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(programs, noises, ts, xs, lp)
+        # a leg that failed must not hide inside a line that looks normal: name it at the top level (and on stderr)
+        bad_legs = sorted(k for k, v in out.items() if isinstance(v, dict) and "error" in v)
+        bad_legs += sorted(f"config.{k}" for k, v in out["config"].items() if isinstance(v, dict) and "error" in v)
+        out["leg_errors"] = bad_legs
+        for k in bad_legs:
+            print(f"[bench] leg {k} FAILED: {(out.get(k) or out['config'].get(k.split('.', 1)[-1]) or {}).get('error')}", file=sys.stderr, flush=True)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

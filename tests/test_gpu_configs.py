@@ -280,6 +280,13 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["config"]["particles_total"] == 64 and out["config"]["particles_per_gpu"] == 32
     assert out["config"]["allgather_selfcheck"] is True
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
+    # the gradient sweep split both ways, every rank timing its share: modelled cost beside measured time (what the first real
+    # multi-GPU run checks the plan's constants with)
+    gs = out["config"]["gradient_sweep_split"]
+    assert "error" not in gs and out["leg_errors"] == [], (gs, out["leg_errors"])
+    for split in ("block_split", "cost_aware_plan"):
+        assert len(gs[split]["modelled_cost_per_rank"]) == 2 and all(t > 0 for t in gs[split]["measured_ms_per_rank"]), gs
+    assert out["series_version"] == 2
 
 
 def _bench_line(argv, extra_env=None, timeout=1200):
