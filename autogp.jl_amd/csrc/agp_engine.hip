@@ -920,7 +920,18 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         if (sT.info[b2] == 0) { h_out_lp[part[1][b2]] = sT.lp[b2]; if (h_out_info) h_out_info[part[1][b2]] = 0; ++n_done; }
         else refused.push_back(part[1][b2]);          // the dense path decides (and names LAPACK's info)
       }
-      { std::lock_guard<std::mutex> g(c->mu); c->n_toeplitz_value += n_done; }
+      {
+        std::lock_guard<std::mutex> g(c->mu);
+        c->n_toeplitz_value += n_done;
+        if (via_store) {          // (the gradient call of the same leapfrog step must not re-decide: see agp_ctx::schur_keys)
+          if (c->schur_keys.size() > 32768) c->schur_keys.clear();
+          for (size_t b2 = 0; b2 < part[1].size(); ++b2)
+            if (sT.info[b2] == 0) {
+              const int p = part[1][b2];
+              c->schur_keys.insert(particle_key(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p], prm_off[p + 1] - prm_off[p], noise[p]));
+            }
+        }
+      }
       const int rcR = dense(refused);
       if (rcR) return rcR;
       return AGP_OK;
@@ -1026,7 +1037,19 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         if (it != fs.index.end() && fs.n_cached[(size_t)it->second] == n && fs.info_h[(size_t)it->second] == 0) { resident[(size_t)q] = 1; --n_struct; }
       }
     }
-    const bool struct_pays = c->grad_struct >= 2 || struct_grad_pays(n_struct, n);
+    // ... and a class particle the value call before this one scored by the recursion takes the structured sweep whatever this
+    // batch's size test says (the decision is sticky per particle: the two batches of a leapfrog step need not have the same size)
+    bool sticky = false;
+    if (store_live && c->toeplitz && use_toep && n_struct > 0) {
+      std::lock_guard<std::mutex> g(c->mu);
+      if (!c->schur_keys.empty())
+        for (int q = 0; q < P && !sticky; ++q) {
+          if (!(bt.ghdr[q].flags & GFLAG_LAGTOEP) || resident[(size_t)q]) continue;
+          const int p = bt.order[q];
+          sticky = c->schur_keys.erase(particle_key(ops + op_off[p], op_off[p + 1] - op_off[p], prm + prm_off[p], prm_off[p + 1] - prm_off[p], noise[p])) > 0;
+        }
+    }
+    const bool struct_pays = c->grad_struct >= 2 || sticky || struct_grad_pays(n_struct, n);
     if (use_toep && n_struct > 0 && struct_pays && n <= STRUCT_GRAD_N_MAX && !tl_in_tgrad && !tl_no_toep && !c->profiling && c->grad_struct &&
         h_out_lp && !d_user_lp && !d_user_info && !use_user_stream && (!store_live || c->toeplitz)) {
       std::vector<int> part[2];
@@ -1872,6 +1895,7 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
                         std::memcmp(xs, c->h_xs.data(), sizeof(double) * (size_t)c->n_max) == 0;
     if (!prefix) {
       c->store.forget(); c->store.ghost_clear();
+      { std::lock_guard<std::mutex> gk(c->mu); c->schur_keys.clear(); }
       std::lock_guard<std::mutex> q(c->qmu);          // (another series: another population of callers)
       c->caller_ids.clear(); c->n_callers = 0;
     }
@@ -2215,7 +2239,12 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
   std::unique_lock<std::mutex> lk(c->qmu);
   c->queue.push_back(&req);
   ++c->arrivals;
-  if (c->caller_ids.size() < 65536 && c->caller_ids.insert(std::this_thread::get_id()).second) c->n_callers = (int)c->caller_ids.size();
+  if (c->caller_ids.size() < 65536) c->caller_ids.insert(std::this_thread::get_id());
+  {
+    const int fl = ++c->inflight;
+    c->n_callers = std::max(c->n_callers.load(), std::max(fl, (int)c->caller_ids.size()));
+  }
+  struct InflightGuard { std::atomic<int>& v; ~InflightGuard() { --v; } } inflight_guard{c->inflight};
   if (c->leader_gathering) c->qcv_leader.notify_one();      // only the gathering leader cares about arrivals
   bool lead = !c->leader_active;
   if (lead) c->leader_active = true;

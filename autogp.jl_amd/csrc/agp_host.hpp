@@ -200,6 +200,11 @@ struct agp_ctx {
   bool lag_contig = false;        // ... and occupy CONSECUTIVE lattice points (a regular grid): sorted sweeps with per-tile tables, Toeplitz paths
   double lat_tol_abs = 0.0;       // admitted deviation of a point from its lattice position (lag_tol_h x the spacing; with gaps: x the smallest gap)
   int64_t n_lat = 0;              // lattice points the series spans: largest index + 1 (== n_max on a regular grid)
+  // Class-aware leapfrog pairs (AGP_LAG >= 2): keys of the particles a coalesced VALUE batch scored by the Schur recursion (and so kept out
+  // of the store).  The gradient batch that follows takes the structured sweep for them whatever ITS OWN size test says — the two
+  // batches are whatever the coalescer formed, and a class near the threshold scored structurally by one and refused by the other was
+  // factored densely from scratch: the double factoring the mode exists to remove.  Bounded; cleared by agp_set_data (mu).
+  std::unordered_set<std::string> schur_keys;
   int ref_arith = 0;              // AGP_REFERENCE_ARITHMETIC=1 / agp_set_reference_arithmetic: ONE arithmetic whatever the call order — dense Cholesky
                                   // on one fixed schedule, every element from its own t_i - t_j, dense predictive pass, element-wise gradient, no store
   int lattice_enable = 1;         // admit lattices with gaps (calendar-indexed series: monthly / quarterly / yearly / business-day dates are
@@ -235,7 +240,8 @@ struct agp_ctx {
   // update -> choice_gradients at the same parameters — so this many factors are waiting for their gradient call at any time,
   // however small the coalesced batches are.  The factor store sizes itself by it (extend_impl).
   std::unordered_set<std::thread::id> caller_ids;
-  std::atomic<int> n_callers{0};
+  std::atomic<int> n_callers{0};          // max(distinct thread ids, peak number of calls in flight): short-lived host threads recycle their ids
+  std::atomic<int> inflight{0};
   bool leader_active = false;
   int coalesce_us = 2000;    // upper bound of a leader's wait for followers (it also never exceeds a quarter of the
                              // last sweep's duration); 0 = every call runs alone (env AGP_COALESCE_US)

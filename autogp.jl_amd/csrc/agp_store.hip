@@ -167,6 +167,22 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     const int want_nt = std::max(fs.nt_cap, std::max(nt, round_up(c->n_max, NB) / NB));
     static const bool self_size = [] { const char* e = getenv("AGP_STORE_SELF_SIZE"); return !(e && atoi(e) == 0); }();      // (0: round 5's rule, for A/B runs)
     int want_slots = std::max(fs.n_slots.load(), std::max(std::max(2 * U, self_size ? 2 * c->n_callers.load() : 0), 32));
+    // ... and never evict a factor that is still waiting for its first use while memory allows growth: callers that the thread count
+    // cannot see (short-lived host threads recycle their ids; a population scored in a value PHASE and differentiated in a later
+    // one, as 160 Python threads do) are seen by what they leave behind — the factors stored within the last STORE_YOUNG_CALLS sweeps
+    // that nothing has started from.  Needed = this batch's misses; evictable = free slots + factors already used or aged out.
+    if (self_size && fs.n_slots > 0) {
+      const uint64_t now = fs.clock + 1;
+      int misses = 0, evictable = 0;
+      for (int u = 0; u < U; ++u) misses += fs.index.find(keys[u]) == fs.index.end() ? 1 : 0;
+      std::unordered_set<int> mine;
+      for (int u = 0; u < U; ++u) { auto it = fs.index.find(keys[u]); if (it != fs.index.end()) mine.insert(it->second); }
+      for (int sl = 0; sl < fs.n_slots; ++sl) {
+        if (mine.count(sl)) continue;
+        if (fs.key[(size_t)sl].empty() || fs.used[(size_t)sl] || now - fs.born[(size_t)sl] > STORE_YOUNG_CALLS) ++evictable;
+      }
+      if (misses > evictable) want_slots = std::max(want_slots, fs.n_slots + (misses - evictable));
+    }
     if (want_slots > fs.n_slots && fs.n_slots > 0) want_slots = std::max(want_slots, fs.n_slots + fs.n_slots / 2);   // (growth copies the store: few, larger steps)
     const size_t budget = (size_t)(fs.max_frac * (double)c->total_mem);
     const size_t per = store_bytes_per_slot(want_nt);

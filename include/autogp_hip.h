@@ -128,7 +128,8 @@ int agp_extend_reset(agp_ctx* ctx, int release_memory);
  * demand (keeping its contents, within its 45 % share of device memory) to twice the largest batch AND to twice the number of
  * distinct threads that have called the single-particle entries (agp_logpdf / agp_logpdf_grad are coalesced into batches of
  * whatever size the callers' arrival times give, while every thread's value factor waits for its gradient call: sized by the batch
- * alone, a population arriving in small batches evicted its own factors between update and choice_gradients).  Reserving up front
+ * alone, a population arriving in small batches evicted its own factors between update and choice_gradients) — and it grows rather
+ * than evict a factor of the last 64 sweeps that nothing has started from yet (a waiting value factor), while memory allows.  Reserving up front
  * only saves the growth copies of the first sweeps.  agp_extend_stats2 shows the outcome (evicted_before_reuse, slots, callers). */
 int agp_extend_reserve(agp_ctx* ctx, int64_t n_cap, int32_t n_slots);
 /* The predictive entries consult the same store: a particle whose factor of exactly the prefix n is resident (the

@@ -869,5 +869,30 @@ def test_class_aware_leapfrog_pairs(pkg, monkeypatch):
             sc = max(1.0, np.abs(go).max() if len(go) else 0.0, abs(gno))
             assert abs(grads[i][0] - lpo) <= LP_TOL * max(1.0, abs(lpo))
             assert (np.abs(grads[i][1] - go).max() if len(go) else 0.0) <= 1e-7 * sc and abs(grads[i][2] - gno) <= 1e-7 * sc
+        # The annealing prefixes fit_smc! runs its HMC moves on (src/inference_smc_anneal_data.jl:240-252): a series handed over in TIME
+        # ORDER, a prefix of it — n consecutive grid points, so the class stays structured — and no agp_extend_reserve (the store sizes
+        # itself by the callers).  Same counters: the class is never factored densely, nobody is factored twice.
+        ts2, xs2 = pkg.prior.synthetic_series(n, seed=78, shuffle=False)
+        n_pre = 384
+        ref.set_data(ts2, xs2); eng.extend_reset(release_memory=True); eng.set_data(ts2, xs2)
+        p_lp, p_g, p_gn, p_info = ref.logpdf_grad_batch(nodes, noises, n=n_pre, check=False)
+        k_t0, k_s0, g0 = eng.toeplitz_particles(), eng.grad_structured_particles(), eng.grad_reuse_stats()
+        vals = phase(lambda nd, z, check: eng.logpdf(nd, z, n=n_pre, check=check))
+        k_t1 = eng.toeplitz_particles()
+        grads = phase(lambda nd, z, check: eng.logpdf_grad(nd, z, n=n_pre, check=check))
+        k_s1, g1 = eng.grad_structured_particles(), eng.grad_reuse_stats()
+        ok = p_info == 0
+        n_cls_ok = int((cls & ok).sum())
+        assert k_t1 - k_t0 >= n_cls_ok - 2 and k_s1 - k_s0 >= n_cls_ok - 2, (k_t1 - k_t0, k_s1 - k_s0, n_cls_ok)
+        st = eng.extend_stats()
+        assert g1["reused"] - g0["reused"] >= int((~cls & ok).sum()) and g1["factored"] - g0["factored"] <= 2, (g0, g1, st, eng.coalesce_stats())
+        assert st["evicted_before_reuse"] == 0 and st["slots"] >= int((~cls).sum()), st      # (no reservation: the store grew by what was waiting in it)
+        for i in range(T):
+            if not ok[i]:
+                continue
+            lp, g, gn = grads[i]
+            sc = max(1.0, np.abs(p_g[i]).max() if len(p_g[i]) else 0.0, abs(p_gn[i]))
+            assert abs(vals[i] - p_lp[i]) <= 1e-10 * max(1.0, abs(p_lp[i])) and abs(lp - p_lp[i]) <= 1e-10 * max(1.0, abs(p_lp[i])), i
+            assert (np.abs(g - p_g[i]).max() if len(g) else 0.0) <= 1e-7 * sc and abs(gn - p_gn[i]) <= 1e-7 * sc, i
     finally:
         ref.close(); eng.close()
