@@ -56,7 +56,7 @@ def test_encode_batch(pkg):
 def test_header_symbols_exported(pkg):
     """Every function declared in include/autogp_hip.h is exported by the built library."""
     hdr = (ROOT / "include" / "autogp_hip.h").read_text()
-    declared = sorted(set(re.findall(r"\b(agp_[a-z_]+)\s*\(", hdr)))
+    declared = sorted(set(re.findall(r"\b(agp_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 12
     assert set(declared) == set(pkg.EXPORTED_SYMBOLS)
     assert pkg.LIB_PATH.exists(), "build the engine first: python __graft_entry__.py"
