@@ -484,8 +484,13 @@ def build_roofline(pkg, acc, n_prof, args, n, P, world, prof_every):
             tj = json.loads(tf.read_text())
             traffic = tj.get("k_chol_update_bytes_per_launch")
             traffic_step = tj.get("bytes_per_step")
-            traffic_src = {"file": "profiles/hbm_traffic.json", "tag": tj.get("tag"), "date": tj.get("date"),
-                           "note": "rocprofv3 --pmc pass of this command on an earlier box (FETCH_SIZE, WRITE_SIZE corrected per MI355X_MICROARCH.md); not re-measured in this run"}
+            import hashlib
+            lib_now = hashlib.sha256(pkg.LIB_PATH.read_bytes()).hexdigest()[:16]
+            traffic_src = {"file": "profiles/hbm_traffic.json", "tag": tj.get("tag"), "date": tj.get("date"), "git_head": tj.get("git_head"),
+                           "library_sha256_16_of_the_counter_pass": tj.get("library_sha256_16"), "library_sha256_16_of_this_run": lib_now,
+                           "same_library_build": tj.get("library_sha256_16") == lib_now,
+                           "note": "rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE in separate passes, corrected per MI355X_MICROARCH.md) by "
+                                   "tools/run_evidence.sh; not re-measured inside this run — same_library_build says whether the counters describe this binary"}
         except Exception:
             traffic = None
     alg_step = P * algorithmic_bytes_per_eval(n)

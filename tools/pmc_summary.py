@@ -60,9 +60,14 @@ import re
 upd = [k for k in res if re.search(r"k_chol_update<true, \d, true, 2\b", k)] or [k for k in res if "k_chol_update<true" in k]
 if upd and "fetch" in res[upd[0]] and "write" in res[upd[0]]:
     tot = res[upd[0]]["fetch"] + res[upd[0]]["write"]
-    import datetime
+    import datetime, hashlib, os
+    lib = ROOT / "autogp.jl_amd" / "lib" / "libautogp_hip.so"
     (ROOT / "profiles/hbm_traffic.json").write_text(json.dumps({
         "tag": tag, "date": datetime.date.today().isoformat(),
+        # which build the counters were taken on: the library's own hash (bench.py compares it with the library it runs) and, when the
+        # evidence script was handed one (AGP_GIT_HEAD: the GPU box holds no .git), the commit
+        "library_sha256_16": hashlib.sha256(lib.read_bytes()).hexdigest()[:16] if lib.exists() else None,
+        "git_head": os.environ.get("AGP_GIT_HEAD"),
         "k_chol_update_bytes_per_launch": tot, "bytes_per_step": (step_bytes["fetch"] + step_bytes["write"]) if len(step_bytes) == 2 else None,
         "kernel": upd[0], "fetch_bytes_corrected_x2": res[upd[0]]["fetch"], "write_bytes": res[upd[0]]["write"],
         "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python bench.py --steps 2 --warmup 1`, {tag}; "

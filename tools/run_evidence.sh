@@ -23,6 +23,9 @@ python tools/gpu_grad_lagdom_check.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}_
 python tools/gpu_scratch_via_store.py 2>&1 | grep "^n=" > gpurun_out/${TAG}_store_scratch.txt; cat gpurun_out/${TAG}_store_scratch.txt
 python tools/gpu_calendar_bench.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_calendar.json; cut -c1-300 gpurun_out/${TAG}_calendar.json
 (for T in 64 512; do tools/native/hmc_replay 2048 $T 2; tools/native/hmc_replay 2048 $T 2 10 0.02 grid; AGP_LAG=2 tools/native/hmc_replay 2048 $T 2 10 0.02 grid; tools/native/hmc_replay 2048 $T 2 10 0.02 monthly; AGP_FACTOR_CACHE=0 tools/native/hmc_replay 2048 $T 2; done; tools/native/hmc_replay 2048 192 2 10 0.02 grid; AGP_LAG=2 tools/native/hmc_replay 2048 192 2 10 0.02 grid; tools/native/hmc_replay 512 256 4; tools/native/threads_bench 2048 512 8; tools/native/threads_bench 2048 64 8; tools/native/threads_bench 2048 512 4 grad) 2>&1 | grep "^{" > gpurun_out/${TAG}_native.jsonl; cut -c1-220 gpurun_out/${TAG}_native.jsonl
+# round 6: the factor store sizing itself (ragged arrivals, no reservation; AGP_STORE_SELF_SIZE=0 = round 5's rule), dependent-issue latencies
+(for T in 512 1024; do for S in 1 0; do AGP_STORE_SELF_SIZE=$S HMC_JITTER_US=20000 HMC_WINDOW_US=5 tools/native/hmc_replay 512 $T 2; done; done; for R in 0 1; do HMC_JITTER_US=3000 HMC_WINDOW_US=20 HMC_RESERVE=$R tools/native/hmc_replay 2048 512 2; done) 2>&1 | grep "^{" > gpurun_out/${TAG}_store_selfsize.jsonl; cut -c1-200 gpurun_out/${TAG}_store_selfsize.jsonl
+tools/native/lat_bench > gpurun_out/${TAG}_lat_bench.json 2>&1; cut -c1-300 gpurun_out/${TAG}_lat_bench.json
 # stand-alone diagonal-tile harness (per-phase clocks), predictive passes, extension sweeps alone, dataflow traces (measurement library)
 (tools/native/diag_bench 8 0 20; tools/native/diag_bench 512 0 20; tools/native/diag_bench 512 8 20; tools/native/diag_bench 64 8 20) > gpurun_out/${TAG}_diag_bench.txt 2>&1; tail -1 gpurun_out/${TAG}_diag_bench.txt | cut -c1-160
 (python tools/gpu_predict_perf.py; python tools/gpu_predict_perf.py 2048:2048:128 --off-lattice) 2>&1 | grep "^predict" > gpurun_out/${TAG}_predict_perf.txt; tail -2 gpurun_out/${TAG}_predict_perf.txt
@@ -42,6 +45,9 @@ rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof64 -o bench -- python $R/b
 cd $R
 python tools/rocprof_summary.py $(find gpurun_out/prof64 -name "*.db" | head -1) gpurun_out/${TAG}_bench_P64_kernel_stats.txt --particles 64 --cmd "python bench.py --particles 64 --steps 20 --warmup 2 --no-cpu-baseline --no-extra-legs" | head -8
 bash tools/run_pmc.sh 2>&1 | tail -5
+# the element-wise gradient sweep (what an irregular series pays): kernel statistics and the vector / matrix pipes' activity
+bash tools/prof_cmd.sh ${TAG}_grad_elementwise python $R/tools/gpu_grad_phases.py | head -12
+(bash tools/run_pmc_cmd.sh gradsq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS" -- python $R/tools/gpu_grad_phases.py) > gpurun_out/${TAG}_grad_pmc.txt 2>&1; cd $R; grep -E "k_trtri|k_kinv|k_grad_contract|Counter_Name|kernel" gpurun_out/${TAG}_grad_pmc.txt | cut -c1-260 | head -8
 # the 64-particle share (dataflow kernel): MFMA busy, HBM bytes
 (bash tools/run_pmc_cmd.sh sq64 "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs; bash tools/run_pmc_cmd.sh fetch64 "FETCH_SIZE" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs; bash tools/run_pmc_cmd.sh write64 "WRITE_SIZE" -- python $R/bench.py --particles 64 --steps 3 --warmup 1 --no-cpu-baseline --no-extra-legs) 2>&1 | grep -v "at::native\|rocclr" > gpurun_out/${TAG}_pmc_P64.txt; cd $R; head -12 gpurun_out/${TAG}_pmc_P64.txt | cut -c1-250
 python tools/pmc_summary.py ${TAG} > /dev/null 2>&1; cp profiles/${TAG}_pmc_summary.txt gpurun_out/ 2>/dev/null; cp profiles/hbm_traffic.json gpurun_out/${TAG}_hbm_traffic.json 2>/dev/null
