@@ -2,7 +2,7 @@
 (column halves, 8 blocks per wave, 4 waves per SIMD).  Needs the experiments build (python __graft_entry__.py --experiments)."""
 import sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import os
 import __graft_entry__ as g

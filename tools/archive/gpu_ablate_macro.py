@@ -2,7 +2,7 @@
 tiles per workgroup sharing the column operand's LDS slab, one workgroup per CU).  Needs the experiments build."""
 import sys
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import os
 import __graft_entry__ as g

@@ -12,7 +12,7 @@ from pathlib import Path
 import numpy as np
 import scipy.linalg as sla
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import __graft_entry__ as g  # noqa: E402
 from oracle import oracle as O  # noqa: E402

@@ -3,7 +3,7 @@ same wave (independent instruction streams), and split across the waves of a wor
 UP in the third, the covariance evaluation (fp64 VALU) can never hide under the factorisation's MFMAs."""
 import sys, time
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import __graft_entry__ as g
 pkg = g.load_package()

@@ -2,7 +2,7 @@
 import sys, time, json
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import __graft_entry__ as g
 pkg = g.load_package()
