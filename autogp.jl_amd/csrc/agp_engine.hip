@@ -815,6 +815,7 @@ static thread_local bool tl_in_tgrad = false;
 // parameters — Gen.hmc's update -> choice_gradients pair, src/inference_smc_anneal_data.jl:63-67 — finds those factors resident,
 // while the Toeplitz class never enters the store (value from the Schur recursion, gradient from the structured sweep).
 static thread_local bool tl_dense_via_store = false;
+thread_local const uint64_t* tl_callers = nullptr;
 struct TlClear {          // a thread-local switch cleared for a scope (the store's own fallbacks must run plain sweeps)
   bool& f; bool was;
   explicit TlClear(bool& f_) : f(f_), was(f_) { f = false; }
@@ -2173,6 +2174,8 @@ static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
   }
   std::vector<double> grad(want_grad ? std::max<size_t>(1, prm.size()) : 0);
   if (prm.empty()) prm.push_back(0.0);
+  std::vector<uint64_t> callers((size_t)P);
+  for (int i = 0; i < P; ++i) callers[(size_t)i] = batch[i]->caller;
   hp_asm.stop();
   auto sweep = [&](int64_t n, int32_t Pn, const int32_t* oo, const uint8_t* o, const int32_t* po, const double* q,
                    const double* nz, double* out_lp, double* out_g, double* out_gn, int32_t* out_info) {
@@ -2186,8 +2189,10 @@ static void run_coalesced(agp_ctx* c, std::vector<LpRequest*>& batch) {
         return logpdf_batch_impl(c, n, Pn, oo, o, po, q, nz, out_lp, out_info, nullptr, nullptr, nullptr, false);
       });
     }
-    return c->factor_cache ? extend_impl(c, n, Pn, oo, o, po, q, nz, out_lp, out_info)
-                                          : agp_logpdf_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_info);
+    if (!c->factor_cache) return agp_logpdf_batch(c, n, Pn, oo, o, po, q, nz, out_lp, out_info);
+    struct Scope { const uint64_t* was; ~Scope() { tl_callers = was; } } scope{tl_callers};
+    tl_callers = (Pn == P && oo == op_off.data()) ? callers.data() : nullptr;          // (the whole batch, in request order)
+    return extend_impl(c, n, Pn, oo, o, po, q, nz, out_lp, out_info);
   };
   int rc = sweep(batch[0]->n, P, op_off.data(), ops.data(), prm_off.data(), prm.data(), noise.data(), lp.data(),
                  grad.data(), gn.data(), info.data());
@@ -2235,6 +2240,7 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
   }
   LpRequest req;
   req.n = n; req.ops = ops; req.n_ops = n_ops; req.prm = prm; req.n_prm = n_prm; req.noise = noise;
+  req.caller = (uint64_t)std::hash<std::thread::id>()(std::this_thread::get_id()) | 1ull;
   if (want_grad) req.grad = n_prm > 0 ? out_grad : &gdummy;
   std::unique_lock<std::mutex> lk(c->qmu);
   c->queue.push_back(&req);

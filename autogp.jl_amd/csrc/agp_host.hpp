@@ -134,6 +134,7 @@ struct LpRequest {
   const double* prm; int32_t n_prm;
   double noise;
   double* grad = nullptr;        // value + gradient request: d logpdf / d prm[0..n_prm), caller's storage
+  uint64_t caller = 0;           // hash of the calling thread's id (the factor store links a caller's factors: see FactorStore::slot_caller)
   double gnoise = 0.0;
   double lp = 0.0; int32_t info = 0; int rc = 0;
   // hand-back: every waiting caller sleeps on its OWN condition variable (a shared one made all followers of a finished batch —
@@ -267,6 +268,11 @@ struct agp_ctx {
     std::vector<int32_t> info_h;        // host copy of the slot's LAPACK info (a predictive pass only reuses info == 0)
     std::vector<uint8_t> used;          // the slot's factor has been STARTED FROM since it was stored (extension, gradient or predictive sweep)
     std::vector<uint64_t> born;         // clock of the sweep that stored the slot's factor from scratch
+    // Which caller (thread of the single-particle entries) stored the slot's factor, and each caller's latest slot: a caller that stores
+    // a NEW factor while its previous one has never been started from has moved on without a gradient call (a value-only stream: MH
+    // proposals, re-scoring) — the previous factor is abandoned, i.e. first in line for eviction and no longer "waiting".
+    std::vector<uint64_t> slot_caller;
+    std::unordered_map<uint64_t, int> caller_slot;
     // Factors dropped for room that nothing had started from, remembered by key (bounded FIFO): a later lookup that finds its key
     // HERE is the cliff a too-small store falls off — the gradient call of a leapfrog step refactoring what the value call before it
     // had just computed.  evicted_before_reuse counts those lookups (agp_extend_stats2); factors nobody comes back for (the end of a
@@ -286,8 +292,8 @@ struct agp_ctx {
     double max_frac = 0.45;             // share of the device memory the store may take
     std::atomic<size_t> footprint{0};   // bytes the store holds right now (read by ws_limit_bytes without the lock)
     size_t failed_bytes = 0;            // size of the last (re)allocation that failed: not retried at that size or above
-    void forget() { failed_bytes = 0; index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); std::fill(zrows.begin(), zrows.end(), 0); std::fill(used.begin(), used.end(), 0); std::fill(born.begin(), born.end(), 0); }
-    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); z_release(); zrows.clear(); n_slots = 0; nt_cap = 0; footprint = 0; failed_bytes = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); used.clear(); born.clear(); }
+    void forget() { failed_bytes = 0; index.clear(); std::fill(key.begin(), key.end(), std::string()); std::fill(n_cached.begin(), n_cached.end(), 0); std::fill(zrows.begin(), zrows.end(), 0); std::fill(used.begin(), used.end(), 0); std::fill(born.begin(), born.end(), 0); std::fill(slot_caller.begin(), slot_caller.end(), 0); caller_slot.clear(); }
+    void release() { A.release(); W.release(); vec.release(); partial.release(); info.release(); ready.release(); tflag.release(); flowq.release(); z_release(); zrows.clear(); n_slots = 0; nt_cap = 0; footprint = 0; failed_bytes = 0; forget(); key.clear(); n_cached.clear(); stamp.clear(); info_h.clear(); used.clear(); born.clear(); slot_caller.clear(); caller_slot.clear(); }
   } store;
   // ---- RCCL communicator of the particle-sharded deployment (agp_comm_init_rank / agp_init_multi) ----
   ncclComm_t comm = nullptr;
@@ -472,6 +478,8 @@ struct HostProf {
 };
 
 // a thread-local switch held for a scope (nested sweeps of the structured paths)
+extern thread_local const uint64_t* tl_callers;      // (run_coalesced -> extend_impl) caller id per particle of the batch, or null
+
 struct TlFlag {
   bool& f;
   explicit TlFlag(bool& f_) : f(f_) { f = true; }

@@ -76,7 +76,7 @@ int store_resize(agp_ctx* c, int nt_cap, int n_slots) {
     if (!fs.key[sl].empty()) fs.index.erase(fs.key[sl]);
   fs.key.resize((size_t)n_slots); fs.n_cached.resize((size_t)n_slots, 0); fs.stamp.resize((size_t)n_slots, 0);
   fs.z_release(); fs.zrows.assign((size_t)n_slots, 0);          // (the resident L^-T does not survive a resize: rare, rebuilt on demand)
-  fs.info_h.resize((size_t)n_slots, 0); fs.used.resize((size_t)n_slots, 0); fs.born.resize((size_t)n_slots, 0);
+  fs.info_h.resize((size_t)n_slots, 0); fs.used.resize((size_t)n_slots, 0); fs.born.resize((size_t)n_slots, 0); fs.slot_caller.resize((size_t)n_slots, 0);
   fs.nt_cap = nt_cap; fs.n_slots = n_slots; fs.strideA = strideA;
   fs.footprint = A.cap + W.cap + vec.cap + partial.cap + info.cap + ready.cap + fs.tflag.cap + fs.flowq.cap;
   return AGP_OK;
@@ -159,29 +159,30 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   HostProf hp_cap(11);
   std::unique_lock<std::mutex> lk(fs.mu);
   {
-    // capacity: slots sized for the resident data, at least as many as this population (twice, so that a population
-    // mid-rejuvenation keeps its previous states), within the store's share of device memory
-    // ... and at least twice the number of threads that drive the single-particle entries: their calls are coalesced into batches
-    // of whatever size the arrival times give, while EVERY thread's value factor waits for its gradient call (HMC leapfrog) — a
-    // store sized by the batch alone evicted a population's factors between update and choice_gradients (NOTES round 5)
+    // capacity: slots sized for the resident data, at least twice this batch (a population mid-rejuvenation keeps its previous
+    // states), within the store's share of device memory — and beyond that DRIVEN BY PRESSURE: the store grows rather than evict a
+    // factor that is still waiting for its first use.  A waiting factor = stored within the last STORE_YOUNG_CALLS sweeps, nothing
+    // has started from it, and its caller has not moved on (used == 2: abandoned).  The single-particle entries are coalesced into
+    // batches of whatever size the arrival times give, while EVERY thread's value factor waits for its gradient call (Gen.hmc's
+    // update -> choice_gradients): sized by the batch alone, a population arriving in small batches evicted its own factors in between
+    // (NOTES round 5).  Needed = this batch's misses; evictable = free slots + factors used, abandoned or aged out.  The growth is capped
+    // at twice what the batch and the callers seen (distinct thread ids / calls in flight) ask for: a stream of value calls nothing ever
+    // comes back for must not walk the store up to its whole share of memory, growth copy by growth copy (a growth to 36 GB costs
+    // ~1.7 s of allocation: measured with 512 short-lived threads whose ids inflated the caller count — hence no growth without pressure).
     const int want_nt = std::max(fs.nt_cap, std::max(nt, round_up(c->n_max, NB) / NB));
     static const bool self_size = [] { const char* e = getenv("AGP_STORE_SELF_SIZE"); return !(e && atoi(e) == 0); }();      // (0: round 5's rule, for A/B runs)
-    int want_slots = std::max(fs.n_slots.load(), std::max(std::max(2 * U, self_size ? 2 * c->n_callers.load() : 0), 32));
-    // ... and never evict a factor that is still waiting for its first use while memory allows growth: callers that the thread count
-    // cannot see (short-lived host threads recycle their ids; a population scored in a value PHASE and differentiated in a later
-    // one, as 160 Python threads do) are seen by what they leave behind — the factors stored within the last STORE_YOUNG_CALLS sweeps
-    // that nothing has started from.  Needed = this batch's misses; evictable = free slots + factors already used or aged out.
+    const int basic_slots = std::max(std::max(2 * U, self_size ? 2 * c->n_callers.load() : 0), 32);
+    int want_slots = std::max(fs.n_slots.load(), std::max(2 * U, 32));
     if (self_size && fs.n_slots > 0) {
       const uint64_t now = fs.clock + 1;
       int misses = 0, evictable = 0;
-      for (int u = 0; u < U; ++u) misses += fs.index.find(keys[u]) == fs.index.end() ? 1 : 0;
       std::unordered_set<int> mine;
-      for (int u = 0; u < U; ++u) { auto it = fs.index.find(keys[u]); if (it != fs.index.end()) mine.insert(it->second); }
+      for (int u = 0; u < U; ++u) { auto it = fs.index.find(keys[u]); if (it != fs.index.end()) mine.insert(it->second); else ++misses; }
       for (int sl = 0; sl < fs.n_slots; ++sl) {
         if (mine.count(sl)) continue;
         if (fs.key[(size_t)sl].empty() || fs.used[(size_t)sl] || now - fs.born[(size_t)sl] > STORE_YOUNG_CALLS) ++evictable;
       }
-      if (misses > evictable) want_slots = std::max(want_slots, fs.n_slots + (misses - evictable));
+      if (misses > evictable) want_slots = std::max(want_slots, std::min(fs.n_slots + (misses - evictable), std::max(fs.n_slots.load(), 2 * basic_slots)));
     }
     if (want_slots > fs.n_slots && fs.n_slots > 0) want_slots = std::max(want_slots, fs.n_slots + fs.n_slots / 2);   // (growth copies the store: few, larger steps)
     const size_t budget = (size_t)(fs.max_frac * (double)c->total_mem);
@@ -214,7 +215,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     // replay with ragged arrivals: ~100 refactorisations per 30 000 gradient calls with 2 x population slots).  Old unused factors —
     // rejected proposals nobody comes back for — age out of the protection and go by their stamp like the rest.
     static const bool protect_young = [] { const char* e = getenv("AGP_STORE_SELF_SIZE"); return !(e && atoi(e) == 0); }();      // (0: round 5's plain LRU, for A/B runs)
-    auto young_unused = [&](int sl) { return protect_young && !fs.used[(size_t)sl] && call - fs.born[(size_t)sl] <= STORE_YOUNG_CALLS; };
+    auto young_unused = [&](int sl) { return protect_young && !fs.used[(size_t)sl] && call - fs.born[(size_t)sl] <= STORE_YOUNG_CALLS; };      // (used: 1 started from, 2 abandoned by its caller)
     std::sort(cand.begin(), cand.end(), [&](int a, int b) {
       const bool ea = fs.key[a].empty(), eb = fs.key[b].empty();
       if (ea != eb) return ea;
@@ -385,7 +386,18 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   for (int u = 0; u < U; ++u) {
     const int sl = slot[u];
     fs.key[sl] = keys[u]; fs.index[keys[u]] = sl; fs.n_cached[sl] = n; fs.info_h[sl] = hinfo[u];
-    if (i0[u] == 0) { fs.used[(size_t)sl] = 0; fs.born[(size_t)sl] = call; }          // a fresh factor: nothing has started from it yet
+    if (i0[u] == 0) {          // a fresh factor: nothing has started from it yet
+      fs.used[(size_t)sl] = 0; fs.born[(size_t)sl] = call;
+      const uint64_t cid = tl_callers ? tl_callers[uniq[u]] : 0;
+      fs.slot_caller[(size_t)sl] = cid;
+      if (cid != 0) {
+        auto pr = fs.caller_slot.find(cid);
+        if (pr != fs.caller_slot.end() && pr->second != sl && pr->second < fs.n_slots && fs.slot_caller[(size_t)pr->second] == cid &&
+            !fs.key[(size_t)pr->second].empty() && fs.used[(size_t)pr->second] == 0)
+          fs.used[(size_t)pr->second] = 2;          // the caller moved on without ever starting from it: abandoned
+        fs.caller_slot[cid] = sl;
+      }
+    }
     if (i0[u] > 0) ++fs.hits; else ++fs.misses;
   }
   fs.tile_rows_reused += rows_reused; fs.tile_rows_total += (int64_t)U * nt;

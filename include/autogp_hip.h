@@ -124,13 +124,17 @@ int agp_extend_stats(agp_ctx* ctx, int64_t* out4);
 int agp_extend_stats2(agp_ctx* ctx, int64_t* out, int32_t n_out);
 /* forget every resident factor (release_memory != 0 also frees the store) */
 int agp_extend_reset(agp_ctx* ctx, int release_memory);
-/* pre-size the store for series of up to n_cap observations and n_slots particles.  OPTIONAL: the store sizes itself — it grows on
- * demand (keeping its contents, within its 45 % share of device memory) to twice the largest batch AND to twice the number of
- * distinct threads that have called the single-particle entries (agp_logpdf / agp_logpdf_grad are coalesced into batches of
- * whatever size the callers' arrival times give, while every thread's value factor waits for its gradient call: sized by the batch
- * alone, a population arriving in small batches evicted its own factors between update and choice_gradients) — and it grows rather
- * than evict a factor of the last 64 sweeps that nothing has started from yet (a waiting value factor), while memory allows.  Reserving up front
- * only saves the growth copies of the first sweeps.  agp_extend_stats2 shows the outcome (evicted_before_reuse, slots, callers). */
+/* pre-size the store for series of up to n_cap observations and n_slots particles.  OPTIONAL: the store sizes itself — twice the
+ * largest batch to begin with, and from there DRIVEN BY PRESSURE: it grows (keeping its contents, within its 45 % share of device
+ * memory) rather than evict a factor that is still waiting for its first use — stored within the last 64 sweeps, nothing has started
+ * from it, and its caller (the thread of the single-particle entry that stored it) has not stored another one since.  agp_logpdf /
+ * agp_logpdf_grad are coalesced into batches of whatever size the callers' arrival times give, while every thread's value factor waits
+ * for its gradient call: sized by the batch alone, a population arriving in small batches evicted its own factors between update and
+ * choice_gradients.  Eviction order: free slots, factors already started from / abandoned by their caller / aged out (least recently
+ * used first), and only then waiting ones.  The growth by pressure is capped at twice what the batch and the callers seen ask for
+ * (value calls nothing comes back for — rejected proposals — must not fill the store's whole share).  Reserving up front only saves
+ * the growth copies of the first sweeps; callers that score a whole population BEFORE differentiating any of it from short-lived
+ * threads (thread ids recycled) are the one pattern that still profits.  agp_extend_stats2 shows the outcome. */
 int agp_extend_reserve(agp_ctx* ctx, int64_t n_cap, int32_t n_slots);
 /* The predictive entries consult the same store: a particle whose factor of exactly the prefix n is resident (the
  * per-step callback of the streaming workload predicts right after the reweight: scripts/online.jl:43,59 ->

@@ -170,29 +170,35 @@ int main(int argc, char** argv) {
   std::vector<Particle> ps(T);
   for (auto& p : ps) { gen_tree(g, 2, p); p.noise = 0.05 + 0.3 * u(g); }
   Counters cnt;
-  auto run = [&](int reps, Counters& c) {
-    std::vector<std::thread> th;
-    th.reserve(T);
-    for (int t = 0; t < T; ++t)
-      th.emplace_back([&, t] {
+  // (the threads persist across the warm-up iteration and the timed ones, as Julia's thread pool does: a barrier in between)
+  std::atomic<int> arrived{0};
+  std::atomic<bool> go{false};
+  Counters warm;
+  std::vector<std::thread> th;
+  th.reserve(T);
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t] {
+      const Particle& p = ps[t];
+      for (int phase = 0; phase < 2; ++phase) {
+        Counters& c = phase == 0 ? warm : cnt;
         std::mt19937_64 rng(1000 + t);
-        const Particle& p = ps[t];
         std::vector<double> q(p.prm.size());
         for (size_t i = 0; i < q.size(); ++i) q[i] = std::log(p.prm[i]);
         double qn = std::log(p.noise);
-        for (int it = 0; it < reps; ++it) {
+        for (int it = 0; it < (phase == 0 ? 1 : iters); ++it) {
           // rejuvenate_particle_parameters: hmc on the numeric parameters, then hmc on :noise
           if (hmc_move(ctx, n, p, q, qn, false, L, eps, rng, c)) c.accepted.fetch_add(1);
           hmc_move(ctx, n, p, q, qn, true, L, eps, rng, c);
         }
-      });
-    for (auto& x : th) x.join();
-  };
-  { Counters warm; run(1, warm); }
+        if (phase == 0) { arrived.fetch_add(1); while (!go.load(std::memory_order_acquire)) std::this_thread::yield(); }
+      }
+    });
+  while (arrived.load() < T) std::this_thread::yield();
   int64_t c0, b0, c1, b1;
   agp_get_coalesce_stats(ctx, &c0, &b0);
   const auto t0 = std::chrono::steady_clock::now();
-  run(iters, cnt);
+  go.store(true, std::memory_order_release);
+  for (auto& x : th) x.join();
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   agp_get_coalesce_stats(ctx, &c1, &b1);
   double cot[4] = {0, 0, 0, 0};

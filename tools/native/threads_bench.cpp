@@ -49,33 +49,40 @@ int main(int argc, char** argv) {
   for (auto& p : ps) { gen_tree(g, 2, p); p.noise = 0.05 + 0.3 * u(g); }
   std::vector<double> lp(T, 0.0);
   std::atomic<int> bad{0}, api_errors{0};
-  auto sweep = [&](int reps) {
-    std::vector<std::thread> th;
-    th.reserve(T);
-    for (int t = 0; t < T; ++t)
-      th.emplace_back([&, t] {
-        for (int r = 0; r < reps; ++r) {
-          int32_t info = 0;
-          Particle& p = ps[t];
-          // FRESH parameters at every call (an MCMC move proposes new values): the library keeps the factors of value
-          // calls resident, a repeated call at unchanged parameters would only measure the lookup
-          p.noise *= 1.0 + 1e-7;
-          double g[64], gn = 0.0;       // trees of depth <= 2: at most 4 leaves x 3 parameters
-          const int rc = grad ? agp_logpdf_grad(ctx, n, p.ops.data(), (int32_t)p.ops.size(), p.prm.data(), (int32_t)p.prm.size(),
-                                                p.noise, &lp[t], g, &gn, &info)
-                              : agp_logpdf(ctx, n, p.ops.data(), (int32_t)p.ops.size(), p.prm.data(), (int32_t)p.prm.size(),
-                                           p.noise, &lp[t], &info);
-          if (rc != 0) api_errors.fetch_add(1);
-          if (rc != 0 || info != 0) bad.fetch_add(1);
-        }
-      });
-    for (auto& x : th) x.join();
+  // The threads PERSIST across the warm-up and the timed region, as the reference's Julia threads do (Threads.@threads: one pool for
+  // the whole fit): a barrier separates the two.  (Fresh threads per phase look like twice the population to the library's factor
+  // store, which links a caller's factors by its thread: round 6.)
+  std::atomic<int> arrived{0};
+  std::atomic<bool> go{false};
+  auto one_call = [&](int t) {
+    int32_t info = 0;
+    Particle& p = ps[t];
+    // FRESH parameters at every call (an MCMC move proposes new values): the library keeps the factors of value
+    // calls resident, a repeated call at unchanged parameters would only measure the lookup
+    p.noise *= 1.0 + 1e-7;
+    double g[64], gn = 0.0;       // trees of depth <= 2: at most 4 leaves x 3 parameters
+    const int rc = grad ? agp_logpdf_grad(ctx, n, p.ops.data(), (int32_t)p.ops.size(), p.prm.data(), (int32_t)p.prm.size(),
+                                          p.noise, &lp[t], g, &gn, &info)
+                        : agp_logpdf(ctx, n, p.ops.data(), (int32_t)p.ops.size(), p.prm.data(), (int32_t)p.prm.size(),
+                                     p.noise, &lp[t], &info);
+    if (rc != 0) api_errors.fetch_add(1);
+    if (rc != 0 || info != 0) bad.fetch_add(1);
   };
-  sweep(2);                                           // warm-up (workspace allocation, batch-size hint)
+  std::vector<std::thread> th;
+  th.reserve(T);
+  for (int t = 0; t < T; ++t)
+    th.emplace_back([&, t] {
+      for (int r = 0; r < 2; ++r) one_call(t);          // warm-up (workspace allocation, batch-size hint, the store's first growth)
+      arrived.fetch_add(1);
+      while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+      for (int r = 0; r < iters; ++r) one_call(t);
+    });
+  while (arrived.load() < T) std::this_thread::yield();
   int64_t c0, b0, c1, b1;
   agp_get_coalesce_stats(ctx, &c0, &b0);
   const auto t0 = std::chrono::steady_clock::now();
-  sweep(iters);
+  go.store(true, std::memory_order_release);
+  for (auto& x : th) x.join();
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   agp_get_coalesce_stats(ctx, &c1, &b1);
   // reference values through the batch entry: coalescing must not change a result
