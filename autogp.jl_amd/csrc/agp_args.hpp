@@ -5,6 +5,21 @@
 
 namespace agp {
 
+// COMPACT lag tables — calendar lattices too long for a table over their lags (2048 month starts span 62 304 days; the reference's
+// dates arrive through datetime2unix + the min-max transform, src/api.jl:49-51,98-101).  In time order the lattice indices g_i of
+// such a series grow almost evenly: all pairs (i, i + od) have lattice lags within base[od] .. base[od] + W - 1 (month starts: W <= 5),
+// so a stationary subtree's table needs only W entries per ordinal difference — entry W od + (lag - base[od]) — instead of one per
+// lattice lag.  A point's key packs (ordinal << CLT_SHIFT) | g; an element reads table[(|dkey| & CLT_MASK) + B[|dkey| >> CLT_SHIFT]]
+// with B[od] = W od - base[od].  W = 0 in the struct: whole tables in LDS (sweeps in the caller's order, W n <= 4096 entries);
+// W > 0: sorted sweep, a tile copies the window of its 256 ordinal differences.
+constexpr int CLT_SHIFT = 19, CLT_MASK = (1 << CLT_SHIFT) - 1;
+struct CltArgs {
+  const int32_t* B = nullptr;   // [n_pad + 256] W od - base[od]; null: not a compact sweep
+  int W = 0;                    // entries per ordinal difference on a sorted sweep (per-tile windows), 0: whole tables
+  int nB = 0;                   // entries of B a tile stages in LDS (even)
+  int gstride = 0;              // doubles per table in global memory
+};
+
 struct CovArgs {
   const double* tt;      // time points in padded joint layout, length nt*NB
   int n1;                // valid training points  [0, n1)
@@ -30,6 +45,7 @@ struct CovArgs {
   int lag_stride;        //   point in the sorted series; a leaf's table then holds all lag_stride lags 0 .. n_max-1 (see cov_prologue)
   int csplit;            // 4: a tile is shared by four workgroups (grid.z; 32 columns each) — launches of a few large trees,
                          // whose length is ONE workgroup's walk over its tile (launch_cov); otherwise one workgroup per tile
+  CltArgs clt;           // compact tables (lagr then holds the points' keys)
 };
 
 struct LagArgs {
@@ -112,6 +128,7 @@ struct CholArgs {
   const double* lagtab; // ... and their tables (k_lag_tables)
   const int32_t* lagr;  // rank tables (sweeps in the caller's order; see cov_prologue): ranks of the resident points, null = sorted sweep
   int lag_stride;       // ... doubles per table
+  CltArgs clt;          // compact tables (lagr then holds the points' keys; lag_stride = doubles per table in LDS)
 };
 // LDS byte budget of the update kernel: GEMM double buffers and the potrf block store alias.
 constexpr int U_SLAB = KB * LDS_STRIDE;                // doubles per slab buffer

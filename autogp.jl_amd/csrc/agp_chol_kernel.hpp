@@ -443,14 +443,17 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
     const int lstride = rankt ? a.lag_stride : 256;
     int* xrk = reinterpret_cast<int*>(sig + h.n_cp * 256 + (LAGM ? h.n_lag * lstride : 0));
     const int* rk = rankt ? xrk : nullptr;
-    double* prm = reinterpret_cast<double*>(xrk) + (rankt ? 128 : 0);
+    const bool cltm = rankt && a.clt.B != nullptr;                 // compact tables: B behind the keys (see CltArgs)
+    int* cbl = xrk + 256;
+    const int* cbp = cltm ? cbl - (a.clt.W > 0 && ti > tk ? (ti - tk) * NB - (NB - 1) : 0) : nullptr;
+    double* prm = reinterpret_cast<double*>(xrk) + (rankt ? 128 + (cltm ? a.clt.nB / 2 : 0) : 0);
     int* ops = reinterpret_cast<int*>(prm + h.n_prm + 2);
     for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
     for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
     double* etab = sm + U_MAIN_DOUBLES;      // exp table in the (still unused) forward-solve scratch: rvec[128]
     if (AGP_EXP_TABLE && !LAGM && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];      // (lag sweeps evaluate no exponential)
     // (program, parameters, time points and lag tables travel in ONE round trip; the prologue's barrier publishes all of it)
-    cov_prologue<LAGM>(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt, LAGM ? a.lagr : nullptr, lstride, xrk);
+    cov_prologue<LAGM>(a.tt, a.code, ti, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt, LAGM ? a.lagr : nullptr, lstride, xrk, true, a.clt, cbl);
     const double noise = a.noise[p];
     // GammaExp leaves read log|dt| from the data set's table (L2 / Infinity-Cache resident: every particle reads
     // the same 128 KiB tile); the loads are issued at the top of the pass and consumed by the first such leaf
@@ -481,7 +484,10 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
         for (int r = 0; r < 4; ++r) {
           const int cs = cb * 16 + 4 * r + lq;
           double v0, v1;
-          if (rk) {
+          if (cbp) {
+            const int rc = rk[NB + cs], e0 = rk0 - rc, e1 = rk1 - rc, d0 = e0 < 0 ? -e0 : e0, d1 = e1 < 0 ? -e1 : e1;
+            v0 = -lagt[(d0 & CLT_MASK) + cbp[d0 >> CLT_SHIFT]]; v1 = -lagt[(d1 & CLT_MASK) + cbp[d1 >> CLT_SHIFT]];
+          } else if (rk) {
             const int rc = rk[NB + cs], d0 = rk0 - rc, d1 = rk1 - rc;
             v0 = -lagt[d0 < 0 ? -d0 : d0]; v1 = -lagt[d1 < 0 ? -d1 : d1];
           } else {
@@ -523,9 +529,9 @@ __device__ __forceinline__ void chol_tile(const CholArgs& a, const int p_, const
         // one-node program (three quarters of a prior-sampled population in a lag sweep — stationary subtrees are tables —,
         // two thirds otherwise): no interpreter, the pass is the leaf's arithmetic alone instead of ~2 us of opcode /
         // parameter / stack latency around it
-        eval_leaf<4, (LAGM ? 3 : TAB ? 2 : 1)>(op1, q0, q1, q2, sig, lagt, tr, tc, ri, ci, lt, etab, out, rk);
+        eval_leaf<4, (LAGM ? 3 : TAB ? 2 : 1)>(op1, q0, q1, q2, sig, lagt, tr, tc, ri, ci, lt, etab, out, rk, cbp);
       } else {
-        eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt, rk, lstride);
+        eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt, rk, lstride, cbp);
       }
       d4 v;
 #pragma unroll
@@ -890,13 +896,16 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
     const int lstride = rankt ? a.lag_stride : 256;
     int* xrk = reinterpret_cast<int*>(sig + h.n_cp * 256 + (LAGM ? h.n_lag * lstride : 0));
     const int* rk = rankt ? xrk : nullptr;
-    double* prm = reinterpret_cast<double*>(xrk) + (rankt ? 128 : 0);
+    const bool cltm = rankt && a.clt.B != nullptr;                 // compact tables (see chol_tile; a diagonal tile's window starts at od = 0)
+    int* cbl = xrk + 256;
+    const int* cbp = cltm ? cbl : nullptr;
+    double* prm = reinterpret_cast<double*>(xrk) + (rankt ? 128 + (cltm ? a.clt.nB / 2 : 0) : 0);
     int* ops = reinterpret_cast<int*>(prm + h.n_prm + 2);
     for (int i = tid; i < h.n_prm + 2; i += 256) prm[i] = a.prm[h.prm_off + i];   // + tail padding
     for (int i = tid; i < h.n_ops; i += 256) ops[i] = (int)a.ops[h.op_off + i];
     double* etab = rvec;                     // exp table in the (still unused) forward-solve scratch
     if (AGP_EXP_TABLE && !LAGM && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
-    cov_prologue<LAGM>(a.tt, a.code, tk, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt, LAGM ? a.lagr : nullptr, lstride, xrk);
+    cov_prologue<LAGM>(a.tt, a.code, tk, tk, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt, LAGM ? a.lagr : nullptr, lstride, xrk, true, a.clt, cbl);
     const double noise = a.noise[p];
     const bool use_tab = TAB && (h.flags & 1) != 0;
     const double* __restrict__ ltile = a.logdt + tile_off(tk, tk);      // only dereferenced when use_tab
@@ -928,7 +937,8 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
           const int cs = cbe[e] * 16 + 4 * r + lq;
           double v;
           if (pure_lag) {
-            if (rk) { const int d = rk[rs] - rk[NB + cs]; v = lagt[d < 0 ? -d : d]; }
+            if (cbp) { const int d0 = rk[rs] - rk[NB + cs], d = d0 < 0 ? -d0 : d0; v = lagt[(d & CLT_MASK) + cbp[d >> CLT_SHIFT]]; }
+            else if (rk) { const int d = rk[rs] - rk[NB + cs]; v = lagt[d < 0 ? -d : d]; }
             else v = lq_[rs - cs];
           } else {
             v = q1 + q2 * (ue * (tpt[NB + cs] - q0));
@@ -955,9 +965,9 @@ __device__ __forceinline__ void chol_diag_tile(const CholArgs& a, const int p_, 
         ri[r] = rslot; ci[r] = NB + cslot;
       }
       if (one_node) {       // (one-node program: no interpreter, see chol_tile)
-        eval_leaf<4, (LAGM ? 3 : TAB ? 2 : 1)>(op1, q0, q1, q2, sig, lagt, tr, tc, ri, ci, lt, etab, out, rk);
+        eval_leaf<4, (LAGM ? 3 : TAB ? 2 : 1)>(op1, q0, q1, q2, sig, lagt, tr, tc, ri, ci, lt, etab, out, rk, cbp);
       } else {
-        eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt, rk, lstride);
+        eval_program<(DCOV > 0 ? DCOV : 4), 4, (LAGM ? 3 : TAB ? 2 : 1)>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lagt, rk, lstride, cbp);
       }
       d4 v;
 #pragma unroll

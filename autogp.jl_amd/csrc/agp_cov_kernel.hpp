@@ -56,7 +56,7 @@ __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, cons
                                              double* tpt, double* sig, int tid,
                                              const double* __restrict__ lagtab = nullptr, int nt = 0,
                                              const int32_t* __restrict__ rank = nullptr, int lstride = 256, int* xrk = nullptr,
-                                             bool copy_rank_tables = true) {
+                                             bool copy_rank_tables = true, const CltArgs clt = CltArgs{}, int* cbl = nullptr) {
   const int g = (tid < NB) ? (ti * NB + tid) : (tj * NB + (tid - NB));
   const double tg = tt[g];
   if (LAG && h.n_lag > 0) {
@@ -67,9 +67,23 @@ __device__ __forceinline__ void cov_prologue(const double* __restrict__ tt, cons
       // tile copies it whole (16 KiB at n_max = 2048) with the ranks of its 256 points, and an element reads
       // table[|rank_row - rank_col|]
       // (k_cov_tiles leaves the tables where they are — L2-resident, a tree there may carry dozens — and only stages the ranks)
-      const double* __restrict__ src = lagtab + (long long)h.lag_off * lstride;
-      if (copy_rank_tables)
-        for (int i = tid; i < h.n_lag * lstride; i += 256) lag[i] = src[i];
+      if (clt.B != nullptr && copy_rank_tables) {
+        // COMPACT tables (a lattice too long for a table over its lags: month starts, quarters — see CltArgs): the table of a leaf is
+        // indexed by (ordinal difference od, lattice lag - base[od]); the tile copies either the whole of it (caller's order: any od)
+        // or, on a sorted sweep, the window of the 256 ordinal differences its elements can have, and the matching entries of
+        // B[od] = W od - base[od] re-based to the window
+        const int odmin = clt.W > 0 ? (ti > tj ? (ti - tj) * NB - (NB - 1) : 0) : 0;
+        const int woff = clt.W * odmin;
+        for (int li = 0; li < h.n_lag; ++li) {
+          const double* __restrict__ src = lagtab + (long long)(h.lag_off + li) * clt.gstride + woff;
+          for (int i = tid; i < lstride; i += 256) lag[li * lstride + i] = src[i];
+        }
+        for (int i = tid; i < clt.nB; i += 256) cbl[i] = clt.B[odmin + i] - woff;
+      } else {
+        const double* __restrict__ src = lagtab + (long long)h.lag_off * lstride;
+        if (copy_rank_tables)
+          for (int i = tid; i < h.n_lag * lstride; i += 256) lag[i] = src[i];
+      }
       xrk[tid] = rank[g];
     } else {
       // this tile's lag tables: block lag ti - tj of every OP_LAG_* leaf, 2 KiB each, built once per sweep by k_lag_tables
@@ -111,7 +125,7 @@ __device__ __forceinline__ void eval_leaf(const int o, const double p0, const do
                                           const double* sg, const double* lg,
                                           const double (&tr)[E], const double (&tc)[E],
                                           const int (&ri)[E], const int (&ci)[E], const double (&lt)[E],
-                                          const double* etab, double (&v)[E], const int* rk = nullptr) {
+                                          const double* etab, double (&v)[E], const int* rk = nullptr, const int* cb = nullptr) {
   auto ex = [&](double x) { return (AGP_EXP_TABLE != 0) ? fm::exp_t(x, etab) : fm::exp_f(x); };
   if (o == OP_SEL) {
 #pragma unroll
@@ -128,7 +142,15 @@ __device__ __forceinline__ void eval_leaf(const int o, const double p0, const do
     for (int e = 0; e < E; ++e) v[e] = p1 + p2 * ((tr[e] - p0) * (tc[e] - p0));
   } else if ((GEMODE == 0 || GEMODE == 3) && (GEMODE == 3 || o == OP_LAG)) {
     // stationary subtree of a regular grid: the tile's lag table (sorted sweep: by position; rk: by the points' ranks)
-    if (rk != nullptr) {
+    if (cb != nullptr) {
+      // compact tables: the points' keys are (ordinal << CLT_SHIFT) | lattice index, both increasing with time, so |key_r - key_c| =
+      // (|ordinal difference| << CLT_SHIFT) + |lattice lag|; entry = lag + B[od] (cb is biased by the window's first od)
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int d0 = rk[ri[e]] - rk[ci[e]], d = d0 < 0 ? -d0 : d0;
+        v[e] = lg[(d & CLT_MASK) + cb[d >> CLT_SHIFT]];
+      }
+    } else if (rk != nullptr) {
 #pragma unroll
       for (int e = 0; e < E; ++e) { const int d = rk[ri[e]] - rk[ci[e]]; v[e] = lg[d < 0 ? -d : d]; }
     } else {
@@ -169,7 +191,7 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
                                              const double (&tr)[E], const double (&tc)[E],
                                              const int (&ri)[E], const int (&ci)[E], const double (&lt)[E],
                                              double (&out)[E], const double* etab = nullptr, const double* lag = nullptr,
-                                             const int* rk = nullptr, int lstride = 256) {
+                                             const int* rk = nullptr, int lstride = 256, const int* cb = nullptr) {
   double st[D][E];
 #pragma unroll
   for (int d = 0; d < D; ++d)
@@ -186,7 +208,7 @@ __device__ __forceinline__ void eval_program(const ProgHdr& h, const OpT* __rest
       // carry two doubles of tail padding — and picked by opcode afterwards
       const double p0 = prm[q], p1 = prm[q + 1], p2 = prm[q + 2];
       double v[E];
-      eval_leaf<E, GEMODE>(o, p0, p1, p2, sig + cpi * 256, lag + li * lstride, tr, tc, ri, ci, lt, etab, v, rk);
+      eval_leaf<E, GEMODE>(o, p0, p1, p2, sig + cpi * 256, lag + li * lstride, tr, tc, ri, ci, lt, etab, v, rk, cb);
       if (o == OP_SEL) ++cpi;
       if (o == OP_LAG) ++li;
 #pragma unroll
@@ -269,13 +291,14 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
   const uint8_t* __restrict__ ops = a.ops + h.op_off;
   const double* __restrict__ prm = a.prm + h.prm_off;
   const bool rankt = a.lagr != nullptr;       // rank tables: read in place (global memory), only the tile's ranks go to LDS
-  const int lstride = rankt ? a.lag_stride : 256;
+  const int lstride = rankt ? (a.clt.B != nullptr ? a.clt.gstride : a.lag_stride) : 256;      // (compact tables: whole, in place, with B)
   int* xrk = reinterpret_cast<int*>(sig + h.n_cp * 256 + (rankt ? 0 : h.n_lag * 256));      // [256] ranks (rank tables only)
   double* etab = reinterpret_cast<double*>(xrk) + (rankt ? 128 : 0);      // [128] exp table (launch_cov sizes the dynamic LDS for all of it)
   if (AGP_EXP_TABLE && tid < AGP_EXP_TAB_N) etab[tid] = fm::c_exp_tab[tid];
   cov_prologue<true>(a.tt, a.code, ti, tj, h, ops, prm, tpt, sig, tid, a.lagtab, a.nt, a.lagr, lstride, xrk, false);
   const double* lag = rankt ? a.lagtab + (long long)h.lag_off * lstride : sig + h.n_cp * 256;
   const int* rk = rankt ? xrk : nullptr;
+  const int* cb = rankt ? a.clt.B : nullptr;
 
   const int rp = tid & 63;        // row pair: rows 2rp, 2rp+1
   const int cb0 = a.csplit == 4 ? (int)blockIdx.z * 32 + (tid >> 6) * 8 : (tid >> 6) * 32;      // this thread's first column
@@ -314,8 +337,8 @@ __global__ __launch_bounds__(256, AGP_COV_WGS) void k_cov_tiles(CovArgs a) {
       ri[e] = r0 + (e & 1);
       ci[e] = NB + c0 + (e >> 1);
     }
-    if (one_node) eval_leaf<E, 0>(op1, q0, q1, q2, sig, lag, tr, tc, ri, ci, lt, etab, out, rk);      // (no interpreter: see chol_tile)
-    else eval_program<D, E, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lag, rk, lstride);
+    if (one_node) eval_leaf<E, 0>(op1, q0, q1, q2, sig, lag, tr, tc, ri, ci, lt, etab, out, rk, cb);      // (no interpreter: see chol_tile)
+    else eval_program<D, E, 0>(h, ops, prm, sig, tr, tc, ri, ci, lt, out, etab, lag, rk, lstride, cb);
 #pragma unroll
     for (int cc = 0; cc < CPP; ++cc) {
       const int gj = tj * NB + c0 + cc;

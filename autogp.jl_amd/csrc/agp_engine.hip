@@ -296,9 +296,10 @@ int emit_grad(const std::vector<CNode>& nodes, int id, Batch& bt, int prm_base, 
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                   const double* prm, Batch& bt, bool allow_sel, bool want_grad, bool ge_tab,
-                  bool fuse_hint, bool flow_limit, bool lag, int lag_units, bool rank_mode) {
-  // (lag_units: LDS footprint of one lag table in 256-double units — 1 on a sorted sweep, n_max / 256 for rank tables; rank_mode
-  // adds one unit for the tile's ranks and, in k_cov_tiles, the exponential table behind them — also when n_max <= 256)
+                  bool fuse_hint, bool flow_limit, bool lag, int lag_units, int rank_extra) {
+  // (lag_units: LDS footprint of one lag table in 256-double units — 1 on a sorted sweep, n_max / 256 for rank tables; rank_extra > 0:
+  // rank / compact tables — that many units for the tile's ranks or keys (in k_cov_tiles: and the exponential table behind them; also
+  // when n_max <= 256) and, with compact tables, the B entries the tile stages)
   std::vector<Compiled> cps(P);
   std::vector<double> cost(P, 0.0);
   for (int p = 0; p < P; ++p) {
@@ -324,7 +325,7 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   // stationary leaves there — see compile_program — must be prebuilt: the GM = 2 instantiations have no transcendental code)
   auto lag_ok = [&](int p) { bool direct = false; for (uint8_t o : cps[p].ops) direct |= (o == OP_SE || o == OP_GE || o == OP_PER || o == OP_GE_TAB); return !direct; };
   auto fusable = [&](int p) {
-    if (lag) return fuse_on && cost[p] <= fuse_limit && lag_ok(p) && cps[p].n_cp + cps[p].n_lag * lag_units + (rank_mode ? 1 : 0) <= U_MAX_CP;
+    if (lag) return fuse_on && cost[p] <= fuse_limit && lag_ok(p) && cps[p].n_cp + cps[p].n_lag * lag_units + rank_extra <= U_MAX_CP;
     return fuse_on && cost[p] <= fuse_limit && cps[p].n_cp <= U_MAX_CP;
   };
   bt.order.resize(P);
@@ -355,8 +356,8 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
     bt.hdr[q] = h;
     bt.ops.insert(bt.ops.end(), cp.ops.begin(), cp.ops.end());
     bt.prm.insert(bt.prm.end(), cp.prm.begin(), cp.prm.end());
-    const int lds_units = cp.n_cp + cp.n_lag * lag_units + (rank_mode ? 1 : 0);      // LDS tables of any kind (per-point + lag), 256 doubles each
-    bt.max_cp = std::max(bt.max_cp, rank_mode ? cp.n_cp + 1 : lds_units);      // (k_cov_tiles reads rank tables in place)
+    const int lds_units = cp.n_cp + cp.n_lag * lag_units + rank_extra;      // LDS tables of any kind (per-point + lag), 256 doubles each
+    bt.max_cp = std::max(bt.max_cp, rank_extra > 0 ? cp.n_cp + 1 : lds_units);      // (k_cov_tiles reads rank / compact tables, and B, in place)
     bt.max_depth = std::max(bt.max_depth, cp.depth_need);
     if (fusable(bt.order[q])) {
       bt.n_fused = q + 1;
@@ -965,16 +966,30 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   // gather costs the texture path ~64 clocks per wave instruction whatever the locality (NOTES_dead_ends.md, round 5) — so such a
   // series keeps the general evaluator.
   bool lagr = !lag && allow_lag && c->lag_rank_enable && c->lag_enable && c->lag_ok && n > 0 && rank_units <= LAG_LDS_MAX_UNITS;
-  const bool sorted = lag;          // the sweep runs on the sorted copy of the series (d_ts_s / d_xs_s)
+  // COMPACT tables (CltArgs) for what that bound keeps out — month starts, quarters, years: W entries per ordinal difference instead of
+  // one per lattice lag.  Whole tables in LDS while W n_max <= 4096 entries (any order of the points, any prefix: the sweeps Gen drives
+  // through the store included); longer series on the batch entry's sorted sweep, where a tile needs the window of its 256 ordinal
+  // differences only (W x 2 KiB per table).
+  const bool clt = !lag && !lagr && allow_lag && c->lag_rank_enable && c->lag_enable && c->clt_ok && n > 0;
+  const int clt_wunits = clt ? (int)(((int64_t)c->clt_W * c->n_max + 255) / 256) : 0;
+  const bool cltw = clt && clt_wunits <= LAG_LDS_MAX_UNITS;
+  const bool clts = clt && !cltw && !go && n == c->n_max;
+  const bool rankm = lagr || cltw || clts;          // tables read through per-point ranks / keys
+  const int tab_units = cltw ? clt_wunits : clts ? c->clt_W : rank_units;          // LDS units (256 doubles) per table
+  const int tab_gstride = (cltw || clts) ? c->clt_gstride : rank_units * 256;      // doubles per table in global memory
+  const int clt_nB = cltw ? (int)((c->n_max + 1) & ~(int64_t)1) : clts ? 256 : 0;
+  const int rank_extra = (cltw || clts) ? (256 + clt_nB + 511) / 512 : lagr ? 1 : 0;
+  const bool sorted = lag || clts;          // the sweep runs on the sorted copy of the series (d_ts_s / d_xs_s)
   HostProf hp_cb(2);
-  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint, lag || lagr, lagr ? rank_units : 1, lagr);
+  int rc = compile_batch(c, P, op_off, ops, prm_off, prm, bt, false, go != nullptr, ge_tab, flow_hint, flow_hint, lag || rankm, rankm ? tab_units : 1, rank_extra);
   hp_cb.stop();
   if (rc) return rc;
   HostProf hp_cls(3);
   if (lagr) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_rank_sweeps; }
+  if (cltw || clts) { std::lock_guard<std::mutex> g(c->mu); ++c->n_clt_sweeps; }
   if (go && bt.g_max_nodes > 64) return fail(c, AGP_ERR_PROGRAM, "gradient supports kernel trees of up to 64 nodes");
   if (go && n > 23040) return fail(c, AGP_ERR_ARG, "gradient sweeps address a particle's packed matrix with 32-bit byte offsets: n <= 23040");
-  if (sorted) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_sweeps; }
+  if (lag) { std::lock_guard<std::mutex> g(c->mu); ++c->n_lag_sweeps; }
   // Gradient sweeps on a regular grid (any order of the points): particles whose kernel is a sum of stationary subtrees and
   // Linear leaves are contracted in the lag domain (k_kinv_tiles / k_lag_grad, agp_grad_kernel.hpp)
   int32_t toep_rank0 = 0;
@@ -1260,17 +1275,18 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       up.add(s->goff.p, goff_sorted.data(), sizeof(int32_t) * P);
       HIPCHK(c, up.flush(s->h_stage2, st));
     }
-    if ((lag || lagr) && bt.n_lag_tables > 0) {
+    if ((lag || rankm) && bt.n_lag_tables > 0) {
       // the sweep's lag tables: every stationary leaf of every particle at the 255 lags of each of the nt block diagonals
       // (sorted sweep) / at every lag 0 .. n_max-1 of the series (rank tables)
       LagArgs la = {};
-      la.tt = lagr ? c->d_ts_lat : c->d_ts_s; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
+      la.tt = (cltw || clts) ? c->d_clt_tt : lagr ? c->d_ts_lat : c->d_ts_s; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
       la.tops = reinterpret_cast<const uint8_t*>(dstage + o_tops); la.tprm = reinterpret_cast<const double*>(dstage + o_tprm);
       la.n_tables = bt.n_lag_tables;
-      if (lagr) {
-        HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * rank_units * 256));
-        la.tab = s->lagtab.as<double>(); la.nt = (int)((c->n_lat + NB - 1) / NB); la.full = 1; la.stride = rank_units * 256;
-        launch_lag_tables(st, la, rank_units, bt.n_lag_tables);
+      if (rankm) {
+        // (compact tables: entry e at the "time" d_clt_tt[e] = its lattice lag x h, every entry of the padded table is evaluated)
+        HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * tab_gstride));
+        la.tab = s->lagtab.as<double>(); la.nt = lagr ? (int)((c->n_lat + NB - 1) / NB) : tab_gstride / NB; la.full = 1; la.stride = tab_gstride;
+        launch_lag_tables(st, la, tab_gstride / 256, bt.n_lag_tables);
       } else {
         HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * nt * 256));
         la.tab = s->lagtab.as<double>(); la.nt = nt;
@@ -1293,9 +1309,10 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         cv.tt = sorted ? c->d_ts_s : c->d_ts; cv.n1 = (int)n; cv.n1_pad = n_pad; cv.m2 = 0; cv.nt = nt;
         cv.hdr = d_hdr + p0 + g0; cv.ops = d_ops; cv.prm = d_prm;
         cv.noise = d_noise + p0 + g0; cv.A = s->A.as<double>() + (size_t)g0 * strideA;
-        cv.strideA = strideA; cv.P = Pg; cv.logdt = (ge_tab && !lag && !lagr) ? c->d_logdt : nullptr;
-        cv.lagtab = (lag || lagr) ? s->lagtab.as<double>() : nullptr;
-        cv.lagr = lagr ? c->d_rank : nullptr; cv.lag_stride = rank_units * 256;
+        cv.strideA = strideA; cv.P = Pg; cv.logdt = (ge_tab && !lag && !rankm) ? c->d_logdt : nullptr;
+        cv.lagtab = (lag || rankm) ? s->lagtab.as<double>() : nullptr;
+        cv.lagr = lagr ? c->d_rank : cltw ? c->d_clt_key : clts ? c->d_clt_key_s : nullptr; cv.lag_stride = tab_units * 256;
+        if (cltw || clts) { cv.clt.B = c->d_clt_B; cv.clt.W = clts ? c->clt_W : 0; cv.clt.nB = clt_nB; cv.clt.gstride = tab_gstride; }
         int i0min = 0;
         if (n_hit > 0) {
           // resident factors: forward-solve vector and partials are copied out of the store; L and the inverse blocks
@@ -1326,7 +1343,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         ca.partial = s->partial.as<double>() + (size_t)g0 * 2 * nt;
         ca.info = s->info.as<int>() + g0; ca.P = Pg; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
         set_cov(ca, cv);
-        ca.lag = (lag || lagr) ? 1 : 0;
+        ca.lag = (lag || rankm) ? 1 : 0;
         ca.n_fused = nf;
         ca.ready = s->ready.as<int>() + g0;
         ca.i0 = cv.i0;
@@ -1726,6 +1743,10 @@ void agp_destroy(agp_ctx* c) {
   if (c->d_ts_s) (void)hipFree(c->d_ts_s);
   if (c->d_xs_s) (void)hipFree(c->d_xs_s);
   if (c->d_rank) (void)hipFree(c->d_rank);
+  if (c->d_clt_key) (void)hipFree(c->d_clt_key);
+  if (c->d_clt_key_s) (void)hipFree(c->d_clt_key_s);
+  if (c->d_clt_B) (void)hipFree(c->d_clt_B);
+  if (c->d_clt_tt) (void)hipFree(c->d_clt_tt);
   if (c->d_ts_lat) (void)hipFree(c->d_ts_lat);
   if (c->d_fft_tw) (void)hipFree(c->d_fft_tw);
   if (c->d_flow_trace) (void)hipFree(c->d_flow_trace);
@@ -1777,7 +1798,10 @@ struct LatticeFit {
 // hint_h: spacing of the lattice the previous series sat on (an append, src/api.jl:426-443, keeps the old points — the reference
 // transforms the new dates with the model's own slope and intercept — so the old spacing is tried first: the times of the
 // unoccupied lattice points, and with them the resident factors' table entries, then stay bit for bit what they were).
-static LatticeFit fit_lattice(const std::vector<double>& tss, double lag_tol_h, bool allow_gaps, double hint_h = 0.0) {
+// max_lat / table_bound: the longest lattice admitted and whether a table over its lags must stay shorter than the elements it stands
+// for (rank tables: LATTICE_MAX, yes; compact tables, which hold W entries per ORDINAL difference: CLT_MAX_LAT, no).
+static LatticeFit fit_lattice(const std::vector<double>& tss, double lag_tol_h, bool allow_gaps, double hint_h = 0.0,
+                              int64_t max_lat = LATTICE_MAX, bool table_bound = true) {
   LatticeFit lf;
   const int64_t n_max = (int64_t)tss.size();
   if (n_max < 2) return lf;
@@ -1819,7 +1843,7 @@ static LatticeFit fit_lattice(const std::vector<double>& tss, double lag_tol_h, 
       const double tol_l = lag_tol_h * dmin - quant;
       if (distinct && tol_l > 0.0) {
         lat.resize((size_t)n_max);
-        if (hint_h > 0.0 && (t1 - t0) / hint_h <= (double)(LATTICE_MAX - 1) && 2.0 * ((t1 - t0) / hint_h) <= (double)n_max * (double)n_max) {
+        if (hint_h > 0.0 && (t1 - t0) / hint_h <= (double)(max_lat - 1) && (!table_bound || 2.0 * ((t1 - t0) / hint_h) <= (double)n_max * (double)n_max)) {
           bool ok = true;
           for (int64_t i = 0; ok && i < n_max; ++i) {
             const double g = std::nearbyint((tss[(size_t)i] - t0) / hint_h);
@@ -1831,7 +1855,7 @@ static LatticeFit fit_lattice(const std::vector<double>& tss, double lag_tol_h, 
         for (int k = 1; k <= LATTICE_MAX_DIV && !lattice; ++k) {
           const double h0 = dmin / (double)k;
           // (a table of n_lat lags must stay below the n (n + 1) / 2 elements it stands for)
-          if ((t1 - t0) / h0 > (double)(LATTICE_MAX - 1) || 2.0 * ((t1 - t0) / h0) > (double)n_max * (double)n_max) break;
+          if ((t1 - t0) / h0 > (double)(max_lat - 1) || (table_bound && 2.0 * ((t1 - t0) / h0) > (double)n_max * (double)n_max)) break;
           bool ok = true;
           for (int64_t i = 0; ok && i < n_max; ++i) {
             const double q = (tss[(size_t)i] - t0) / h0, g = std::nearbyint(q);
@@ -1853,6 +1877,37 @@ static LatticeFit fit_lattice(const std::vector<double>& tss, double lag_tol_h, 
   return lf;
 }
 
+// Compact-table test of a sorted series the rank-table bounds turned away (see CltArgs): the lattice, the smallest lattice lag
+// base[od] of every ordinal difference and the number W of lags per ordinal difference; ok when W <= CLT_MAX_W.
+struct CompactFit {
+  bool ok = false;
+  int64_t W = 0;
+  LatticeFit lat;
+  std::vector<int64_t> base;
+};
+static CompactFit fit_compact(const std::vector<double>& tss, double lag_tol_h, double hint_h = 0.0) {
+  CompactFit cf;
+  const int64_t n_max = (int64_t)tss.size();
+  if (n_max < 3 || n_max > CLT_MAX_N) return cf;
+  cf.lat = fit_lattice(tss, lag_tol_h, true, hint_h, CLT_MAX_LAT, false);
+  if (cf.lat.kind != 2 || cf.lat.n_lat > CLT_MAX_LAT) return cf;
+  const std::vector<int64_t>& gl = cf.lat.index;
+  std::vector<int64_t> top((size_t)n_max, 0);
+  cf.base.assign((size_t)n_max, INT64_MAX);
+  cf.base[0] = 0;
+  for (int64_t i = 0; i < n_max; ++i)
+    for (int64_t j = i + 1; j < n_max; ++j) {
+      const int64_t lagv = gl[(size_t)j] - gl[(size_t)i];
+      int64_t& b = cf.base[(size_t)(j - i)]; int64_t& tp = top[(size_t)(j - i)];
+      if (lagv < b) b = lagv;
+      if (lagv > tp) tp = lagv;
+    }
+  cf.W = 1;
+  for (int64_t od = 1; od < n_max; ++od) cf.W = std::max(cf.W, top[(size_t)od] - cf.base[(size_t)od] + 1);
+  cf.ok = cf.W <= CLT_MAX_W;
+  return cf;
+}
+
 int agp_probe_lattice(const double* ts, int64_t n, int32_t* kind, int64_t* n_lattice, double* spacing, int64_t* index_out) {
   if (n < 0 || (n > 0 && !ts)) return AGP_ERR_ARG;
   for (int64_t i = 0; i < n; ++i)
@@ -1869,7 +1924,11 @@ int agp_probe_lattice(const double* ts, int64_t n, int32_t* kind, int64_t* n_lat
     std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return ts[a] < ts[b]; });
     std::vector<double> tss((size_t)n);
     for (int64_t i = 0; i < n; ++i) tss[(size_t)i] = ts[perm[(size_t)i]];
-    const LatticeFit lf = fit_lattice(tss, 1e-11, true);
+    LatticeFit lf = fit_lattice(tss, 1e-11, true);
+    if (lf.kind == 0) {          // (kind 3: a longer lattice served by compact tables, see CltArgs)
+      CompactFit cf = fit_compact(tss, 1e-11);
+      if (cf.ok) { lf = std::move(cf.lat); lf.kind = 3; }
+    }
     if (kind) *kind = lf.kind;
     if (n_lattice) *n_lattice = lf.kind ? lf.n_lat : 0;
     if (spacing) *spacing = lf.kind ? lf.h : 0.0;
@@ -1902,6 +1961,8 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
     }
   }
   const bool lag_was = c->lag_ok, contig_was = c->lag_contig;
+  const bool clt_was = c->clt_ok;
+  const double clt_h_was = c->clt_h, clt_t0_was = c->clt_t0;
   const std::vector<double> tlat_was = c->h_ts_lat;
   const double grid_h_was = c->grid_h;
   const double t0_was = c->h_ts_sorted.empty() ? std::nan("") : c->h_ts_sorted.front();
@@ -1928,6 +1989,11 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
   if (c->d_ts_s) { HIPCHK(c, hipFree(c->d_ts_s)); c->d_ts_s = nullptr; }
   if (c->d_xs_s) { HIPCHK(c, hipFree(c->d_xs_s)); c->d_xs_s = nullptr; }
   if (c->d_rank) { HIPCHK(c, hipFree(c->d_rank)); c->d_rank = nullptr; }
+  c->clt_ok = false; c->clt_W = 0; c->clt_gstride = 0;
+  if (c->d_clt_key) { HIPCHK(c, hipFree(c->d_clt_key)); c->d_clt_key = nullptr; }
+  if (c->d_clt_key_s) { HIPCHK(c, hipFree(c->d_clt_key_s)); c->d_clt_key_s = nullptr; }
+  if (c->d_clt_B) { HIPCHK(c, hipFree(c->d_clt_B)); c->d_clt_B = nullptr; }
+  if (c->d_clt_tt) { HIPCHK(c, hipFree(c->d_clt_tt)); c->d_clt_tt = nullptr; }
   bool finite_ts = true;      // (a NaN among the time points would break the sort's ordering; such a series takes the general path)
   for (int64_t i = 0; i < n_max && finite_ts; ++i) finite_ts = std::isfinite(ts[i]);
   if (c->lag_enable && n_max >= 2 && finite_ts) {
@@ -1995,6 +2061,51 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
       c->h_ts_sorted = tss;
       c->h_rank.assign(rank.begin(), rank.begin() + n_max);
       c->h_ts_lat.assign(tl.begin(), tl.begin() + n_lat);
+    } else if (c->lattice_enable != 0 && n_max >= 3 && n_max <= CLT_MAX_N) {
+      // Compact tables: a lattice with gaps beyond LATTICE_MAX points.  In time order the lattice lag of a pair (i, i + od) lies in
+      // base[od] .. base[od] + W - 1; month starts have W <= 5 (od months last 28 od .. 31 od days, but every run of od consecutive months
+      // is within 4 days of every other), a daily index with a few long gaps has a large W and keeps the general evaluator.  The old
+      // spacing is tried first after an append, as for the shorter lattices: the table entries k(lag x h) of the resident factors'
+      // rows then stay what they were.
+      const CompactFit cf = fit_compact(tss, c->lag_tol_h, (clt_was && clt_t0_was == t0) ? clt_h_was : 0.0);
+      {
+        const LatticeFit& lc = cf.lat;
+        const std::vector<int64_t>& gl = lc.index;
+        const std::vector<int64_t>& base = cf.base;
+        const int64_t W = cf.W;
+        if (cf.ok) {
+          const int64_t n_pad = ((n_max + NB - 1) / NB) * NB;
+          const int64_t gstride = ((W * (n_pad + 256) + 255) / 256) * 256;
+          std::vector<int32_t> key((size_t)npad, 0), key_s((size_t)npad, 0), Bv((size_t)npad + 256, 0);
+          for (int64_t i = 0; i < n_max; ++i) {
+            const int32_t k = (int32_t)((i << CLT_SHIFT) | gl[(size_t)i]);
+            key_s[(size_t)i] = k; key[(size_t)perm[(size_t)i]] = k;
+          }
+          // (padding rows / columns: the last point's key — their elements are overwritten, their table reads must stay in range)
+          for (int64_t i = n_max; i < npad; ++i) { key_s[(size_t)i] = key_s[(size_t)n_max - 1]; key[(size_t)i] = key_s[(size_t)n_max - 1]; }
+          std::vector<double> ttc((size_t)gstride, 0.0);
+          for (int64_t od = 0; od < n_max; ++od) {
+            Bv[(size_t)od] = (int32_t)(W * od - base[(size_t)od]);
+            for (int64_t off = 0; off < W; ++off) ttc[(size_t)(W * od + off)] = (double)(base[(size_t)od] + off) * lc.h;      // (lag x h as ONE product: see the lattice times above)
+          }
+          for (int64_t od = n_max; od < npad + 256; ++od) Bv[(size_t)od] = Bv[(size_t)n_max - 1];
+          HIPCHK(c, hipMalloc((void**)&c->d_ts_s, sizeof(double) * npad));
+          HIPCHK(c, hipMalloc((void**)&c->d_xs_s, sizeof(double) * npad));
+          HIPCHK(c, hipMemset(c->d_ts_s, 0, sizeof(double) * npad));
+          HIPCHK(c, hipMemset(c->d_xs_s, 0, sizeof(double) * npad));
+          HIPCHK(c, hipMemcpy(c->d_ts_s, tss.data(), sizeof(double) * n_max, hipMemcpyHostToDevice));
+          HIPCHK(c, hipMemcpy(c->d_xs_s, xss.data(), sizeof(double) * n_max, hipMemcpyHostToDevice));
+          HIPCHK(c, hipMalloc((void**)&c->d_clt_key, sizeof(int32_t) * npad));
+          HIPCHK(c, hipMalloc((void**)&c->d_clt_key_s, sizeof(int32_t) * npad));
+          HIPCHK(c, hipMalloc((void**)&c->d_clt_B, sizeof(int32_t) * (npad + 256)));
+          HIPCHK(c, hipMalloc((void**)&c->d_clt_tt, sizeof(double) * gstride));
+          HIPCHK(c, hipMemcpy(c->d_clt_key, key.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice));
+          HIPCHK(c, hipMemcpy(c->d_clt_key_s, key_s.data(), sizeof(int32_t) * npad, hipMemcpyHostToDevice));
+          HIPCHK(c, hipMemcpy(c->d_clt_B, Bv.data(), sizeof(int32_t) * (npad + 256), hipMemcpyHostToDevice));
+          HIPCHK(c, hipMemcpy(c->d_clt_tt, ttc.data(), sizeof(double) * gstride, hipMemcpyHostToDevice));
+          c->clt_ok = true; c->clt_W = (int)W; c->clt_h = lc.h; c->clt_t0 = t0; c->clt_gstride = (int)gstride; c->clt_n_lat = lc.n_lat;
+        }
+      }
     }
   }
   if (!c->lag_ok) { c->h_ts_sorted.clear(); c->h_rank.clear(); c->h_ts_lat.clear(); c->lag_contig = false; c->n_lat = 0; }
@@ -2006,7 +2117,8 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
     std::lock_guard<std::mutex> g(c->store.mu);
     // (lattice times: on a regular grid the sorted series itself; with gaps also the computed times of the unoccupied points,
     // which move by an ulp when an append changes the refined spacing)
-    bool same = lag_was == c->lag_ok && contig_was == c->lag_contig;
+    // (compact tables: an entry is k(lag x h), so the resident rows keep their values exactly when the spacing is bit for bit the same)
+    bool same = lag_was == c->lag_ok && contig_was == c->lag_contig && clt_was == c->clt_ok && (!clt_was || clt_h_was == c->clt_h);
     if (same && c->lag_ok)
       same = tlat_was.size() <= c->h_ts_lat.size() &&
              std::memcmp(tlat_was.data(), c->h_ts_lat.data(), sizeof(double) * tlat_was.size()) == 0;

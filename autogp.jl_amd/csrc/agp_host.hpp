@@ -210,6 +210,19 @@ struct agp_ctx {
                                   // on one fixed schedule, every element from its own t_i - t_j, dense predictive pass, element-wise gradient, no store
   int lattice_enable = 1;         // admit lattices with gaps (calendar-indexed series: monthly / quarterly / yearly / business-day dates are
                                   // integer multiples of a day after datetime2unix, src/api.jl:49-51,98-101); env AGP_LATTICE=0: regular grids only
+  // Compact lag tables (CltArgs, agp_args.hpp): a lattice with gaps too long for rank tables — more than LATTICE_MAX lattice points —
+  // whose lattice lags at a fixed ordinal difference span at most CLT_MAX_W values (month starts, quarters, years).  lag_ok stays
+  // false: only the tile evaluators of the value / factorisation sweeps read these tables.
+  bool clt_ok = false;
+  int clt_W = 0;                  // lattice lags per ordinal difference
+  double clt_h = 0.0, clt_t0 = 0.0;      // lattice spacing (a table entry is k(lag * h)), first time point
+  int32_t* d_clt_key = nullptr;   // (ordinal << CLT_SHIFT) | lattice index of resident point i (caller's order, padded with the last point's key)
+  int32_t* d_clt_key_s = nullptr; // ... of sorted point i
+  int32_t* d_clt_B = nullptr;     // [npad + 256] W od - base[od]
+  double* d_clt_tt = nullptr;     // [clt_gstride] "time" of table entry e = W od + off: (base[od] + off) * h
+  int clt_gstride = 0;            // doubles per table (global memory)
+  int64_t clt_n_lat = 0;          // lattice points the series spans
+  int64_t n_clt_sweeps = 0;
   std::vector<double> h_ts_lat;   // time of lattice point g (length n_lat).  Regular grid (lag_contig): the data's own value (keeps table and element bit-compatible).  Lattice with gaps: g * h as ONE product, relative to lattice point 0 — never the difference of two rescaled dates (NOTES round 5)
   double* d_ts_lat = nullptr;     // ... on the device, padded to a whole 256-lag unit + one (k_lag_tables, rank tables)
   int toeplitz = 0;              // structured value sweeps (Schur algorithm) for the Toeplitz + rank-2 class; env AGP_LAG=2 / agp_set_lag_tables(ctx, 2)
@@ -368,7 +381,7 @@ struct Batch {
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                   const double* prm, Batch& bt, bool allow_sel = false, bool want_grad = false, bool ge_tab = false,
-                  bool fuse_hint = false, bool flow_limit = false, bool lag = false, int lag_units = 1, bool rank_mode = false);
+                  bool fuse_hint = false, bool flow_limit = false, bool lag = false, int lag_units = 1, int rank_extra = 0);
 
 // A tile evaluation longer than this (cost model op_cost_us: measured per-leaf cost of one 128x128 tile with two workgroups per
 // CU) would set the duration of the short launches; such particles get their tiles from k_cov_tiles.  Measured: per-column
@@ -379,6 +392,9 @@ constexpr double FUSE_MAX_US = 25.0, FLOW_FUSE_MAX_US = 70.0, FLOW_LAG_FUSE_MAX_
 constexpr int LAG_LDS_MAX_UNITS = 16;     // rank tables of up to 16 x 256 lags are copied into the evaluators' LDS
 constexpr int64_t LATTICE_MAX = LAG_LDS_MAX_UNITS * 256;   // longest lattice admitted: its rank tables must fit that LDS budget (longer tables would be
                                           // gathered from L2, which is slower than evaluating the leaves: logpdf_batch_impl, NOTES_dead_ends.md round 5)
+constexpr int64_t CLT_MAX_LAT = (int64_t)1 << CLT_SHIFT;      // compact tables: lattice indices below 2^19 (1 400 years of days) ...
+constexpr int CLT_MAX_N = 4096;                // ... ordinals in the 12 bits above them
+constexpr int CLT_MAX_W = 8;                   // ... and at most this many lattice lags per ordinal difference
 constexpr int LATTICE_MAX_DIV = 400;      // the lattice spacing is sought as (smallest gap) / k, k <= this (a yearly index: 365 / 366 days)
 constexpr int HYBRID_BLOCKS = 512;        // medium populations: right-looking once a block column offers fewer workgroups (run_factor)
 constexpr double GRAD_TOEP_MAX_AMP = 1e4;  // ... and the largest entry of U' T^-1 U C it accepts (the downdate loses that factor times ~100 eps)
@@ -406,7 +422,7 @@ int64_t ws_limit_bytes(agp_ctx* c);       // bytes a call may take for its per-p
 inline void set_cov(CholArgs& ca, const CovArgs& cv) {
   ca.tt = cv.tt; ca.n1 = cv.n1; ca.n1_pad = cv.n1_pad; ca.m2 = cv.m2;
   ca.hdr = cv.hdr; ca.ops = cv.ops; ca.prm = cv.prm; ca.noise = cv.noise; ca.code = cv.code; ca.logdt = cv.logdt;
-  ca.lagtab = cv.lagtab; ca.lagr = cv.lagr; ca.lag_stride = cv.lag_stride;
+  ca.lagtab = cv.lagtab; ca.lagr = cv.lagr; ca.lag_stride = cv.lag_stride; ca.clt = cv.clt;
 }
 
 

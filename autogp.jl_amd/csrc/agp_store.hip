@@ -158,6 +158,9 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   hp_k.stop();
   HostProf hp_cap(11);
   std::unique_lock<std::mutex> lk(fs.mu);
+  std::vector<int32_t> hit;            // slot of distinct particle u from the capacity pass's lookup (valid while the store keeps its size)
+  bool hit_valid = false;
+  int n_miss = 0;
   {
     // capacity: slots sized for the resident data, at least twice this batch (a population mid-rejuvenation keeps its previous
     // states), within the store's share of device memory — and beyond that DRIVEN BY PRESSURE: the store grows rather than evict a
@@ -173,22 +176,30 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     static const bool self_size = [] { const char* e = getenv("AGP_STORE_SELF_SIZE"); return !(e && atoi(e) == 0); }();      // (0: round 5's rule, for A/B runs)
     const int basic_slots = std::max(std::max(2 * U, self_size ? 2 * c->n_callers.load() : 0), 32);
     int want_slots = std::max(fs.n_slots.load(), std::max(2 * U, 32));
-    if (self_size && fs.n_slots > 0) {
+    if (fs.n_slots > 0) {
+      // (one lookup per distinct particle, kept for the slot assignment below unless the store is resized in between; a sweep whose
+      // particles are all resident — the common extension step — then touches nothing else: no scan of the slots, no candidate list)
+      hit.assign((size_t)U, -1);
+      for (int u = 0; u < U; ++u) { auto it = fs.index.find(keys[u]); if (it != fs.index.end()) hit[(size_t)u] = it->second; else ++n_miss; }
+      hit_valid = true;
+    } else n_miss = U;
+    if (self_size && fs.n_slots > 0 && n_miss > 0) {
       const uint64_t now = fs.clock + 1;
-      int misses = 0, evictable = 0;
-      std::unordered_set<int> mine;
-      for (int u = 0; u < U; ++u) { auto it = fs.index.find(keys[u]); if (it != fs.index.end()) mine.insert(it->second); else ++misses; }
+      int evictable = 0;
+      std::vector<uint8_t> mine((size_t)fs.n_slots, 0);
+      for (int u = 0; u < U; ++u) if (hit[(size_t)u] >= 0) mine[(size_t)hit[(size_t)u]] = 1;
       for (int sl = 0; sl < fs.n_slots; ++sl) {
-        if (mine.count(sl)) continue;
+        if (mine[(size_t)sl]) continue;
         if (fs.key[(size_t)sl].empty() || fs.used[(size_t)sl] || now - fs.born[(size_t)sl] > STORE_YOUNG_CALLS) ++evictable;
       }
-      if (misses > evictable) want_slots = std::max(want_slots, std::min(fs.n_slots + (misses - evictable), std::max(fs.n_slots.load(), 2 * basic_slots)));
+      if (n_miss > evictable) want_slots = std::max(want_slots, std::min(fs.n_slots + (n_miss - evictable), std::max(fs.n_slots.load(), 2 * basic_slots)));
     }
     if (want_slots > fs.n_slots && fs.n_slots > 0) want_slots = std::max(want_slots, fs.n_slots + fs.n_slots / 2);   // (growth copies the store: few, larger steps)
     const size_t budget = (size_t)(fs.max_frac * (double)c->total_mem);
     const size_t per = store_bytes_per_slot(want_nt);
     if ((size_t)want_slots * per > budget) want_slots = (int)std::min<size_t>((size_t)want_slots, budget / per);
     if (want_slots < U) { lk.unlock(); return plain(); }      // population larger than the store may hold: no caching
+    if (want_nt != fs.nt_cap || want_slots != fs.n_slots) hit_valid = false;
     const int rc = store_resize(c, want_nt, want_slots);
     if (rc) { lk.unlock(); return plain(); }                  // no memory for the store right now: no caching
   }
@@ -196,16 +207,17 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   std::vector<int32_t> slot(U, -1), i0(U, 0);
   int64_t rows_reused = 0;
   for (int u = 0; u < U; ++u) {
-    auto it = fs.index.find(keys[u]);
-    if (it == fs.index.end()) { fs.ghost_probe(keys[u]); continue; }
-    const int sl = it->second;
+    int sl;
+    if (hit_valid) sl = hit[(size_t)u];
+    else { auto it = fs.index.find(keys[u]); sl = it == fs.index.end() ? -1 : it->second; }
+    if (sl < 0) { fs.ghost_probe(keys[u]); continue; }
     slot[u] = sl; fs.stamp[sl] = call;
     const int64_t nc = fs.n_cached[sl];
     i0[u] = nc == n ? nt : (nc < n ? (int32_t)(nc / NB) : 0);     // a factor of a LONGER prefix is redone
     if (i0[u] > 0) fs.used[(size_t)sl] = 1;
     rows_reused += i0[u];
   }
-  {
+  if (!hit_valid || n_miss > 0) {
     std::vector<int> cand;
     for (int sl = 0; sl < fs.n_slots; ++sl) if (fs.stamp[sl] != call) cand.push_back(sl);
     // Free slots first; then least recently used — EXCEPT that a factor nothing has started from yet, stored within the last
@@ -257,12 +269,21 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   // (rank tables too long for LDS — a lattice with gaps — do not pay in the caller's order: see logpdf_batch_impl)
   const int rank_units = (int)((c->n_lat + 255) / 256);
   const bool lagr = c->lag_rank_enable && c->lag_enable && c->lag_ok && rank_units <= LAG_LDS_MAX_UNITS;
-  const bool ge_tab = c->logdt_ok && !lagr;
+  // (compact tables, whole in LDS: see logpdf_batch_impl — again a property of the resident series alone)
+  const int clt_wunits = c->clt_ok ? (int)(((int64_t)c->clt_W * c->n_max + 255) / 256) : 0;
+  const bool cltw = !lagr && c->lag_rank_enable && c->lag_enable && c->clt_ok && clt_wunits <= LAG_LDS_MAX_UNITS;
+  const bool rankm = lagr || cltw;
+  const int tab_units = cltw ? clt_wunits : rank_units;
+  const int tab_gstride = cltw ? c->clt_gstride : rank_units * 256;
+  const int clt_nB = cltw ? (int)((c->n_max + 1) & ~(int64_t)1) : 0;
+  const int rank_extra = cltw ? (256 + clt_nB + 511) / 512 : lagr ? 1 : 0;
+  const bool ge_tab = c->logdt_ok && !rankm;
   // (tiles are evaluated inside the factorisation kernels whatever the population size: the prebuilt-tile variants of
   // the split launches carry the most register spills, and the store never needs K itself)
   int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, ge_tab, /*fuse_hint=*/true,
-                         /*flow_limit=*/c->flow != 0 && U <= FLOW_MAX_PARTICLES, lagr, lagr ? rank_units : 1, lagr);
+                         /*flow_limit=*/c->flow != 0 && U <= FLOW_MAX_PARTICLES, rankm, rankm ? tab_units : 1, rank_extra);
   if (rc) { poison(); return rc; }
+  if (cltw) { std::lock_guard<std::mutex> g(c->mu); ++c->n_clt_sweeps; }
   int i0min = nt;
   for (int u = 0; u < U; ++u) i0min = std::min(i0min, (int)i0[u]);
 
@@ -322,14 +343,14 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   int32_t* d_info = reinterpret_cast<int32_t*>(d_lp + U);
 
   if (i0min < nt) {
-    if (lagr && bt.n_lag_tables > 0) {
-      EXTCHK(s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * rank_units * 256));
+    if (rankm && bt.n_lag_tables > 0) {
+      EXTCHK(s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * tab_gstride));
       LagArgs la = {};
-      la.tt = c->d_ts_lat; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
+      la.tt = cltw ? c->d_clt_tt : c->d_ts_lat; la.thdr = reinterpret_cast<const LagTabHdr*>(dstage + o_thdr);
       la.tops = reinterpret_cast<const uint8_t*>(dstage + o_tops); la.tprm = reinterpret_cast<const double*>(dstage + o_tprm);
-      la.n_tables = bt.n_lag_tables; la.tab = s->lagtab.as<double>(); la.nt = (int)((c->n_lat + NB - 1) / NB);
-      la.full = 1; la.stride = rank_units * 256;
-      launch_lag_tables(st, la, rank_units, bt.n_lag_tables);
+      la.n_tables = bt.n_lag_tables; la.tab = s->lagtab.as<double>(); la.nt = cltw ? tab_gstride / NB : (int)((c->n_lat + NB - 1) / NB);
+      la.full = 1; la.stride = tab_gstride;
+      launch_lag_tables(st, la, tab_gstride / 256, bt.n_lag_tables);
       EXTCHK(hipGetLastError());
     }
     launch_init_extend(st, U, fs.vec.as<double>(), fs.nt_cap * NB, n_pad, c->d_xs, (int)n, d_slot, d_i0, fs.info.as<int>(), fs.ready.as<int>());
@@ -338,7 +359,8 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     cv.hdr = reinterpret_cast<ProgHdr*>(dstage + o_hdr); cv.ops = reinterpret_cast<uint8_t*>(dstage + o_ops);
     cv.prm = reinterpret_cast<double*>(dstage + o_prm); cv.noise = reinterpret_cast<double*>(dstage + o_noise);
     cv.A = fs.A.as<double>(); cv.strideA = fs.strideA; cv.P = U; cv.logdt = ge_tab ? c->d_logdt : nullptr;
-    cv.lagtab = lagr ? s->lagtab.as<double>() : nullptr; cv.lagr = lagr ? c->d_rank : nullptr; cv.lag_stride = rank_units * 256;
+    cv.lagtab = rankm ? s->lagtab.as<double>() : nullptr; cv.lagr = lagr ? c->d_rank : cltw ? c->d_clt_key : nullptr; cv.lag_stride = tab_units * 256;
+    if (cltw) { cv.clt.B = c->d_clt_B; cv.clt.W = 0; cv.clt.nB = clt_nB; cv.clt.gstride = tab_gstride; }
     cv.slot = d_slot; cv.i0 = d_i0;
     const int nf = std::max(0, std::min(U, bt.n_fused));
     const int dcov = nf > 0 ? bt.max_depth_fused : 0;
@@ -349,7 +371,7 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
     ca.vec = fs.vec.as<double>(); ca.ldv = fs.nt_cap * NB; ca.partial = fs.partial.as<double>(); ca.ntp = fs.nt_cap;
     ca.info = fs.info.as<int>(); ca.ready = fs.ready.as<int>(); ca.P = U; ca.nt = nt; ca.k = 0; ca.nt1 = nt;
     set_cov(ca, cv);
-    ca.lag = lagr ? 1 : 0;
+    ca.lag = rankm ? 1 : 0;
     ca.n_fused = nf; ca.slot = d_slot; ca.i0 = d_i0;
     // an extension touches every block column (the new rows' tiles of the old columns, then the new columns): one
     // dataflow launch instead of nt small per-column launches, whatever the amount of work
@@ -475,9 +497,20 @@ int agp_get_lattice_stats(agp_ctx* c, int32_t* kind, int64_t* n_lattice, double*
   if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
   std::lock_guard<std::mutex> g(c->mu);
   const bool on = c->lag_enable && c->lag_ok;
-  if (kind) *kind = !on ? 0 : c->lag_contig ? 1 : 2;
-  if (n_lattice) *n_lattice = on ? c->n_lat : 0;
-  if (spacing) *spacing = on ? c->grid_h : 0.0;
+  const bool compact = !on && c->lag_enable && c->clt_ok;
+  if (kind) *kind = compact ? 3 : !on ? 0 : c->lag_contig ? 1 : 2;
+  if (n_lattice) *n_lattice = compact ? c->clt_n_lat : on ? c->n_lat : 0;
+  if (spacing) *spacing = compact ? c->clt_h : on ? c->grid_h : 0.0;
+  return AGP_OK;
+}
+
+int agp_get_compact_stats(agp_ctx* c, int32_t* lags_per_ordinal, int64_t* table_entries, int64_t* n_sweeps) {
+  if (!c) return fail(nullptr, AGP_ERR_ARG, "null context");
+  std::lock_guard<std::mutex> g(c->mu);
+  const bool on = c->lag_enable && c->clt_ok;
+  if (lags_per_ordinal) *lags_per_ordinal = on ? c->clt_W : 0;
+  if (table_entries) *table_entries = on ? (int64_t)c->clt_W * c->n_max : 0;
+  if (n_sweeps) *n_sweeps = c->n_clt_sweeps;
   return AGP_OK;
 }
 

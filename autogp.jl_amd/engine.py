@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "agp_shard_range", "agp_comm_get_unique_id", "agp_comm_init_rank", "agp_comm_info", "agp_init_multi", "agp_set_data_multi",
     "agp_allgather_logweights", "agp_allgather_logweights_device", "agp_logpdf_batch_multi", "agp_logpdf_batch_extend_multi",
     "agp_debug_compact_shards", "agp_logpdf_batch_extend", "agp_extend_stats", "agp_extend_reset", "agp_extend_reserve",
-    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_get_lattice_stats", "agp_set_lattice", "agp_probe_lattice", "agp_set_reference_arithmetic", "agp_shard_plan", "agp_get_coalesce_timing", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_predict_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
+    "agp_predict_reuse_stats", "agp_grad_reuse_stats", "agp_set_factor_cache", "agp_wait", "agp_comm_count", "agp_get_lag_stats", "agp_get_lattice_stats", "agp_get_compact_stats", "agp_set_lattice", "agp_probe_lattice", "agp_set_reference_arithmetic", "agp_shard_plan", "agp_get_coalesce_timing", "agp_set_lag_tables", "agp_set_grad_lag_domain", "agp_get_grad_lag_domain_stats", "agp_get_grad_toeplitz_stats", "agp_get_grad_structured_stats", "agp_get_predict_structured_stats", "agp_get_toeplitz_stats", "agp_set_lag_rank_tables", "agp_get_lag_rank_stats", "agp_get_lag_predict_stats",
     "agp_logpdf_grad_batch_multi", "agp_predict_batch_multi", "agp_extend_stats2",
 ]
 COMM_ID_BYTES = 128
@@ -147,6 +147,7 @@ def load_library(path=None):
     lib.agp_get_lag_stats.argtypes = [vp, i32p, C.POINTER(C.c_int64)]; lib.agp_get_lag_stats.restype = C.c_int
     lib.agp_set_lag_tables.argtypes = [vp, C.c_int32]; lib.agp_set_lag_tables.restype = C.c_int
     lib.agp_get_lattice_stats.argtypes = [vp, i32p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]; lib.agp_get_lattice_stats.restype = C.c_int
+    lib.agp_get_compact_stats.argtypes = [vp, i32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]; lib.agp_get_compact_stats.restype = C.c_int
     lib.agp_set_lattice.argtypes = [vp, C.c_int32]; lib.agp_set_lattice.restype = C.c_int
     lib.agp_set_reference_arithmetic.argtypes = [vp, C.c_int32]; lib.agp_set_reference_arithmetic.restype = C.c_int
     lib.agp_probe_lattice.argtypes = [dp, C.c_int64, i32p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int64)]; lib.agp_probe_lattice.restype = C.c_int
@@ -368,10 +369,16 @@ class GPEngine:
 
     def lattice_stats(self):
         """dict(kind, n_lattice, spacing) of the resident series: kind 0 irregular (general path), 1 regular grid, 2 lattice with
-        gaps (calendar-indexed series: table-driven sweeps over n_lattice lags)."""
+        gaps (calendar-indexed series: table-driven sweeps over n_lattice lags), 3 a longer lattice served by compact tables."""
         k = C.c_int32(); g = C.c_int64(); h = C.c_double()
         self._check(self._lib.agp_get_lattice_stats(self._ctx, C.byref(k), C.byref(g), C.byref(h)))
         return {"kind": int(k.value), "n_lattice": int(g.value), "spacing": float(h.value)}
+
+    def compact_stats(self):
+        """dict(lags_per_ordinal, table_entries, sweeps): compact lag tables of a long calendar lattice (agp_get_compact_stats)."""
+        w = C.c_int32(); e = C.c_int64(); k = C.c_int64()
+        self._check(self._lib.agp_get_compact_stats(self._ctx, C.byref(w), C.byref(e), C.byref(k)))
+        return {"lags_per_ordinal": int(w.value), "table_entries": int(e.value), "sweeps": int(k.value)}
 
     def set_lattice(self, on):
         """Admit lattices with gaps at the next set_data (off: regular grids only)."""

@@ -421,7 +421,13 @@ function set_lag_tables!(eng::Engine, level::Integer)
 end
 set_lag_rank_tables!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_lag_rank_tables, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 1 : 0))
 set_grad_lag_domain!(eng::Engine, on::Bool) = check(eng, ccall((:agp_set_grad_lag_domain, LIB), Cint, (Ptr{Cvoid}, Int32), eng.ptr, on ? 2 : 0))
-"(kind, n_lattice, spacing) of the resident series: kind 0 irregular, 1 regular grid, 2 lattice with gaps (calendar indices)"
+"(lags_per_ordinal, table_entries, sweeps): compact lag tables of a long calendar lattice (monthly / quarterly / yearly dates)"
+function compact_stats(eng::Engine)
+    w = Ref{Int32}(0); ne = Ref{Int64}(0); ns = Ref{Int64}(0)
+    check(eng, ccall((:agp_get_compact_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int64}, Ref{Int64}), eng.ptr, w, ne, ns))
+    return (lags_per_ordinal = Int(w[]), table_entries = Int(ne[]), sweeps = Int(ns[]))
+end
+"(kind, n_lattice, spacing) of the resident series: kind 0 irregular, 1 regular grid, 2 lattice with gaps (calendar indices), 3 a longer lattice served by compact tables"
 function lattice_stats(eng::Engine)
     kind = Ref{Int32}(0); nl = Ref{Int64}(0); h = Ref{Float64}(0.0)
     check(eng, ccall((:agp_get_lattice_stats, LIB), Cint, (Ptr{Cvoid}, Ref{Int32}, Ref{Int64}, Ref{Float64}), eng.ptr, kind, nl, h))

@@ -327,8 +327,10 @@ def calendar_leg(pkg, programs, nodes, noises, n, device):
         n_lattice <= 4096 days: every caller-order sweep reads its stationary subtrees from rank tables in LDS, the gradient's
         contraction runs over the lattice's lags (K^-1 tiles' lag histograms); no Toeplitz path (the points are not consecutive);
       * `calendar_monthly`: n month starts from 1949-01-01 (28..31-day spacings; 62 304 days at n = 2048): too long a lattice for
-        LDS tables (gathering them from L2 was measured slower than evaluating the leaves: NOTES_dead_ends.md, round 5): general
-        evaluator, dense factor + L^-T + K^-1 + element-wise contraction for every particle."""
+        tables over its lags (gathering them from L2 was measured slower than evaluating the leaves: NOTES_dead_ends.md, round 5);
+        round 6: COMPACT tables indexed by (ordinal difference, lattice lag - base) — W n entries, per-tile windows in LDS on the value
+        entry's sorted sweep; the gradient and predictive sweeps keep the general evaluator (dense factor + L^-T + K^-1 + element-wise
+        contraction for every particle)."""
     import torch
     res = {}
     P = len(noises)
@@ -342,7 +344,7 @@ def calendar_leg(pkg, programs, nodes, noises, n, device):
             gen.set_lattice(False)
             eng.set_data(ts, xs); gen.set_data(ts, xs)
             st = eng.lattice_stats()
-            tables = st["kind"] == 2
+            tables = st["kind"] in (2, 3)
             d_lp = torch.zeros(P, dtype=torch.float64, device=f"cuda:{device}"); d_info = torch.zeros(P, dtype=torch.int32, device=f"cuda:{device}")
 
             def value(e, reps=20):
@@ -355,7 +357,8 @@ def calendar_leg(pkg, programs, nodes, noises, n, device):
                 return (time.perf_counter() - t0) / reps, d_lp.cpu().numpy(), d_info.cpu().numpy()
             dt, lp, info = value(eng)
             out = {"what": f"n={n} {'business days from 1949-01-03' if freq == 'B' else 'month starts from 1949-01-01'} (datetime2unix + min-max rescaling, shuffled), the same {P} particles",
-                   "lattice": st, "rank_tables": tables, "evals_per_s": P / dt, "ms_per_step": dt * 1e3}
+                   "lattice": st, "rank_tables": st["kind"] == 2, "compact_tables": eng.compact_stats() if st["kind"] == 3 else None,
+                   "evals_per_s": P / dt, "ms_per_step": dt * 1e3}
             if tables:
                 dt_g, lp_g, info_g = value(gen, 10)
                 ok = (info == 0) & (info_g == 0)

@@ -186,9 +186,22 @@ int agp_set_lag_tables(agp_ctx* ctx, int32_t on);
  * the table-driven evaluator.  The sorted sweeps with per-tile tables, the Toeplitz paths and the lag-domain gradient need
  * CONSECUTIVE lattice points and stay with regular grids.  Longer lattices (2048 month starts span 62 304 days) keep the general
  * evaluator: their tables would be gathered from L2, which was measured slower than evaluating the leaves (NOTES_dead_ends.md,
- * round 5).  agp_get_lattice_stats: kind = 0 (general path), 1 (regular grid), 2 (lattice with gaps); AGP_LATTICE=0 /
- * agp_set_lattice(ctx, 0) admit regular grids only (read at the next agp_set_data). */
+ * round 5).  agp_get_lattice_stats: kind = 0 (general path), 1 (regular grid), 2 (lattice with gaps), 3 (a longer lattice served by
+ * COMPACT tables, below); AGP_LATTICE=0 / agp_set_lattice(ctx, 0) admit regular grids only (read at the next agp_set_data).
+ *
+ * Compact tables (kind 3; round 6): the reference's flagship series are monthly (docs/src/tutorials/assets/tsdl.161.csv through
+ * src/api.jl:49-51,98-101) and a table over the lattice LAGS of 135 or more month starts exceeds the 4096 entries above.  In time
+ * order, though, the lattice lag of a pair (i, i + od) of such a series takes only a few values — month starts: at most 5 whatever
+ * od, quarters 4, years 2 — so a stationary subtree's table is indexed by (ordinal difference od, lattice lag - base[od]) and holds
+ * W n entries, W = the largest number of distinct lags at one ordinal difference (admitted up to 8, n <= 4096, spans below 2^19
+ * lattice points; the same position bound as above).  While W n <= 4096 the whole table sits in the evaluators' LDS and every value /
+ * factorisation sweep in the CALLER's order reads it (batch, prefix, factor store, the factorisation of a gradient sweep): 819 month
+ * starts, 68 years of monthly data.  Longer series (2048 month starts: 10 240 entries) use them on agp_logpdf_batch's sorted sweep over
+ * the whole series, where a tile needs the window of its 256 ordinal differences only.  The lag-domain gradient contraction, the
+ * predictive rank tables and the Toeplitz paths do not apply (lag_ok semantics unchanged).  agp_get_compact_stats: W, W n, and the
+ * number of sweeps that read compact tables. */
 int agp_get_lattice_stats(agp_ctx* ctx, int32_t* kind, int64_t* n_lattice, double* spacing);
+int agp_get_compact_stats(agp_ctx* ctx, int32_t* lags_per_ordinal, int64_t* table_entries, int64_t* n_sweeps);
 int agp_set_lattice(agp_ctx* ctx, int32_t on);
 /* The admission test alone, on n time points in any order (host code only: no context, no device): kind as above, the lattice's
  * length and spacing, and per point its lattice index (index_out, nullable; -1 when kind = 0). */

@@ -2,8 +2,9 @@
 datetime2unix and the min-max LinearTransform (src/api.jl:49-51,98-101; src/Transforms.jl:38,55-65): business days (gaps of 1 and 3
 days), month starts (28..31 days) and series with missing observations are not equally spaced but are all integer multiples of one
 day, so agp_set_data admits them as a lattice with gaps — up to 4096 lattice points, the LDS budget of a rank table — and every
-caller-order sweep reads its stationary subtrees from rank tables over the lattice's lags; longer lattices (700 month starts) keep
-the general evaluator.  Checked against the oracle (1e-8, north_star's tolerance; gradient 1e-7 of its scale), against an engine
+caller-order sweep reads its stationary subtrees from rank tables over the lattice's lags; longer lattices (700 month starts:
+21 276 days) are served by COMPACT tables indexed by (ordinal difference, lattice lag - base) — whole in LDS while W n <= 4096
+entries, per-tile windows on the batch entry's sorted sweep beyond that (2048 month starts).  Checked against the oracle (1e-8, north_star's tolerance; gradient 1e-7 of its scale), against an engine
 that admits regular grids only (the general evaluator: 1e-10), bit for bit between extension and from-scratch sweeps of the factor
 store, and that the paths that need CONSECUTIVE lattice points (sorted sweeps, Toeplitz class) are not taken."""
 import numpy as np
@@ -45,7 +46,13 @@ def series(pkg, freq, n, seed, shuffle=True):
                                                           ("missing", 1000, 24, 3, True, 2),  # a daily index with missing observations
                                                           ("M", 120, 5, 3, True, 2),          # month starts: 3 622 lattice points; right-looking schedule
                                                           ("B", 1024, 16, 6, True, 2),        # deep trees: many tables, ChangePoints beside them
-                                                          ("M", 700, 40, 3, True, 0)])        # 21 276 lattice points: general evaluator
+                                                          ("M", 700, 40, 3, True, 3),         # 21 276 lattice points: compact tables, whole in LDS (3 500 entries)
+                                                          ("M", 819, 300, 3, False, 3),       # ... at the LDS bound (4 095 entries), per-column launches
+                                                          ("Q", 300, 24, 6, True, 3),         # quarter starts, deep trees: tables read in place by k_cov_tiles
+                                                          ("Y", 200, 6, 3, True, 3),          # year starts (365 / 366 days): right-looking schedule
+                                                          ("M", 1400, 40, 3, True, 3),        # 8 400 entries: per-tile windows on the sorted sweep; prefixes: general evaluator
+                                                          ("M", 2048, 300, 3, True, 3),       # the bench's monthly series (62 304 days), per-column launches
+                                                          ("B", 3000, 24, 3, True, 3)])       # business days beyond the rank tables' 4096 lattice points
 def test_calendar_value_sweeps(pkg, freq, n, P, depth, shuffle, kind):
     ts, xs = series(pkg, freq, n, seed=n, shuffle=shuffle)
     kw = dict(max_depth=depth) if depth < 6 else dict(max_depth=6, min_depth=5, max_size=63)
@@ -54,11 +61,16 @@ def test_calendar_value_sweeps(pkg, freq, n, P, depth, shuffle, kind):
     try:
         st = a.lattice_stats()
         assert st["kind"] == kind and b.lattice_stats()["kind"] == 0
-        assert kind == 0 or 4096 >= st["n_lattice"] > n
-        assert a.lag_stats()[0] is False                       # not a regular grid: no sorted sweep, no Toeplitz class
-        k0 = a.lag_rank_sweeps()
+        assert kind != 2 or 4096 >= st["n_lattice"] > n
+        cs = a.compact_stats()
+        assert (kind == 3) == (cs["lags_per_ordinal"] > 0) and (kind != 3 or (st["n_lattice"] > 4096 or st["n_lattice"] > n * n // 2))
+        whole = kind == 3 and cs["table_entries"] <= 4096          # compact tables whole in LDS: every order, every prefix
+        assert kind != 3 or (2 <= cs["lags_per_ordinal"] <= 8 and cs["table_entries"] == cs["lags_per_ordinal"] * n)
+        assert a.lag_stats()[0] is False                       # not a regular grid: no regular-grid sorted sweep, no Toeplitz class
+        k0, c0 = a.lag_rank_sweeps(), cs["sweeps"]
         la, ia = a.logpdf_batch(nodes, noises, check=False)
         assert a.lag_rank_sweeps() == k0 + (1 if kind == 2 else 0) and a.lag_stats()[1] == 0
+        assert a.compact_stats()["sweeps"] == c0 + (1 if kind == 3 else 0)
         lb, ib = b.logpdf_batch(nodes, noises, check=False)
         assert b.lag_rank_sweeps() == 0
         assert np.array_equal(ia, ib) or np.sum(ia != ib) <= 1
@@ -73,6 +85,7 @@ def test_calendar_value_sweeps(pkg, freq, n, P, depth, shuffle, kind):
         m = (2 * n) // 3
         lp, info = a.logpdf_batch(nodes, noises, n=m, check=False)
         assert a.lag_rank_sweeps() == k0 + (2 if kind == 2 else 0)
+        assert a.compact_stats()["sweeps"] == c0 + (0 if kind != 3 else 2 if whole else 1)
         refp, rip = F.gp_logpdf_many(pkg.encode_batch(nodes), noises, ts[:m], xs[:m])
         okp = (info == 0) & (rip == 0)
         assert okp.mean() >= 0.8 and lp_err(lp[okp], refp[okp]).max() <= LP_TOL
@@ -80,8 +93,10 @@ def test_calendar_value_sweeps(pkg, freq, n, P, depth, shuffle, kind):
         a.close(); b.close()
 
 
-def test_calendar_fixture_kernels(pkg):
-    """Every leaf kind and combinator on a business-day index, incl. WhiteNoise (lag 0 of its table) and ChangePoints."""
+@pytest.mark.parametrize("freq,n,kind", [("B", 400, 2), ("M", 400, 3), ("M", 1100, 3)])
+def test_calendar_fixture_kernels(pkg, freq, n, kind):
+    """Every leaf kind and combinator on a business-day index, incl. WhiteNoise (lag 0 of its table) and ChangePoints; on month starts
+    with compact tables (400: whole in LDS, caller's order; 1100: per-tile windows on the sorted sweep)."""
     G = pkg
     base = [G.WhiteNoise(0.3), G.Constant(0.5), G.Linear(0.1, 1.3, 0.7), G.SquaredExponential(0.47, 0.13),
             G.GammaExponential(0.42, 0.58, 3.2), G.Periodic(0.96, 0.21, 1.1)]
@@ -93,11 +108,13 @@ def test_calendar_fixture_kernels(pkg):
     ks += [G.SquaredExponential(0.01, 0.9), G.Periodic(0.5, 0.015, 1.1), G.GammaExponential(0.01, 1.0, 0.7),
            G.Periodic(0.8, 0.02, 1.0) * G.SquaredExponential(0.2, 0.8), G.GammaExponential(0.02, 1.9, 0.6) + G.WhiteNoise(0.01)]
     nz = np.full(len(ks), 0.07)
-    ts, xs = pkg.prior.calendar_series(400, "B", seed=2, shuffle=True)
+    ts, xs = pkg.prior.calendar_series(n, freq, seed=2, shuffle=True)
     a, b = two_engines(pkg, ts, xs)
     try:
-        assert a.lattice_stats()["kind"] == 2
+        assert a.lattice_stats()["kind"] == kind
+        c0 = a.compact_stats()["sweeps"]
         la, ia = a.logpdf_batch(ks, nz, check=False)
+        assert a.compact_stats()["sweeps"] == c0 + (1 if kind == 3 else 0)
         lb, ib = b.logpdf_batch(ks, nz, check=False)
         assert (ia == 0).all() and (ib == 0).all()
         assert lp_err(la, lb).max() <= 1e-10
@@ -117,7 +134,7 @@ def test_calendar_gradient(pkg, freq, n):
     """agp_logpdf_grad_batch on a lattice with gaps: rank tables in the factorisation and the lag-domain contraction from the K^-1
     tiles' lag histograms over the lattice's lags (sums of stationary subtrees and Linear leaves; Linear leaves inside products by
     moment histograms); the spectral / Toeplitz sources of the lag sums need consecutive lattice points and must stay off.  520 month
-    starts are no admitted lattice: element-wise contraction."""
+    starts (15 796 days) take compact tables in the factorisation and the element-wise contraction."""
     P = 40
     ts, xs = series(pkg, freq, n, seed=11)
     nodes, noises = pkg.prior.sample_particles(np.random.default_rng(77), P, max_depth=3)
@@ -127,9 +144,11 @@ def test_calendar_gradient(pkg, freq, n):
     a, b = two_engines(pkg, ts, xs)
     try:
         kind = a.lattice_stats()["kind"]
-        assert kind == (0 if freq == "M" else 2)
+        assert kind == (3 if freq == "M" else 2)
         k0 = (a.grad_lag_domain_particles(), a.grad_toeplitz_particles(), a.grad_structured_particles())
+        c0 = a.compact_stats()["sweeps"]
         lp, grads, gn, info = a.logpdf_grad_batch(nodes, noises, check=False)
+        assert a.compact_stats()["sweeps"] == c0 + (1 if kind == 3 else 0)
         k1 = (a.grad_lag_domain_particles(), a.grad_toeplitz_particles(), a.grad_structured_particles())
         assert k1[1:] == k0[1:] and ((k1[0] - k0[0] >= P // 2) if kind == 2 else k1[0] == k0[0])
         lp2, grads2, gn2, info2 = b.logpdf_grad_batch(nodes, noises, check=False)
@@ -174,10 +193,11 @@ def test_calendar_predictive(pkg, freq):
     nodes, noises = pkg.prior.sample_particles(np.random.default_rng(41), P, max_depth=3)
     a, b = two_engines(pkg, ts, xs)
     try:
-        assert a.lattice_stats()["kind"] == (2 if freq == "B" else 0)
+        assert a.lattice_stats()["kind"] == (2 if freq == "B" else 3)
         k0 = a.lag_predict_passes()
         mean, var, cov, info = a.predict_batch(nodes, noises, tq, check=False)
-        # (business days: 770 lattice points, rank tables in LDS; 400 month starts are no admitted lattice: general evaluator)
+        # (business days: 770 lattice points, rank tables in LDS; 400 month starts: compact tables serve the value sweeps only — the
+        # predictive pass keeps the general evaluator)
         on_tables = freq == "B"
         assert a.lag_predict_passes() == k0 + (1 if on_tables else 0)
         mean_b, var_b, _, info_b = b.predict_batch(nodes, noises, tq, check=False)
@@ -208,13 +228,15 @@ def test_calendar_predictive(pkg, freq):
         a.close(); b.close()
 
 
-def test_calendar_store_extension_and_append(pkg):
+@pytest.mark.parametrize("freq,kind", [("B", 2), ("M", 3)])
+def test_calendar_store_extension_and_append(pkg, freq, kind):
     """The factor store on a lattice with gaps: extension sweeps equal from-scratch sweeps of the same entry bit for bit; an append
     (add_data!, src/api.jl:426-443) of further business days — transformed with the model's own slope and intercept, as the
-    reference does — keeps lattice and store, a point off the lattice drops both."""
+    reference does — keeps lattice and store, a point off the lattice drops both.  Month starts: the same with compact tables
+    (640 months x 5 lags per ordinal difference: whole tables in LDS, the store's caller-order sweeps read them)."""
     P = 20
     # as add_data! does it: the model's transform (min-max over the first 512 dates) applied to the later dates as well
-    u = pkg.prior.datetime2unix(pkg.prior.calendar_dates(640, "B", "1990-01-01"))
+    u = pkg.prior.datetime2unix(pkg.prior.calendar_dates(640, freq, "1990-01-01"))
     slope, icpt = pkg.prior.linear_transform_minmax(u[:512])
     x = slope * u + icpt
     rng = np.random.default_rng(5)
@@ -227,10 +249,12 @@ def test_calendar_store_extension_and_append(pkg):
     try:
         a.set_data(x[:512], xs[:512]); c.set_data(x[:512], xs[:512])
         st = a.lattice_stats()
-        assert st["kind"] == 2
+        assert st["kind"] == kind
+        c0 = a.compact_stats()["sweeps"]
         l1, i1 = a.logpdf_batch_extend(nodes, noises, n=256, check=False)
         l2, i2 = a.logpdf_batch_extend(nodes, noises, n=512, check=False)
         assert a.extend_stats()["tile_rows_reused"] > 0
+        assert kind != 3 or a.compact_stats()["lags_per_ordinal"] >= 4
         c.extend_reset()
         l2c, i2c = c.logpdf_batch_extend(nodes, noises, n=512, check=False)
         assert np.array_equal(i2, i2c) and np.array_equal(l2[i2 == 0], l2c[i2 == 0])
@@ -241,7 +265,7 @@ def test_calendar_store_extension_and_append(pkg):
         r0 = a.extend_stats()["tile_rows_reused"]
         a.set_data(x, xs)
         st2 = a.lattice_stats()
-        assert st2["kind"] == 2 and st2["spacing"] == st["spacing"] and st2["n_lattice"] > st["n_lattice"]
+        assert st2["kind"] == kind and st2["spacing"] == st["spacing"] and st2["n_lattice"] > st["n_lattice"]
         l3, i3 = a.logpdf_batch_extend(nodes, noises, n=640, check=False)
         assert a.extend_stats()["tile_rows_reused"] > r0
         ref3, ri3 = F.gp_logpdf_many(pkg.encode_batch(nodes), noises, x, xs)

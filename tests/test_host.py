@@ -159,7 +159,7 @@ def test_documented_build_recipes_produce_the_full_library(pkg, tmp_path):
 def test_lattice_admission_of_calendar_indices(pkg):
     """agp_probe_lattice = the admission test of agp_set_data on its own (host code): date indices as GPModel ingests them
     (datetime2unix + min-max LinearTransform, src/api.jl:49-51,98-101) are lattices with gaps, with the day as spacing — admitted
-    up to 4096 lattice points (the LDS budget of a rank table)."""
+    up to 4096 lattice points (the LDS budget of a rank table); longer calendar lattices by compact tables (kind 3)."""
     pr = pkg.prior
     for freq, n, gaps in (("B", 2048, {1, 3}), ("B", 2900, {1, 3}), ("M", 134, {28, 29, 30, 31}), ("M", 64, {28, 29, 30, 31})):
         for shuffle in (False, True):
@@ -182,14 +182,27 @@ def test_lattice_admission_of_calendar_indices(pkg):
     r = pkg.probe_lattice(np.delete(np.linspace(0.0, 1.0, 400), [17, 18, 200, 333]))
     assert r["kind"] == 2 and r["n_lattice"] == 400
     # refused: irregular times; an offset grid (ulp(1000) / h = 4.6e-10); a business-day index with one date moved by 1e-9 gaps;
-    # duplicates; lattices beyond 4096 points (2048 month starts: 62 304 days; 3000 business days) or with more lags than
-    # elements (n_lattice > n^2 / 2: 40 month starts)
+    # duplicates; a daily index with a few long gaps (the lattice lags at one ordinal difference then spread over too many values)
     rng = np.random.default_rng(0)
     ts, _ = pr.calendar_series(512, "B")
     moved = ts.copy(); moved[100] += 1e-9 * np.diff(ts).min()
-    for bad in (np.sort(rng.random(500)), np.linspace(1000.0, 1001.0, 2048), moved, np.concatenate([ts, ts[5:6]]),
-                pr.calendar_series(2048, "M")[0], pr.calendar_series(3000, "B")[0], pr.calendar_series(300, "Y")[0], pr.calendar_series(40, "M")[0]):
+    days = np.cumsum(np.where(rng.random(3000) < 0.02, rng.integers(5, 40, 3000), 1)).astype(float)
+    for bad in (np.sort(rng.random(500)), np.linspace(1000.0, 1001.0, 2048), moved, np.concatenate([ts, ts[5:6]]), days / days.max()):
         assert pkg.probe_lattice(bad)["kind"] == 0
+    # lattices beyond 4096 points (2048 month starts: 62 304 days; 3000 business days) or with more lags than elements
+    # (n_lattice > n^2 / 2: 40 month starts) get no table over their LAGS — but in time order the lag of a pair (i, i + od) takes few
+    # values (months: <= 6 over 170 years, business days 3, years <= 4 across 2100): kind 3, compact tables indexed by (ordinal difference, lag - base[od])
+    for freq, n, wmax in (("M", 2048, 6), ("B", 3000, 3), ("Y", 300, 4), ("M", 40, 5), ("Q", 400, 5)):
+        for shuffle in (False, True):
+            ts, _ = pr.calendar_series(n, freq, seed=2, shuffle=shuffle)
+            r = pkg.probe_lattice(ts)
+            assert r["kind"] == 3, (freq, n)
+            g = np.sort(r["index"])
+            daysq = (pr.datetime2unix(pr.calendar_dates(n, freq)) / 86400.0)
+            assert np.array_equal(g, np.sort(daysq - daysq.min()).astype(np.int64))
+            assert np.abs(ts - (ts.min() + r["index"] * r["spacing"])).max() <= 1e-11 * np.diff(np.sort(ts)).min()
+            w = max(int((g[od:] - g[:-od]).max() - (g[od:] - g[:-od]).min()) + 1 for od in range(1, n))
+            assert w == wmax <= 8
 
 
 def test_julia_block_structure(tmp_path):
