@@ -12,7 +12,7 @@ from oracle import oracle as O
 
 def run(pkg, eng, cases=60, seed=1, big=False):
     rng = np.random.default_rng(seed)
-    worst = 0.0; worst_g = 0.0; t0 = time.time(); nbad = 0; nstore = 0; nlat = 0
+    worst = 0.0; worst_g = 0.0; t0 = time.time(); nbad = 0; nstore = 0; nlat = 0; ncomp = 0
     for c in range(cases):
         n = int(rng.choice([1, 2, 63, 127, 128, 129, 255, 256, 257, 383, 385, 500, 640, 777, 900] + ([1025, 1100, 1536, 2048] if big else [])))      # (big: the spectral lag sums of gradient sweeps start above 1024 points)
         P = int(rng.choice([1, 2, 7, 8, 9, 47, 48, 49, 63, 100, 129, 255, 256, 257, 300, 513]))
@@ -36,7 +36,7 @@ def run(pkg, eng, cases=60, seed=1, big=False):
         else:
             ts, xs = pkg.prior.calendar_series(n, "B" if kind == "business" else "M", seed=sd, shuffle=shuf)
         lat = pkg.probe_lattice(ts)
-        nlat += lat["kind"] == 2
+        nlat += lat["kind"] == 2; ncomp += lat["kind"] == 3
         nodes, noises = pkg.prior.sample_particles(rng, P, max_depth=depth, max_size=31)
         eng.set_data(ts, xs)
         lp, info = eng.logpdf_batch(nodes, noises, check=False)
@@ -107,7 +107,7 @@ def run(pkg, eng, cases=60, seed=1, big=False):
                     assert abs(g1[0][q] - g0[0][q]) <= 1e-10 * max(1.0, abs(g0[0][q])), ("gradient reuse value", n, P, q)
                     assert (np.abs(g1[1][q] - g0[1][q]).max() if g0[1][q].size else 0.0) <= 1e-8 * scg and abs(g1[2][q] - g0[2][q]) <= 1e-8 * scg, ("gradient reuse", n, P, q)
             nstore += 1
-    msg = f"fuzz ok: {cases} cases ({nstore} with factor-store sweeps, {nlat} on lattices with gaps), worst logpdf rel err {worst:.2e}, worst gradient rel err {worst_g:.2e}, not-PD particles skipped {nbad}, {time.time()-t0:.0f}s"
+    msg = f"fuzz ok: {cases} cases ({nstore} with factor-store sweeps, {nlat} on lattices with gaps, {ncomp} on longer lattices with compact tables), worst logpdf rel err {worst:.2e}, worst gradient rel err {worst_g:.2e}, not-PD particles skipped {nbad}, {time.time()-t0:.0f}s"
     return msg
 
 

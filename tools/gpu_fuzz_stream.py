@@ -25,7 +25,8 @@ def _run(pkg, eng, ref, sequences=20, seed=1, steps=14, big=False):
         if regular and N <= 2048 and rng.random() < 0.3:
             # a business-day index (a lattice with gaps: rank tables over the lattice's lags, no Toeplitz path); the part that arrives
             # by add_data! keeps the transform of the whole index, so the old points' lattice survives the append
-            ts, xs = pkg.prior.calendar_series(N, "B", seed=int(rng.integers(1 << 30)), shuffle=not ordered)
+            # (month / quarter starts: compact tables — whole in LDS for the store's sweeps while W N <= 4096 entries, else the general evaluator)
+            ts, xs = pkg.prior.calendar_series(N, str(rng.choice(["B", "B", "M", "Q"])), seed=int(rng.integers(1 << 30)), shuffle=not ordered)
         n_avail = N if rng.random() < 0.5 else int(rng.integers(N // 2, N))           # the rest arrives by add_data!
         eng.set_data(ts[:n_avail], xs[:n_avail]); ref.set_data(ts[:n_avail], xs[:n_avail])
         eng.extend_reset()
