@@ -183,8 +183,9 @@ struct GradArgs {
   const double* gprm;    // ORIGINAL (untransformed-by-us) parameter values, device node order
   const double* tt;      // time points (padded)
   const double* logdt;   // log|dt| table of the resident data (null: GammaExp leaves compute the power); see CovArgs
-  double* gpart;         // [P][ntiles][gstride] per-tile partial sums (slot 0..n_prm-1 params, n_prm = noise)
+  double* gpart;         // [P][ntiles][csplit][gstride] per-tile partial sums (slot 0..n_prm-1 params, n_prm = noise)
   int gstride;
+  int csplit;            // k_grad_contract: workgroups per tile (grid.z; 1, or 4 in sweeps with fewer tiles than workgroup slots)
   const int32_t* gmap;   // per particle parameter slot -> index in the caller's parameter array
   const int32_t* out_off;   // [P] offset of the particle's gradient block in out_grad (caller order, via map)
   const int32_t* pmap;   // sorted particle -> caller particle

@@ -1337,6 +1337,21 @@ __global__ __launch_bounds__(256) void k_copy_rows(double* __restrict__ dst, lon
 
 // out[p] = lp[rep[p]]: the distinct particles' results expanded to the caller's population order (device-resident
 // output of the extension sweeps: the shard handed to the log-weight all-gather).
+// One upload per sweep instead of one per array (PinnedUploads): the blob carries its own table — {n_items} at byte 0, items
+// {destination, offset, bytes} from byte 16 — and block (item, slice) copies that item to where its consumers expect it, 16 bytes
+// per lane and step (destinations are allocation bases, offsets multiples of 16), the last bytes one by one.  A small sweep's eight
+// program arrays cost eight copy commands of ~4 us with ~5 us between them; this is one copy and one launch.
+__global__ __launch_bounds__(256) void k_scatter_uploads(const char* __restrict__ blob) {
+  struct Item { unsigned long long dev, off, bytes; };
+  const Item it = reinterpret_cast<const Item*>(blob + 16)[blockIdx.x];
+  char* __restrict__ dst = reinterpret_cast<char*>(it.dev);
+  const char* __restrict__ src = blob + it.off;
+  const unsigned long long n16 = it.bytes >> 4;
+  for (unsigned long long i = (unsigned long long)blockIdx.y * 256 + threadIdx.x; i < n16; i += 256ull * gridDim.y)
+    reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+  if (blockIdx.y == 0 && threadIdx.x < (it.bytes & 15)) dst[(n16 << 4) + threadIdx.x] = src[(n16 << 4) + threadIdx.x];
+}
+
 __global__ void k_expand_rep(const double* __restrict__ lp, const int32_t* __restrict__ rep, int P, double* __restrict__ out) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < P) out[p] = lp[rep[p]];

@@ -642,7 +642,7 @@ static int toeplitz_sweep(agp_ctx* c, int64_t n, int32_t rank0, int P, const int
   up.add(s->prm.p, bt.prm.data(), sizeof(double) * bt.prm.size());
   up.add(s->noise.p, nz.data(), sizeof(double) * (size_t)P);
   up.add(s->pl_prog.p, hp.data(), prog_bytes);
-  HIPCHK(c, up.flush(s->h_stage, st));
+  HIPCHK(c, up.flush(s->h_stage, s->up_blob, st));
   const int stride = rank_units * 256;
   if (bt.n_lag_tables > 0) {
     HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * stride));
@@ -746,7 +746,7 @@ static int toeplitz_grad_sweep(agp_ctx* c, int64_t n, int32_t rank0, int P, cons
   up.add(s->goff.p, goff.data(), sizeof(int32_t) * (size_t)P);
   up.add(s->map.p, bt.order.data(), sizeof(int32_t) * (size_t)P);
   up.add(s->plist.p, plist.data(), sizeof(int32_t) * (size_t)P);
-  HIPCHK(c, up.flush(s->h_stage, st));
+  HIPCHK(c, up.flush(s->h_stage, s->up_blob, st));
   HIPCHK(c, hipMemsetAsync(s->dgrad.p, 0, sizeof(double) * (size_t)std::max(1, n_prm_total), st));
   HIPCHK(c, hipMemsetAsync(s->dgnoise.p, 0, sizeof(double) * (size_t)P, st));
   HIPCHK(c, hipMemsetAsync(s->tretry.p, 0, sizeof(int32_t) * (size_t)P, st));      // (k_lag_grad receives it; the TSOL branch never writes it)
@@ -1184,6 +1184,9 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     // (the dataflow schedule has several block columns of a particle in flight: every column keeps its inverse blocks)
     const int wsteps = (go || c->flow != 0) ? nt : 1;
     const int gstride = go ? bt.g_max_prm + 1 : 0;
+    // k_grad_contract: a sweep with fewer tiles than workgroup slots shares each tile among four workgroups (one rule per sweep: the
+    // partial sums' layout; reference arithmetic keeps one grouping of them whatever the batch)
+    const int gcsplit = (!c->ref_arith && (long long)ntiles * P < 512) ? 4 : 1;      // (by the CALL's population, not the chunk: the workspace limit must not change a bit)
 
     HIPCHK(c, s->A.ensure((size_t)strideA * 8 * chunk));
     HIPCHK(c, s->W.ensure(sizeof(double) * NSB * 256 * (size_t)chunk * wsteps));
@@ -1193,7 +1196,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       HIPCHK(c, s->tsol.ensure(sizeof(double) * 3 * (size_t)n_pad * chunk));
       HIPCHK(c, s->tretry.ensure(sizeof(int32_t) * (size_t)P));
       HIPCHK(c, hipMemsetAsync(s->tretry.p, 0, sizeof(int32_t) * (size_t)P, st));
-      HIPCHK(c, s->gpart.ensure(sizeof(double) * (size_t)chunk * ntiles * gstride));
+      HIPCHK(c, s->gpart.ensure(sizeof(double) * (size_t)chunk * ntiles * gstride * gcsplit));
       HIPCHK(c, s->ghdr.ensure(sizeof(GProgHdr) * (size_t)P));
       HIPCHK(c, s->gops.ensure(bt.gops.size() + 4)); HIPCHK(c, s->glc.ensure(bt.glc.size() + 4)); HIPCHK(c, s->grc.ensure(bt.grc.size() + 4));
       HIPCHK(c, s->gpoff.ensure(sizeof(int32_t) * (bt.gpoff.size() + 1)));
@@ -1273,7 +1276,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       up.add(s->gprm.p, bt.gprm.data(), sizeof(double) * bt.gprm.size());
       up.add(s->gmap.p, bt.gmap.data(), sizeof(int32_t) * bt.gmap.size());
       up.add(s->goff.p, goff_sorted.data(), sizeof(int32_t) * P);
-      HIPCHK(c, up.flush(s->h_stage2, st));
+      HIPCHK(c, up.flush(s->h_stage2, s->up_blob2, st));
     }
     if ((lag || rankm) && bt.n_lag_tables > 0) {
       // the sweep's lag tables: every stationary leaf of every particle at the 255 lags of each of the nt block diagonals
@@ -1392,7 +1395,8 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           ga.P = Pg; ga.nt = nt; ga.n = (int)n;
           ga.ghdr = s->ghdr.as<GProgHdr>() + p0 + g0; ga.gops = s->gops.as<uint8_t>(); ga.glc = s->glc.as<uint8_t>();
           ga.grc = s->grc.as<uint8_t>(); ga.gpoff = s->gpoff.as<int32_t>(); ga.gprm = s->gprm.as<double>();
-          ga.tt = c->d_ts; ga.logdt = c->logdt_ok ? c->d_logdt : nullptr; ga.gpart = s->gpart.as<double>() + (size_t)g0 * ntiles * gstride; ga.gstride = gstride;
+          ga.tt = c->d_ts; ga.logdt = c->logdt_ok ? c->d_logdt : nullptr; ga.csplit = gcsplit;
+          ga.gpart = s->gpart.as<double>() + (size_t)g0 * ntiles * gstride * ga.csplit; ga.gstride = gstride;
           ga.gmap = s->gmap.as<int32_t>(); ga.out_off = s->goff.as<int32_t>() + p0 + g0;
           ga.pmap = d_map + p0 + g0; ga.out_grad = s->dgrad.as<double>(); ga.out_gnoise = s->dgnoise.as<double>();
           // (lag histograms: one bin per lattice lag, lag g at time t_lat[g] - t_lat[0]; on a regular grid d_ts_lat holds the sorted series)

@@ -1429,9 +1429,13 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
       ltn[e] = use_tab ? ltile[cslot * NB + rslot] : 0.0;
     }
   };
-  fetch(0);
+  // (small sweeps — fewer tiles than workgroup slots — share a tile among csplit = 4 workgroups, 16 of the thread's 64 columns
+  // each: a tile is a ~130 us walk for one workgroup whatever the batch, and a sweep of eight 144-point particles has 24 of them)
+  const int cs = a.csplit > 1 ? a.csplit : 1, zz = cs > 1 ? (int)blockIdx.z : 0;
+  const int c_lo = (64 / cs) * zz, c_hi = c_lo + 64 / cs;
+  fetch(c_lo);
 #pragma unroll 1
-  for (int c0 = 0; c0 < 64; c0 += E) {
+  for (int c0 = c_lo; c0 < c_hi; c0 += E) {
     int ri[E], ci[E];
     double ta[E], tb[E], wg[E], lt[E];
 #pragma unroll
@@ -1444,7 +1448,7 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
       ri[e] = rslot; ci[e] = NB + cslot; ta[e] = tpt[rslot]; tb[e] = tpt[NB + cslot]; wg[e] = wfac * G;
       lt[e] = ltn[e];
     }
-    if (c0 + E < 64) fetch(c0 + E);
+    if (c0 + E < c_hi) fetch(c0 + E);
     grad_elements<GS, E>(h, ops, lc, rc, mv, poff, prm, sig, ri, ci, ta, tb, wg, lt, use_tab, tape, sacc);
   }
   gacc[h.n_prm] = gnoise;
@@ -1456,7 +1460,7 @@ __global__ __launch_bounds__(256) void k_grad_contract(GradArgs a) {
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (l == 0) red[w] = s;
     __syncthreads();
-    if (tid == 0) a.gpart[((long long)p * (a.nt * (a.nt + 1) / 2) + tix) * a.gstride + q] = red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) a.gpart[(((long long)p * (a.nt * (a.nt + 1) / 2) + tix) * cs + zz) * a.gstride + q] = red[0] + red[1] + red[2] + red[3];
     __syncthreads();
   }
 }
@@ -1465,7 +1469,7 @@ __global__ void k_grad_finish(GradArgs a) {
   const int p = blockIdx.x;
   const GProgHdr h = a.ghdr[p];
   if (h.flags & (GFLAG_LAGDOM | GFLAG_LAGPOLY)) return;          // (k_lag_grad wrote this particle's outputs)
-  const int ntiles = a.nt * (a.nt + 1) / 2;
+  const int ntiles = a.nt * (a.nt + 1) / 2 * (a.csplit > 1 ? a.csplit : 1);      // (partial sums per tile: one per workgroup that shared it)
   for (int q = threadIdx.x; q <= h.n_prm; q += blockDim.x) {
     double s = 0.0;
     for (int t = 0; t < ntiles; ++t) s += a.gpart[((long long)p * ntiles + t) * a.gstride + q];

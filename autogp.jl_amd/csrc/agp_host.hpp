@@ -77,17 +77,42 @@ struct PinnedUploads {
     std::memcpy(blob.data() + off, host, bytes);
     items.push_back({dev, off, bytes});
   }
-  hipError_t flush(HostBuf& hb, hipStream_t st) {
+  // ONE copy of the whole blob into `db` and one launch that moves every array to its own buffer (k_scatter_uploads); a single
+  // array travels directly.  (The pinned blob and `db` belong to the slot: reused by its next sweep, after this one's stream has drained.)
+  hipError_t flush(HostBuf& hb, DevBuf& db, hipStream_t st) {
     if (items.empty()) return hipSuccess;
-    hipError_t e = hb.ensure(blob.size());
-    if (e != hipSuccess) return e;
-    std::memcpy(hb.p, blob.data(), blob.size());
-    for (const Item& it : items) {
-      e = hipMemcpyAsync(it.dev, static_cast<char*>(hb.p) + it.off, it.bytes, hipMemcpyHostToDevice, st);
+    hipError_t e;
+    if (items.size() == 1) {
+      e = hb.ensure(blob.size());
       if (e != hipSuccess) return e;
+      std::memcpy(hb.p, blob.data(), blob.size());
+      e = hipMemcpyAsync(items[0].dev, static_cast<char*>(hb.p) + items[0].off, items[0].bytes, hipMemcpyHostToDevice, st);
+      items.clear(); blob.clear();
+      return e;
     }
+    struct Rec { unsigned long long dev, off, bytes; };
+    const size_t table = (16 + sizeof(Rec) * items.size() + 15) & ~(size_t)15;
+    const size_t total = table + blob.size();
+    e = hb.ensure(total);
+    if (e != hipSuccess) return e;
+    e = db.ensure(total);
+    if (e != hipSuccess) return e;
+    char* h = static_cast<char*>(hb.p);
+    std::memset(h, 0, table);
+    *reinterpret_cast<unsigned long long*>(h) = items.size();
+    size_t largest = 0;
+    for (size_t i = 0; i < items.size(); ++i) {
+      Rec r{(unsigned long long)(uintptr_t)items[i].dev, (unsigned long long)(table + items[i].off), (unsigned long long)items[i].bytes};
+      std::memcpy(h + 16 + sizeof(Rec) * i, &r, sizeof(Rec));
+      largest = std::max(largest, items[i].bytes);
+    }
+    std::memcpy(h + table, blob.data(), blob.size());
+    e = hipMemcpyAsync(db.p, hb.p, total, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess) return e;
+    const int slices = (int)std::min<size_t>(64, std::max<size_t>(1, largest / (16 * 256 * 4)));
+    launch_scatter_uploads(st, db.p, (int)items.size(), slices);
     items.clear(); blob.clear();
-    return hipSuccess;
+    return hipGetLastError();
   }
 };
 
@@ -96,6 +121,7 @@ struct Slot {
   DevBuf stage;             // one upload per sweep: [hdr | prm | noise | map | ops]
   HostBuf h_stage, h_out;   // its pinned source, and the pinned landing zone of [logpdf | info]
   HostBuf h_stage2;         // pinned source of the gradient programs (the sweep's stage copy may still be reading h_stage)
+  DevBuf up_blob, up_blob2; // device landing zones of PinnedUploads' blobs (h_stage / h_stage2)
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
       Z, alpha, tsol, tretry, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq, lagtab,
@@ -116,7 +142,7 @@ struct Slot {
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
                       &Z, &alpha, &tsol, &tretry, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab, &pl_rank, &pl_tl, &pl_prog})
       b->release();
-    stage.release(); h_stage.release(); h_stage2.release(); h_out.release(); h_async_info.release();
+    stage.release(); h_stage.release(); h_stage2.release(); h_out.release(); h_async_info.release(); up_blob.release(); up_blob2.release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
     for (auto& q : gq) { if (q) (void)hipStreamDestroy(q); q = nullptr; }

@@ -123,6 +123,9 @@ void launch_gather_factor(hipStream_t st, int gx, int P, const GatherArgs& ga) {
 void launch_copy_rows(hipStream_t st, int gx, int rows, double* dst, long long dpitch, const double* src, long long spitch, long long width) {
   hipLaunchKernelGGL(k_copy_rows, dim3(gx, rows), dim3(256), 0, st, dst, dpitch, src, spitch, width);
 }
+void launch_scatter_uploads(hipStream_t st, const void* blob, int n_items, int slices) {
+  hipLaunchKernelGGL(k_scatter_uploads, dim3(n_items, slices), dim3(256), 0, st, static_cast<const char*>(blob));
+}
 void launch_expand_rep(hipStream_t st, int P, const double* lp, const int32_t* rep, double* out) {
   hipLaunchKernelGGL(k_expand_rep, dim3((P + 255) / 256), dim3(256), 0, st, lp, rep, P, out);
 }

@@ -27,7 +27,7 @@ void launch_toep_solve(hipStream_t st, int P, size_t lds, const GradArgs& ga) { 
 void launch_zspec(hipStream_t st, int nt, int P, const GradArgs& ga) { hipLaunchKernelGGL(k_zspec, dim3(nt, P), dim3(256), 0, st, ga); }
 void launch_kinv_tiles(hipStream_t st, int grid, const GradArgs& ga) { hipLaunchKernelGGL(k_kinv_tiles, dim3(grid), dim3(256), 0, st, ga); }
 hipError_t launch_grad_contract(int maxs, hipStream_t st, const GradArgs& ga, int ntiles, int P, size_t lds) {
-  const dim3 grid(ntiles, P), block(256);
+  const dim3 grid(ntiles, P, ga.csplit > 1 ? ga.csplit : 1), block(256);
   if (maxs == 64) hipLaunchKernelGGL(k_grad_contract<64>, grid, block, lds, st, ga);
   else if (maxs == 16) hipLaunchKernelGGL(k_grad_contract<16>, grid, block, lds, st, ga);
   else hipLaunchKernelGGL(k_grad_contract<0>, grid, block, lds, st, ga);

@@ -31,6 +31,7 @@ void launch_init_extend(hipStream_t st, int U, double* vec, int ldv, int n_pad, 
 void launch_init_flow_flags(hipStream_t st, int P, int* tflag, int ntri_stride, int ntri, const int* slot, const int* i0);
 void launch_gather_factor(hipStream_t st, int gx, int P, const GatherArgs& ga);
 void launch_copy_rows(hipStream_t st, int gx, int rows, double* dst, long long dpitch, const double* src, long long spitch, long long width);
+void launch_scatter_uploads(hipStream_t st, const void* blob, int n_items, int slices);      // PinnedUploads: one blob -> its destinations
 void launch_expand_rep(hipStream_t st, int P, const double* lp, const int32_t* rep, double* out);
 void launch_pred_extract(hipStream_t st, long long nel, int P, const PredArgs& pa);
 void launch_unpack_dense(hipStream_t st, const double* A, int n, int lower_only, double* out);

@@ -232,7 +232,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     if (zstore) { up.add(d + 2 * P, zi0v.data(), sizeof(int32_t) * P); d_zi0 = d + 2 * P; }
     d_src = d; d_i0 = d + P;
   }
-  if (!lagr) HIPCHK(c, up.flush(s->h_stage, st));
+  if (!lagr) HIPCHK(c, up.flush(s->h_stage, s->up_blob, st));
 
   if (lagr) {
     // ranks of the joint points, lag times, table programs; one table of R lags per stationary subtree of the batch
@@ -260,7 +260,7 @@ int predict_core(agp_ctx* c, int64_t n, const double* ts_pred, int64_t m, int32_
     up.add(s->pl_prog.p, hp.data(), prog_bytes);
     up.add(s->pl_rank.p, rankJ.data(), sizeof(int32_t) * rankJ.size());
     up.add(s->pl_tl.p, pl->tl.data(), sizeof(double) * pl->tl.size());
-    HIPCHK(c, up.flush(s->h_stage, st));
+    HIPCHK(c, up.flush(s->h_stage, s->up_blob, st));
     if (bt.n_lag_tables > 0) {
       HIPCHK(c, s->lagtab.ensure(sizeof(double) * (size_t)bt.n_lag_tables * pl->rank_units * 256));
       LagArgs la = {};
@@ -517,7 +517,7 @@ int toeplitz_predict_sweep(agp_ctx* c, int64_t n, int32_t rank0, int mF, const P
     HIPCHK(c, s->mu1.ensure(sizeof(double) * (size_t)n));
     up.add(s->mu1.p, xs_sorted_host, sizeof(double) * (size_t)n);
   }
-  HIPCHK(c, up.flush(s->h_stage, st));
+  HIPCHK(c, up.flush(s->h_stage, s->up_blob, st));
   if (bt.n_lag_tables > 0) {
     LagArgs la = {};
     la.tt = s->pl_tl.as<double>(); la.thdr = s->pl_prog.as<LagTabHdr>();
