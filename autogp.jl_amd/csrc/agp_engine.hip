@@ -1335,7 +1335,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
         const int dcov = nf > 0 ? bt.max_depth_fused : 0;
         size_t e0 = pf.mark(q);
         cv.p_off = nf;
-        HIPCHK(c, launch_cov(q, cv, ntiles, Pg - nf, bt.max_cp, bt.max_depth));
+        if (!(n_hit > 0 && i0min == nt)) HIPCHK(c, launch_cov(q, cv, ntiles, Pg - nf, bt.max_cp, bt.max_depth));      // (every particle resident: no tile to build)
         size_t e1 = pf.mark(q);
         pf.span(1, e0, e1);
 
@@ -1430,7 +1430,9 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           // (all lag-domain particles of a sweep take the same source of their lag sums)
           const bool any_fft = Pn < Pg && (bt.ghdr[p0 + g0 + pl[Pn]].flags & GFLAG_LAGFFT) != 0;
           const bool any_toep = Pn < Pg && (bt.ghdr[p0 + g0 + pl[Pn]].flags & GFLAG_LAGTOEP) != 0;
-          const bool fork = true;
+          // (a sweep with fewer tiles than workgroup slots has nothing to run side by side: its launches stay on one stream, in order —
+          // ten event / wait calls and two cross-stream hand-overs less per sweep, ~50 us of a 350 us sweep at n = 144)
+          const bool fork = (long long)ntiles * P >= 512;
           hipStream_t qs[4] = {q, q, q, q};
           if (fork) {
             for (int i2 = 0; i2 < 3; ++i2) if (!s->gq[i2]) HIPCHK(c, hipStreamCreateWithFlags(&s->gq[i2], hipStreamNonBlocking));
@@ -1506,7 +1508,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
             }
             if (Pe < Pn) {
               // polynomial particles: behind the K^-1 tiles' moment histograms
-              HIPCHK(c, hipStreamWaitEvent(qs[3], s->gq_ev[3], 0));
+              if (fork) HIPCHK(c, hipStreamWaitEvent(qs[3], s->gq_ev[3], 0));
               GradArgs gp = ga; gp.plist = d_pl + Pe;
               // (2 d + 1 moment histograms of n_max lags for the class's largest degree d: admission keeps them within one tile of LDS)
               int dmax = 1;
@@ -2354,6 +2356,14 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
                                    n_prm > 0 ? out_grad : &gdummy, out_grad_noise, out_info);
     return agp_logpdf_batch(c, n, 1, op_off, ops, prm_off, n_prm > 0 ? prm : &dummy, &noise, out_logpdf, out_info);
   }
+  // callers that may spin at a time (AGP_SPIN=<n>; 0: always sleep): 8 at most, and no more than a quarter of the host's hardware
+  // threads — measured on a 256-thread host under a container CPU quota: 8 callers 587 -> 730 HMC iterations/s at n = 144, but 64
+  // spinning callers ran into the 16-core quota (2 424 -> 667), and 16 gained nothing at n = 443
+  static const int spin_cores = [] {
+    const char* e = getenv("AGP_SPIN");
+    if (e) return std::max(0, atoi(e));
+    return (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 4));
+  }();
   LpRequest req;
   req.n = n; req.ops = ops; req.n_ops = n_ops; req.prm = prm; req.n_prm = n_prm; req.noise = noise;
   req.caller = (uint64_t)std::hash<std::thread::id>()(std::this_thread::get_id()) | 1ull;
@@ -2373,12 +2383,24 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
   for (;;) {
     if (!lead) {
       // ---- follower: sleep on this request's own condition variable until its results are in or it is promoted ----
+      // (short sweeps, few callers: spin on the request's flag for about as long as a sweep lasts before sleeping — the mutex is
+      // taken either way, so the request outlives the leader's notification)
+      const double lsu = c->last_sweep_us;
+      const bool spin = spin_cores > 0 && c->inflight.load(std::memory_order_relaxed) <= spin_cores && lsu < 1500.0;
       lk.unlock();
+      if (spin) {
+        const auto t_spin = std::chrono::steady_clock::now();
+        const double limit_us = 2.0 * lsu + 300.0;
+        for (int it = 0; req.poke.load(std::memory_order_acquire) == 0; ++it) {
+          __builtin_ia32_pause();
+          if ((it & 255) == 255 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_spin).count() > limit_us) break;
+        }
+      }
       {
         std::unique_lock<std::mutex> l(req.m);
         req.cv.wait(l, [&] { return req.done || req.lead; });
         if (req.done) break;
-        req.lead = false;
+        req.lead = false; req.poke.store(0, std::memory_order_relaxed);
       }
       lk.lock();
       lead = true;                       // (leader_active stayed true: the finishing leader handed the role over)
@@ -2398,6 +2420,7 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
         const auto t_start = clk::now();
         c->leader_gathering = true;
         while (c->queue.size() < target) {
+          if (c->queue.size() >= c->caller_ids.size()) break;      // every thread that has ever called is here: nobody left to wait for
           const long long seen = c->arrivals;
           c->qcv_leader.wait_for(lk, quiet);
           const double waited = std::chrono::duration<double, std::micro>(clk::now() - t_start).count();
@@ -2431,6 +2454,7 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
           if (r == &req) continue;
           std::lock_guard<std::mutex> l(r->m);
           r->done = true;
+          r->poke.store(1, std::memory_order_release);
           r->cv.notify_one();
         }
       }
@@ -2444,6 +2468,7 @@ static int logpdf_one(agp_ctx* c, int64_t n, const uint8_t* ops, int32_t n_ops, 
         LpRequest* nx = c->queue.front();
         std::lock_guard<std::mutex> l(nx->m);
         nx->lead = true;
+        nx->poke.store(2, std::memory_order_release);
         nx->cv.notify_one();
       } else {
         c->leader_active = false;

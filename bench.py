@@ -117,11 +117,13 @@ def cpu_baseline(programs, noises, ts, xs, gpu_lp, budget_s=20.0):
     return {"value": ns / dt, "unit": "evals/s", "cores": used, "kind": "port",
             "sample": f"first {ns} particles of the same workload (n={len(ts)}), oracle/fast.py: C restatement of eval_cov "
                       f"(oracle/agp_oracle.c) + LAPACK dpotrf/dtrtrs via SciPy-OpenBLAS (Julia reference not installed), "
-                      f"one particle per worker process ({used} workers on {cores} host cores), 1 BLAS thread each, {dt:.1f} s",
+                      f"one particle per worker process ({used} workers; the host shows {F.visible_cores()} hardware threads, its CPU quota "
+                      f"allows {F.cpu_quota_cores() or 'all of them'} cores), 1 BLAS thread each, {dt:.1f} s",
+            "host_hardware_threads": F.visible_cores(), "host_cpu_quota_cores": F.cpu_quota_cores(),
             "gflops": gf, "gflops_per_core": gf / max(1, min(used, ns)),
             "one_worker_evals_per_s": 1.0 / t_one, "one_worker_gflops": cholesky_flops(len(ts)) / t_one / 1e9,
             "one_worker_note": "the same code with ONE worker process on an otherwise idle host: the uncontended per-core rate "
-                               "(the all-core figure is a saturated socket: memory bandwidth and shared caches, not the port, limit it)",
+                               "(the many-worker figure is bounded by the container's CPU quota and by shared caches / memory bandwidth)",
             "parity_max_rel_err_vs_gpu": err}
 
 

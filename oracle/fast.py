@@ -43,8 +43,32 @@ def _lib():
     return _LIB
 
 
-def host_cores():
+def cpu_quota_cores():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota); None when unlimited.  A GPU box shows 256 hardware
+    threads under a quota of 16: 256 worker processes there are 16 cores' worth of work plus the throttling."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(-(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            return max(1, -(-q // per))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def visible_cores():
     return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+
+def host_cores():
+    """Worker processes worth starting: the hardware threads this process may run on, capped by the container's CPU quota."""
+    q = cpu_quota_cores()
+    return min(visible_cores(), q) if q else visible_cores()
 
 
 def gp_logpdf_program(ops, prm, noise, ts, xs):
