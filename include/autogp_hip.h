@@ -81,7 +81,10 @@ int agp_set_data(agp_ctx* ctx, const double* ts, const double* xs, int64_t n_max
  * callers (one per Julia thread, src/inference_smc_anneal_data.jl:133-135) are coalesced inside the
  * library into one batched sweep: the first arrival gathers the others for at most the coalescing window
  * (default 2000 us, and never more than a quarter of the previous sweep's duration; env AGP_COALESCE_US,
- * agp_set_coalesce_window; 0 disables).  A lone caller never waits. */
+ * agp_set_coalesce_window; 0 disables).  A lone caller never waits, and the gathering stops as soon as every thread that has ever
+ * called is queued.  While sweeps are short (< 1.5 ms: the reference's tutorial sizes) up to AGP_SPIN (default 8; 0 = never) waiting
+ * callers spin on their result for about one sweep before they sleep — a futex wake-up costs ~50 us, a sweep of eight 144-point
+ * particles ~200. */
 int agp_logpdf(agp_ctx* ctx, int64_t n,
                const uint8_t* ops, int32_t n_ops, const double* prm, int32_t n_prm,
                double noise, double* out_logpdf, int32_t* out_info);
