@@ -1346,10 +1346,18 @@ __global__ __launch_bounds__(256) void k_scatter_uploads(const char* __restrict_
   const Item it = reinterpret_cast<const Item*>(blob + 16)[blockIdx.x];
   char* __restrict__ dst = reinterpret_cast<char*>(it.dev);
   const char* __restrict__ src = blob + it.off;
-  const unsigned long long n16 = it.bytes >> 4;
-  for (unsigned long long i = (unsigned long long)blockIdx.y * 256 + threadIdx.x; i < n16; i += 256ull * gridDim.y)
-    reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
-  if (blockIdx.y == 0 && threadIdx.x < (it.bytes & 15)) dst[(n16 << 4) + threadIdx.x] = src[(n16 << 4) + threadIdx.x];
+  const unsigned long long t0 = (unsigned long long)blockIdx.y * 256 + threadIdx.x, ts = 256ull * gridDim.y;
+  if (((it.dev | it.off) & 15) == 0) {
+    const unsigned long long n16 = it.bytes >> 4;
+    for (unsigned long long i = t0; i < n16; i += ts) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    if (blockIdx.y == 0 && threadIdx.x < (it.bytes & 15)) dst[(n16 << 4) + threadIdx.x] = src[(n16 << 4) + threadIdx.x];
+  } else if (((it.dev | it.off) & 3) == 0) {      // (a destination inside a buffer — index arrays packed one behind the other — is only word-aligned)
+    const unsigned long long n4 = it.bytes >> 2;
+    for (unsigned long long i = t0; i < n4; i += ts) reinterpret_cast<unsigned*>(dst)[i] = reinterpret_cast<const unsigned*>(src)[i];
+    if (blockIdx.y == 0 && threadIdx.x < (it.bytes & 3)) dst[(n4 << 2) + threadIdx.x] = src[(n4 << 2) + threadIdx.x];
+  } else {
+    for (unsigned long long i = t0; i < it.bytes; i += ts) dst[i] = src[i];
+  }
 }
 
 __global__ void k_expand_rep(const double* __restrict__ lp, const int32_t* __restrict__ rep, int P, double* __restrict__ out) {
