@@ -26,6 +26,8 @@ python tools/gpu_calendar_bench.py 2>/dev/null | tail -1 > gpurun_out/${TAG}_cal
 # round 6: the factor store sizing itself (ragged arrivals, no reservation; AGP_STORE_SELF_SIZE=0 = round 5's rule), dependent-issue latencies
 (for T in 512 1024; do for S in 1 0; do AGP_STORE_SELF_SIZE=$S HMC_JITTER_US=20000 HMC_WINDOW_US=5 tools/native/hmc_replay 512 $T 2; done; done; for R in 0 1; do HMC_JITTER_US=3000 HMC_WINDOW_US=20 HMC_RESERVE=$R tools/native/hmc_replay 2048 512 2; done) 2>&1 | grep "^{" > gpurun_out/${TAG}_store_selfsize.jsonl; cut -c1-200 gpurun_out/${TAG}_store_selfsize.jsonl
 tools/native/lat_bench > gpurun_out/${TAG}_lat_bench.json 2>&1; cut -c1-300 gpurun_out/${TAG}_lat_bench.json
+# round 6: the reference's tutorial sizes (135-442 points, 8-64 caller threads): launch-bound sweeps
+(for N in 144 443; do for T in 8 16 64; do tools/native/hmc_replay $N $T 20; tools/native/hmc_replay $N $T 20 10 0.02 grid; tools/native/hmc_replay $N $T 20 10 0.02 monthly; done; done; tools/native/threads_bench 144 8 400; tools/native/threads_bench 144 8 400 grad; tools/native/threads_bench 144 64 100; tools/native/threads_bench 144 64 100 grad; tools/native/threads_bench 144 1 400; tools/native/threads_bench 144 1 400 grad) 2>&1 | grep "^{" > gpurun_out/${TAG}_small_native.jsonl; cut -c1-200 gpurun_out/${TAG}_small_native.jsonl | head -3
 # stand-alone diagonal-tile harness (per-phase clocks), predictive passes, extension sweeps alone, dataflow traces (measurement library)
 (tools/native/diag_bench 8 0 20; tools/native/diag_bench 512 0 20; tools/native/diag_bench 512 8 20; tools/native/diag_bench 64 8 20) > gpurun_out/${TAG}_diag_bench.txt 2>&1; tail -1 gpurun_out/${TAG}_diag_bench.txt | cut -c1-160
 (python tools/gpu_predict_perf.py; python tools/gpu_predict_perf.py 2048:2048:128 --off-lattice) 2>&1 | grep "^predict" > gpurun_out/${TAG}_predict_perf.txt; tail -2 gpurun_out/${TAG}_predict_perf.txt
