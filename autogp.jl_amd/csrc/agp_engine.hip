@@ -296,7 +296,7 @@ int emit_grad(const std::vector<CNode>& nodes, int id, Batch& bt, int prm_base, 
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                   const double* prm, Batch& bt, bool allow_sel, bool want_grad, bool ge_tab,
-                  bool fuse_hint, bool flow_limit, bool lag, int lag_units, int rank_extra) {
+                  bool fuse_hint, bool flow_limit, bool lag, int lag_units, int rank_extra, bool never_fuse) {
   // (lag_units: LDS footprint of one lag table in 256-double units — 1 on a sorted sweep, n_max / 256 for rank tables; rank_extra > 0:
   // rank / compact tables — that many units for the tile's ranks or keys (in k_cov_tiles: and the exponential table behind them; also
   // when n_max <= 256) and, with compact tables, the B entries the tile stages)
@@ -315,7 +315,8 @@ int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, 
   // Sort: fused particles first, most expensive evaluation first (their workgroups are dispatched
   // first inside every launch); particles whose tiles are prebuilt go last.
   // (fuse_hint: the caller will run the dataflow schedule, which evaluates tiles in-kernel whatever the batch size)
-  const bool fuse_on = c->fuse_mode == 1 || (c->fuse_mode < 0 && (P >= 256 || fuse_hint));
+  // (never_fuse: the factor store's sweeps over a series of at most two tile rows, see extend_impl)
+  const bool fuse_on = !never_fuse && (c->fuse_mode == 1 || (c->fuse_mode < 0 && (P >= 256 || fuse_hint)));
   // (the dataflow schedule has no launch tail for a long evaluation to hold up: its limit is higher — measured 35 / 70 /
   // 150 / 1000 us: config 2 0.99 / 0.92 / 0.92 / 0.91 ms, 2048 x 64 4.47 / 4.45 / 4.61 / 4.62 ms, config 4 62.9 / 61.9 / 63.6 / 63.6 ms)
   const double fuse_limit = flow_limit ? (lag ? FLOW_LAG_FUSE_MAX_US : FLOW_FUSE_MAX_US) : (lag ? LAG_FUSE_MAX_US : FUSE_MAX_US);
@@ -1968,6 +1969,7 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
   }
   const bool lag_was = c->lag_ok, contig_was = c->lag_contig;
   const bool clt_was = c->clt_ok;
+  const bool small_was = c->n_max > 0 && (c->n_max + NB - 1) / NB <= 2;      // (the store's sweeps prebuild their tiles: extend_impl)
   const double clt_h_was = c->clt_h, clt_t0_was = c->clt_t0;
   const std::vector<double> tlat_was = c->h_ts_lat;
   const double grid_h_was = c->grid_h;
@@ -2125,6 +2127,9 @@ static int set_data_body(agp_ctx* c, const double* ts, const double* xs, int64_t
     // which move by an ulp when an append changes the refined spacing)
     // (compact tables: an entry is k(lag x h), so the resident rows keep their values exactly when the spacing is bit for bit the same)
     bool same = lag_was == c->lag_ok && contig_was == c->lag_contig && clt_was == c->clt_ok && (!clt_was || clt_h_was == c->clt_h);
+    // (... and while the series stays on its side of the two-tile-row bound: the store's sweeps start their accumulators from the
+    // evaluated tile above it and subtract a prebuilt tile below it — the same numbers in a different order)
+    same = same && small_was == (n_max > 0 && (n_max + NB - 1) / NB <= 2);
     if (same && c->lag_ok)
       same = tlat_was.size() <= c->h_ts_lat.size() &&
              std::memcmp(tlat_was.data(), c->h_ts_lat.data(), sizeof(double) * tlat_was.size()) == 0;

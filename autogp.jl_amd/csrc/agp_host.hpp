@@ -409,7 +409,8 @@ struct Batch {
 
 int compile_batch(agp_ctx* c, int P, const int32_t* op_off, const uint8_t* ops, const int32_t* prm_off,
                   const double* prm, Batch& bt, bool allow_sel = false, bool want_grad = false, bool ge_tab = false,
-                  bool fuse_hint = false, bool flow_limit = false, bool lag = false, int lag_units = 1, int rank_extra = 0);
+                  bool fuse_hint = false, bool flow_limit = false, bool lag = false, int lag_units = 1, int rank_extra = 0,
+                  bool never_fuse = false);
 
 // A tile evaluation longer than this (cost model op_cost_us: measured per-leaf cost of one 128x128 tile with two workgroups per
 // CU) would set the duration of the short launches; such particles get their tiles from k_cov_tiles.  Measured: per-column

@@ -279,9 +279,16 @@ int extend_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, const u
   const int rank_extra = cltw ? (256 + clt_nB + 511) / 512 : lagr ? 1 : 0;
   const bool ge_tab = c->logdt_ok && !rankm;
   // (tiles are evaluated inside the factorisation kernels whatever the population size: the prebuilt-tile variants of
-  // the split launches carry the most register spills, and the store never needs K itself)
+  // the split launches carry the most register spills, and the store never needs K itself — EXCEPT for a resident series of at
+  // most two tile rows, the reference's tutorial sizes: there a sweep is three tiles per particle on an empty GPU, one workgroup's
+  // walk through its tile's evaluation sits on the critical path (k_chol_update 97 us per column against ~50 with the tile
+  // prebuilt by k_cov_tiles, four workgroups per tile): HMC replay n = 144 / 8 threads 725 -> 852 iterations/s, n = 256 / 64
+  // threads 3 171 -> 3 376; from three tile rows on fusing wins again (n = 300: 602 vs 563).  The rule reads the resident series
+  // alone — not this sweep's prefix or population — so an extension and a from-scratch sweep of the entry keep one arithmetic.)
+  const bool small_series = (c->n_max + NB - 1) / NB <= 2;
   int rc = compile_batch(c, U, uo.data(), uops.data(), up.data(), uprm.data(), bt, false, false, ge_tab, /*fuse_hint=*/true,
-                         /*flow_limit=*/c->flow != 0 && U <= FLOW_MAX_PARTICLES, rankm, rankm ? tab_units : 1, rank_extra);
+                         /*flow_limit=*/c->flow != 0 && U <= FLOW_MAX_PARTICLES, rankm, rankm ? tab_units : 1, rank_extra,
+                         /*never_fuse=*/small_series);
   if (rc) { poison(); return rc; }
   if (cltw) { std::lock_guard<std::mutex> g(c->mu); ++c->n_clt_sweeps; }
   int i0min = nt;
