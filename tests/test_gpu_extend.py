@@ -479,3 +479,54 @@ def test_predictive_passes_keep_the_inverse_factor_resident(pkg):
             check(n, nodes3, nz3)
     finally:
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("irregular", [False, True])
+def test_small_series_prebuilt_tiles_and_append_across_the_bound(pkg, irregular):
+    """A resident series of at most two tile rows (the reference's tutorial sizes, docs/src/tutorials/assets: 135-442 points): the
+    store's sweeps prebuild their tiles instead of evaluating them inside the factorisation kernels — a rule of the resident series
+    alone, so extension == from scratch bit for bit whatever the prefix and the population; an append (add_data!, src/api.jl:426-443)
+    that takes the series across the bound changes the arithmetic of every sweep, so the resident factors are dropped: again bit for
+    bit what an engine that only ever saw the longer series computes."""
+    P = 12
+    ts, xs = pkg.prior.synthetic_series(300, seed=21, shuffle=True)
+    if irregular:
+        ts = ts + np.random.default_rng(2).uniform(-0.3, 0.3, 300) / 300
+    nodes, noises = pkg.prior.sample_particles(np.random.default_rng(4), P, max_depth=3)
+    a = pkg.GPEngine(0); b = pkg.GPEngine(0); c = pkg.GPEngine(0)
+    try:
+        a.set_data(ts[:250], xs[:250]); b.set_data(ts[:250], xs[:250])
+        l1, i1 = a.logpdf_batch_extend(nodes, noises, n=128, check=False)
+        l2, i2 = a.logpdf_batch_extend(nodes, noises, n=250, check=False)          # tile row 0 kept, row 1 new
+        assert a.extend_stats()["tile_rows_reused"] > 0
+        l2b, i2b = b.logpdf_batch_extend(nodes[:5], noises[:5], n=250, check=False)  # from scratch, another population
+        assert same(l2[:5], l2b) and np.array_equal(i2[:5], i2b)
+        ref, rinfo = F.gp_logpdf_many(pkg.encode_batch(nodes), noises, ts[:250], xs[:250])
+        ok = (i2 == 0) & (rinfo == 0)
+        assert ok.sum() >= 6 and lp_err(l2[ok], ref[ok]).max() <= LP_TOL
+        # the plain entry (in-kernel evaluation at this population) agrees to rounding, not to the bit
+        lp, ip = a.logpdf_batch(nodes, noises, n=250, check=False)
+        assert np.array_equal(ip, i2) and lp_err(lp[ok], l2[ok]).max() <= 1e-10
+        # append 50 points: three tile rows now — nothing resident survives, the sweep equals a fresh engine's
+        r0 = a.extend_stats()["tile_rows_reused"]
+        a.set_data(ts, xs); c.set_data(ts, xs)
+        l3, i3 = a.logpdf_batch_extend(nodes, noises, n=300, check=False)
+        assert a.extend_stats()["tile_rows_reused"] == r0
+        l3c, i3c = c.logpdf_batch_extend(nodes, noises, n=300, check=False)
+        assert same(l3, l3c) and np.array_equal(i3, i3c)
+        ref3, ri3 = F.gp_logpdf_many(pkg.encode_batch(nodes), noises, ts, xs)
+        ok3 = (i3 == 0) & (ri3 == 0)
+        assert lp_err(l3[ok3], ref3[ok3]).max() <= LP_TOL
+        # an append that stays below the bound keeps the store
+        b.extend_reset()
+        b.set_data(ts[:200], xs[:200])
+        b.logpdf_batch_extend(nodes, noises, n=200, check=False)
+        r1 = b.extend_stats()["tile_rows_reused"]
+        b.set_data(ts[:256], xs[:256])
+        l4, i4 = b.logpdf_batch_extend(nodes, noises, n=256, check=False)
+        assert b.extend_stats()["tile_rows_reused"] > r1
+        c.set_data(ts[:256], xs[:256]); c.extend_reset()
+        l4c, i4c = c.logpdf_batch_extend(nodes, noises, n=256, check=False)
+        assert same(l4, l4c) and np.array_equal(i4, i4c)
+    finally:
+        a.close(); b.close(); c.close()
