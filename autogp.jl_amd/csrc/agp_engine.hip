@@ -1196,7 +1196,7 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
       HIPCHK(c, s->alpha.ensure(sizeof(double) * (size_t)n_pad * chunk));
       HIPCHK(c, s->tsol.ensure(sizeof(double) * 3 * (size_t)n_pad * chunk));
       HIPCHK(c, s->tretry.ensure(sizeof(int32_t) * (size_t)P));
-      HIPCHK(c, hipMemsetAsync(s->tretry.p, 0, sizeof(int32_t) * (size_t)P, st));
+      if (any_toep_sweep) HIPCHK(c, hipMemsetAsync(s->tretry.p, 0, sizeof(int32_t) * (size_t)P, st));      // (only the Toeplitz solves raise these flags)
       HIPCHK(c, s->gpart.ensure(sizeof(double) * (size_t)chunk * ntiles * gstride * gcsplit));
       HIPCHK(c, s->ghdr.ensure(sizeof(GProgHdr) * (size_t)P));
       HIPCHK(c, s->gops.ensure(bt.gops.size() + 4)); HIPCHK(c, s->glc.ensure(bt.glc.size() + 4)); HIPCHK(c, s->grc.ensure(bt.grc.size() + 4));
@@ -1426,7 +1426,13 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
           int Pn = 0, Pe = 0;          // Pn: particles that need L^-T and K^-1 tiles (classes 0, 1);  Pe: class 0
           for (int r = 0; r < Pg; ++r) { Pn += !lagdom(r); Pe += cls(r) == 0; }
           int32_t* d_pl = s->plist.as<int32_t>() + p0 + g0;
-          HIPCHK(c, hipMemcpyAsync(d_pl, pl.data(), sizeof(int32_t) * Pg, hipMemcpyHostToDevice, q));
+          {
+            // (from pinned memory: a copy out of the pageable vector goes through the runtime's staging, ~7 us and a hand-over)
+            HIPCHK(c, s->h_pl.ensure(sizeof(int32_t) * (size_t)P));
+            int32_t* hpl = static_cast<int32_t*>(s->h_pl.p) + p0 + g0;
+            std::memcpy(hpl, pl.data(), sizeof(int32_t) * (size_t)Pg);
+            HIPCHK(c, hipMemcpyAsync(d_pl, hpl, sizeof(int32_t) * Pg, hipMemcpyHostToDevice, q));
+          }
           ga.plist = d_pl;
           // (all lag-domain particles of a sweep take the same source of their lag sums)
           const bool any_fft = Pn < Pg && (bt.ghdr[p0 + g0 + pl[Pn]].flags & GFLAG_LAGFFT) != 0;
@@ -1563,16 +1569,21 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
   }
   HostProf hp_wait(8);
   const size_t out_bytes = sizeof(double) * P + sizeof(int32_t) * P;
+  // (gradients land in the slot's pinned buffer too and are handed to the caller after the synchronisation: a copy straight into the
+  // caller's pageable arrays goes through the runtime's own staging, ~20 us of a 230-us sweep at n = 144)
+  size_t h_need = own_out ? out_bytes : 0, o_gn = 0, o_gr = 0;
+  if (go && n > 0) { o_gn = (h_need + 15) & ~(size_t)15; o_gr = o_gn + sizeof(double) * (size_t)P; h_need = o_gr + sizeof(double) * (size_t)n_prm_total; }
+  if (h_need > 0) HIPCHK(c, s->h_out.ensure(h_need));
   if (own_out) {
-    HIPCHK(c, s->h_out.ensure(out_bytes));
     HIPCHK(c, hipMemcpyAsync(s->h_out.p, d_lp, out_bytes, hipMemcpyDeviceToHost, st));
   } else if (h_out_lp) {
     HIPCHK(c, hipMemcpyAsync(h_out_lp, d_lp, sizeof(double) * P, hipMemcpyDeviceToHost, st));
   }
   if (go && n > 0) {
+    char* ho = static_cast<char*>(s->h_out.p);
     if (n_prm_total > 0)
-      HIPCHK(c, hipMemcpyAsync(go->grad, s->dgrad.p, sizeof(double) * n_prm_total, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipMemcpyAsync(go->gnoise, s->dgnoise.p, sizeof(double) * P, hipMemcpyDeviceToHost, st));
+      HIPCHK(c, hipMemcpyAsync(ho + o_gr, s->dgrad.p, sizeof(double) * n_prm_total, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(ho + o_gn, s->dgnoise.p, sizeof(double) * P, hipMemcpyDeviceToHost, st));
     if (any_toep_sweep) {
       toep_retry.resize((size_t)P);
       HIPCHK(c, hipMemcpyAsync(toep_retry.data(), s->tretry.p, sizeof(int32_t) * (size_t)P, hipMemcpyDeviceToHost, st));
@@ -1589,6 +1600,11 @@ int logpdf_batch_impl(agp_ctx* c, int64_t n, int32_t P, const int32_t* op_off, c
     const double* hl = static_cast<const double*>(s->h_out.p);
     if (h_out_lp) std::memcpy(h_out_lp, hl, sizeof(double) * P);
     std::memcpy(h_info, hl + P, sizeof(int32_t) * P);
+  }
+  if (go && n > 0) {
+    const char* ho = static_cast<const char*>(s->h_out.p);
+    if (n_prm_total > 0) std::memcpy(go->grad, ho + o_gr, sizeof(double) * (size_t)n_prm_total);
+    std::memcpy(go->gnoise, ho + o_gn, sizeof(double) * (size_t)P);
   }
   for (int p = 0; p < P; ++p)
     if (h_info[p] < 0) return fail(c, AGP_ERR_HIP, "in-kernel panel solve timed out waiting for its diagonal factor");

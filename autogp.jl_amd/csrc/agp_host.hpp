@@ -122,6 +122,7 @@ struct Slot {
   HostBuf h_stage, h_out;   // its pinned source, and the pinned landing zone of [logpdf | info]
   HostBuf h_stage2;         // pinned source of the gradient programs (the sweep's stage copy may still be reading h_stage)
   DevBuf up_blob, up_blob2; // device landing zones of PinnedUploads' blobs (h_stage / h_stage2)
+  HostBuf h_pl;             // pinned source of the gradient sweeps' particle lists
   DevBuf A, W, vec, partial, info, out_lp, out_info, hdr, ops, prm, noise, noise_pred, tt, mu1, mu2,
       pred_mean, pred_var, pred_cov, dense, map, ready, code, diag_add,
       Z, alpha, tsol, tretry, gpart, ghdr, gops, glc, grc, gpoff, gprm, gmap, goff, dgrad, dgnoise, plist, tflag, flowq, lagtab,
@@ -142,7 +143,7 @@ struct Slot {
                       &noise_pred, &tt, &mu1, &mu2, &pred_mean, &pred_var, &pred_cov, &dense, &map, &ready, &code, &diag_add,
                       &Z, &alpha, &tsol, &tretry, &gpart, &ghdr, &gops, &glc, &grc, &gpoff, &gprm, &gmap, &goff, &dgrad, &dgnoise, &plist, &tflag, &flowq, &lagtab, &pl_rank, &pl_tl, &pl_prog})
       b->release();
-    stage.release(); h_stage.release(); h_stage2.release(); h_out.release(); h_async_info.release(); up_blob.release(); up_blob2.release();
+    stage.release(); h_stage.release(); h_stage2.release(); h_out.release(); h_async_info.release(); up_blob.release(); up_blob2.release(); h_pl.release();
     for (auto e : events) (void)hipEventDestroy(e);
     events.clear();
     for (auto& q : gq) { if (q) (void)hipStreamDestroy(q); q = nullptr; }

@@ -101,6 +101,8 @@ def test_factor_store_sizes_itself_for_small_batches():
     assert r["evicted_before_reuse"] == 0, r
     rr = _native("hmc_replay", 512, 192, 2, 10, 0.02, env_extra=dict(env, HMC_RESERVE="1"))
     assert rr["evicted_before_reuse"] == 0 and rr["store_reserved"] is True
-    assert r["gradient_particles_factored"] <= rr["gradient_particles_factored"] + 0.02 * r["value_calls"], (r, rr)
+    # (the arrivals are random: the few gradient calls that meet the store while it grows vary from run to run — 0 .. 170 of 7 650
+    # calls over ten runs; round 5's rule, the control below, refactors thousands)
+    assert r["gradient_particles_factored"] <= rr["gradient_particles_factored"] + 0.05 * r["value_calls"], (r, rr)
     old = _native("hmc_replay", 512, 192, 2, 10, 0.02, env_extra=dict(env, AGP_STORE_SELF_SIZE="0"))
     assert old["evicted_before_reuse"] > 0 and old["gradient_particles_factored"] > r["gradient_particles_factored"], (old, r)
