@@ -180,12 +180,18 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
   // Look-ahead inside the tile: while waves 1-3 apply block column jb to the trailing blocks, wave 0 applies it to the
   // NEXT diagonal block only and factors that block at once — the wave-serial 16x16 step (the longest phase of an
   // iteration) runs beside the MFMA updates instead of in front of them.
+  // The last tile row of a series is ragged: rows from n1 on are identity padding (cov_finalize), whose 16 x 16 blocks factor to
+  // themselves — identity L, identity inverse, zero panel, alpha 0, bit for bit what the steps below would produce.  Only the
+  // nbk block steps that hold data are run (n = 144: one of the eight steps of tile 1, ~28 us of a 125-us value sweep).  n1 = 0:
+  // a dense-input factorisation, whose padding this function knows nothing about — all steps.
+  const int rows_real = a.n1 > 0 ? a.n1 - tk * NB : NB;
+  const int nbk = rows_real >= NB ? NSB : rows_real <= 16 ? 1 : (rows_real + 15) >> 4;
   AGP_DPROBE(2);
   if (w == 0) factor16(0);
   AGP_DPROBE(3);
   __syncthreads();
   AGP_DPROBE(4);
-  for (int jb = 0; jb < NSB; ++jb) {
+  for (int jb = 0; jb < nbk; ++jb) {
     // ---- (b) panel: L(ib,jb) = S(ib,jb) W^T for ib > jb (MFMA); alpha_jb = W r_jb ----
     // (at most two blocks per wave; their four-MFMA chains are interleaved — one after the other each MFMA waits for its
     // predecessor's result)
@@ -296,11 +302,21 @@ __device__ __forceinline__ void factor_diag_tile(const CholArgs& a, int p, int t
         rvec[ti_] = t0 + t1;
       }
       if (jb == 0) AGP_DPROBE(6);
-      if (w == 0 && jb + 1 < NSB) factor16(jb + 1);      // (its block was brought up to date by this wave just above)
+      if (w == 0 && jb + 1 < nbk) factor16(jb + 1);      // (its block was brought up to date by this wave just above)
       if (jb == 0) AGP_DPROBE(7);
     }
     __syncthreads();
     if (jb == 0) AGP_DPROBE(8);
+  }
+  if (nbk < NSB) {
+    // the padding's block steps, written down instead of computed: inverse blocks I, alpha 0 (the blocks of L already hold I and 0)
+    for (int jb = nbk + w; jb < NSB; jb += 4) {
+      double* Wg = a.W + (((long long)p * a.wsteps + a.k % a.wsteps) * NSB + jb) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Wg[l15 * 16 + 4 * r + lq] = (l15 == 4 * r + lq) ? 1.0 : 0.0;
+    }
+    if (tid >= nbk * 16 && tid < NB) avec[tid] = 0.0;
+    __syncthreads();
   }
   AGP_DPROBE(9);
 
