@@ -90,7 +90,8 @@ int agp_shard_plan(int64_t n, int32_t P, const int32_t* op_off, const uint8_t* o
       if (op_off[p + 1] < op_off[p] || prm_off[p + 1] < prm_off[p] || op_off[p] < 0 || prm_off[p] < 0)
         return fail(nullptr, AGP_ERR_ARG, "offsets must be non-decreasing");
     const double nn = (double)std::max<int64_t>(n, 1);
-    const int kind = regular_grid < 0 ? 0 : regular_grid > 2 ? 2 : regular_grid;      // 0 irregular, 1 regular grid, 2 lattice with gaps
+    // 0 irregular, 1 regular grid, 2 lattice with gaps; 3 (compact tables: only tile evaluation differs) and anything else: dense-priced
+    const int kind = (regular_grid < 0 || regular_grid > 2) ? 0 : regular_grid;
     const double dense = sweep == 1 ? 3.4 : sweep == 2 ? 2.0 + 3.0 * (double)std::max<int64_t>(m_future, 0) / nn : 1.0;
     const double toep = (sweep == 1 ? 0.42 : sweep == 2 ? 0.3 : 0.08) * (2048.0 / nn);
     // On a lattice WITH gaps the class keeps its dense factor, L^-T and K^-1; only its contraction runs over the lattice's lags

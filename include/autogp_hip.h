@@ -402,7 +402,8 @@ void agp_shard_range(int32_t P, int32_t rank, int32_t n_ranks, int32_t* lo, int3
  * sweeps 1-3 WHERE THE ENGINE ADMITS the structured sweep (the engine's own size tests, applied to the class particles one rank
  * will hold: n <= 2048 and a class large enough for sweep 1, n + m_future <= 4096 and >= 32 class particles for sweep 2, ...;
  * refused classes are dense-priced) —, 2 lattice with gaps (calendar indices: the class keeps its dense factor, only its gradient
- * contraction runs over the lattice's lags).  Copies of an earlier particle (resampled populations,
+ * contraction runs over the lattice's lags); 3 (a longer lattice served by compact tables: only tile evaluation differs) is priced
+ * like 0.  Copies of an earlier particle (resampled populations,
  * src/inference_smc_anneal_data.jl:198-204) cost nothing and follow their representative.  Longest-processing-time greedy over
  * the distinct particles.  owner_out[p] = rank of particle p; cost_out[p] (nullable) = its modelled cost in units of one dense
  * factorisation (n^3/3 flops); rank_cost_out[r] (nullable) = the ranks' totals.  A rank evaluates its particles in ascending
